@@ -1,0 +1,320 @@
+"""numpy twin of the CPU restatement (stages A0-A8 and A7).
+
+TEST INFRASTRUCTURE ONLY, PARITY UNPINNED (see oracle/pcp_oracle.h).  Written
+independently of pcp_oracle.c from the same reference lines so that the two
+restatements check each other; it also generates the committed golden vectors
+(tests/golden/make_golden.py).  numpy fp32 / fp64 array ops are individually
+rounded (no FMA contraction), which is the arithmetic model of Appendix A.
+
+PCP/ = /root/reference/PointCloudProcessor/.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+f32 = np.float32
+f64 = np.float64
+FLT_MAX = np.finfo(np.float32).max
+
+
+# --------------------------------------------------------------------------- A1
+def quat_to_rot(qw, qx, qy, qz):
+    """Eigen Quaterniond::toRotationMatrix, no normalisation [upstream]."""
+    tx, ty, tz = 2.0 * qx, 2.0 * qy, 2.0 * qz
+    twx, twy, twz = tx * qw, ty * qw, tz * qw
+    txx, txy, txz = tx * qx, ty * qx, tz * qx
+    tyy, tyz, tzz = ty * qy, tz * qy, tz * qz
+    return np.array([
+        [1.0 - (tyy + tzz), txy - twz, txz + twy],
+        [txy + twz, 1.0 - (txx + tzz), tyz - twx],
+        [txz - twy, tyz + twx, 1.0 - (txx + tyy)],
+    ], dtype=f64)
+
+
+def pose_to_matrices(pose, T_opt=None):
+    """PCP/src/PointCloudProcessor.cpp:495-519 -> (w2c, c2w) 3x4 fp32."""
+    x, y, z, qw, qx, qy, qz = [float(v) for v in pose]
+    R = quat_to_rot(qw, qx, qy, qz)
+    t = np.array([x, y, z], f64)
+    if T_opt is None:
+        Rt = R.T
+        tr = -((Rt[:, 0] * t[0] + Rt[:, 1] * t[1]) + Rt[:, 2] * t[2])
+        w2c = np.concatenate([Rt, tr[:, None]], axis=1).astype(f32)
+        c2w = np.concatenate([R, t[:, None]], axis=1).astype(f32)
+        return w2c, c2w
+    T = np.asarray(T_opt, f64).reshape(4, 4)
+    M = np.zeros((3, 4), f64)
+    for r in range(3):
+        for c in range(4):
+            s = (R[r, 0] * T[0, c] + R[r, 1] * T[1, c]) + R[r, 2] * T[2, c]
+            if c == 3:
+                s = s + t[r] * T[3, 3]
+            M[r, c] = s
+    c2w = M.astype(f32)
+    return affine_inverse_f32(c2w), c2w
+
+
+def affine_inverse_f32(m):
+    """General fp32 affine inverse (Eigen Affine3f::inverse) [upstream, op order unverified]."""
+    m = np.asarray(m, f32).reshape(3, 4)
+    a, b, c = m[0, 0], m[0, 1], m[0, 2]
+    d, e, f = m[1, 0], m[1, 1], m[1, 2]
+    g, h, i = m[2, 0], m[2, 1], m[2, 2]
+    c00 = e * i - f * h
+    c01 = f * g - d * i
+    c02 = d * h - e * g
+    det = (a * c00 + b * c01) + c * c02
+    inv = f32(1.0) / det
+    L = np.array([
+        [c00 * inv, (c * h - b * i) * inv, (b * f - c * e) * inv],
+        [c01 * inv, (a * i - c * g) * inv, (c * d - a * f) * inv],
+        [c02 * inv, (b * g - a * h) * inv, (a * e - b * d) * inv],
+    ], f32)
+    t = m[:, 3]
+    out = np.zeros((3, 4), f32)
+    out[:, :3] = L
+    out[:, 3] = -((L[:, 0] * t[0] + L[:, 1] * t[1]) + L[:, 2] * t[2])
+    return out
+
+
+# --------------------------------------------------------------------------- A2
+def transform(m, x, y, z):
+    """pcl::transformPointCloud, PCL 1.10 SSE association [upstream]."""
+    m = np.asarray(m, f32).reshape(3, 4)
+    x, y, z = (np.asarray(a, f32) for a in (x, y, z))
+    out = []
+    for r in range(3):
+        out.append(x * m[r, 0] + (y * m[r, 1] + (z * m[r, 2] + m[r, 3])))
+    return out
+
+
+# --------------------------------------------------------------------------- A3
+def project(cam: dict, xc, yc, zc):
+    """PCP/include/camera/pinhole.hpp:13-51, fp64, left-to-right."""
+    X, Y, Z = (np.asarray(a, f64) for a in (xc, yc, zc))
+    with np.errstate(all="ignore"):
+        xn = X / Z
+        yn = Y / Z
+        x2 = xn * xn
+        y2 = yn * yn
+        r2 = x2 + y2
+        r4 = r2 * r2
+        r6 = r2 * r4
+        rc = ((1.0 + cam["k1"] * r2) + cam["k2"] * r4) + cam["k3"] * r6
+        t1 = (2.0 * xn) * yn
+        t2 = r2 + 2.0 * x2
+        t3 = r2 + 2.0 * y2
+        xd = (rc * xn + cam["p1"] * t1) + cam["p2"] * t2
+        yd = (rc * yn + cam["p1"] * t3) + cam["p2"] * t1
+        u = cam["fx"] * xd + cam["cx"]
+        v = cam["fy"] * yd + cam["cy"]
+    return u, v
+
+
+def _trunc_ok(a):
+    a = np.asarray(a)
+    return np.isfinite(a) & (a > -2147483648.0) & (a < 2147483648.0)
+
+
+def project_frame(cam: dict, w2c, x, y, z, ds: int = 14):
+    """A2-A5 per point: cam coords, (u,v), cell, pixel, range."""
+    xc, yc, zc = transform(w2c, x, y, z)
+    front = zc > 0
+    u, v = project(cam, xc, yc, zc)
+    X, Y, Z = xc.astype(f64), yc.astype(f64), zc.astype(f64)
+    rng = np.sqrt((X * X + Y * Y) + Z * Z)
+    W, H = cam["cull_width"], cam["cull_height"]
+    mw, mh = W // ds, H // ds
+    with np.errstate(all="ignore"):
+        cxf = u.astype(f32) / f32(ds)
+        cyf = v.astype(f32) / f32(ds)
+    ok = front & _trunc_ok(cxf) & _trunc_ok(cyf)
+    cxi = np.where(ok, np.trunc(np.where(ok, cxf, 0)), -1).astype(np.int64)
+    cyi = np.where(ok, np.trunc(np.where(ok, cyf, 0)), -1).astype(np.int64)
+    cand = ok & (cxi >= 0) & (cyi >= 0) & (cxi < W) & (cyi < H)
+    inmap = cand & (cxi < mw) & (cyi < mh)
+    cell = np.where(inmap, cyi * mw + cxi, np.where(cand, -2, -1)).astype(np.int32)
+    okp = front & _trunc_ok(u) & _trunc_ok(v)
+    ui = np.where(okp, np.trunc(np.where(okp, u, 0)), -1).astype(np.int64)
+    vi = np.where(okp, np.trunc(np.where(okp, v, 0)), -1).astype(np.int64)
+    inimg = okp & (ui >= 0) & (ui < cam["image_width"]) & (vi >= 0) & (vi < cam["image_height"])
+    pixel = np.where(inimg, vi * cam["image_width"] + ui, -1).astype(np.int32)
+    range_f = np.where(front, rng, FLT_MAX).astype(f32)
+    return dict(xc=xc, yc=yc, zc=zc, u=u, v=v, cell=cell, pixel=pixel, range=range_f, range64=rng)
+
+
+# --------------------------------------------------------------------------- A4
+def cull_frame(cam: dict, w2c, x, y, z, ds: int = 14, slack: float = 0.05, enable_zbuffer: bool = True):
+    """view_culling.cpp:52-174: returns keep mask, depth map, projection dict."""
+    p = project_frame(cam, w2c, x, y, z, ds)
+    mw, mh = cam["cull_width"] // ds, cam["cull_height"] // ds
+    dmap = np.full(mw * mh, FLT_MAX, f32)
+    if not enable_zbuffer:
+        return p["cell"] != -1, dmap.reshape(mh, mw), p
+    inmap = p["cell"] >= 0
+    np.minimum.at(dmap, p["cell"][inmap], p["range"][inmap])
+    keep = np.zeros(len(p["cell"]), bool)
+    keep[inmap] = ~(p["range64"][inmap] > dmap[p["cell"][inmap]].astype(f64) + slack)
+    return keep, dmap.reshape(mh, mw), p
+
+
+# --------------------------------------------------------------------------- A6
+def scores(xc, yc, zc, pose):
+    """hpp:205-236 + cpp:588 (identity mode)."""
+    xc, yc, zc = (np.asarray(a, f32) for a in (xc, yc, zc))
+    px, py, pz = float(pose[0]), float(pose[1]), float(pose[2])
+    dx, dy, dz = xc.astype(f64) - px, yc.astype(f64) - py, zc.astype(f64) - pz
+    sq = (dx * dx + dy * dy) + dz * dz
+    with np.errstate(all="ignore"):
+        cosA = np.where(sq > 0, dz / np.sqrt(sq), dz)
+    o = ((cosA + 1.0) / 2.0).astype(f32)
+    o = f32(0.2) + f32(0.8) * o
+    dist = np.sqrt((xc * xc + yc * yc) + zc * zc).astype(f32)
+    nd = np.abs(dist - f32(2.0)) / f32(2.0)
+    nd = np.where(nd < f32(1.0), nd, f32(1.0)).astype(f32)
+    d = f32(1.0) - nd
+    d = f32(0.2) + f32(0.8) * d
+    final = ((o + d).astype(f64) / 2.0).astype(f32)
+    return o, d, final
+
+
+# --------------------------------------------------------------------------- A8
+def colorize(cam: dict, x, y, z, poses, images, ds: int = 14, slack: float = 0.05, enable_zbuffer: bool = True,
+             T_opt=None):
+    """Collect-all + stable sort (the reference's shape, cpp:590-591,604-631)."""
+    n = len(x)
+    lists = [[] for _ in range(n)]
+    for f, pose in enumerate(poses):
+        T = None
+        if T_opt is not None:
+            T = np.asarray(T_opt, f64).reshape(-1, 16)
+            T = T[f if len(T) > 1 else 0]
+        w2c, _ = pose_to_matrices(pose, T)
+        keep, _, p = cull_frame(cam, w2c, x, y, z, ds, slack, enable_zbuffer)
+        sel = np.nonzero(keep & (p["pixel"] >= 0))[0]
+        if len(sel) == 0:
+            continue
+        img = np.asarray(images[f], np.uint8).reshape(-1, 3)
+        bgr = img[p["pixel"][sel]]
+        _, _, fin = scores(p["xc"][sel], p["yc"][sel], p["zc"][sel], pose)
+        for k, i in enumerate(sel):
+            lists[i].append((float(fin[k]), int(bgr[k, 2]), int(bgr[k, 1]), int(bgr[k, 0]), f))
+    rgb = np.zeros((n, 3), np.uint8)
+    count = np.zeros(n, np.int32)
+    top_score = np.full((n, 5), -1.0, f32)
+    top_rgb = np.zeros((n, 5), np.uint32)
+    top_frame = np.full((n, 5), -1, np.int32)
+    for i, lst in enumerate(lists):
+        count[i] = len(lst)
+        if not lst:
+            continue
+        lst = sorted(lst, key=lambda e: -e[0])  # stable: ties keep ascending frame order (B8)
+        lst = lst[:5]
+        tot = f32(0)
+        acc = [f32(0), f32(0), f32(0)]
+        for k, (s, r, g, b, fr) in enumerate(lst):
+            s = f32(s)
+            acc[0] = acc[0] + f32(r) * s
+            acc[1] = acc[1] + f32(g) * s
+            acc[2] = acc[2] + f32(b) * s
+            tot = tot + s
+            top_score[i, k] = s
+            top_rgb[i, k] = (r << 16) | (g << 8) | b
+            top_frame[i, k] = fr
+        for c in range(3):
+            rgb[i, c] = np.uint8(int(acc[c] / tot))
+    has = (rgb != 0).any(axis=1).astype(np.uint8)
+    return dict(rgb=rgb, has=has, count=count, top_score=top_score, top_rgb=top_rgb, top_frame=top_frame)
+
+
+# --------------------------------------------------------------------------- A7
+def _eigen33_smallest(C):
+    """Smallest eigenpair of a symmetric 3x3 (any accurate solver, Appendix A7.3)."""
+    w, V = np.linalg.eigh(C)
+    return w[0], V[:, 0]
+
+
+def mls(x, y, z, radius: float = 0.03, order: int = 2):
+    """PCL MovingLeastSquares, NONE upsampling, SIMPLE projection [upstream];
+    brute-force neighbours (small n only)."""
+    x, y, z = (np.asarray(a, f32) for a in (x, y, z))
+    n = len(x)
+    P = np.stack([x, y, z], axis=1)
+    sq_r = f32(radius * radius)
+    nr_coeff = (order + 1) * (order + 2) // 2
+    out_xyz, out_n, out_c, out_i = [], [], [], []
+    for i in range(n):
+        d = P - P[i]
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        nn = np.nonzero(d2 < sq_r)[0]
+        K = len(nn)
+        if K < 3:
+            continue
+        nb = P[nn].astype(f64)
+        c = nb.sum(axis=0) / K
+        dm = nb - c
+        C = dm.T @ dm
+        ev, nrm = _eigen33_smallest(C)
+        q = P[i].astype(f64)
+        dist = q @ nrm - c @ nrm
+        mean = q - dist * nrm
+        tr = np.trace(C)
+        curv = abs(ev / tr) if tr != 0 else 0.0
+        if not (abs(nrm[0]) <= abs(nrm[2]) * 1e-12) or not (abs(nrm[1]) <= abs(nrm[2]) * 1e-12):
+            inv = 1.0 / np.sqrt(nrm[0] ** 2 + nrm[1] ** 2)
+            v = np.array([-nrm[1] * inv, nrm[0] * inv, 0.0])
+        else:
+            inv = 1.0 / np.sqrt(nrm[1] ** 2 + nrm[2] ** 2)
+            v = np.array([0.0, -nrm[2] * inv, nrm[1] * inv])
+        u = np.cross(nrm, v)
+        pt, nn_out = mean, nrm
+        if order > 1 and K >= nr_coeff:
+            de = nb - mean
+            w = np.exp(-(de * de).sum(axis=1) / (radius * radius))
+            uc, vc, fz = de @ u, de @ v, de @ nrm
+            rows = []
+            for ui in range(order + 1):
+                for vi in range(order - ui + 1):
+                    rows.append(uc ** ui * vc ** vi)
+            Pm = np.stack(rows, axis=0)
+            A = (Pm * w) @ Pm.T
+            b = (Pm * w) @ fz
+            try:
+                L = np.linalg.cholesky(A)
+                cvec = np.linalg.solve(L.T, np.linalg.solve(L, b))
+            except np.linalg.LinAlgError:
+                cvec = np.full(nr_coeff, np.nan)
+            if np.isfinite(cvec[0]):
+                pt = mean + cvec[0] * nrm
+                nn_out = nrm - cvec[order + 1] * u - cvec[1] * v
+                nn_out = nn_out / np.linalg.norm(nn_out)
+        out_xyz.append(pt)
+        out_n.append(nn_out)
+        out_c.append(curv)
+        out_i.append(i)
+    return dict(xyz=np.array(out_xyz, f64).reshape(-1, 3).astype(f32),
+                normal=np.array(out_n, f64).reshape(-1, 3).astype(f32),
+                curvature=np.array(out_c, f64).astype(f32), index=np.array(out_i, np.int32))
+
+
+# --------------------------------------------------------------------------- A4'
+def hpr_frame(cam: dict, w2c, x, y, z, flip_radius: float = 90000.0):
+    """The ACTIVE reference cull (Katz HPR, view_culling.cpp:266-334) through
+    scipy's bundled qhull_r -- CPU-only documented alternative (Appendix B1)."""
+    from scipy.spatial import ConvexHull
+
+    p = project_frame(cam, w2c, x, y, z)
+    u, v = p["u"], p["v"]
+    ok = (p["zc"] > 0) & _trunc_ok(u) & _trunc_ok(v)
+    ui = np.where(ok, np.trunc(np.where(ok, u, 0)), -1)
+    vi = np.where(ok, np.trunc(np.where(ok, v, 0)), -1)
+    cand = ok & (ui >= 0) & (ui < cam["cull_width"]) & (vi >= 0) & (vi < cam["cull_height"])
+    idx = np.nonzero(cand)[0]
+    if len(idx) < 4:
+        return idx
+    pts = np.stack([p["xc"][idx], p["yc"][idx], p["zc"][idx]], axis=1).astype(f64)
+    nrm = np.linalg.norm(pts, axis=1, keepdims=True)
+    flipped = pts + 2.0 * (flip_radius - nrm) * pts / nrm
+    hull = ConvexHull(np.concatenate([flipped, np.zeros((1, 3))], axis=0))
+    vis = np.array(sorted(int(k) for k in hull.vertices if k < len(idx)), dtype=np.int64)
+    return idx[vis]

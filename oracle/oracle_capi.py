@@ -1,0 +1,268 @@
+"""ctypes view of oracle/libpcp_oracle.so (the CPU restatement).
+
+TEST INFRASTRUCTURE ONLY -- see oracle/pcp_oracle.h.  Importable from tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg; never from the
+product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libpcp_oracle.so")
+
+
+class Pose(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("x", "y", "z", "qw", "qx", "qy", "qz")]
+
+
+class Camera(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3")] + [
+        (k, C.c_int32) for k in ("image_width", "image_height", "cull_width", "cull_height")
+    ]
+
+
+class CullParams(C.Structure):
+    _fields_ = [
+        ("enable_depth_buffer_culling", C.c_int32),
+        ("downsample_factor", C.c_int32),
+        ("depth_slack", C.c_double),
+    ]
+
+
+class MLSParams(C.Structure):
+    _fields_ = [
+        ("search_radius", C.c_double),
+        ("sqr_gauss_param", C.c_double),
+        ("polynomial_order", C.c_int32),
+        ("compute_normals", C.c_int32),
+        ("upsampling", C.c_int32),
+        ("vgd_iterations", C.c_int32),
+        ("vgd_voxel_size", C.c_float),
+        ("threads", C.c_int32),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile the restatement with the committed Makefile (gcc, -ffp-contract=off)."""
+    srcs = [os.path.join(_HERE, f) for f in ("pcp_oracle.c", "pcp_oracle_mls.c", "pcp_oracle.h", "Makefile")]
+    stale = force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
+    )
+    if stale:
+        subprocess.run(["make", "-C", _HERE, "libpcp_oracle.so"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        fp = C.POINTER(C.c_float)
+        L.orc_cull_frame.restype = C.c_int64
+        L.orc_frame_visible.restype = C.c_int64
+        L.orc_mls.restype = C.c_int64
+        L.orc_mls_voxel_dilation.restype = C.c_int64
+        L.orc_sor.restype = C.c_int64
+        L.orc_select_keyframes.restype = C.c_int32
+        L.orc_hardware_threads.restype = C.c_int32
+        L.orc_colorize.restype = C.c_int
+        _ = fp
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, t=None):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def default_camera(width: int | None = None, height: int | None = None) -> Camera:
+    cam = Camera()
+    lib().orc_default_camera(C.byref(cam))
+    if width is not None:
+        cam.image_width = cam.cull_width = int(width)
+    if height is not None:
+        cam.image_height = cam.cull_height = int(height)
+    return cam
+
+
+def default_cull_params() -> CullParams:
+    p = CullParams()
+    lib().orc_default_cull_params(C.byref(p))
+    return p
+
+
+def default_mls_params() -> MLSParams:
+    p = MLSParams()
+    lib().orc_default_mls_params(C.byref(p))
+    return p
+
+
+def make_pose(v) -> Pose:
+    return Pose(*[float(t) for t in v])
+
+
+def poses_array(poses: np.ndarray):
+    poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 7)
+    arr = (Pose * len(poses))()
+    C.memmove(arr, poses.ctypes.data, poses.nbytes)
+    return arr
+
+
+def pose_to_matrices(pose, T_opt=None):
+    w2c = np.zeros(12, np.float32)
+    c2w = np.zeros(12, np.float32)
+    p = make_pose(pose)
+    T = None if T_opt is None else np.ascontiguousarray(T_opt, np.float64).reshape(16)
+    lib().orc_pose_to_matrices(C.byref(p), _p(T), _p(w2c), _p(c2w))
+    return w2c, c2w
+
+
+def project_frame(cam, cp, w2c, x, y, z):
+    x, y, z = _f32(x), _f32(y), _f32(z)
+    n = len(x)
+    cell = np.empty(n, np.int32)
+    pix = np.empty(n, np.int32)
+    rng = np.empty(n, np.float32)
+    xc = np.empty(n, np.float32)
+    yc = np.empty(n, np.float32)
+    zc = np.empty(n, np.float32)
+    w2c = _f32(w2c)
+    lib().orc_project_frame(C.byref(cam), C.byref(cp), _p(w2c), _p(x), _p(y), _p(z), C.c_int64(n), _p(cell),
+                            _p(pix), _p(rng), _p(xc), _p(yc), _p(zc))
+    return dict(cell=cell, pixel=pix, range=rng, xc=xc, yc=yc, zc=zc)
+
+
+def cull_frame(cam, cp, w2c, x, y, z, threads: int = 1):
+    x, y, z = _f32(x), _f32(y), _f32(z)
+    n = len(x)
+    mw = cam.cull_width // cp.downsample_factor
+    mh = cam.cull_height // cp.downsample_factor
+    keep = np.empty(n, np.uint8)
+    dmap = np.empty(mw * mh, np.float32)
+    w2c = _f32(w2c)
+    kept = lib().orc_cull_frame(C.byref(cam), C.byref(cp), _p(w2c), _p(x), _p(y), _p(z), C.c_int64(n), _p(keep),
+                                _p(dmap), C.c_int32(threads))
+    return keep, dmap.reshape(mh, mw), int(kept)
+
+
+def scores(xc, yc, zc, pose):
+    o = C.c_float()
+    d = C.c_float()
+    f = C.c_float()
+    p = make_pose(pose)
+    lib().orc_scores(C.c_float(xc), C.c_float(yc), C.c_float(zc), C.byref(p), C.byref(o), C.byref(d), C.byref(f))
+    return o.value, d.value, f.value
+
+
+def colorize(cam, cp, x, y, z, poses, images, T_opt=None, threads: int = 1, want_top: bool = True):
+    x, y, z = _f32(x), _f32(y), _f32(z)
+    n = len(x)
+    poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)
+    F = len(poses)
+    parr = poses_array(poses)
+    imgs = [np.ascontiguousarray(im, np.uint8) for im in images]
+    assert len(imgs) == F
+    for im in imgs:
+        assert im.shape == (cam.image_height, cam.image_width, 3), im.shape
+    iptr = (C.c_void_p * F)(*[im.ctypes.data for im in imgs])
+    rgb = np.zeros((n, 3), np.uint8)
+    has = np.zeros(n, np.uint8)
+    cnt = np.zeros(n, np.int32)
+    ts = np.zeros((n, 5), np.float32) if want_top else None
+    tr = np.zeros((n, 5), np.uint32) if want_top else None
+    tf = np.zeros((n, 5), np.int32) if want_top else None
+    T = None
+    stride = 0
+    if T_opt is not None:
+        T = np.ascontiguousarray(T_opt, np.float64)
+        stride = 16 if T.size == 16 * F and F > 1 else 0
+        T = T.reshape(-1)
+    rc = lib().orc_colorize(C.byref(cam), C.byref(cp), _p(x), _p(y), _p(z), C.c_int64(n), parr, C.c_int32(F),
+                            _p(T), C.c_int32(stride), iptr, _p(rgb), _p(has), _p(cnt), _p(ts), _p(tr), _p(tf),
+                            C.c_int32(threads))
+    if rc != 0:
+        raise RuntimeError("orc_colorize failed")
+    return dict(rgb=rgb, has=has, count=cnt, top_score=ts, top_rgb=tr, top_frame=tf)
+
+
+def frame_visible(cam, cp, pose, x, y, z, image, mask=None, T_opt=None):
+    x, y, z = _f32(x), _f32(y), _f32(z)
+    n = len(x)
+    idx = np.empty(n, np.int32)
+    rgb = np.empty((n, 3), np.uint8)
+    mv = np.empty(n, np.uint16)
+    cam_xyz = np.empty((n, 3), np.float32)
+    wrd_xyz = np.empty((n, 3), np.float32)
+    p = make_pose(pose)
+    image = None if image is None else np.ascontiguousarray(image, np.uint8)
+    mask = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    T = None if T_opt is None else np.ascontiguousarray(T_opt, np.float64).reshape(16)
+    m = lib().orc_frame_visible(C.byref(cam), C.byref(cp), C.byref(p), _p(T), _p(x), _p(y), _p(z), C.c_int64(n),
+                                _p(image), _p(mask), _p(idx), _p(rgb), _p(mv), _p(cam_xyz), _p(wrd_xyz))
+    m = int(m)
+    return dict(index=idx[:m], rgb=rgb[:m], mask=mv[:m], xyz_cam=cam_xyz[:m], xyz_world=wrd_xyz[:m])
+
+
+def mls(x, y, z, params: MLSParams):
+    x, y, z = _f32(x), _f32(y), _f32(z)
+    n = len(x)
+    xyz = np.empty((n, 3), np.float32)
+    nrm = np.empty((n, 3), np.float32)
+    curv = np.empty(n, np.float32)
+    idx = np.empty(n, np.int32)
+    m = int(lib().orc_mls(_p(x), _p(y), _p(z), C.c_int64(n), C.byref(params), _p(xyz), _p(nrm), _p(curv), _p(idx)))
+    if m < 0:
+        raise RuntimeError("orc_mls failed")
+    return dict(xyz=xyz[:m], normal=nrm[:m], curvature=curv[:m], index=idx[:m])
+
+
+def mls_voxel_dilation(x, y, z, params: MLSParams):
+    x, y, z = _f32(x), _f32(y), _f32(z)
+    n = len(x)
+    m = int(lib().orc_mls_voxel_dilation(_p(x), _p(y), _p(z), C.c_int64(n), C.byref(params), C.c_int64(0), None,
+                                         None, None, None))
+    if m < 0:
+        raise RuntimeError("orc_mls_voxel_dilation failed")
+    xyz = np.empty((m, 3), np.float32)
+    nrm = np.empty((m, 3), np.float32)
+    curv = np.empty(m, np.float32)
+    idx = np.empty(m, np.int32)
+    lib().orc_mls_voxel_dilation(_p(x), _p(y), _p(z), C.c_int64(n), C.byref(params), C.c_int64(m), _p(xyz),
+                                 _p(nrm), _p(curv), _p(idx))
+    return dict(xyz=xyz, normal=nrm, curvature=curv, index=idx)
+
+
+def sor(x, y, z, mean_k: int = 60, std_mul: float = 0.7, threads: int = 0):
+    x, y, z = _f32(x), _f32(y), _f32(z)
+    n = len(x)
+    keep = np.empty(n, np.uint8)
+    kept = int(lib().orc_sor(_p(x), _p(y), _p(z), C.c_int64(n), C.c_int32(mean_k), C.c_double(std_mul), _p(keep),
+                             C.c_int32(threads)))
+    return keep, kept
+
+
+def select_keyframes(poses, dist_threshold: float = 0.1):
+    poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)
+    parr = poses_array(poses)
+    out = np.empty(len(poses), np.int32)
+    m = lib().orc_select_keyframes(parr, C.c_int32(len(poses)), C.c_double(dist_threshold), _p(out))
+    return out[:m]
+
+
+def hardware_threads() -> int:
+    return int(lib().orc_hardware_threads())

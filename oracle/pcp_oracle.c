@@ -1,0 +1,584 @@
+/*
+ * pcp_oracle.c -- CPU restatement (colour path A0-A8, z-buffer cull, scores,
+ * top-5 mean).  See pcp_oracle.h: TEST INFRASTRUCTURE ONLY, PARITY UNPINNED.
+ *
+ * Every function cites the reference lines it restates.  PCP/ =
+ * /root/reference/PointCloudProcessor/.  Build: oracle/Makefile
+ * (-O2 -ffp-contract=off -fno-fast-math).
+ */
+#include "pcp_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ */
+/* defaults                                                            */
+/* ------------------------------------------------------------------ */
+
+/* PCP/src/PointCloudProcessor.cpp:57-62 (K, D), :525 (cull size). */
+void orc_default_camera(orc_camera *cam) {
+  cam->fx = 4818.200388954926;
+  cam->fy = 4819.10345841615;
+  cam->cx = 2032.4178620390019;
+  cam->cy = 1535.1895959282901;
+  cam->k1 = 0.003043514741045163;
+  cam->k2 = 0.06634739187544138;
+  cam->p1 = -0.000217681797407554;
+  cam->p2 = -0.0006654964142658197;
+  cam->k3 = 0.0;
+  cam->image_width = 4096;
+  cam->image_height = 3000;
+  cam->cull_width = 4096;
+  cam->cull_height = 3000;
+}
+
+/* PCP/include/vlcal/calib/view_culling.hpp:12-15; view_culling.cpp:63,157 */
+void orc_default_cull_params(orc_cull_params *p) {
+  p->enable_depth_buffer_culling = 1;
+  p->downsample_factor = 14;
+  p->depth_slack = 0.05;
+}
+
+/* PCP/src/PointCloudProcessor.cpp:67-86 */
+void orc_default_mls_params(orc_mls_params *p) {
+  p->search_radius = 0.03;
+  p->sqr_gauss_param = 0.0009;
+  p->polynomial_order = 2;
+  p->compute_normals = 1;
+  p->upsampling = 3;
+  p->vgd_iterations = 4;
+  p->vgd_voxel_size = 0.001f;
+  p->threads = 30;
+}
+
+int32_t orc_hardware_threads(void) {
+#ifdef _OPENMP
+  return (int32_t)omp_get_num_procs();
+#else
+  return 1;
+#endif
+}
+
+static int resolve_threads(int32_t t) {
+#ifdef _OPENMP
+  int hw = omp_get_num_procs();
+  if (t <= 0 || t > hw) return hw;
+  return t;
+#else
+  (void)t;
+  return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------ */
+/* A1 pose -> matrices                                                 */
+/* ------------------------------------------------------------------ */
+
+/* Eigen::Quaterniond::toRotationMatrix (no normalisation) [upstream Eigen 3.3
+ * Quaternion.h], reached from t_c2w.rotate(q), PCP/src/PointCloudProcessor.cpp:497. */
+static void quat_to_rot(const orc_pose *p, double R[9]) {
+  const double tx = 2.0 * p->qx, ty = 2.0 * p->qy, tz = 2.0 * p->qz;
+  const double twx = tx * p->qw, twy = ty * p->qw, twz = tz * p->qw;
+  const double txx = tx * p->qx, txy = ty * p->qx, txz = tz * p->qx;
+  const double tyy = ty * p->qy, tyz = tz * p->qy, tzz = tz * p->qz;
+  R[0] = 1.0 - (tyy + tzz);
+  R[1] = txy - twz;
+  R[2] = txz + twy;
+  R[3] = txy + twz;
+  R[4] = 1.0 - (txx + tzz);
+  R[5] = tyz - twx;
+  R[6] = txz - twy;
+  R[7] = tyz + twx;
+  R[8] = 1.0 - (txx + tyy);
+}
+
+/* General fp32 affine inverse: Eigen Transform<float,3,Affine>::inverse()
+ * = [L^-1 | -L^-1 t] with the 3x3 cofactor inverse [upstream, op order
+ * unverified here].  PCP/src/PointCloudProcessor.cpp:509,518. */
+static void affine_inverse_f32(const float m[12], float out[12]) {
+  const float a = m[0], b = m[1], c = m[2];
+  const float d = m[4], e = m[5], f = m[6];
+  const float g = m[8], h = m[9], i = m[10];
+  const float c00 = e * i - f * h;
+  const float c01 = f * g - d * i;
+  const float c02 = d * h - e * g;
+  const float det = (a * c00 + b * c01) + c * c02;
+  const float inv = 1.0f / det;
+  float L[9];
+  L[0] = c00 * inv;
+  L[1] = (c * h - b * i) * inv;
+  L[2] = (b * f - c * e) * inv;
+  L[3] = c01 * inv;
+  L[4] = (a * i - c * g) * inv;
+  L[5] = (c * d - a * f) * inv;
+  L[6] = c02 * inv;
+  L[7] = (b * g - a * h) * inv;
+  L[8] = (a * e - b * d) * inv;
+  const float t0 = m[3], t1 = m[7], t2 = m[11];
+  for (int r = 0; r < 3; ++r) {
+    out[4 * r + 0] = L[3 * r + 0];
+    out[4 * r + 1] = L[3 * r + 1];
+    out[4 * r + 2] = L[3 * r + 2];
+    out[4 * r + 3] = -((L[3 * r + 0] * t0 + L[3 * r + 1] * t1) + L[3 * r + 2] * t2);
+  }
+}
+
+/* PCP/src/PointCloudProcessor.cpp:495-519 (same at :186-194). */
+void orc_pose_to_matrices(const orc_pose *pose, const double *T_opt, float w2c[12], float c2w[12]) {
+  double R[9];
+  quat_to_rot(pose, R);
+  const double t[3] = {pose->x, pose->y, pose->z};
+  if (!T_opt) {
+    /* Isometry3d::inverse(): [R^T | -(R^T t)], then cast<float>() (:499-501). */
+    for (int r = 0; r < 3; ++r) {
+      const double a0 = R[0 + r], a1 = R[3 + r], a2 = R[6 + r]; /* row r of R^T */
+      w2c[4 * r + 0] = (float)a0;
+      w2c[4 * r + 1] = (float)a1;
+      w2c[4 * r + 2] = (float)a2;
+      w2c[4 * r + 3] = (float)(-((a0 * t[0] + a1 * t[1]) + a2 * t[2]));
+      c2w[4 * r + 0] = (float)R[3 * r + 0];
+      c2w[4 * r + 1] = (float)R[3 * r + 1];
+      c2w[4 * r + 2] = (float)R[3 * r + 2];
+      c2w[4 * r + 3] = (float)t[r];
+    }
+    return;
+  }
+  /* (t_c2w * T_opt).cast<float>(), then general fp32 inverse (:506-509,515-518). */
+  double M[12];
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 4; ++c) {
+      double s = (R[3 * r + 0] * T_opt[0 * 4 + c] + R[3 * r + 1] * T_opt[1 * 4 + c]) + R[3 * r + 2] * T_opt[2 * 4 + c];
+      if (c == 3) s = s + t[r] * T_opt[3 * 4 + 3];
+      M[4 * r + c] = s;
+    }
+  }
+  for (int k = 0; k < 12; ++k) c2w[k] = (float)M[k];
+  affine_inverse_f32(c2w, w2c);
+}
+
+/* ------------------------------------------------------------------ */
+/* A2 transform                                                        */
+/* ------------------------------------------------------------------ */
+
+/* pcl::transformPointCloud(..., Affine3f), PCL 1.10 detail::Transformer::se3
+ * SSE path: x*c0 + (y*c1 + (z*c2 + c3)) per output row [upstream].  Call sites
+ * PCP/src/PointCloudProcessor.cpp:196,521,549,555. */
+static inline void xform_point(const float m[12], float x, float y, float z, float *xc, float *yc, float *zc) {
+  *xc = x * m[0] + (y * m[1] + (z * m[2] + m[3]));
+  *yc = x * m[4] + (y * m[5] + (z * m[6] + m[7]));
+  *zc = x * m[8] + (y * m[9] + (z * m[10] + m[11]));
+}
+
+void orc_transform(const float m[12], const float *x, const float *y, const float *z, int64_t n, float *xc,
+                   float *yc, float *zc) {
+  for (int64_t i = 0; i < n; ++i) xform_point(m, x[i], y[i], z[i], &xc[i], &yc[i], &zc[i]);
+}
+
+/* ------------------------------------------------------------------ */
+/* A3 projection                                                       */
+/* ------------------------------------------------------------------ */
+
+/* PCP/include/camera/pinhole.hpp:13-51; duplicate PCP/include/PointCloudProcessor.hpp:100-123.
+ * Left-to-right association exactly as written in the source. */
+void orc_project_point(const orc_camera *cam, double xc, double yc, double zc, double *u, double *v) {
+  const double xn = xc / zc;
+  const double yn = yc / zc;
+  const double x2 = xn * xn;
+  const double y2 = yn * yn;
+  const double r2 = x2 + y2;
+  const double r4 = r2 * r2;
+  const double r6 = r2 * r4;
+  const double rc = ((1.0 + cam->k1 * r2) + cam->k2 * r4) + cam->k3 * r6;
+  const double t1 = (2.0 * xn) * yn;
+  const double t2 = r2 + 2.0 * x2;
+  const double t3 = r2 + 2.0 * y2;
+  const double xd = (rc * xn + cam->p1 * t1) + cam->p2 * t2;
+  const double yd = (rc * yn + cam->p1 * t3) + cam->p2 * t1;
+  *u = cam->fx * xd + cam->cx;
+  *v = cam->fy * yd + cam->cy;
+}
+
+/* float/double -> int32 with C truncation; values that do not fit (or NaN) are
+ * UB in the reference (Appendix B6) and are rejected here. */
+static inline int trunc_d(double v, int32_t *out) {
+  if (!(v > -2147483648.0 && v < 2147483648.0)) return 0;
+  *out = (int32_t)v;
+  return 1;
+}
+static inline int trunc_f(float v, int32_t *out) {
+  if (!(v > -2147483648.0f && v < 2147483648.0f)) return 0;
+  *out = (int32_t)v;
+  return 1;
+}
+
+typedef struct projected {
+  float xc, yc, zc;
+  double range;   /* ||p_c|| fp64 (view_culling.cpp:102,144) */
+  int32_t cell;   /* >=0 in map, -2 candidate outside map, -1 rejected */
+  int32_t pixel;  /* >=0 colour pixel, -1 rejected */
+} projected;
+
+/* view_culling.cpp:27-38 (float->double promote), :76 (z test, B6: z<=0 rejected),
+ * :86-90 (project, cast<float>, /14, cast<int>, bounds vs full image_size),
+ * :116 (map bounds), :102 (norm).  Colour pixel: PointCloudProcessor.cpp:748-754. */
+static inline void project_one(const orc_camera *cam, const orc_cull_params *cp, const float m[12], float x,
+                               float y, float z, projected *o) {
+  xform_point(m, x, y, z, &o->xc, &o->yc, &o->zc);
+  o->cell = -1;
+  o->pixel = -1;
+  o->range = (double)FLT_MAX;
+  if (!(o->zc > 0.0f)) return;
+  const double X = (double)o->xc, Y = (double)o->yc, Z = (double)o->zc;
+  o->range = sqrt((X * X + Y * Y) + Z * Z);
+  double u, v;
+  orc_project_point(cam, X, Y, Z, &u, &v);
+  /* A4 cell */
+  {
+    const float ds = (float)cp->downsample_factor;
+    const float uf = (float)u, vf = (float)v;
+    int32_t cx, cy;
+    if (trunc_f(uf / ds, &cx) && trunc_f(vf / ds, &cy)) {
+      if (cx >= 0 && cy >= 0 && cx < cam->cull_width && cy < cam->cull_height) {
+        const int32_t mw = cam->cull_width / cp->downsample_factor;
+        const int32_t mh = cam->cull_height / cp->downsample_factor;
+        o->cell = (cx < mw && cy < mh) ? cy * mw + cx : -2;
+      }
+    }
+  }
+  /* A5 pixel */
+  {
+    int32_t ui, vi;
+    if (trunc_d(u, &ui) && trunc_d(v, &vi)) {
+      if (ui >= 0 && ui < cam->image_width && vi >= 0 && vi < cam->image_height)
+        o->pixel = vi * cam->image_width + ui;
+    }
+  }
+}
+
+void orc_project_frame(const orc_camera *cam, const orc_cull_params *cp, const float w2c[12], const float *x,
+                       const float *y, const float *z, int64_t n, int32_t *out_cell, int32_t *out_pixel,
+                       float *out_range, float *out_xc, float *out_yc, float *out_zc) {
+  for (int64_t i = 0; i < n; ++i) {
+    projected p;
+    project_one(cam, cp, w2c, x[i], y[i], z[i], &p);
+    if (out_cell) out_cell[i] = p.cell;
+    if (out_pixel) out_pixel[i] = p.pixel;
+    if (out_range) out_range[i] = (float)p.range;
+    if (out_xc) out_xc[i] = p.xc;
+    if (out_yc) out_yc[i] = p.yc;
+    if (out_zc) out_zc[i] = p.zc;
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* A4 z-buffer cull                                                    */
+/* ------------------------------------------------------------------ */
+
+static void depth_map_fill(float *map, int64_t cells) {
+  for (int64_t i = 0; i < cells; ++i) map[i] = FLT_MAX; /* view_culling.cpp:64 */
+}
+
+/* pass 1, view_culling.cpp:99-125: if (dist > map) continue; map = (float)dist.
+ * Sequential result == MIN over f32(dist) (rounding is monotone), so the
+ * threaded variant below (private maps + MIN merge) is exactly equivalent. */
+static void depth_pass(const orc_camera *cam, const orc_cull_params *cp, const float m[12], const float *x,
+                       const float *y, const float *z, int64_t n, float *map, int threads) {
+  const int64_t cells = (int64_t)(cam->cull_width / cp->downsample_factor) * (cam->cull_height / cp->downsample_factor);
+  depth_map_fill(map, cells);
+  if (threads <= 1) {
+    for (int64_t i = 0; i < n; ++i) {
+      projected p;
+      project_one(cam, cp, m, x[i], y[i], z[i], &p);
+      if (p.cell < 0) continue;
+      if (p.range > (double)map[p.cell]) continue;
+      map[p.cell] = (float)p.range;
+    }
+    return;
+  }
+#ifdef _OPENMP
+#pragma omp parallel num_threads(threads)
+  {
+    float *priv = (float *)malloc((size_t)cells * sizeof(float));
+    depth_map_fill(priv, cells);
+#pragma omp for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+      projected p;
+      project_one(cam, cp, m, x[i], y[i], z[i], &p);
+      if (p.cell < 0) continue;
+      if (p.range > (double)priv[p.cell]) continue;
+      priv[p.cell] = (float)p.range;
+    }
+#pragma omp critical
+    {
+      for (int64_t c = 0; c < cells; ++c)
+        if (priv[c] < map[c]) map[c] = priv[c];
+    }
+    free(priv);
+  }
+#endif
+}
+
+/* pass 2 keep rule, view_culling.cpp:135-171: keep iff cell in map and
+ * !(dist > (double)map + 0.05); without depth-buffer culling every candidate
+ * (cell >= 0 or -2) is kept (:92-93, indices.emplace_back). */
+static inline int keep_rule(const orc_cull_params *cp, const projected *p, const float *map) {
+  if (!cp->enable_depth_buffer_culling) return p->cell != -1;
+  if (p->cell < 0) return 0;
+  return !(p->range > (double)map[p->cell] + cp->depth_slack);
+}
+
+int64_t orc_cull_frame(const orc_camera *cam, const orc_cull_params *cp, const float w2c[12], const float *x,
+                       const float *y, const float *z, int64_t n, uint8_t *out_keep, float *depth_map,
+                       int32_t threads) {
+  const int nt = threads == 1 ? 1 : resolve_threads(threads);
+  const int64_t cells = (int64_t)(cam->cull_width / cp->downsample_factor) * (cam->cull_height / cp->downsample_factor);
+  float *map = depth_map ? depth_map : (float *)malloc((size_t)(cells > 0 ? cells : 1) * sizeof(float));
+  depth_pass(cam, cp, w2c, x, y, z, n, map, nt);
+  int64_t kept = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nt) reduction(+ : kept)
+#endif
+  for (int64_t i = 0; i < n; ++i) {
+    projected p;
+    project_one(cam, cp, w2c, x[i], y[i], z[i], &p);
+    const int k = keep_rule(cp, &p, map);
+    if (out_keep) out_keep[i] = (uint8_t)k;
+    kept += k;
+  }
+  if (!depth_map) free(map);
+  return kept;
+}
+
+/* ------------------------------------------------------------------ */
+/* A6 scores                                                           */
+/* ------------------------------------------------------------------ */
+
+/* computeOrientationScore PCP/include/PointCloudProcessor.hpp:205-220 (B4: world
+ * camera position subtracted from a camera-frame point, reproduced);
+ * computeDistanceScore :222-236; final PCP/src/PointCloudProcessor.cpp:588.
+ * Identity mode (Appendix B3): the camera-frame point is the transform output. */
+void orc_scores(float xc, float yc, float zc, const orc_pose *pose, float *orientation, float *distance,
+                float *final_score) {
+  const double dx = (double)xc - pose->x, dy = (double)yc - pose->y, dz = (double)zc - pose->z;
+  const double sq = (dx * dx + dy * dy) + dz * dz;
+  /* Eigen normalized(): v / sqrt(sq) if sq > 0 else v [upstream]; dot with (0,0,1) = z */
+  const double cosA = sq > 0.0 ? dz / sqrt(sq) : dz;
+  float o = (float)((cosA + 1.0) / 2.0);
+  o = 0.2f + 0.8f * o;
+  const float dist = sqrtf((xc * xc + yc * yc) + zc * zc);
+  const float diff = fabsf(dist - 2.0f);
+  float nd = diff / 2.0f;
+  if (!(nd < 1.0f)) nd = 1.0f; /* std::min(nd, 1.0f) */
+  float d = 1.0f - nd;
+  d = 0.2f + 0.8f * d;
+  if (orientation) *orientation = o;
+  if (distance) *distance = d;
+  if (final_score) *final_score = (float)((double)(o + d) / 2.0);
+}
+
+/* ------------------------------------------------------------------ */
+/* A8 top-5 accumulate / finalise                                      */
+/* ------------------------------------------------------------------ */
+
+#define ORC_TOPM 5 /* PCP/src/PointCloudProcessor.cpp:615 */
+
+typedef struct top5 {
+  float score[ORC_TOPM];
+  uint32_t rgb[ORC_TOPM]; /* 0x00RRGGBB */
+  int32_t frame[ORC_TOPM];
+  int32_t count;
+} top5;
+
+/* Streaming equivalent of "collect all, std::sort descending by finalScore, keep
+ * 5" (PCP/src/PointCloudProcessor.cpp:612-615) with ties -> lower keyframe index
+ * (B8): frames arrive in ascending order, a new entry goes after equal scores. */
+static inline void top5_insert(top5 *t, float score, uint32_t rgb, int32_t frame) {
+  if (t->count < INT32_MAX) t->count++;
+  int pos = ORC_TOPM;
+  for (int k = 0; k < ORC_TOPM; ++k) {
+    if (t->frame[k] < 0 || score > t->score[k]) {
+      pos = k;
+      break;
+    }
+  }
+  if (pos == ORC_TOPM) return;
+  for (int k = ORC_TOPM - 1; k > pos; --k) {
+    t->score[k] = t->score[k - 1];
+    t->rgb[k] = t->rgb[k - 1];
+    t->frame[k] = t->frame[k - 1];
+  }
+  t->score[pos] = score;
+  t->rgb[pos] = rgb;
+  t->frame[pos] = frame;
+}
+
+/* smoothColors PCP/src/PointCloudProcessor.cpp:616-629: fp32 sums in sorted
+ * order, r/total truncated to uint8; no entries -> (0,0,0) (B7). */
+static inline void top5_finalise(const top5 *t, uint8_t rgb[3]) {
+  float total = 0.0f, r = 0.0f, g = 0.0f, b = 0.0f;
+  int m = 0;
+  for (int k = 0; k < ORC_TOPM; ++k) {
+    if (t->frame[k] < 0) break;
+    const float s = t->score[k];
+    r += (float)((t->rgb[k] >> 16) & 0xff) * s;
+    g += (float)((t->rgb[k] >> 8) & 0xff) * s;
+    b += (float)(t->rgb[k] & 0xff) * s;
+    total += s;
+    ++m;
+  }
+  if (m == 0) {
+    rgb[0] = rgb[1] = rgb[2] = 0;
+    return;
+  }
+  rgb[0] = (uint8_t)(r / total);
+  rgb[1] = (uint8_t)(g / total);
+  rgb[2] = (uint8_t)(b / total);
+}
+
+int orc_colorize(const orc_camera *cam, const orc_cull_params *cp, const float *x, const float *y, const float *z,
+                 int64_t n, const orc_pose *poses, int32_t n_frames, const double *T_opt, int32_t T_opt_stride,
+                 const uint8_t *const *images, uint8_t *out_rgb, uint8_t *out_has, int32_t *out_count,
+                 float *out_top_score, uint32_t *out_top_rgb, int32_t *out_top_frame, int32_t threads) {
+  const int nt = threads == 1 ? 1 : resolve_threads(threads);
+  const int64_t cells = (int64_t)(cam->cull_width / cp->downsample_factor) * (cam->cull_height / cp->downsample_factor);
+  float *map = (float *)malloc((size_t)(cells > 0 ? cells : 1) * sizeof(float));
+  top5 *state = (top5 *)malloc((size_t)(n > 0 ? n : 1) * sizeof(top5));
+  if (!map || !state) {
+    free(map);
+    free(state);
+    return -1;
+  }
+  for (int64_t i = 0; i < n; ++i) {
+    state[i].count = 0;
+    for (int k = 0; k < ORC_TOPM; ++k) {
+      state[i].score[k] = -1.0f;
+      state[i].rgb[k] = 0;
+      state[i].frame[k] = -1;
+    }
+  }
+  for (int32_t f = 0; f < n_frames; ++f) { /* PCP/src/PointCloudProcessor.cpp:488 */
+    float w2c[12], c2w[12];
+    const double *T = T_opt ? T_opt + (int64_t)T_opt_stride * f : NULL;
+    orc_pose_to_matrices(&poses[f], T, w2c, c2w);
+    if (cp->enable_depth_buffer_culling) depth_pass(cam, cp, w2c, x, y, z, n, map, nt);
+    const uint8_t *img = images[f];
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nt)
+#endif
+    for (int64_t i = 0; i < n; ++i) {
+      projected p;
+      project_one(cam, cp, w2c, x[i], y[i], z[i], &p);
+      if (!keep_rule(cp, &p, map)) continue; /* ViewCulling::cull, :527 */
+      if (p.pixel < 0) continue;             /* generateColorMap bounds, :748-754 */
+      const uint8_t *px = img + (int64_t)p.pixel * 3; /* BGR, :760-762 */
+      const uint32_t rgb = ((uint32_t)px[2] << 16) | ((uint32_t)px[1] << 8) | (uint32_t)px[0];
+      float fs;
+      orc_scores(p.xc, p.yc, p.zc, &poses[f], NULL, NULL, &fs); /* :584-588 */
+      top5_insert(&state[i], fs, rgb, f);                      /* :590-591 */
+    }
+  }
+  for (int64_t i = 0; i < n; ++i) {
+    uint8_t rgb[3];
+    top5_finalise(&state[i], rgb);
+    out_rgb[3 * i + 0] = rgb[0];
+    out_rgb[3 * i + 1] = rgb[1];
+    out_rgb[3 * i + 2] = rgb[2];
+    /* removePointsWithNoColor PCP/include/PointCloudProcessor.hpp:238-252 */
+    if (out_has) out_has[i] = (uint8_t)(rgb[0] != 0 || rgb[1] != 0 || rgb[2] != 0);
+    if (out_count) out_count[i] = state[i].count;
+    for (int k = 0; k < ORC_TOPM; ++k) {
+      if (out_top_score) out_top_score[ORC_TOPM * i + k] = state[i].score[k];
+      if (out_top_rgb) out_top_rgb[ORC_TOPM * i + k] = state[i].rgb[k];
+      if (out_top_frame) out_top_frame[ORC_TOPM * i + k] = state[i].frame[k];
+    }
+  }
+  free(map);
+  free(state);
+  return 0;
+}
+
+/* generateColorMap + generateSegmentMap + transform to world,
+ * PCP/src/PointCloudProcessor.cpp:531-551,743-766,783-815. */
+int64_t orc_frame_visible(const orc_camera *cam, const orc_cull_params *cp, const orc_pose *pose,
+                          const double *T_opt, const float *x, const float *y, const float *z, int64_t n,
+                          const uint8_t *image, const uint8_t *mask, int32_t *out_index, uint8_t *out_rgb,
+                          uint16_t *out_mask, float *out_xyz_cam, float *out_xyz_world) {
+  float w2c[12], c2w[12];
+  orc_pose_to_matrices(pose, T_opt, w2c, c2w);
+  const int64_t cells = (int64_t)(cam->cull_width / cp->downsample_factor) * (cam->cull_height / cp->downsample_factor);
+  float *map = (float *)malloc((size_t)(cells > 0 ? cells : 1) * sizeof(float));
+  if (cp->enable_depth_buffer_culling) depth_pass(cam, cp, w2c, x, y, z, n, map, 1);
+  int64_t m = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    projected p;
+    project_one(cam, cp, w2c, x[i], y[i], z[i], &p);
+    if (!keep_rule(cp, &p, map)) continue;
+    if (p.pixel < 0) continue;
+    uint8_t r = 0, g = 0, b = 0;
+    if (image) {
+      const uint8_t *px = image + (int64_t)p.pixel * 3;
+      b = px[0];
+      g = px[1];
+      r = px[2];
+    }
+    uint16_t mv = 0;
+    if (mask) {
+      mv = mask[p.pixel]; /* grayImg.at<uchar>(v,u), :803 */
+      if (mv == 255) {     /* :805-810 */
+        r = 255;
+        g = 0;
+        b = 0;
+      }
+    }
+    if (out_index) out_index[m] = (int32_t)i;
+    if (out_rgb) {
+      out_rgb[3 * m + 0] = r;
+      out_rgb[3 * m + 1] = g;
+      out_rgb[3 * m + 2] = b;
+    }
+    if (out_mask) out_mask[m] = mv;
+    if (out_xyz_cam) {
+      out_xyz_cam[3 * m + 0] = p.xc;
+      out_xyz_cam[3 * m + 1] = p.yc;
+      out_xyz_cam[3 * m + 2] = p.zc;
+    }
+    if (out_xyz_world) { /* transformPointCloud(c2w), :549,555 */
+      xform_point(c2w, p.xc, p.yc, p.zc, &out_xyz_world[3 * m + 0], &out_xyz_world[3 * m + 1],
+                  &out_xyz_world[3 * m + 2]);
+    }
+    ++m;
+  }
+  free(map);
+  return m;
+}
+
+/* ------------------------------------------------------------------ */
+/* keyframes                                                           */
+/* ------------------------------------------------------------------ */
+
+/* markKeyframe PCP/include/PointCloudProcessor.hpp:151-191 (distance-only rule,
+ * B9) driven by selectKeyframes PCP/src/PointCloudProcessor.cpp:1050-1075. */
+int32_t orc_select_keyframes(const orc_pose *poses, int32_t n, double dist_threshold, int32_t *out_indices) {
+  int32_t m = 0, last = -1;
+  for (int32_t i = 0; i < n; ++i) {
+    int key = 0;
+    if (last < 0) {
+      key = 1;
+    } else {
+      const double dx = poses[i].x - poses[last].x;
+      const double dy = poses[i].y - poses[last].y;
+      const double dz = poses[i].z - poses[last].z;
+      key = sqrt(dx * dx + dy * dy + dz * dz) >= dist_threshold;
+    }
+    if (key) {
+      out_indices[m++] = i;
+      last = i;
+    }
+  }
+  return m;
+}
