@@ -1,0 +1,204 @@
+/*
+ * pcp_hip.h -- C ABI of libpcp_hip.so: the MI355X (gfx950) implementation of
+ * PointCloudProcessor's colourisation / view-culling / MLS hot path.
+ *
+ * The reference (ChunLI-666/PointCloudProcessor @2024_10_08) has no FFI or
+ * plugin interface: the path is reached through C++ member calls.  Every entry
+ * point below names the reference call site it replaces (PCP/ =
+ * PointCloudProcessor/ in the reference tree); INTEGRATION.md shows the shim a
+ * maintainer adds at each site.
+ *
+ * Conventions
+ *  - plain C types, caller-owned host buffers, no exceptions across the
+ *    boundary: every call returns PCP_OK (0) or a negative error class and
+ *    pcp_last_error() holds the message (the C++ shim rethrows
+ *    std::runtime_error so that main.cpp:64-68 still maps it to exit code -2);
+ *  - the library owns all device memory behind the opaque handle; no host
+ *    pointer is retained after a call returns;
+ *  - one calling thread per handle (the reference makes every hot-path call
+ *    from its main thread, PointCloudProcessor.cpp:1007-1032);
+ *  - there is no CPU fallback: without a usable HIP device pcp_create() fails.
+ *  - results: pixel / cell indices, depth maps and keep masks are bit-exact
+ *    with the CPU restatement in oracle/; colours and MLS outputs within 1e-4
+ *    relative.
+ */
+#ifndef PCP_HIP_H
+#define PCP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCP_ABI_VERSION 1
+
+#define PCP_OK 0
+#define PCP_ERR_INVALID (-1) /* bad argument */
+#define PCP_ERR_STATE (-2)   /* call order: camera / cloud / frames / images missing */
+#define PCP_ERR_DEVICE (-3)  /* HIP runtime failure */
+#define PCP_ERR_NOMEM (-4)   /* host or device allocation failed */
+#define PCP_ERR_RANGE (-5)   /* frame index or capacity out of range */
+
+typedef struct pcp_context pcp_context;
+
+/* PCP/include/FrameData.hpp:9-12 (Pose); odometry line "ts x y z qw qx qy qz",
+ * PCP/src/PointCloudProcessor.cpp:970-978. */
+typedef struct pcp_pose {
+  double x, y, z, qw, qx, qy, qz;
+} pcp_pose;
+
+/* K_camera / D_camera, PCP/src/PointCloudProcessor.cpp:57-62; image size used by
+ * generateColorMap (:754); ViewCulling image_size hard-coded {4096,3000} (:206,:525). */
+typedef struct pcp_camera {
+  double fx, fy, cx, cy;
+  double k1, k2, p1, p2, k3;
+  int32_t image_width, image_height;
+  int32_t cull_width, cull_height;
+} pcp_camera;
+
+/* vlcal::ViewCullingParams, PCP/include/vlcal/calib/view_culling.hpp:10-19, plus
+ * the constants 14 (view_culling.cpp:63) and 0.05 (:157). */
+typedef struct pcp_cull_params {
+  int32_t enable_depth_buffer_culling;
+  int32_t downsample_factor;
+  double depth_slack;
+} pcp_cull_params;
+
+/* MLSParameters, PCP/include/cloudSmooth.hpp:21-36; values
+ * PCP/src/PointCloudProcessor.cpp:67-86. */
+typedef struct pcp_mls_params {
+  double search_radius;
+  double sqr_gauss_param;
+  int32_t polynomial_order;
+  int32_t compute_normals;
+  int32_t upsampling; /* 0 NONE, 3 VOXEL_GRID_DILATION (cloudSmooth.hpp enum order) */
+  int32_t vgd_iterations;
+  float vgd_voxel_size;
+  int32_t sor_mean_k;   /* 60  (PointCloudProcessor.cpp:84) */
+  double sor_std_mul;   /* 0.7 (PointCloudProcessor.cpp:86) */
+} pcp_mls_params;
+
+/* kernel ids for pcp_timing_get() */
+enum {
+  PCP_K_PROJECT = 0,    /* single-frame projection (the roofline kernel) */
+  PCP_K_DEPTH = 1,      /* batched z-buffer MIN pass */
+  PCP_K_COLOUR = 2,     /* batched visibility + colour + score + top-5 pass */
+  PCP_K_VISIBILITY = 3, /* single-frame keep mask */
+  PCP_K_MLS_GRID = 4,   /* MLS cell binning / counting sort */
+  PCP_K_MLS_FIT = 5,    /* MLS radius search + polynomial fit + projection */
+  PCP_K_MISC = 6,       /* fills, compaction, permutation */
+  PCP_K_SOR = 7,        /* StatisticalOutlierRemoval kNN mean distance */
+  PCP_K_MLS_VOXEL = 8,  /* VOXEL_GRID_DILATION upsampling */
+  PCP_K_COUNT = 9
+};
+
+/* ---- lifecycle ---------------------------------------------------------- */
+int pcp_abi_version(void);
+/* device: HIP device ordinal.  Fails (PCP_ERR_DEVICE) when no GPU is usable. */
+int pcp_create(int32_t device, pcp_context **out);
+void pcp_destroy(pcp_context *ctx);
+/* message of the last failing call on ctx (or of pcp_create when ctx == NULL) */
+const char *pcp_last_error(const pcp_context *ctx);
+/* run on an externally owned hipStream_t (e.g. torch's current stream); NULL = own stream */
+int pcp_set_stream(pcp_context *ctx, void *hip_stream);
+int pcp_synchronize(pcp_context *ctx);
+
+/* ---- configuration ------------------------------------------------------ */
+void pcp_default_camera(pcp_camera *cam);
+void pcp_default_cull_params(pcp_cull_params *p);
+void pcp_default_mls_params(pcp_mls_params *p);
+/* replaces create_camera + ViewCulling ctor, PointCloudProcessor.cpp:522-525 */
+int pcp_set_camera(pcp_context *ctx, const pcp_camera *cam, const pcp_cull_params *cull);
+
+/* ---- cloud -------------------------------------------------------------- */
+/* SoA fp32 upload of the map (`cloud`, PointCloudProcessor.cpp:148). */
+int pcp_upload_cloud(pcp_context *ctx, const float *x, const float *y, const float *z, int64_t n);
+/* AoS upload straight from pcl::PointCloud<PointXYZI>::points.data(): x,y,z are
+ * the first three floats of every `stride_bytes` record (32 for PointXYZI). */
+int pcp_upload_cloud_aos(pcp_context *ctx, const void *points, int64_t n, int64_t stride_bytes);
+int64_t pcp_cloud_size(const pcp_context *ctx);
+
+/* ---- frames ------------------------------------------------------------- */
+/* Host helper: pose -> (w2c, c2w) 3x4 row-major fp32, PointCloudProcessor.cpp:495-519.
+ * T_opt: NULL, or a 4x4 row-major fp64 T_camera_lidar_optimized (:504-519). */
+int pcp_pose_to_matrices(const pcp_pose *pose, const double *T_opt, float w2c[12], float c2w[12]);
+/* Keyframe poses of the run (selectKeyframes output).  T_opt: NULL, 16 doubles
+ * (stride 0, NID result) or n_frames*16 (stride 16, per-keyframe manual guess). */
+int pcp_set_frames(pcp_context *ctx, const pcp_pose *poses, int32_t n_frames, const double *T_opt,
+                   int32_t T_opt_stride);
+int32_t pcp_frame_count(const pcp_context *ctx);
+/* Decoded BGR8 image of one keyframe (what generateColorMap holds after the HSV
+ * round trip, PointCloudProcessor.cpp:716-741), image_height rows of image_width
+ * pixels, row_stride_bytes apart (cv::Mat::step). */
+int pcp_upload_image(pcp_context *ctx, int32_t frame, const uint8_t *bgr, int64_t row_stride_bytes);
+/* gray8 segmentation mask (cv::IMREAD_GRAYSCALE, PointCloudProcessor.cpp:775) */
+int pcp_upload_mask(pcp_context *ctx, int32_t frame, const uint8_t *gray, int64_t row_stride_bytes);
+
+/* ---- single keyframe (drop-in for the calls inside the per-keyframe loop) -- */
+/* transformPointCloud + project (PointCloudProcessor.cpp:521, view_culling.cpp:86-90,
+ * PointCloudProcessor.cpp:748-754).  All outputs nullable, length n, input order:
+ *   out_cell  z-buffer cell cy*mw+cx; -2 candidate outside the /14 map; -1 rejected
+ *   out_pixel colour pixel v*image_width+u; -1 rejected
+ *   out_range f32(||p_c||), valid where out_cell != -1 (FLT_MAX elsewhere)
+ *   out_xyz_cam 3*n floats, SoA (x[n] y[n] z[n]) camera coordinates
+ * With every output NULL the kernel still runs and leaves cell/range on the
+ * device (used by bench.py to time the kernel without PCIe traffic). */
+int pcp_project_frame(pcp_context *ctx, int32_t frame, int32_t *out_cell, int32_t *out_pixel, float *out_range,
+                      float *out_xyz_cam);
+/* ViewCulling::cull with the z-buffer routine (view_culling.cpp:23-50,52-174).
+ * out_keep n bytes (nullable), out_depth_map (H/14)*(W/14) floats (nullable). */
+int pcp_cull_frame(pcp_context *ctx, int32_t frame, uint8_t *out_keep, int64_t *out_kept, float *out_depth_map);
+/* cull + generateColorMap + generateSegmentMap + transform to world
+ * (PointCloudProcessor.cpp:527-551): the kept and coloured points of one keyframe
+ * in input order.  rgb after the mask==255 -> (255,0,0) override when a mask was
+ * uploaded.  All outputs nullable; capacity in points; *out_count = true count. */
+int pcp_frame_visible(pcp_context *ctx, int32_t frame, int64_t capacity, int32_t *out_index, uint8_t *out_rgb,
+                      uint16_t *out_mask, float *out_xyz_cam, float *out_xyz_world, int64_t *out_count);
+
+/* ---- whole run (pcdColorizationAndSmooth, PointCloudProcessor.cpp:474-602) -- */
+/* z-buffer MIN pass for keyframes [frame_begin, frame_end) over the local points */
+int pcp_depth_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end);
+/* device address of the n_frames*(H/14)*(W/14) fp32 depth maps, for the
+ * all-reduce(MIN) across point shards (multi-GPU), and its length in floats */
+int pcp_depth_maps_device(pcp_context *ctx, void **device_ptr, int64_t *n_floats);
+int pcp_download_depth_map(pcp_context *ctx, int32_t frame, float *out_depth_map);
+int pcp_colour_reset(pcp_context *ctx);
+/* visibility + colour lookup + scores + per-point top-5 for [frame_begin, frame_end) */
+int pcp_colour_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end);
+/* smoothColors + removePointsWithNoColor flag (PointCloudProcessor.cpp:604-631,
+ * hpp:238-252).  out_rgb n*3 (r,g,b), out_has n; optional: out_count n (#views),
+ * out_top_score/out_top_rgb(0x00RRGGBB)/out_top_frame n*5 (desc, -1 padded). */
+int pcp_colour_finalise(pcp_context *ctx, uint8_t *out_rgb, uint8_t *out_has, int32_t *out_count,
+                        float *out_top_score, uint32_t *out_top_rgb, int32_t *out_top_frame);
+/* reset + depth_pass(all) + colour_pass(all) + finalise */
+int pcp_colorize(pcp_context *ctx, uint8_t *out_rgb, uint8_t *out_has);
+/* device address of the packed per-point result (r | g<<8 | b<<16 | has<<24),
+ * valid after pcp_colour_finalise / pcp_colorize, for device-side gathers */
+int pcp_colour_result_device(pcp_context *ctx, void **device_ptr, int64_t *n_words);
+
+/* ---- MLS (CloudSmooth::process, PCP/src/cloudSmooth.cpp:77-185) ---------- */
+/* pcl::MovingLeastSquares on the uploaded cloud (radius search + order-2 fit +
+ * SIMPLE projection; upsampling NONE or VOXEL_GRID_DILATION).  Results stay on
+ * the device; *out_count = number of output points. */
+int pcp_mls_process(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_count);
+/* xyz / normal 3*m floats AoS, curvature m, source index m (input order for
+ * NONE; ascending voxel key for VOXEL_GRID_DILATION). */
+int pcp_mls_fetch(pcp_context *ctx, int64_t capacity, float *out_xyz, float *out_normal, float *out_curvature,
+                  int32_t *out_index);
+/* pcl::StatisticalOutlierRemoval (k, std_mul) keep mask of the uploaded cloud,
+ * cloudSmooth.cpp:109-116,160-164. */
+int pcp_sor(pcp_context *ctx, int32_t mean_k, double std_mul, uint8_t *out_keep, int64_t *out_kept);
+
+/* ---- measurement -------------------------------------------------------- */
+/* When enabled every kernel launch is bracketed by hipEvents on the context's
+ * stream; totals are read back with pcp_timing_get (which synchronises). */
+int pcp_timing_enable(pcp_context *ctx, int32_t on);
+int pcp_timing_reset(pcp_context *ctx);
+int pcp_timing_get(pcp_context *ctx, int32_t kernel_id, double *total_ms, int64_t *launches);
+const char *pcp_kernel_name(int32_t kernel_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCP_HIP_H */

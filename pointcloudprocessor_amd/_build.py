@@ -1,0 +1,69 @@
+"""Build recipe of libpcp_hip.so (hipcc, gfx950 only, in-tree).
+
+The shared library is plain HIP runtime + C ABI: no torch types, no Python.
+`build()` is what __graft_entry__.build() calls; it cross-compiles without a
+GPU.  -ffp-contract=off is part of the numerical contract (pcp_device.hpp).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+CSRC = os.path.join(_PKG, "csrc")
+LIB_DIR = os.path.join(_PKG, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libpcp_hip.so")
+INCLUDE = os.path.join(_ROOT, "include")
+
+SOURCES = ["pcp_context.hip", "pcp_colour.hip", "pcp_mls.hip"]
+HEADERS = ["pcp_internal.hpp", "pcp_device.hpp"]
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-shared",
+    "-ffp-contract=off",
+    "-fhip-fp32-correctly-rounded-divide-sqrt",
+    "-Wall",
+    "-Wextra",
+]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(INCLUDE, "pcp_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP translation unit into pointcloudprocessor_amd/lib/libpcp_hip.so."""
+    if not force and not is_stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INCLUDE, "-I", CSRC, "-o", LIB_PATH] + [
+        os.path.join(CSRC, s) for s in SOURCES
+    ]
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or proc.returncode != 0:
+        print(" ".join(cmd))
+        print(proc.stdout)
+        print(proc.stderr)
+    if proc.returncode != 0:
+        raise RuntimeError("hipcc failed building libpcp_hip.so:\n" + proc.stderr[-4000:])
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,358 @@
+"""ctypes binding of include/pcp_hip.h (libpcp_hip.so).
+
+This is the Python view of the drop-in boundary used by tests and bench.py; the
+C++ host shim (pointcloudprocessor_amd/host/) binds the same symbols.  There is
+no fallback: if the library is missing or no GPU is usable, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+from . import _build
+
+# error classes (pcp_hip.h)
+PCP_OK = 0
+PCP_ERR_INVALID = -1
+PCP_ERR_STATE = -2
+PCP_ERR_DEVICE = -3
+PCP_ERR_NOMEM = -4
+PCP_ERR_RANGE = -5
+
+K_PROJECT, K_DEPTH, K_COLOUR, K_VISIBILITY, K_MLS_GRID, K_MLS_FIT, K_MISC, K_SOR, K_MLS_VOXEL = range(9)
+K_COUNT = 9
+
+
+class PcpError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"pcp error {code}: {msg}")
+        self.code = code
+
+
+class Pose(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("x", "y", "z", "qw", "qx", "qy", "qz")]
+
+
+class Camera(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3")] + [
+        (k, C.c_int32) for k in ("image_width", "image_height", "cull_width", "cull_height")
+    ]
+
+
+class CullParams(C.Structure):
+    _fields_ = [
+        ("enable_depth_buffer_culling", C.c_int32),
+        ("downsample_factor", C.c_int32),
+        ("depth_slack", C.c_double),
+    ]
+
+
+class MLSParams(C.Structure):
+    _fields_ = [
+        ("search_radius", C.c_double),
+        ("sqr_gauss_param", C.c_double),
+        ("polynomial_order", C.c_int32),
+        ("compute_normals", C.c_int32),
+        ("upsampling", C.c_int32),
+        ("vgd_iterations", C.c_int32),
+        ("vgd_voxel_size", C.c_float),
+        ("sor_mean_k", C.c_int32),
+        ("sor_std_mul", C.c_double),
+    ]
+
+
+def declared_symbols() -> list[str]:
+    """Every function include/pcp_hip.h declares (parsed from the header)."""
+    with open(os.path.join(_build.INCLUDE, "pcp_hip.h")) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pcp_[a-z0-9_]+)\s*\(", text)))
+
+
+_lib = None
+
+
+def load(build_if_needed: bool = True) -> C.CDLL:
+    """dlopen libpcp_hip.so (building it in-tree first when stale)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_needed:
+        try:
+            _build.build()
+        except Exception:
+            if not os.path.exists(_build.LIB_PATH):
+                raise
+    if not os.path.exists(_build.LIB_PATH):
+        raise PcpError(PCP_ERR_DEVICE, f"{_build.LIB_PATH} is missing: the HIP extension is not built")
+    L = C.CDLL(_build.LIB_PATH)
+    L.pcp_last_error.restype = C.c_char_p
+    L.pcp_last_error.argtypes = [C.c_void_p]
+    L.pcp_kernel_name.restype = C.c_char_p
+    L.pcp_cloud_size.restype = C.c_int64
+    L.pcp_cloud_size.argtypes = [C.c_void_p]
+    L.pcp_frame_count.restype = C.c_int32
+    L.pcp_frame_count.argtypes = [C.c_void_p]
+    L.pcp_destroy.restype = None
+    L.pcp_destroy.argtypes = [C.c_void_p]
+    for name in ("pcp_default_camera", "pcp_default_cull_params", "pcp_default_mls_params"):
+        getattr(L, name).restype = None
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def default_camera() -> Camera:
+    cam = Camera()
+    load().pcp_default_camera(C.byref(cam))
+    return cam
+
+
+def camera_from_dict(d: dict) -> Camera:
+    cam = Camera()
+    for k, _ in Camera._fields_:
+        setattr(cam, k, d[k])
+    return cam
+
+
+def default_cull_params() -> CullParams:
+    p = CullParams()
+    load().pcp_default_cull_params(C.byref(p))
+    return p
+
+
+def default_mls_params() -> MLSParams:
+    p = MLSParams()
+    load().pcp_default_mls_params(C.byref(p))
+    return p
+
+
+def pose_to_matrices(pose, T_opt=None):
+    p = Pose(*[float(v) for v in pose])
+    w2c = np.zeros(12, np.float32)
+    c2w = np.zeros(12, np.float32)
+    T = None if T_opt is None else np.ascontiguousarray(T_opt, np.float64).reshape(16)
+    rc = load().pcp_pose_to_matrices(C.byref(p), _ptr(T), _ptr(w2c), _ptr(c2w))
+    if rc != PCP_OK:
+        raise PcpError(rc, load().pcp_last_error(None).decode())
+    return w2c, c2w
+
+
+class Context:
+    """Owns one pcp_context (one GPU)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.pcp_create(C.c_int32(device), C.byref(h))
+        if rc != PCP_OK:
+            raise PcpError(rc, self.lib.pcp_last_error(None).decode())
+        self.h = h
+        self.n = 0
+        self.n_frames = 0
+        self.camera = None
+        self.cull = None
+
+    # -- plumbing ---------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != PCP_OK:
+            raise PcpError(rc, self.lib.pcp_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pcp_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr: int | None):
+        self._check(self.lib.pcp_set_stream(self.h, C.c_void_p(stream_ptr or 0)))
+
+    def synchronize(self):
+        self._check(self.lib.pcp_synchronize(self.h))
+
+    # -- configuration ----------------------------------------------------
+    def set_camera(self, cam: Camera, cull: CullParams | None = None):
+        self.camera = cam
+        self.cull = cull if cull is not None else default_cull_params()
+        self._check(self.lib.pcp_set_camera(self.h, C.byref(cam), C.byref(self.cull)))
+
+    @property
+    def map_shape(self):
+        ds = self.cull.downsample_factor
+        return (self.camera.cull_height // ds, self.camera.cull_width // ds)
+
+    def upload_cloud(self, x, y, z):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.ascontiguousarray(y, np.float32)
+        z = np.ascontiguousarray(z, np.float32)
+        assert len(x) == len(y) == len(z)
+        self._check(self.lib.pcp_upload_cloud(self.h, _ptr(x), _ptr(y), _ptr(z), C.c_int64(len(x))))
+        self.n = len(x)
+
+    def upload_cloud_aos(self, pts: np.ndarray):
+        pts = np.ascontiguousarray(pts)
+        self._check(self.lib.pcp_upload_cloud_aos(self.h, _ptr(pts), C.c_int64(pts.shape[0]),
+                                                  C.c_int64(pts.strides[0])))
+        self.n = pts.shape[0]
+
+    def set_frames(self, poses, T_opt=None):
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)
+        F = len(poses)
+        arr = (Pose * max(F, 1))()
+        if F:
+            C.memmove(arr, poses.ctypes.data, poses.nbytes)
+        T = None
+        stride = 0
+        if T_opt is not None:
+            T = np.ascontiguousarray(T_opt, np.float64).reshape(-1)
+            stride = 16 if (T.size == 16 * F and F > 1) else 0
+        self._check(self.lib.pcp_set_frames(self.h, arr, C.c_int32(F), _ptr(T), C.c_int32(stride)))
+        self.n_frames = F
+
+    def upload_image(self, frame: int, bgr: np.ndarray):
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        assert bgr.shape == (self.camera.image_height, self.camera.image_width, 3), bgr.shape
+        self._check(self.lib.pcp_upload_image(self.h, C.c_int32(frame), _ptr(bgr), C.c_int64(bgr.strides[0])))
+
+    def upload_mask(self, frame: int, gray: np.ndarray):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        assert gray.shape == (self.camera.image_height, self.camera.image_width), gray.shape
+        self._check(self.lib.pcp_upload_mask(self.h, C.c_int32(frame), _ptr(gray), C.c_int64(gray.strides[0])))
+
+    # -- single keyframe --------------------------------------------------
+    def project_frame(self, frame: int, want_pixel=True, want_cam=True, device_only=False):
+        if device_only:
+            self._check(self.lib.pcp_project_frame(self.h, C.c_int32(frame), None, None, None, None))
+            return None
+        n = self.n
+        cell = np.empty(n, np.int32)
+        rng = np.empty(n, np.float32)
+        pix = np.empty(n, np.int32) if want_pixel else None
+        cam = np.empty((3, n), np.float32) if want_cam else None
+        self._check(self.lib.pcp_project_frame(self.h, C.c_int32(frame), _ptr(cell), _ptr(pix), _ptr(rng), _ptr(cam)))
+        out = dict(cell=cell, range=rng)
+        if want_pixel:
+            out["pixel"] = pix
+        if want_cam:
+            out.update(xc=cam[0], yc=cam[1], zc=cam[2])
+        return out
+
+    def cull_frame(self, frame: int):
+        keep = np.empty(self.n, np.uint8)
+        mh, mw = self.map_shape
+        dmap = np.empty(mh * mw, np.float32)
+        kept = C.c_int64()
+        self._check(self.lib.pcp_cull_frame(self.h, C.c_int32(frame), _ptr(keep), C.byref(kept), _ptr(dmap)))
+        return keep, dmap.reshape(mh, mw), kept.value
+
+    def frame_visible(self, frame: int, capacity: int | None = None):
+        cap = self.n if capacity is None else capacity
+        idx = np.empty(cap, np.int32)
+        rgb = np.empty((cap, 3), np.uint8)
+        mv = np.empty(cap, np.uint16)
+        cam = np.empty((cap, 3), np.float32)
+        wrd = np.empty((cap, 3), np.float32)
+        cnt = C.c_int64()
+        self._check(self.lib.pcp_frame_visible(self.h, C.c_int32(frame), C.c_int64(cap), _ptr(idx), _ptr(rgb), _ptr(mv),
+                                               _ptr(cam), _ptr(wrd), C.byref(cnt)))
+        m = min(cnt.value, cap)
+        return dict(index=idx[:m], rgb=rgb[:m], mask=mv[:m], xyz_cam=cam[:m], xyz_world=wrd[:m], count=cnt.value)
+
+    # -- whole run --------------------------------------------------------
+    def depth_pass(self, f0: int = 0, f1: int | None = None):
+        self._check(self.lib.pcp_depth_pass(self.h, C.c_int32(f0), C.c_int32(self.n_frames if f1 is None else f1)))
+
+    def depth_maps_device(self):
+        p = C.c_void_p()
+        n = C.c_int64()
+        self._check(self.lib.pcp_depth_maps_device(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def download_depth_map(self, frame: int):
+        mh, mw = self.map_shape
+        d = np.empty(mh * mw, np.float32)
+        self._check(self.lib.pcp_download_depth_map(self.h, C.c_int32(frame), _ptr(d)))
+        return d.reshape(mh, mw)
+
+    def colour_reset(self):
+        self._check(self.lib.pcp_colour_reset(self.h))
+
+    def colour_pass(self, f0: int = 0, f1: int | None = None):
+        self._check(self.lib.pcp_colour_pass(self.h, C.c_int32(f0), C.c_int32(self.n_frames if f1 is None else f1)))
+
+    def colour_finalise(self, want_top: bool = False, download: bool = True):
+        n = self.n
+        rgb = np.empty((n, 3), np.uint8) if download else None
+        has = np.empty(n, np.uint8) if download else None
+        cnt = np.empty(n, np.int32) if want_top else None
+        ts = np.empty((n, 5), np.float32) if want_top else None
+        tr = np.empty((n, 5), np.uint32) if want_top else None
+        tf = np.empty((n, 5), np.int32) if want_top else None
+        self._check(self.lib.pcp_colour_finalise(self.h, _ptr(rgb), _ptr(has), _ptr(cnt), _ptr(ts), _ptr(tr), _ptr(tf)))
+        return dict(rgb=rgb, has=has, count=cnt, top_score=ts, top_rgb=tr, top_frame=tf)
+
+    def colorize(self, download: bool = True):
+        n = self.n
+        rgb = np.empty((n, 3), np.uint8) if download else None
+        has = np.empty(n, np.uint8) if download else None
+        self._check(self.lib.pcp_colorize(self.h, _ptr(rgb), _ptr(has)))
+        return dict(rgb=rgb, has=has)
+
+    def colour_result_device(self):
+        p = C.c_void_p()
+        n = C.c_int64()
+        self._check(self.lib.pcp_colour_result_device(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    # -- MLS --------------------------------------------------------------
+    def mls_process(self, params: MLSParams) -> int:
+        cnt = C.c_int64()
+        self._check(self.lib.pcp_mls_process(self.h, C.byref(params), C.byref(cnt)))
+        return cnt.value
+
+    def mls_fetch(self, count: int):
+        xyz = np.empty((count, 3), np.float32)
+        nrm = np.empty((count, 3), np.float32)
+        curv = np.empty(count, np.float32)
+        idx = np.empty(count, np.int32)
+        self._check(self.lib.pcp_mls_fetch(self.h, C.c_int64(count), _ptr(xyz), _ptr(nrm), _ptr(curv), _ptr(idx)))
+        return dict(xyz=xyz, normal=nrm, curvature=curv, index=idx)
+
+    def sor(self, mean_k: int = 60, std_mul: float = 0.7):
+        keep = np.empty(self.n, np.uint8)
+        kept = C.c_int64()
+        self._check(self.lib.pcp_sor(self.h, C.c_int32(mean_k), C.c_double(std_mul), _ptr(keep), C.byref(kept)))
+        return keep, kept.value
+
+    # -- measurement ------------------------------------------------------
+    def timing_enable(self, on: bool = True):
+        self._check(self.lib.pcp_timing_enable(self.h, C.c_int32(1 if on else 0)))
+
+    def timing_reset(self):
+        self._check(self.lib.pcp_timing_reset(self.h))
+
+    def timing_get(self, kernel_id: int):
+        ms = C.c_double()
+        cnt = C.c_int64()
+        self._check(self.lib.pcp_timing_get(self.h, C.c_int32(kernel_id), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    def kernel_name(self, kernel_id: int) -> str:
+        return self.lib.pcp_kernel_name(C.c_int32(kernel_id)).decode()

@@ -1,0 +1,877 @@
+// pcp_colour.hip -- HIP kernels and C-ABI entry points of the colour path:
+// per-keyframe SE(3) transform, pinhole projection, z-buffer MIN pass,
+// visibility, colour / mask lookup, view scores and the per-point top-5 mean.
+//
+// gfx950 only.  Build with -ffp-contract=off (see pcp_device.hpp).
+//
+// Data layout in HBM
+//   cloud        SoA fp32 x[n] y[n] z[n] (12 B/point), twice: input order for the
+//                per-keyframe calls, Morton order for the batched run
+//   frames       DevFrame[F], 128 B each, read through the scalar cache
+//   images       uint32 per pixel  B | G<<8 | R<<16 | mask<<24  (one gather
+//                fetches colour and segmentation mask)
+//   depth maps   uint32[F][mh*mw], the bit pattern of a positive fp32 range:
+//                unsigned MIN == float MIN, so atomicMin is exactly the
+//                reference's sequential running minimum (view_culling.cpp:117-123)
+//   cand bits    uint32[(F+31)/32][n]: bit f of word (f>>5, j) = point j is a cull
+//                candidate with an in-image colour pixel in keyframe f
+//   top-5 state  SoA score[5][n] rgb[5][n] frame[5][n] count[n]
+#include <algorithm>
+#include <cfloat>
+
+#include "pcp_device.hpp"
+
+namespace pcp {
+
+constexpr int kBlock = 256;
+constexpr uint32_t kFltMaxBits = 0x7f7fffffu;  // FLT_MAX, view_culling.cpp:64
+
+// ---------------------------------------------------------------------------
+// K1: single-keyframe projection (the roofline kernel): 12 B read, 4 B cell +
+// 4 B range written per point (optionally pixel and camera coordinates).
+// 4 points per lane: dwordx4 loads / stores, 1 KiB per wave-instruction.
+// ---------------------------------------------------------------------------
+struct ProjectOut {
+  int32_t *cell;
+  int32_t *pixel;
+  float *range;
+  float *xc, *yc, *zc;
+};
+
+__device__ __forceinline__ void project_store_one(const DevCamera &cam, const DevFrame &fr, float x, float y, float z,
+                                                  int32_t &cell, int32_t &pixel, float &range, float &xc, float &yc,
+                                                  float &zc) {
+  const Projected p = project_point(cam, fr.w2c, x, y, z);
+  cell = p.cell;
+  pixel = p.pixel;
+  range = p.cell != -1 ? static_cast<float>(range64(p.xc, p.yc, p.zc)) : FLT_MAX;
+  xc = p.xc;
+  yc = p.yc;
+  zc = p.zc;
+}
+
+__global__ __launch_bounds__(kBlock) void k_project_frame(const float *__restrict__ x, const float *__restrict__ y,
+                                                          const float *__restrict__ z, int64_t n, DevCamera cam,
+                                                          DevFrame fr, ProjectOut out) {
+  const int64_t q = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;  // quad index
+  const int64_t i0 = q * 4;
+  if (i0 >= n) return;
+  if (i0 + 3 < n) {
+    const float4 vx = *reinterpret_cast<const float4 *>(x + i0);
+    const float4 vy = *reinterpret_cast<const float4 *>(y + i0);
+    const float4 vz = *reinterpret_cast<const float4 *>(z + i0);
+    int4 cell, pixel;
+    float4 range, xc, yc, zc;
+    project_store_one(cam, fr, vx.x, vy.x, vz.x, cell.x, pixel.x, range.x, xc.x, yc.x, zc.x);
+    project_store_one(cam, fr, vx.y, vy.y, vz.y, cell.y, pixel.y, range.y, xc.y, yc.y, zc.y);
+    project_store_one(cam, fr, vx.z, vy.z, vz.z, cell.z, pixel.z, range.z, xc.z, yc.z, zc.z);
+    project_store_one(cam, fr, vx.w, vy.w, vz.w, cell.w, pixel.w, range.w, xc.w, yc.w, zc.w);
+    if (out.cell) *reinterpret_cast<int4 *>(out.cell + i0) = cell;
+    if (out.range) *reinterpret_cast<float4 *>(out.range + i0) = range;
+    if (out.pixel) *reinterpret_cast<int4 *>(out.pixel + i0) = pixel;
+    if (out.xc) {
+      *reinterpret_cast<float4 *>(out.xc + i0) = xc;
+      *reinterpret_cast<float4 *>(out.yc + i0) = yc;
+      *reinterpret_cast<float4 *>(out.zc + i0) = zc;
+    }
+  } else {
+    for (int64_t i = i0; i < n; ++i) {
+      int32_t cell, pixel;
+      float range, xc, yc, zc;
+      project_store_one(cam, fr, x[i], y[i], z[i], cell, pixel, range, xc, yc, zc);
+      if (out.cell) out.cell[i] = cell;
+      if (out.range) out.range[i] = range;
+      if (out.pixel) out.pixel[i] = pixel;
+      if (out.xc) {
+        out.xc[i] = xc;
+        out.yc[i] = yc;
+        out.zc[i] = zc;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K2: z-buffer MIN pass, keyframes [f0, f1), one lane per point, the point
+// stays in registers across the keyframe loop (12 B read per point per pass).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void depth_min(uint32_t *__restrict__ map, int32_t cell, float range) {
+  const uint32_t bits = __float_as_uint(range);
+  // a plain (possibly stale, hence >= current) read filters most atomics
+  if (bits < map[cell]) atomicMin(map + cell, bits);
+}
+
+__global__ __launch_bounds__(kBlock) void k_depth_pass(const float *__restrict__ x, const float *__restrict__ y,
+                                                       const float *__restrict__ z, int64_t n, DevCamera cam,
+                                                       const DevFrame *__restrict__ frames, int32_t f0, int32_t f1,
+                                                       uint32_t *__restrict__ depth, int64_t cells,
+                                                       int32_t depth_first_frame,
+                                                       uint32_t *__restrict__ cand_bits) {
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const bool live = j < n;
+  const float px = live ? x[j] : 0.0f, py = live ? y[j] : 0.0f, pz = live ? z[j] : 0.0f;
+  for (int32_t w = f0 >> 5; w <= (f1 - 1) >> 5; ++w) {
+    const int32_t fb = max(f0, w << 5), fe = min(f1, (w << 5) + 32);
+    uint32_t word = 0u;
+    for (int32_t f = fb; f < fe; ++f) {
+      const DevFrame &fr = frames[f];
+      const Projected p = project_point(cam, fr.w2c, px, py, pz);
+      if (!live) continue;
+      const bool cand = cam.enable_zbuf ? p.cell >= 0 : p.cell != -1;
+      if (cam.enable_zbuf && p.cell >= 0)
+        depth_min(depth + static_cast<int64_t>(f - depth_first_frame) * cells, p.cell,
+                  static_cast<float>(range64(p.xc, p.yc, p.zc)));
+      if (cand && p.pixel >= 0) word |= 1u << (f & 31);
+    }
+    if (cand_bits && live) {
+      uint32_t *dst = cand_bits + static_cast<int64_t>(w) * n + j;
+      const int32_t nb = fe - fb;
+      if (nb == 32) {
+        *dst = word;
+      } else {
+        const uint32_t mask = ((nb >= 32) ? 0xffffffffu : ((1u << nb) - 1u)) << (fb & 31);
+        *dst = (*dst & ~mask) | word;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K3: single-keyframe keep mask (pass 2 of view_culling, input order).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_visibility(const float *__restrict__ x, const float *__restrict__ y,
+                                                       const float *__restrict__ z, int64_t n, DevCamera cam,
+                                                       DevFrame fr, const uint32_t *__restrict__ depth,
+                                                       uint8_t *__restrict__ keep, int32_t require_pixel) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const Projected p = project_point(cam, fr.w2c, x[i], y[i], z[i]);
+  bool k = keep_rule(cam, p, depth);
+  if (require_pixel) k = k && p.pixel >= 0;
+  keep[i] = k ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------
+// K4: visibility + colour + scores + top-5 over keyframes [f0, f1).
+// flags: bit0 load state, bit1 store state, bit2 write packed result.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v |= __shfl_xor(v, o, 64);
+  return v;
+}
+
+struct TopState {
+  float *score;
+  uint32_t *rgb;
+  int32_t *frame;
+  int32_t *count;
+};
+
+__global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict__ x, const float *__restrict__ y,
+                                                        const float *__restrict__ z, int64_t n, DevCamera cam,
+                                                        const DevFrame *__restrict__ frames, int32_t f0, int32_t f1,
+                                                        const uint32_t *__restrict__ depth, int64_t cells,
+                                                        const uint32_t *__restrict__ cand_bits,
+                                                        const uint32_t *__restrict__ images, int64_t image_px,
+                                                        TopState st, uint32_t *__restrict__ rgba, int32_t flags) {
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const bool live = j < n;
+  const float px = live ? x[j] : 0.0f, py = live ? y[j] : 0.0f, pz = live ? z[j] : 0.0f;
+  Top5 t;
+  t.init();
+  if ((flags & 1) && live) {
+    t.s0 = st.score[0 * n + j]; t.s1 = st.score[1 * n + j]; t.s2 = st.score[2 * n + j];
+    t.s3 = st.score[3 * n + j]; t.s4 = st.score[4 * n + j];
+    t.c0 = st.rgb[0 * n + j]; t.c1 = st.rgb[1 * n + j]; t.c2 = st.rgb[2 * n + j];
+    t.c3 = st.rgb[3 * n + j]; t.c4 = st.rgb[4 * n + j];
+    t.f0 = st.frame[0 * n + j]; t.f1 = st.frame[1 * n + j]; t.f2 = st.frame[2 * n + j];
+    t.f3 = st.frame[3 * n + j]; t.f4 = st.frame[4 * n + j];
+    t.count = st.count[j];
+  }
+  for (int32_t w = f0 >> 5; w <= (f1 - 1) >> 5; ++w) {
+    const int32_t fb = max(f0, w << 5), fe = min(f1, (w << 5) + 32);
+    const int32_t nb = fe - fb;
+    const uint32_t mask = ((nb >= 32) ? 0xffffffffu : ((1u << nb) - 1u)) << (fb & 31);
+    const uint32_t word = live ? (cand_bits[static_cast<int64_t>(w) * n + j] & mask) : 0u;
+    // keyframes any lane of this wave needs, as a wave-uniform scalar
+    uint32_t todo = __builtin_amdgcn_readfirstlane(wave_or(word));
+    while (todo) {
+      const int32_t b = __builtin_ctz(todo);
+      todo &= todo - 1u;
+      const int32_t f = (w << 5) + b;
+      if ((word >> b) & 1u) {
+        const DevFrame &fr = frames[f];
+        const Projected p = project_point(cam, fr.w2c, px, py, pz);
+        if (p.pixel >= 0 && keep_rule(cam, p, depth + static_cast<int64_t>(f) * cells)) {
+          const uint32_t texel = images[static_cast<int64_t>(f) * image_px + p.pixel];  // B | G<<8 | R<<16
+          // 0x00RRGGBB == R<<16 | G<<8 | B: the texel's low 24 bits (PointCloudProcessor.cpp:760-762)
+          const float s = final_score(p.xc, p.yc, p.zc, fr.px, fr.py, fr.pz);
+          t.insert(s, texel & 0xffffffu, f);
+        }
+      }
+    }
+  }
+  if (!live) return;
+  if (flags & 2) {
+    st.score[0 * n + j] = t.s0; st.score[1 * n + j] = t.s1; st.score[2 * n + j] = t.s2;
+    st.score[3 * n + j] = t.s3; st.score[4 * n + j] = t.s4;
+    st.rgb[0 * n + j] = t.c0; st.rgb[1 * n + j] = t.c1; st.rgb[2 * n + j] = t.c2;
+    st.rgb[3 * n + j] = t.c3; st.rgb[4 * n + j] = t.c4;
+    st.frame[0 * n + j] = t.f0; st.frame[1 * n + j] = t.f1; st.frame[2 * n + j] = t.f2;
+    st.frame[3 * n + j] = t.f3; st.frame[4 * n + j] = t.f4;
+    st.count[j] = t.count;
+  }
+  if (flags & 4) rgba[j] = t.finalise();
+}
+
+// finalise from stored state (multi-batch runs)
+__global__ __launch_bounds__(kBlock) void k_finalise(int64_t n, TopState st, uint32_t *__restrict__ rgba) {
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (j >= n) return;
+  Top5 t;
+  t.s0 = st.score[0 * n + j]; t.s1 = st.score[1 * n + j]; t.s2 = st.score[2 * n + j];
+  t.s3 = st.score[3 * n + j]; t.s4 = st.score[4 * n + j];
+  t.c0 = st.rgb[0 * n + j]; t.c1 = st.rgb[1 * n + j]; t.c2 = st.rgb[2 * n + j];
+  t.c3 = st.rgb[3 * n + j]; t.c4 = st.rgb[4 * n + j];
+  t.f0 = st.frame[0 * n + j]; t.f1 = st.frame[1 * n + j]; t.f2 = st.frame[2 * n + j];
+  t.f3 = st.frame[3 * n + j]; t.f4 = st.frame[4 * n + j];
+  t.count = st.count[j];
+  rgba[j] = t.finalise();
+}
+
+// ---------------------------------------------------------------------------
+// small utility kernels
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_fill_u32(uint32_t *__restrict__ p, int64_t n, uint32_t v) {
+  int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+// out[perm[j]] = in[j]
+__global__ __launch_bounds__(kBlock) void k_scatter_u32(const uint32_t *__restrict__ in,
+                                                        const int32_t *__restrict__ perm, int64_t n,
+                                                        uint32_t *__restrict__ out) {
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (j < n) out[perm[j]] = in[j];
+}
+
+// BGR8 rows -> packed texels, keeping the mask byte
+__global__ __launch_bounds__(kBlock) void k_pack_bgr(const uint8_t *__restrict__ bgr, int64_t row_stride, int32_t w,
+                                                     int32_t h, uint32_t *__restrict__ texels, int32_t clear_mask) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= static_cast<int64_t>(w) * h) return;
+  const int32_t v = static_cast<int32_t>(i / w), u = static_cast<int32_t>(i - static_cast<int64_t>(v) * w);
+  const uint8_t *p = bgr + static_cast<int64_t>(v) * row_stride + 3 * u;
+  const uint32_t keep = clear_mask ? 0u : (texels[i] & 0xff000000u);
+  texels[i] = keep | p[0] | (static_cast<uint32_t>(p[1]) << 8) | (static_cast<uint32_t>(p[2]) << 16);
+}
+
+__global__ __launch_bounds__(kBlock) void k_pack_mask(const uint8_t *__restrict__ gray, int64_t row_stride, int32_t w,
+                                                      int32_t h, uint32_t *__restrict__ texels) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= static_cast<int64_t>(w) * h) return;
+  const int32_t v = static_cast<int32_t>(i / w), u = static_cast<int32_t>(i - static_cast<int64_t>(v) * w);
+  texels[i] = (texels[i] & 0x00ffffffu) | (static_cast<uint32_t>(gray[static_cast<int64_t>(v) * row_stride + u]) << 24);
+}
+
+// ---- ordered compaction of a byte flag array (tile = 1024 flags) -------------
+constexpr int kTile = 1024;
+
+__device__ __forceinline__ int32_t block_exclusive_scan(int32_t v, int32_t *total) {
+  __shared__ int32_t wave_sum[kBlock / 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int32_t incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int32_t t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wave_sum[wid] = incl;
+  __syncthreads();
+  int32_t base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < kBlock / 64; ++k) {
+    if (k < wid) base += wave_sum[k];
+    tot += wave_sum[k];
+  }
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_tile_count(const uint8_t *__restrict__ flags, int64_t n,
+                                                       int32_t *__restrict__ tile_count) {
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kTile + threadIdx.x * 4;
+  int32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (base + k < n) c += flags[base + k] ? 1 : 0;
+  int32_t total;
+  (void)block_exclusive_scan(c, &total);
+  if (threadIdx.x == 0) tile_count[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of tile counts in place, grand total to *total
+__global__ __launch_bounds__(kBlock) void k_scan_tiles(int32_t *__restrict__ tile_count, int64_t tiles,
+                                                       unsigned long long *__restrict__ total) {
+  __shared__ int64_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < tiles; base += kBlock) {
+    const int64_t i = base + threadIdx.x;
+    const int32_t v = i < tiles ? tile_count[i] : 0;
+    int32_t tot;
+    const int32_t ex = block_exclusive_scan(v, &tot);
+    const int64_t c = carry;
+    if (i < tiles) tile_count[i] = static_cast<int32_t>(c + ex);
+    __syncthreads();
+    if (threadIdx.x == 0) carry = c + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = static_cast<unsigned long long>(carry);
+}
+
+__global__ __launch_bounds__(kBlock) void k_tile_scatter(const uint8_t *__restrict__ flags, int64_t n,
+                                                         const int32_t *__restrict__ tile_offset,
+                                                         int32_t *__restrict__ out_index, int64_t capacity) {
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kTile + threadIdx.x * 4;
+  int32_t c = 0;
+  bool fl[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    fl[k] = base + k < n && flags[base + k];
+    c += fl[k] ? 1 : 0;
+  }
+  int32_t total;
+  int64_t pos = tile_offset[blockIdx.x] + block_exclusive_scan(c, &total);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (fl[k]) {
+      if (pos < capacity) out_index[pos] = static_cast<int32_t>(base + k);
+      ++pos;
+    }
+}
+
+// records of the visible points of one keyframe, by compacted index list
+__global__ __launch_bounds__(kBlock) void k_gather_visible(const float *__restrict__ x, const float *__restrict__ y,
+                                                           const float *__restrict__ z, DevCamera cam, DevFrame fr,
+                                                           const int32_t *__restrict__ index, int64_t m,
+                                                           const uint32_t *__restrict__ image, int32_t has_image,
+                                                           int32_t has_mask, uint32_t *__restrict__ out_rgbm,
+                                                           float *__restrict__ out_cam, float *__restrict__ out_world) {
+  const int64_t k = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (k >= m) return;
+  const int32_t i = index[k];
+  const Projected p = project_point(cam, fr.w2c, x[i], y[i], z[i]);
+  uint32_t r = 0, g = 0, b = 0, mv = 0;
+  if (p.pixel >= 0) {
+    const uint32_t texel = image[p.pixel];
+    if (has_image) {
+      b = texel & 0xffu;
+      g = (texel >> 8) & 0xffu;
+      r = (texel >> 16) & 0xffu;
+    }
+    if (has_mask) {
+      mv = texel >> 24;  // generateSegmentMap, PointCloudProcessor.cpp:803-810
+      if (mv == 255u) {
+        r = 255u;
+        g = 0u;
+        b = 0u;
+      }
+    }
+  }
+  out_rgbm[k] = r | (g << 8) | (b << 16) | (mv << 24);
+  if (out_cam) {
+    out_cam[3 * k + 0] = p.xc;
+    out_cam[3 * k + 1] = p.yc;
+    out_cam[3 * k + 2] = p.zc;
+  }
+  if (out_world) {  // transformPointCloud(c2w), PointCloudProcessor.cpp:549,555
+    float wx, wy, wz;
+    xform(fr.c2w, p.xc, p.yc, p.zc, wx, wy, wz);
+    out_world[3 * k + 0] = wx;
+    out_world[3 * k + 1] = wy;
+    out_world[3 * k + 2] = wz;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host helpers
+// ---------------------------------------------------------------------------
+static inline int64_t cells_of(const pcp_context *ctx) { return static_cast<int64_t>(ctx->dcam.mw) * ctx->dcam.mh; }
+static inline size_t plane_of(const pcp_context *ctx) { return (static_cast<size_t>(ctx->n) + 3) & ~size_t(3); }
+static inline uint32_t blocks_for(int64_t n) { return static_cast<uint32_t>(std::max<int64_t>(1, div_up(n, kBlock))); }
+
+static int check_ready(pcp_context *ctx, const char *who, bool need_frames) {
+  if (!ctx) return PCP_ERR_INVALID;
+  if (!ctx->have_camera) return set_error(ctx, PCP_ERR_STATE, "%s: pcp_set_camera has not been called", who);
+  if (ctx->xyz.p == nullptr && ctx->n == 0 && ctx->xyz.count == 0)
+    return set_error(ctx, PCP_ERR_STATE, "%s: no cloud uploaded", who);
+  if (need_frames && ctx->n_frames <= 0) return set_error(ctx, PCP_ERR_STATE, "%s: pcp_set_frames has not been called", who);
+  hipError_t e = hipSetDevice(ctx->device);
+  if (e != hipSuccess) return set_error(ctx, PCP_ERR_DEVICE, "%s: hipSetDevice failed: %s", who, hipGetErrorString(e));
+  return PCP_OK;
+}
+
+static int check_frame(pcp_context *ctx, const char *who, int32_t frame) {
+  if (frame < 0 || frame >= ctx->n_frames)
+    return set_error(ctx, PCP_ERR_RANGE, "%s: keyframe %d out of range (0..%d)", who, frame, ctx->n_frames - 1);
+  return PCP_OK;
+}
+
+static int fill_u32(pcp_context *ctx, uint32_t *p, int64_t n, uint32_t v) {
+  if (n <= 0) return PCP_OK;
+  LaunchTimer t(ctx, PCP_K_MISC);
+  const uint32_t grid = static_cast<uint32_t>(std::min<int64_t>(div_up(n, kBlock), 8192));
+  hipLaunchKernelGGL(k_fill_u32, dim3(grid), dim3(kBlock), 0, ctx->stream, p, n, v);
+  PCP_HIP_TRY(ctx, hipGetLastError());
+  return PCP_OK;
+}
+
+static int ensure_images(pcp_context *ctx) {
+  const size_t px = static_cast<size_t>(ctx->dcam.img_w) * ctx->dcam.img_h;
+  const size_t need = px * static_cast<size_t>(ctx->n_frames) + 4;
+  if (ctx->images.count < need) {
+    PCP_HIP_TRY(ctx, ctx->images.ensure(need));
+    PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->images.p, 0, need * 4, ctx->stream));
+    ctx->image_set.assign(static_cast<size_t>(ctx->n_frames), 0);
+    ctx->mask_set.assign(static_cast<size_t>(ctx->n_frames), 0);
+  }
+  return PCP_OK;
+}
+
+static int ensure_depth(pcp_context *ctx) {
+  const size_t need = static_cast<size_t>(cells_of(ctx)) * ctx->n_frames + 4;
+  if (ctx->depth.count < need) {
+    PCP_HIP_TRY(ctx, ctx->depth.ensure(need));
+    std::fill(ctx->depth_valid.begin(), ctx->depth_valid.end(), uint8_t(0));
+  }
+  const size_t words = static_cast<size_t>((ctx->n_frames + 31) / 32) * static_cast<size_t>(ctx->n) + 4;
+  if (ctx->cand_bits.count < words) {
+    PCP_HIP_TRY(ctx, ctx->cand_bits.ensure(words));
+    PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->cand_bits.p, 0, words * 4, ctx->stream));
+    std::fill(ctx->depth_valid.begin(), ctx->depth_valid.end(), uint8_t(0));
+  }
+  return PCP_OK;
+}
+
+static int ensure_state(pcp_context *ctx) {
+  const size_t sn = static_cast<size_t>(ctx->n);
+  PCP_HIP_TRY(ctx, ctx->top_score.ensure(kTopM * sn + 4));
+  PCP_HIP_TRY(ctx, ctx->top_rgb.ensure(kTopM * sn + 4));
+  PCP_HIP_TRY(ctx, ctx->top_frame.ensure(kTopM * sn + 4));
+  PCP_HIP_TRY(ctx, ctx->view_count.ensure(sn + 4));
+  PCP_HIP_TRY(ctx, ctx->rgba_sorted.ensure(sn + 4));
+  PCP_HIP_TRY(ctx, ctx->rgba.ensure(sn + 4));
+  return PCP_OK;
+}
+
+// ordered compaction of ctx->s_keep[0..n) into ctx->s_cell (index list); returns count
+static int compact_flags(pcp_context *ctx, int64_t n, int64_t capacity, bool want_indices, int64_t *count) {
+  const int64_t tiles = std::max<int64_t>(1, div_up(n, kTile));
+  PCP_HIP_TRY(ctx, ctx->s_pixel.ensure(static_cast<size_t>(tiles) + 4));  // tile counts / offsets
+  PCP_HIP_TRY(ctx, ctx->s_counter.ensure(4));
+  {
+    LaunchTimer t(ctx, PCP_K_MISC);
+    hipLaunchKernelGGL(k_tile_count, dim3(static_cast<uint32_t>(tiles)), dim3(kBlock), 0, ctx->stream, ctx->s_keep.p, n,
+                       ctx->s_pixel.p);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->s_pixel.p, tiles, ctx->s_counter.p);
+    if (want_indices)
+      hipLaunchKernelGGL(k_tile_scatter, dim3(static_cast<uint32_t>(tiles)), dim3(kBlock), 0, ctx->stream,
+                         ctx->s_keep.p, n, ctx->s_pixel.p, ctx->s_cell.p, capacity);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  unsigned long long total = 0;
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->s_counter.p, sizeof(total), hipMemcpyDeviceToHost, ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  *count = static_cast<int64_t>(total);
+  return PCP_OK;
+}
+
+// depth map of one keyframe from the input-order cloud into ctx->s_u32 (scratch)
+static int single_frame_depth(pcp_context *ctx, int32_t frame) {
+  const int64_t cells = cells_of(ctx);
+  PCP_HIP_TRY(ctx, ctx->s_u32.ensure(static_cast<size_t>(cells) + 4));
+  int rc = fill_u32(ctx, ctx->s_u32.p, cells, kFltMaxBits);
+  if (rc != PCP_OK) return rc;
+  if (ctx->n > 0 && ctx->dcam.enable_zbuf) {
+    const size_t plane = plane_of(ctx);
+    LaunchTimer t(ctx, PCP_K_DEPTH);
+    hipLaunchKernelGGL(k_depth_pass, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, ctx->xyz.p,
+                       ctx->xyz.p + plane, ctx->xyz.p + 2 * plane, ctx->n, ctx->dcam, ctx->frames.p, frame, frame + 1,
+                       ctx->s_u32.p, cells, frame, static_cast<uint32_t *>(nullptr));
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  return PCP_OK;
+}
+
+}  // namespace pcp
+
+using namespace pcp;
+
+extern "C" {
+
+int pcp_upload_image(pcp_context *ctx, int32_t frame, const uint8_t *bgr, int64_t row_stride_bytes) {
+  int rc = check_ready(ctx, "pcp_upload_image", true);
+  if (rc != PCP_OK) return rc;
+  if ((rc = check_frame(ctx, "pcp_upload_image", frame)) != PCP_OK) return rc;
+  const int32_t w = ctx->dcam.img_w, h = ctx->dcam.img_h;
+  if (!bgr || row_stride_bytes < 3 * static_cast<int64_t>(w))
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_upload_image: NULL image or row stride < 3*width");
+  if ((rc = ensure_images(ctx)) != PCP_OK) return rc;
+  const size_t bytes = static_cast<size_t>(row_stride_bytes) * h;
+  PCP_HIP_TRY(ctx, ctx->s_keep.ensure(bytes + 16));
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->s_keep.p, bgr, bytes, hipMemcpyHostToDevice, ctx->stream));
+  const int64_t px = static_cast<int64_t>(w) * h;
+  {
+    LaunchTimer t(ctx, PCP_K_MISC);
+    hipLaunchKernelGGL(k_pack_bgr, dim3(blocks_for(px)), dim3(kBlock), 0, ctx->stream, ctx->s_keep.p, row_stride_bytes,
+                       w, h, ctx->images.p + static_cast<int64_t>(frame) * px, ctx->mask_set[frame] ? 0 : 1);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the host buffer may be reused by the caller
+  ctx->image_set[static_cast<size_t>(frame)] = 1;
+  return PCP_OK;
+}
+
+int pcp_upload_mask(pcp_context *ctx, int32_t frame, const uint8_t *gray, int64_t row_stride_bytes) {
+  int rc = check_ready(ctx, "pcp_upload_mask", true);
+  if (rc != PCP_OK) return rc;
+  if ((rc = check_frame(ctx, "pcp_upload_mask", frame)) != PCP_OK) return rc;
+  const int32_t w = ctx->dcam.img_w, h = ctx->dcam.img_h;
+  if (!gray || row_stride_bytes < static_cast<int64_t>(w))
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_upload_mask: NULL mask or row stride < width");
+  if ((rc = ensure_images(ctx)) != PCP_OK) return rc;
+  const size_t bytes = static_cast<size_t>(row_stride_bytes) * h;
+  PCP_HIP_TRY(ctx, ctx->s_keep.ensure(bytes + 16));
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->s_keep.p, gray, bytes, hipMemcpyHostToDevice, ctx->stream));
+  const int64_t px = static_cast<int64_t>(w) * h;
+  {
+    LaunchTimer t(ctx, PCP_K_MISC);
+    hipLaunchKernelGGL(k_pack_mask, dim3(blocks_for(px)), dim3(kBlock), 0, ctx->stream, ctx->s_keep.p,
+                       row_stride_bytes, w, h, ctx->images.p + static_cast<int64_t>(frame) * px);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->mask_set[static_cast<size_t>(frame)] = 1;
+  return PCP_OK;
+}
+
+int pcp_project_frame(pcp_context *ctx, int32_t frame, int32_t *out_cell, int32_t *out_pixel, float *out_range,
+                      float *out_xyz_cam) {
+  int rc = check_ready(ctx, "pcp_project_frame", true);
+  if (rc != PCP_OK) return rc;
+  if ((rc = check_frame(ctx, "pcp_project_frame", frame)) != PCP_OK) return rc;
+  const int64_t n = ctx->n;
+  const size_t plane = plane_of(ctx);
+  PCP_HIP_TRY(ctx, ctx->s_cell.ensure(plane + 4));
+  PCP_HIP_TRY(ctx, ctx->s_range.ensure(plane + 4));
+  if (out_pixel) PCP_HIP_TRY(ctx, ctx->s_pixel.ensure(plane + 4));
+  if (out_xyz_cam) PCP_HIP_TRY(ctx, ctx->s_cam.ensure(3 * plane + 4));
+  if (n == 0) return PCP_OK;
+  ProjectOut o{};
+  o.cell = ctx->s_cell.p;
+  o.range = ctx->s_range.p;
+  o.pixel = out_pixel ? ctx->s_pixel.p : nullptr;
+  o.xc = out_xyz_cam ? ctx->s_cam.p : nullptr;
+  o.yc = out_xyz_cam ? ctx->s_cam.p + plane : nullptr;
+  o.zc = out_xyz_cam ? ctx->s_cam.p + 2 * plane : nullptr;
+  {
+    LaunchTimer t(ctx, PCP_K_PROJECT);
+    hipLaunchKernelGGL(k_project_frame, dim3(blocks_for(div_up(n, 4))), dim3(kBlock), 0, ctx->stream, ctx->xyz.p,
+                       ctx->xyz.p + plane, ctx->xyz.p + 2 * plane, n, ctx->dcam,
+                       ctx->hframes[static_cast<size_t>(frame)], o);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  const size_t sn = static_cast<size_t>(n);
+  if (out_cell) PCP_HIP_TRY(ctx, hipMemcpyAsync(out_cell, o.cell, sn * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_range) PCP_HIP_TRY(ctx, hipMemcpyAsync(out_range, o.range, sn * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_pixel) PCP_HIP_TRY(ctx, hipMemcpyAsync(out_pixel, o.pixel, sn * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_xyz_cam) {
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(out_xyz_cam, o.xc, sn * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(out_xyz_cam + sn, o.yc, sn * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(out_xyz_cam + 2 * sn, o.zc, sn * 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (out_cell || out_range || out_pixel || out_xyz_cam) PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PCP_OK;
+}
+
+int pcp_cull_frame(pcp_context *ctx, int32_t frame, uint8_t *out_keep, int64_t *out_kept, float *out_depth_map) {
+  int rc = check_ready(ctx, "pcp_cull_frame", true);
+  if (rc != PCP_OK) return rc;
+  if ((rc = check_frame(ctx, "pcp_cull_frame", frame)) != PCP_OK) return rc;
+  const int64_t n = ctx->n;
+  if ((rc = single_frame_depth(ctx, frame)) != PCP_OK) return rc;
+  PCP_HIP_TRY(ctx, ctx->s_keep.ensure(static_cast<size_t>(n) + 16));
+  if (n > 0) {
+    const size_t plane = plane_of(ctx);
+    LaunchTimer t(ctx, PCP_K_VISIBILITY);
+    hipLaunchKernelGGL(k_visibility, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, ctx->xyz.p, ctx->xyz.p + plane,
+                       ctx->xyz.p + 2 * plane, n, ctx->dcam, ctx->hframes[static_cast<size_t>(frame)], ctx->s_u32.p,
+                       ctx->s_keep.p, 0);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  if (out_kept) {
+    int64_t cnt = 0;
+    if (n > 0 && (rc = compact_flags(ctx, n, 0, false, &cnt)) != PCP_OK) return rc;
+    *out_kept = cnt;
+  }
+  if (out_keep && n > 0)
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(out_keep, ctx->s_keep.p, static_cast<size_t>(n), hipMemcpyDeviceToHost, ctx->stream));
+  if (out_depth_map)
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(out_depth_map, ctx->s_u32.p, static_cast<size_t>(cells_of(ctx)) * 4,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PCP_OK;
+}
+
+int pcp_frame_visible(pcp_context *ctx, int32_t frame, int64_t capacity, int32_t *out_index, uint8_t *out_rgb,
+                      uint16_t *out_mask, float *out_xyz_cam, float *out_xyz_world, int64_t *out_count) {
+  int rc = check_ready(ctx, "pcp_frame_visible", true);
+  if (rc != PCP_OK) return rc;
+  if ((rc = check_frame(ctx, "pcp_frame_visible", frame)) != PCP_OK) return rc;
+  if (capacity < 0) return set_error(ctx, PCP_ERR_INVALID, "pcp_frame_visible: negative capacity");
+  const int64_t n = ctx->n;
+  if (out_count) *out_count = 0;
+  if (n == 0) return PCP_OK;
+  if ((rc = ensure_images(ctx)) != PCP_OK) return rc;
+  if ((rc = single_frame_depth(ctx, frame)) != PCP_OK) return rc;
+  const size_t plane = plane_of(ctx);
+  PCP_HIP_TRY(ctx, ctx->s_keep.ensure(static_cast<size_t>(n) + 16));
+  PCP_HIP_TRY(ctx, ctx->s_cell.ensure(plane + 4));
+  {
+    LaunchTimer t(ctx, PCP_K_VISIBILITY);
+    hipLaunchKernelGGL(k_visibility, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, ctx->xyz.p, ctx->xyz.p + plane,
+                       ctx->xyz.p + 2 * plane, n, ctx->dcam, ctx->hframes[static_cast<size_t>(frame)], ctx->s_u32.p,
+                       ctx->s_keep.p, 1);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  int64_t m = 0;
+  if ((rc = compact_flags(ctx, n, static_cast<int64_t>(plane), true, &m)) != PCP_OK) return rc;
+  if (out_count) *out_count = m;
+  const int64_t take = std::min(m, capacity);
+  if (take == 0) return PCP_OK;
+  const size_t st = static_cast<size_t>(take);
+  PCP_HIP_TRY(ctx, ctx->s_range.ensure(st + 4));  // packed rgbm as raw words
+  const bool want_cam = out_xyz_cam != nullptr, want_world = out_xyz_world != nullptr;
+  PCP_HIP_TRY(ctx, ctx->s_cam.ensure((want_cam ? 3 * st : 0) + (want_world ? 3 * st : 0) + 4));
+  float *d_cam = want_cam ? ctx->s_cam.p : nullptr;
+  float *d_world = want_world ? ctx->s_cam.p + (want_cam ? 3 * st : 0) : nullptr;
+  const int64_t px = static_cast<int64_t>(ctx->dcam.img_w) * ctx->dcam.img_h;
+  {
+    LaunchTimer t(ctx, PCP_K_MISC);
+    hipLaunchKernelGGL(k_gather_visible, dim3(blocks_for(take)), dim3(kBlock), 0, ctx->stream, ctx->xyz.p,
+                       ctx->xyz.p + plane, ctx->xyz.p + 2 * plane, ctx->dcam, ctx->hframes[static_cast<size_t>(frame)],
+                       ctx->s_cell.p, take, ctx->images.p + static_cast<int64_t>(frame) * px,
+                       static_cast<int32_t>(ctx->image_set[static_cast<size_t>(frame)]),
+                       static_cast<int32_t>(ctx->mask_set[static_cast<size_t>(frame)]),
+                       reinterpret_cast<uint32_t *>(ctx->s_range.p), d_cam, d_world);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  std::vector<uint32_t> rgbm;
+  if (out_rgb || out_mask) {
+    rgbm.resize(st);
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(rgbm.data(), ctx->s_range.p, st * 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (out_index) PCP_HIP_TRY(ctx, hipMemcpyAsync(out_index, ctx->s_cell.p, st * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (want_cam) PCP_HIP_TRY(ctx, hipMemcpyAsync(out_xyz_cam, d_cam, 3 * st * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (want_world) PCP_HIP_TRY(ctx, hipMemcpyAsync(out_xyz_world, d_world, 3 * st * 4, hipMemcpyDeviceToHost, ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t k = 0; k < rgbm.size(); ++k) {
+    if (out_rgb) {
+      out_rgb[3 * k + 0] = static_cast<uint8_t>(rgbm[k] & 0xffu);
+      out_rgb[3 * k + 1] = static_cast<uint8_t>((rgbm[k] >> 8) & 0xffu);
+      out_rgb[3 * k + 2] = static_cast<uint8_t>((rgbm[k] >> 16) & 0xffu);
+    }
+    if (out_mask) out_mask[k] = static_cast<uint16_t>(rgbm[k] >> 24);
+  }
+  return PCP_OK;
+}
+
+int pcp_depth_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
+  int rc = check_ready(ctx, "pcp_depth_pass", true);
+  if (rc != PCP_OK) return rc;
+  if (frame_begin < 0 || frame_end > ctx->n_frames || frame_begin > frame_end)
+    return set_error(ctx, PCP_ERR_RANGE, "pcp_depth_pass: keyframe range [%d,%d) outside 0..%d", frame_begin, frame_end,
+                     ctx->n_frames);
+  if (frame_begin == frame_end) return PCP_OK;
+  if ((rc = ensure_depth(ctx)) != PCP_OK) return rc;
+  const int64_t cells = cells_of(ctx);
+  if ((rc = fill_u32(ctx, ctx->depth.p + static_cast<int64_t>(frame_begin) * cells,
+                     static_cast<int64_t>(frame_end - frame_begin) * cells, kFltMaxBits)) != PCP_OK)
+    return rc;
+  if (ctx->n > 0) {
+    const size_t plane = plane_of(ctx);
+    LaunchTimer t(ctx, PCP_K_DEPTH);
+    hipLaunchKernelGGL(k_depth_pass, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
+                       ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, ctx->n, ctx->dcam, ctx->frames.p, frame_begin,
+                       frame_end, ctx->depth.p, cells, 0, ctx->cand_bits.p);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  for (int32_t f = frame_begin; f < frame_end; ++f) ctx->depth_valid[static_cast<size_t>(f)] = 1;
+  return PCP_OK;
+}
+
+int pcp_depth_maps_device(pcp_context *ctx, void **device_ptr, int64_t *n_floats) {
+  int rc = check_ready(ctx, "pcp_depth_maps_device", true);
+  if (rc != PCP_OK) return rc;
+  if ((rc = ensure_depth(ctx)) != PCP_OK) return rc;
+  if (device_ptr) *device_ptr = ctx->depth.p;
+  if (n_floats) *n_floats = cells_of(ctx) * ctx->n_frames;
+  return PCP_OK;
+}
+
+int pcp_download_depth_map(pcp_context *ctx, int32_t frame, float *out_depth_map) {
+  int rc = check_ready(ctx, "pcp_download_depth_map", true);
+  if (rc != PCP_OK) return rc;
+  if ((rc = check_frame(ctx, "pcp_download_depth_map", frame)) != PCP_OK) return rc;
+  if (!out_depth_map) return set_error(ctx, PCP_ERR_INVALID, "pcp_download_depth_map: NULL output");
+  if (!ctx->depth.p || !ctx->depth_valid[static_cast<size_t>(frame)])
+    return set_error(ctx, PCP_ERR_STATE, "pcp_download_depth_map: pcp_depth_pass has not covered keyframe %d", frame);
+  const int64_t cells = cells_of(ctx);
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(out_depth_map, ctx->depth.p + static_cast<int64_t>(frame) * cells,
+                                  static_cast<size_t>(cells) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PCP_OK;
+}
+
+int pcp_colour_reset(pcp_context *ctx) {
+  if (!ctx) return PCP_ERR_INVALID;
+  ctx->colour_state_live = false;
+  ctx->colour_result_live = false;
+  return PCP_OK;
+}
+
+static int colour_pass_impl(pcp_context *ctx, int32_t frame_begin, int32_t frame_end, bool one_shot) {
+  int rc = check_ready(ctx, "pcp_colour_pass", true);
+  if (rc != PCP_OK) return rc;
+  if (frame_begin < 0 || frame_end > ctx->n_frames || frame_begin > frame_end)
+    return set_error(ctx, PCP_ERR_RANGE, "pcp_colour_pass: keyframe range [%d,%d) outside 0..%d", frame_begin, frame_end,
+                     ctx->n_frames);
+  for (int32_t f = frame_begin; f < frame_end; ++f) {
+    if (!ctx->depth.p || !ctx->depth_valid[static_cast<size_t>(f)])
+      return set_error(ctx, PCP_ERR_STATE, "pcp_colour_pass: pcp_depth_pass has not covered keyframe %d", f);
+    if (!ctx->images.p || !ctx->image_set[static_cast<size_t>(f)])
+      return set_error(ctx, PCP_ERR_STATE, "pcp_colour_pass: no image uploaded for keyframe %d", f);
+  }
+  if ((rc = ensure_state(ctx)) != PCP_OK) return rc;
+  if (ctx->n == 0 || frame_begin == frame_end) {
+    return PCP_OK;
+  }
+  const size_t plane = plane_of(ctx);
+  TopState st{ctx->top_score.p, ctx->top_rgb.p, ctx->top_frame.p, ctx->view_count.p};
+  int32_t flags = 0;
+  if (ctx->colour_state_live) flags |= 1;
+  if (one_shot)
+    flags |= 4;
+  else
+    flags |= 2;
+  {
+    LaunchTimer t(ctx, PCP_K_COLOUR);
+    hipLaunchKernelGGL(k_colour_pass, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
+                       ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, ctx->n, ctx->dcam, ctx->frames.p, frame_begin,
+                       frame_end, ctx->depth.p, cells_of(ctx), ctx->cand_bits.p, ctx->images.p,
+                       static_cast<int64_t>(ctx->dcam.img_w) * ctx->dcam.img_h, st, ctx->rgba_sorted.p, flags);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  if (!one_shot) ctx->colour_state_live = true;
+  return PCP_OK;
+}
+
+int pcp_colour_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
+  return colour_pass_impl(ctx, frame_begin, frame_end, false);
+}
+
+static int publish_result(pcp_context *ctx, uint8_t *out_rgb, uint8_t *out_has) {
+  const int64_t n = ctx->n;
+  if (n > 0) {
+    LaunchTimer t(ctx, PCP_K_MISC);
+    hipLaunchKernelGGL(k_scatter_u32, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, ctx->rgba_sorted.p, ctx->perm.p,
+                       n, ctx->rgba.p);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  ctx->colour_result_live = true;
+  if ((out_rgb || out_has) && n > 0) {
+    std::vector<uint32_t> h(static_cast<size_t>(n));
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(h.data(), ctx->rgba.p, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < n; ++i) {
+      const uint32_t v = h[static_cast<size_t>(i)];
+      if (out_rgb) {
+        out_rgb[3 * i + 0] = static_cast<uint8_t>(v & 0xffu);
+        out_rgb[3 * i + 1] = static_cast<uint8_t>((v >> 8) & 0xffu);
+        out_rgb[3 * i + 2] = static_cast<uint8_t>((v >> 16) & 0xffu);
+      }
+      if (out_has) out_has[i] = static_cast<uint8_t>(v >> 24);
+    }
+  }
+  return PCP_OK;
+}
+
+int pcp_colour_finalise(pcp_context *ctx, uint8_t *out_rgb, uint8_t *out_has, int32_t *out_count, float *out_top_score,
+                        uint32_t *out_top_rgb, int32_t *out_top_frame) {
+  int rc = check_ready(ctx, "pcp_colour_finalise", false);
+  if (rc != PCP_OK) return rc;
+  const int64_t n = ctx->n;
+  if ((rc = ensure_state(ctx)) != PCP_OK) return rc;
+  const size_t sn = static_cast<size_t>(n);
+  if (!ctx->colour_state_live && n > 0) {
+    // no keyframe processed: empty lists
+    PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->rgba_sorted.p, 0, sn * 4, ctx->stream));
+    if ((rc = fill_u32(ctx, reinterpret_cast<uint32_t *>(ctx->top_score.p), kTopM * n, 0xbf800000u)) != PCP_OK) return rc;
+    PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->top_rgb.p, 0, kTopM * sn * 4, ctx->stream));
+    PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->top_frame.p, 0xff, kTopM * sn * 4, ctx->stream));
+    PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->view_count.p, 0, sn * 4, ctx->stream));
+  } else if (n > 0) {
+    TopState st{ctx->top_score.p, ctx->top_rgb.p, ctx->top_frame.p, ctx->view_count.p};
+    LaunchTimer t(ctx, PCP_K_COLOUR);
+    hipLaunchKernelGGL(k_finalise, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, n, st, ctx->rgba_sorted.p);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  if ((rc = publish_result(ctx, out_rgb, out_has)) != PCP_OK) return rc;
+  if ((out_count || out_top_score || out_top_rgb || out_top_frame) && n > 0) {
+    std::vector<int32_t> perm(sn), cnt;
+    std::vector<uint32_t> tmp(kTopM * sn);
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(perm.data(), ctx->perm.p, sn * 4, hipMemcpyDeviceToHost, ctx->stream));
+    auto fetch5 = [&](const void *src, void *dst_v) -> int {
+      PCP_HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), src, kTopM * sn * 4, hipMemcpyDeviceToHost, ctx->stream));
+      PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      uint32_t *dst = static_cast<uint32_t *>(dst_v);
+      for (size_t j = 0; j < sn; ++j)
+        for (int k = 0; k < kTopM; ++k) dst[static_cast<size_t>(perm[j]) * kTopM + k] = tmp[static_cast<size_t>(k) * sn + j];
+      return PCP_OK;
+    };
+    if (out_top_score && (rc = fetch5(ctx->top_score.p, out_top_score)) != PCP_OK) return rc;
+    if (out_top_rgb && (rc = fetch5(ctx->top_rgb.p, out_top_rgb)) != PCP_OK) return rc;
+    if (out_top_frame && (rc = fetch5(ctx->top_frame.p, out_top_frame)) != PCP_OK) return rc;
+    if (out_count) {
+      cnt.resize(sn);
+      PCP_HIP_TRY(ctx, hipMemcpyAsync(cnt.data(), ctx->view_count.p, sn * 4, hipMemcpyDeviceToHost, ctx->stream));
+      PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      for (size_t j = 0; j < sn; ++j) out_count[perm[j]] = cnt[j];
+    }
+  }
+  return PCP_OK;
+}
+
+int pcp_colorize(pcp_context *ctx, uint8_t *out_rgb, uint8_t *out_has) {
+  int rc = check_ready(ctx, "pcp_colorize", true);
+  if (rc != PCP_OK) return rc;
+  pcp_colour_reset(ctx);
+  if ((rc = pcp_depth_pass(ctx, 0, ctx->n_frames)) != PCP_OK) return rc;
+  if ((rc = colour_pass_impl(ctx, 0, ctx->n_frames, true)) != PCP_OK) return rc;
+  return publish_result(ctx, out_rgb, out_has);
+}
+
+int pcp_colour_result_device(pcp_context *ctx, void **device_ptr, int64_t *n_words) {
+  if (!ctx) return PCP_ERR_INVALID;
+  if (!ctx->colour_result_live)
+    return set_error(ctx, PCP_ERR_STATE, "pcp_colour_result_device: no result (call pcp_colorize / pcp_colour_finalise)");
+  if (device_ptr) *device_ptr = ctx->rgba.p;
+  if (n_words) *n_words = ctx->n;
+  return PCP_OK;
+}
+
+}  // extern "C"

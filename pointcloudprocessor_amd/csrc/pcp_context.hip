@@ -1,0 +1,514 @@
+// pcp_context.hip -- handle lifecycle, configuration, uploads, host-side pose
+// algebra (A1) and the hipEvent timing facility of libpcp_hip.so.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <new>
+
+#include "pcp_internal.hpp"
+
+namespace pcp {
+
+static thread_local std::string g_error;
+
+int set_error(const pcp_context *ctx, int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx)
+    ctx->error = buf;
+  else
+    g_error = buf;
+  return code;
+}
+
+void set_global_error(const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_error = buf;
+}
+
+LaunchTimer::LaunchTimer(pcp_context *c, int32_t kernel) : ctx(c) {
+  if (!ctx->timing) return;
+  auto grab = [&](hipEvent_t &e) {
+    if (!ctx->event_pool.empty()) {
+      e = ctx->event_pool.back();
+      ctx->event_pool.pop_back();
+      return true;
+    }
+    return hipEventCreate(&e) == hipSuccess;
+  };
+  if (!grab(ev.start)) return;
+  if (!grab(ev.stop)) {
+    ctx->event_pool.push_back(ev.start);
+    return;
+  }
+  ev.kernel = kernel;
+  active = hipEventRecord(ev.start, ctx->stream) == hipSuccess;
+}
+
+LaunchTimer::~LaunchTimer() {
+  if (!active) return;
+  (void)hipEventRecord(ev.stop, ctx->stream);
+  ctx->pending.push_back(ev);
+}
+
+int drain_timing(pcp_context *ctx) {
+  for (auto &p : ctx->pending) {
+    float ms = 0.0f;
+    hipError_t e = hipEventSynchronize(p.stop);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, p.start, p.stop);
+    if (e == hipSuccess && p.kernel >= 0 && p.kernel < PCP_K_COUNT) {
+      ctx->slots[p.kernel].total_ms += ms;
+      ctx->slots[p.kernel].launches += 1;
+    }
+    ctx->event_pool.push_back(p.start);
+    ctx->event_pool.push_back(p.stop);
+  }
+  ctx->pending.clear();
+  return PCP_OK;
+}
+
+// ---- A1: pose -> matrices (PointCloudProcessor.cpp:495-519) --------------------
+// Eigen::Quaterniond::toRotationMatrix without normalisation, fp64.
+static void rotation_from_quaternion(const pcp_pose &p, double R[3][3]) {
+  const double tx = 2.0 * p.qx, ty = 2.0 * p.qy, tz = 2.0 * p.qz;
+  const double twx = tx * p.qw, twy = ty * p.qw, twz = tz * p.qw;
+  const double txx = tx * p.qx, txy = ty * p.qx, txz = tz * p.qx;
+  const double tyy = ty * p.qy, tyz = tz * p.qy, tzz = tz * p.qz;
+  R[0][0] = 1.0 - (tyy + tzz);
+  R[0][1] = txy - twz;
+  R[0][2] = txz + twy;
+  R[1][0] = txy + twz;
+  R[1][1] = 1.0 - (txx + tzz);
+  R[1][2] = tyz - twx;
+  R[2][0] = txz - twy;
+  R[2][1] = tyz + twx;
+  R[2][2] = 1.0 - (txx + tyy);
+}
+
+// Eigen Transform<float,3,Affine>::inverse(): cofactor inverse of the linear part
+// and -L^-1 t, all fp32 (PointCloudProcessor.cpp:509,518).
+static void invert_affine_f32(const float in[12], float out[12]) {
+  const float a = in[0], b = in[1], c = in[2];
+  const float d = in[4], e = in[5], f = in[6];
+  const float g = in[8], h = in[9], i = in[10];
+  const float k00 = e * i - f * h, k01 = f * g - d * i, k02 = d * h - e * g;
+  const float det = (a * k00 + b * k01) + c * k02;
+  const float inv = 1.0f / det;
+  const float L[3][3] = {{k00 * inv, (c * h - b * i) * inv, (b * f - c * e) * inv},
+                         {k01 * inv, (a * i - c * g) * inv, (c * d - a * f) * inv},
+                         {k02 * inv, (b * g - a * h) * inv, (a * e - b * d) * inv}};
+  for (int r = 0; r < 3; ++r) {
+    out[4 * r + 0] = L[r][0];
+    out[4 * r + 1] = L[r][1];
+    out[4 * r + 2] = L[r][2];
+    out[4 * r + 3] = -((L[r][0] * in[3] + L[r][1] * in[7]) + L[r][2] * in[11]);
+  }
+}
+
+static void matrices_from_pose(const pcp_pose &pose, const double *T, float w2c[12], float c2w[12]) {
+  double R[3][3];
+  rotation_from_quaternion(pose, R);
+  const double t[3] = {pose.x, pose.y, pose.z};
+  if (!T) {
+    // Isometry3d::inverse() = [R^T | -(R^T t)] in fp64, then cast<float>()
+    for (int r = 0; r < 3; ++r) {
+      const double a0 = R[0][r], a1 = R[1][r], a2 = R[2][r];
+      w2c[4 * r + 0] = static_cast<float>(a0);
+      w2c[4 * r + 1] = static_cast<float>(a1);
+      w2c[4 * r + 2] = static_cast<float>(a2);
+      w2c[4 * r + 3] = static_cast<float>(-((a0 * t[0] + a1 * t[1]) + a2 * t[2]));
+      c2w[4 * r + 0] = static_cast<float>(R[r][0]);
+      c2w[4 * r + 1] = static_cast<float>(R[r][1]);
+      c2w[4 * r + 2] = static_cast<float>(R[r][2]);
+      c2w[4 * r + 3] = static_cast<float>(t[r]);
+    }
+    return;
+  }
+  // (t_c2w * T_camera_lidar_optimized).cast<float>(), then the general fp32 inverse
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) {
+      double s = (R[r][0] * T[0 * 4 + c] + R[r][1] * T[1 * 4 + c]) + R[r][2] * T[2 * 4 + c];
+      if (c == 3) s = s + t[r] * T[15];
+      c2w[4 * r + c] = static_cast<float>(s);
+    }
+  invert_affine_f32(c2w, w2c);
+}
+
+// 30-bit Morton key of a point inside the cloud's bounding box.
+static inline uint32_t spread10(uint32_t v) {
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+// Spatial order for the batched run: 64 consecutive points (one wavefront) then
+// fall in few z-buffer cells and mostly share their keyframe visibility.
+static void spatial_permutation(const float *x, const float *y, const float *z, int64_t n, const float mn[3],
+                                const float mx[3], std::vector<int32_t> &perm) {
+  perm.resize(static_cast<size_t>(n));
+  std::vector<uint64_t> keys(static_cast<size_t>(n)), tmp(static_cast<size_t>(n));
+  float sc[3];
+  for (int a = 0; a < 3; ++a) {
+    const float ext = mx[a] - mn[a];
+    sc[a] = ext > 0.0f ? 1023.999f / ext : 0.0f;
+  }
+  for (int64_t i = 0; i < n; ++i) {
+    const uint32_t ix = static_cast<uint32_t>((x[i] - mn[0]) * sc[0]);
+    const uint32_t iy = static_cast<uint32_t>((y[i] - mn[1]) * sc[1]);
+    const uint32_t iz = static_cast<uint32_t>((z[i] - mn[2]) * sc[2]);
+    const uint64_t key = spread10(ix) | (spread10(iy) << 1) | (spread10(iz) << 2);
+    keys[static_cast<size_t>(i)] = (key << 32) | static_cast<uint32_t>(i);
+  }
+  // LSD radix sort on the 30 key bits (3 passes of 10 bits); stable, so equal keys keep input order
+  for (int pass = 0; pass < 3; ++pass) {
+    const int shift = 32 + 10 * pass;
+    size_t hist[1025] = {0};
+    for (int64_t i = 0; i < n; ++i) hist[((keys[static_cast<size_t>(i)] >> shift) & 0x3ffu) + 1]++;
+    for (int b = 0; b < 1024; ++b) hist[b + 1] += hist[b];
+    for (int64_t i = 0; i < n; ++i) {
+      const uint64_t k = keys[static_cast<size_t>(i)];
+      tmp[hist[(k >> shift) & 0x3ffu]++] = k;
+    }
+    keys.swap(tmp);
+  }
+  for (int64_t i = 0; i < n; ++i) perm[static_cast<size_t>(i)] = static_cast<int32_t>(keys[static_cast<size_t>(i)] & 0xffffffffu);
+}
+
+static int store_cloud(pcp_context *ctx, const float *x, const float *y, const float *z, int64_t n) {
+  PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int64_t i = 0; i < n; ++i) {
+    mn[0] = std::min(mn[0], x[i]);
+    mx[0] = std::max(mx[0], x[i]);
+    mn[1] = std::min(mn[1], y[i]);
+    mx[1] = std::max(mx[1], y[i]);
+    mn[2] = std::min(mn[2], z[i]);
+    mx[2] = std::max(mx[2], z[i]);
+  }
+  if (n == 0) mn[0] = mn[1] = mn[2] = mx[0] = mx[1] = mx[2] = 0.0f;
+  for (int a = 0; a < 3; ++a) {
+    ctx->host_min[a] = mn[a];
+    ctx->host_max[a] = mx[a];
+  }
+  const size_t sn = static_cast<size_t>(n);
+  // pad every SoA plane to a multiple of 4 floats so float4 loads stay aligned
+  const size_t plane = (sn + 3) & ~size_t(3);
+  PCP_HIP_TRY(ctx, ctx->xyz.ensure(3 * plane + 4));
+  PCP_HIP_TRY(ctx, ctx->sxyz.ensure(3 * plane + 4));
+  PCP_HIP_TRY(ctx, ctx->perm.ensure(sn + 4));
+  ctx->n = n;
+  ctx->colour_state_live = false;
+  ctx->colour_result_live = false;
+  ctx->mls_count = 0;
+  std::fill(ctx->depth_valid.begin(), ctx->depth_valid.end(), uint8_t(0));
+  if (n == 0) return PCP_OK;
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->xyz.p, x, sn * 4, hipMemcpyHostToDevice, ctx->stream));
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->xyz.p + plane, y, sn * 4, hipMemcpyHostToDevice, ctx->stream));
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->xyz.p + 2 * plane, z, sn * 4, hipMemcpyHostToDevice, ctx->stream));
+  std::vector<int32_t> perm;
+  spatial_permutation(x, y, z, n, mn, mx, perm);
+  std::vector<float> sorted(3 * plane, 0.0f);
+  for (int64_t j = 0; j < n; ++j) {
+    const int32_t i = perm[static_cast<size_t>(j)];
+    sorted[static_cast<size_t>(j)] = x[i];
+    sorted[plane + static_cast<size_t>(j)] = y[i];
+    sorted[2 * plane + static_cast<size_t>(j)] = z[i];
+  }
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->sxyz.p, sorted.data(), 3 * plane * 4, hipMemcpyHostToDevice, ctx->stream));
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->perm.p, perm.data(), sn * 4, hipMemcpyHostToDevice, ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PCP_OK;
+}
+
+}  // namespace pcp
+
+using namespace pcp;
+
+extern "C" {
+
+int pcp_abi_version(void) { return PCP_ABI_VERSION; }
+
+int pcp_create(int32_t device, pcp_context **out) {
+  if (!out) {
+    set_global_error("pcp_create: out is NULL");
+    return PCP_ERR_INVALID;
+  }
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    set_global_error("pcp_create: no HIP device available (%s); libpcp_hip has no CPU fallback",
+                     e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return PCP_ERR_DEVICE;
+  }
+  if (device < 0 || device >= count) {
+    set_global_error("pcp_create: device %d out of range (0..%d)", device, count - 1);
+    return PCP_ERR_INVALID;
+  }
+  e = hipSetDevice(device);
+  if (e != hipSuccess) {
+    set_global_error("pcp_create: hipSetDevice(%d) failed: %s", device, hipGetErrorString(e));
+    return PCP_ERR_DEVICE;
+  }
+  pcp_context *ctx = new (std::nothrow) pcp_context();
+  if (!ctx) {
+    set_global_error("pcp_create: out of host memory");
+    return PCP_ERR_NOMEM;
+  }
+  ctx->device = device;
+  e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    set_global_error("pcp_create: hipStreamCreate failed: %s", hipGetErrorString(e));
+    delete ctx;
+    return PCP_ERR_DEVICE;
+  }
+  ctx->stream = ctx->own_stream;
+  pcp_default_camera(&ctx->camera);
+  pcp_default_cull_params(&ctx->cull);
+  *out = ctx;
+  return PCP_OK;
+}
+
+void pcp_destroy(pcp_context *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  drain_timing(ctx);
+  for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  ctx->xyz.release();
+  ctx->sxyz.release();
+  ctx->perm.release();
+  ctx->frames.release();
+  ctx->images.release();
+  ctx->depth.release();
+  ctx->cand_bits.release();
+  ctx->top_score.release();
+  ctx->top_rgb.release();
+  ctx->top_frame.release();
+  ctx->view_count.release();
+  ctx->rgba_sorted.release();
+  ctx->rgba.release();
+  ctx->s_cell.release();
+  ctx->s_pixel.release();
+  ctx->s_range.release();
+  ctx->s_cam.release();
+  ctx->s_keep.release();
+  ctx->s_u32.release();
+  ctx->s_counter.release();
+  ctx->mls_xyz.release();
+  ctx->mls_normal.release();
+  ctx->mls_curv.release();
+  ctx->mls_index.release();
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+const char *pcp_last_error(const pcp_context *ctx) { return ctx ? ctx->error.c_str() : g_error.c_str(); }
+
+int pcp_set_stream(pcp_context *ctx, void *hip_stream) {
+  if (!ctx) return PCP_ERR_INVALID;
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  return PCP_OK;
+}
+
+int pcp_synchronize(pcp_context *ctx) {
+  if (!ctx) return PCP_ERR_INVALID;
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PCP_OK;
+}
+
+// PointCloudProcessor.cpp:57-62,525
+void pcp_default_camera(pcp_camera *cam) {
+  cam->fx = 4818.200388954926;
+  cam->fy = 4819.10345841615;
+  cam->cx = 2032.4178620390019;
+  cam->cy = 1535.1895959282901;
+  cam->k1 = 0.003043514741045163;
+  cam->k2 = 0.06634739187544138;
+  cam->p1 = -0.000217681797407554;
+  cam->p2 = -0.0006654964142658197;
+  cam->k3 = 0.0;
+  cam->image_width = 4096;
+  cam->image_height = 3000;
+  cam->cull_width = 4096;
+  cam->cull_height = 3000;
+}
+
+// view_culling.hpp:12-15, view_culling.cpp:63,157
+void pcp_default_cull_params(pcp_cull_params *p) {
+  p->enable_depth_buffer_culling = 1;
+  p->downsample_factor = 14;
+  p->depth_slack = 0.05;
+}
+
+// PointCloudProcessor.cpp:67-86
+void pcp_default_mls_params(pcp_mls_params *p) {
+  p->search_radius = 0.03;
+  p->sqr_gauss_param = 0.0009;
+  p->polynomial_order = 2;
+  p->compute_normals = 1;
+  p->upsampling = 3;
+  p->vgd_iterations = 4;
+  p->vgd_voxel_size = 0.001f;
+  p->sor_mean_k = 60;
+  p->sor_std_mul = 0.7;
+}
+
+int pcp_set_camera(pcp_context *ctx, const pcp_camera *cam, const pcp_cull_params *cull) {
+  if (!ctx || !cam) return set_error(ctx, PCP_ERR_INVALID, "pcp_set_camera: NULL argument");
+  pcp_cull_params cp;
+  if (cull)
+    cp = *cull;
+  else
+    pcp_default_cull_params(&cp);
+  if (cam->image_width <= 0 || cam->image_height <= 0 || cam->cull_width <= 0 || cam->cull_height <= 0)
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_set_camera: image / cull size must be positive");
+  if (cp.downsample_factor <= 0) return set_error(ctx, PCP_ERR_INVALID, "pcp_set_camera: downsample_factor must be > 0");
+  if (static_cast<int64_t>(cam->image_width) * cam->image_height >= (int64_t(1) << 31))
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_set_camera: image too large for int32 pixel indices");
+  ctx->camera = *cam;
+  ctx->cull = cp;
+  DevCamera &d = ctx->dcam;
+  d.fx = cam->fx;
+  d.fy = cam->fy;
+  d.cx = cam->cx;
+  d.cy = cam->cy;
+  d.k1 = cam->k1;
+  d.k2 = cam->k2;
+  d.p1 = cam->p1;
+  d.p2 = cam->p2;
+  d.k3 = cam->k3;
+  d.slack = cp.depth_slack;
+  d.ds = cp.downsample_factor;
+  d.ds_f = static_cast<float>(cp.downsample_factor);
+  d.img_w = cam->image_width;
+  d.img_h = cam->image_height;
+  d.cull_w = cam->cull_width;
+  d.cull_h = cam->cull_height;
+  d.mw = cam->cull_width / cp.downsample_factor;
+  d.mh = cam->cull_height / cp.downsample_factor;
+  d.enable_zbuf = cp.enable_depth_buffer_culling ? 1 : 0;
+  d.pad_ = 0;
+  ctx->have_camera = true;
+  // images / depth maps are sized by the camera: drop them
+  ctx->image_set.assign(ctx->image_set.size(), 0);
+  ctx->mask_set.assign(ctx->mask_set.size(), 0);
+  std::fill(ctx->depth_valid.begin(), ctx->depth_valid.end(), uint8_t(0));
+  ctx->colour_state_live = false;
+  ctx->colour_result_live = false;
+  return PCP_OK;
+}
+
+int pcp_upload_cloud(pcp_context *ctx, const float *x, const float *y, const float *z, int64_t n) {
+  if (!ctx) return PCP_ERR_INVALID;
+  if (n < 0 || n >= (int64_t(1) << 31)) return set_error(ctx, PCP_ERR_INVALID, "pcp_upload_cloud: n=%lld out of range", (long long)n);
+  if (n > 0 && (!x || !y || !z)) return set_error(ctx, PCP_ERR_INVALID, "pcp_upload_cloud: NULL coordinate array");
+  return store_cloud(ctx, x, y, z, n);
+}
+
+int pcp_upload_cloud_aos(pcp_context *ctx, const void *points, int64_t n, int64_t stride_bytes) {
+  if (!ctx) return PCP_ERR_INVALID;
+  if (n < 0 || n >= (int64_t(1) << 31)) return set_error(ctx, PCP_ERR_INVALID, "pcp_upload_cloud_aos: n out of range");
+  if (stride_bytes < 12) return set_error(ctx, PCP_ERR_INVALID, "pcp_upload_cloud_aos: stride must be >= 12 bytes");
+  if (n > 0 && !points) return set_error(ctx, PCP_ERR_INVALID, "pcp_upload_cloud_aos: NULL points");
+  std::vector<float> x(static_cast<size_t>(n)), y(static_cast<size_t>(n)), z(static_cast<size_t>(n));
+  const uint8_t *base = static_cast<const uint8_t *>(points);
+  for (int64_t i = 0; i < n; ++i) {
+    float v[3];
+    std::memcpy(v, base + i * stride_bytes, 12);
+    x[static_cast<size_t>(i)] = v[0];
+    y[static_cast<size_t>(i)] = v[1];
+    z[static_cast<size_t>(i)] = v[2];
+  }
+  return store_cloud(ctx, x.data(), y.data(), z.data(), n);
+}
+
+int64_t pcp_cloud_size(const pcp_context *ctx) { return ctx ? ctx->n : -1; }
+
+int pcp_pose_to_matrices(const pcp_pose *pose, const double *T_opt, float w2c[12], float c2w[12]) {
+  if (!pose || !w2c || !c2w) {
+    set_global_error("pcp_pose_to_matrices: NULL argument");
+    return PCP_ERR_INVALID;
+  }
+  matrices_from_pose(*pose, T_opt, w2c, c2w);
+  return PCP_OK;
+}
+
+int pcp_set_frames(pcp_context *ctx, const pcp_pose *poses, int32_t n_frames, const double *T_opt,
+                   int32_t T_opt_stride) {
+  if (!ctx) return PCP_ERR_INVALID;
+  if (n_frames < 0 || (n_frames > 0 && !poses)) return set_error(ctx, PCP_ERR_INVALID, "pcp_set_frames: bad poses");
+  if (T_opt && T_opt_stride != 0 && T_opt_stride != 16)
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_set_frames: T_opt_stride must be 0 (global) or 16 (per keyframe)");
+  PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ctx->poses.assign(poses, poses + n_frames);
+  ctx->hframes.resize(static_cast<size_t>(n_frames));
+  for (int32_t f = 0; f < n_frames; ++f) {
+    DevFrame &d = ctx->hframes[static_cast<size_t>(f)];
+    const double *T = T_opt ? T_opt + static_cast<int64_t>(T_opt_stride) * f : nullptr;
+    matrices_from_pose(poses[f], T, d.w2c, d.c2w);
+    d.px = poses[f].x;
+    d.py = poses[f].y;
+    d.pz = poses[f].z;
+    d.pad_ = 0.0;
+  }
+  PCP_HIP_TRY(ctx, ctx->frames.ensure(static_cast<size_t>(n_frames) + 1));
+  if (n_frames > 0)
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->frames.p, ctx->hframes.data(), sizeof(DevFrame) * n_frames,
+                                    hipMemcpyHostToDevice, ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->n_frames = n_frames;
+  ctx->image_set.assign(static_cast<size_t>(n_frames), 0);
+  ctx->mask_set.assign(static_cast<size_t>(n_frames), 0);
+  ctx->depth_valid.assign(static_cast<size_t>(n_frames), 0);
+  ctx->colour_state_live = false;
+  ctx->colour_result_live = false;
+  return PCP_OK;
+}
+
+int32_t pcp_frame_count(const pcp_context *ctx) { return ctx ? ctx->n_frames : -1; }
+
+int pcp_timing_enable(pcp_context *ctx, int32_t on) {
+  if (!ctx) return PCP_ERR_INVALID;
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  drain_timing(ctx);
+  ctx->timing = on != 0;
+  return PCP_OK;
+}
+
+int pcp_timing_reset(pcp_context *ctx) {
+  if (!ctx) return PCP_ERR_INVALID;
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  drain_timing(ctx);
+  for (auto &s : ctx->slots) s = TimingSlot{};
+  return PCP_OK;
+}
+
+int pcp_timing_get(pcp_context *ctx, int32_t kernel_id, double *total_ms, int64_t *launches) {
+  if (!ctx) return PCP_ERR_INVALID;
+  if (kernel_id < 0 || kernel_id >= PCP_K_COUNT) return set_error(ctx, PCP_ERR_RANGE, "pcp_timing_get: bad kernel id %d", kernel_id);
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  drain_timing(ctx);
+  if (total_ms) *total_ms = ctx->slots[kernel_id].total_ms;
+  if (launches) *launches = ctx->slots[kernel_id].launches;
+  return PCP_OK;
+}
+
+const char *pcp_kernel_name(int32_t kernel_id) {
+  static const char *names[PCP_K_COUNT] = {"project_frame", "depth_pass", "colour_pass", "visibility", "mls_grid",
+                                           "mls_fit",       "misc",       "sor",         "mls_voxel"};
+  return (kernel_id >= 0 && kernel_id < PCP_K_COUNT) ? names[kernel_id] : "?";
+}
+
+}  // extern "C"

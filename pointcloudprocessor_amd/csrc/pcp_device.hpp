@@ -1,0 +1,195 @@
+// pcp_device.hpp -- device arithmetic of the colour path, stated operation by
+// operation as SURVEY.md Appendix A fixes it.  This translation unit MUST be
+// built with -ffp-contract=off (no FMA contraction): every fp32 / fp64 multiply
+// and add below is individually rounded, exactly as the reference's x86-64
+// baseline build executes them.  Division and sqrt are the correctly rounded
+// IEEE forms (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt; fp64
+// divide / sqrt expand to correctly rounded sequences on gfx950).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+
+#include "pcp_internal.hpp"
+
+namespace pcp {
+
+// A2: pcl::transformPointCloud(Affine3f), PCL 1.10 SSE association
+// x*c0 + (y*c1 + (z*c2 + c3)); call sites PointCloudProcessor.cpp:196,521,549,555.
+__device__ __forceinline__ void xform(const float *__restrict__ m, float x, float y, float z, float &xc, float &yc,
+                                      float &zc) {
+  xc = x * m[0] + (y * m[1] + (z * m[2] + m[3]));
+  yc = x * m[4] + (y * m[5] + (z * m[6] + m[7]));
+  zc = x * m[8] + (y * m[9] + (z * m[10] + m[11]));
+}
+
+// A3: PinholeProjection::operator() + distort, pinhole.hpp:13-51 (duplicate
+// PointCloudProcessor.hpp:100-123), fp64, left-to-right as written.
+__device__ __forceinline__ void project_uv(const DevCamera &c, double X, double Y, double Z, double &u, double &v) {
+  const double xn = X / Z;
+  const double yn = Y / Z;
+  const double x2 = xn * xn;
+  const double y2 = yn * yn;
+  const double r2 = x2 + y2;
+  const double r4 = r2 * r2;
+  const double r6 = r2 * r4;
+  const double rc = ((1.0 + c.k1 * r2) + c.k2 * r4) + c.k3 * r6;
+  const double t1 = (2.0 * xn) * yn;
+  const double t2 = r2 + 2.0 * x2;
+  const double t3 = r2 + 2.0 * y2;
+  const double xd = (rc * xn + c.p1 * t1) + c.p2 * t2;
+  const double yd = (rc * yn + c.p1 * t3) + c.p2 * t1;
+  u = c.fx * xd + c.cx;
+  v = c.fy * yd + c.cy;
+}
+
+// A4 cell: (project(p).cast<float>() / 14).cast<int>(), bounds vs the FULL cull
+// size (view_culling.cpp:86-90, sic) then vs the /14 map (:116,:155).
+// Returns cy*mw+cx, -2 (candidate outside the map) or -1 (rejected).
+// Values that do not fit an int32 (UB in the reference, Appendix B6) are rejected.
+__device__ __forceinline__ int32_t cull_cell(const DevCamera &c, double u, double v) {
+  const float cxf = static_cast<float>(u) / c.ds_f;
+  const float cyf = static_cast<float>(v) / c.ds_f;
+  if (!(cxf > -2147483648.0f && cxf < 2147483648.0f && cyf > -2147483648.0f && cyf < 2147483648.0f)) return -1;
+  const int32_t cx = static_cast<int32_t>(cxf);
+  const int32_t cy = static_cast<int32_t>(cyf);
+  if (cx < 0 || cy < 0 || cx >= c.cull_w || cy >= c.cull_h) return -1;
+  return (cx < c.mw && cy < c.mh) ? cy * c.mw + cx : -2;
+}
+
+// A5 pixel: static_cast<int>(fx*xd+cx) with C truncation, bounds vs the actual
+// image (PointCloudProcessor.cpp:752-754).  -1 when rejected.
+__device__ __forceinline__ int32_t colour_pixel(const DevCamera &c, double u, double v) {
+  if (!(u > -2147483648.0 && u < 2147483648.0 && v > -2147483648.0 && v < 2147483648.0)) return -1;
+  const int32_t ui = static_cast<int32_t>(u);
+  const int32_t vi = static_cast<int32_t>(v);
+  if (ui < 0 || ui >= c.img_w || vi < 0 || vi >= c.img_h) return -1;
+  return vi * c.img_w + ui;
+}
+
+// ||p_c|| in fp64 on the promoted fp32 camera coordinates (view_culling.cpp:102,144).
+__device__ __forceinline__ double range64(float xc, float yc, float zc) {
+  const double X = xc, Y = yc, Z = zc;
+  return sqrt((X * X + Y * Y) + Z * Z);
+}
+
+struct Projected {
+  float xc, yc, zc;
+  int32_t cell;   // >=0, -2, -1
+  int32_t pixel;  // >=0, -1
+};
+
+// transform + z test (B6: z <= 0 rejected) + projection + both truncation rules.
+__device__ __forceinline__ Projected project_point(const DevCamera &c, const float *__restrict__ m, float x, float y,
+                                                   float z) {
+  Projected p;
+  xform(m, x, y, z, p.xc, p.yc, p.zc);
+  p.cell = -1;
+  p.pixel = -1;
+  if (p.zc > 0.0f) {
+    double u, v;
+    project_uv(c, static_cast<double>(p.xc), static_cast<double>(p.yc), static_cast<double>(p.zc), u, v);
+    p.cell = cull_cell(c, u, v);
+    p.pixel = colour_pixel(c, u, v);
+  }
+  return p;
+}
+
+// A4 keep rule (view_culling.cpp:135-171).  depth = this keyframe's map.
+__device__ __forceinline__ bool keep_rule(const DevCamera &c, const Projected &p, const uint32_t *__restrict__ depth) {
+  if (!c.enable_zbuf) return p.cell != -1;
+  if (p.cell < 0) return false;
+  const double r = range64(p.xc, p.yc, p.zc);
+  const double lim = static_cast<double>(__uint_as_float(depth[p.cell])) + c.slack;
+  return !(r > lim);
+}
+
+// A6 scores: computeOrientationScore hpp:205-220 (B4 reproduced),
+// computeDistanceScore hpp:222-236, final cpp:588 (identity mode, B3).
+__device__ __forceinline__ float final_score(float xc, float yc, float zc, double px, double py, double pz) {
+  const double dx = static_cast<double>(xc) - px;
+  const double dy = static_cast<double>(yc) - py;
+  const double dz = static_cast<double>(zc) - pz;
+  const double sq = (dx * dx + dy * dy) + dz * dz;
+  const double cosA = sq > 0.0 ? dz / sqrt(sq) : dz;
+  float o = static_cast<float>((cosA + 1.0) / 2.0);
+  o = 0.2f + 0.8f * o;
+  const float dist = sqrtf((xc * xc + yc * yc) + zc * zc);
+  const float diff = fabsf(dist - 2.0f);
+  float nd = diff / 2.0f;
+  nd = nd < 1.0f ? nd : 1.0f;
+  float d = 1.0f - nd;
+  d = 0.2f + 0.8f * d;
+  return static_cast<float>(static_cast<double>(o + d) / 2.0);
+}
+
+// Per-point top-5 held in registers across the keyframe loop (A8).  Streaming
+// equivalent of "append all, std::sort descending, take 5" with ties -> lower
+// keyframe index (B8): keyframes arrive ascending, a new entry goes behind equals.
+struct Top5 {
+  float s0, s1, s2, s3, s4;
+  uint32_t c0, c1, c2, c3, c4;
+  int32_t f0, f1, f2, f3, f4;
+  int32_t count;
+  __device__ __forceinline__ void init() {
+    s0 = s1 = s2 = s3 = s4 = -1.0f;
+    c0 = c1 = c2 = c3 = c4 = 0u;
+    f0 = f1 = f2 = f3 = f4 = -1;
+    count = 0;
+  }
+  __device__ __forceinline__ void insert(float s, uint32_t c, int32_t f) {
+    count += 1;
+    // scores are >= 0.2 and empty slots hold -1, so "s > slot" also fills empties
+    if (s > s4) {
+      s4 = s; c4 = c; f4 = f;
+      if (s4 > s3) {
+        float ts = s3; s3 = s4; s4 = ts;
+        uint32_t tc = c3; c3 = c4; c4 = tc;
+        int32_t tf = f3; f3 = f4; f4 = tf;
+        if (s3 > s2) {
+          ts = s2; s2 = s3; s3 = ts;
+          tc = c2; c2 = c3; c3 = tc;
+          tf = f2; f2 = f3; f3 = tf;
+          if (s2 > s1) {
+            ts = s1; s1 = s2; s2 = ts;
+            tc = c1; c1 = c2; c2 = tc;
+            tf = f1; f1 = f2; f2 = tf;
+            if (s1 > s0) {
+              ts = s0; s0 = s1; s1 = ts;
+              tc = c0; c0 = c1; c1 = tc;
+              tf = f0; f0 = f1; f1 = tf;
+            }
+          }
+        }
+      }
+    }
+  }
+  // smoothColors PointCloudProcessor.cpp:616-629: fp32 sums in sorted order,
+  // truncation to uint8, no entries -> (0,0,0) (B7).  Packed r | g<<8 | b<<16 | has<<24.
+  __device__ __forceinline__ uint32_t finalise() const {
+    float total = 0.0f, r = 0.0f, g = 0.0f, b = 0.0f;
+    const float ss[5] = {s0, s1, s2, s3, s4};
+    const uint32_t cc[5] = {c0, c1, c2, c3, c4};
+    const int32_t ff[5] = {f0, f1, f2, f3, f4};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      if (ff[k] >= 0) {
+        const float s = ss[k];
+        r += static_cast<float>((cc[k] >> 16) & 0xffu) * s;
+        g += static_cast<float>((cc[k] >> 8) & 0xffu) * s;
+        b += static_cast<float>(cc[k] & 0xffu) * s;
+        total += s;
+      }
+    }
+    if (f0 < 0) return 0u;
+    const uint32_t ri = static_cast<uint32_t>(r / total) & 0xffu;
+    const uint32_t gi = static_cast<uint32_t>(g / total) & 0xffu;
+    const uint32_t bi = static_cast<uint32_t>(b / total) & 0xffu;
+    const uint32_t has = (ri | gi | bi) ? 1u : 0u;  // removePointsWithNoColor hpp:238-252
+    return ri | (gi << 8) | (bi << 16) | (has << 24);
+  }
+};
+
+}  // namespace pcp

@@ -1,0 +1,168 @@
+// pcp_internal.hpp -- context, device parameter blocks and launch/timing helpers
+// shared by the translation units of libpcp_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pcp_hip.h"
+
+namespace pcp {
+
+// ---- device-side parameter blocks (passed by value as kernel arguments, so they
+// land in SGPRs through the kernarg segment; nothing here is per-lane) ----------
+struct DevCamera {
+  double fx, fy, cx, cy;
+  double k1, k2, p1, p2, k3;
+  double slack;  // 0.05, view_culling.cpp:157
+  float ds_f;    // 14.0f
+  int32_t ds;
+  int32_t img_w, img_h;
+  int32_t cull_w, cull_h;
+  int32_t mw, mh;  // cull_w/ds, cull_h/ds
+  int32_t enable_zbuf;
+  int32_t pad_;
+};
+
+// One keyframe: w2c / c2w 3x4 row-major fp32 (A1) and the pose translation used
+// by computeOrientationScore (hpp:207, B4).  128 B so a frame is two cache lines.
+struct DevFrame {
+  float w2c[12];
+  float c2w[12];
+  double px, py, pz;
+  double pad_;
+};
+static_assert(sizeof(DevFrame) == 128, "DevFrame layout");
+
+// Per-point top-5 state, SoA over points: score[k][n], rgb[k][n], frame[k][n], count[n].
+constexpr int kTopM = 5;  // PointCloudProcessor.cpp:615
+
+struct TimingSlot {
+  double total_ms = 0.0;
+  int64_t launches = 0;
+};
+
+struct PendingEvent {
+  hipEvent_t start, stop;
+  int32_t kernel;
+};
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t count = 0;
+  hipError_t ensure(size_t n) {
+    if (n <= count && p) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    count = 0;
+    if (n == 0) return hipSuccess;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T));
+    if (e == hipSuccess) count = n;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    count = 0;
+  }
+};
+
+}  // namespace pcp
+
+struct pcp_context {
+  int32_t device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  mutable std::string error;
+
+  // configuration
+  bool have_camera = false;
+  pcp_camera camera{};
+  pcp_cull_params cull{};
+  pcp::DevCamera dcam{};
+
+  // cloud: original order (per-keyframe drop-in calls) and spatially sorted copy
+  // (batched run + MLS); perm[j] = original index of sorted point j.
+  int64_t n = 0;
+  pcp::DevBuf<float> xyz;    // x[n] y[n] z[n]
+  pcp::DevBuf<float> sxyz;   // sorted x[n] y[n] z[n]
+  pcp::DevBuf<int32_t> perm; // n
+  std::vector<float> host_min = {0, 0, 0}, host_max = {0, 0, 0};
+
+  // frames
+  int32_t n_frames = 0;
+  std::vector<pcp_pose> poses;
+  std::vector<pcp::DevFrame> hframes;
+  pcp::DevBuf<pcp::DevFrame> frames;
+  pcp::DevBuf<uint32_t> images;  // n_frames * img_h * img_w  (B | G<<8 | R<<16 | mask<<24)
+  std::vector<uint8_t> image_set, mask_set;
+
+  // depth maps [n_frames][mh*mw] as uint view of positive floats
+  pcp::DevBuf<uint32_t> depth;
+  std::vector<uint8_t> depth_valid;
+
+  // candidate bitmask from the depth pass: words[(f/32)*n + j], sorted order
+  pcp::DevBuf<uint32_t> cand_bits;
+
+  // per-point colour state (sorted order) and packed results
+  pcp::DevBuf<float> top_score;     // 5*n
+  pcp::DevBuf<uint32_t> top_rgb;    // 5*n
+  pcp::DevBuf<int32_t> top_frame;   // 5*n
+  pcp::DevBuf<int32_t> view_count;  // n
+  pcp::DevBuf<uint32_t> rgba_sorted, rgba;  // n
+  bool colour_state_live = false;
+  bool colour_result_live = false;
+
+  // scratch for the single-frame calls
+  pcp::DevBuf<int32_t> s_cell, s_pixel;
+  pcp::DevBuf<float> s_range, s_cam;
+  pcp::DevBuf<uint8_t> s_keep;
+  pcp::DevBuf<uint32_t> s_u32;
+  pcp::DevBuf<unsigned long long> s_counter;
+
+  // MLS results
+  pcp::DevBuf<float> mls_xyz, mls_normal, mls_curv;
+  pcp::DevBuf<int32_t> mls_index;
+  int64_t mls_count = 0;
+
+  // measurement
+  bool timing = false;
+  pcp::TimingSlot slots[PCP_K_COUNT];
+  std::vector<pcp::PendingEvent> pending;
+  std::vector<hipEvent_t> event_pool;
+};
+
+namespace pcp {
+
+int set_error(const pcp_context *ctx, int code, const char *fmt, ...);
+void set_global_error(const char *fmt, ...);
+
+#define PCP_HIP_TRY(ctx, expr)                                                                       \
+  do {                                                                                               \
+    hipError_t e__ = (expr);                                                                         \
+    if (e__ != hipSuccess)                                                                           \
+      return pcp::set_error((ctx), e__ == hipErrorOutOfMemory ? PCP_ERR_NOMEM : PCP_ERR_DEVICE,       \
+                            "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+
+// RAII bracket: records start/stop events around a launch when timing is on.
+struct LaunchTimer {
+  pcp_context *ctx;
+  PendingEvent ev{};
+  bool active = false;
+  LaunchTimer(pcp_context *c, int32_t kernel);
+  ~LaunchTimer();
+};
+
+int drain_timing(pcp_context *ctx);
+
+inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace pcp

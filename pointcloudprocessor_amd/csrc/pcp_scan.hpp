@@ -1,0 +1,92 @@
+// pcp_scan.hpp -- device-wide exclusive prefix sum over int32 counts (three
+// launches: tile sums, single-block scan of the sums, per-tile apply).  Used by
+// the MLS cell binning; 64-wide wavefront scans through __shfl_up.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace pcp {
+
+constexpr int kScanBlock = 256;
+constexpr int kScanTile = 1024;  // 4 items per lane
+
+__device__ __forceinline__ int32_t scan_block_exclusive(int32_t v, int32_t *total, int32_t *wave_sum /* [4] LDS */) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int32_t incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int32_t t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wave_sum[wid] = incl;
+  __syncthreads();
+  int32_t base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < kScanBlock / 64; ++k) {
+    if (k < wid) base += wave_sum[k];
+    tot += wave_sum[k];
+  }
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+
+static __global__ __launch_bounds__(kScanBlock) void k_scan_tile_sums(const int32_t *__restrict__ in, int64_t n,
+                                                                      int32_t *__restrict__ tile_sum) {
+  __shared__ int32_t ws[kScanBlock / 64];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kScanTile + threadIdx.x * 4;
+  int32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (base + k < n) c += in[base + k];
+  int32_t total;
+  (void)scan_block_exclusive(c, &total, ws);
+  if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of tile sums in place; grand total to *total
+static __global__ __launch_bounds__(kScanBlock) void k_scan_tile_offsets(int32_t *__restrict__ tile_sum, int64_t tiles,
+                                                                         unsigned long long *__restrict__ total) {
+  __shared__ int32_t ws[kScanBlock / 64];
+  __shared__ long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < tiles; base += kScanBlock) {
+    const int64_t i = base + threadIdx.x;
+    const int32_t v = i < tiles ? tile_sum[i] : 0;
+    int32_t tot;
+    const int32_t ex = scan_block_exclusive(v, &tot, ws);
+    const long long c = carry;
+    if (i < tiles) tile_sum[i] = static_cast<int32_t>(c + ex);
+    __syncthreads();
+    if (threadIdx.x == 0) carry = c + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && total) *total = static_cast<unsigned long long>(carry);
+}
+
+// out[i] = tile_offset[tile] + exclusive prefix inside the tile (in and out may alias)
+static __global__ __launch_bounds__(kScanBlock) void k_scan_apply(const int32_t *in, int64_t n,
+                                                                  const int32_t *__restrict__ tile_offset,
+                                                                  int32_t *out) {
+  __shared__ int32_t ws[kScanBlock / 64];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kScanTile + threadIdx.x * 4;
+  int32_t v[4];
+  int32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[k] = base + k < n ? in[base + k] : 0;
+    c += v[k];
+  }
+  int32_t total;
+  int32_t run = tile_offset[blockIdx.x] + scan_block_exclusive(c, &total, ws);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (base + k < n) out[base + k] = run;
+    run += v[k];
+  }
+}
+
+}  // namespace pcp

@@ -1,0 +1,199 @@
+"""GPU parity of the colour path: HIP kernels (through the C ABI) vs the CPU
+restatement in oracle/ on the same seeded inputs.  Bars:
+cells / pixels / depth maps / keep masks bit-exact; colours within 1e-4 relative
+(uint8 equal unless R/S sits within 1e-4*255 of an integer)."""
+import numpy as np
+import pytest
+
+from conftest import cam_struct
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(ctx, capi, scene, cam_overrides=None, cull=None, with_masks=False):
+    cd = dict(scene["cam"])
+    if cam_overrides:
+        cd.update(cam_overrides)
+    ctx.set_camera(cam_struct(capi, cd), cull)
+    ctx.upload_cloud(scene["x"], scene["y"], scene["z"])
+    ctx.set_frames(scene["poses"])
+    for f, im in enumerate(scene["images"]):
+        ctx.upload_image(f, im)
+        if with_masks:
+            ctx.upload_mask(f, scene["masks"][f])
+    return cd
+
+
+def test_pose_to_matrices_matches_oracle(oracle, small_scene):
+    from pointcloudprocessor_amd import capi
+
+    for pose in small_scene["poses"]:
+        a = capi.pose_to_matrices(pose)
+        b = oracle.pose_to_matrices(pose)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    T = np.eye(4)
+    T[:3, 3] = [0.01, -0.02, 0.005]
+    a = capi.pose_to_matrices(small_scene["poses"][0], T)
+    b = oracle.pose_to_matrices(small_scene["poses"][0], T)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_project_frame_bit_exact(gpu_ctx_factory, oracle, small_scene):
+    from pointcloudprocessor_amd import capi
+
+    ctx = gpu_ctx_factory()
+    cd = _setup(ctx, capi, small_scene)
+    ocam, ocp = cam_struct(oracle, cd), oracle.default_cull_params()
+    for f, pose in enumerate(small_scene["poses"]):
+        w2c, _ = oracle.pose_to_matrices(pose)
+        ref = oracle.project_frame(ocam, ocp, w2c, small_scene["x"], small_scene["y"], small_scene["z"])
+        got = ctx.project_frame(f)
+        for k in ("xc", "yc", "zc", "cell", "pixel"):
+            assert np.array_equal(got[k], ref[k]), (f, k)
+        cand = ref["cell"] != -1
+        assert cand.sum() > 100
+        assert np.array_equal(got["range"][cand], ref["range"][cand])
+        assert np.all(got["range"][~cand] == np.finfo(np.float32).max)
+
+
+def test_project_frame_ragged_sizes(gpu_ctx_factory, oracle, small_scene):
+    """n not a multiple of 4 / 256, n < 4, n == 0."""
+    from pointcloudprocessor_amd import capi
+
+    ctx = gpu_ctx_factory()
+    cd = small_scene["cam"]
+    ctx.set_camera(cam_struct(capi, cd))
+    ctx.set_frames(small_scene["poses"][:1])
+    ocam, ocp = cam_struct(oracle, cd), oracle.default_cull_params()
+    w2c, _ = oracle.pose_to_matrices(small_scene["poses"][0])
+    for n in (0, 1, 3, 5, 255, 257, 1023, 4099):
+        x, y, z = (small_scene[k][:n] for k in "xyz")
+        ctx.upload_cloud(x, y, z)
+        got = ctx.project_frame(0)
+        ref = oracle.project_frame(ocam, ocp, w2c, x, y, z)
+        for k in ("cell", "pixel", "xc", "yc", "zc"):
+            assert np.array_equal(got[k], ref[k]), (n, k)
+
+
+def test_cull_frame_depth_and_keep_exact(gpu_ctx_factory, oracle, small_scene):
+    from pointcloudprocessor_amd import capi
+
+    ctx = gpu_ctx_factory()
+    cd = _setup(ctx, capi, small_scene)
+    ocam, ocp = cam_struct(oracle, cd), oracle.default_cull_params()
+    for f, pose in enumerate(small_scene["poses"]):
+        w2c, _ = oracle.pose_to_matrices(pose)
+        keep_r, dmap_r, kept_r = oracle.cull_frame(ocam, ocp, w2c, small_scene["x"], small_scene["y"], small_scene["z"])
+        keep_g, dmap_g, kept_g = ctx.cull_frame(f)
+        assert np.array_equal(dmap_g.view(np.uint32), dmap_r.view(np.uint32)), f
+        assert np.array_equal(keep_g, keep_r), f
+        assert kept_g == kept_r
+        assert 0 < kept_r < (dmap_r < 1e30).sum() * 50
+
+
+def test_cull_frame_without_depth_buffer(gpu_ctx_factory, oracle, small_scene):
+    from pointcloudprocessor_amd import capi
+
+    ctx = gpu_ctx_factory()
+    cull = capi.default_cull_params()
+    cull.enable_depth_buffer_culling = 0
+    cd = _setup(ctx, capi, small_scene, cull=cull)
+    ocp = oracle.default_cull_params()
+    ocp.enable_depth_buffer_culling = 0
+    w2c, _ = oracle.pose_to_matrices(small_scene["poses"][2])
+    keep_r, _, kept_r = oracle.cull_frame(cam_struct(oracle, cd), ocp, w2c, small_scene["x"], small_scene["y"],
+                                          small_scene["z"])
+    keep_g, _, kept_g = ctx.cull_frame(2)
+    assert np.array_equal(keep_g, keep_r) and kept_g == kept_r
+
+
+def _colour_close(got_rgb, ref):
+    """uint8 equal except where the fp32 quotient is within 1e-4*255 of an integer."""
+    diff = got_rgb.astype(np.int32) - ref["rgb"].astype(np.int32)
+    bad = np.nonzero(diff.any(axis=1))[0]
+    for i in bad:
+        s = ref["top_score"][i]
+        c = ref["top_rgb"][i]
+        m = (ref["top_frame"][i] >= 0)
+        tot = float(np.sum(s[m].astype(np.float64)))
+        for ch, sh in enumerate((16, 8, 0)):
+            q = float(np.sum(((c[m] >> sh) & 0xFF).astype(np.float64) * s[m])) / tot
+            assert abs(int(got_rgb[i, ch]) - int(ref["rgb"][i, ch])) <= 1 and abs(q - round(q)) < 1e-4 * 255, (i, ch, q)
+    return len(bad)
+
+
+def test_colorize_matches_oracle(gpu_ctx_factory, oracle, small_scene):
+    from pointcloudprocessor_amd import capi
+
+    ctx = gpu_ctx_factory()
+    cd = _setup(ctx, capi, small_scene)
+    ref = oracle.colorize(cam_struct(oracle, cd), oracle.default_cull_params(), small_scene["x"], small_scene["y"],
+                          small_scene["z"], small_scene["poses"], small_scene["images"])
+    assert ref["has"].sum() > 500 and ref["count"].max() >= 3
+    # staged run: depth maps, state, top-5 lists
+    ctx.colour_reset()
+    ctx.depth_pass()
+    for f, pose in enumerate(small_scene["poses"]):
+        w2c, _ = oracle.pose_to_matrices(pose)
+        _, dmap_r, _ = oracle.cull_frame(cam_struct(oracle, cd), oracle.default_cull_params(), w2c, small_scene["x"],
+                                         small_scene["y"], small_scene["z"])
+        assert np.array_equal(ctx.download_depth_map(f).view(np.uint32), dmap_r.view(np.uint32)), f
+    ctx.colour_pass()
+    got = ctx.colour_finalise(want_top=True)
+    assert np.array_equal(got["count"], ref["count"])
+    assert np.array_equal(got["top_frame"], ref["top_frame"])
+    assert np.array_equal(got["top_rgb"], ref["top_rgb"])
+    np.testing.assert_allclose(got["top_score"], ref["top_score"], rtol=1e-4, atol=0)
+    _colour_close(got["rgb"], ref)
+    assert np.array_equal(got["has"], (got["rgb"] != 0).any(axis=1).astype(np.uint8))
+    # one-shot run gives the same colours
+    one = ctx.colorize()
+    assert np.array_equal(one["rgb"], got["rgb"]) and np.array_equal(one["has"], got["has"])
+    # two batches of keyframes give the same result as one
+    ctx.colour_reset()
+    ctx.depth_pass(0, 3)
+    ctx.depth_pass(3, 6)
+    ctx.colour_pass(0, 2)
+    ctx.colour_pass(2, 6)
+    two = ctx.colour_finalise(want_top=True)
+    for k in ("rgb", "has", "count", "top_frame", "top_rgb", "top_score"):
+        assert np.array_equal(two[k], got[k]), k
+
+
+def test_frame_visible_with_masks(gpu_ctx_factory, oracle, small_scene):
+    from pointcloudprocessor_amd import capi
+
+    ctx = gpu_ctx_factory()
+    cd = _setup(ctx, capi, small_scene, with_masks=True)
+    ocam, ocp = cam_struct(oracle, cd), oracle.default_cull_params()
+    for f in (0, 3, 5):
+        ref = oracle.frame_visible(ocam, ocp, small_scene["poses"][f], small_scene["x"], small_scene["y"],
+                                   small_scene["z"], small_scene["images"][f], small_scene["masks"][f])
+        got = ctx.frame_visible(f)
+        assert got["count"] == len(ref["index"]) > 50
+        for k in ("index", "rgb", "mask", "xyz_cam", "xyz_world"):
+            assert np.array_equal(got[k], ref[k]), (f, k)
+    # capacity smaller than the count: truncated prefix, true count reported
+    got = ctx.frame_visible(0, capacity=10)
+    ref = oracle.frame_visible(ocam, ocp, small_scene["poses"][0], small_scene["x"], small_scene["y"],
+                               small_scene["z"], small_scene["images"][0], small_scene["masks"][0])
+    assert got["count"] == len(ref["index"]) and np.array_equal(got["index"], ref["index"][:10])
+
+
+def test_errors_are_loud(gpu_ctx_factory, small_scene):
+    from pointcloudprocessor_amd import capi
+
+    ctx = gpu_ctx_factory()
+    with pytest.raises(capi.PcpError) as e:
+        ctx.n = 0
+        ctx.project_frame(0)
+    assert e.value.code == capi.PCP_ERR_STATE
+    ctx.set_camera(cam_struct(capi, small_scene["cam"]))
+    ctx.upload_cloud(small_scene["x"], small_scene["y"], small_scene["z"])
+    ctx.set_frames(small_scene["poses"])
+    with pytest.raises(capi.PcpError) as e:
+        ctx.project_frame(99)
+    assert e.value.code == capi.PCP_ERR_RANGE
+    with pytest.raises(capi.PcpError) as e:
+        ctx.colour_pass()
+    assert e.value.code == capi.PCP_ERR_STATE
