@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpoints x frames / s colourised on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the whole hot path (z-buffer MIN pass over every
+keyframe -> [all-reduce(MIN) of depth maps across point shards] -> visibility +
+colour + scores + top-5 + smoothColors -> packed colours on the host) over the
+synthetic scene of SURVEY.md 8(d).  Default workload: BASELINE.json configs[2]
+without the MLS leg timed inside the step (10 M points x 256 keyframes @
+1920x1080 per GPU; north_star quotes its targets on it); MLS throughput is
+reported beside it as "mls".  Inputs (cloud, poses, images) are resident in HBM
+before the timed region starts.  Multi-GPU: weak scaling, every rank owns its
+own 10 M-point slice of an N x 10 M map, keyframes and images replicated.
+
+One JSON line on rank 0.  `roofline` is the single-keyframe projection kernel
+(20 B per point: 12 read + 4 + 4 written), timed with hipEvents on the stream
+it is launched on (pcp_timing_*), one launch per keyframe.  `cpu_baseline` is
+the oracle (CPU restatement, OpenMP, all host cores) on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PROJ_BYTES_PER_POINT = 20  # 12 B xyz read + 4 B cell + 4 B range written
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--points", type=int, default=10_000_000, help="points per GPU")
+    ap.add_argument("--frames", type=int, default=256)
+    ap.add_argument("--camera", default="cfg", choices=["cfg", "ref", "tiny"])
+    ap.add_argument("--mls-points", type=int, default=10_000_000)
+    ap.add_argument("--no-mls", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-points", type=int, default=1_000_000)
+    ap.add_argument("--cpu-frames", type=int, default=16)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0 and world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+            sys.exit(2)
+    import torch
+
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    from pointcloudprocessor_amd import capi, pipeline, synth
+
+    cam = synth.camera_dict(args.camera)
+    N, F = args.points, args.frames
+    t_setup = time.time()
+    eng = pipeline.HipEngine(local_rank)
+    eng.configure(cam)
+    # every rank samples its own slice of the (world x N)-point map
+    x, y, z, _ = synth.make_cloud(N, seed=synth.SEED + 1000 * rank)
+    eng.upload_cloud(x, y, z)
+    poses, _ = synth.make_trajectory(F)
+    eng.ctx.set_frames(poses)
+    W, H = cam["image_width"], cam["image_height"]
+    for f in range(F):
+        eng.ctx.upload_image(f, synth.make_image(f, W, H))
+    eng.ctx.synchronize()
+    t_setup = time.time() - t_setup
+
+    col = pipeline.PointCloudColorizer(eng, rank, world)
+    pinned = torch.empty(N, dtype=torch.int32).pin_memory()
+
+    def step():
+        col.run(download=False)
+        eng.ctx.download_result_packed(out_ptr=pinned.data_ptr())
+
+    def fence():
+        eng.ctx.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms_per_step = dt / max(args.steps, 1) * 1e3
+    value = world * N * F * args.steps / dt / 1e6  # Mpoints x frames / s, whole job
+
+    result = None
+    if rank == 0:
+        coloured = int(((pinned.numpy().view(np.uint32) >> 24) & 1).sum())
+        # ---- per-kernel times of one more step (hipEvents on the launch stream) ----
+        eng.ctx.timing_enable(True)
+        eng.ctx.timing_reset()
+        step()
+        kt = {eng.ctx.kernel_name(k): eng.ctx.timing_get(k) for k in (capi.K_DEPTH, capi.K_COLOUR, capi.K_MISC)}
+        # ---- roofline leg: the single-keyframe projection kernel, one launch per keyframe ----
+        eng.ctx.timing_reset()
+        for f in range(F):
+            eng.ctx.project_frame(f, device_only=True)
+        proj_ms, proj_launches = eng.ctx.timing_get(capi.K_PROJECT)
+        eng.ctx.timing_enable(False)
+        avg_s = proj_ms / max(proj_launches, 1) / 1e3
+        achieved = PROJ_BYTES_PER_POINT * N / avg_s / 1e9
+        roofline = {
+            "kernel": "k_project_frame",
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "traffic": None,
+            "bytes_per_launch": PROJ_BYTES_PER_POINT * N,
+            "avg_launch_ms": round(avg_s * 1e3, 4),
+            "launches": proj_launches,
+        }
+        # ---- MLS leg (Mpoints/s at r = 0.03, order 2, NONE upsampling) ----
+        mls = None
+        if not args.no_mls:
+            try:
+                mp = capi.default_mls_params()
+                mp.upsampling = 0
+                nm = min(args.mls_points, N)
+                if nm != N:
+                    eng.upload_cloud(x[:nm], y[:nm], z[:nm])
+                eng.ctx.mls_process(mp)  # warm-up (allocations)
+                eng.ctx.synchronize()
+                t1 = time.perf_counter()
+                m = eng.ctx.mls_process(mp)
+                eng.ctx.synchronize()
+                t_mls = time.perf_counter() - t1
+                mls = {"value": round(nm / t_mls / 1e6, 2), "unit": "Mpoints/s", "points": nm, "outputs": int(m),
+                       "radius": 0.03, "order": 2, "upsampling": "NONE", "ms": round(t_mls * 1e3, 2)}
+            except capi.PcpError as e:  # reported, never hidden
+                mls = {"error": str(e)}
+        # ---- CPU baseline: the oracle on a bounded sample, all host cores ----
+        cpu = None
+        if not args.no_cpu:
+            from oracle import oracle_capi as oc
+
+            ocam = oc.Camera()
+            for k, _ in oc.Camera._fields_:
+                setattr(ocam, k, cam[k])
+            ocp = oc.default_cull_params()
+            cores = oc.hardware_threads()
+            oc.colorize(ocam, ocp, x[:1000], y[:1000], z[:1000], poses[:1], [synth.make_image(0, W, H)], threads=cores,
+                        want_top=False)  # thread-pool warm-up
+
+            def cpu_run(cn, cf, threads):
+                imgs = [synth.make_image(f, W, H) for f in range(cf)]
+                t1 = time.perf_counter()
+                oc.colorize(ocam, ocp, x[:cn], y[:cn], z[:cn], poses[:cf], imgs, threads=threads, want_top=False)
+                return time.perf_counter() - t1
+
+            # calibrate, then size the sample for ~15 s of CPU work
+            cn, cf = min(args.cpu_points, N), min(args.cpu_frames, F)
+            t_cal = cpu_run(cn, cf, cores)
+            scale = 15.0 / max(t_cal, 1e-3)
+            if scale > 2.0:
+                cn2 = int(min(N, cn * min(scale, 10.0)))
+                cf2 = int(min(F, max(cf, cf * scale * cn / cn2)))
+                cn, cf = cn2, max(cf2, 1)
+                t_cpu = cpu_run(cn, cf, cores)
+            else:
+                t_cpu = t_cal
+            cf1 = max(min(cf, 4), 1)
+            cn1 = min(cn, 1_000_000)
+            t_cpu1 = cpu_run(cn1, cf1, 1)
+            cpu = {
+                "value": round(cn * cf / t_cpu / 1e6, 3),
+                "unit": "Mpoints*frames/s",
+                "cores": cores,
+                "kind": "port",
+                "sample": f"{cn} points x {cf} keyframes of the same scene ({t_cpu:.1f} s), oracle/pcp_oracle.c, "
+                          f"OpenMP {cores} threads",
+                "single_thread_value": round(cn1 * cf1 / t_cpu1 / 1e6, 3),
+            }
+        result = {
+            "metric": "Mpoints*frames/sec colorized",
+            "value": round(value, 1),
+            "unit": "Mpoints*frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32/f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{N} points/GPU x {F} keyframes @{W}x{H}, z-buffer cull /14, top-5 colour mean "
+                            f"(BASELINE configs[2] colourisation leg)",
+                "points_per_gpu": N,
+                "keyframes": F,
+                "camera": args.camera,
+                "parallelism": f"point-index shards x{world}, all-reduce(MIN) of depth maps",
+            },
+            "coloured_points_rank0": coloured,
+            "kernels_ms": {k: round(v[0], 3) for k, v in kt.items()},
+            "setup_s": round(t_setup, 1),
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "mls": mls,
+        }
+        if cpu:
+            result["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -173,6 +173,12 @@ int pcp_colour_finalise(pcp_context *ctx, uint8_t *out_rgb, uint8_t *out_has, in
                         float *out_top_score, uint32_t *out_top_rgb, int32_t *out_top_frame);
 /* reset + depth_pass(all) + colour_pass(all) + finalise */
 int pcp_colorize(pcp_context *ctx, uint8_t *out_rgb, uint8_t *out_has);
+/* visibility + colour + top-5 + smoothColors in one launch over ALL keyframes,
+ * given depth maps that already cover them (after pcp_depth_pass and, across
+ * point shards, the all-reduce(MIN)).  out_* nullable. */
+int pcp_colorize_from_depth(pcp_context *ctx, uint8_t *out_rgb, uint8_t *out_has);
+/* packed result r | g<<8 | b<<16 | has<<24, n words, one plain device-to-host copy */
+int pcp_download_result_packed(pcp_context *ctx, uint32_t *out_rgba);
 /* device address of the packed per-point result (r | g<<8 | b<<16 | has<<24),
  * valid after pcp_colour_finalise / pcp_colorize, for device-side gathers */
 int pcp_colour_result_device(pcp_context *ctx, void **device_ptr, int64_t *n_words);

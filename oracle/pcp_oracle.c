@@ -301,24 +301,22 @@ static void depth_pass(const orc_camera *cam, const orc_cull_params *cp, const f
     return;
   }
 #ifdef _OPENMP
-#pragma omp parallel num_threads(threads)
+  /* shared map, lock-free MIN on the bit pattern of the positive fp32 range
+   * (unsigned order == float order), same final map as the sequential loop */
   {
-    float *priv = (float *)malloc((size_t)cells * sizeof(float));
-    depth_map_fill(priv, cells);
-#pragma omp for schedule(static)
+    uint32_t *bits = (uint32_t *)map;
+#pragma omp parallel for schedule(static) num_threads(threads)
     for (int64_t i = 0; i < n; ++i) {
       projected p;
       project_one(cam, cp, m, x[i], y[i], z[i], &p);
       if (p.cell < 0) continue;
-      if (p.range > (double)priv[p.cell]) continue;
-      priv[p.cell] = (float)p.range;
+      const float rf = (float)p.range;
+      uint32_t nb;
+      memcpy(&nb, &rf, 4);
+      uint32_t cur = __atomic_load_n(&bits[p.cell], __ATOMIC_RELAXED);
+      while (nb < cur && !__atomic_compare_exchange_n(&bits[p.cell], &cur, nb, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+      }
     }
-#pragma omp critical
-    {
-      for (int64_t c = 0; c < cells; ++c)
-        if (priv[c] < map[c]) map[c] = priv[c];
-    }
-    free(priv);
   }
 #endif
 }
@@ -453,6 +451,9 @@ int orc_colorize(const orc_camera *cam, const orc_cull_params *cp, const float *
     free(state);
     return -1;
   }
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nt)
+#endif
   for (int64_t i = 0; i < n; ++i) {
     state[i].count = 0;
     for (int k = 0; k < ORC_TOPM; ++k) {
@@ -482,6 +483,9 @@ int orc_colorize(const orc_camera *cam, const orc_cull_params *cp, const float *
       top5_insert(&state[i], fs, rgb, f);                      /* :590-591 */
     }
   }
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nt)
+#endif
   for (int64_t i = 0; i < n; ++i) {
     uint8_t rgb[3];
     top5_finalise(&state[i], rgb);

@@ -315,6 +315,23 @@ class Context:
         self._check(self.lib.pcp_colorize(self.h, _ptr(rgb), _ptr(has)))
         return dict(rgb=rgb, has=has)
 
+    def colorize_from_depth(self, download: bool = True):
+        n = self.n
+        rgb = np.empty((n, 3), np.uint8) if download else None
+        has = np.empty(n, np.uint8) if download else None
+        self._check(self.lib.pcp_colorize_from_depth(self.h, _ptr(rgb), _ptr(has)))
+        return dict(rgb=rgb, has=has)
+
+    def download_result_packed(self, out: np.ndarray | None = None, out_ptr: int | None = None):
+        """n uint32 words r | g<<8 | b<<16 | has<<24 (out_ptr: e.g. a pinned host buffer)."""
+        if out_ptr is not None:
+            self._check(self.lib.pcp_download_result_packed(self.h, C.c_void_p(out_ptr)))
+            return None
+        if out is None:
+            out = np.empty(self.n, np.uint32)
+        self._check(self.lib.pcp_download_result_packed(self.h, _ptr(out)))
+        return out
+
     def colour_result_device(self):
         p = C.c_void_p()
         n = C.c_int64()

@@ -865,6 +865,25 @@ int pcp_colorize(pcp_context *ctx, uint8_t *out_rgb, uint8_t *out_has) {
   return publish_result(ctx, out_rgb, out_has);
 }
 
+int pcp_colorize_from_depth(pcp_context *ctx, uint8_t *out_rgb, uint8_t *out_has) {
+  int rc = check_ready(ctx, "pcp_colorize_from_depth", true);
+  if (rc != PCP_OK) return rc;
+  pcp_colour_reset(ctx);
+  if ((rc = colour_pass_impl(ctx, 0, ctx->n_frames, true)) != PCP_OK) return rc;
+  return publish_result(ctx, out_rgb, out_has);
+}
+
+int pcp_download_result_packed(pcp_context *ctx, uint32_t *out_rgba) {
+  if (!ctx) return PCP_ERR_INVALID;
+  if (!ctx->colour_result_live)
+    return set_error(ctx, PCP_ERR_STATE, "pcp_download_result_packed: no result (call pcp_colorize / pcp_colour_finalise)");
+  if (!out_rgba && ctx->n > 0) return set_error(ctx, PCP_ERR_INVALID, "pcp_download_result_packed: NULL output");
+  if (ctx->n > 0)
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(out_rgba, ctx->rgba.p, static_cast<size_t>(ctx->n) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PCP_OK;
+}
+
 int pcp_colour_result_device(pcp_context *ctx, void **device_ptr, int64_t *n_words) {
   if (!ctx) return PCP_ERR_INVALID;
   if (!ctx->colour_result_live)

@@ -1,0 +1,151 @@
+"""Host-side mirror of the reference's operator interface for the hot path, on
+top of the C ABI (capi.py).  Names follow the reference:
+
+  ViewCulling.cull            vlcal::ViewCulling::cull     (view_culling.hpp:34)
+  PointCloudColorizer.run     pcdColorizationAndSmooth     (PointCloudProcessor.cpp:474-602)
+  CloudSmooth.process         CloudSmooth::process         (cloudSmooth.cpp:77-185)
+
+plus the point-index sharding of SURVEY.md section 8(e): every rank owns a
+contiguous slice of the map, all keyframes / images are replicated, and the one
+exchange step is an all-reduce(MIN) of the per-keyframe depth maps.  Per-point
+results (top-5 lists, colours) are rank-local, so no other collective is on the
+data path; outputs are assembled with an all-gather when asked for.
+
+The compute engine is libpcp_hip.so; there is no CPU engine in this package.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import capi
+
+
+def shard_bounds(n: int, rank: int, world: int):
+    """Contiguous index range of `rank` (first n % world ranks get one extra point)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class _DeviceArray:
+    """Minimal __cuda_array_interface__ carrier for a raw device pointer."""
+
+    def __init__(self, ptr: int, n: int, typestr: str = "<f4"):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class HipEngine:
+    """One GPU worth of the hot path (one pcp_context)."""
+
+    def __init__(self, device: int = 0):
+        self.ctx = capi.Context(device)
+        self.device = device
+
+    def configure(self, camera: dict | capi.Camera, cull: capi.CullParams | None = None):
+        cam = camera if isinstance(camera, capi.Camera) else capi.camera_from_dict(camera)
+        self.ctx.set_camera(cam, cull)
+
+    def upload_cloud(self, x, y, z):
+        self.ctx.upload_cloud(x, y, z)
+
+    def set_keyframes(self, poses, images=None, masks=None, T_opt=None):
+        self.ctx.set_frames(poses, T_opt)
+        if images is not None:
+            for f, im in enumerate(images):
+                self.ctx.upload_image(f, im)
+        if masks is not None:
+            for f, m in enumerate(masks):
+                if m is not None:
+                    self.ctx.upload_mask(f, m)
+
+    # hooks used by the sharded driver
+    def depth_pass(self):
+        self.ctx.depth_pass()
+
+    def depth_maps_tensor(self):
+        """torch view (no copy) of the device-resident depth maps, for RCCL."""
+        import torch
+
+        ptr, n = self.ctx.depth_maps_device()
+        self.ctx.synchronize()
+        return torch.as_tensor(_DeviceArray(ptr, n), device=f"cuda:{self.device}")
+
+    def colour_from_depth(self, download=True):
+        return self.ctx.colorize_from_depth(download=download)
+
+    def close(self):
+        self.ctx.close()
+
+
+class ViewCulling:
+    """vlcal::ViewCulling with the z-buffer routine (view_culling.cpp:52-174)."""
+
+    def __init__(self, engine: HipEngine):
+        self.engine = engine
+
+    def cull(self, keyframe: int):
+        """Returns (indices kept, in input order; depth map)."""
+        keep, dmap, _ = self.engine.ctx.cull_frame(keyframe)
+        return np.nonzero(keep)[0].astype(np.int32), dmap
+
+
+class PointCloudColorizer:
+    """pcdColorizationAndSmooth over a (possibly sharded) map."""
+
+    def __init__(self, engine, rank: int = 0, world: int = 1, group=None):
+        self.engine = engine
+        self.rank = rank
+        self.world = world
+        self.group = group
+
+    def run(self, download: bool = True):
+        """Local points' colours: dict(rgb (n,3) uint8, has (n,) uint8)."""
+        self.engine.depth_pass()
+        if self.world > 1:
+            import torch.distributed as dist
+
+            t = self.engine.depth_maps_tensor()
+            # ranges are positive finite floats: float MIN == the uint-bits MIN the kernel used
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            if t.is_cuda:
+                import torch
+
+                torch.cuda.current_stream().synchronize()
+        return self.engine.colour_from_depth(download=download)
+
+    def gather(self, local: dict, n_total: int):
+        """All-gather the per-shard colours into full-length arrays (every rank)."""
+        if self.world == 1:
+            return local
+        import torch
+        import torch.distributed as dist
+
+        sizes = [shard_bounds(n_total, r, self.world) for r in range(self.world)]
+        maxn = max(hi - lo for lo, hi in sizes)
+        packed = np.zeros((maxn, 4), np.uint8)
+        lo, hi = sizes[self.rank]
+        packed[: hi - lo, :3] = local["rgb"]
+        packed[: hi - lo, 3] = local["has"]
+        dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        mine = torch.from_numpy(packed).to(dev)
+        outs = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(outs, mine, group=self.group)
+        rgb = np.zeros((n_total, 3), np.uint8)
+        has = np.zeros(n_total, np.uint8)
+        for r, (lo, hi) in enumerate(sizes):
+            a = outs[r].cpu().numpy()
+            rgb[lo:hi] = a[: hi - lo, :3]
+            has[lo:hi] = a[: hi - lo, 3]
+        return dict(rgb=rgb, has=has)
+
+
+class CloudSmooth:
+    """CloudSmooth::process: MovingLeastSquares (+ optional SOR brackets)."""
+
+    def __init__(self, engine: HipEngine, params: capi.MLSParams | None = None):
+        self.engine = engine
+        self.params = params if params is not None else capi.default_mls_params()
+
+    def process(self):
+        m = self.engine.ctx.mls_process(self.params)
+        return self.engine.ctx.mls_fetch(m)

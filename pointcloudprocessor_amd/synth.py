@@ -209,19 +209,33 @@ def _hash32(a: np.ndarray) -> np.ndarray:
     return a
 
 
+_NOISE_CACHE: dict = {}
+
+
+def _noise_plane(width: int, height: int, seed: int) -> np.ndarray:
+    """(H,W) uint32 hash noise, computed once per (size, seed)."""
+    key = (width, height, seed)
+    if key not in _NOISE_CACHE:
+        v, u = np.meshgrid(np.arange(height, dtype=np.uint32), np.arange(width, dtype=np.uint32), indexing="ij")
+        _NOISE_CACHE.clear()
+        _NOISE_CACHE[key] = _hash32((v * np.uint32(width) + u) ^ np.uint32(seed & 0xFFFFFFFF))
+    return _NOISE_CACHE[key]
+
+
 def make_image(frame: int, width: int, height: int, seed: int = SEED) -> np.ndarray:
-    """Procedural BGR8 (H,W,3): frame-seeded smooth gradient + 8-bit hash noise;
-    stands for the image *after* the HSV round trip (Appendix B5)."""
-    v, u = np.meshgrid(np.arange(height, dtype=np.uint32), np.arange(width, dtype=np.uint32), indexing="ij")
-    h0 = _hash32(np.array([seed * 7919 + frame * 104729 + 13], dtype=np.uint64).astype(np.uint32))[0]
-    lin = v * np.uint32(width) + u
-    noise = _hash32(lin ^ h0)
-    a = [int((h0 >> (8 * k)) & 0xFF) for k in range(3)]
+    """Procedural BGR8 (H,W,3): frame-seeded smooth gradient + 6-bit hash noise
+    (a frame-dependent roll of one cached noise plane); stands for the image
+    *after* the HSV round trip (Appendix B5).  Green is never 0, so a coloured
+    point can never be mistaken for the never-seen (0,0,0)."""
+    h0 = int(_hash32(np.array([(seed * 7919 + frame * 104729 + 13) & 0xFFFFFFFF], dtype=np.uint32))[0])
+    noise = np.roll(_noise_plane(width, height, seed), (h0 % height, (h0 >> 12) % width), axis=(0, 1))
+    u = np.arange(width, dtype=np.uint32)[None, :]
+    v = np.arange(height, dtype=np.uint32)[:, None]
     img = np.empty((height, width, 3), np.uint8)
     for c in range(3):
-        grad = (u * np.uint32(3 + c) + v * np.uint32(5 - c)) // np.uint32(16) + np.uint32(a[c])
+        a = (h0 >> (8 * c)) & 0xFF
+        grad = (u * np.uint32(3 + c)) // np.uint32(16) + (v * np.uint32(5 - c)) // np.uint32(16) + np.uint32(a)
         img[:, :, c] = ((grad + ((noise >> np.uint32(8 * c)) & np.uint32(0x3F))) & np.uint32(0xFF)).astype(np.uint8)
-    # never emit pure black so "never seen" (0,0,0) stays distinguishable in tests
     img[:, :, 1] |= 1
     return img
 
