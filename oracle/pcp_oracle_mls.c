@@ -448,7 +448,8 @@ static void mls_project_point(const mls_result *r, const double p[3], int requir
 static mls_result *mls_compute_all(const float *x, const float *y, const float *z, int64_t n,
                                    const orc_mls_params *p, uint8_t *has) {
   grid g;
-  if (grid_build(&g, x, y, z, n, (float)p->search_radius) != 0) return NULL;
+  /* cell 0.1 % above r so that reach = 1 cell is safe against fp32 slop in the cell assignment */
+  if (grid_build(&g, x, y, z, n, (float)p->search_radius * 1.001f) != 0) return NULL;
   mls_result *res = (mls_result *)calloc((size_t)(n > 0 ? n : 1), sizeof(mls_result));
   const float sq_radius = (float)(p->search_radius * p->search_radius);
   int nt = 1;

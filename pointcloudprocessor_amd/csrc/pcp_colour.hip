@@ -468,19 +468,20 @@ static int ensure_state(pcp_context *ctx) {
   return PCP_OK;
 }
 
-// ordered compaction of ctx->s_keep[0..n) into ctx->s_cell (index list); returns count
-static int compact_flags(pcp_context *ctx, int64_t n, int64_t capacity, bool want_indices, int64_t *count) {
+// ordered compaction of a byte flag array into an index list (nullable); returns the count
+int compact_flags(pcp_context *ctx, const uint8_t *flags, int64_t n, int32_t *out_index, int64_t capacity,
+                  int64_t *count) {
   const int64_t tiles = std::max<int64_t>(1, div_up(n, kTile));
-  PCP_HIP_TRY(ctx, ctx->s_pixel.ensure(static_cast<size_t>(tiles) + 4));  // tile counts / offsets
+  PCP_HIP_TRY(ctx, ctx->s_tiles.ensure(static_cast<size_t>(tiles) + 4));
   PCP_HIP_TRY(ctx, ctx->s_counter.ensure(4));
   {
     LaunchTimer t(ctx, PCP_K_MISC);
-    hipLaunchKernelGGL(k_tile_count, dim3(static_cast<uint32_t>(tiles)), dim3(kBlock), 0, ctx->stream, ctx->s_keep.p, n,
-                       ctx->s_pixel.p);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->s_pixel.p, tiles, ctx->s_counter.p);
-    if (want_indices)
-      hipLaunchKernelGGL(k_tile_scatter, dim3(static_cast<uint32_t>(tiles)), dim3(kBlock), 0, ctx->stream,
-                         ctx->s_keep.p, n, ctx->s_pixel.p, ctx->s_cell.p, capacity);
+    hipLaunchKernelGGL(k_tile_count, dim3(static_cast<uint32_t>(tiles)), dim3(kBlock), 0, ctx->stream, flags, n,
+                       ctx->s_tiles.p);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->s_tiles.p, tiles, ctx->s_counter.p);
+    if (out_index)
+      hipLaunchKernelGGL(k_tile_scatter, dim3(static_cast<uint32_t>(tiles)), dim3(kBlock), 0, ctx->stream, flags, n,
+                         ctx->s_tiles.p, out_index, capacity);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   unsigned long long total = 0;
@@ -615,7 +616,7 @@ int pcp_cull_frame(pcp_context *ctx, int32_t frame, uint8_t *out_keep, int64_t *
   }
   if (out_kept) {
     int64_t cnt = 0;
-    if (n > 0 && (rc = compact_flags(ctx, n, 0, false, &cnt)) != PCP_OK) return rc;
+    if (n > 0 && (rc = compact_flags(ctx, ctx->s_keep.p, n, nullptr, 0, &cnt)) != PCP_OK) return rc;
     *out_kept = cnt;
   }
   if (out_keep && n > 0)
@@ -649,7 +650,7 @@ int pcp_frame_visible(pcp_context *ctx, int32_t frame, int64_t capacity, int32_t
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   int64_t m = 0;
-  if ((rc = compact_flags(ctx, n, static_cast<int64_t>(plane), true, &m)) != PCP_OK) return rc;
+  if ((rc = compact_flags(ctx, ctx->s_keep.p, n, ctx->s_cell.p, static_cast<int64_t>(plane), &m)) != PCP_OK) return rc;
   if (out_count) *out_count = m;
   const int64_t take = std::min(m, capacity);
   if (take == 0) return PCP_OK;

@@ -305,6 +305,15 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->s_keep.release();
   ctx->s_u32.release();
   ctx->s_counter.release();
+  ctx->s_tiles.release();
+  ctx->g_cell.release();
+  ctx->g_rank.release();
+  ctx->g_start.release();
+  ctx->g_order.release();
+  ctx->g_xyz.release();
+  ctx->m_tmp.release();
+  ctx->m_state.release();
+  ctx->m_flag.release();
   ctx->mls_xyz.release();
   ctx->mls_normal.release();
   ctx->mls_curv.release();

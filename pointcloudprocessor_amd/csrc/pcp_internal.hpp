@@ -126,8 +126,15 @@ struct pcp_context {
   pcp::DevBuf<uint8_t> s_keep;
   pcp::DevBuf<uint32_t> s_u32;
   pcp::DevBuf<unsigned long long> s_counter;
+  pcp::DevBuf<int32_t> s_tiles;
 
-  // MLS results
+  // MLS: uniform grid (cell id / in-cell rank per point, cell starts, cell-sorted
+  // order + coordinates), per-input-point results, compacted outputs
+  pcp::DevBuf<int32_t> g_cell, g_rank, g_start, g_order;
+  pcp::DevBuf<float> g_xyz;      // cell-sorted x[n] y[n] z[n]
+  pcp::DevBuf<float> m_tmp;      // 7 floats per input point (xyz, normal, curvature), input order
+  pcp::DevBuf<double> m_state;   // per-point MLSResult (mean, axes, c_vec ...) for upsampling
+  pcp::DevBuf<uint8_t> m_flag;   // n
   pcp::DevBuf<float> mls_xyz, mls_normal, mls_curv;
   pcp::DevBuf<int32_t> mls_index;
   int64_t mls_count = 0;
@@ -162,6 +169,10 @@ struct LaunchTimer {
 };
 
 int drain_timing(pcp_context *ctx);
+
+// ordered compaction of a device byte-flag array (pcp_colour.hip): index list (nullable) + count
+int compact_flags(pcp_context *ctx, const uint8_t *flags, int64_t n, int32_t *out_index, int64_t capacity,
+                  int64_t *count);
 
 inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -1,14 +1,522 @@
-// pcp_mls.hip -- placeholder until the MLS kernels land (next commit).
+// pcp_mls.hip -- the enableMLS path on gfx950: pcl::MovingLeastSquares
+// (radius search r, order-2 weighted polynomial fit, SIMPLE projection,
+// upsampling NONE) as CloudSmooth::process configures it
+// (PCP/src/cloudSmooth.cpp:124-154, values PCP/src/PointCloudProcessor.cpp:67-86).
+//
+// The kd-tree of the reference is replaced by a uniform grid (cell >= r) built
+// on the device: cell histogram -> exclusive scan -> scatter -> per-cell order
+// fix-up (so results do not depend on atomic arrival order).  Points are then
+// processed in cell order: the 64 lanes of a wavefront sit in one or two cells
+// and walk the same 9 contiguous runs of neighbour candidates, so their loads
+// are wave-wide broadcasts served by L1/L2.
+//
+// Numerics (Appendix A7): neighbour test in fp32 exactly as FLANN's L2_Simple
+// ((dx*dx + dy*dy) + dz*dz < f32(r*r)); everything after it in fp64.  Moments
+// are accumulated relative to the query point (exact differences of fp32
+// values), which removes the reference's second neighbour sweep without losing
+// digits.  Parity bar: 1e-4 relative on positions, normals up to sign.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+
 #include "pcp_internal.hpp"
+#include "pcp_scan.hpp"
+
+namespace pcp {
+
+constexpr int kMB = 256;
+
+struct GridDesc {
+  float minx, miny, minz, inv_cell;
+  int32_t nx, ny, nz;
+  int32_t reach;  // cells to visit on each side: ceil(r / cell)
+};
+
+__device__ __forceinline__ void grid_coords(const GridDesc &g, float x, float y, float z, int32_t &ix, int32_t &iy,
+                                            int32_t &iz) {
+  ix = min(max(static_cast<int32_t>(floorf((x - g.minx) * g.inv_cell)), 0), g.nx - 1);
+  iy = min(max(static_cast<int32_t>(floorf((y - g.miny) * g.inv_cell)), 0), g.ny - 1);
+  iz = min(max(static_cast<int32_t>(floorf((z - g.minz) * g.inv_cell)), 0), g.nz - 1);
+}
+
+// cell id and arrival rank of every input point; histogram in `count`
+__global__ __launch_bounds__(kMB) void k_grid_count(const float *__restrict__ x, const float *__restrict__ y,
+                                                    const float *__restrict__ z, int64_t n, GridDesc g,
+                                                    int32_t *__restrict__ cell, int32_t *__restrict__ rank,
+                                                    int32_t *__restrict__ count) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  if (i >= n) return;
+  int32_t ix, iy, iz;
+  grid_coords(g, x[i], y[i], z[i], ix, iy, iz);
+  const int32_t c = (iz * g.ny + iy) * g.nx + ix;
+  cell[i] = c;
+  rank[i] = atomicAdd(count + c, 1);
+}
+
+__global__ __launch_bounds__(kMB) void k_grid_scatter(int64_t n, const int32_t *__restrict__ cell,
+                                                      const int32_t *__restrict__ rank,
+                                                      const int32_t *__restrict__ start,
+                                                      int32_t *__restrict__ order) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  if (i >= n) return;
+  order[start[cell[i]] + rank[i]] = static_cast<int32_t>(i);
+}
+
+// make the order inside every cell ascending in the input index (deterministic
+// neighbour order), then gather the coordinates into cell order.  One lane per
+// point: it counts how many members of its cell precede it.
+__global__ __launch_bounds__(kMB) void k_grid_order(const float *__restrict__ x, const float *__restrict__ y,
+                                                    const float *__restrict__ z, int64_t n, int64_t plane,
+                                                    const int32_t *__restrict__ cell,
+                                                    const int32_t *__restrict__ start,
+                                                    const int32_t *__restrict__ order_in,
+                                                    int32_t *__restrict__ order_out, float *__restrict__ sxyz) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  if (i >= n) return;
+  const int32_t c = cell[i];
+  const int32_t b = start[c], e = start[c + 1];
+  int32_t before = 0;
+  for (int32_t k = b; k < e; ++k) before += order_in[k] < static_cast<int32_t>(i) ? 1 : 0;
+  const int64_t j = b + before;
+  order_out[j] = static_cast<int32_t>(i);
+  sxyz[j] = x[i];
+  sxyz[plane + j] = y[i];
+  sxyz[2 * plane + j] = z[i];
+}
+
+// ---- pcl::eigen33 smallest eigenpair (common/impl/eigen.hpp) [upstream] --------
+__device__ __forceinline__ void roots2(double b, double c, double &r0, double &r1, double &r2) {
+  r0 = 0.0;
+  double d = b * b - 4.0 * c;
+  if (d < 0.0) d = 0.0;
+  const double sd = sqrt(d);
+  r2 = 0.5 * (b + sd);
+  r1 = 0.5 * (b - sd);
+}
+
+__device__ __forceinline__ void swap2(double &a, double &b) {
+  const double t = a;
+  a = b;
+  b = t;
+}
+
+__device__ __noinline__ void smallest_eigenpair(const double m[6] /* xx xy xz yy yz zz */, double &ev, double n[3]) {
+  double scale = fmax(fmax(fmax(fabs(m[0]), fabs(m[1])), fmax(fabs(m[2]), fabs(m[3]))), fmax(fabs(m[4]), fabs(m[5])));
+  if (scale <= DBL_MIN) scale = 1.0;
+  const double a00 = m[0] / scale, a01 = m[1] / scale, a02 = m[2] / scale, a11 = m[3] / scale, a12 = m[4] / scale,
+               a22 = m[5] / scale;
+  const double c0 = a00 * a11 * a22 + 2.0 * a01 * a02 * a12 - a00 * a12 * a12 - a11 * a02 * a02 - a22 * a01 * a01;
+  const double c1 = a00 * a11 - a01 * a01 + a00 * a22 - a02 * a02 + a11 * a22 - a12 * a12;
+  const double c2 = a00 + a11 + a22;
+  double r0, r1, r2;
+  if (fabs(c0) < DBL_EPSILON) {
+    roots2(c2, c1, r0, r1, r2);
+  } else {
+    const double inv3 = 1.0 / 3.0;
+    const double sqrt3 = sqrt(3.0);
+    const double c2_3 = c2 * inv3;
+    double a_3 = (c1 - c2 * c2_3) * inv3;
+    if (a_3 > 0.0) a_3 = 0.0;
+    const double half_b = 0.5 * (c0 + c2_3 * (2.0 * c2_3 * c2_3 - c1));
+    double q = half_b * half_b + a_3 * a_3 * a_3;
+    if (q > 0.0) q = 0.0;
+    const double rho = sqrt(-a_3);
+    const double theta = atan2(sqrt(-q), half_b) * inv3;
+    const double ct = cos(theta), st = sin(theta);
+    r0 = c2_3 + 2.0 * rho * ct;
+    r1 = c2_3 - rho * (ct + sqrt3 * st);
+    r2 = c2_3 - rho * (ct - sqrt3 * st);
+    if (r0 >= r1) swap2(r0, r1);
+    if (r1 >= r2) {
+      swap2(r1, r2);
+      if (r0 >= r1) swap2(r0, r1);
+    }
+    if (r0 <= 0.0) roots2(c2, c1, r0, r1, r2);
+  }
+  ev = r0 * scale;
+  // getLargest3x3Eigenvector of (A - r0 I): longest cross product of two rows
+  const double s00 = a00 - r0, s11 = a11 - r0, s22 = a22 - r0;
+  const double k0x = a01 * a12 - a02 * s11, k0y = a02 * a01 - s00 * a12, k0z = s00 * s11 - a01 * a01;  // row0 x row1
+  const double k1x = a01 * s22 - a02 * a12, k1y = a02 * a02 - s00 * s22, k1z = s00 * a12 - a01 * a02;  // row0 x row2
+  const double k2x = s11 * s22 - a12 * a12, k2y = a12 * a02 - a01 * s22, k2z = a01 * a12 - s11 * a02;  // row1 x row2
+  const double l0 = (k0x * k0x + k0y * k0y) + k0z * k0z;
+  const double l1 = (k1x * k1x + k1y * k1y) + k1z * k1z;
+  const double l2 = (k2x * k2x + k2y * k2y) + k2z * k2z;
+  double vx = k0x, vy = k0y, vz = k0z, l = l0;
+  if (l1 > l) {
+    vx = k1x; vy = k1y; vz = k1z; l = l1;
+  }
+  if (l2 > l) {
+    vx = k2x; vy = k2y; vz = k2z; l = l2;
+  }
+  const double len = sqrt(l);
+  n[0] = vx / len;
+  n[1] = vy / len;
+  n[2] = vz / len;
+}
+
+// doubles kept per input point for the upsampling stage (MLSResult)
+constexpr int kMlsState = 22;  // mean3 normal3 u3 v3 c6 curvature K valid(+fitted) pad
+
+struct MlsArgs {
+  const float *sx, *sy, *sz;     // cell-sorted coordinates
+  const int32_t *order;          // cell-sorted -> input index
+  const int32_t *start;          // cell starts (ncell + 1)
+  int64_t n;
+  GridDesc g;
+  float sq_radius;               // f32(r*r): kdtree_flann radiusSearch [upstream]
+  double inv_sq_radius;          // 1 / (r*r), weight exp(-d^2 / r^2) (B13)
+  int32_t order_poly;
+  float *tmp;                    // 7 floats per input point
+  uint8_t *flag;                 // per input point
+  double *state;                 // kMlsState doubles per input point (nullable)
+};
+
+__device__ __forceinline__ float sqdist_f32(float ax, float ay, float az, float bx, float by, float bz) {
+  const float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+__global__ __launch_bounds__(kMB) void k_mls_fit(MlsArgs a) {
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  if (j >= a.n) return;
+  const int32_t i = a.order[j];
+  const float qx = a.sx[j], qy = a.sy[j], qz = a.sz[j];
+  int32_t cx, cy, cz;
+  grid_coords(a.g, qx, qy, qz, cx, cy, cz);
+  const int32_t x0 = max(cx - a.g.reach, 0), x1 = min(cx + a.g.reach, a.g.nx - 1);
+  const int32_t y0 = max(cy - a.g.reach, 0), y1 = min(cy + a.g.reach, a.g.ny - 1);
+  const int32_t z0 = max(cz - a.g.reach, 0), z1 = min(cz + a.g.reach, a.g.nz - 1);
+
+  // sweep 1: neighbour count and moments of (p - q)
+  int32_t K = 0;
+  double s1x = 0, s1y = 0, s1z = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+  for (int32_t zz = z0; zz <= z1; ++zz)
+    for (int32_t yy = y0; yy <= y1; ++yy) {
+      const int32_t row = (zz * a.g.ny + yy) * a.g.nx;
+      const int32_t b = a.start[row + x0], e = a.start[row + x1 + 1];
+      for (int32_t k = b; k < e; ++k) {
+        const float px = a.sx[k], py = a.sy[k], pz = a.sz[k];
+        if (sqdist_f32(px, py, pz, qx, qy, qz) < a.sq_radius) {
+          const double dx = static_cast<double>(px) - static_cast<double>(qx);
+          const double dy = static_cast<double>(py) - static_cast<double>(qy);
+          const double dz = static_cast<double>(pz) - static_cast<double>(qz);
+          ++K;
+          s1x += dx; s1y += dy; s1z += dz;
+          sxx += dx * dx; sxy += dx * dy; sxz += dx * dz;
+          syy += dy * dy; syz += dy * dz; szz += dz * dz;
+        }
+      }
+    }
+  if (K < 3) {  // MovingLeastSquares::performProcessing skips the point
+    a.flag[i] = 0;
+    return;
+  }
+  const double invK = 1.0 / static_cast<double>(K);
+  const double mx = s1x * invK, my = s1y * invK, mz = s1z * invK;  // centroid - q
+  double C[6];
+  C[0] = sxx - s1x * mx;
+  C[1] = sxy - s1x * my;
+  C[2] = sxz - s1x * mz;
+  C[3] = syy - s1y * my;
+  C[4] = syz - s1y * mz;
+  C[5] = szz - s1z * mz;
+  double ev, nrm[3];
+  smallest_eigenpair(C, ev, nrm);
+  float *out = a.tmp + static_cast<int64_t>(i) * 7;
+  double *st = a.state ? a.state + static_cast<int64_t>(i) * kMlsState : nullptr;
+  const double Qx = qx, Qy = qy, Qz = qz;
+  if (!isfinite(nrm[0]) || !isfinite(nrm[1]) || !isfinite(nrm[2])) {
+    out[0] = qx; out[1] = qy; out[2] = qz;
+    out[3] = 0.0f; out[4] = 0.0f; out[5] = 0.0f;
+    out[6] = 0.0f;
+    a.flag[i] = 1;
+    if (st) {
+      for (int k = 0; k < kMlsState; ++k) st[k] = 0.0;
+      st[0] = Qx; st[1] = Qy; st[2] = Qz;
+    }
+    return;
+  }
+  // projected query point: distance = (q - centroid) . n
+  const double distance = -((mx * nrm[0] + my * nrm[1]) + mz * nrm[2]);
+  const double meanx = Qx - distance * nrm[0], meany = Qy - distance * nrm[1], meanz = Qz - distance * nrm[2];
+  double curv = (C[0] + C[3]) + C[5];
+  if (curv != 0.0) curv = fabs(ev / curv);
+  // Darboux frame: v = n.unitOrthogonal(), u = n x v (Eigen OrthoMethods.h)
+  double vx, vy, vz;
+  if (!(fabs(nrm[0]) <= fabs(nrm[2]) * 1e-12) || !(fabs(nrm[1]) <= fabs(nrm[2]) * 1e-12)) {
+    const double inv = 1.0 / sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1]);
+    vx = -nrm[1] * inv; vy = nrm[0] * inv; vz = 0.0;
+  } else {
+    const double inv = 1.0 / sqrt(nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+    vx = 0.0; vy = -nrm[2] * inv; vz = nrm[1] * inv;
+  }
+  const double ux = nrm[1] * vz - nrm[2] * vy, uy = nrm[2] * vx - nrm[0] * vz, uz = nrm[0] * vy - nrm[1] * vx;
+
+  double c[6] = {0, 0, 0, 0, 0, 0};
+  bool fitted = false;
+  if (a.order_poly > 1 && K >= 6) {
+    // sweep 2: weighted normal equations of the 6 monomials (1, v, v^2, u, uv, u^2)
+    double A00 = 0, A01 = 0, A02 = 0, A03 = 0, A04 = 0, A05 = 0, A11 = 0, A12 = 0, A13 = 0, A14 = 0, A15 = 0, A22 = 0,
+           A23 = 0, A24 = 0, A25 = 0, A33 = 0, A34 = 0, A35 = 0, A44 = 0, A45 = 0, A55 = 0;
+    double b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0;
+    for (int32_t zz = z0; zz <= z1; ++zz)
+      for (int32_t yy = y0; yy <= y1; ++yy) {
+        const int32_t row = (zz * a.g.ny + yy) * a.g.nx;
+        const int32_t b = a.start[row + x0], e = a.start[row + x1 + 1];
+        for (int32_t k = b; k < e; ++k) {
+          const float px = a.sx[k], py = a.sy[k], pz = a.sz[k];
+          if (sqdist_f32(px, py, pz, qx, qy, qz) < a.sq_radius) {
+            const double dx = static_cast<double>(px) - meanx, dy = static_cast<double>(py) - meany,
+                         dz = static_cast<double>(pz) - meanz;
+            const double w = exp(-((dx * dx + dy * dy) + dz * dz) * a.inv_sq_radius);
+            const double uc = (dx * ux + dy * uy) + dz * uz;
+            const double vc = (dx * vx + dy * vy) + dz * vz;
+            const double f = (dx * nrm[0] + dy * nrm[1]) + dz * nrm[2];
+            const double p1 = vc, p2 = vc * vc, p3 = uc, p4 = uc * vc, p5 = uc * uc;
+            const double w1 = w * p1, w2 = w * p2, w3 = w * p3, w4 = w * p4, w5 = w * p5;
+            A00 += w; A01 += w1; A02 += w2; A03 += w3; A04 += w4; A05 += w5;
+            A11 += w1 * p1; A12 += w1 * p2; A13 += w1 * p3; A14 += w1 * p4; A15 += w1 * p5;
+            A22 += w2 * p2; A23 += w2 * p3; A24 += w2 * p4; A25 += w2 * p5;
+            A33 += w3 * p3; A34 += w3 * p4; A35 += w3 * p5;
+            A44 += w4 * p4; A45 += w4 * p5;
+            A55 += w5 * p5;
+            b0 += w * f; b1 += w1 * f; b2 += w2 * f; b3 += w3 * f; b4 += w4 * f; b5 += w5 * f;
+          }
+        }
+      }
+    // LLT (lower) + forward / backward substitution, fully unrolled in registers
+    bool ok = true;
+    double L00, L10, L20, L30, L40, L50, L11, L21, L31, L41, L51, L22, L32, L42, L52, L33, L43, L53, L44, L54, L55;
+    double d;
+    d = A00; ok = ok && d > 0.0; L00 = sqrt(d);
+    L10 = A01 / L00; L20 = A02 / L00; L30 = A03 / L00; L40 = A04 / L00; L50 = A05 / L00;
+    d = A11 - L10 * L10; ok = ok && d > 0.0; L11 = sqrt(d);
+    L21 = (A12 - L20 * L10) / L11; L31 = (A13 - L30 * L10) / L11; L41 = (A14 - L40 * L10) / L11;
+    L51 = (A15 - L50 * L10) / L11;
+    d = A22 - L20 * L20 - L21 * L21; ok = ok && d > 0.0; L22 = sqrt(d);
+    L32 = (A23 - L30 * L20 - L31 * L21) / L22; L42 = (A24 - L40 * L20 - L41 * L21) / L22;
+    L52 = (A25 - L50 * L20 - L51 * L21) / L22;
+    d = A33 - L30 * L30 - L31 * L31 - L32 * L32; ok = ok && d > 0.0; L33 = sqrt(d);
+    L43 = (A34 - L40 * L30 - L41 * L31 - L42 * L32) / L33; L53 = (A35 - L50 * L30 - L51 * L31 - L52 * L32) / L33;
+    d = A44 - L40 * L40 - L41 * L41 - L42 * L42 - L43 * L43; ok = ok && d > 0.0; L44 = sqrt(d);
+    L54 = (A45 - L50 * L40 - L51 * L41 - L52 * L42 - L53 * L43) / L44;
+    d = A55 - L50 * L50 - L51 * L51 - L52 * L52 - L53 * L53 - L54 * L54; ok = ok && d > 0.0; L55 = sqrt(d);
+    if (ok) {
+      const double y0_ = b0 / L00;
+      const double y1_ = (b1 - L10 * y0_) / L11;
+      const double y2_ = (b2 - L20 * y0_ - L21 * y1_) / L22;
+      const double y3_ = (b3 - L30 * y0_ - L31 * y1_ - L32 * y2_) / L33;
+      const double y4_ = (b4 - L40 * y0_ - L41 * y1_ - L42 * y2_ - L43 * y3_) / L44;
+      const double y5_ = (b5 - L50 * y0_ - L51 * y1_ - L52 * y2_ - L53 * y3_ - L54 * y4_) / L55;
+      c[5] = y5_ / L55;
+      c[4] = (y4_ - L54 * c[5]) / L44;
+      c[3] = (y3_ - L43 * c[4] - L53 * c[5]) / L33;
+      c[2] = (y2_ - L32 * c[3] - L42 * c[4] - L52 * c[5]) / L22;
+      c[1] = (y1_ - L21 * c[2] - L31 * c[3] - L41 * c[4] - L51 * c[5]) / L11;
+      c[0] = (y0_ - L10 * c[1] - L20 * c[2] - L30 * c[3] - L40 * c[4] - L50 * c[5]) / L00;
+    } else {
+      c[0] = c[1] = c[2] = c[3] = c[4] = c[5] = NAN;  // Eigen's LLT yields NaN; PCL then uses the plane
+    }
+    fitted = true;
+  }
+  // MLSResult::projectQueryPoint(SIMPLE, nr_coeff)
+  double ox = meanx, oy = meany, oz = meanz, nx = nrm[0], ny = nrm[1], nz = nrm[2];
+  if (fitted && isfinite(c[0])) {
+    ox = meanx + c[0] * nrm[0];
+    oy = meany + c[0] * nrm[1];
+    oz = meanz + c[0] * nrm[2];
+    nx = nrm[0] - c[3] * ux - c[1] * vx;
+    ny = nrm[1] - c[3] * uy - c[1] * vy;
+    nz = nrm[2] - c[3] * uz - c[1] * vz;
+    const double l = sqrt((nx * nx + ny * ny) + nz * nz);
+    if (l > 0.0) {
+      nx /= l; ny /= l; nz /= l;
+    }
+  }
+  out[0] = static_cast<float>(ox); out[1] = static_cast<float>(oy); out[2] = static_cast<float>(oz);
+  out[3] = static_cast<float>(nx); out[4] = static_cast<float>(ny); out[5] = static_cast<float>(nz);
+  out[6] = static_cast<float>(curv);
+  a.flag[i] = 1;
+  if (st) {
+    st[0] = meanx; st[1] = meany; st[2] = meanz;
+    st[3] = nrm[0]; st[4] = nrm[1]; st[5] = nrm[2];
+    st[6] = ux; st[7] = uy; st[8] = uz;
+    st[9] = vx; st[10] = vy; st[11] = vz;
+    for (int k = 0; k < 6; ++k) st[12 + k] = c[k];
+    st[18] = curv;
+    st[19] = static_cast<double>(K);
+    st[20] = fitted ? 2.0 : 1.0;  // 0 invalid, 1 valid plane only, 2 polynomial fitted
+    st[21] = 0.0;
+  }
+}
+
+// dense outputs by compacted index list
+__global__ __launch_bounds__(kMB) void k_mls_gather(const float *__restrict__ tmp, const int32_t *__restrict__ index,
+                                                    int64_t m, float *__restrict__ xyz, float *__restrict__ normal,
+                                                    float *__restrict__ curv) {
+  const int64_t k = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  if (k >= m) return;
+  const float *t = tmp + static_cast<int64_t>(index[k]) * 7;
+  xyz[3 * k + 0] = t[0]; xyz[3 * k + 1] = t[1]; xyz[3 * k + 2] = t[2];
+  normal[3 * k + 0] = t[3]; normal[3 * k + 1] = t[4]; normal[3 * k + 2] = t[5];
+  curv[k] = t[6];
+}
+
+static inline uint32_t blocks_of(int64_t n) { return static_cast<uint32_t>(std::max<int64_t>(1, div_up(n, kMB))); }
+
+// device-wide exclusive scan of counts[0..m) into out[0..m], out[m] = total
+static int exclusive_scan(pcp_context *ctx, int32_t *counts, int64_t m) {
+  const int64_t tiles = std::max<int64_t>(1, div_up(m + 1, kScanTile));
+  PCP_HIP_TRY(ctx, ctx->s_tiles.ensure(static_cast<size_t>(tiles) + 4));
+  hipLaunchKernelGGL(k_scan_tile_sums, dim3(static_cast<uint32_t>(tiles)), dim3(kScanBlock), 0, ctx->stream, counts,
+                     m + 1, ctx->s_tiles.p);
+  hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kScanBlock), 0, ctx->stream, ctx->s_tiles.p, tiles,
+                     static_cast<unsigned long long *>(nullptr));
+  hipLaunchKernelGGL(k_scan_apply, dim3(static_cast<uint32_t>(tiles)), dim3(kScanBlock), 0, ctx->stream, counts, m + 1,
+                     ctx->s_tiles.p, counts);
+  PCP_HIP_TRY(ctx, hipGetLastError());
+  return PCP_OK;
+}
+
+// uniform grid over the uploaded cloud, cell edge >= `cell`; fills ctx->g_*
+static int build_grid(pcp_context *ctx, float cell, float radius, GridDesc *out) {
+  const int64_t n = ctx->n;
+  GridDesc g{};
+  const float *mn = ctx->host_min.data(), *mx = ctx->host_max.data();
+  for (;;) {  // bound the table: grow the cell until it fits 2^27 cells
+    const double ex = static_cast<double>(mx[0] - mn[0]) / cell + 1.0, ey = static_cast<double>(mx[1] - mn[1]) / cell + 1.0,
+                 ez = static_cast<double>(mx[2] - mn[2]) / cell + 1.0;
+    if (ex * ey * ez <= 134217728.0) break;
+    cell *= 2.0f;
+  }
+  g.minx = mn[0];
+  g.miny = mn[1];
+  g.minz = mn[2];
+  g.inv_cell = 1.0f / cell;
+  g.nx = static_cast<int32_t>(floorf((mx[0] - mn[0]) * g.inv_cell)) + 1;
+  g.ny = static_cast<int32_t>(floorf((mx[1] - mn[1]) * g.inv_cell)) + 1;
+  g.nz = static_cast<int32_t>(floorf((mx[2] - mn[2]) * g.inv_cell)) + 1;
+  g.reach = static_cast<int32_t>(ceilf(radius * g.inv_cell));
+  const int64_t ncell = static_cast<int64_t>(g.nx) * g.ny * g.nz;
+  const size_t sn = static_cast<size_t>(n);
+  const size_t plane = (sn + 3) & ~size_t(3);
+  PCP_HIP_TRY(ctx, ctx->g_cell.ensure(sn + 4));
+  PCP_HIP_TRY(ctx, ctx->g_rank.ensure(sn + 4));
+  PCP_HIP_TRY(ctx, ctx->g_order.ensure(2 * sn + 8));
+  PCP_HIP_TRY(ctx, ctx->g_start.ensure(static_cast<size_t>(ncell) + 8));
+  PCP_HIP_TRY(ctx, ctx->g_xyz.ensure(3 * plane + 4));
+  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->g_start.p, 0, (static_cast<size_t>(ncell) + 8) * 4, ctx->stream));
+  const float *x = ctx->xyz.p, *y = ctx->xyz.p + plane, *z = ctx->xyz.p + 2 * plane;
+  {
+    LaunchTimer t(ctx, PCP_K_MLS_GRID);
+    hipLaunchKernelGGL(k_grid_count, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, x, y, z, n, g, ctx->g_cell.p,
+                       ctx->g_rank.p, ctx->g_start.p);
+    int rc = exclusive_scan(ctx, ctx->g_start.p, ncell);
+    if (rc != PCP_OK) return rc;
+    hipLaunchKernelGGL(k_grid_scatter, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, n, ctx->g_cell.p, ctx->g_rank.p,
+                       ctx->g_start.p, ctx->g_order.p + sn + 4);
+    hipLaunchKernelGGL(k_grid_order, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, x, y, z, n,
+                       static_cast<int64_t>(plane), ctx->g_cell.p, ctx->g_start.p, ctx->g_order.p + sn + 4,
+                       ctx->g_order.p, ctx->g_xyz.p);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  *out = g;
+  return PCP_OK;
+}
+
+}  // namespace pcp
+
 using namespace pcp;
+
 extern "C" {
-int pcp_mls_process(pcp_context *ctx, const pcp_mls_params *, int64_t *) {
-  return set_error(ctx, PCP_ERR_STATE, "pcp_mls_process: not built yet");
+
+int pcp_mls_process(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_count) {
+  if (!ctx) return PCP_ERR_INVALID;
+  if (!p) return set_error(ctx, PCP_ERR_INVALID, "pcp_mls_process: NULL params");
+  if (!ctx->xyz.p) return set_error(ctx, PCP_ERR_STATE, "pcp_mls_process: no cloud uploaded");
+  // MovingLeastSquares::process refuses these (mls.hpp) [upstream]
+  if (!(p->search_radius > 0.0) || !(p->sqr_gauss_param > 0.0))
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_mls_process: search_radius and sqr_gauss_param must be > 0");
+  if (p->polynomial_order < 0 || p->polynomial_order > 2)
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_mls_process: polynomial_order %d unsupported (0..2; the reference uses 2)",
+                     p->polynomial_order);
+  if (p->upsampling != 0 && p->upsampling != 3)
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_mls_process: upsampling %d unsupported (0 NONE, 3 VOXEL_GRID_DILATION)",
+                     p->upsampling);
+  if (p->upsampling == 3)
+    return set_error(ctx, PCP_ERR_STATE, "pcp_mls_process: VOXEL_GRID_DILATION is not built yet (use upsampling = 0)");
+  PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int64_t n = ctx->n;
+  ctx->mls_count = 0;
+  if (out_count) *out_count = 0;
+  if (n == 0) return PCP_OK;
+  const size_t sn = static_cast<size_t>(n);
+  const size_t plane = (sn + 3) & ~size_t(3);
+  GridDesc g;
+  // cell edge 0.1 % above r: two points closer than r then differ by < 1 in every cell
+  // coordinate even with the fp32 slop of the cell assignment, so reach 1 suffices
+  int rc = build_grid(ctx, static_cast<float>(p->search_radius) * 1.001f, static_cast<float>(p->search_radius), &g);
+  if (rc != PCP_OK) return rc;
+  PCP_HIP_TRY(ctx, ctx->m_tmp.ensure(7 * sn + 8));
+  PCP_HIP_TRY(ctx, ctx->m_flag.ensure(sn + 16));
+  MlsArgs a{};
+  a.sx = ctx->g_xyz.p;
+  a.sy = ctx->g_xyz.p + plane;
+  a.sz = ctx->g_xyz.p + 2 * plane;
+  a.order = ctx->g_order.p;
+  a.start = ctx->g_start.p;
+  a.n = n;
+  a.g = g;
+  a.sq_radius = static_cast<float>(p->search_radius * p->search_radius);
+  a.inv_sq_radius = 1.0 / (p->search_radius * p->search_radius);
+  a.order_poly = p->polynomial_order;
+  a.tmp = ctx->m_tmp.p;
+  a.flag = ctx->m_flag.p;
+  a.state = nullptr;
+  {
+    LaunchTimer t(ctx, PCP_K_MLS_FIT);
+    hipLaunchKernelGGL(k_mls_fit, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, a);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  // points with < 3 neighbours are dropped; output keeps the input order
+  PCP_HIP_TRY(ctx, ctx->mls_index.ensure(sn + 4));
+  int64_t m = 0;
+  if ((rc = compact_flags(ctx, ctx->m_flag.p, n, ctx->mls_index.p, n, &m)) != PCP_OK) return rc;
+  PCP_HIP_TRY(ctx, ctx->mls_xyz.ensure(3 * static_cast<size_t>(m) + 4));
+  PCP_HIP_TRY(ctx, ctx->mls_normal.ensure(3 * static_cast<size_t>(m) + 4));
+  PCP_HIP_TRY(ctx, ctx->mls_curv.ensure(static_cast<size_t>(m) + 4));
+  if (m > 0) {
+    LaunchTimer t(ctx, PCP_K_MLS_FIT);
+    hipLaunchKernelGGL(k_mls_gather, dim3(blocks_of(m)), dim3(kMB), 0, ctx->stream, ctx->m_tmp.p, ctx->mls_index.p, m,
+                       ctx->mls_xyz.p, ctx->mls_normal.p, ctx->mls_curv.p);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  ctx->mls_count = m;
+  if (out_count) *out_count = m;
+  return PCP_OK;
 }
-int pcp_mls_fetch(pcp_context *ctx, int64_t, float *, float *, float *, int32_t *) {
-  return set_error(ctx, PCP_ERR_STATE, "pcp_mls_fetch: not built yet");
+
+int pcp_mls_fetch(pcp_context *ctx, int64_t capacity, float *out_xyz, float *out_normal, float *out_curvature,
+                  int32_t *out_index) {
+  if (!ctx) return PCP_ERR_INVALID;
+  if (capacity < 0) return set_error(ctx, PCP_ERR_INVALID, "pcp_mls_fetch: negative capacity");
+  PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t m = static_cast<size_t>(std::min<int64_t>(capacity, ctx->mls_count));
+  if (m > 0) {
+    if (out_xyz) PCP_HIP_TRY(ctx, hipMemcpyAsync(out_xyz, ctx->mls_xyz.p, 3 * m * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_normal)
+      PCP_HIP_TRY(ctx, hipMemcpyAsync(out_normal, ctx->mls_normal.p, 3 * m * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_curvature)
+      PCP_HIP_TRY(ctx, hipMemcpyAsync(out_curvature, ctx->mls_curv.p, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_index) PCP_HIP_TRY(ctx, hipMemcpyAsync(out_index, ctx->mls_index.p, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PCP_OK;
 }
+
 int pcp_sor(pcp_context *ctx, int32_t, double, uint8_t *, int64_t *) {
   return set_error(ctx, PCP_ERR_STATE, "pcp_sor: not built yet");
 }
-}
+
+}  // extern "C"

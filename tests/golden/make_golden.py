@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Generates the committed golden vectors under tests/golden/ with the numpy twin
+(oracle/np_oracle.py) and, for the HPR variant, scipy's bundled qhull_r.
+
+The reference ships no fixtures and cannot be built or run in this image
+(SURVEY.md 8c), so these vectors do NOT come from the reference: they pin the
+restatement against itself across languages (numpy here, C in
+oracle/pcp_oracle.c, HIP in csrc/) and across time.  Parity stays "unpinned"
+in the sense of the task statement; see DESIGN.md.
+
+    python tests/golden/make_golden.py        # rewrites the .npz files
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import np_oracle as npo  # noqa: E402
+from pointcloudprocessor_amd import synth  # noqa: E402
+
+
+def nano_camera():
+    d = dict(fx=188.2083, fy=188.2083, cx=80.0, cy=45.0)
+    d.update(synth.REF_D)
+    d.update(image_width=160, image_height=90, cull_width=160, cull_height=90)
+    return d
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def cam_array(cam):
+    keys = ["fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3", "image_width", "image_height", "cull_width",
+            "cull_height"]
+    return np.array([cam[k] for k in keys], np.float64)
+
+
+def main():
+    rng = np.random.default_rng(20241008)
+    poses, _ = synth.make_trajectory(6)
+
+    # g1: projection with the REFERENCE constants (4096x3000), points in front of one pose
+    cam = synth.camera_dict("ref")
+    x, y, z, _ = synth.make_cloud(3000, seed=11)
+    w2c, c2w = npo.pose_to_matrices(poses[0])
+    p = npo.project_frame(cam, w2c, x, y, z)
+    T = np.eye(4)
+    T[:3, :3] = npo.quat_to_rot(0.9998, 0.01, -0.012, 0.008)
+    T[:3, 3] = [0.02, -0.015, 0.03]
+    w2c_T, c2w_T = npo.pose_to_matrices(poses[1], T)
+    save("g1_projection.npz", camera=cam_array(cam), pose=poses[0], x=x, y=y, z=z, w2c=w2c, c2w=c2w, xc=p["xc"],
+         yc=p["yc"], zc=p["zc"], u=p["u"], v=p["v"], cell=p["cell"], pixel=p["pixel"], range=p["range"],
+         pose_T=poses[1], T_opt=T, w2c_T=w2c_T, c2w_T=c2w_T)
+
+    # g2: z-buffer cull with real occluders, nano camera
+    cam = nano_camera()
+    x, y, z, _ = synth.make_cloud(20000, seed=12)
+    keeps, dmaps = [], []
+    for f in range(3):
+        w2c, _ = npo.pose_to_matrices(poses[f])
+        keep, dmap, _ = npo.cull_frame(cam, w2c, x, y, z)
+        keeps.append(keep)
+        dmaps.append(dmap)
+    save("g2_zbuffer.npz", camera=cam_array(cam), poses=poses[:3], x=x, y=y, z=z, keep=np.array(keeps),
+         depth=np.array(dmaps))
+
+    # g3: HPR (the cull that is ACTIVE in the reference) on the same points, frame 0
+    w2c, _ = npo.pose_to_matrices(poses[0])
+    hpr = npo.hpr_frame(cam, w2c, x, y, z)
+    save("g3_hpr.npz", camera=cam_array(cam), pose=poses[0], x=x, y=y, z=z, visible=hpr.astype(np.int32),
+         zbuffer_keep=np.nonzero(keeps[0])[0].astype(np.int32))
+
+    # g4: 6-keyframe colour run, procedural images
+    imgs = [synth.make_image(f, cam["image_width"], cam["image_height"], seed=5) for f in range(6)]
+    col = npo.colorize(cam, x, y, z, poses, imgs)
+    save("g4_colour.npz", camera=cam_array(cam), poses=poses, x=x, y=y, z=z, images=np.array(imgs), rgb=col["rgb"],
+         has=col["has"], count=col["count"], top_score=col["top_score"], top_rgb=col["top_rgb"],
+         top_frame=col["top_frame"])
+
+    # g5: MLS on plane / sphere / saddle patches
+    n = 700
+    a = rng.uniform(-0.12, 0.12, (n, 2))
+    plane = np.stack([a[:, 0] + 1.0, a[:, 1] - 2.0, 0.2 * a[:, 0] - 0.1 * a[:, 1] + 0.7 + rng.normal(0, 1e-3, n)], 1)
+    d = rng.normal(size=(n, 3))
+    d[:, 2] = np.abs(d[:, 2]) + 3.0
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    sphere = np.array([-2.0, 0.5, 1.0]) + (0.6 + rng.normal(0, 1e-3, n))[:, None] * d
+    a = rng.uniform(-0.12, 0.12, (n, 2))
+    saddle = np.stack([a[:, 0], a[:, 1] + 3.0, 2.0 * a[:, 0] ** 2 - 1.5 * a[:, 1] ** 2 + rng.normal(0, 5e-4, n)], 1)
+    stray = rng.uniform(-5, 5, (12, 3))
+    pts = np.concatenate([plane, sphere, saddle, stray]).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    m = npo.mls(pts[:, 0], pts[:, 1], pts[:, 2])
+    save("g5_mls.npz", x=pts[:, 0], y=pts[:, 1], z=pts[:, 2], xyz=m["xyz"], normal=m["normal"],
+         curvature=m["curvature"], index=m["index"])
+
+    # g6: odometry / keyframe goldens
+    od_poses, ts = synth.make_trajectory(12, spacing=0.06)  # every second pose passes the 0.1 m rule
+    lines = []
+    for t, p_ in zip(ts, od_poses):
+        lines.append("%.6f %.6f %.6f %.6f %.8f %.8f %.8f %.8f" % (t, p_[0], p_[1], p_[2], p_[3], p_[4], p_[5], p_[6]))
+    key = [0]
+    for i in range(1, len(od_poses)):
+        if np.linalg.norm(od_poses[i, :3] - od_poses[key[-1], :3]) >= 0.1:
+            key.append(i)
+    save("g6_odometry.npz", text=np.array("\n".join(lines) + "\n"), poses=od_poses, ts=ts,
+         keyframes=np.array(key, np.int32))
+
+
+if __name__ == "__main__":
+    main()

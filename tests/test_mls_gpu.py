@@ -1,0 +1,143 @@
+"""GPU parity of the MLS path (pcp_mls_process) against the CPU restatement.
+Bars: output set and source indices exact; positions
+<= 1e-4 relative to the search radius (3 um) and 1e-4 relative in world
+coordinates; normals up to sign; curvature 1e-4 relative (+1e-9 abs)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+R = 0.03
+
+
+def _patches(seed=7, n=6000):
+    rng = np.random.default_rng(seed)
+    out = []
+    # noisy plane, tilted, away from the origin
+    a = rng.uniform(-0.2, 0.2, (n, 2))
+    nrm = np.array([0.3, -0.5, 0.81])
+    nrm /= np.linalg.norm(nrm)
+    e1 = np.cross(nrm, [0, 0, 1.0])
+    e1 /= np.linalg.norm(e1)
+    e2 = np.cross(nrm, e1)
+    p = np.array([3.0, -2.0, 1.5]) + a[:, :1] * e1 + a[:, 1:] * e2 + rng.normal(0, 1e-3, (n, 1)) * nrm
+    out.append(p)
+    # sphere cap radius 0.8
+    d = rng.normal(size=(n, 3))
+    d[:, 2] = np.abs(d[:, 2]) + 2.0
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    out.append(np.array([-4.0, 1.0, 2.0]) + (0.8 + rng.normal(0, 1e-3, n))[:, None] * d)
+    # saddle
+    a = rng.uniform(-0.2, 0.2, (n, 2))
+    z = 1.5 * a[:, 0] ** 2 - 1.2 * a[:, 1] ** 2 + 0.4 * a[:, 0] * a[:, 1] + rng.normal(0, 5e-4, n)
+    out.append(np.stack([a[:, 0] + 0.5, a[:, 1] + 4.0, z + 0.3], axis=1))
+    # sparse stragglers: isolated points and tiny clusters (K < 3, 3 <= K < 6)
+    s = rng.uniform(-7, 7, (40, 3))
+    cl = s[:10, None, :] + rng.normal(0, 4e-3, (10, 4, 3))
+    out.append(s)
+    out.append(cl.reshape(-1, 3))
+    pts = np.concatenate(out, axis=0)
+    pts = pts[rng.permutation(len(pts))].astype(np.float32)
+    return pts[:, 0].copy(), pts[:, 1].copy(), pts[:, 2].copy()
+
+
+def _compare(got, ref, xyz_in):
+    assert np.array_equal(got["index"], ref["index"])
+    d = np.abs(got["xyz"].astype(np.float64) - ref["xyz"].astype(np.float64))
+    scale = np.maximum(np.abs(ref["xyz"].astype(np.float64)), 1.0)
+    assert d.max() <= 1e-4 * R, d.max()
+    assert (d / scale).max() <= 1e-4
+    sgn = np.sign((got["normal"].astype(np.float64) * ref["normal"]).sum(axis=1))
+    sgn[sgn == 0] = 1.0
+    dn = np.abs(got["normal"] * sgn[:, None] - ref["normal"])
+    assert dn.max() <= 1e-4, dn.max()
+    np.testing.assert_allclose(got["curvature"], ref["curvature"], rtol=1e-4, atol=1e-9)
+
+
+def test_mls_none_matches_oracle(gpu_ctx_factory, oracle):
+    from pointcloudprocessor_amd import capi
+
+    x, y, z = _patches()
+    ctx = gpu_ctx_factory()
+    ctx.upload_cloud(x, y, z)
+    mp = capi.default_mls_params()
+    mp.upsampling = 0
+    m = ctx.mls_process(mp)
+    got = ctx.mls_fetch(m)
+    op = oracle.default_mls_params()
+    op.upsampling = 0
+    op.threads = 8
+    ref = oracle.mls(x, y, z, op)
+    assert 0 < len(ref["index"]) < len(x)  # stragglers with < 3 neighbours are dropped
+    _compare(got, ref, (x, y, z))
+    # run-to-run determinism (cell order fix-up)
+    m2 = ctx.mls_process(mp)
+    again = ctx.mls_fetch(m2)
+    for k in got:
+        assert np.array_equal(got[k], again[k]), k
+
+
+def test_mls_on_scene_sample(gpu_ctx_factory, oracle):
+    """A dense crop of the bench scene (walls + sphere), ~65 neighbours per point."""
+    from pointcloudprocessor_amd import capi, synth
+
+    x, y, z, _ = synth.make_cloud(3_000_000)
+    sel = (x > 2.0) & (x < 2.6) & (y > -5.1) & (y < -4.4) & (z < 0.7)
+    x, y, z = x[sel], y[sel], z[sel]
+    assert 3000 < len(x) < 60000
+    ctx = gpu_ctx_factory()
+    ctx.upload_cloud(x, y, z)
+    mp = capi.default_mls_params()
+    mp.upsampling = 0
+    got = ctx.mls_fetch(ctx.mls_process(mp))
+    op = oracle.default_mls_params()
+    op.upsampling = 0
+    op.threads = 8
+    ref = oracle.mls(x, y, z, op)
+    _compare(got, ref, (x, y, z))
+
+
+def test_mls_plane_known_answer(gpu_ctx_factory):
+    """Exact plane z = 0 on a lattice: zero displacement, normal = +-z, curvature 0."""
+    from pointcloudprocessor_amd import capi
+
+    g = np.arange(-0.1, 0.1, 0.004, dtype=np.float32)
+    xx, yy = np.meshgrid(g, g)
+    x, y = xx.ravel().copy(), yy.ravel().copy()
+    z = np.zeros_like(x)
+    ctx = gpu_ctx_factory()
+    ctx.upload_cloud(x, y, z)
+    mp = capi.default_mls_params()
+    mp.upsampling = 0
+    got = ctx.mls_fetch(ctx.mls_process(mp))
+    assert len(got["index"]) == len(x)
+    assert np.abs(got["xyz"] - np.stack([x, y, z], 1)).max() < 1e-7
+    assert np.abs(np.abs(got["normal"][:, 2]) - 1.0).max() < 1e-6
+    assert got["curvature"].max() < 1e-9
+
+
+def test_mls_edge_cases(gpu_ctx_factory, oracle):
+    from pointcloudprocessor_amd import capi
+
+    ctx = gpu_ctx_factory()
+    mp = capi.default_mls_params()
+    mp.upsampling = 0
+    e = np.zeros(0, np.float32)
+    ctx.upload_cloud(e, e, e)
+    assert ctx.mls_process(mp) == 0
+    # two points only: both dropped
+    ctx.upload_cloud(np.float32([0, 0.001]), np.float32([0, 0]), np.float32([0, 0]))
+    assert ctx.mls_process(mp) == 0
+    # order 1: plane projection only
+    x, y, z = _patches(seed=3, n=1500)
+    ctx.upload_cloud(x, y, z)
+    mp.polynomial_order = 1
+    got = ctx.mls_fetch(ctx.mls_process(mp))
+    op = oracle.default_mls_params()
+    op.upsampling = 0
+    op.polynomial_order = 1
+    ref = oracle.mls(x, y, z, op)
+    _compare(got, ref, (x, y, z))
+    mp.polynomial_order = 7
+    with pytest.raises(capi.PcpError):
+        ctx.mls_process(mp)
