@@ -581,9 +581,16 @@ int64_t orc_mls_voxel_dilation(const float *x, const float *y, const float *z, i
       const int32_t iz = (int32_t)id;
       for (int dx = -1; dx <= 1; ++dx)
         for (int dy = -1; dy <= 1; ++dy)
-          for (int dz = -1; dz <= 1; ++dz)
+          for (int dz = -1; dz <= 1; ++dz) {
+            /* B16: PCL lets a negative neighbour index wrap in its uint64 key
+             * arithmetic (MLSVoxelGrid::dilate + getIndexIn1D [upstream]), which
+             * decodes to a voxel ~1.5 extents away and emits a few garbage points
+             * next to the bounding-box minimum faces.  Normalised: such neighbours
+             * are not created. */
+            if (ix + dx < 0 || iy + dy < 0 || iz + dz < 0) continue;
             nw[m++] = (uint64_t)(int64_t)(ix + dx) * S * S + (uint64_t)(int64_t)(iy + dy) * S +
                       (uint64_t)(int64_t)(iz + dz);
+          }
     }
     free(keys);
     keys = nw;

@@ -1,0 +1,255 @@
+"""CPU suite: the C restatement (oracle/pcp_oracle.c) against the committed golden
+vectors, against the independent numpy twin, and against analytic known answers.
+No GPU needed."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import cam_struct
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CAM_KEYS = ["fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3", "image_width", "image_height", "cull_width",
+            "cull_height"]
+
+
+def cam_from_array(oracle, a):
+    d = {k: (int(v) if k.endswith(("width", "height")) else float(v)) for k, v in zip(CAM_KEYS, a)}
+    return cam_struct(oracle, d), d
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name), allow_pickle=False)
+
+
+def test_defaults_are_the_reference_constants(oracle):
+    cam = oracle.default_camera()
+    # PointCloudProcessor.cpp:57-62, :525
+    assert (cam.fx, cam.fy) == (4818.200388954926, 4819.10345841615)
+    assert (cam.cx, cam.cy) == (2032.4178620390019, 1535.1895959282901)
+    assert (cam.k1, cam.k2, cam.p1, cam.p2, cam.k3) == (0.003043514741045163, 0.06634739187544138,
+                                                        -0.000217681797407554, -0.0006654964142658197, 0.0)
+    assert (cam.cull_width, cam.cull_height) == (4096, 3000)
+    cp = oracle.default_cull_params()
+    assert (cp.enable_depth_buffer_culling, cp.downsample_factor, cp.depth_slack) == (1, 14, 0.05)
+    mp = oracle.default_mls_params()
+    assert (mp.search_radius, mp.sqr_gauss_param, mp.polynomial_order, mp.upsampling, mp.vgd_iterations) == (
+        0.03, 0.0009, 2, 3, 4)
+
+
+def test_g1_projection_golden(oracle):
+    g = load("g1_projection.npz")
+    cam, _ = cam_from_array(oracle, g["camera"])
+    w2c, c2w = oracle.pose_to_matrices(g["pose"])
+    assert np.array_equal(w2c.reshape(3, 4), g["w2c"]) and np.array_equal(c2w.reshape(3, 4), g["c2w"])
+    p = oracle.project_frame(cam, oracle.default_cull_params(), w2c, g["x"], g["y"], g["z"])
+    for k in ("xc", "yc", "zc", "cell", "pixel"):
+        assert np.array_equal(p[k], g[k]), k
+    front = g["zc"] > 0
+    assert np.array_equal(p["range"][front], g["range"][front])
+    # optimised-extrinsic branch (general fp32 inverse)
+    w2c_T, c2w_T = oracle.pose_to_matrices(g["pose_T"], g["T_opt"])
+    assert np.array_equal(w2c_T.reshape(3, 4), g["w2c_T"]) and np.array_equal(c2w_T.reshape(3, 4), g["c2w_T"])
+    # per-point fp64 (u, v)
+    import ctypes as C
+
+    u, v = C.c_double(), C.c_double()
+    for i in np.nonzero(front)[0][:200]:
+        oracle.lib().orc_project_point(C.byref(cam), C.c_double(float(g["xc"][i])), C.c_double(float(g["yc"][i])),
+                                       C.c_double(float(g["zc"][i])), C.byref(u), C.byref(v))
+        assert u.value == g["u"][i] and v.value == g["v"][i]
+
+
+def test_g2_zbuffer_golden(oracle):
+    g = load("g2_zbuffer.npz")
+    cam, _ = cam_from_array(oracle, g["camera"])
+    for f, pose in enumerate(g["poses"]):
+        w2c, _ = oracle.pose_to_matrices(pose)
+        for threads in (1, 4):
+            keep, dmap, kept = oracle.cull_frame(cam, oracle.default_cull_params(), w2c, g["x"], g["y"], g["z"], threads)
+            assert np.array_equal(dmap, g["depth"][f]) and np.array_equal(keep.astype(bool), g["keep"][f])
+            assert kept == g["keep"][f].sum()
+    assert g["keep"].sum() > 100
+
+
+def test_g3_hpr_differs_from_zbuffer_as_documented():
+    """HPR (active in the reference) keeps essentially every in-frustum point at
+    R = 90000; the z-buffer (north_star) is the stricter cull."""
+    g = load("g3_hpr.npz")
+    vis, zb = set(g["visible"].tolist()), set(g["zbuffer_keep"].tolist())
+    assert len(vis) > len(zb) > 0
+    assert len(zb - vis) < 0.15 * len(zb)
+
+
+def test_g3_hpr_regenerates(oracle):
+    from oracle import np_oracle as npo
+
+    g = load("g3_hpr.npz")
+    _, d = cam_from_array(oracle, g["camera"])
+    w2c, _ = npo.pose_to_matrices(g["pose"])
+    assert np.array_equal(npo.hpr_frame(d, w2c, g["x"], g["y"], g["z"]), g["visible"])
+
+
+def test_g4_colour_golden(oracle):
+    g = load("g4_colour.npz")
+    cam, _ = cam_from_array(oracle, g["camera"])
+    for threads in (1, 4):
+        r = oracle.colorize(cam, oracle.default_cull_params(), g["x"], g["y"], g["z"], g["poses"], list(g["images"]),
+                            threads=threads)
+        for k in ("rgb", "has", "count", "top_score", "top_rgb", "top_frame"):
+            assert np.array_equal(r[k], g[k]), (threads, k)
+    assert g["has"].sum() > 200 and g["count"].max() >= 3
+
+
+def test_g5_mls_golden(oracle):
+    g = load("g5_mls.npz")
+    mp = oracle.default_mls_params()
+    mp.upsampling = 0
+    mp.threads = 4
+    r = oracle.mls(g["x"], g["y"], g["z"], mp)
+    assert np.array_equal(r["index"], g["index"])
+    assert np.abs(r["xyz"].astype(np.float64) - g["xyz"]).max() <= 3e-6
+    sgn = np.sign((r["normal"] * g["normal"]).sum(axis=1))
+    assert np.abs(r["normal"] * sgn[:, None] - g["normal"]).max() <= 1e-4
+    np.testing.assert_allclose(r["curvature"], g["curvature"], rtol=1e-4, atol=1e-9)
+    assert len(g["index"]) < len(g["x"])  # strays dropped
+
+
+def test_g6_keyframes_golden(oracle):
+    g = load("g6_odometry.npz")
+    assert np.array_equal(oracle.select_keyframes(g["poses"], 0.1), g["keyframes"])
+    assert 1 < len(g["keyframes"]) < len(g["poses"])
+
+
+def test_c_and_numpy_twins_agree_on_fresh_data(oracle, small_scene):
+    from oracle import np_oracle as npo
+
+    cd = small_scene["cam"]
+    cam, cp = cam_struct(oracle, cd), oracle.default_cull_params()
+    x, y, z = small_scene["x"], small_scene["y"], small_scene["z"]
+    for f in (0, 4):
+        w2c_c, _ = oracle.pose_to_matrices(small_scene["poses"][f])
+        w2c_n, _ = npo.pose_to_matrices(small_scene["poses"][f])
+        pc = oracle.project_frame(cam, cp, w2c_c, x, y, z)
+        pn = npo.project_frame(cd, w2c_n, x, y, z)
+        for k in ("cell", "pixel", "range", "xc", "yc", "zc"):
+            assert np.array_equal(pc[k], pn[k]), k
+    rc = oracle.colorize(cam, cp, x, y, z, small_scene["poses"], small_scene["images"])
+    rn = npo.colorize(cd, x, y, z, small_scene["poses"], small_scene["images"])
+    for k in rc:
+        assert np.array_equal(rc[k], rn[k]), k
+
+
+# ---- analytic known answers ------------------------------------------------------
+def test_kat_identity_pose_and_optical_axis(oracle):
+    cam, cp = oracle.default_camera(), oracle.default_cull_params()
+    w2c, c2w = oracle.pose_to_matrices([0, 0, 0, 1, 0, 0, 0])
+    eye = np.float32([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]]).reshape(12)
+    assert np.array_equal(w2c, eye) and np.array_equal(c2w, eye)
+    x, y, z = np.float32([0, 0.3, -0.2, 0]), np.float32([0, -0.1, 0.4, 0]), np.float32([2.5, 1.0, 3.0, -1.0])
+    p = oracle.project_frame(cam, cp, w2c, x, y, z)
+    assert np.array_equal(p["xc"], x) and np.array_equal(p["yc"], y) and np.array_equal(p["zc"], z)
+    # a point on the optical axis lands on (cx, cy)
+    assert p["pixel"][0] == int(cam.cy) * cam.image_width + int(cam.cx)
+    assert p["cell"][0] == (int(np.float32(cam.cy) / np.float32(14))) * (4096 // 14) + int(np.float32(cam.cx) / np.float32(14))
+    assert p["range"][0] == np.float32(2.5)
+    assert p["cell"][3] == -1 and p["pixel"][3] == -1  # behind the camera
+
+
+def test_kat_left_edge_truncation_rules(oracle):
+    """u in (-14, 0): the z-buffer cell truncates to 0 (candidate) while the colour
+    pixel rule (int)u rejects u <= -1 (Appendix A4/A5)."""
+    cam, cp = oracle.default_camera(), oracle.default_cull_params()
+    cam.k1 = cam.k2 = cam.p1 = cam.p2 = 0.0
+    w2c, _ = oracle.pose_to_matrices([0, 0, 0, 1, 0, 0, 0])
+    z = 2.0
+    us = np.array([-13.5, -0.5, 0.5])
+    xs = ((us - cam.cx) / cam.fx * z).astype(np.float32)
+    p = oracle.project_frame(cam, cp, w2c, xs, np.zeros(3, np.float32), np.full(3, z, np.float32))
+    assert (p["cell"] >= 0).all()
+    assert p["pixel"][0] == -1 and p["pixel"][1] >= 0 and p["pixel"][2] >= 0  # (int)(-0.5) == 0
+
+
+def test_kat_scores(oracle):
+    # camera at the world origin (B4 has no effect), point on the axis at the ideal distance 2.0
+    o, d, f = oracle.scores(0.0, 0.0, 2.0, [0, 0, 0, 1, 0, 0, 0])
+    assert o == np.float32(1.0) and d == np.float32(1.0) and f == np.float32(1.0)
+    o, d, f = oracle.scores(0.0, 0.0, 4.0, [0, 0, 0, 1, 0, 0, 0])
+    assert d == np.float32(0.2) and f == np.float32((np.float32(1.0) + np.float32(0.2)) / 2)
+    # 90 degrees off axis: cos = 0 -> orientation 0.2 + 0.8 * 0.5
+    o, _, _ = oracle.scores(1.0, 0.0, 0.0, [0, 0, 0, 1, 0, 0, 0])
+    assert o == np.float32(0.2) + np.float32(0.8) * np.float32(0.5)
+
+
+def test_kat_top5_weighted_mean(oracle):
+    """One point straight ahead of 7 cameras at increasing distance: the 5 best
+    scores win, colour = score-weighted mean truncated to uint8."""
+    cam = oracle.default_camera(8, 8)
+    cam.fx = cam.fy = 100.0
+    cam.cx = cam.cy = 4.0
+    cam.k1 = cam.k2 = cam.p1 = cam.p2 = 0.0
+    cp = oracle.default_cull_params()
+    cp.enable_depth_buffer_culling = 0
+    dists = [2.0, 2.2, 1.7, 3.0, 2.6, 3.9, 1.2]
+    poses = [[0, 0, -d, 1, 0, 0, 0] for d in dists]
+    images = []
+    for f in range(7):
+        im = np.zeros((8, 8, 3), np.uint8)
+        im[..., 0], im[..., 1], im[..., 2] = 10 * f + 1, 20 + f, 200 - 9 * f
+        images.append(im)
+    r = oracle.colorize(cam, cp, np.float32([0]), np.float32([0]), np.float32([0]), poses, images)
+    assert r["count"][0] == 7
+    sc = np.array([oracle.scores(0, 0, d, p)[2] for d, p in zip(dists, poses)], np.float32)
+    order = np.argsort(-sc, kind="stable")[:5]
+    assert np.array_equal(r["top_frame"][0], order)
+    s = sc[order]
+    tot = np.float32(0)
+    acc = np.zeros(3, np.float32)
+    for k, f in enumerate(order):
+        bgr = images[f][0, 0].astype(np.float32)
+        for c, ch in enumerate((2, 1, 0)):
+            acc[c] = acc[c] + bgr[ch] * s[k]
+        tot = tot + s[k]
+    assert np.array_equal(r["rgb"][0], (acc / tot).astype(np.uint8))
+
+
+def test_kat_never_seen_point_is_black_and_dropped(oracle, small_scene):
+    cd = small_scene["cam"]
+    r = oracle.colorize(cam_struct(oracle, cd), oracle.default_cull_params(), np.float32([100.0]), np.float32([100.0]),
+                        np.float32([100.0]), small_scene["poses"][:2], small_scene["images"][:2])
+    assert r["count"][0] == 0 and not r["rgb"].any() and r["has"][0] == 0
+
+
+def test_kat_mls_sphere_radius(oracle):
+    """Noise-free sphere of radius R: the order-2 fit projects onto it with error O(r^4 / R^3)."""
+    rng = np.random.default_rng(3)
+    d = rng.normal(size=(60000, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    Rs = 0.5
+    p = (Rs * d).astype(np.float32)
+    sel = p[:, 2] > 0.42
+    mp = oracle.default_mls_params()
+    mp.upsampling = 0
+    mp.threads = 4
+    r = oracle.mls(p[sel, 0], p[sel, 1], p[sel, 2], mp)
+    rad = np.linalg.norm(r["xyz"].astype(np.float64), axis=1)
+    K_ok = np.ones(len(rad), bool)
+    assert np.abs(rad[K_ok] - Rs).max() < 5 * 0.03 ** 4 / Rs ** 3 + 2e-6
+    cosn = np.abs((r["normal"] * (r["xyz"] / rad[:, None])).sum(axis=1))
+    assert cosn.min() > 1 - 1e-3
+
+
+def test_sor_and_voxel_dilation_smoke(oracle):
+    rng = np.random.default_rng(9)
+    a = rng.uniform(-0.1, 0.1, (3000, 2))
+    x, y = a[:, 0].astype(np.float32), a[:, 1].astype(np.float32)
+    z = rng.normal(0, 1e-3, 3000).astype(np.float32)
+    z[:5] += 0.5  # gross outliers
+    keep, kept = oracle.sor(x, y, z, 60, 0.7, 4)
+    assert not keep[:5].any() and 0.5 * len(x) < kept < len(x)
+    mp = oracle.default_mls_params()
+    mp.vgd_voxel_size = 0.01
+    mp.vgd_iterations = 1
+    mp.threads = 4
+    r = oracle.mls_voxel_dilation(x[5:], y[5:], z[5:], mp)
+    assert len(r["index"]) > 300 and np.abs(r["xyz"][:, 2]).max() < 0.02

@@ -1,0 +1,145 @@
+"""world_size-2 `gloo` rehearsal of the multi-GPU path: points are
+sharded by contiguous index range, the only exchange on the data path is an
+all-reduce(MIN) of the per-keyframe depth maps, outputs are all-gathered.  The
+driver under test is pointcloudprocessor_amd.pipeline.PointCloudColorizer; the
+compute engine here is an oracle-backed stand-in defined in this test (the
+product has no CPU engine)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleEngine:
+    """Same hooks as pipeline.HipEngine, computed with the numpy twin."""
+
+    def __init__(self, cam, x, y, z, poses, images):
+        self.cam, self.x, self.y, self.z, self.poses, self.images = cam, x, y, z, poses, images
+        self.depth = None
+        self.proj = None
+
+    def depth_pass(self):
+        from oracle import np_oracle as npo
+
+        maps, self.proj = [], []
+        for pose in self.poses:
+            w2c, _ = npo.pose_to_matrices(pose)
+            _, dmap, p = npo.cull_frame(self.cam, w2c, self.x, self.y, self.z)
+            maps.append(dmap.reshape(-1))
+            self.proj.append(p)
+        self.depth = np.ascontiguousarray(np.concatenate(maps).astype(np.float32))
+
+    def depth_maps_tensor(self):
+        import torch
+
+        return torch.from_numpy(self.depth)  # shares memory: the all-reduce lands in self.depth
+
+    def colour_from_depth(self, download=True):
+        from oracle import np_oracle as npo
+
+        n = len(self.x)
+        cells = self.depth.size // len(self.poses)
+        lists = [[] for _ in range(n)]
+        for f, pose in enumerate(self.poses):
+            p = self.proj[f]
+            dmap = self.depth[f * cells:(f + 1) * cells]
+            inmap = p["cell"] >= 0
+            keep = np.zeros(n, bool)
+            keep[inmap] = ~(p["range64"][inmap] > dmap[p["cell"][inmap]].astype(np.float64) + 0.05)
+            sel = np.nonzero(keep & (p["pixel"] >= 0))[0]
+            if len(sel) == 0:
+                continue
+            bgr = np.asarray(self.images[f]).reshape(-1, 3)[p["pixel"][sel]]
+            _, _, fin = npo.scores(p["xc"][sel], p["yc"][sel], p["zc"][sel], pose)
+            for k, i in enumerate(sel):
+                lists[i].append((float(fin[k]), int(bgr[k, 2]), int(bgr[k, 1]), int(bgr[k, 0])))
+        rgb = np.zeros((n, 3), np.uint8)
+        for i, lst in enumerate(lists):
+            if not lst:
+                continue
+            lst = sorted(lst, key=lambda e: -e[0])[:5]
+            tot = np.float32(0)
+            acc = [np.float32(0)] * 3
+            for s, r, g, b in lst:
+                s = np.float32(s)
+                acc = [acc[0] + np.float32(r) * s, acc[1] + np.float32(g) * s, acc[2] + np.float32(b) * s]
+                tot = tot + s
+            rgb[i] = [np.uint8(int(a / tot)) for a in acc]
+        return dict(rgb=rgb, has=(rgb != 0).any(axis=1).astype(np.uint8))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+
+    from pointcloudprocessor_amd import pipeline, synth
+    from test_sharding_gloo import OracleEngine
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cam = synth.camera_dict("tiny")
+    x, y, z, _ = synth.make_cloud(n, seed=77)
+    poses, _ = synth.make_trajectory(4)
+    imgs = [synth.make_image(f, cam["image_width"], cam["image_height"]) for f in range(4)]
+    lo, hi = pipeline.shard_bounds(n, rank, world)
+    eng = OracleEngine(cam, x[lo:hi], y[lo:hi], z[lo:hi], poses, imgs)
+    col = pipeline.PointCloudColorizer(eng, rank, world)
+    local = col.run()
+    full = col.gather(local, n)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rgb=full["rgb"], has=full["has"], depth=eng.depth)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_bounds_partition():
+    from pointcloudprocessor_amd import pipeline
+
+    for n in (0, 1, 7, 8, 1000, 1001):
+        for w in (1, 2, 3, 8):
+            b = [pipeline.shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_equals_single_process(tmp_path, oracle):
+    import torch.multiprocessing as mp
+
+    from conftest import cam_struct
+    from pointcloudprocessor_amd import synth
+
+    n, world = 6000, 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)
+    cam = synth.camera_dict("tiny")
+    x, y, z, _ = synth.make_cloud(n, seed=77)
+    poses, _ = synth.make_trajectory(4)
+    imgs = [synth.make_image(f, cam["image_width"], cam["image_height"]) for f in range(4)]
+    ref = oracle.colorize(cam_struct(oracle, cam), oracle.default_cull_params(), x, y, z, poses, imgs)
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    # the reduced depth maps are identical on both ranks and equal the single-process maps
+    assert np.array_equal(r0["depth"], r1["depth"])
+    for f in range(4):
+        w2c, _ = oracle.pose_to_matrices(poses[f])
+        _, dmap, _ = oracle.cull_frame(cam_struct(oracle, cam), oracle.default_cull_params(), w2c, x, y, z)
+        cells = dmap.size
+        assert np.array_equal(r0["depth"][f * cells:(f + 1) * cells], dmap.reshape(-1))
+    # sharded colours == unsharded colours, bit for bit, on every rank
+    for r in (r0, r1):
+        assert np.array_equal(r["rgb"], ref["rgb"]) and np.array_equal(r["has"], ref["has"])
+    assert ref["has"].sum() > 100
