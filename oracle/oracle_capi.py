@@ -265,4 +265,27 @@ def select_keyframes(poses, dist_threshold: float = 0.1):
 
 
 def hardware_threads() -> int:
-    return int(lib().orc_hardware_threads())
+    """Host cores this process may actually use: min(affinity mask, cgroup cpu quota)."""
+    import math
+
+    n = int(lib().orc_hardware_threads())
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, math.ceil(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        n = min(n, max(1, math.ceil(q / int(g.read().split()[0]))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)

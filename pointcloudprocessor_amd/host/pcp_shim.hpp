@@ -1,0 +1,145 @@
+// pcp_shim.hpp -- C++ host shim above the C ABI (include/pcp_hip.h).
+//
+// Mirrors the reference's operator interface for the hot path so that the
+// existing C++ binary keeps its call structure:
+//
+//   pcp_amd::ViewCulling::cull        <- vlcal::ViewCulling::cull           (view_culling.hpp:34)
+//   pcp_amd::Colorizer::colorize      <- pcdColorizationAndSmooth inner loop (PointCloudProcessor.cpp:488-596)
+//   pcp_amd::Colorizer::frameVisible  <- generateColorMap + generateSegmentMap (:531-551)
+//   pcp_amd::CloudSmooth::process     <- CloudSmooth::process               (cloudSmooth.cpp:77-185)
+//
+// Error convention: the ABI never throws; this shim rethrows std::runtime_error
+// so that main.cpp:64-68 still maps failures to exit code -2.
+// Header-only, depends on the C ABI alone (no PCL / Eigen / OpenCV types): the
+// caller passes raw pointers taken from its own containers.
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "pcp_hip.h"
+
+namespace pcp_amd {
+
+class Device {
+ public:
+  explicit Device(int ordinal = 0) {
+    if (pcp_create(ordinal, &ctx_) != PCP_OK) throw std::runtime_error(std::string("pcp_hip: ") + pcp_last_error(nullptr));
+  }
+  ~Device() { pcp_destroy(ctx_); }
+  Device(const Device &) = delete;
+  Device &operator=(const Device &) = delete;
+  pcp_context *get() const { return ctx_; }
+  void check(int rc) const {
+    if (rc != PCP_OK) throw std::runtime_error(std::string("pcp_hip: ") + pcp_last_error(ctx_));
+  }
+
+  // `cloud` of the reference: pcl::PointCloud<pcl::PointXYZI>::points.data(), stride sizeof(pcl::PointXYZI) == 32
+  void uploadCloudAoS(const void *points, int64_t n, int64_t stride_bytes) { check(pcp_upload_cloud_aos(ctx_, points, n, stride_bytes)); }
+  void uploadCloud(const float *x, const float *y, const float *z, int64_t n) { check(pcp_upload_cloud(ctx_, x, y, z, n)); }
+  int64_t cloudSize() const { return pcp_cloud_size(ctx_); }
+
+  // K_camera_coefficients / D_camera (PointCloudProcessor.cpp:57-62) + ViewCulling image size (:525)
+  void setCamera(const pcp_camera &cam, const pcp_cull_params *cull = nullptr) { check(pcp_set_camera(ctx_, &cam, cull)); }
+  // selectedKeyframes' poses; T_camera_lidar_optimized when NID / manual guess ran (:504-519)
+  void setKeyframes(const std::vector<pcp_pose> &poses, const double *T_opt = nullptr, int T_opt_stride = 0) {
+    check(pcp_set_frames(ctx_, poses.data(), static_cast<int32_t>(poses.size()), T_opt, T_opt_stride));
+  }
+  // cv::Mat rgb (CV_8UC3, after the HSV round trip): data, step
+  void uploadImage(int keyframe, const uint8_t *bgr, int64_t step) { check(pcp_upload_image(ctx_, keyframe, bgr, step)); }
+  // cv::Mat grayImg (CV_8UC1)
+  void uploadMask(int keyframe, const uint8_t *gray, int64_t step) { check(pcp_upload_mask(ctx_, keyframe, gray, step)); }
+
+ private:
+  pcp_context *ctx_ = nullptr;
+};
+
+// vlcal::ViewCulling with the z-buffer routine (view_culling.cpp:52-174)
+class ViewCulling {
+ public:
+  explicit ViewCulling(Device &dev) : dev_(dev) {}
+  // indices of the kept points in input order (what `sample(points, point_indices)` consumes)
+  std::vector<int32_t> cull(int keyframe) const {
+    std::vector<uint8_t> keep(static_cast<size_t>(dev_.cloudSize()));
+    int64_t kept = 0;
+    dev_.check(pcp_cull_frame(dev_.get(), keyframe, keep.data(), &kept, nullptr));
+    std::vector<int32_t> idx;
+    idx.reserve(static_cast<size_t>(kept));
+    for (size_t i = 0; i < keep.size(); ++i)
+      if (keep[i]) idx.push_back(static_cast<int32_t>(i));
+    return idx;
+  }
+
+ private:
+  Device &dev_;
+};
+
+struct VisiblePoints {  // one keyframe's coloredCloud / scanInBodyWithRGBandMask
+  std::vector<int32_t> index;
+  std::vector<uint8_t> rgb;      // 3 per point
+  std::vector<uint16_t> mask;    // segmentMask
+  std::vector<float> xyz_cam;    // 3 per point, camera frame
+  std::vector<float> xyz_world;  // 3 per point, transformPointCloud(c2w)
+};
+
+class Colorizer {
+ public:
+  explicit Colorizer(Device &dev) : dev_(dev) {}
+  // rgbCloud.cloudWithSmoothedColor after smoothColors: rgb (3 per input point) and the
+  // removePointsWithNoColor keep flag
+  void colorize(std::vector<uint8_t> &rgb, std::vector<uint8_t> &has) const {
+    const size_t n = static_cast<size_t>(dev_.cloudSize());
+    rgb.resize(3 * n);
+    has.resize(n);
+    dev_.check(pcp_colorize(dev_.get(), rgb.data(), has.data()));
+  }
+  VisiblePoints frameVisible(int keyframe) const {
+    int64_t m = 0;
+    dev_.check(pcp_frame_visible(dev_.get(), keyframe, 0, nullptr, nullptr, nullptr, nullptr, nullptr, &m));
+    VisiblePoints v;
+    const size_t sm = static_cast<size_t>(m);
+    v.index.resize(sm);
+    v.rgb.resize(3 * sm);
+    v.mask.resize(sm);
+    v.xyz_cam.resize(3 * sm);
+    v.xyz_world.resize(3 * sm);
+    if (m > 0)
+      dev_.check(pcp_frame_visible(dev_.get(), keyframe, m, v.index.data(), v.rgb.data(), v.mask.data(), v.xyz_cam.data(),
+                                   v.xyz_world.data(), &m));
+    return v;
+  }
+
+ private:
+  Device &dev_;
+};
+
+struct SmoothedCloud {  // pcl::PointCloud<pcl::PointNormal> mls_points + corresponding_input_indices
+  std::vector<float> xyz, normal, curvature;
+  std::vector<int32_t> index;
+};
+
+class CloudSmooth {
+ public:
+  explicit CloudSmooth(Device &dev) : dev_(dev) { pcp_default_mls_params(&params_); }
+  void initialize(const pcp_mls_params &p) { params_ = p; }  // CloudSmooth::initialize(MLSParameters)
+  SmoothedCloud process() const {
+    int64_t m = 0;
+    dev_.check(pcp_mls_process(dev_.get(), &params_, &m));
+    SmoothedCloud s;
+    const size_t sm = static_cast<size_t>(m);
+    s.xyz.resize(3 * sm);
+    s.normal.resize(3 * sm);
+    s.curvature.resize(sm);
+    s.index.resize(sm);
+    dev_.check(pcp_mls_fetch(dev_.get(), m, s.xyz.data(), s.normal.data(), s.curvature.data(), s.index.data()));
+    return s;
+  }
+
+ private:
+  Device &dev_;
+  pcp_mls_params params_;
+};
+
+}  // namespace pcp_amd

@@ -1,0 +1,34 @@
+"""g++ build of the C++ host side above the C ABI (pointcloudprocessor_amd/host/)."""
+from __future__ import annotations
+
+import os
+import subprocess
+
+from . import _build
+
+HOST = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host")
+BIN = os.path.join(HOST, "bin")
+
+TARGETS = {
+    "pcp_shim_selftest": ["shim_selftest.cpp"],
+}
+
+
+def build(force: bool = False) -> dict:
+    os.makedirs(BIN, exist_ok=True)
+    out = {}
+    for name, srcs in TARGETS.items():
+        exe = os.path.join(BIN, name)
+        deps = [os.path.join(HOST, s) for s in srcs] + [os.path.join(HOST, "pcp_shim.hpp"),
+                                                       os.path.join(_build.INCLUDE, "pcp_hip.h")]
+        deps = [d for d in deps if os.path.exists(d)]
+        stale = force or not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps)
+        if stale:
+            cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-I", _build.INCLUDE, "-I", HOST] + [
+                os.path.join(HOST, s) for s in srcs] + ["-L", _build.LIB_DIR, "-lpcp_hip",
+                                                        "-Wl,-rpath,$ORIGIN/../../lib", "-o", exe]
+            proc = subprocess.run(cmd, capture_output=True, text=True)
+            if proc.returncode != 0:
+                raise RuntimeError(f"g++ failed for {name}:\n{proc.stderr[-3000:]}")
+        out[name] = exe
+    return out
