@@ -138,7 +138,8 @@ int pcp_upload_mask(pcp_context *ctx, int32_t frame, const uint8_t *gray, int64_
 /* ---- single keyframe (drop-in for the calls inside the per-keyframe loop) -- */
 /* transformPointCloud + project (PointCloudProcessor.cpp:521, view_culling.cpp:86-90,
  * PointCloudProcessor.cpp:748-754).  All outputs nullable, length n, input order:
- *   out_cell  z-buffer cell cy*mw+cx; -2 candidate outside the /14 map; -1 rejected
+ *   out_cell  z-buffer cell cy*mw+cx; -1 rejected; -2 = candidate outside the /14 map,
+ *             reported only when enable_depth_buffer_culling == 0 (where it is kept)
  *   out_pixel colour pixel v*image_width+u; -1 rejected
  *   out_range f32(||p_c||), valid where out_cell != -1 (FLT_MAX elsewhere)
  *   out_xyz_cam 3*n floats, SoA (x[n] y[n] z[n]) camera coordinates

@@ -116,7 +116,7 @@ def _trunc_ok(a):
     return np.isfinite(a) & (a > -2147483648.0) & (a < 2147483648.0)
 
 
-def project_frame(cam: dict, w2c, x, y, z, ds: int = 14):
+def project_frame(cam: dict, w2c, x, y, z, ds: int = 14, enable_zbuffer: bool = True):
     """A2-A5 per point: cam coords, (u,v), cell, pixel, range."""
     xc, yc, zc = transform(w2c, x, y, z)
     front = zc > 0
@@ -133,7 +133,8 @@ def project_frame(cam: dict, w2c, x, y, z, ds: int = 14):
     cyi = np.where(ok, np.trunc(np.where(ok, cyf, 0)), -1).astype(np.int64)
     cand = ok & (cxi >= 0) & (cyi >= 0) & (cxi < W) & (cyi < H)
     inmap = cand & (cxi < mw) & (cyi < mh)
-    cell = np.where(inmap, cyi * mw + cxi, np.where(cand, -2, -1)).astype(np.int32)
+    # -2 (candidate without a map cell) is only reported when the depth buffer is off
+    cell = np.where(inmap, cyi * mw + cxi, np.where(cand & (not enable_zbuffer), -2, -1)).astype(np.int32)
     okp = front & _trunc_ok(u) & _trunc_ok(v)
     ui = np.where(okp, np.trunc(np.where(okp, u, 0)), -1).astype(np.int64)
     vi = np.where(okp, np.trunc(np.where(okp, v, 0)), -1).astype(np.int64)
@@ -146,7 +147,7 @@ def project_frame(cam: dict, w2c, x, y, z, ds: int = 14):
 # --------------------------------------------------------------------------- A4
 def cull_frame(cam: dict, w2c, x, y, z, ds: int = 14, slack: float = 0.05, enable_zbuffer: bool = True):
     """view_culling.cpp:52-174: returns keep mask, depth map, projection dict."""
-    p = project_frame(cam, w2c, x, y, z, ds)
+    p = project_frame(cam, w2c, x, y, z, ds, enable_zbuffer)
     mw, mh = cam["cull_width"] // ds, cam["cull_height"] // ds
     dmap = np.full(mw * mh, FLT_MAX, f32)
     if not enable_zbuffer:

@@ -246,7 +246,9 @@ static inline void project_one(const orc_camera *cam, const orc_cull_params *cp,
       if (cx >= 0 && cy >= 0 && cx < cam->cull_width && cy < cam->cull_height) {
         const int32_t mw = cam->cull_width / cp->downsample_factor;
         const int32_t mh = cam->cull_height / cp->downsample_factor;
-        o->cell = (cx < mw && cy < mh) ? cy * mw + cx : -2;
+        /* -2 (candidate without a map cell) only matters, and is only reported, when the
+         * depth buffer is off: with it on such a point is dropped in pass 2 (:166-169) */
+        o->cell = (cx < mw && cy < mh) ? cy * mw + cx : (cp->enable_depth_buffer_culling ? -1 : -2);
       }
     }
   }

@@ -75,8 +75,9 @@ void orc_transform(const float m[12], const float *x, const float *y, const floa
 void orc_project_point(const orc_camera *cam, double xc, double yc, double zc, double *u, double *v);
 
 /* A2+A3+A4(candidate test)+A5(pixel): per-point outputs, all nullable.
- *   out_cell : cy*mw+cx for z-buffer candidates inside the map,
- *              -2 candidate outside the downsampled map, -1 rejected
+ *   out_cell : cy*mw+cx for z-buffer candidates inside the map, -1 rejected;
+ *              -2 = candidate outside the downsampled map, reported only when
+ *              enable_depth_buffer_culling == 0 (where such points are kept)
  *   out_pixel: vi*image_width+ui (colour lookup), -1 rejected
  *   out_range: f32(||p_c||) (valid where z_c > 0, else FLT_MAX)
  */

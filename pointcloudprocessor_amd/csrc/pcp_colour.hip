@@ -137,18 +137,19 @@ __global__ __launch_bounds__(kBlock) void k_depth_pass(const float *__restrict__
 }
 
 // ---------------------------------------------------------------------------
-// K3: single-keyframe keep mask (pass 2 of view_culling, input order).
+// K3: single-keyframe keep mask (pass 2 of view_culling), flags in input order.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_visibility(const float *__restrict__ x, const float *__restrict__ y,
                                                        const float *__restrict__ z, int64_t n, DevCamera cam,
                                                        DevFrame fr, const uint32_t *__restrict__ depth,
+                                                       const int32_t *__restrict__ perm,
                                                        uint8_t *__restrict__ keep, int32_t require_pixel) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (i >= n) return;
   const Projected p = project_point(cam, fr.w2c, x[i], y[i], z[i]);
   bool k = keep_rule(cam, p, depth);
   if (require_pixel) k = k && p.pixel >= 0;
-  keep[i] = k ? 1 : 0;
+  keep[perm ? perm[i] : i] = k ? 1 : 0;  // the cloud is walked in Morton order, flags land in input order
 }
 
 // ---------------------------------------------------------------------------
@@ -491,7 +492,7 @@ int compact_flags(pcp_context *ctx, const uint8_t *flags, int64_t n, int32_t *ou
   return PCP_OK;
 }
 
-// depth map of one keyframe from the input-order cloud into ctx->s_u32 (scratch)
+// depth map of one keyframe into ctx->s_u32 (scratch)
 static int single_frame_depth(pcp_context *ctx, int32_t frame) {
   const int64_t cells = cells_of(ctx);
   PCP_HIP_TRY(ctx, ctx->s_u32.ensure(static_cast<size_t>(cells) + 4));
@@ -500,8 +501,8 @@ static int single_frame_depth(pcp_context *ctx, int32_t frame) {
   if (ctx->n > 0 && ctx->dcam.enable_zbuf) {
     const size_t plane = plane_of(ctx);
     LaunchTimer t(ctx, PCP_K_DEPTH);
-    hipLaunchKernelGGL(k_depth_pass, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, ctx->xyz.p,
-                       ctx->xyz.p + plane, ctx->xyz.p + 2 * plane, ctx->n, ctx->dcam, ctx->frames.p, frame, frame + 1,
+    hipLaunchKernelGGL(k_depth_pass, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
+                       ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, ctx->n, ctx->dcam, ctx->frames.p, frame, frame + 1,
                        ctx->s_u32.p, cells, frame, static_cast<uint32_t *>(nullptr));
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
@@ -572,6 +573,8 @@ int pcp_project_frame(pcp_context *ctx, int32_t frame, int32_t *out_cell, int32_
   if (out_pixel) PCP_HIP_TRY(ctx, ctx->s_pixel.ensure(plane + 4));
   if (out_xyz_cam) PCP_HIP_TRY(ctx, ctx->s_cam.ensure(3 * plane + 4));
   if (n == 0) return PCP_OK;
+  // The kernel walks the Morton-ordered copy (wave-uniform early-outs) and leaves its
+  // results in that order on the device; host outputs are scattered back to input order.
   ProjectOut o{};
   o.cell = ctx->s_cell.p;
   o.range = ctx->s_range.p;
@@ -581,21 +584,33 @@ int pcp_project_frame(pcp_context *ctx, int32_t frame, int32_t *out_cell, int32_
   o.zc = out_xyz_cam ? ctx->s_cam.p + 2 * plane : nullptr;
   {
     LaunchTimer t(ctx, PCP_K_PROJECT);
-    hipLaunchKernelGGL(k_project_frame, dim3(blocks_for(div_up(n, 4))), dim3(kBlock), 0, ctx->stream, ctx->xyz.p,
-                       ctx->xyz.p + plane, ctx->xyz.p + 2 * plane, n, ctx->dcam,
+    hipLaunchKernelGGL(k_project_frame, dim3(blocks_for(div_up(n, 4))), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
+                       ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, n, ctx->dcam,
                        ctx->hframes[static_cast<size_t>(frame)], o);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
+  if (!(out_cell || out_range || out_pixel || out_xyz_cam)) return PCP_OK;
   const size_t sn = static_cast<size_t>(n);
-  if (out_cell) PCP_HIP_TRY(ctx, hipMemcpyAsync(out_cell, o.cell, sn * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (out_range) PCP_HIP_TRY(ctx, hipMemcpyAsync(out_range, o.range, sn * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (out_pixel) PCP_HIP_TRY(ctx, hipMemcpyAsync(out_pixel, o.pixel, sn * 4, hipMemcpyDeviceToHost, ctx->stream));
+  PCP_HIP_TRY(ctx, ctx->s_u32.ensure(plane + 4));
+  auto fetch = [&](const void *sorted, void *host) -> int {
+    {
+      LaunchTimer t(ctx, PCP_K_MISC);
+      hipLaunchKernelGGL(k_scatter_u32, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream,
+                         static_cast<const uint32_t *>(sorted), ctx->perm.p, n, ctx->s_u32.p);
+      PCP_HIP_TRY(ctx, hipGetLastError());
+    }
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(host, ctx->s_u32.p, sn * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PCP_OK;
+  };
+  if (out_cell && (rc = fetch(o.cell, out_cell)) != PCP_OK) return rc;
+  if (out_range && (rc = fetch(o.range, out_range)) != PCP_OK) return rc;
+  if (out_pixel && (rc = fetch(o.pixel, out_pixel)) != PCP_OK) return rc;
   if (out_xyz_cam) {
-    PCP_HIP_TRY(ctx, hipMemcpyAsync(out_xyz_cam, o.xc, sn * 4, hipMemcpyDeviceToHost, ctx->stream));
-    PCP_HIP_TRY(ctx, hipMemcpyAsync(out_xyz_cam + sn, o.yc, sn * 4, hipMemcpyDeviceToHost, ctx->stream));
-    PCP_HIP_TRY(ctx, hipMemcpyAsync(out_xyz_cam + 2 * sn, o.zc, sn * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = fetch(o.xc, out_xyz_cam)) != PCP_OK) return rc;
+    if ((rc = fetch(o.yc, out_xyz_cam + sn)) != PCP_OK) return rc;
+    if ((rc = fetch(o.zc, out_xyz_cam + 2 * sn)) != PCP_OK) return rc;
   }
-  if (out_cell || out_range || out_pixel || out_xyz_cam) PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return PCP_OK;
 }
 
@@ -609,9 +624,9 @@ int pcp_cull_frame(pcp_context *ctx, int32_t frame, uint8_t *out_keep, int64_t *
   if (n > 0) {
     const size_t plane = plane_of(ctx);
     LaunchTimer t(ctx, PCP_K_VISIBILITY);
-    hipLaunchKernelGGL(k_visibility, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, ctx->xyz.p, ctx->xyz.p + plane,
-                       ctx->xyz.p + 2 * plane, n, ctx->dcam, ctx->hframes[static_cast<size_t>(frame)], ctx->s_u32.p,
-                       ctx->s_keep.p, 0);
+    hipLaunchKernelGGL(k_visibility, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
+                       ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, n, ctx->dcam,
+                       ctx->hframes[static_cast<size_t>(frame)], ctx->s_u32.p, ctx->perm.p, ctx->s_keep.p, 0);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   if (out_kept) {
@@ -644,9 +659,9 @@ int pcp_frame_visible(pcp_context *ctx, int32_t frame, int64_t capacity, int32_t
   PCP_HIP_TRY(ctx, ctx->s_cell.ensure(plane + 4));
   {
     LaunchTimer t(ctx, PCP_K_VISIBILITY);
-    hipLaunchKernelGGL(k_visibility, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, ctx->xyz.p, ctx->xyz.p + plane,
-                       ctx->xyz.p + 2 * plane, n, ctx->dcam, ctx->hframes[static_cast<size_t>(frame)], ctx->s_u32.p,
-                       ctx->s_keep.p, 1);
+    hipLaunchKernelGGL(k_visibility, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
+                       ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, n, ctx->dcam,
+                       ctx->hframes[static_cast<size_t>(frame)], ctx->s_u32.p, ctx->perm.p, ctx->s_keep.p, 1);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   int64_t m = 0;

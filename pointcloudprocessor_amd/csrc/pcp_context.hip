@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <new>
 
 #include "pcp_internal.hpp"
@@ -408,7 +409,38 @@ int pcp_set_camera(pcp_context *ctx, const pcp_camera *cam, const pcp_cull_param
   d.mw = cam->cull_width / cp.downsample_factor;
   d.mh = cam->cull_height / cp.downsample_factor;
   d.enable_zbuf = cp.enable_depth_buffer_culling ? 1 : 0;
-  d.pad_ = 0;
+  // conservative fp32 rejection test (pcp_device.hpp): parameters
+  d.pretest = 1;
+  d.qfx = static_cast<float>(cam->fx);
+  d.qfy = static_cast<float>(cam->fy);
+  d.qcx = static_cast<float>(cam->cx);
+  d.qcy = static_cast<float>(cam->cy);
+  d.qk1 = static_cast<float>(cam->k1);
+  d.qk2 = static_cast<float>(cam->k2);
+  d.qk3 = static_cast<float>(cam->k3);
+  d.qp1 = static_cast<float>(cam->p1);
+  d.qp2 = static_cast<float>(cam->p2);
+  d.ak1 = std::fabs(d.qk1);
+  d.ak2 = std::fabs(d.qk2);
+  d.ak3 = std::fabs(d.qk3);
+  d.ap1 = std::fabs(d.qp1);
+  d.ap2 = std::fabs(d.qp2);
+  d.afx = std::fabs(d.qfx);
+  d.afy = std::fabs(d.qfy);
+  d.acx = std::fabs(d.qcx);
+  d.acy = std::fabs(d.qcy);
+  {
+    // cell rule accepts trunc(f32(u)/ds) in [0, mw) (depth buffer on) or [0, cull_w) (off);
+    // pixel rule accepts (int)u in [0, img_w).  Box = union, +-0.5 px.
+    const float ds = static_cast<float>(cp.downsample_factor);
+    const float cw = ds * static_cast<float>(d.enable_zbuf ? d.mw : d.cull_w);
+    const float ch = ds * static_cast<float>(d.enable_zbuf ? d.mh : d.cull_h);
+    d.u_lo = -(ds + 0.5f);
+    d.v_lo = -(ds + 0.5f);
+    d.u_hi = std::max(cw, static_cast<float>(d.img_w)) + 0.5f;
+    d.v_hi = std::max(ch, static_cast<float>(d.img_h)) + 0.5f;
+  }
+  if (const char *e = std::getenv("PCP_DISABLE_PRETEST")) d.pretest = (e[0] == '1') ? 0 : 1;
   ctx->have_camera = true;
   // images / depth maps are sized by the camera: drop them
   ctx->image_set.assign(ctx->image_set.size(), 0);

@@ -47,7 +47,7 @@ __device__ __forceinline__ void project_uv(const DevCamera &c, double X, double 
 
 // A4 cell: (project(p).cast<float>() / 14).cast<int>(), bounds vs the FULL cull
 // size (view_culling.cpp:86-90, sic) then vs the /14 map (:116,:155).
-// Returns cy*mw+cx, -2 (candidate outside the map) or -1 (rejected).
+// Returns cy*mw+cx, -1 (rejected) or, with the depth buffer off, -2 (candidate outside the map).
 // Values that do not fit an int32 (UB in the reference, Appendix B6) are rejected.
 __device__ __forceinline__ int32_t cull_cell(const DevCamera &c, double u, double v) {
   const float cxf = static_cast<float>(u) / c.ds_f;
@@ -56,7 +56,8 @@ __device__ __forceinline__ int32_t cull_cell(const DevCamera &c, double u, doubl
   const int32_t cx = static_cast<int32_t>(cxf);
   const int32_t cy = static_cast<int32_t>(cyf);
   if (cx < 0 || cy < 0 || cx >= c.cull_w || cy >= c.cull_h) return -1;
-  return (cx < c.mw && cy < c.mh) ? cy * c.mw + cx : -2;
+  // -2 (candidate without a map cell) is only reported when the depth buffer is off
+  return (cx < c.mw && cy < c.mh) ? cy * c.mw + cx : (c.enable_zbuf ? -1 : -2);
 }
 
 // A5 pixel: static_cast<int>(fx*xd+cx) with C truncation, bounds vs the actual
@@ -75,6 +76,41 @@ __device__ __forceinline__ double range64(float xc, float yc, float zc) {
   return sqrt((X * X + Y * Y) + Z * Z);
 }
 
+// Conservative fp32 rejection test.  Returns true only when the reference's fp64
+// projection of (xc, yc, zc), zc > 0, is CERTAIN to fail both the cull-cell rule
+// and the colour-pixel rule, so that skipping the fp64 path cannot change any result.
+//
+// The distortion polynomial g(xn, yn) is evaluated in fp32 (FMAs: this arithmetic is
+// ours, not the reference's) together with S = the same polynomial with every monomial
+// replaced by its absolute value.  Error budget against the reference's fp64 value:
+//   inputs: xn~ = xc * rcp(zc), relative error <= 2^-22 + 2^-24 (v_rcp_f32 is 1 ulp);
+//           a relative perturbation e of (xn, yn) moves a degree-<=7 polynomial by at
+//           most 7 e S  ->  <= 2.2 * 2^-20 S
+//   rounding: <= 24 fp32 operations                      ->  <= 1.5 * 2^-20 S
+//   total <= 0.93 * 2^-18 S; the test uses 2^-16 S (4x margin), the same on the final
+//   u = fx xd + cx, and the acceptance box is widened by 0.5 px.
+// Non-finite intermediates make every comparison false, i.e. "not rejected".
+__device__ __forceinline__ bool surely_rejected(const DevCamera &c, float xc, float yc, float zc) {
+  const float rz = __builtin_amdgcn_rcpf(zc);
+  const float xn = xc * rz, yn = yc * rz;
+  const float x2 = xn * xn, y2 = yn * yn;
+  const float r2 = x2 + y2, r4 = r2 * r2, r6 = r2 * r4;
+  const float rc = __builtin_fmaf(c.qk3, r6, __builtin_fmaf(c.qk2, r4, __builtin_fmaf(c.qk1, r2, 1.0f)));
+  const float ra = __builtin_fmaf(c.ak3, r6, __builtin_fmaf(c.ak2, r4, __builtin_fmaf(c.ak1, r2, 1.0f)));
+  const float t1 = 2.0f * xn * yn;
+  const float t2 = __builtin_fmaf(2.0f, x2, r2), t3 = __builtin_fmaf(2.0f, y2, r2);
+  const float at1 = fabsf(t1);
+  const float xd = __builtin_fmaf(c.qp2, t2, __builtin_fmaf(c.qp1, t1, rc * xn));
+  const float yd = __builtin_fmaf(c.qp2, t1, __builtin_fmaf(c.qp1, t3, rc * yn));
+  const float sx = __builtin_fmaf(c.ap2, t2, __builtin_fmaf(c.ap1, at1, ra * fabsf(xn)));
+  const float sy = __builtin_fmaf(c.ap2, at1, __builtin_fmaf(c.ap1, t3, ra * fabsf(yn)));
+  const float u = __builtin_fmaf(c.qfx, xd, c.qcx), v = __builtin_fmaf(c.qfy, yd, c.qcy);
+  constexpr float kErr = 1.52587890625e-05f;  // 2^-16
+  const float eu = kErr * __builtin_fmaf(c.afx, sx, c.acx);
+  const float ev = kErr * __builtin_fmaf(c.afy, sy, c.acy);
+  return (u + eu < c.u_lo) | (u - eu > c.u_hi) | (v + ev < c.v_lo) | (v - ev > c.v_hi);
+}
+
 struct Projected {
   float xc, yc, zc;
   int32_t cell;   // >=0, -2, -1
@@ -88,7 +124,7 @@ __device__ __forceinline__ Projected project_point(const DevCamera &c, const flo
   xform(m, x, y, z, p.xc, p.yc, p.zc);
   p.cell = -1;
   p.pixel = -1;
-  if (p.zc > 0.0f) {
+  if (p.zc > 0.0f && !(c.pretest && surely_rejected(c, p.xc, p.yc, p.zc))) {
     double u, v;
     project_uv(c, static_cast<double>(p.xc), static_cast<double>(p.yc), static_cast<double>(p.zc), u, v);
     p.cell = cull_cell(c, u, v);

@@ -27,7 +27,15 @@ struct DevCamera {
   int32_t cull_w, cull_h;
   int32_t mw, mh;  // cull_w/ds, cull_h/ds
   int32_t enable_zbuf;
-  int32_t pad_;
+  int32_t pretest;  // 1: run the conservative fp32 rejection test before the fp64 projection
+  // fp32 copies for the rejection test (pcp_device.hpp surely_rejected): signed and
+  // absolute coefficients, and the (u, v) box outside of which BOTH the cell rule and
+  // the pixel rule reject, widened by 0.5 px
+  float qfx, qfy, qcx, qcy;
+  float qk1, qk2, qk3, qp1, qp2;
+  float ak1, ak2, ak3, ap1, ap2;
+  float afx, afy, acx, acy;
+  float u_lo, u_hi, v_lo, v_hi;
 };
 
 // One keyframe: w2c / c2w 3x4 row-major fp32 (A1) and the pose translation used
