@@ -129,7 +129,7 @@ def main():
         eng.ctx.timing_enable(True)
         eng.ctx.timing_reset()
         step()
-        kt = {eng.ctx.kernel_name(k): eng.ctx.timing_get(k) for k in (capi.K_DEPTH, capi.K_COLOUR, capi.K_MISC)}
+        kt = {eng.ctx.kernel_name(k): eng.ctx.timing_get(k) for k in (capi.K_TILE_MASK, capi.K_DEPTH, capi.K_COLOUR, capi.K_MISC)}
         # ---- roofline leg: the single-keyframe projection kernel, one launch per keyframe ----
         eng.ctx.timing_reset()
         for f in range(F):
@@ -234,6 +234,7 @@ def main():
             },
             "coloured_points_rank0": coloured,
             "kernels_ms": {k: round(v[0], 3) for k, v in kt.items()},
+            "tile_pairs_kept": round(eng.ctx.tile_mask_density(), 4),
             "setup_s": round(t_setup, 1),
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -90,7 +90,8 @@ enum {
   PCP_K_MISC = 6,       /* fills, compaction, permutation */
   PCP_K_SOR = 7,        /* StatisticalOutlierRemoval kNN mean distance */
   PCP_K_MLS_VOXEL = 8,  /* VOXEL_GRID_DILATION upsampling */
-  PCP_K_COUNT = 9
+  PCP_K_TILE_MASK = 9,  /* tile x keyframe visibility masks (conservative culling) */
+  PCP_K_COUNT = 10
 };
 
 /* ---- lifecycle ---------------------------------------------------------- */
@@ -204,6 +205,8 @@ int pcp_timing_enable(pcp_context *ctx, int32_t on);
 int pcp_timing_reset(pcp_context *ctx);
 int pcp_timing_get(pcp_context *ctx, int32_t kernel_id, double *total_ms, int64_t *launches);
 const char *pcp_kernel_name(int32_t kernel_id);
+/* diagnostic: fraction of (tile, keyframe) pairs the conservative culling keeps (after pcp_depth_pass) */
+int pcp_tile_mask_density(pcp_context *ctx, double *kept_fraction);
 
 #ifdef __cplusplus
 }

@@ -22,8 +22,8 @@ PCP_ERR_DEVICE = -3
 PCP_ERR_NOMEM = -4
 PCP_ERR_RANGE = -5
 
-K_PROJECT, K_DEPTH, K_COLOUR, K_VISIBILITY, K_MLS_GRID, K_MLS_FIT, K_MISC, K_SOR, K_MLS_VOXEL = range(9)
-K_COUNT = 9
+K_PROJECT, K_DEPTH, K_COLOUR, K_VISIBILITY, K_MLS_GRID, K_MLS_FIT, K_MISC, K_SOR, K_MLS_VOXEL, K_TILE_MASK = range(10)
+K_COUNT = 10
 
 
 class PcpError(RuntimeError):
@@ -370,6 +370,11 @@ class Context:
         cnt = C.c_int64()
         self._check(self.lib.pcp_timing_get(self.h, C.c_int32(kernel_id), C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+    def tile_mask_density(self) -> float:
+        v = C.c_double()
+        self._check(self.lib.pcp_tile_mask_density(self.h, C.byref(v)))
+        return v.value
 
     def kernel_name(self, kernel_id: int) -> str:
         return self.lib.pcp_kernel_name(C.c_int32(kernel_id)).decode()

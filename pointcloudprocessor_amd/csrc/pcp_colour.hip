@@ -18,6 +18,7 @@
 //   top-5 state  SoA score[5][n] rgb[5][n] frame[5][n] count[n]
 #include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 
 #include "pcp_device.hpp"
 
@@ -92,8 +93,103 @@ __global__ __launch_bounds__(kBlock) void k_project_frame(const float *__restric
 }
 
 // ---------------------------------------------------------------------------
-// K2: z-buffer MIN pass, keyframes [f0, f1), one lane per point, the point
-// stays in registers across the keyframe loop (12 B read per point per pass).
+// K0: tile x keyframe visibility masks.  A tile is 64 consecutive Morton-ordered
+// points = one wavefront of the batched kernels; its bounding sphere is computed
+// at upload.  Bit f of tile_mask[tile][f >> 5] is CLEARED only when every point of
+// the tile is certain to be rejected by the reference in keyframe f, proved in fp64
+// with outward-padded interval arithmetic:
+//   (a) the sphere, transformed with the fp32 matrix the reference uses and
+//       inflated by the matrix's spectral-norm bound and the fp32 rounding slack of
+//       the per-point transform, lies in z <= 0; or
+//   (b) it lies in z > 0 and the interval image of its normalised coordinates under
+//       the distortion polynomial misses the acceptance box of both the cull-cell
+//       and the colour-pixel rule (same box as surely_rejected()).
+// Anything else (straddling z = 0, fold-back distortion, huge tiles) keeps the bit.
+// ---------------------------------------------------------------------------
+struct Interval {
+  double lo, hi;
+};
+__device__ __forceinline__ Interval iv_add(Interval a, Interval b) { return {a.lo + b.lo, a.hi + b.hi}; }
+__device__ __forceinline__ Interval iv_scale(double k, Interval a) {
+  return k >= 0.0 ? Interval{k * a.lo, k * a.hi} : Interval{k * a.hi, k * a.lo};
+}
+__device__ __forceinline__ Interval iv_mul(Interval a, Interval b) {
+  const double p0 = a.lo * b.lo, p1 = a.lo * b.hi, p2 = a.hi * b.lo, p3 = a.hi * b.hi;
+  return {fmin(fmin(p0, p1), fmin(p2, p3)), fmax(fmax(p0, p1), fmax(p2, p3))};
+}
+__device__ __forceinline__ Interval iv_sqr(Interval a) {
+  const double l = fabs(a.lo), h = fabs(a.hi);
+  const double mx = fmax(l, h), mn = (a.lo <= 0.0 && a.hi >= 0.0) ? 0.0 : fmin(l, h);
+  return {mn * mn, mx * mx};
+}
+__device__ __forceinline__ Interval iv_pad(Interval a) {  // absorbs the fp64 rounding of the interval arithmetic
+  const double e = 1e-12 * (fabs(a.lo) + fabs(a.hi)) + 1e-300;
+  return {a.lo - e, a.hi + e};
+}
+
+__device__ __forceinline__ bool tile_surely_rejected(const DevCamera &c, const DevFrame &fr, float4 sph) {
+  const double cx = sph.x, cy = sph.y, cz = sph.z;
+  const float *m = fr.w2c;
+  const double X = (m[0] * cx + m[1] * cy) + (m[2] * cz + m[3]);
+  const double Y = (m[4] * cx + m[5] * cy) + (m[6] * cz + m[7]);
+  const double Z = (m[8] * cx + m[9] * cy) + (m[10] * cz + m[11]);
+  // |M (p - c)| <= s |p - c|; fp32 transform rounding <= 3 * 2^-24 * sum of term magnitudes
+  const double mag = fr.norm_bound * (fabs(cx) + fabs(cy) + fabs(cz) + 3.0 * sph.w) + fabs(static_cast<double>(m[3])) +
+                     fabs(static_cast<double>(m[7])) + fabs(static_cast<double>(m[11])) + 1e-3;
+  const double rho = fr.norm_bound * static_cast<double>(sph.w) * (1.0 + 1e-6) + 1e-6 * mag;
+  if (!(rho >= 0.0) || !isfinite(X + Y + Z + rho)) return false;
+  if (Z + rho <= 0.0) return true;   // (a) entirely behind the camera
+  if (Z - rho <= 0.0) return false;  // straddles z = 0: no bound on x / z
+  const Interval zi{Z - rho, Z + rho};
+  const Interval iz{1.0 / zi.hi, 1.0 / zi.lo};
+  const Interval xn = iv_pad(iv_mul(Interval{X - rho, X + rho}, iz));
+  const Interval yn = iv_pad(iv_mul(Interval{Y - rho, Y + rho}, iz));
+  const Interval x2 = iv_sqr(xn), y2 = iv_sqr(yn);
+  const Interval r2 = iv_add(x2, y2);
+  const Interval r4 = iv_sqr(r2);
+  const Interval r6 = iv_mul(r2, r4);
+  Interval rc = iv_add(iv_add(iv_scale(c.k1, r2), iv_scale(c.k2, r4)), iv_scale(c.k3, r6));
+  rc.lo += 1.0;
+  rc.hi += 1.0;
+  const Interval t1 = iv_scale(2.0, iv_mul(xn, yn));
+  const Interval t2 = iv_add(r2, iv_scale(2.0, x2));
+  const Interval t3 = iv_add(r2, iv_scale(2.0, y2));
+  const Interval xd = iv_pad(iv_add(iv_add(iv_mul(rc, xn), iv_scale(c.p1, t1)), iv_scale(c.p2, t2)));
+  const Interval yd = iv_pad(iv_add(iv_add(iv_mul(rc, yn), iv_scale(c.p1, t3)), iv_scale(c.p2, t1)));
+  Interval u = iv_pad(iv_scale(c.fx, xd)), v = iv_pad(iv_scale(c.fy, yd));
+  u.lo += c.cx; u.hi += c.cx;
+  v.lo += c.cy; v.hi += c.cy;
+  if (!isfinite(u.lo + u.hi + v.lo + v.hi)) return false;
+  // the box already carries a 0.5 px margin (pcp_set_camera)
+  return u.hi < static_cast<double>(c.u_lo) || u.lo > static_cast<double>(c.u_hi) ||
+         v.hi < static_cast<double>(c.v_lo) || v.lo > static_cast<double>(c.v_hi);
+}
+
+// one lane per (tile, 32-keyframe word)
+__global__ __launch_bounds__(kBlock) void k_tile_mask(const float4 *__restrict__ spheres, int64_t tiles, DevCamera cam,
+                                                      const DevFrame *__restrict__ frames, int32_t n_frames,
+                                                      int32_t w0, int32_t w1, int32_t words,
+                                                      uint32_t *__restrict__ tile_mask, int32_t cull_enabled) {
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int32_t nw = w1 - w0;
+  const int64_t tile = g / nw;
+  if (tile >= tiles) return;
+  const int32_t w = w0 + static_cast<int32_t>(g - tile * nw);
+  const float4 sph = spheres[tile];
+  uint32_t word = 0u;
+  for (int32_t b = 0; b < 32; ++b) {
+    const int32_t f = (w << 5) + b;
+    if (f >= n_frames) break;
+    if (!(cull_enabled && tile_surely_rejected(cam, frames[f], sph))) word |= 1u << b;
+  }
+  tile_mask[tile * words + w] = word;
+}
+
+// ---------------------------------------------------------------------------
+// K2: z-buffer MIN pass, keyframes [f0, f1).  One lane per point, one wavefront
+// per tile; the point stays in registers across the keyframe loop (12 B read per
+// point per pass) and the wavefront only visits keyframes its tile mask keeps.
+// tile_mask == nullptr: visit every keyframe of the range.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void depth_min(uint32_t *__restrict__ map, int32_t cell, float range) {
   const uint32_t bits = __float_as_uint(range);
@@ -101,37 +197,65 @@ __device__ __forceinline__ void depth_min(uint32_t *__restrict__ map, int32_t ce
   if (bits < map[cell]) atomicMin(map + cell, bits);
 }
 
+__device__ __forceinline__ uint32_t range_bits(int32_t w, int32_t f0, int32_t f1) {
+  const int32_t fb = max(f0, w << 5), fe = min(f1, (w << 5) + 32);
+  const int32_t nb = fe - fb;
+  return nb <= 0 ? 0u : (((nb >= 32) ? 0xffffffffu : ((1u << nb) - 1u)) << (fb & 31));
+}
+
 __global__ __launch_bounds__(kBlock) void k_depth_pass(const float *__restrict__ x, const float *__restrict__ y,
                                                        const float *__restrict__ z, int64_t n, DevCamera cam,
                                                        const DevFrame *__restrict__ frames, int32_t f0, int32_t f1,
                                                        uint32_t *__restrict__ depth, int64_t cells,
-                                                       int32_t depth_first_frame,
-                                                       uint32_t *__restrict__ cand_bits) {
+                                                       int32_t depth_first_frame, uint32_t *__restrict__ tile_mask,
+                                                       int32_t words) {
+  // per-wavefront combining table: slot = cell & 63 holds min over (cell << 32 | range bits)
+  __shared__ unsigned long long combine[kBlock];
+  const int lane = threadIdx.x & 63;
+  unsigned long long *tbl = combine + (threadIdx.x & ~63);
   const int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const bool live = j < n;
   const float px = live ? x[j] : 0.0f, py = live ? y[j] : 0.0f, pz = live ? z[j] : 0.0f;
+  const int64_t tile = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(j >> 6));
   for (int32_t w = f0 >> 5; w <= (f1 - 1) >> 5; ++w) {
-    const int32_t fb = max(f0, w << 5), fe = min(f1, (w << 5) + 32);
-    uint32_t word = 0u;
-    for (int32_t f = fb; f < fe; ++f) {
+    const uint32_t in_range = range_bits(w, f0, f1);
+    uint32_t todo = in_range;
+    if (tile_mask) todo &= tile_mask[tile * words + w];
+    todo = __builtin_amdgcn_readfirstlane(todo);
+    uint32_t seen = 0u;  // keyframes in which some lane can be coloured
+    while (todo) {
+      const int32_t b = __builtin_ctz(todo);
+      const int32_t f = (w << 5) + b;
+      todo &= todo - 1u;
       const DevFrame &fr = frames[f];
       const Projected p = project_point(cam, fr.w2c, px, py, pz);
-      if (!live) continue;
-      const bool cand = cam.enable_zbuf ? p.cell >= 0 : p.cell != -1;
-      if (cam.enable_zbuf && p.cell >= 0)
-        depth_min(depth + static_cast<int64_t>(f - depth_first_frame) * cells, p.cell,
-                  static_cast<float>(range64(p.xc, p.yc, p.zc)));
-      if (cand && p.pixel >= 0) word |= 1u << (f & 31);
-    }
-    if (cand_bits && live) {
-      uint32_t *dst = cand_bits + static_cast<int64_t>(w) * n + j;
-      const int32_t nb = fe - fb;
-      if (nb == 32) {
-        *dst = word;
-      } else {
-        const uint32_t mask = ((nb >= 32) ? 0xffffffffu : ((1u << nb) - 1u)) << (fb & 31);
-        *dst = (*dst & ~mask) | word;
+      const bool in_map = live && p.cell >= 0;
+      const bool cand = live && p.pixel >= 0 && (cam.enable_zbuf ? p.cell >= 0 : p.cell != -1);
+      if (__ballot(cand)) seen |= 1u << b;
+      if (cam.enable_zbuf && __ballot(in_map)) {
+        // wave-level combine: lanes of a tile hit a handful of cells, one atomic per cell suffices
+        uint32_t *map = depth + static_cast<int64_t>(f - depth_first_frame) * cells;
+        unsigned long long key = ~0ull;
+        if (in_map)
+          key = (static_cast<unsigned long long>(static_cast<uint32_t>(p.cell)) << 32) |
+                __float_as_uint(static_cast<float>(range64(p.xc, p.yc, p.zc)));
+        tbl[lane] = ~0ull;
+        __builtin_amdgcn_wave_barrier();
+        if (in_map) atomicMin(&tbl[p.cell & 63], key);
+        __builtin_amdgcn_wave_barrier();
+        if (in_map) {
+          const unsigned long long got = tbl[p.cell & 63];
+          // winner of its cell, or a cell that lost its slot to a smaller cell id
+          if (got == key || static_cast<uint32_t>(got >> 32) != static_cast<uint32_t>(p.cell))
+            depth_min(map, p.cell, __uint_as_float(static_cast<uint32_t>(key)));
+        }
+        __builtin_amdgcn_wave_barrier();
       }
+    }
+    // drop the pairs in which no lane is a colouring candidate: the colour pass skips them
+    if (tile_mask && lane == 0 && live) {
+      uint32_t *dst = tile_mask + tile * words + w;
+      *dst = (*dst & ~in_range) | seen;
     }
   }
 }
@@ -153,15 +277,9 @@ __global__ __launch_bounds__(kBlock) void k_visibility(const float *__restrict__
 }
 
 // ---------------------------------------------------------------------------
-// K4: visibility + colour + scores + top-5 over keyframes [f0, f1).
-// flags: bit0 load state, bit1 store state, bit2 write packed result.
+// K4: visibility + colour + scores + top-5 over keyframes [f0, f1), same tile
+// mask walk as K2.  flags: bit0 load state, bit1 store state, bit2 write packed result.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v |= __shfl_xor(v, o, 64);
-  return v;
-}
-
 struct TopState {
   float *score;
   uint32_t *rgb;
@@ -173,12 +291,13 @@ __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict_
                                                         const float *__restrict__ z, int64_t n, DevCamera cam,
                                                         const DevFrame *__restrict__ frames, int32_t f0, int32_t f1,
                                                         const uint32_t *__restrict__ depth, int64_t cells,
-                                                        const uint32_t *__restrict__ cand_bits,
+                                                        const uint32_t *__restrict__ tile_mask, int32_t words,
                                                         const uint32_t *__restrict__ images, int64_t image_px,
                                                         TopState st, uint32_t *__restrict__ rgba, int32_t flags) {
   const int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const bool live = j < n;
   const float px = live ? x[j] : 0.0f, py = live ? y[j] : 0.0f, pz = live ? z[j] : 0.0f;
+  const int64_t tile = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(j >> 6));
   Top5 t;
   t.init();
   if ((flags & 1) && live) {
@@ -191,25 +310,19 @@ __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict_
     t.count = st.count[j];
   }
   for (int32_t w = f0 >> 5; w <= (f1 - 1) >> 5; ++w) {
-    const int32_t fb = max(f0, w << 5), fe = min(f1, (w << 5) + 32);
-    const int32_t nb = fe - fb;
-    const uint32_t mask = ((nb >= 32) ? 0xffffffffu : ((1u << nb) - 1u)) << (fb & 31);
-    const uint32_t word = live ? (cand_bits[static_cast<int64_t>(w) * n + j] & mask) : 0u;
-    // keyframes any lane of this wave needs, as a wave-uniform scalar
-    uint32_t todo = __builtin_amdgcn_readfirstlane(wave_or(word));
+    uint32_t todo = range_bits(w, f0, f1);
+    if (tile_mask) todo &= tile_mask[tile * words + w];
+    todo = __builtin_amdgcn_readfirstlane(todo);
     while (todo) {
-      const int32_t b = __builtin_ctz(todo);
+      const int32_t f = (w << 5) + __builtin_ctz(todo);
       todo &= todo - 1u;
-      const int32_t f = (w << 5) + b;
-      if ((word >> b) & 1u) {
-        const DevFrame &fr = frames[f];
-        const Projected p = project_point(cam, fr.w2c, px, py, pz);
-        if (p.pixel >= 0 && keep_rule(cam, p, depth + static_cast<int64_t>(f) * cells)) {
-          const uint32_t texel = images[static_cast<int64_t>(f) * image_px + p.pixel];  // B | G<<8 | R<<16
-          // 0x00RRGGBB == R<<16 | G<<8 | B: the texel's low 24 bits (PointCloudProcessor.cpp:760-762)
-          const float s = final_score(p.xc, p.yc, p.zc, fr.px, fr.py, fr.pz);
-          t.insert(s, texel & 0xffffffu, f);
-        }
+      const DevFrame &fr = frames[f];
+      const Projected p = project_point(cam, fr.w2c, px, py, pz);
+      if (live && p.pixel >= 0 && keep_rule(cam, p, depth + static_cast<int64_t>(f) * cells)) {
+        // texel = B | G<<8 | R<<16 | mask<<24; its low 24 bits are 0x00RRGGBB (PointCloudProcessor.cpp:760-762)
+        const uint32_t texel = images[static_cast<int64_t>(f) * image_px + p.pixel];
+        const float s = final_score(p.xc, p.yc, p.zc, fr.px, fr.py, fr.pz);
+        t.insert(s, texel & 0xffffffu, f);
       }
     }
   }
@@ -449,10 +562,11 @@ static int ensure_depth(pcp_context *ctx) {
     PCP_HIP_TRY(ctx, ctx->depth.ensure(need));
     std::fill(ctx->depth_valid.begin(), ctx->depth_valid.end(), uint8_t(0));
   }
-  const size_t words = static_cast<size_t>((ctx->n_frames + 31) / 32) * static_cast<size_t>(ctx->n) + 4;
-  if (ctx->cand_bits.count < words) {
-    PCP_HIP_TRY(ctx, ctx->cand_bits.ensure(words));
-    PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->cand_bits.p, 0, words * 4, ctx->stream));
+  const int32_t words = (ctx->n_frames + 31) / 32;
+  const size_t need_mask = static_cast<size_t>(words) * static_cast<size_t>(std::max<int64_t>(ctx->n_tiles, 1)) + 4;
+  if (ctx->tile_mask.count < need_mask || ctx->mask_words != words) {
+    PCP_HIP_TRY(ctx, ctx->tile_mask.ensure(need_mask));
+    ctx->mask_words = words;
     std::fill(ctx->depth_valid.begin(), ctx->depth_valid.end(), uint8_t(0));
   }
   return PCP_OK;
@@ -503,7 +617,7 @@ static int single_frame_depth(pcp_context *ctx, int32_t frame) {
     LaunchTimer t(ctx, PCP_K_DEPTH);
     hipLaunchKernelGGL(k_depth_pass, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
                        ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, ctx->n, ctx->dcam, ctx->frames.p, frame, frame + 1,
-                       ctx->s_u32.p, cells, frame, static_cast<uint32_t *>(nullptr));
+                       ctx->s_u32.p, cells, frame, static_cast<uint32_t *>(nullptr), 0);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   return PCP_OK;
@@ -720,11 +834,27 @@ int pcp_depth_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
     return rc;
   if (ctx->n > 0) {
     const size_t plane = plane_of(ctx);
-    LaunchTimer t(ctx, PCP_K_DEPTH);
-    hipLaunchKernelGGL(k_depth_pass, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
-                       ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, ctx->n, ctx->dcam, ctx->frames.p, frame_begin,
-                       frame_end, ctx->depth.p, cells, 0, ctx->cand_bits.p);
-    PCP_HIP_TRY(ctx, hipGetLastError());
+    // tile x keyframe masks for the words this range touches
+    const int32_t w0 = frame_begin >> 5, w1 = ((frame_end - 1) >> 5) + 1;
+    static const bool cull_tiles = [] {
+      const char *e = std::getenv("PCP_DISABLE_TILE_CULL");
+      return !(e && e[0] == '1');
+    }();
+    {
+      LaunchTimer t(ctx, PCP_K_TILE_MASK);
+      const int64_t items = ctx->n_tiles * (w1 - w0);
+      hipLaunchKernelGGL(k_tile_mask, dim3(blocks_for(items)), dim3(kBlock), 0, ctx->stream,
+                         reinterpret_cast<const float4 *>(ctx->tile_sphere.p), ctx->n_tiles, ctx->dcam, ctx->frames.p,
+                         ctx->n_frames, w0, w1, ctx->mask_words, ctx->tile_mask.p, cull_tiles ? 1 : 0);
+      PCP_HIP_TRY(ctx, hipGetLastError());
+    }
+    {
+      LaunchTimer t(ctx, PCP_K_DEPTH);
+      hipLaunchKernelGGL(k_depth_pass, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
+                         ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, ctx->n, ctx->dcam, ctx->frames.p, frame_begin,
+                         frame_end, ctx->depth.p, cells, 0, ctx->tile_mask.p, ctx->mask_words);
+      PCP_HIP_TRY(ctx, hipGetLastError());
+    }
   }
   for (int32_t f = frame_begin; f < frame_end; ++f) ctx->depth_valid[static_cast<size_t>(f)] = 1;
   return PCP_OK;
@@ -788,7 +918,7 @@ static int colour_pass_impl(pcp_context *ctx, int32_t frame_begin, int32_t frame
     LaunchTimer t(ctx, PCP_K_COLOUR);
     hipLaunchKernelGGL(k_colour_pass, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
                        ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, ctx->n, ctx->dcam, ctx->frames.p, frame_begin,
-                       frame_end, ctx->depth.p, cells_of(ctx), ctx->cand_bits.p, ctx->images.p,
+                       frame_end, ctx->depth.p, cells_of(ctx), ctx->tile_mask.p, ctx->mask_words, ctx->images.p,
                        static_cast<int64_t>(ctx->dcam.img_w) * ctx->dcam.img_h, st, ctx->rgba_sorted.p, flags);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
@@ -897,6 +1027,19 @@ int pcp_download_result_packed(pcp_context *ctx, uint32_t *out_rgba) {
   if (ctx->n > 0)
     PCP_HIP_TRY(ctx, hipMemcpyAsync(out_rgba, ctx->rgba.p, static_cast<size_t>(ctx->n) * 4, hipMemcpyDeviceToHost, ctx->stream));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PCP_OK;
+}
+
+int pcp_tile_mask_density(pcp_context *ctx, double *kept_fraction) {
+  if (!ctx || !kept_fraction) return PCP_ERR_INVALID;
+  if (!ctx->tile_mask.p || ctx->n_tiles == 0 || ctx->n_frames == 0)
+    return set_error(ctx, PCP_ERR_STATE, "pcp_tile_mask_density: no masks (call pcp_depth_pass)");
+  std::vector<uint32_t> h(static_cast<size_t>(ctx->n_tiles) * ctx->mask_words);
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(h.data(), ctx->tile_mask.p, h.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  uint64_t bits = 0;
+  for (uint32_t w : h) bits += static_cast<uint64_t>(__builtin_popcount(w));
+  *kept_fraction = static_cast<double>(bits) / (static_cast<double>(ctx->n_tiles) * ctx->n_frames);
   return PCP_OK;
 }
 

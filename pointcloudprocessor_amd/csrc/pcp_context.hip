@@ -208,6 +208,7 @@ static int store_cloud(pcp_context *ctx, const float *x, const float *y, const f
   PCP_HIP_TRY(ctx, ctx->sxyz.ensure(3 * plane + 4));
   PCP_HIP_TRY(ctx, ctx->perm.ensure(sn + 4));
   ctx->n = n;
+  ctx->n_tiles = 0;
   ctx->colour_state_live = false;
   ctx->colour_result_live = false;
   ctx->mls_count = 0;
@@ -225,6 +226,38 @@ static int store_cloud(pcp_context *ctx, const float *x, const float *y, const f
     sorted[plane + static_cast<size_t>(j)] = y[i];
     sorted[2 * plane + static_cast<size_t>(j)] = z[i];
   }
+  // bounding sphere of every 64-point tile (one wavefront of the batched kernels)
+  const int64_t tiles = (n + 63) / 64;
+  std::vector<float> spheres(static_cast<size_t>(tiles) * 4);
+  for (int64_t t = 0; t < tiles; ++t) {
+    const int64_t b = t * 64, e = std::min<int64_t>(n, b + 64);
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int64_t j = b; j < e; ++j)
+      for (int a = 0; a < 3; ++a) {
+        const double v = sorted[static_cast<size_t>(a) * plane + static_cast<size_t>(j)];
+        lo[a] = std::min(lo[a], v);
+        hi[a] = std::max(hi[a], v);
+      }
+    float c[3];
+    for (int a = 0; a < 3; ++a) c[a] = static_cast<float>(0.5 * (lo[a] + hi[a]));
+    double r2 = 0.0;
+    for (int64_t j = b; j < e; ++j) {
+      double d2 = 0.0;
+      for (int a = 0; a < 3; ++a) {
+        const double d = static_cast<double>(sorted[static_cast<size_t>(a) * plane + static_cast<size_t>(j)]) - static_cast<double>(c[a]);
+        d2 += d * d;
+      }
+      r2 = std::max(r2, d2);
+    }
+    spheres[static_cast<size_t>(t) * 4 + 0] = c[0];
+    spheres[static_cast<size_t>(t) * 4 + 1] = c[1];
+    spheres[static_cast<size_t>(t) * 4 + 2] = c[2];
+    // rounded up: the radius must dominate every member's distance to the fp32 centre
+    spheres[static_cast<size_t>(t) * 4 + 3] = std::nextafter(static_cast<float>(std::sqrt(r2) * (1.0 + 1e-6)), FLT_MAX);
+  }
+  ctx->n_tiles = tiles;
+  PCP_HIP_TRY(ctx, ctx->tile_sphere.ensure(static_cast<size_t>(tiles) * 4 + 4));
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->tile_sphere.p, spheres.data(), static_cast<size_t>(tiles) * 16, hipMemcpyHostToDevice, ctx->stream));
   PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->sxyz.p, sorted.data(), 3 * plane * 4, hipMemcpyHostToDevice, ctx->stream));
   PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->perm.p, perm.data(), sn * 4, hipMemcpyHostToDevice, ctx->stream));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -292,7 +325,8 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->frames.release();
   ctx->images.release();
   ctx->depth.release();
-  ctx->cand_bits.release();
+  ctx->tile_sphere.release();
+  ctx->tile_mask.release();
   ctx->top_score.release();
   ctx->top_rgb.release();
   ctx->top_frame.release();
@@ -441,6 +475,9 @@ int pcp_set_camera(pcp_context *ctx, const pcp_camera *cam, const pcp_cull_param
     d.v_hi = std::max(ch, static_cast<float>(d.img_h)) + 0.5f;
   }
   if (const char *e = std::getenv("PCP_DISABLE_PRETEST")) d.pretest = (e[0] == '1') ? 0 : 1;
+  d.exp_flags = 0;
+  d.pad2_ = 0;
+  if (const char *e = std::getenv("PCP_EXP")) d.exp_flags = std::atoi(e);
   ctx->have_camera = true;
   // images / depth maps are sized by the camera: drop them
   ctx->image_set.assign(ctx->image_set.size(), 0);
@@ -502,7 +539,19 @@ int pcp_set_frames(pcp_context *ctx, const pcp_pose *poses, int32_t n_frames, co
     d.px = poses[f].x;
     d.py = poses[f].y;
     d.pz = poses[f].z;
-    d.pad_ = 0.0;
+    {
+      // spectral norm of the 3x3 linear part L of w2c (as stored, fp32): lambda_max(L^T L)
+      // <= ||L^T L||_inf; 1 for a rotation, larger for un-normalised quaternions
+      double g[3][3];
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+          g[a][b] = 0.0;
+          for (int k = 0; k < 3; ++k) g[a][b] += static_cast<double>(d.w2c[4 * k + a]) * static_cast<double>(d.w2c[4 * k + b]);
+        }
+      double rowmax = 0.0;
+      for (int a = 0; a < 3; ++a) rowmax = std::max(rowmax, std::fabs(g[a][0]) + std::fabs(g[a][1]) + std::fabs(g[a][2]));
+      d.norm_bound = std::sqrt(rowmax) * (1.0 + 1e-9);
+    }
   }
   PCP_HIP_TRY(ctx, ctx->frames.ensure(static_cast<size_t>(n_frames) + 1));
   if (n_frames > 0)
@@ -548,7 +597,7 @@ int pcp_timing_get(pcp_context *ctx, int32_t kernel_id, double *total_ms, int64_
 
 const char *pcp_kernel_name(int32_t kernel_id) {
   static const char *names[PCP_K_COUNT] = {"project_frame", "depth_pass", "colour_pass", "visibility", "mls_grid",
-                                           "mls_fit",       "misc",       "sor",         "mls_voxel"};
+                                           "mls_fit",       "misc",       "sor",         "mls_voxel",   "tile_mask"};
   return (kernel_id >= 0 && kernel_id < PCP_K_COUNT) ? names[kernel_id] : "?";
 }
 

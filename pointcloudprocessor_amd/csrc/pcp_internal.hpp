@@ -36,15 +36,18 @@ struct DevCamera {
   float ak1, ak2, ak3, ap1, ap2;
   float afx, afy, acx, acy;
   float u_lo, u_hi, v_lo, v_hi;
+  int32_t exp_flags;  // PCP_EXP experiments (profiling only)
+  int32_t pad2_;
 };
 
-// One keyframe: w2c / c2w 3x4 row-major fp32 (A1) and the pose translation used
-// by computeOrientationScore (hpp:207, B4).  128 B so a frame is two cache lines.
+// One keyframe: w2c / c2w 3x4 row-major fp32 (A1), the pose translation used by
+// computeOrientationScore (hpp:207, B4) and an upper bound of the spectral norm of
+// w2c's linear part (tile culling).  128 B so a frame is two cache lines.
 struct DevFrame {
   float w2c[12];
   float c2w[12];
   double px, py, pz;
-  double pad_;
+  double norm_bound;
 };
 static_assert(sizeof(DevFrame) == 128, "DevFrame layout");
 
@@ -116,8 +119,12 @@ struct pcp_context {
   pcp::DevBuf<uint32_t> depth;
   std::vector<uint8_t> depth_valid;
 
-  // candidate bitmask from the depth pass: words[(f/32)*n + j], sorted order
-  pcp::DevBuf<uint32_t> cand_bits;
+  // tiles = wavefront-sized runs of 64 Morton-ordered points: bounding spheres
+  // (x, y, z, radius) and the tile x keyframe visibility masks [tile][mask_words]
+  int64_t n_tiles = 0;
+  pcp::DevBuf<float> tile_sphere;
+  pcp::DevBuf<uint32_t> tile_mask;
+  int32_t mask_words = 0;
 
   // per-point colour state (sorted order) and packed results
   pcp::DevBuf<float> top_score;     // 5*n

@@ -94,3 +94,61 @@ def test_pretest_on_scene_all_keyframes(gpu_ctx_factory, oracle):
         keep_r, dmap_r, kept_r = oracle.cull_frame(ocam, ocp, w2c, x, y, z, 8)
         keep_g, dmap_g, kept_g = ctx.cull_frame(f)
         assert np.array_equal(dmap_g.view(np.uint32), dmap_r.view(np.uint32)) and np.array_equal(keep_g, keep_r)
+
+
+@pytest.mark.parametrize("name", ["reference", "barrel", "fold_back", "tangential"])
+def test_tile_culling_never_changes_colours(gpu_ctx_factory, oracle, name):
+    """Whole batched run (tile masks + pre-test) against the oracle for several
+    distortion models: depth maps bit-exact, top-5 lists and colours equal."""
+    from pointcloudprocessor_amd import capi, synth
+
+    cd = dict(synth.camera_dict("tiny"))
+    cd.update(CAMS[name])
+    x, y, z, _ = synth.make_cloud(150_000, seed=5)
+    poses, _ = synth.make_trajectory(40)
+    poses = poses[::5]  # 8 well-separated keyframes
+    W, H = cd["image_width"], cd["image_height"]
+    imgs = [synth.make_image(f, W, H) for f in range(len(poses))]
+    ctx = gpu_ctx_factory()
+    ctx.set_camera(cam_struct(capi, cd))
+    ctx.upload_cloud(x, y, z)
+    ctx.set_frames(poses)
+    for f, im in enumerate(imgs):
+        ctx.upload_image(f, im)
+    ocam, ocp = cam_struct(oracle, cd), oracle.default_cull_params()
+    ref = oracle.colorize(ocam, ocp, x, y, z, poses, imgs, threads=8)
+    ctx.colour_reset()
+    ctx.depth_pass()
+    for f in range(len(poses)):
+        w2c, _ = oracle.pose_to_matrices(poses[f])
+        _, dmap, _ = oracle.cull_frame(ocam, ocp, w2c, x, y, z, 8)
+        assert np.array_equal(ctx.download_depth_map(f).view(np.uint32), dmap.view(np.uint32)), (name, f)
+    ctx.colour_pass()
+    got = ctx.colour_finalise(want_top=True)
+    assert np.array_equal(got["count"], ref["count"]), name
+    assert np.array_equal(got["top_frame"], ref["top_frame"]) and np.array_equal(got["top_rgb"], ref["top_rgb"])
+    assert np.array_equal(got["top_score"], ref["top_score"])
+    assert np.array_equal(got["rgb"], ref["rgb"]) and np.array_equal(got["has"], ref["has"])
+    assert ref["has"].sum() > 2000
+    ctx.close()
+
+
+def test_colorize_1m_points_16_keyframes_cfg_camera(gpu_ctx_factory, oracle):
+    from pointcloudprocessor_amd import capi, synth
+
+    cd = synth.camera_dict("cfg")
+    x, y, z, _ = synth.make_cloud(1_000_000)
+    poses, _ = synth.make_trajectory(16)
+    imgs = [synth.make_image(f, 1920, 1080) for f in range(16)]
+    ctx = gpu_ctx_factory()
+    ctx.set_camera(cam_struct(capi, cd))
+    ctx.upload_cloud(x, y, z)
+    ctx.set_frames(poses)
+    for f, im in enumerate(imgs):
+        ctx.upload_image(f, im)
+    got = ctx.colorize()
+    ref = oracle.colorize(cam_struct(oracle, cd), oracle.default_cull_params(), x, y, z, poses, imgs, threads=8,
+                          want_top=False)
+    assert np.array_equal(got["rgb"], ref["rgb"]) and np.array_equal(got["has"], ref["has"])
+    assert ref["has"].sum() > 50_000
+    ctx.close()
