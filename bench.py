@@ -138,6 +138,16 @@ def main():
         eng.ctx.timing_enable(False)
         avg_s = proj_ms / max(proj_launches, 1) / 1e3
         achieved = PROJ_BYTES_PER_POINT * N / avg_s / 1e9
+        # HBM traffic of the same kernel from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as
+        # MI355X_MICROARCH.md prescribes), collected with this command and committed under profiles/
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_project_frame.json")) as fh:
+                pmc = json.load(fh)
+            if pmc.get("points_per_launch") == N:
+                traffic = round(pmc["k_project_frame"]["traffic_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = {
             "kernel": "k_project_frame",
             "bound": "hbm",
@@ -145,7 +155,8 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": "profiles/r01_pmc_project_frame.json" if traffic else None,
             "bytes_per_launch": PROJ_BYTES_PER_POINT * N,
             "avg_launch_ms": round(avg_s * 1e3, 4),
             "launches": proj_launches,

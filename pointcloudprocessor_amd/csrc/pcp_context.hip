@@ -349,6 +349,8 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->m_tmp.release();
   ctx->m_state.release();
   ctx->m_flag.release();
+  ctx->v_bitmap.release();
+  ctx->v_offsets.release();
   ctx->mls_xyz.release();
   ctx->mls_normal.release();
   ctx->mls_curv.release();

@@ -150,6 +150,8 @@ struct pcp_context {
   pcp::DevBuf<float> m_tmp;      // 7 floats per input point (xyz, normal, curvature), input order
   pcp::DevBuf<double> m_state;   // per-point MLSResult (mean, axes, c_vec ...) for upsampling
   pcp::DevBuf<uint8_t> m_flag;   // n
+  pcp::DevBuf<uint32_t> v_bitmap;  // dilated voxel set, dense bitmap over the bounding box
+  pcp::DevBuf<int32_t> v_offsets;  // exclusive popcount prefix per bitmap word
   pcp::DevBuf<float> mls_xyz, mls_normal, mls_curv;
   pcp::DevBuf<int32_t> mls_index;
   int64_t mls_count = 0;

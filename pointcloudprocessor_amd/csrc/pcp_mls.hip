@@ -363,6 +363,309 @@ __global__ __launch_bounds__(kMB) void k_mls_gather(const float *__restrict__ tm
   curv[k] = t[6];
 }
 
+// ---------------------------------------------------------------------------
+// VOXEL_GRID_DILATION upsampling (pcl::MovingLeastSquares::performUpsampling +
+// MLSVoxelGrid [upstream mls.hpp]; configured at PCP/src/cloudSmooth.cpp:144-147,
+// values PCP/src/PointCloudProcessor.cpp:78-81).
+//
+// PCL keeps the voxels in a std::map keyed ix*S^2 + iy*S + iz and dilates it
+// `iterations` times by the 26-neighbourhood.  Here the voxel set is a dense bitmap
+// over the cloud's bounding box, bit index ((ix*NY + iy)*NZ + iz): ascending bit
+// index is ascending PCL key, so the output order is the reference's.  k dilations
+// of a voxel are the (2k+1)^3 cube around it (restricted to non-negative indices,
+// Appendix B16), which every input point stamps directly with atomicOr.
+// ---------------------------------------------------------------------------
+struct VoxelDesc {
+  float bminx, bminy, bminz, vs;
+  int32_t NX, NY, NZ, it;
+  int64_t words;  // 32-bit words of the bitmap
+};
+
+__device__ __forceinline__ void voxel_of(const VoxelDesc &v, float x, float y, float z, int32_t &ix, int32_t &iy,
+                                         int32_t &iz) {
+  // MLSVoxelGrid::getCellIndex: (p - bounding_min) / voxel_size in fp32, truncated
+  ix = static_cast<int32_t>(__fdiv_rn(__fsub_rn(x, v.bminx), v.vs));
+  iy = static_cast<int32_t>(__fdiv_rn(__fsub_rn(y, v.bminy), v.vs));
+  iz = static_cast<int32_t>(__fdiv_rn(__fsub_rn(z, v.bminz), v.vs));
+}
+
+__global__ __launch_bounds__(kMB) void k_voxel_stamp(const float *__restrict__ x, const float *__restrict__ y,
+                                                     const float *__restrict__ z, int64_t n, VoxelDesc v,
+                                                     uint32_t *__restrict__ bitmap) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  if (i >= n) return;
+  const float px = x[i];
+  if (!isfinite(px)) return;  // MLSVoxelGrid ctor skips non-finite points
+  int32_t ix, iy, iz;
+  voxel_of(v, px, y[i], z[i], ix, iy, iz);
+  const int32_t z0 = max(iz - v.it, 0), z1 = min(iz + v.it, v.NZ - 1);
+  for (int32_t cx = max(ix - v.it, 0); cx <= min(ix + v.it, v.NX - 1); ++cx)
+    for (int32_t cy = max(iy - v.it, 0); cy <= min(iy + v.it, v.NY - 1); ++cy) {
+      const int64_t l0 = (static_cast<int64_t>(cx) * v.NY + cy) * v.NZ + z0;
+      const int64_t l1 = l0 + (z1 - z0);  // inclusive
+      for (int64_t wd = l0 >> 5; wd <= (l1 >> 5); ++wd) {
+        const int64_t b0 = max(l0, wd << 5) - (wd << 5), b1 = min(l1, (wd << 5) + 31) - (wd << 5);
+        const uint32_t m = ((b1 - b0 + 1) >= 32 ? 0xffffffffu : ((1u << (b1 - b0 + 1)) - 1u)) << b0;
+        atomicOr(bitmap + wd, m);
+      }
+    }
+}
+
+__global__ __launch_bounds__(kMB) void k_voxel_popcount(const uint32_t *__restrict__ bitmap, int64_t words,
+                                                        int32_t *__restrict__ counts) {
+  const int64_t w = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  if (w < words) counts[w] = __popc(bitmap[w]);
+}
+
+struct VoxelEmitArgs {
+  const uint32_t *bitmap;
+  const int32_t *offsets;  // exclusive prefix of the popcounts
+  VoxelDesc v;
+  // neighbour grid of the MLS stage (cell-sorted coordinates)
+  const float *sx, *sy, *sz;
+  const int32_t *order, *start;
+  GridDesc g;
+  int32_t reach;
+  const double *state;  // kMlsState doubles per input point
+  int32_t order_poly, required_neighbors;
+  float *xyz, *normal, *curv;
+  int32_t *index;
+  uint8_t *valid;
+};
+
+__global__ __launch_bounds__(kMB) void k_voxel_emit(VoxelEmitArgs a) {
+  const int64_t w = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  if (w >= a.v.words) return;
+  uint32_t bits = a.bitmap[w];
+  int64_t out = a.offsets[w];
+  while (bits) {
+    const int32_t b = __builtin_ctz(bits);
+    bits &= bits - 1u;
+    const int64_t L = (w << 5) + b;
+    const int32_t iz = static_cast<int32_t>(L % a.v.NZ);
+    const int64_t q = L / a.v.NZ;
+    const int32_t iy = static_cast<int32_t>(q % a.v.NY), ix = static_cast<int32_t>(q / a.v.NY);
+    // MLSVoxelGrid::getPosition: float(index) * voxel_size + bounding_min
+    const float px = __fadd_rn(__fmul_rn(static_cast<float>(ix), a.v.vs), a.v.bminx);
+    const float py = __fadd_rn(__fmul_rn(static_cast<float>(iy), a.v.vs), a.v.bminy);
+    const float pz = __fadd_rn(__fmul_rn(static_cast<float>(iz), a.v.vs), a.v.bminz);
+    // tree_->nearestKSearch(p, 1): closest input point (fp32 L2_Simple); ties -> lower index
+    int32_t cx, cy, cz;
+    grid_coords(a.g, px, py, pz, cx, cy, cz);
+    int32_t best = -1;
+    float bestd = FLT_MAX;
+    for (int32_t zz = max(cz - a.reach, 0); zz <= min(cz + a.reach, a.g.nz - 1); ++zz)
+      for (int32_t yy = max(cy - a.reach, 0); yy <= min(cy + a.reach, a.g.ny - 1); ++yy) {
+        const int32_t row = (zz * a.g.ny + yy) * a.g.nx;
+        const int32_t s0 = a.start[row + max(cx - a.reach, 0)], s1 = a.start[row + min(cx + a.reach, a.g.nx - 1) + 1];
+        for (int32_t k = s0; k < s1; ++k) {
+          const float d = sqdist_f32(a.sx[k], a.sy[k], a.sz[k], px, py, pz);
+          const int32_t id = a.order[k];
+          if (d < bestd || (d == bestd && id < best)) {
+            bestd = d;
+            best = id;
+          }
+        }
+      }
+    bool ok = best >= 0;
+    const double *st = a.state + static_cast<int64_t>(ok ? best : 0) * kMlsState;
+    ok = ok && st[20] >= 1.0;  // mls_results_[input_index].valid
+    if (ok) {
+      // MLSResult::projectPoint(pt, SIMPLE, 5 * nr_coeff)
+      const double dx = static_cast<double>(px) - st[0], dy = static_cast<double>(py) - st[1],
+                   dz = static_cast<double>(pz) - st[2];
+      const double u = (dx * st[6] + dy * st[7]) + dz * st[8];
+      const double vv = (dx * st[9] + dy * st[10]) + dz * st[11];
+      double wgt = 0.0, nx = st[3], ny = st[4], nz = st[5];
+      if (a.order_poly > 1 && st[19] >= static_cast<double>(a.required_neighbors) && st[20] >= 2.0 && isfinite(st[12])) {
+        // getPolynomialPartialDerivative: monomials 1, v, v^2, u, uv, u^2
+        const double c0 = st[12], c1 = st[13], c2 = st[14], c3 = st[15], c4 = st[16], c5 = st[17];
+        wgt = c0 + vv * c1 + (vv * vv) * c2 + u * c3 + (u * vv) * c4 + (u * u) * c5;
+        const double zu = c3 + c4 * vv + c5 * 2.0 * u;
+        const double zv = c1 + c2 * 2.0 * vv + c4 * u;
+        nx -= zu * st[6] + zv * st[9];
+        ny -= zu * st[7] + zv * st[10];
+        nz -= zu * st[8] + zv * st[11];
+        const double l = sqrt((nx * nx + ny * ny) + nz * nz);
+        if (l > 0.0) {
+          nx /= l; ny /= l; nz /= l;
+        }
+      }
+      a.xyz[3 * out + 0] = static_cast<float>(st[0] + u * st[6] + vv * st[9] + wgt * st[3]);
+      a.xyz[3 * out + 1] = static_cast<float>(st[1] + u * st[7] + vv * st[10] + wgt * st[4]);
+      a.xyz[3 * out + 2] = static_cast<float>(st[2] + u * st[8] + vv * st[11] + wgt * st[5]);
+      a.normal[3 * out + 0] = static_cast<float>(nx);
+      a.normal[3 * out + 1] = static_cast<float>(ny);
+      a.normal[3 * out + 2] = static_cast<float>(nz);
+      a.curv[out] = static_cast<float>(st[18]);
+      a.index[out] = best;
+    }
+    a.valid[out] = ok ? 1 : 0;
+    ++out;
+  }
+}
+
+// in-place style compaction of the voxel outputs when some voxels were dropped
+__global__ __launch_bounds__(kMB) void k_voxel_compact(const int32_t *__restrict__ keep_index, int64_t m,
+                                                       const float *__restrict__ xyz, const float *__restrict__ normal,
+                                                       const float *__restrict__ curv, const int32_t *__restrict__ index,
+                                                       float *__restrict__ oxyz, float *__restrict__ onormal,
+                                                       float *__restrict__ ocurv, int32_t *__restrict__ oindex) {
+  const int64_t k = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  if (k >= m) return;
+  const int64_t s_ = keep_index[k];
+  for (int c = 0; c < 3; ++c) {
+    oxyz[3 * k + c] = xyz[3 * s_ + c];
+    onormal[3 * k + c] = normal[3 * s_ + c];
+  }
+  ocurv[k] = curv[s_];
+  oindex[k] = index[s_];
+}
+
+// ---------------------------------------------------------------------------
+// pcl::StatisticalOutlierRemoval (filters/impl/statistical_outlier_removal.hpp
+// [upstream]; configured at PCP/src/cloudSmooth.cpp:109-116,160-164: k = 60, 0.7 sigma).
+// Per point: mean distance to its mean_k nearest neighbours (the query itself is hit
+// 0 of nearestKSearch(k+1) and is skipped), then keep iff distance <= mean + mul*sigma.
+// One lane per point; its k+1 best squared distances live in a max-heap in LDS
+// (column layout heap[e][lane]: conflict-free).  Cells are visited ring by ring until
+// the heap's maximum is closer than the next ring.
+// ---------------------------------------------------------------------------
+constexpr int kSorBlock = 128;
+
+__device__ __forceinline__ void heap_push(float *heap, int &size, int k, float d) {
+  // heap[e * kSorBlock] : e-th slot of this lane's max-heap
+  if (size < k) {
+    int c = size++;
+    while (c > 0) {
+      const int pnt = (c - 1) >> 1;
+      const float pv = heap[pnt * kSorBlock];
+      if (pv >= d) break;
+      heap[c * kSorBlock] = pv;
+      c = pnt;
+    }
+    heap[c * kSorBlock] = d;
+    return;
+  }
+  if (!(d < heap[0])) return;
+  int c = 0;
+  for (;;) {
+    const int l = 2 * c + 1, r = l + 1;
+    if (l >= k) break;
+    int big = l;
+    float bv = heap[l * kSorBlock];
+    if (r < k) {
+      const float rv = heap[r * kSorBlock];
+      if (rv > bv) {
+        bv = rv;
+        big = r;
+      }
+    }
+    if (bv <= d) break;
+    heap[c * kSorBlock] = bv;
+    c = big;
+  }
+  heap[c * kSorBlock] = d;
+}
+
+__global__ __launch_bounds__(kSorBlock) void k_sor_mean_distance(const float *__restrict__ sx, const float *__restrict__ sy,
+                                                                 const float *__restrict__ sz,
+                                                                 const int32_t *__restrict__ order,
+                                                                 const int32_t *__restrict__ start, int64_t n, GridDesc g,
+                                                                 int32_t mean_k, float *__restrict__ distances) {
+  extern __shared__ float sor_heap[];
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * kSorBlock + threadIdx.x;
+  if (j >= n) return;
+  float *heap = sor_heap + threadIdx.x;
+  const int k = mean_k + 1;
+  const float qx = sx[j], qy = sy[j], qz = sz[j];
+  int32_t cx, cy, cz;
+  grid_coords(g, qx, qy, qz, cx, cy, cz);
+  const float cell = 1.0f / g.inv_cell;
+  const int32_t maxr = max(g.nx, max(g.ny, g.nz));
+  int size = 0;
+  for (int32_t ring = 0; ring <= maxr; ++ring) {
+    if (size == k && ring >= 1) {
+      // every unvisited point is at least (ring - 1) cells away; 0.999 absorbs the fp32 cell-assignment slop
+      const float reach = static_cast<float>(ring - 1) * cell * 0.999f;
+      if (reach * reach > heap[0]) break;
+    }
+    for (int32_t zz = max(cz - ring, 0); zz <= min(cz + ring, g.nz - 1); ++zz)
+      for (int32_t yy = max(cy - ring, 0); yy <= min(cy + ring, g.ny - 1); ++yy) {
+        const bool shell_yz = zz == cz - ring || zz == cz + ring || yy == cy - ring || yy == cy + ring;
+        const int32_t row = (zz * g.ny + yy) * g.nx;
+        if (shell_yz) {
+          const int32_t b = start[row + max(cx - ring, 0)], e = start[row + min(cx + ring, g.nx - 1) + 1];
+          for (int32_t q = b; q < e; ++q) heap_push(heap, size, k, sqdist_f32(sx[q], sy[q], sz[q], qx, qy, qz));
+        } else {
+          if (cx - ring >= 0) {
+            const int32_t b = start[row + cx - ring], e = start[row + cx - ring + 1];
+            for (int32_t q = b; q < e; ++q) heap_push(heap, size, k, sqdist_f32(sx[q], sy[q], sz[q], qx, qy, qz));
+          }
+          if (cx + ring < g.nx && ring > 0) {
+            const int32_t b = start[row + cx + ring], e = start[row + cx + ring + 1];
+            for (int32_t q = b; q < e; ++q) heap_push(heap, size, k, sqdist_f32(sx[q], sy[q], sz[q], qx, qy, qz));
+          }
+        }
+      }
+  }
+  // sum of sqrt over the hits except hit 0 (the smallest, the query itself)
+  double sum = 0.0;
+  float smallest = FLT_MAX;
+  for (int e = 0; e < size; ++e) {
+    const float d = heap[e * kSorBlock];
+    sum += static_cast<double>(sqrtf(d));
+    smallest = fminf(smallest, d);
+  }
+  if (size > 0) sum -= static_cast<double>(sqrtf(smallest));
+  distances[order[j]] = static_cast<float>(sum / static_cast<double>(mean_k));
+}
+
+// sum and sum of squares (fp32 squares, as the reference) of the distances, fp64 accumulation
+__global__ __launch_bounds__(kMB) void k_sor_stats(const float *__restrict__ distances, int64_t n,
+                                                   double *__restrict__ sums /* [2] */) {
+  __shared__ double sh[2][kMB / 64];
+  double s = 0.0, q = 0.0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kMB) {
+    const float d = distances[i];
+    s += static_cast<double>(d);
+    q += static_cast<double>(__fmul_rn(d, d));
+  }
+  for (int o = 32; o >= 1; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    q += __shfl_xor(q, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sh[0][threadIdx.x >> 6] = s;
+    sh[1][threadIdx.x >> 6] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ts = 0.0, tq = 0.0;
+    for (int k = 0; k < kMB / 64; ++k) {
+      ts += sh[0][k];
+      tq += sh[1][k];
+    }
+    atomicAdd(sums, ts);
+    atomicAdd(sums + 1, tq);
+  }
+}
+
+__global__ __launch_bounds__(kMB) void k_sor_classify(const float *__restrict__ distances, int64_t n, double threshold,
+                                                      uint8_t *__restrict__ keep) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  if (i < n) keep[i] = !(static_cast<double>(distances[i]) > threshold) ? 1 : 0;
+}
+
+// occupied cells of the current grid (surface density estimate)
+__global__ __launch_bounds__(kMB) void k_count_occupied(const int32_t *__restrict__ start, int64_t ncell,
+                                                        unsigned long long *__restrict__ occupied) {
+  const int64_t c = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  const bool occ = c < ncell && start[c + 1] > start[c];
+  const unsigned long long m = __ballot(occ);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(occupied, static_cast<unsigned long long>(__popcll(m)));
+}
+
 static inline uint32_t blocks_of(int64_t n) { return static_cast<uint32_t>(std::max<int64_t>(1, div_up(n, kMB))); }
 
 // device-wide exclusive scan of counts[0..m) into out[0..m], out[m] = total
@@ -425,6 +728,135 @@ static int build_grid(pcp_context *ctx, float cell, float radius, GridDesc *out)
   return PCP_OK;
 }
 
+// performUpsampling(VOXEL_GRID_DILATION) on the fitted surfaces in ctx->m_state
+static int voxel_grid_dilation(pcp_context *ctx, const pcp_mls_params *p, const GridDesc &g, int64_t *out_count) {
+  const int64_t n = ctx->n;
+  const size_t sn = static_cast<size_t>(n);
+  const size_t plane = (sn + 3) & ~size_t(3);
+  VoxelDesc v{};
+  v.bminx = ctx->host_min[0];
+  v.bminy = ctx->host_min[1];
+  v.bminz = ctx->host_min[2];
+  v.vs = p->vgd_voxel_size;
+  v.it = p->vgd_iterations;
+  // largest cell index per axis (float division as MLSVoxelGrid::getCellIndex) + dilation reach
+  const int64_t mx = static_cast<int64_t>((ctx->host_max[0] - v.bminx) / v.vs) + v.it + 1;
+  const int64_t my = static_cast<int64_t>((ctx->host_max[1] - v.bminy) / v.vs) + v.it + 1;
+  const int64_t mz = static_cast<int64_t>((ctx->host_max[2] - v.bminz) / v.vs) + v.it + 1;
+  const double bits = static_cast<double>(mx) * static_cast<double>(my) * static_cast<double>(mz);
+  size_t free_b = 0, total_b = 0;
+  PCP_HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+  // bitmap (bits / 8) + popcount offsets (bits / 8): both must fit with room for the outputs
+  if (mx >= (int64_t(1) << 31) || my >= (int64_t(1) << 31) || mz >= (int64_t(1) << 31) || bits / 4.0 > 0.5 * static_cast<double>(free_b))
+    return set_error(ctx, PCP_ERR_NOMEM,
+                     "pcp_mls_process: the %lld x %lld x %lld voxel grid (%.3g voxels at %.4g m) does not fit the device; "
+                     "use a larger vgd_voxel_size or crop the cloud",
+                     (long long)mx, (long long)my, (long long)mz, bits, static_cast<double>(v.vs));
+  v.NX = static_cast<int32_t>(mx);
+  v.NY = static_cast<int32_t>(my);
+  v.NZ = static_cast<int32_t>(mz);
+  v.words = (static_cast<int64_t>(v.NX) * v.NY * v.NZ + 31) / 32;
+  const size_t sw = static_cast<size_t>(v.words);
+  PCP_HIP_TRY(ctx, ctx->v_bitmap.ensure(sw + 8));
+  PCP_HIP_TRY(ctx, ctx->v_offsets.ensure(sw + 8));
+  PCP_HIP_TRY(ctx, ctx->s_counter.ensure(4));
+  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->v_bitmap.p, 0, (sw + 8) * 4, ctx->stream));
+  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->v_offsets.p, 0, (sw + 8) * 4, ctx->stream));
+  const float *x = ctx->xyz.p, *y = ctx->xyz.p + plane, *z = ctx->xyz.p + 2 * plane;
+  unsigned long long total = 0;
+  {
+    LaunchTimer t(ctx, PCP_K_MLS_VOXEL);
+    hipLaunchKernelGGL(k_voxel_stamp, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, x, y, z, n, v, ctx->v_bitmap.p);
+    hipLaunchKernelGGL(k_voxel_popcount, dim3(blocks_of(v.words)), dim3(kMB), 0, ctx->stream, ctx->v_bitmap.p, v.words,
+                       ctx->v_offsets.p);
+    // exclusive scan of words + 1 counts; 64-bit grand total through the tile-offset kernel
+    const int64_t tiles = std::max<int64_t>(1, div_up(v.words + 1, kScanTile));
+    PCP_HIP_TRY(ctx, ctx->s_tiles.ensure(static_cast<size_t>(tiles) + 4));
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(static_cast<uint32_t>(tiles)), dim3(kScanBlock), 0, ctx->stream,
+                       ctx->v_offsets.p, v.words + 1, ctx->s_tiles.p);
+    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kScanBlock), 0, ctx->stream, ctx->s_tiles.p, tiles,
+                       ctx->s_counter.p);
+    hipLaunchKernelGGL(k_scan_apply, dim3(static_cast<uint32_t>(tiles)), dim3(kScanBlock), 0, ctx->stream,
+                       ctx->v_offsets.p, v.words + 1, ctx->s_tiles.p, ctx->v_offsets.p);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->s_counter.p, sizeof(total), hipMemcpyDeviceToHost, ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (total >= (1ull << 31))
+    return set_error(ctx, PCP_ERR_NOMEM, "pcp_mls_process: %llu dilated voxels exceed the 2^31 output limit", total);
+  const size_t st = static_cast<size_t>(total);
+  PCP_HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+  if (static_cast<double>(st) * 70.0 > static_cast<double>(free_b) + static_cast<double>(ctx->mls_xyz.count) * 4.0 * 2.4)
+    return set_error(ctx, PCP_ERR_NOMEM, "pcp_mls_process: %llu upsampled points do not fit the device memory", total);
+  PCP_HIP_TRY(ctx, ctx->mls_xyz.ensure(3 * st + 4));
+  PCP_HIP_TRY(ctx, ctx->mls_normal.ensure(3 * st + 4));
+  PCP_HIP_TRY(ctx, ctx->mls_curv.ensure(st + 4));
+  PCP_HIP_TRY(ctx, ctx->mls_index.ensure(st + 4));
+  PCP_HIP_TRY(ctx, ctx->m_flag.ensure(st + 16));
+  VoxelEmitArgs e{};
+  e.bitmap = ctx->v_bitmap.p;
+  e.offsets = ctx->v_offsets.p;
+  e.v = v;
+  e.sx = ctx->g_xyz.p;
+  e.sy = ctx->g_xyz.p + plane;
+  e.sz = ctx->g_xyz.p + 2 * plane;
+  e.order = ctx->g_order.p;
+  e.start = ctx->g_start.p;
+  e.g = g;
+  // a dilated voxel's corner lies within sqrt(3) * (it + 1) voxels of the point that stamped it
+  e.reach = std::max(1, static_cast<int32_t>(std::ceil(1.7321 * (v.it + 1) * static_cast<double>(v.vs) * g.inv_cell)));
+  e.state = ctx->m_state.p;
+  e.order_poly = p->polynomial_order;
+  const int32_t nr_coeff = (p->polynomial_order + 1) * (p->polynomial_order + 2) / 2;
+  e.required_neighbors = 5 * nr_coeff;
+  e.xyz = ctx->mls_xyz.p;
+  e.normal = ctx->mls_normal.p;
+  e.curv = ctx->mls_curv.p;
+  e.index = ctx->mls_index.p;
+  e.valid = ctx->m_flag.p;
+  int64_t m = static_cast<int64_t>(total);
+  if (total > 0) {
+    {
+      LaunchTimer t(ctx, PCP_K_MLS_VOXEL);
+      hipLaunchKernelGGL(k_voxel_emit, dim3(blocks_of(v.words)), dim3(kMB), 0, ctx->stream, e);
+      PCP_HIP_TRY(ctx, hipGetLastError());
+    }
+    // voxels whose nearest point has no valid fit are skipped by PCL: compact if any
+    PCP_HIP_TRY(ctx, ctx->s_cell.ensure(st + 4));
+    int64_t kept = 0;
+    int rc = compact_flags(ctx, ctx->m_flag.p, static_cast<int64_t>(total), ctx->s_cell.p, static_cast<int64_t>(total), &kept);
+    if (rc != PCP_OK) return rc;
+    if (kept != static_cast<int64_t>(total)) {
+      const size_t sk = static_cast<size_t>(kept);
+      DevBuf<float> nx_, nn_, nc_;
+      DevBuf<int32_t> ni_;
+      PCP_HIP_TRY(ctx, nx_.ensure(3 * sk + 4));
+      PCP_HIP_TRY(ctx, nn_.ensure(3 * sk + 4));
+      PCP_HIP_TRY(ctx, nc_.ensure(sk + 4));
+      PCP_HIP_TRY(ctx, ni_.ensure(sk + 4));
+      if (kept > 0) {
+        LaunchTimer t(ctx, PCP_K_MLS_VOXEL);
+        hipLaunchKernelGGL(k_voxel_compact, dim3(blocks_of(kept)), dim3(kMB), 0, ctx->stream, ctx->s_cell.p, kept,
+                           ctx->mls_xyz.p, ctx->mls_normal.p, ctx->mls_curv.p, ctx->mls_index.p, nx_.p, nn_.p, nc_.p, ni_.p);
+        PCP_HIP_TRY(ctx, hipGetLastError());
+      }
+      PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      std::swap(ctx->mls_xyz, nx_);
+      std::swap(ctx->mls_normal, nn_);
+      std::swap(ctx->mls_curv, nc_);
+      std::swap(ctx->mls_index, ni_);
+      nx_.release();
+      nn_.release();
+      nc_.release();
+      ni_.release();
+      m = kept;
+    }
+  }
+  ctx->mls_count = m;
+  if (out_count) *out_count = m;
+  return PCP_OK;
+}
+
 }  // namespace pcp
 
 using namespace pcp;
@@ -444,8 +876,8 @@ int pcp_mls_process(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_coun
   if (p->upsampling != 0 && p->upsampling != 3)
     return set_error(ctx, PCP_ERR_INVALID, "pcp_mls_process: upsampling %d unsupported (0 NONE, 3 VOXEL_GRID_DILATION)",
                      p->upsampling);
-  if (p->upsampling == 3)
-    return set_error(ctx, PCP_ERR_STATE, "pcp_mls_process: VOXEL_GRID_DILATION is not built yet (use upsampling = 0)");
+  if (p->upsampling == 3 && (!(p->vgd_voxel_size > 0.0f) || p->vgd_iterations < 0 || p->vgd_iterations > 15))
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_mls_process: vgd_voxel_size must be > 0 and vgd_iterations in 0..15");
   PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int64_t n = ctx->n;
   ctx->mls_count = 0;
@@ -474,11 +906,18 @@ int pcp_mls_process(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_coun
   a.tmp = ctx->m_tmp.p;
   a.flag = ctx->m_flag.p;
   a.state = nullptr;
+  if (p->upsampling == 3) {
+    PCP_HIP_TRY(ctx, ctx->m_state.ensure(static_cast<size_t>(kMlsState) * sn + 8));
+    // points skipped by the fit (< 3 neighbours) must read as "invalid" later
+    PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->m_state.p, 0, static_cast<size_t>(kMlsState) * sn * sizeof(double), ctx->stream));
+    a.state = ctx->m_state.p;
+  }
   {
     LaunchTimer t(ctx, PCP_K_MLS_FIT);
     hipLaunchKernelGGL(k_mls_fit, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, a);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
+  if (p->upsampling == 3) return voxel_grid_dilation(ctx, p, g, out_count);
   // points with < 3 neighbours are dropped; output keeps the input order
   PCP_HIP_TRY(ctx, ctx->mls_index.ensure(sn + 4));
   int64_t m = 0;
@@ -515,8 +954,79 @@ int pcp_mls_fetch(pcp_context *ctx, int64_t capacity, float *out_xyz, float *out
   return PCP_OK;
 }
 
-int pcp_sor(pcp_context *ctx, int32_t, double, uint8_t *, int64_t *) {
-  return set_error(ctx, PCP_ERR_STATE, "pcp_sor: not built yet");
+int pcp_sor(pcp_context *ctx, int32_t mean_k, double std_mul, uint8_t *out_keep, int64_t *out_kept) {
+  if (!ctx) return PCP_ERR_INVALID;
+  if (!ctx->xyz.p) return set_error(ctx, PCP_ERR_STATE, "pcp_sor: no cloud uploaded");
+  if (mean_k < 1 || mean_k > 254) return set_error(ctx, PCP_ERR_INVALID, "pcp_sor: mean_k %d out of range (1..254)", mean_k);
+  PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int64_t n = ctx->n;
+  if (out_kept) *out_kept = 0;
+  if (n == 0) return PCP_OK;
+  const size_t sn = static_cast<size_t>(n);
+  const size_t plane = (sn + 3) & ~size_t(3);
+  // cell edge: first a volume-based guess, then refined from the number of occupied cells so that
+  // a 3x3x3 neighbourhood of a surface patch holds ~2.5 (k + 1) points
+  const float *mn = ctx->host_min.data(), *mx = ctx->host_max.data();
+  const double vol = std::max<double>(mx[0] - mn[0], 1e-3) * std::max<double>(mx[1] - mn[1], 1e-3) * std::max<double>(mx[2] - mn[2], 1e-3);
+  float cell = static_cast<float>(std::cbrt(vol / static_cast<double>(n) * 4.0));
+  if (!(cell > 1e-4f)) cell = 1e-4f;
+  GridDesc g;
+  int rc = build_grid(ctx, cell, cell, &g);
+  if (rc != PCP_OK) return rc;
+  {
+    const int64_t ncell = static_cast<int64_t>(g.nx) * g.ny * g.nz;
+    PCP_HIP_TRY(ctx, ctx->s_counter.ensure(4));
+    PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->s_counter.p, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_count_occupied, dim3(blocks_of(ncell)), dim3(kMB), 0, ctx->stream, ctx->g_start.p, ncell,
+                       ctx->s_counter.p);
+    unsigned long long occ = 0;
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(&occ, ctx->s_counter.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const double c0 = 1.0 / g.inv_cell;
+    if (occ > 0) {
+      const double per_area = static_cast<double>(n) / (static_cast<double>(occ) * c0 * c0);  // points per unit area
+      const double want = std::sqrt(2.5 * (mean_k + 1) / (9.0 * per_area));
+      if (want > 0.0 && (want < 0.7 * c0 || want > 1.4 * c0)) {
+        rc = build_grid(ctx, static_cast<float>(want), static_cast<float>(want), &g);
+        if (rc != PCP_OK) return rc;
+      }
+    }
+  }
+  PCP_HIP_TRY(ctx, ctx->m_tmp.ensure(sn + 8));
+  PCP_HIP_TRY(ctx, ctx->m_flag.ensure(sn + 16));
+  PCP_HIP_TRY(ctx, ctx->m_state.ensure(4));
+  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->m_state.p, 0, 2 * sizeof(double), ctx->stream));
+  float *dist = ctx->m_tmp.p;
+  {
+    LaunchTimer t(ctx, PCP_K_SOR);
+    const size_t lds = static_cast<size_t>(mean_k + 1) * kSorBlock * sizeof(float);
+    hipLaunchKernelGGL(k_sor_mean_distance, dim3(static_cast<uint32_t>(div_up(n, kSorBlock))), dim3(kSorBlock), lds,
+                       ctx->stream, ctx->g_xyz.p, ctx->g_xyz.p + plane, ctx->g_xyz.p + 2 * plane, ctx->g_order.p,
+                       ctx->g_start.p, n, g, mean_k, dist);
+    hipLaunchKernelGGL(k_sor_stats, dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(n, kMB), 1024))), dim3(kMB), 0,
+                       ctx->stream, dist, n, ctx->m_state.p);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  double sums[2] = {0, 0};
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(sums, ctx->m_state.p, sizeof(sums), hipMemcpyDeviceToHost, ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const double dn = static_cast<double>(n);
+  const double mean = sums[0] / dn;
+  const double variance = (sums[1] - sums[0] * sums[0] / dn) / (dn - 1.0);
+  const double threshold = mean + std_mul * std::sqrt(variance);
+  {
+    LaunchTimer t(ctx, PCP_K_SOR);
+    hipLaunchKernelGGL(k_sor_classify, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, dist, n, threshold, ctx->m_flag.p);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  if (out_kept) {
+    int64_t kept = 0;
+    if ((rc = compact_flags(ctx, ctx->m_flag.p, n, nullptr, 0, &kept)) != PCP_OK) return rc;
+    *out_kept = kept;
+  }
+  if (out_keep) PCP_HIP_TRY(ctx, hipMemcpyAsync(out_keep, ctx->m_flag.p, sn, hipMemcpyDeviceToHost, ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PCP_OK;
 }
 
 }  // extern "C"

@@ -141,3 +141,52 @@ def test_mls_edge_cases(gpu_ctx_factory, oracle):
     mp.polynomial_order = 7
     with pytest.raises(capi.PcpError):
         ctx.mls_process(mp)
+
+
+def test_mls_voxel_grid_dilation_matches_oracle(gpu_ctx_factory, oracle):
+    """VOXEL_GRID_DILATION with the reference's parameters (1 mm voxels, 4 iterations):
+    same voxel set in the same (ascending key) order, same source indices, projected
+    positions within 1e-4 relative."""
+    from pointcloudprocessor_amd import capi
+
+    rng = np.random.default_rng(21)
+    n = 2500
+    a = rng.uniform(-0.08, 0.08, (n, 2))
+    zz = 0.8 * a[:, 0] ** 2 - 0.5 * a[:, 0] * a[:, 1] + rng.normal(0, 5e-4, n)
+    pts = np.stack([a[:, 0] + 2.0, a[:, 1] - 1.0, zz + 0.5], 1)
+    pts = np.concatenate([pts, rng.uniform(-0.1, 0.1, (6, 3)) + [2.0, -1.0, 0.6]]).astype(np.float32)  # a few strays
+    x, y, z = pts[:, 0].copy(), pts[:, 1].copy(), pts[:, 2].copy()
+    ctx = gpu_ctx_factory()
+    ctx.upload_cloud(x, y, z)
+    for vs, it in ((0.001, 4), (0.004, 1), (0.002, 0)):
+        mp = capi.default_mls_params()
+        mp.upsampling = 3
+        mp.vgd_voxel_size = vs
+        mp.vgd_iterations = it
+        m = ctx.mls_process(mp)
+        got = ctx.mls_fetch(m)
+        op = oracle.default_mls_params()
+        op.upsampling = 3
+        op.vgd_voxel_size = vs
+        op.vgd_iterations = it
+        op.threads = 8
+        ref = oracle.mls_voxel_dilation(x, y, z, op)
+        assert m == len(ref["index"]) > n // 2, (vs, it, m, len(ref["index"]))
+        assert np.array_equal(got["index"], ref["index"]), (vs, it)
+        d = np.abs(got["xyz"].astype(np.float64) - ref["xyz"].astype(np.float64))
+        assert d.max() <= 1e-4 * R, (vs, it, d.max())
+        sgn = np.sign((got["normal"].astype(np.float64) * ref["normal"]).sum(axis=1))
+        sgn[sgn == 0] = 1.0
+        assert np.abs(got["normal"] * sgn[:, None] - ref["normal"]).max() <= 1e-4
+        np.testing.assert_allclose(got["curvature"], ref["curvature"], rtol=1e-4, atol=1e-9)
+
+
+def test_mls_voxel_grid_dilation_refuses_oversized_grids(gpu_ctx_factory):
+    from pointcloudprocessor_amd import capi
+
+    ctx = gpu_ctx_factory()
+    ctx.upload_cloud(np.float32([0, 3000]), np.float32([0, 3000]), np.float32([0, 3000]))
+    mp = capi.default_mls_params()  # 1 mm voxels over a 3 km cube: 2.7e19 voxels
+    with pytest.raises(capi.PcpError) as e:
+        ctx.mls_process(mp)
+    assert e.value.code == capi.PCP_ERR_NOMEM
