@@ -247,12 +247,16 @@ def mls_voxel_dilation(x, y, z, params: MLSParams):
     return dict(xyz=xyz, normal=nrm, curvature=curv, index=idx)
 
 
-def sor(x, y, z, mean_k: int = 60, std_mul: float = 0.7, threads: int = 0):
+def sor(x, y, z, mean_k: int = 60, std_mul: float = 0.7, threads: int = 0, details: bool = False):
     x, y, z = _f32(x), _f32(y), _f32(z)
     n = len(x)
     keep = np.empty(n, np.uint8)
+    dist = np.empty(n, np.float32)
+    thr = C.c_double()
     kept = int(lib().orc_sor(_p(x), _p(y), _p(z), C.c_int64(n), C.c_int32(mean_k), C.c_double(std_mul), _p(keep),
-                             C.c_int32(threads)))
+                             _p(dist), C.byref(thr), C.c_int32(threads)))
+    if details:
+        return keep, kept, dist, thr.value
     return keep, kept
 
 

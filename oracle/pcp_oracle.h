@@ -136,9 +136,10 @@ int64_t orc_mls_voxel_dilation(const float *x, const float *y, const float *z, i
 int32_t orc_select_keyframes(const orc_pose *poses, int32_t n, double dist_threshold, int32_t *out_indices);
 
 /* StatisticalOutlierRemoval (k, std_mul) [upstream], cloudSmooth.cpp:109-116.
- * out_keep n bytes; returns number kept. */
+ * out_keep n bytes; out_distance n floats (mean kNN distance), out_threshold: both
+ * nullable; returns number kept. */
 int64_t orc_sor(const float *x, const float *y, const float *z, int64_t n, int32_t mean_k, double std_mul,
-                uint8_t *out_keep, int32_t threads);
+                uint8_t *out_keep, float *out_distance, double *out_threshold, int32_t threads);
 
 int32_t orc_hardware_threads(void);
 

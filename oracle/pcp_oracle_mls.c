@@ -711,7 +711,7 @@ static void knn_push(nbr *heap, int *size, int k, float d, int32_t i) {
 }
 
 int64_t orc_sor(const float *x, const float *y, const float *z, int64_t n, int32_t mean_k, double std_mul,
-                uint8_t *out_keep, int32_t threads) {
+                uint8_t *out_keep, float *out_distance, double *out_threshold, int32_t threads) {
   if (n == 0) return 0;
   /* grid sized for ~mean_k points per 27-cell neighbourhood */
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
@@ -788,6 +788,8 @@ int64_t orc_sor(const float *x, const float *y, const float *z, int64_t n, int32
   const double variance = (sq_sum - sum * sum / (double)n) / ((double)n - 1.0);
   const double stddev = sqrt(variance);
   const double threshold = mean + std_mul * stddev;
+  if (out_threshold) *out_threshold = threshold;
+  if (out_distance) memcpy(out_distance, distances, (size_t)n * sizeof(float));
   int64_t kept = 0;
   for (int64_t i = 0; i < n; ++i) {
     const int keep = !((double)distances[i] > threshold);

@@ -1,0 +1,55 @@
+"""GPU parity of StatisticalOutlierRemoval (pcp_sor) against the CPU restatement:
+keep flags equal except for points whose mean kNN distance sits within 1e-6
+relative of the threshold (fp64 summation order)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(ctx, oracle, x, y, z, mean_k, mul):
+    ctx.upload_cloud(x, y, z)
+    keep_g, kept_g = ctx.sor(mean_k, mul)
+    keep_r, kept_r, dist, thr = oracle.sor(x, y, z, mean_k, mul, threads=8, details=True)
+    diff = np.nonzero(keep_g != keep_r)[0]
+    assert np.all(np.abs(dist[diff] - thr) <= 1e-6 * thr), (len(diff), dist[diff][:5], thr)
+    assert abs(kept_g - kept_r) <= len(diff)
+    assert kept_g == int(keep_g.sum())
+    return kept_r
+
+
+def test_sor_matches_oracle_on_surface_with_outliers(gpu_ctx_factory, oracle):
+    rng = np.random.default_rng(4)
+    n = 40000
+    a = rng.uniform(-0.5, 0.5, (n, 2))
+    pts = np.stack([a[:, 0], a[:, 1], 0.1 * np.sin(6 * a[:, 0]) + rng.normal(0, 1e-3, n)], 1)
+    out = rng.uniform(-0.5, 0.5, (300, 3))
+    pts = np.concatenate([pts, out]).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    ctx = gpu_ctx_factory()
+    kept = _check(ctx, oracle, pts[:, 0].copy(), pts[:, 1].copy(), pts[:, 2].copy(), 60, 0.7)
+    assert 0.5 * len(pts) < kept < len(pts)
+    _check(ctx, oracle, pts[:, 0].copy(), pts[:, 1].copy(), pts[:, 2].copy(), 8, 1.5)
+
+
+def test_sor_on_scene_crop(gpu_ctx_factory, oracle):
+    from pointcloudprocessor_amd import synth
+
+    x, y, z, _ = synth.make_cloud(2_000_000)
+    sel = (x > 1.0) & (x < 3.0) & (y > -5.1) & (y < -3.5) & (z < 1.5)
+    ctx = gpu_ctx_factory()
+    kept = _check(ctx, oracle, x[sel], y[sel], z[sel], 60, 0.7)
+    assert kept > 1000
+
+
+def test_sor_edge_cases(gpu_ctx_factory):
+    from pointcloudprocessor_amd import capi
+
+    ctx = gpu_ctx_factory()
+    e = np.zeros(0, np.float32)
+    ctx.upload_cloud(e, e, e)
+    keep, kept = ctx.sor()
+    assert kept == 0 and len(keep) == 0
+    ctx.upload_cloud(np.float32([0, 1, 2]), np.float32([0, 0, 0]), np.float32([0, 0, 0]))
+    with pytest.raises(capi.PcpError):
+        ctx.sor(mean_k=0)
