@@ -194,6 +194,10 @@ int pcp_mls_process(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_coun
  * NONE; ascending voxel key for VOXEL_GRID_DILATION). */
 int pcp_mls_fetch(pcp_context *ctx, int64_t capacity, float *out_xyz, float *out_normal, float *out_curvature,
                   int32_t *out_index);
+/* CloudSmooth::process end to end on the device: SOR(sor_mean_k, sor_std_mul) ->
+ * MovingLeastSquares (+ upsampling) -> SOR, cloudSmooth.cpp:109-164.  Results through
+ * pcp_mls_fetch; out_index refers to the uploaded cloud. */
+int pcp_cloud_smooth(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_count);
 /* pcl::StatisticalOutlierRemoval (k, std_mul) keep mask of the uploaded cloud,
  * cloudSmooth.cpp:109-116,160-164. */
 int pcp_sor(pcp_context *ctx, int32_t mean_k, double std_mul, uint8_t *out_keep, int64_t *out_kept);

@@ -344,6 +344,11 @@ class Context:
         self._check(self.lib.pcp_mls_process(self.h, C.byref(params), C.byref(cnt)))
         return cnt.value
 
+    def cloud_smooth(self, params: MLSParams) -> int:
+        cnt = C.c_int64()
+        self._check(self.lib.pcp_cloud_smooth(self.h, C.byref(params), C.byref(cnt)))
+        return cnt.value
+
     def mls_fetch(self, count: int):
         xyz = np.empty((count, 3), np.float32)
         nrm = np.empty((count, 3), np.float32)

@@ -349,6 +349,10 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->m_tmp.release();
   ctx->m_state.release();
   ctx->m_flag.release();
+  ctx->m_sums.release();
+  ctx->c_index.release();
+  ctx->c_xyz.release();
+  ctx->c_xyz2.release();
   ctx->v_bitmap.release();
   ctx->v_offsets.release();
   ctx->mls_xyz.release();

@@ -150,6 +150,9 @@ struct pcp_context {
   pcp::DevBuf<float> m_tmp;      // 7 floats per input point (xyz, normal, curvature), input order
   pcp::DevBuf<double> m_state;   // per-point MLSResult (mean, axes, c_vec ...) for upsampling
   pcp::DevBuf<uint8_t> m_flag;   // n
+  pcp::DevBuf<double> m_sums;    // SOR statistics
+  pcp::DevBuf<int32_t> c_index;  // pcp_cloud_smooth: survivors of the 1st SOR (indices into the uploaded cloud)
+  pcp::DevBuf<float> c_xyz, c_xyz2;  // pcp_cloud_smooth: intermediate clouds (SoA)
   pcp::DevBuf<uint32_t> v_bitmap;  // dilated voxel set, dense bitmap over the bounding box
   pcp::DevBuf<int32_t> v_offsets;  // exclusive popcount prefix per bitmap word
   pcp::DevBuf<float> mls_xyz, mls_normal, mls_curv;

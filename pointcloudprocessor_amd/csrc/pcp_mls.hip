@@ -666,6 +666,72 @@ __global__ __launch_bounds__(kMB) void k_count_occupied(const int32_t *__restric
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(occupied, static_cast<unsigned long long>(__popcll(m)));
 }
 
+// a cloud on the device the smoothing stages operate on (the uploaded map, or an
+// intermediate of pcp_cloud_smooth); mn/mx = its bounding box
+struct CloudView {
+  const float *x, *y, *z;
+  int64_t n;
+  float mn[3], mx[3];
+};
+
+__device__ __forceinline__ uint32_t ordered_bits(float f) {
+  const uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// bounding box as order-preserving uint keys: box[0..2] = min, box[3..5] = max
+__global__ __launch_bounds__(kMB) void k_bbox(const float *__restrict__ x, const float *__restrict__ y,
+                                              const float *__restrict__ z, int64_t n, uint32_t *__restrict__ box) {
+  uint32_t lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kMB) {
+    const uint32_t k[3] = {ordered_bits(x[i]), ordered_bits(y[i]), ordered_bits(z[i])};
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = min(lo[a], k[a]);
+      hi[a] = max(hi[a], k[a]);
+    }
+  }
+  for (int a = 0; a < 3; ++a) {
+    for (int o = 32; o >= 1; o >>= 1) {
+      lo[a] = min(lo[a], static_cast<uint32_t>(__shfl_xor(static_cast<int>(lo[a]), o, 64)));
+      hi[a] = max(hi[a], static_cast<uint32_t>(__shfl_xor(static_cast<int>(hi[a]), o, 64)));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(box + a, lo[a]);
+      atomicMax(box + 3 + a, hi[a]);
+    }
+  }
+}
+
+// out[k] = in[index[k]] for three SoA planes
+__global__ __launch_bounds__(kMB) void k_gather_xyz(const float *__restrict__ x, const float *__restrict__ y,
+                                                    const float *__restrict__ z, const int32_t *__restrict__ index,
+                                                    int64_t m, float *__restrict__ ox, float *__restrict__ oy,
+                                                    float *__restrict__ oz) {
+  const int64_t k = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  if (k >= m) return;
+  const int32_t i = index[k];
+  ox[k] = x[i];
+  oy[k] = y[i];
+  oz[k] = z[i];
+}
+
+// AoS xyz[3m] -> SoA planes
+__global__ __launch_bounds__(kMB) void k_deinterleave(const float *__restrict__ xyz, int64_t m, float *__restrict__ ox,
+                                                      float *__restrict__ oy, float *__restrict__ oz) {
+  const int64_t k = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  if (k >= m) return;
+  ox[k] = xyz[3 * k + 0];
+  oy[k] = xyz[3 * k + 1];
+  oz[k] = xyz[3 * k + 2];
+}
+
+// index[k] = map[index[k]]
+__global__ __launch_bounds__(kMB) void k_remap_index(int32_t *__restrict__ index, int64_t m,
+                                                     const int32_t *__restrict__ map) {
+  const int64_t k = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  if (k < m) index[k] = map[index[k]];
+}
+
 static inline uint32_t blocks_of(int64_t n) { return static_cast<uint32_t>(std::max<int64_t>(1, div_up(n, kMB))); }
 
 // device-wide exclusive scan of counts[0..m) into out[0..m], out[m] = total
@@ -682,11 +748,11 @@ static int exclusive_scan(pcp_context *ctx, int32_t *counts, int64_t m) {
   return PCP_OK;
 }
 
-// uniform grid over the uploaded cloud, cell edge >= `cell`; fills ctx->g_*
-static int build_grid(pcp_context *ctx, float cell, float radius, GridDesc *out) {
-  const int64_t n = ctx->n;
+// uniform grid over a cloud view, cell edge >= `cell`; fills ctx->g_*
+static int build_grid(pcp_context *ctx, const CloudView &cv, float cell, float radius, GridDesc *out) {
+  const int64_t n = cv.n;
   GridDesc g{};
-  const float *mn = ctx->host_min.data(), *mx = ctx->host_max.data();
+  const float *mn = cv.mn, *mx = cv.mx;
   for (;;) {  // bound the table: grow the cell until it fits 2^27 cells
     const double ex = static_cast<double>(mx[0] - mn[0]) / cell + 1.0, ey = static_cast<double>(mx[1] - mn[1]) / cell + 1.0,
                  ez = static_cast<double>(mx[2] - mn[2]) / cell + 1.0;
@@ -710,7 +776,7 @@ static int build_grid(pcp_context *ctx, float cell, float radius, GridDesc *out)
   PCP_HIP_TRY(ctx, ctx->g_start.ensure(static_cast<size_t>(ncell) + 8));
   PCP_HIP_TRY(ctx, ctx->g_xyz.ensure(3 * plane + 4));
   PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->g_start.p, 0, (static_cast<size_t>(ncell) + 8) * 4, ctx->stream));
-  const float *x = ctx->xyz.p, *y = ctx->xyz.p + plane, *z = ctx->xyz.p + 2 * plane;
+  const float *x = cv.x, *y = cv.y, *z = cv.z;
   {
     LaunchTimer t(ctx, PCP_K_MLS_GRID);
     hipLaunchKernelGGL(k_grid_count, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, x, y, z, n, g, ctx->g_cell.p,
@@ -729,20 +795,21 @@ static int build_grid(pcp_context *ctx, float cell, float radius, GridDesc *out)
 }
 
 // performUpsampling(VOXEL_GRID_DILATION) on the fitted surfaces in ctx->m_state
-static int voxel_grid_dilation(pcp_context *ctx, const pcp_mls_params *p, const GridDesc &g, int64_t *out_count) {
-  const int64_t n = ctx->n;
+static int voxel_grid_dilation(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *p, const GridDesc &g,
+                               int64_t *out_count) {
+  const int64_t n = cv.n;
   const size_t sn = static_cast<size_t>(n);
   const size_t plane = (sn + 3) & ~size_t(3);
   VoxelDesc v{};
-  v.bminx = ctx->host_min[0];
-  v.bminy = ctx->host_min[1];
-  v.bminz = ctx->host_min[2];
+  v.bminx = cv.mn[0];
+  v.bminy = cv.mn[1];
+  v.bminz = cv.mn[2];
   v.vs = p->vgd_voxel_size;
   v.it = p->vgd_iterations;
   // largest cell index per axis (float division as MLSVoxelGrid::getCellIndex) + dilation reach
-  const int64_t mx = static_cast<int64_t>((ctx->host_max[0] - v.bminx) / v.vs) + v.it + 1;
-  const int64_t my = static_cast<int64_t>((ctx->host_max[1] - v.bminy) / v.vs) + v.it + 1;
-  const int64_t mz = static_cast<int64_t>((ctx->host_max[2] - v.bminz) / v.vs) + v.it + 1;
+  const int64_t mx = static_cast<int64_t>((cv.mx[0] - v.bminx) / v.vs) + v.it + 1;
+  const int64_t my = static_cast<int64_t>((cv.mx[1] - v.bminy) / v.vs) + v.it + 1;
+  const int64_t mz = static_cast<int64_t>((cv.mx[2] - v.bminz) / v.vs) + v.it + 1;
   const double bits = static_cast<double>(mx) * static_cast<double>(my) * static_cast<double>(mz);
   size_t free_b = 0, total_b = 0;
   PCP_HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
@@ -762,7 +829,7 @@ static int voxel_grid_dilation(pcp_context *ctx, const pcp_mls_params *p, const 
   PCP_HIP_TRY(ctx, ctx->s_counter.ensure(4));
   PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->v_bitmap.p, 0, (sw + 8) * 4, ctx->stream));
   PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->v_offsets.p, 0, (sw + 8) * 4, ctx->stream));
-  const float *x = ctx->xyz.p, *y = ctx->xyz.p + plane, *z = ctx->xyz.p + 2 * plane;
+  const float *x = cv.x, *y = cv.y, *z = cv.z;
   unsigned long long total = 0;
   {
     LaunchTimer t(ctx, PCP_K_MLS_VOXEL);
@@ -857,29 +924,39 @@ static int voxel_grid_dilation(pcp_context *ctx, const pcp_mls_params *p, const 
   return PCP_OK;
 }
 
-}  // namespace pcp
+static CloudView uploaded_view(const pcp_context *ctx) {
+  CloudView cv{};
+  const size_t plane = (static_cast<size_t>(ctx->n) + 3) & ~size_t(3);
+  cv.x = ctx->xyz.p;
+  cv.y = ctx->xyz.p + plane;
+  cv.z = ctx->xyz.p + 2 * plane;
+  cv.n = ctx->n;
+  for (int a = 0; a < 3; ++a) {
+    cv.mn[a] = ctx->host_min[static_cast<size_t>(a)];
+    cv.mx[a] = ctx->host_max[static_cast<size_t>(a)];
+  }
+  return cv;
+}
 
-using namespace pcp;
-
-extern "C" {
-
-int pcp_mls_process(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_count) {
-  if (!ctx) return PCP_ERR_INVALID;
-  if (!p) return set_error(ctx, PCP_ERR_INVALID, "pcp_mls_process: NULL params");
-  if (!ctx->xyz.p) return set_error(ctx, PCP_ERR_STATE, "pcp_mls_process: no cloud uploaded");
+static int check_mls_params(pcp_context *ctx, const pcp_mls_params *p) {
+  if (!p) return set_error(ctx, PCP_ERR_INVALID, "pcp_mls: NULL params");
   // MovingLeastSquares::process refuses these (mls.hpp) [upstream]
   if (!(p->search_radius > 0.0) || !(p->sqr_gauss_param > 0.0))
-    return set_error(ctx, PCP_ERR_INVALID, "pcp_mls_process: search_radius and sqr_gauss_param must be > 0");
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_mls: search_radius and sqr_gauss_param must be > 0");
   if (p->polynomial_order < 0 || p->polynomial_order > 2)
-    return set_error(ctx, PCP_ERR_INVALID, "pcp_mls_process: polynomial_order %d unsupported (0..2; the reference uses 2)",
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_mls: polynomial_order %d unsupported (0..2; the reference uses 2)",
                      p->polynomial_order);
   if (p->upsampling != 0 && p->upsampling != 3)
-    return set_error(ctx, PCP_ERR_INVALID, "pcp_mls_process: upsampling %d unsupported (0 NONE, 3 VOXEL_GRID_DILATION)",
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_mls: upsampling %d unsupported (0 NONE, 3 VOXEL_GRID_DILATION)",
                      p->upsampling);
   if (p->upsampling == 3 && (!(p->vgd_voxel_size > 0.0f) || p->vgd_iterations < 0 || p->vgd_iterations > 15))
-    return set_error(ctx, PCP_ERR_INVALID, "pcp_mls_process: vgd_voxel_size must be > 0 and vgd_iterations in 0..15");
-  PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const int64_t n = ctx->n;
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_mls: vgd_voxel_size must be > 0 and vgd_iterations in 0..15");
+  return PCP_OK;
+}
+
+// MovingLeastSquares::process on a cloud view; results in ctx->mls_* (index = view index)
+static int mls_run(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *p, int64_t *out_count) {
+  const int64_t n = cv.n;
   ctx->mls_count = 0;
   if (out_count) *out_count = 0;
   if (n == 0) return PCP_OK;
@@ -888,7 +965,7 @@ int pcp_mls_process(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_coun
   GridDesc g;
   // cell edge 0.1 % above r: two points closer than r then differ by < 1 in every cell
   // coordinate even with the fp32 slop of the cell assignment, so reach 1 suffices
-  int rc = build_grid(ctx, static_cast<float>(p->search_radius) * 1.001f, static_cast<float>(p->search_radius), &g);
+  int rc = build_grid(ctx, cv, static_cast<float>(p->search_radius) * 1.001f, static_cast<float>(p->search_radius), &g);
   if (rc != PCP_OK) return rc;
   PCP_HIP_TRY(ctx, ctx->m_tmp.ensure(7 * sn + 8));
   PCP_HIP_TRY(ctx, ctx->m_flag.ensure(sn + 16));
@@ -917,7 +994,7 @@ int pcp_mls_process(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_coun
     hipLaunchKernelGGL(k_mls_fit, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, a);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
-  if (p->upsampling == 3) return voxel_grid_dilation(ctx, p, g, out_count);
+  if (p->upsampling == 3) return voxel_grid_dilation(ctx, cv, p, g, out_count);
   // points with < 3 neighbours are dropped; output keeps the input order
   PCP_HIP_TRY(ctx, ctx->mls_index.ensure(sn + 4));
   int64_t m = 0;
@@ -934,6 +1011,115 @@ int pcp_mls_process(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_coun
   ctx->mls_count = m;
   if (out_count) *out_count = m;
   return PCP_OK;
+}
+
+// StatisticalOutlierRemoval on a cloud view: keep flags in ctx->m_flag (view order)
+static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double std_mul) {
+  const int64_t n = cv.n;
+  if (n == 0) return PCP_OK;
+  const size_t sn = static_cast<size_t>(n);
+  const size_t plane = (sn + 3) & ~size_t(3);
+  // cell edge: first a volume-based guess, then refined from the number of occupied cells so that
+  // a 3x3x3 neighbourhood of a surface patch holds ~2.5 (k + 1) points
+  const double vol = std::max<double>(cv.mx[0] - cv.mn[0], 1e-3) * std::max<double>(cv.mx[1] - cv.mn[1], 1e-3) *
+                     std::max<double>(cv.mx[2] - cv.mn[2], 1e-3);
+  float cell = static_cast<float>(std::cbrt(vol / static_cast<double>(n) * 4.0));
+  if (!(cell > 1e-4f)) cell = 1e-4f;
+  GridDesc g;
+  int rc = build_grid(ctx, cv, cell, cell, &g);
+  if (rc != PCP_OK) return rc;
+  {
+    const int64_t ncell = static_cast<int64_t>(g.nx) * g.ny * g.nz;
+    PCP_HIP_TRY(ctx, ctx->s_counter.ensure(4));
+    PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->s_counter.p, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_count_occupied, dim3(blocks_of(ncell)), dim3(kMB), 0, ctx->stream, ctx->g_start.p, ncell,
+                       ctx->s_counter.p);
+    unsigned long long occ = 0;
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(&occ, ctx->s_counter.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const double c0 = 1.0 / g.inv_cell;
+    if (occ > 0) {
+      const double per_area = static_cast<double>(n) / (static_cast<double>(occ) * c0 * c0);  // points per unit area
+      const double want = std::sqrt(2.5 * (mean_k + 1) / (9.0 * per_area));
+      if (want > 0.0 && (want < 0.7 * c0 || want > 1.4 * c0)) {
+        rc = build_grid(ctx, cv, static_cast<float>(want), static_cast<float>(want), &g);
+        if (rc != PCP_OK) return rc;
+      }
+    }
+  }
+  PCP_HIP_TRY(ctx, ctx->m_tmp.ensure(sn + 8));
+  PCP_HIP_TRY(ctx, ctx->m_flag.ensure(sn + 16));
+  PCP_HIP_TRY(ctx, ctx->m_sums.ensure(4));
+  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->m_sums.p, 0, 2 * sizeof(double), ctx->stream));
+  float *dist = ctx->m_tmp.p;
+  {
+    LaunchTimer t(ctx, PCP_K_SOR);
+    const size_t lds = static_cast<size_t>(mean_k + 1) * kSorBlock * sizeof(float);
+    hipLaunchKernelGGL(k_sor_mean_distance, dim3(static_cast<uint32_t>(div_up(n, kSorBlock))), dim3(kSorBlock), lds,
+                       ctx->stream, ctx->g_xyz.p, ctx->g_xyz.p + plane, ctx->g_xyz.p + 2 * plane, ctx->g_order.p,
+                       ctx->g_start.p, n, g, mean_k, dist);
+    hipLaunchKernelGGL(k_sor_stats, dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(n, kMB), 1024))), dim3(kMB), 0,
+                       ctx->stream, dist, n, ctx->m_sums.p);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  double sums[2] = {0, 0};
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(sums, ctx->m_sums.p, sizeof(sums), hipMemcpyDeviceToHost, ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const double dn = static_cast<double>(n);
+  const double mean = sums[0] / dn;
+  const double variance = (sums[1] - sums[0] * sums[0] / dn) / (dn - 1.0);
+  const double threshold = mean + std_mul * std::sqrt(variance);
+  {
+    LaunchTimer t(ctx, PCP_K_SOR);
+    hipLaunchKernelGGL(k_sor_classify, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, dist, n, threshold, ctx->m_flag.p);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  return PCP_OK;
+}
+
+// bounding box of three device planes -> view
+static int view_of(pcp_context *ctx, const float *x, const float *y, const float *z, int64_t n, CloudView *cv) {
+  cv->x = x;
+  cv->y = y;
+  cv->z = z;
+  cv->n = n;
+  for (int a = 0; a < 3; ++a) cv->mn[a] = cv->mx[a] = 0.0f;
+  if (n == 0) return PCP_OK;
+  PCP_HIP_TRY(ctx, ctx->s_u32.ensure(8));
+  const uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->s_u32.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_bbox, dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(n, kMB), 1024))), dim3(kMB), 0, ctx->stream,
+                     x, y, z, n, ctx->s_u32.p);
+  PCP_HIP_TRY(ctx, hipGetLastError());
+  uint32_t box[6];
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(box, ctx->s_u32.p, sizeof(box), hipMemcpyDeviceToHost, ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  auto decode = [](uint32_t k) {
+    const uint32_t b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    float f;
+    std::memcpy(&f, &b, 4);
+    return f;
+  };
+  for (int a = 0; a < 3; ++a) {
+    cv->mn[a] = decode(box[a]);
+    cv->mx[a] = decode(box[3 + a]);
+  }
+  return PCP_OK;
+}
+
+}  // namespace pcp
+
+using namespace pcp;
+
+extern "C" {
+
+int pcp_mls_process(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_count) {
+  if (!ctx) return PCP_ERR_INVALID;
+  int rc = check_mls_params(ctx, p);
+  if (rc != PCP_OK) return rc;
+  if (!ctx->xyz.p) return set_error(ctx, PCP_ERR_STATE, "pcp_mls_process: no cloud uploaded");
+  PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return mls_run(ctx, uploaded_view(ctx), p, out_count);
 }
 
 int pcp_mls_fetch(pcp_context *ctx, int64_t capacity, float *out_xyz, float *out_normal, float *out_curvature,
@@ -962,70 +1148,92 @@ int pcp_sor(pcp_context *ctx, int32_t mean_k, double std_mul, uint8_t *out_keep,
   const int64_t n = ctx->n;
   if (out_kept) *out_kept = 0;
   if (n == 0) return PCP_OK;
-  const size_t sn = static_cast<size_t>(n);
-  const size_t plane = (sn + 3) & ~size_t(3);
-  // cell edge: first a volume-based guess, then refined from the number of occupied cells so that
-  // a 3x3x3 neighbourhood of a surface patch holds ~2.5 (k + 1) points
-  const float *mn = ctx->host_min.data(), *mx = ctx->host_max.data();
-  const double vol = std::max<double>(mx[0] - mn[0], 1e-3) * std::max<double>(mx[1] - mn[1], 1e-3) * std::max<double>(mx[2] - mn[2], 1e-3);
-  float cell = static_cast<float>(std::cbrt(vol / static_cast<double>(n) * 4.0));
-  if (!(cell > 1e-4f)) cell = 1e-4f;
-  GridDesc g;
-  int rc = build_grid(ctx, cell, cell, &g);
+  int rc = sor_run(ctx, uploaded_view(ctx), mean_k, std_mul);
   if (rc != PCP_OK) return rc;
-  {
-    const int64_t ncell = static_cast<int64_t>(g.nx) * g.ny * g.nz;
-    PCP_HIP_TRY(ctx, ctx->s_counter.ensure(4));
-    PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->s_counter.p, 0, 8, ctx->stream));
-    hipLaunchKernelGGL(k_count_occupied, dim3(blocks_of(ncell)), dim3(kMB), 0, ctx->stream, ctx->g_start.p, ncell,
-                       ctx->s_counter.p);
-    unsigned long long occ = 0;
-    PCP_HIP_TRY(ctx, hipMemcpyAsync(&occ, ctx->s_counter.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const double c0 = 1.0 / g.inv_cell;
-    if (occ > 0) {
-      const double per_area = static_cast<double>(n) / (static_cast<double>(occ) * c0 * c0);  // points per unit area
-      const double want = std::sqrt(2.5 * (mean_k + 1) / (9.0 * per_area));
-      if (want > 0.0 && (want < 0.7 * c0 || want > 1.4 * c0)) {
-        rc = build_grid(ctx, static_cast<float>(want), static_cast<float>(want), &g);
-        if (rc != PCP_OK) return rc;
-      }
-    }
-  }
-  PCP_HIP_TRY(ctx, ctx->m_tmp.ensure(sn + 8));
-  PCP_HIP_TRY(ctx, ctx->m_flag.ensure(sn + 16));
-  PCP_HIP_TRY(ctx, ctx->m_state.ensure(4));
-  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->m_state.p, 0, 2 * sizeof(double), ctx->stream));
-  float *dist = ctx->m_tmp.p;
-  {
-    LaunchTimer t(ctx, PCP_K_SOR);
-    const size_t lds = static_cast<size_t>(mean_k + 1) * kSorBlock * sizeof(float);
-    hipLaunchKernelGGL(k_sor_mean_distance, dim3(static_cast<uint32_t>(div_up(n, kSorBlock))), dim3(kSorBlock), lds,
-                       ctx->stream, ctx->g_xyz.p, ctx->g_xyz.p + plane, ctx->g_xyz.p + 2 * plane, ctx->g_order.p,
-                       ctx->g_start.p, n, g, mean_k, dist);
-    hipLaunchKernelGGL(k_sor_stats, dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(n, kMB), 1024))), dim3(kMB), 0,
-                       ctx->stream, dist, n, ctx->m_state.p);
-    PCP_HIP_TRY(ctx, hipGetLastError());
-  }
-  double sums[2] = {0, 0};
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(sums, ctx->m_state.p, sizeof(sums), hipMemcpyDeviceToHost, ctx->stream));
-  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  const double dn = static_cast<double>(n);
-  const double mean = sums[0] / dn;
-  const double variance = (sums[1] - sums[0] * sums[0] / dn) / (dn - 1.0);
-  const double threshold = mean + std_mul * std::sqrt(variance);
-  {
-    LaunchTimer t(ctx, PCP_K_SOR);
-    hipLaunchKernelGGL(k_sor_classify, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, dist, n, threshold, ctx->m_flag.p);
-    PCP_HIP_TRY(ctx, hipGetLastError());
-  }
   if (out_kept) {
     int64_t kept = 0;
     if ((rc = compact_flags(ctx, ctx->m_flag.p, n, nullptr, 0, &kept)) != PCP_OK) return rc;
     *out_kept = kept;
   }
-  if (out_keep) PCP_HIP_TRY(ctx, hipMemcpyAsync(out_keep, ctx->m_flag.p, sn, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_keep)
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(out_keep, ctx->m_flag.p, static_cast<size_t>(n), hipMemcpyDeviceToHost, ctx->stream));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PCP_OK;
+}
+
+// CloudSmooth::process end to end on the device (cloudSmooth.cpp:109-164):
+// SOR -> MovingLeastSquares (+ upsampling) -> SOR.  Results through pcp_mls_fetch;
+// out_index refers to the uploaded cloud.
+int pcp_cloud_smooth(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_count) {
+  if (!ctx) return PCP_ERR_INVALID;
+  int rc = check_mls_params(ctx, p);
+  if (rc != PCP_OK) return rc;
+  if (!ctx->xyz.p) return set_error(ctx, PCP_ERR_STATE, "pcp_cloud_smooth: no cloud uploaded");
+  if (p->sor_mean_k < 1 || p->sor_mean_k > 254)
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_cloud_smooth: sor_mean_k %d out of range (1..254)", p->sor_mean_k);
+  PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ctx->mls_count = 0;
+  if (out_count) *out_count = 0;
+  const CloudView cv0 = uploaded_view(ctx);
+  if (cv0.n == 0) return PCP_OK;
+  // 1st SOR (cloudSmooth.cpp:109-116) and the surviving points as a new device cloud
+  if ((rc = sor_run(ctx, cv0, p->sor_mean_k, p->sor_std_mul)) != PCP_OK) return rc;
+  PCP_HIP_TRY(ctx, ctx->c_index.ensure(static_cast<size_t>(cv0.n) + 4));
+  int64_t n1 = 0;
+  if ((rc = compact_flags(ctx, ctx->m_flag.p, cv0.n, ctx->c_index.p, cv0.n, &n1)) != PCP_OK) return rc;
+  if (n1 == 0) return PCP_OK;
+  const size_t plane1 = (static_cast<size_t>(n1) + 3) & ~size_t(3);
+  PCP_HIP_TRY(ctx, ctx->c_xyz.ensure(3 * plane1 + 4));
+  float *x1 = ctx->c_xyz.p, *y1 = ctx->c_xyz.p + plane1, *z1 = ctx->c_xyz.p + 2 * plane1;
+  hipLaunchKernelGGL(k_gather_xyz, dim3(blocks_of(n1)), dim3(kMB), 0, ctx->stream, cv0.x, cv0.y, cv0.z, ctx->c_index.p, n1,
+                     x1, y1, z1);
+  PCP_HIP_TRY(ctx, hipGetLastError());
+  CloudView cv1;
+  if ((rc = view_of(ctx, x1, y1, z1, n1, &cv1)) != PCP_OK) return rc;
+  // MLS (cloudSmooth.cpp:124-154)
+  int64_t m = 0;
+  if ((rc = mls_run(ctx, cv1, p, &m)) != PCP_OK) return rc;
+  if (m == 0) return PCP_OK;
+  // source indices back to the uploaded cloud
+  hipLaunchKernelGGL(k_remap_index, dim3(blocks_of(m)), dim3(kMB), 0, ctx->stream, ctx->mls_index.p, m, ctx->c_index.p);
+  PCP_HIP_TRY(ctx, hipGetLastError());
+  // 2nd SOR on the MLS output (cloudSmooth.cpp:160-164)
+  const size_t plane2 = (static_cast<size_t>(m) + 3) & ~size_t(3);
+  PCP_HIP_TRY(ctx, ctx->c_xyz2.ensure(3 * plane2 + 4));
+  float *x2 = ctx->c_xyz2.p, *y2 = ctx->c_xyz2.p + plane2, *z2 = ctx->c_xyz2.p + 2 * plane2;
+  hipLaunchKernelGGL(k_deinterleave, dim3(blocks_of(m)), dim3(kMB), 0, ctx->stream, ctx->mls_xyz.p, m, x2, y2, z2);
+  PCP_HIP_TRY(ctx, hipGetLastError());
+  CloudView cv2;
+  if ((rc = view_of(ctx, x2, y2, z2, m, &cv2)) != PCP_OK) return rc;
+  if ((rc = sor_run(ctx, cv2, p->sor_mean_k, p->sor_std_mul)) != PCP_OK) return rc;
+  PCP_HIP_TRY(ctx, ctx->s_cell.ensure(static_cast<size_t>(m) + 4));
+  int64_t kept = 0;
+  if ((rc = compact_flags(ctx, ctx->m_flag.p, m, ctx->s_cell.p, m, &kept)) != PCP_OK) return rc;
+  if (kept != m) {
+    const size_t sk = static_cast<size_t>(kept);
+    DevBuf<float> nx_, nn_, nc_;
+    DevBuf<int32_t> ni_;
+    PCP_HIP_TRY(ctx, nx_.ensure(3 * sk + 4));
+    PCP_HIP_TRY(ctx, nn_.ensure(3 * sk + 4));
+    PCP_HIP_TRY(ctx, nc_.ensure(sk + 4));
+    PCP_HIP_TRY(ctx, ni_.ensure(sk + 4));
+    if (kept > 0) {
+      hipLaunchKernelGGL(k_voxel_compact, dim3(blocks_of(kept)), dim3(kMB), 0, ctx->stream, ctx->s_cell.p, kept, ctx->mls_xyz.p,
+                         ctx->mls_normal.p, ctx->mls_curv.p, ctx->mls_index.p, nx_.p, nn_.p, nc_.p, ni_.p);
+      PCP_HIP_TRY(ctx, hipGetLastError());
+    }
+    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::swap(ctx->mls_xyz, nx_);
+    std::swap(ctx->mls_normal, nn_);
+    std::swap(ctx->mls_curv, nc_);
+    std::swap(ctx->mls_index, ni_);
+    nx_.release();
+    nn_.release();
+    nc_.release();
+    ni_.release();
+  }
+  ctx->mls_count = kept;
+  if (out_count) *out_count = kept;
   return PCP_OK;
 }
 

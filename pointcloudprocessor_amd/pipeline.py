@@ -146,6 +146,8 @@ class CloudSmooth:
         self.engine = engine
         self.params = params if params is not None else capi.default_mls_params()
 
-    def process(self):
-        m = self.engine.ctx.mls_process(self.params)
-        return self.engine.ctx.mls_fetch(m)
+    def process(self, with_outlier_removal: bool = True):
+        """SOR -> MLS (+ upsampling) -> SOR as cloudSmooth.cpp:109-164; MLS alone when asked."""
+        ctx = self.engine.ctx
+        m = ctx.cloud_smooth(self.params) if with_outlier_removal else ctx.mls_process(self.params)
+        return ctx.mls_fetch(m)
