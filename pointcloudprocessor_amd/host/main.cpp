@@ -1,0 +1,402 @@
+// main.cpp -- `PointCloudProcessor` command line on top of libpcp_hip.so.
+//
+// Same flags, same odometry / PCD inputs, same output files and exit codes as the
+// reference binary (PCP/src/main.cpp:7-71, PCP/src/PointCloudProcessor.cpp:1007-1032):
+//   --point_cloud_path/-p --odometry_path/-o --images_folder/-i --mask_image_folder/-m
+//   --output_path/-t --enableMLS --enableNIDOptimize --enableInitialGuessManual --help/-h
+// Stages kept on the host: odometry parsing (:965-1005), keyframe selection (:1050-1075,
+// hpp:151-191), trajectory crop (:92-136), PCD reading / ASCII writing.  Hot path on the
+// GPU through pcp_shim.hpp.
+//
+// Differences, all forced by what this image can decode (no OpenCV / libjpeg / libpng):
+//   * a keyframe's image is <images_folder><ts>.ppm (binary P6, stored BGR or RGB ->
+//     see --ppm_is_bgr) when <ts>.jpg cannot be decoded here; masks are <ts>.pgm (P5).
+//     The real binary keeps cv::imread and hands the decoded cv::Mat to the shim.
+//   * the 8-bit BGR->HSV->BGR round trip of generateColorMap (:722-741, Appendix B5) is
+//     not applied (pixels are taken as already adjusted).
+//   * --enableNIDOptimize / --enableInitialGuessManual are accepted and rejected with an
+//     exception (exit -2): Ceres / the GUI are out of scope.
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <filesystem>
+#include <fstream>
+#include <iostream>
+#include <memory>
+#include <sstream>
+
+#include "pcd_io.hpp"
+#include "pcp_shim.hpp"
+
+namespace fs = std::filesystem;
+using namespace pcp_amd;
+
+struct Frame {  // FrameData (PCP/include/FrameData.hpp:89-126)
+  std::string imagePath, maskImagePath;
+  double imageTimestamp = 0;
+  pcp_pose pose{};
+};
+
+struct Options {
+  std::string pointCloudPath, odometryPath, imagesFolder, maskImageFolder, outputPath = ".";
+  bool have_p = false, have_o = false, have_i = false;
+  bool enableMLS = false, enableNIDOptimize = false, enableInitialGuessManual = false;
+  bool help = false;
+  bool ppm_is_bgr = false;
+  bool skip_filtered_dumps = false;
+};
+
+static bool parse_bool(const std::string &v) {  // boost::program_options bool semantics
+  std::string s;
+  for (char c : v) s += static_cast<char>(std::tolower(c));
+  if (s == "1" || s == "true" || s == "yes" || s == "on") return true;
+  if (s == "0" || s == "false" || s == "no" || s == "off") return false;
+  throw std::runtime_error("the argument ('" + v + "') for a boolean option is invalid");
+}
+
+static Options parse(int argc, char **argv) {
+  Options o;
+  for (int k = 1; k < argc; ++k) {
+    std::string a = argv[k], val;
+    bool has_val = false;
+    const size_t eq = a.find('=');
+    if (a.rfind("--", 0) == 0 && eq != std::string::npos) {
+      val = a.substr(eq + 1);
+      a = a.substr(0, eq);
+      has_val = true;
+    }
+    auto next = [&]() -> std::string {
+      if (has_val) return val;
+      if (k + 1 >= argc) throw std::runtime_error("the required argument for option '" + a + "' is missing");
+      return argv[++k];
+    };
+    if (a == "--help" || a == "-h") o.help = true;
+    else if (a == "--point_cloud_path" || a == "-p") { o.pointCloudPath = next(); o.have_p = true; }
+    else if (a == "--odometry_path" || a == "-o") { o.odometryPath = next(); o.have_o = true; }
+    else if (a == "--images_folder" || a == "-i") { o.imagesFolder = next(); o.have_i = true; }
+    else if (a == "--mask_image_folder" || a == "-m") o.maskImageFolder = next();
+    else if (a == "--output_path" || a == "-t") o.outputPath = next();
+    else if (a == "--enableMLS") o.enableMLS = parse_bool(next());
+    else if (a == "--enableNIDOptimize") o.enableNIDOptimize = parse_bool(next());
+    else if (a == "--enableInitialGuessManual") o.enableInitialGuessManual = parse_bool(next());
+    else if (a == "--ppm_is_bgr") o.ppm_is_bgr = parse_bool(next());
+    else if (a == "--skip_filtered_dumps") o.skip_filtered_dumps = parse_bool(next());
+    else throw std::runtime_error("unrecognised option '" + a + "'");
+  }
+  return o;
+}
+
+static void usage(std::ostream &os) {
+  os << "Allowed options:\n"
+        "  -h [ --help ]                         Produce help message\n"
+        "  -p [ --point_cloud_path ] arg         Path to the point cloud data file\n"
+        "  -o [ --odometry_path ] arg            Path to odometry data file\n"
+        "  -i [ --images_folder ] arg            Path to directory containing images\n"
+        "  -m [ --mask_image_folder ] arg        Path to directory for segmented images\n"
+        "  -t [ --output_path ] arg (=.)         Path to save processed output\n"
+        "  --enableMLS arg (=0)                  Enable MLS smoothing\n"
+        "  --enableNIDOptimize arg (=0)          Enable NID-based camera pose optimization\n"
+        "  --enableInitialGuessManual arg (=0)   Enable manual pickup point based camera pose optimization\n";
+}
+
+// binary PPM (P6) / PGM (P5), maxval 255
+static bool read_pnm(const std::string &path, int expect_channels, int &w, int &h, std::vector<uint8_t> &px) {
+  std::ifstream in(path, std::ios::binary);
+  if (!in) return false;
+  std::string magic;
+  in >> magic;
+  if ((expect_channels == 3 && magic != "P6") || (expect_channels == 1 && magic != "P5")) return false;
+  auto next_int = [&]() {
+    int v = 0;
+    for (;;) {
+      int c = in.peek();
+      if (c == '#') {
+        std::string skip;
+        std::getline(in, skip);
+      } else if (std::isspace(c)) {
+        in.get();
+      } else {
+        break;
+      }
+    }
+    in >> v;
+    return v;
+  };
+  w = next_int();
+  h = next_int();
+  const int maxv = next_int();
+  in.get();
+  if (w <= 0 || h <= 0 || maxv != 255) return false;
+  px.resize(static_cast<size_t>(w) * h * expect_channels);
+  in.read(reinterpret_cast<char *>(px.data()), static_cast<std::streamsize>(px.size()));
+  return static_cast<bool>(in);
+}
+
+class Processor {
+ public:
+  explicit Processor(const Options &o) : opt(o), enableMaskSegmentation(!o.maskImageFolder.empty()) {}
+
+  void process() {  // PointCloudProcessor::process, PointCloudProcessor.cpp:1007-1032
+    loadImagesAndOdometry();
+    loadPointCloud();
+    generateResultStorageFolder();
+    selectKeyframes();
+    setupDevice();
+    if (!opt.skip_filtered_dumps) viewCullingAndSaveFilteredPcds();
+    if (opt.enableNIDOptimize)
+      throw std::runtime_error("NID-based pose optimisation (Ceres) is not part of this build");
+    if (opt.enableInitialGuessManual)
+      throw std::runtime_error("the manual initial-guess GUI is not part of this build");
+    pcdColorizationAndSmooth();
+  }
+
+ private:
+  Options opt;
+  bool enableMaskSegmentation;
+  std::vector<Frame> frames, keyframes;
+  XYZICloud cloud;
+  std::unique_ptr<Device> gpu;
+  int img_w = 0, img_h = 0;
+
+  void loadImagesAndOdometry() {  // :965-1005
+    std::ifstream vo(opt.odometryPath);
+    std::string line;
+    while (std::getline(vo, line)) {
+      std::istringstream iss(line);
+      double ts, x, y, z, qw, qx, qy, qz;
+      if (!(iss >> ts >> x >> y >> z >> qw >> qx >> qy >> qz)) break;  // stop at the first malformed line
+      Frame f;
+      f.pose = {x, y, z, qw, qx, qy, qz};
+      f.imageTimestamp = ts;
+      const std::string stem = opt.imagesFolder + std::to_string(ts);  // "%f": 6 decimals (:981)
+      if (fs::exists(stem + ".jpg") && !fs::exists(stem + ".ppm"))
+        throw std::runtime_error("cannot decode " + stem + ".jpg in this build (no OpenCV): provide " + stem + ".ppm");
+      f.imagePath = stem + ".ppm";
+      if (!fs::exists(f.imagePath)) continue;  // skip this frame if its image does not exist
+      if (enableMaskSegmentation) f.maskImagePath = opt.maskImageFolder + std::to_string(ts) + ".pgm";
+      frames.push_back(f);
+    }
+  }
+
+  void loadPointCloud() {  // :92-154
+    double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {DBL_MIN, DBL_MIN, DBL_MIN};  // DBL_MIN: sic (B10)
+    for (const auto &f : frames) {
+      const double p[3] = {f.pose.x, f.pose.y, f.pose.z};
+      for (int a = 0; a < 3; ++a) {
+        mn[a] = std::min(mn[a], p[a]);
+        mx[a] = std::max(mx[a], p[a]);
+      }
+    }
+    for (int a = 0; a < 3; ++a) {
+      mn[a] -= 2.0;
+      mx[a] += 2.0;
+    }
+    XYZICloud original;
+    if (loadPCDFile(opt.pointCloudPath, original) == -1) throw std::runtime_error("Couldn't read point cloud file.");
+    std::cout << "Start crop pcd..." << std::endl;
+    // pcl::CropBox with Vector4f(min), Vector4f(max): keep min <= p <= max (fp32 bounds)
+    const float fmn[3] = {static_cast<float>(mn[0]), static_cast<float>(mn[1]), static_cast<float>(mn[2])};
+    const float fmx[3] = {static_cast<float>(mx[0]), static_cast<float>(mx[1]), static_cast<float>(mx[2])};
+    XYZICloud cropped;
+    for (size_t i = 0; i < original.size(); ++i) {
+      const float p[3] = {original.x[i], original.y[i], original.z[i]};
+      if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
+      bool in = true;
+      for (int a = 0; a < 3; ++a) in = in && !(p[a] < fmn[a]) && !(p[a] > fmx[a]);
+      if (in) cropped.push_back(p[0], p[1], p[2], original.intensity[i]);
+    }
+    std::cout << "Loaded point cloud with " << original.size() << " points." << std::endl;
+    std::cout << "Cropped point cloud with " << cropped.size() << " points." << std::endl;
+    const std::string cropPath = opt.outputPath + "scans-crop.pcd";  // outputPath must end in '/' (:131)
+    writeASCII_XYZI(cropPath, cropped.x.data(), cropped.y.data(), cropped.z.data(), cropped.intensity.data(), cropped.size());
+    std::cout << "Cropped point cloud saved to: " << cropPath << std::endl;
+    if (opt.enableMLS) {
+      // CloudSmooth re-reads the ASCII crop it was handed (cloudSmooth.cpp:92): 8 significant digits
+      XYZICloud crop8;
+      if (loadPCDFile(cropPath, crop8) == -1) {
+        std::cerr << "Couldn't read file " << cropPath << std::endl;
+        return;
+      }
+      gpu.reset(new Device(0));
+      gpu->uploadCloud(crop8.x.data(), crop8.y.data(), crop8.z.data(), static_cast<int64_t>(crop8.size()));
+      CloudSmooth smooth(*gpu);
+      pcp_mls_params mp;
+      pcp_default_mls_params(&mp);  // PointCloudProcessor.cpp:67-86
+      smooth.initialize(mp);
+      SmoothedCloud s = smooth.processWithOutlierRemoval();
+      const std::string mlsPath = fs::path(cropPath).stem().string() + "_mls.pcd";  // CWD-relative, sic (B14)
+      writeASCII_PointNormal(mlsPath, s.xyz.data(), s.normal.data(), s.curvature.data(), s.curvature.size());
+      cloud.resize(s.curvature.size());
+      for (size_t i = 0; i < cloud.size(); ++i) {
+        cloud.x[i] = s.xyz[3 * i];
+        cloud.y[i] = s.xyz[3 * i + 1];
+        cloud.z[i] = s.xyz[3 * i + 2];
+        cloud.intensity[i] = 0.0f;  // PointNormal carries no intensity (copyPointCloud, :144)
+      }
+    } else {
+      cloud = std::move(original);  // the reference reloads the same file (:148)
+      std::cout << "Loaded point cloud with " << cloud.size() << " points." << std::endl;
+    }
+  }
+
+  void generateResultStorageFolder() {  // :1034-1048
+    const fs::path dir(opt.outputPath + "filtered_pcd/");
+    if (fs::exists(dir)) fs::remove_all(dir);
+    fs::create_directories(dir);
+  }
+
+  void selectKeyframes() {  // :1050-1075 + markKeyframe hpp:151-191 (distance rule only, B9)
+    keyframes.clear();
+    int last_idx = -1;
+    for (size_t i = 0; i < frames.size(); ++i) {
+      bool key = last_idx < 0;
+      if (key) std::cout << "First frame is always a keyframe." << std::endl;
+      if (!key) {
+        const auto &a = frames[i].pose, &b = frames[static_cast<size_t>(last_idx)].pose;
+        const double dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+        key = std::sqrt(dx * dx + dy * dy + dz * dz) >= 0.1;
+      }
+      if (key) {
+        keyframes.push_back(frames[i]);
+        last_idx = static_cast<int>(i);
+      }
+    }
+  }
+
+  void setupDevice() {
+    if (!gpu) gpu.reset(new Device(0));
+    gpu->uploadCloud(cloud.x.data(), cloud.y.data(), cloud.z.data(), static_cast<int64_t>(cloud.size()));
+    // image size from the first keyframe image; cull size stays the reference's {4096,3000} (:206,:525)
+    std::vector<uint8_t> px;
+    if (!keyframes.empty() && !read_pnm(keyframes[0].imagePath, 3, img_w, img_h, px))
+      throw std::runtime_error("Failed to read image from: " + keyframes[0].imagePath);
+    pcp_camera cam;
+    pcp_default_camera(&cam);
+    if (!keyframes.empty()) {
+      cam.image_width = img_w;
+      cam.image_height = img_h;
+    }
+    gpu->setCamera(cam);
+    std::vector<pcp_pose> poses;
+    for (const auto &k : keyframes) poses.push_back(k.pose);
+    gpu->setKeyframes(poses);
+  }
+
+  void viewCullingAndSaveFilteredPcds() {  // :178-224
+    ViewCulling vc(*gpu);
+    const size_t n = cloud.size();
+    std::vector<float> cam(3 * n);
+    for (size_t k = 0; k < keyframes.size(); ++k) {
+      const std::vector<int32_t> kept = vc.cull(static_cast<int>(k));
+      gpu->check(pcp_project_frame(gpu->get(), static_cast<int>(k), nullptr, nullptr, nullptr, cam.data()));
+      std::vector<float> x(kept.size()), y(kept.size()), z(kept.size()), in(kept.size());
+      for (size_t q = 0; q < kept.size(); ++q) {
+        const size_t i = static_cast<size_t>(kept[q]);
+        x[q] = cam[i];
+        y[q] = cam[n + i];
+        z[q] = cam[2 * n + i];
+        in[q] = cloud.intensity[i];
+      }
+      const std::string path =
+          opt.outputPath + "filtered_pcd/" + std::to_string(keyframes[k].imageTimestamp) + "_beforeNID" + ".pcd";
+      if (writeASCII_XYZI(path, x.data(), y.data(), z.data(), in.data(), kept.size()) == -1)
+        throw std::runtime_error("Couldn't save filtered point cloud to PCD file.");
+      std::cout << "Before NID optimization: view culling pcd saved to: " << path << ", the point size is "
+                << kept.size() << std::endl;
+    }
+  }
+
+  void pcdColorizationAndSmooth() {  // :474-602
+    std::vector<uint8_t> px, bgr;
+    for (size_t k = 0; k < keyframes.size(); ++k) {
+      int w = 0, h = 0;
+      std::cout << "Reading image from: " << keyframes[k].imagePath << std::endl;
+      if (!read_pnm(keyframes[k].imagePath, 3, w, h, px) || w != img_w || h != img_h)
+        throw std::runtime_error("Failed to read image from: " + keyframes[k].imagePath);
+      if (!opt.ppm_is_bgr) {  // PPM stores RGB; the boundary takes BGR like cv::Mat
+        bgr.resize(px.size());
+        for (size_t i = 0; i + 2 < px.size(); i += 3) {
+          bgr[i] = px[i + 2];
+          bgr[i + 1] = px[i + 1];
+          bgr[i + 2] = px[i];
+        }
+        gpu->uploadImage(static_cast<int>(k), bgr.data(), static_cast<int64_t>(w) * 3);
+      } else {
+        gpu->uploadImage(static_cast<int>(k), px.data(), static_cast<int64_t>(w) * 3);
+      }
+      if (enableMaskSegmentation) {
+        std::vector<uint8_t> gray;
+        int mw = 0, mh = 0;
+        std::cout << "Reading segment mask image from: " << keyframes[k].maskImagePath << std::endl;
+        if (read_pnm(keyframes[k].maskImagePath, 1, mw, mh, gray) && mw == img_w && mh == img_h)
+          gpu->uploadMask(static_cast<int>(k), gray.data(), mw);
+        else
+          std::cout << "Failed to read image from: " << keyframes[k].maskImagePath << std::endl;  // :779, not fatal
+      }
+    }
+    Colorizer col(*gpu);
+    std::vector<float> wx, wy, wz;  // cloudInWorldWithRGBandMask
+    std::vector<float> wxyz;
+    std::vector<uint8_t> wrgb;
+    std::vector<uint16_t> wmask;
+    if (enableMaskSegmentation) {
+      for (size_t k = 0; k < keyframes.size(); ++k) {
+        const VisiblePoints v = col.frameVisible(static_cast<int>(k));
+        const std::string path =
+            opt.outputPath + "filtered_pcd/" + std::to_string(keyframes[k].imageTimestamp) + "_rgb-mask" + ".pcd";
+        if (writeASCII_XYZRGBMask(path, v.xyz_cam.data(), v.rgb.data(), v.mask.data(), v.index.size()) == -1)
+          throw std::runtime_error("Couldn't save filtered point cloud to PCD file.");
+        std::cout << "Filtered point cloud saved to: " << path << ", the point size is " << v.index.size() << std::endl;
+        wxyz.insert(wxyz.end(), v.xyz_world.begin(), v.xyz_world.end());
+        wrgb.insert(wrgb.end(), v.rgb.begin(), v.rgb.end());
+        wmask.insert(wmask.end(), v.mask.begin(), v.mask.end());
+      }
+    }
+    std::vector<uint8_t> rgb, has;
+    col.colorize(rgb, has);  // smoothColors + removePointsWithNoColor flag
+    XYZICloud out;
+    std::vector<uint8_t> out_rgb;
+    for (size_t i = 0; i < cloud.size(); ++i)
+      if (has[i]) {
+        out.push_back(cloud.x[i], cloud.y[i], cloud.z[i], 0.0f);
+        out_rgb.insert(out_rgb.end(), {rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]});
+      }
+    if (enableMaskSegmentation && !wmask.empty()) {  // saveColorizedPointCloud(rgbCloud, withMask), :933-960
+      const std::string path = opt.outputPath + "cloudInWorldWithRGBandMask.pcd";
+      if (writeASCII_XYZRGBMask(path, wxyz.data(), wrgb.data(), wmask.data(), wmask.size()) == -1)
+        throw std::runtime_error("Couldn't save colorized and segment colored point cloud.");
+      std::cout << "All colored and segment colored cloud saved to: " << path << std::endl;
+    }
+    if (out.size() > 0) {  // :912-929
+      const std::string path = opt.outputPath + "cloudInWorldWithRGB.pcd";
+      if (writeASCII_XYZRGB(path, out.x.data(), out.y.data(), out.z.data(), out_rgb.data(), out.size()) == -1)
+        throw std::runtime_error("Couldn't save colorized point cloud.");
+      std::cout << "All colored cloud saved to: " << path << std::endl;
+    }
+  }
+};
+
+int main(int argc, char **argv) {
+  try {
+    const Options o = parse(argc, argv);
+    if (o.help) {
+      usage(std::cout);
+      return 1;
+    }
+    if (o.have_p && o.have_o && o.have_i) {
+      Processor processor(o);
+      processor.process();
+      std::cout << "Processing completed successfully." << std::endl;
+    } else {
+      std::cerr << "Error: Missing required arguments." << std::endl;
+      usage(std::cerr);
+      return -1;
+    }
+  } catch (const std::exception &e) {
+    std::cerr << "Unhandled Exception reached the top of main: " << e.what() << ", application will now exit"
+              << std::endl;
+    return -2;
+  }
+  return 0;
+}

@@ -1,0 +1,253 @@
+// pcd_io.hpp -- the PCD subset PointCloudProcessor reads and writes, without PCL.
+//
+// Reader: .pcd v0.7, DATA ascii | binary (not binary_compressed), any field list
+// that contains x y z (float32), optional intensity (float32) and rgb (packed).
+// What the reference calls: pcl::io::loadPCDFile<PointXYZI> (PCP/src/PointCloudProcessor.cpp:112,148,
+// PCP/src/cloudSmooth.cpp:92).
+//
+// Writer: the ASCII layout of pcl::PCDWriter::writeASCII (PCL 1.10 pcd_io.hpp
+// [upstream]): header lines VERSION/FIELDS/SIZE/TYPE/COUNT/WIDTH/HEIGHT/VIEWPOINT/
+// POINTS/DATA, then one point per line, floats printed with 8 significant digits
+// (ostream precision 8 == "%.8g"), the `rgb` field as the packed uint32 with TYPE U.
+// Call sites: savePCDFileASCII :135 (x y z intensity), writeASCII :217 (culled cloud,
+// x y z intensity), :542 (x y z rgb segmentMask), :920 (x y z rgb).
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace pcp_amd {
+
+struct XYZICloud {  // pcl::PointCloud<pcl::PointXYZI>
+  std::vector<float> x, y, z, intensity;
+  size_t size() const { return x.size(); }
+  void resize(size_t n) {
+    x.resize(n);
+    y.resize(n);
+    z.resize(n);
+    intensity.resize(n);
+  }
+  void push_back(float a, float b, float c, float i) {
+    x.push_back(a);
+    y.push_back(b);
+    z.push_back(c);
+    intensity.push_back(i);
+  }
+};
+
+struct PcdField {
+  std::string name;
+  int size = 4;
+  char type = 'F';
+  int count = 1;
+  int offset = 0;
+};
+
+inline int loadPCDFile(const std::string &path, XYZICloud &cloud) {
+  std::ifstream in(path, std::ios::binary);
+  if (!in) return -1;
+  std::vector<PcdField> fields;
+  size_t points = 0, width = 0, height = 1;
+  std::string data_mode, line;
+  while (std::getline(in, line)) {
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    if (line.empty() || line[0] == '#') continue;
+    std::istringstream ls(line);
+    std::string key;
+    ls >> key;
+    if (key == "FIELDS" || key == "COLUMNS") {
+      std::string f;
+      while (ls >> f) {
+        PcdField pf;
+        pf.name = f;
+        fields.push_back(pf);
+      }
+    } else if (key == "SIZE") {
+      for (auto &f : fields) ls >> f.size;
+    } else if (key == "TYPE") {
+      for (auto &f : fields) ls >> f.type;
+    } else if (key == "COUNT") {
+      for (auto &f : fields) ls >> f.count;
+    } else if (key == "WIDTH") {
+      ls >> width;
+    } else if (key == "HEIGHT") {
+      ls >> height;
+    } else if (key == "POINTS") {
+      ls >> points;
+    } else if (key == "DATA") {
+      ls >> data_mode;
+      break;
+    }
+  }
+  if (fields.empty() || data_mode.empty()) return -1;
+  if (points == 0) points = width * height;
+  int off = 0, ix = -1, iy = -1, iz = -1, ii = -1;
+  for (size_t k = 0; k < fields.size(); ++k) {
+    fields[k].offset = off;
+    off += fields[k].size * fields[k].count;
+    if (fields[k].name == "x") ix = static_cast<int>(k);
+    if (fields[k].name == "y") iy = static_cast<int>(k);
+    if (fields[k].name == "z") iz = static_cast<int>(k);
+    if (fields[k].name == "intensity") ii = static_cast<int>(k);
+  }
+  if (ix < 0 || iy < 0 || iz < 0) return -1;
+  for (int k : {ix, iy, iz})
+    if (fields[static_cast<size_t>(k)].type != 'F' || fields[static_cast<size_t>(k)].size != 4) return -1;
+  cloud.resize(points);
+  if (data_mode == "ascii") {
+    // column index of every scalar
+    std::vector<int> first_col(fields.size());
+    int col = 0;
+    for (size_t k = 0; k < fields.size(); ++k) {
+      first_col[k] = col;
+      col += fields[k].count;
+    }
+    std::vector<std::string> tok;
+    for (size_t p = 0; p < points; ++p) {
+      if (!std::getline(in, line)) return -1;
+      tok.clear();
+      std::istringstream ls(line);
+      std::string t;
+      while (ls >> t) tok.push_back(t);
+      if (static_cast<int>(tok.size()) < col) return -1;
+      auto val = [&](int f) { return std::strtof(tok[static_cast<size_t>(first_col[static_cast<size_t>(f)])].c_str(), nullptr); };
+      cloud.x[p] = val(ix);
+      cloud.y[p] = val(iy);
+      cloud.z[p] = val(iz);
+      cloud.intensity[p] = ii >= 0 ? val(ii) : 0.0f;
+    }
+  } else if (data_mode == "binary") {
+    std::vector<char> rec(static_cast<size_t>(off));
+    for (size_t p = 0; p < points; ++p) {
+      in.read(rec.data(), off);
+      if (!in) return -1;
+      std::memcpy(&cloud.x[p], rec.data() + fields[static_cast<size_t>(ix)].offset, 4);
+      std::memcpy(&cloud.y[p], rec.data() + fields[static_cast<size_t>(iy)].offset, 4);
+      std::memcpy(&cloud.z[p], rec.data() + fields[static_cast<size_t>(iz)].offset, 4);
+      if (ii >= 0 && fields[static_cast<size_t>(ii)].size == 4)
+        std::memcpy(&cloud.intensity[p], rec.data() + fields[static_cast<size_t>(ii)].offset, 4);
+      else
+        cloud.intensity[p] = 0.0f;
+    }
+  } else {
+    return -1;  // binary_compressed: not supported by this reader
+  }
+  return 0;
+}
+
+namespace detail {
+inline void put_float(std::string &out, float v) {  // ostream << float at precision 8
+  if (std::isnan(v)) {
+    out += "nan";
+    return;
+  }
+  char buf[40];
+  std::snprintf(buf, sizeof(buf), "%.8g", static_cast<double>(v));
+  out += buf;
+}
+inline std::string header(const char *fields, const char *sizes, const char *types, const char *counts, size_t n) {
+  std::ostringstream h;
+  h << "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS " << fields << "\nSIZE " << sizes << "\nTYPE "
+    << types << "\nCOUNT " << counts << "\nWIDTH " << n << "\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS " << n
+    << "\nDATA ascii\n";
+  return h.str();
+}
+inline int flush(const std::string &path, const std::string &body) {
+  std::ofstream out(path, std::ios::binary);
+  if (!out) return -1;
+  out.write(body.data(), static_cast<std::streamsize>(body.size()));
+  return out ? 0 : -1;
+}
+}  // namespace detail
+
+// x y z intensity (pcl::PointXYZI)
+inline int writeASCII_XYZI(const std::string &path, const float *x, const float *y, const float *z, const float *intensity,
+                           size_t n) {
+  std::string s = detail::header("x y z intensity", "4 4 4 4", "F F F F", "1 1 1 1", n);
+  s.reserve(s.size() + n * 48);
+  for (size_t i = 0; i < n; ++i) {
+    detail::put_float(s, x[i]);
+    s += ' ';
+    detail::put_float(s, y[i]);
+    s += ' ';
+    detail::put_float(s, z[i]);
+    s += ' ';
+    detail::put_float(s, intensity ? intensity[i] : 0.0f);
+    s += '\n';
+  }
+  return detail::flush(path, s);
+}
+
+// x y z rgb (pcl::PointXYZRGB): rgb as packed uint32 0xAARRGGBB with A = 255 (PointXYZRGB ctor)
+inline int writeASCII_XYZRGB(const std::string &path, const float *x, const float *y, const float *z, const uint8_t *rgb,
+                             size_t n) {
+  std::string s = detail::header("x y z rgb", "4 4 4 4", "F F F U", "1 1 1 1", n);
+  s.reserve(s.size() + n * 48);
+  char buf[16];
+  for (size_t i = 0; i < n; ++i) {
+    detail::put_float(s, x[i]);
+    s += ' ';
+    detail::put_float(s, y[i]);
+    s += ' ';
+    detail::put_float(s, z[i]);
+    s += ' ';
+    const uint32_t packed = 0xff000000u | (static_cast<uint32_t>(rgb[3 * i]) << 16) |
+                            (static_cast<uint32_t>(rgb[3 * i + 1]) << 8) | rgb[3 * i + 2];
+    std::snprintf(buf, sizeof(buf), "%u", packed);
+    s += buf;
+    s += '\n';
+  }
+  return detail::flush(path, s);
+}
+
+// x y z rgb segmentMask (PointXYZRGBMask, PCP/include/FrameData.hpp:68-87)
+inline int writeASCII_XYZRGBMask(const std::string &path, const float *xyz /* 3 per point */, const uint8_t *rgb,
+                                 const uint16_t *mask, size_t n) {
+  std::string s = detail::header("x y z rgb segmentMask", "4 4 4 4 2", "F F F U U", "1 1 1 1 1", n);
+  s.reserve(s.size() + n * 56);
+  char buf[32];
+  for (size_t i = 0; i < n; ++i) {
+    detail::put_float(s, xyz[3 * i]);
+    s += ' ';
+    detail::put_float(s, xyz[3 * i + 1]);
+    s += ' ';
+    detail::put_float(s, xyz[3 * i + 2]);
+    s += ' ';
+    const uint32_t packed = 0xff000000u | (static_cast<uint32_t>(rgb[3 * i]) << 16) |
+                            (static_cast<uint32_t>(rgb[3 * i + 1]) << 8) | rgb[3 * i + 2];
+    std::snprintf(buf, sizeof(buf), "%u %u", packed, static_cast<unsigned>(mask[i]));
+    s += buf;
+    s += '\n';
+  }
+  return detail::flush(path, s);
+}
+
+// x y z normal_x normal_y normal_z curvature (pcl::PointNormal), savePCDFile default = ASCII (cloudSmooth.cpp:181)
+inline int writeASCII_PointNormal(const std::string &path, const float *xyz, const float *normal, const float *curv,
+                                  size_t n) {
+  std::string s = detail::header("x y z normal_x normal_y normal_z curvature", "4 4 4 4 4 4 4", "F F F F F F F",
+                                 "1 1 1 1 1 1 1", n);
+  s.reserve(s.size() + n * 96);
+  for (size_t i = 0; i < n; ++i) {
+    for (int c = 0; c < 3; ++c) {
+      detail::put_float(s, xyz[3 * i + static_cast<size_t>(c)]);
+      s += ' ';
+    }
+    for (int c = 0; c < 3; ++c) {
+      detail::put_float(s, normal[3 * i + static_cast<size_t>(c)]);
+      s += ' ';
+    }
+    detail::put_float(s, curv[i]);
+    s += '\n';
+  }
+  return detail::flush(path, s);
+}
+
+}  // namespace pcp_amd

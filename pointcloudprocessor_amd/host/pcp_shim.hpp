@@ -124,9 +124,15 @@ class CloudSmooth {
  public:
   explicit CloudSmooth(Device &dev) : dev_(dev) { pcp_default_mls_params(&params_); }
   void initialize(const pcp_mls_params &p) { params_ = p; }  // CloudSmooth::initialize(MLSParameters)
-  SmoothedCloud process() const {
+  // the whole CloudSmooth::process: SOR -> MLS (+ upsampling) -> SOR (cloudSmooth.cpp:109-164)
+  SmoothedCloud processWithOutlierRemoval() const { return run(true); }
+  // pcl::MovingLeastSquares::process alone
+  SmoothedCloud process() const { return run(false); }
+
+ private:
+  SmoothedCloud run(bool with_sor) const {
     int64_t m = 0;
-    dev_.check(pcp_mls_process(dev_.get(), &params_, &m));
+    dev_.check(with_sor ? pcp_cloud_smooth(dev_.get(), &params_, &m) : pcp_mls_process(dev_.get(), &params_, &m));
     SmoothedCloud s;
     const size_t sm = static_cast<size_t>(m);
     s.xyz.resize(3 * sm);
@@ -137,7 +143,6 @@ class CloudSmooth {
     return s;
   }
 
- private:
   Device &dev_;
   pcp_mls_params params_;
 };

@@ -11,6 +11,7 @@ BIN = os.path.join(HOST, "bin")
 
 TARGETS = {
     "pcp_shim_selftest": ["shim_selftest.cpp"],
+    "PointCloudProcessor": ["main.cpp"],
 }
 
 
@@ -19,7 +20,7 @@ def build(force: bool = False) -> dict:
     out = {}
     for name, srcs in TARGETS.items():
         exe = os.path.join(BIN, name)
-        deps = [os.path.join(HOST, s) for s in srcs] + [os.path.join(HOST, "pcp_shim.hpp"),
+        deps = [os.path.join(HOST, s) for s in srcs] + [os.path.join(HOST, "pcp_shim.hpp"), os.path.join(HOST, "pcd_io.hpp"),
                                                        os.path.join(_build.INCLUDE, "pcp_hip.h")]
         deps = [d for d in deps if os.path.exists(d)]
         stale = force or not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps)

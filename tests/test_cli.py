@@ -1,0 +1,153 @@
+"""The C++ command line (pointcloudprocessor_amd/host/main.cpp): the reference's flags,
+exit codes and file contract; on a GPU box an end-to-end run whose PCD outputs are
+compared with the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import cam_struct
+
+
+def _exe():
+    from pointcloudprocessor_amd import _build, host_build
+
+    _build.build()
+    return host_build.build()["PointCloudProcessor"]
+
+
+def test_cli_flags_and_exit_codes(tmp_path):
+    exe = _exe()
+    p = subprocess.run([exe, "--help"], capture_output=True, text=True)
+    assert p.returncode == 1  # PCP/src/main.cpp:28-31
+    for flag in ("--point_cloud_path", "--odometry_path", "--images_folder", "--mask_image_folder", "--output_path",
+                 "--enableMLS", "--enableNIDOptimize", "--enableInitialGuessManual"):
+        assert flag in p.stdout, flag
+    p = subprocess.run([exe, "-p", "x.pcd"], capture_output=True, text=True)
+    assert p.returncode == 255 and "Missing required arguments" in p.stderr  # -1, main.cpp:59-63
+    p = subprocess.run([exe, "-p", str(tmp_path / "none.pcd"), "-o", str(tmp_path / "odo.txt"), "-i", str(tmp_path) + "/"],
+                       capture_output=True, text=True)
+    assert p.returncode == 254 and "Couldn't read point cloud file." in p.stderr  # -2, main.cpp:64-68
+    p = subprocess.run([exe, "--enableMLS", "maybe", "-p", "a", "-o", "b", "-i", "c"], capture_output=True, text=True)
+    assert p.returncode == 254
+
+
+def _write_pcd_binary(path, x, y, z, inten):
+    n = len(x)
+    hdr = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\n"
+           f"TYPE F F F F\nCOUNT 1 1 1 1\nWIDTH {n}\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS {n}\nDATA binary\n")
+    with open(path, "wb") as f:
+        f.write(hdr.encode())
+        f.write(np.stack([x, y, z, inten], 1).astype(np.float32).tobytes())
+
+
+def _read_pcd_ascii(path):
+    with open(path) as f:
+        lines = f.read().split("\n")
+    k = next(i for i, l in enumerate(lines) if l.startswith("DATA"))
+    header = {l.split()[0]: l.split()[1:] for l in lines[:k + 1] if l and not l.startswith("#")}
+    rows = [l.split() for l in lines[k + 1:] if l]
+    return header, rows
+
+
+def test_pcd_writer_format_roundtrip_cpu(tmp_path):
+    """The ASCII writer is exercised on the CPU through the crop step of a run that then
+    fails for lack of a GPU: scans-crop.pcd must still be written in PCL's layout."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("covered by the end-to-end gpu test")
+    from pointcloudprocessor_amd import synth
+
+    x, y, z, inten = synth.make_cloud(500, seed=2)
+    _write_pcd_binary(tmp_path / "scans.pcd", x, y, z, inten)
+    poses, ts = synth.make_trajectory(3)
+    with open(tmp_path / "odo.txt", "w") as f:
+        for t, p in zip(ts, poses):
+            f.write("%.6f %.6f %.6f %.6f %.8f %.8f %.8f %.8f\n" % (t, *p))
+            with open(tmp_path / ("%f.ppm" % t), "wb") as g:
+                g.write(b"P6\n4 2\n255\n" + bytes(24))
+    out = str(tmp_path) + "/"
+    p = subprocess.run([_exe(), "-p", str(tmp_path / "scans.pcd"), "-o", str(tmp_path / "odo.txt"), "-i", out, "-t", out],
+                       capture_output=True, text=True)
+    assert p.returncode == 254 and "no CPU fallback" in p.stderr
+    header, rows = _read_pcd_ascii(tmp_path / "scans-crop.pcd")
+    assert header["FIELDS"] == ["x", "y", "z", "intensity"] and header["TYPE"] == ["F", "F", "F", "F"]
+    assert header["DATA"] == ["ascii"] and int(header["POINTS"][0]) == len(rows) > 0
+    got = np.array(rows, dtype=np.float64)
+    lo = poses[:, :3].min(0) - 2.0
+    hi = np.maximum(poses[:, :3].max(0), 2.2250738585072014e-308) + 2.0
+    sel = np.all((np.stack([x, y, z], 1) >= lo.astype(np.float32)) & (np.stack([x, y, z], 1) <= hi.astype(np.float32)), axis=1)
+    assert len(rows) == sel.sum()
+    ref = np.stack([x, y, z, inten], 1)[sel]
+    assert np.allclose(got, ref, rtol=6e-8, atol=0)  # 8 significant digits
+    assert rows[0][0] == "%.8g" % x[sel][0]
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end_matches_oracle(tmp_path, oracle):
+    from pointcloudprocessor_amd import synth
+
+    W, H = 1024, 750
+    x, y, z, inten = synth.make_cloud(60000, seed=9)
+    _write_pcd_binary(tmp_path / "scans.pcd", x, y, z, inten)
+    poses, ts = synth.make_trajectory(10, spacing=0.06)  # every second pose is a keyframe (0.1 m rule)
+    imgs, masks = {}, {}
+    with open(tmp_path / "odo.txt", "w") as f:
+        for k, (t, p) in enumerate(zip(ts, poses)):
+            f.write("%.6f %.6f %.6f %.6f %.8f %.8f %.8f %.8f\n" % (t, *p))
+            if k == 3:
+                continue  # no image for this pose: the frame is skipped (PointCloudProcessor.cpp:984-987)
+            img = synth.make_image(k, W, H)  # BGR
+            imgs[k] = img
+            with open(tmp_path / ("%f.ppm" % t), "wb") as g:
+                g.write(b"P6\n%d %d\n255\n" % (W, H) + img[:, :, ::-1].tobytes())  # PPM is RGB
+            m = synth.make_mask(k, W, H)
+            masks[k] = m
+            with open(tmp_path / ("%f.pgm" % t), "wb") as g:
+                g.write(b"P5\n%d %d\n255\n" % (W, H) + m.tobytes())
+        f.write("garbage line stops the parser\n")
+        f.write("%.6f 0 0 0 1 0 0 0\n" % (ts[-1] + 1))
+    out = str(tmp_path) + "/"
+    p = subprocess.run([_exe(), "-p", str(tmp_path / "scans.pcd"), "-o", str(tmp_path / "odo.txt"), "-i", out, "-m", out,
+                        "-t", out], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "Processing completed successfully." in p.stdout
+    # keyframes the reference would select
+    usable = [k for k in range(len(poses)) if k != 3]
+    keys = [usable[0]]
+    for k in usable[1:]:
+        if np.linalg.norm(poses[k, :3] - poses[keys[-1], :3]) >= 0.1:
+            keys.append(k)
+    assert 3 <= len(keys) < len(usable)
+    cam = oracle.default_camera()
+    cam.image_width, cam.image_height = W, H  # cull size stays 4096x3000
+    cp = oracle.default_cull_params()
+    kposes = poses[keys]
+    ref = oracle.colorize(cam, cp, x, y, z, kposes, [imgs[k] for k in keys], threads=8)
+    header, rows = _read_pcd_ascii(tmp_path / "cloudInWorldWithRGB.pcd")
+    assert header["FIELDS"] == ["x", "y", "z", "rgb"] and header["TYPE"] == ["F", "F", "F", "U"]
+    sel = np.nonzero(ref["has"])[0]
+    assert len(rows) == len(sel) > 100
+    got_xyz = np.array([[float(v) for v in r[:3]] for r in rows])
+    got_rgb = np.array([int(r[3]) for r in rows], dtype=np.uint64)
+    assert np.allclose(got_xyz, np.stack([x, y, z], 1)[sel], rtol=6e-8)
+    packed = (0xFF000000 | (ref["rgb"][sel, 0].astype(np.uint64) << 16) | (ref["rgb"][sel, 1].astype(np.uint64) << 8)
+              | ref["rgb"][sel, 2].astype(np.uint64))
+    assert np.array_equal(got_rgb, packed)
+    # per-keyframe dumps
+    for q, k in enumerate(keys):
+        w2c, _ = oracle.pose_to_matrices(poses[k])
+        keep, _, kept = oracle.cull_frame(cam, cp, w2c, x, y, z, 8)
+        h2, r2 = _read_pcd_ascii(tmp_path / "filtered_pcd" / ("%f_beforeNID.pcd" % ts[k]))
+        assert h2["FIELDS"] == ["x", "y", "z", "intensity"] and len(r2) == kept
+        vis = oracle.frame_visible(cam, cp, poses[k], x, y, z, imgs[k], masks[k])
+        h3, r3 = _read_pcd_ascii(tmp_path / "filtered_pcd" / ("%f_rgb-mask.pcd" % ts[k]))
+        assert h3["FIELDS"] == ["x", "y", "z", "rgb", "segmentMask"] and len(r3) == len(vis["index"])
+        if len(r3):
+            assert np.array_equal(np.array([int(r[4]) for r in r3]), vis["mask"])
+    h4, r4 = _read_pcd_ascii(tmp_path / "cloudInWorldWithRGBandMask.pcd")
+    total = sum(len(oracle.frame_visible(cam, cp, poses[k], x, y, z, imgs[k], masks[k])["index"]) for k in keys)
+    assert len(r4) == total
+    assert (tmp_path / "scans-crop.pcd").exists()
