@@ -94,11 +94,15 @@ def main():
     t_setup = time.time() - t_setup
 
     col = pipeline.PointCloudColorizer(eng, rank, world)
-    pinned = torch.empty(N, dtype=torch.int32).pin_memory()
+    # two pinned landing buffers: the device-to-host copy of step i (copy stream) overlaps the
+    # kernels of step i + 1; every step's colours are on the host when the timed region ends
+    pinned = [torch.empty(N, dtype=torch.int32).pin_memory() for _ in range(2)]
+    step_no = [0]
 
     def step():
         col.run(download=False)
-        eng.ctx.download_result_packed(out_ptr=pinned.data_ptr())
+        eng.ctx.download_result_packed_async(pinned[step_no[0] & 1].data_ptr())
+        step_no[0] += 1
 
     def fence():
         eng.ctx.synchronize()
@@ -124,7 +128,7 @@ def main():
 
     result = None
     if rank == 0:
-        coloured = int(((pinned.numpy().view(np.uint32) >> 24) & 1).sum())
+        coloured = int(((pinned[(step_no[0] - 1) & 1].numpy().view(np.uint32) >> 24) & 1).sum())
         # ---- per-kernel times of one more step (hipEvents on the launch stream) ----
         eng.ctx.timing_enable(True)
         eng.ctx.timing_reset()

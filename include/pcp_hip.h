@@ -181,6 +181,10 @@ int pcp_colorize(pcp_context *ctx, uint8_t *out_rgb, uint8_t *out_has);
 int pcp_colorize_from_depth(pcp_context *ctx, uint8_t *out_rgb, uint8_t *out_has);
 /* packed result r | g<<8 | b<<16 | has<<24, n words, one plain device-to-host copy */
 int pcp_download_result_packed(pcp_context *ctx, uint32_t *out_rgba);
+/* the same copy on the library's copy stream: returns at once, the result buffer is
+ * double-buffered so the next run's kernels overlap this transfer; out_rgba (pinned
+ * memory for a real overlap) is valid after pcp_synchronize(). */
+int pcp_download_result_packed_async(pcp_context *ctx, uint32_t *out_rgba);
 /* device address of the packed per-point result (r | g<<8 | b<<16 | has<<24),
  * valid after pcp_colour_finalise / pcp_colorize, for device-side gathers */
 int pcp_colour_result_device(pcp_context *ctx, void **device_ptr, int64_t *n_words);

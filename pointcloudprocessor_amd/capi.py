@@ -88,6 +88,13 @@ def load(build_if_needed: bool = True) -> C.CDLL:
                 raise
     if not os.path.exists(_build.LIB_PATH):
         raise PcpError(PCP_ERR_DEVICE, f"{_build.LIB_PATH} is missing: the HIP extension is not built")
+    # One HIP runtime per process: torch ships its own libamdhip64.so.7 and must initialise it
+    # before another copy of the same SONAME is mapped (otherwise torch later reports "No HIP
+    # GPUs are available").  Importing torch first makes libpcp_hip.so bind to torch's copy.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(_build.LIB_PATH)
     L.pcp_last_error.restype = C.c_char_p
     L.pcp_last_error.argtypes = [C.c_void_p]
@@ -331,6 +338,10 @@ class Context:
             out = np.empty(self.n, np.uint32)
         self._check(self.lib.pcp_download_result_packed(self.h, _ptr(out)))
         return out
+
+    def download_result_packed_async(self, out_ptr: int):
+        """Enqueue the device-to-host copy on the copy stream; valid after synchronize()."""
+        self._check(self.lib.pcp_download_result_packed_async(self.h, C.c_void_p(out_ptr)))
 
     def colour_result_device(self):
         p = C.c_void_p()

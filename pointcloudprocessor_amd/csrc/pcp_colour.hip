@@ -165,24 +165,39 @@ __device__ __forceinline__ bool tile_surely_rejected(const DevCamera &c, const D
          v.hi < static_cast<double>(c.v_lo) || v.lo > static_cast<double>(c.v_hi);
 }
 
-// one lane per (tile, 32-keyframe word)
-__global__ __launch_bounds__(kBlock) void k_tile_mask(const float4 *__restrict__ spheres, int64_t tiles, DevCamera cam,
+// one lane per (group of 16 tiles, 32-keyframe word): the group's sphere is tested first and
+// its 16 tiles only when the group survives (most groups are rejected as a whole)
+constexpr int kTileGroup = 16;
+
+__global__ __launch_bounds__(kBlock) void k_tile_mask(const float4 *__restrict__ spheres,
+                                                      const float4 *__restrict__ group_spheres, int64_t tiles,
+                                                      int64_t groups, DevCamera cam,
                                                       const DevFrame *__restrict__ frames, int32_t n_frames,
                                                       int32_t w0, int32_t w1, int32_t words,
                                                       uint32_t *__restrict__ tile_mask, int32_t cull_enabled) {
   const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const int32_t nw = w1 - w0;
-  const int64_t tile = g / nw;
-  if (tile >= tiles) return;
-  const int32_t w = w0 + static_cast<int32_t>(g - tile * nw);
-  const float4 sph = spheres[tile];
-  uint32_t word = 0u;
+  const int64_t group = g / nw;
+  if (group >= groups) return;
+  const int32_t w = w0 + static_cast<int32_t>(g - group * nw);
+  const float4 gs = group_spheres[group];
+  const int64_t t0 = group * kTileGroup;
+  const int32_t nt = static_cast<int32_t>(min<int64_t>(kTileGroup, tiles - t0));
+  uint32_t word[kTileGroup];
+#pragma unroll
+  for (int k = 0; k < kTileGroup; ++k) word[k] = 0u;
   for (int32_t b = 0; b < 32; ++b) {
     const int32_t f = (w << 5) + b;
     if (f >= n_frames) break;
-    if (!(cull_enabled && tile_surely_rejected(cam, frames[f], sph))) word |= 1u << b;
+    const DevFrame &fr = frames[f];
+    if (cull_enabled && tile_surely_rejected(cam, fr, gs)) continue;
+#pragma unroll
+    for (int k = 0; k < kTileGroup; ++k)
+      if (k < nt && !(cull_enabled && tile_surely_rejected(cam, fr, spheres[t0 + k]))) word[k] |= 1u << b;
   }
-  tile_mask[tile * words + w] = word;
+#pragma unroll
+  for (int k = 0; k < kTileGroup; ++k)
+    if (k < nt) tile_mask[(t0 + k) * words + w] = word[k];
 }
 
 // ---------------------------------------------------------------------------
@@ -318,11 +333,18 @@ __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict_
       todo &= todo - 1u;
       const DevFrame &fr = frames[f];
       const Projected p = project_point(cam, fr.w2c, px, py, pz);
-      if (live && p.pixel >= 0 && keep_rule(cam, p, depth + static_cast<int64_t>(f) * cells)) {
+      const bool cand = live && p.pixel >= 0 && (cam.enable_zbuf ? p.cell >= 0 : p.cell != -1);
+      if (cand) {
+        // both gathers are issued before anything depends on them (one latency, not two)
+        const uint32_t dbits = cam.enable_zbuf ? depth[static_cast<int64_t>(f) * cells + p.cell] : 0u;
         // texel = B | G<<8 | R<<16 | mask<<24; its low 24 bits are 0x00RRGGBB (PointCloudProcessor.cpp:760-762)
         const uint32_t texel = images[static_cast<int64_t>(f) * image_px + p.pixel];
         const float s = final_score(p.xc, p.yc, p.zc, fr.px, fr.py, fr.pz);
-        t.insert(s, texel & 0xffffffu, f);
+        // A4 keep rule (view_culling.cpp:135-171)
+        bool keep = true;
+        if (cam.enable_zbuf)
+          keep = !(range64(p.xc, p.yc, p.zc) > static_cast<double>(__uint_as_float(dbits)) + cam.slack);
+        if (keep) t.insert(s, texel & 0xffffffu, f);
       }
     }
   }
@@ -579,7 +601,8 @@ static int ensure_state(pcp_context *ctx) {
   PCP_HIP_TRY(ctx, ctx->top_frame.ensure(kTopM * sn + 4));
   PCP_HIP_TRY(ctx, ctx->view_count.ensure(sn + 4));
   PCP_HIP_TRY(ctx, ctx->rgba_sorted.ensure(sn + 4));
-  PCP_HIP_TRY(ctx, ctx->rgba.ensure(sn + 4));
+  PCP_HIP_TRY(ctx, ctx->rgba2[0].ensure(sn + 4));
+  PCP_HIP_TRY(ctx, ctx->rgba2[1].ensure(sn + 4));
   return PCP_OK;
 }
 
@@ -842,10 +865,13 @@ int pcp_depth_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
     }();
     {
       LaunchTimer t(ctx, PCP_K_TILE_MASK);
-      const int64_t items = ctx->n_tiles * (w1 - w0);
+      const int64_t groups = div_up(ctx->n_tiles, kTileGroup);
+      const int64_t items = groups * (w1 - w0);
       hipLaunchKernelGGL(k_tile_mask, dim3(blocks_for(items)), dim3(kBlock), 0, ctx->stream,
-                         reinterpret_cast<const float4 *>(ctx->tile_sphere.p), ctx->n_tiles, ctx->dcam, ctx->frames.p,
-                         ctx->n_frames, w0, w1, ctx->mask_words, ctx->tile_mask.p, cull_tiles ? 1 : 0);
+                         reinterpret_cast<const float4 *>(ctx->tile_sphere.p),
+                         reinterpret_cast<const float4 *>(ctx->tile_sphere.p + 4 * ctx->n_tiles), ctx->n_tiles, groups,
+                         ctx->dcam, ctx->frames.p, ctx->n_frames, w0, w1, ctx->mask_words, ctx->tile_mask.p,
+                         cull_tiles ? 1 : 0);
       PCP_HIP_TRY(ctx, hipGetLastError());
     }
     {
@@ -932,16 +958,25 @@ int pcp_colour_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
 
 static int publish_result(pcp_context *ctx, uint8_t *out_rgb, uint8_t *out_has) {
   const int64_t n = ctx->n;
+  // next result buffer; if an asynchronous download still reads it, the kernels wait for that copy only
+  const int32_t cur = ctx->rgba_cur ^ 1;
+  if (ctx->copy_pending[cur]) {
+    PCP_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->copy_done[cur], 0));
+    ctx->copy_pending[cur] = false;
+  }
+  uint32_t *dst = ctx->rgba2[cur].p;
   if (n > 0) {
     LaunchTimer t(ctx, PCP_K_MISC);
     hipLaunchKernelGGL(k_scatter_u32, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, ctx->rgba_sorted.p, ctx->perm.p,
-                       n, ctx->rgba.p);
+                       n, dst);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
+  PCP_HIP_TRY(ctx, hipEventRecord(ctx->result_ready[cur], ctx->stream));
+  ctx->rgba_cur = cur;
   ctx->colour_result_live = true;
   if ((out_rgb || out_has) && n > 0) {
     std::vector<uint32_t> h(static_cast<size_t>(n));
-    PCP_HIP_TRY(ctx, hipMemcpyAsync(h.data(), ctx->rgba.p, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(h.data(), dst, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost, ctx->stream));
     PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int64_t i = 0; i < n; ++i) {
       const uint32_t v = h[static_cast<size_t>(i)];
@@ -1025,8 +1060,24 @@ int pcp_download_result_packed(pcp_context *ctx, uint32_t *out_rgba) {
     return set_error(ctx, PCP_ERR_STATE, "pcp_download_result_packed: no result (call pcp_colorize / pcp_colour_finalise)");
   if (!out_rgba && ctx->n > 0) return set_error(ctx, PCP_ERR_INVALID, "pcp_download_result_packed: NULL output");
   if (ctx->n > 0)
-    PCP_HIP_TRY(ctx, hipMemcpyAsync(out_rgba, ctx->rgba.p, static_cast<size_t>(ctx->n) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(out_rgba, ctx->rgba2[ctx->rgba_cur].p, static_cast<size_t>(ctx->n) * 4,
+                                    hipMemcpyDeviceToHost, ctx->stream));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PCP_OK;
+}
+
+int pcp_download_result_packed_async(pcp_context *ctx, uint32_t *out_rgba) {
+  if (!ctx) return PCP_ERR_INVALID;
+  if (!ctx->colour_result_live)
+    return set_error(ctx, PCP_ERR_STATE, "pcp_download_result_packed_async: no result (call pcp_colorize / pcp_colour_finalise)");
+  if (!out_rgba && ctx->n > 0) return set_error(ctx, PCP_ERR_INVALID, "pcp_download_result_packed_async: NULL output");
+  const int32_t cur = ctx->rgba_cur;
+  PCP_HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->result_ready[cur], 0));
+  if (ctx->n > 0)
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(out_rgba, ctx->rgba2[cur].p, static_cast<size_t>(ctx->n) * 4, hipMemcpyDeviceToHost,
+                                    ctx->copy_stream));
+  PCP_HIP_TRY(ctx, hipEventRecord(ctx->copy_done[cur], ctx->copy_stream));
+  ctx->copy_pending[cur] = true;
   return PCP_OK;
 }
 
@@ -1047,7 +1098,7 @@ int pcp_colour_result_device(pcp_context *ctx, void **device_ptr, int64_t *n_wor
   if (!ctx) return PCP_ERR_INVALID;
   if (!ctx->colour_result_live)
     return set_error(ctx, PCP_ERR_STATE, "pcp_colour_result_device: no result (call pcp_colorize / pcp_colour_finalise)");
-  if (device_ptr) *device_ptr = ctx->rgba.p;
+  if (device_ptr) *device_ptr = ctx->rgba2[ctx->rgba_cur].p;
   if (n_words) *n_words = ctx->n;
   return PCP_OK;
 }

@@ -255,9 +255,38 @@ static int store_cloud(pcp_context *ctx, const float *x, const float *y, const f
     // rounded up: the radius must dominate every member's distance to the fp32 centre
     spheres[static_cast<size_t>(t) * 4 + 3] = std::nextafter(static_cast<float>(std::sqrt(r2) * (1.0 + 1e-6)), FLT_MAX);
   }
+  // spheres of groups of 16 tiles (tested first by k_tile_mask), appended after the tile spheres
+  const int64_t groups = (tiles + 15) / 16;
+  spheres.resize(static_cast<size_t>(tiles + groups) * 4);
+  for (int64_t gi = 0; gi < groups; ++gi) {
+    const int64_t b = gi * 1024, e = std::min<int64_t>(n, b + 1024);
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int64_t j = b; j < e; ++j)
+      for (int a = 0; a < 3; ++a) {
+        const double v = sorted[static_cast<size_t>(a) * plane + static_cast<size_t>(j)];
+        lo[a] = std::min(lo[a], v);
+        hi[a] = std::max(hi[a], v);
+      }
+    float c[3];
+    for (int a = 0; a < 3; ++a) c[a] = static_cast<float>(0.5 * (lo[a] + hi[a]));
+    double r2 = 0.0;
+    for (int64_t j = b; j < e; ++j) {
+      double d2 = 0.0;
+      for (int a = 0; a < 3; ++a) {
+        const double d = static_cast<double>(sorted[static_cast<size_t>(a) * plane + static_cast<size_t>(j)]) - static_cast<double>(c[a]);
+        d2 += d * d;
+      }
+      r2 = std::max(r2, d2);
+    }
+    float *o = &spheres[static_cast<size_t>(tiles + gi) * 4];
+    o[0] = c[0];
+    o[1] = c[1];
+    o[2] = c[2];
+    o[3] = std::nextafter(static_cast<float>(std::sqrt(r2) * (1.0 + 1e-6)), FLT_MAX);
+  }
   ctx->n_tiles = tiles;
-  PCP_HIP_TRY(ctx, ctx->tile_sphere.ensure(static_cast<size_t>(tiles) * 4 + 4));
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->tile_sphere.p, spheres.data(), static_cast<size_t>(tiles) * 16, hipMemcpyHostToDevice, ctx->stream));
+  PCP_HIP_TRY(ctx, ctx->tile_sphere.ensure(static_cast<size_t>(tiles + groups) * 4 + 4));
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->tile_sphere.p, spheres.data(), static_cast<size_t>(tiles + groups) * 16, hipMemcpyHostToDevice, ctx->stream));
   PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->sxyz.p, sorted.data(), 3 * plane * 4, hipMemcpyHostToDevice, ctx->stream));
   PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->perm.p, perm.data(), sn * 4, hipMemcpyHostToDevice, ctx->stream));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -307,6 +336,16 @@ int pcp_create(int32_t device, pcp_context **out) {
     return PCP_ERR_DEVICE;
   }
   ctx->stream = ctx->own_stream;
+  e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+  for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+    e = hipEventCreateWithFlags(&ctx->result_ready[k], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->copy_done[k], hipEventDisableTiming);
+  }
+  if (e != hipSuccess) {
+    set_global_error("pcp_create: copy stream / events: %s", hipGetErrorString(e));
+    pcp_destroy(ctx);
+    return PCP_ERR_DEVICE;
+  }
   pcp_default_camera(&ctx->camera);
   pcp_default_cull_params(&ctx->cull);
   *out = ctx;
@@ -317,6 +356,7 @@ void pcp_destroy(pcp_context *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
   drain_timing(ctx);
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   ctx->xyz.release();
@@ -332,7 +372,13 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->top_frame.release();
   ctx->view_count.release();
   ctx->rgba_sorted.release();
-  ctx->rgba.release();
+  ctx->rgba2[0].release();
+  ctx->rgba2[1].release();
+  for (int k = 0; k < 2; ++k) {
+    if (ctx->result_ready[k]) (void)hipEventDestroy(ctx->result_ready[k]);
+    if (ctx->copy_done[k]) (void)hipEventDestroy(ctx->copy_done[k]);
+  }
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   ctx->s_cell.release();
   ctx->s_pixel.release();
   ctx->s_range.release();
@@ -375,6 +421,8 @@ int pcp_set_stream(pcp_context *ctx, void *hip_stream) {
 int pcp_synchronize(pcp_context *ctx) {
   if (!ctx) return PCP_ERR_INVALID;
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+  ctx->copy_pending[0] = ctx->copy_pending[1] = false;
   return PCP_OK;
 }
 

@@ -131,7 +131,14 @@ struct pcp_context {
   pcp::DevBuf<uint32_t> top_rgb;    // 5*n
   pcp::DevBuf<int32_t> top_frame;   // 5*n
   pcp::DevBuf<int32_t> view_count;  // n
-  pcp::DevBuf<uint32_t> rgba_sorted, rgba;  // n
+  pcp::DevBuf<uint32_t> rgba_sorted;  // n, Morton order
+  // packed results in input order, double-buffered so that the device-to-host copy of one
+  // run (copy stream) overlaps the kernels of the next
+  pcp::DevBuf<uint32_t> rgba2[2];
+  int32_t rgba_cur = 0;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t result_ready[2] = {nullptr, nullptr}, copy_done[2] = {nullptr, nullptr};
+  bool copy_pending[2] = {false, false};
   bool colour_state_live = false;
   bool colour_result_live = false;
 
