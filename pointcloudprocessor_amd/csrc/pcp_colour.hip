@@ -165,39 +165,34 @@ __device__ __forceinline__ bool tile_surely_rejected(const DevCamera &c, const D
          v.hi < static_cast<double>(c.v_lo) || v.lo > static_cast<double>(c.v_hi);
 }
 
-// one lane per (group of 16 tiles, 32-keyframe word): the group's sphere is tested first and
-// its 16 tiles only when the group survives (most groups are rejected as a whole)
+// Two launches: first the spheres of groups of 16 tiles (one lane per (group, 32-keyframe
+// word)), then the tiles (one lane per (tile, word)), which only test keyframes their group
+// survived -- most groups are rejected as a whole, and a wavefront of the second launch
+// covers just 4 groups, so it skips most keyframes altogether.
 constexpr int kTileGroup = 16;
 
-__global__ __launch_bounds__(kBlock) void k_tile_mask(const float4 *__restrict__ spheres,
-                                                      const float4 *__restrict__ group_spheres, int64_t tiles,
-                                                      int64_t groups, DevCamera cam,
+__global__ __launch_bounds__(kBlock) void k_tile_mask(const float4 *__restrict__ spheres, int64_t tiles, DevCamera cam,
                                                       const DevFrame *__restrict__ frames, int32_t n_frames,
                                                       int32_t w0, int32_t w1, int32_t words,
+                                                      const uint32_t *__restrict__ parent_mask, int32_t parent_shift,
                                                       uint32_t *__restrict__ tile_mask, int32_t cull_enabled) {
   const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const int32_t nw = w1 - w0;
-  const int64_t group = g / nw;
-  if (group >= groups) return;
-  const int32_t w = w0 + static_cast<int32_t>(g - group * nw);
-  const float4 gs = group_spheres[group];
-  const int64_t t0 = group * kTileGroup;
-  const int32_t nt = static_cast<int32_t>(min<int64_t>(kTileGroup, tiles - t0));
-  uint32_t word[kTileGroup];
-#pragma unroll
-  for (int k = 0; k < kTileGroup; ++k) word[k] = 0u;
-  for (int32_t b = 0; b < 32; ++b) {
+  const int64_t tile = g / nw;
+  if (tile >= tiles) return;
+  const int32_t w = w0 + static_cast<int32_t>(g - tile * nw);
+  const float4 sph = spheres[tile];
+  uint32_t todo = 0xffffffffu;
+  if (parent_mask) todo = parent_mask[(tile >> parent_shift) * words + w];
+  uint32_t word = 0u;
+  while (todo) {
+    const int32_t b = __builtin_ctz(todo);
+    todo &= todo - 1u;
     const int32_t f = (w << 5) + b;
     if (f >= n_frames) break;
-    const DevFrame &fr = frames[f];
-    if (cull_enabled && tile_surely_rejected(cam, fr, gs)) continue;
-#pragma unroll
-    for (int k = 0; k < kTileGroup; ++k)
-      if (k < nt && !(cull_enabled && tile_surely_rejected(cam, fr, spheres[t0 + k]))) word[k] |= 1u << b;
+    if (!(cull_enabled && tile_surely_rejected(cam, frames[f], sph))) word |= 1u << b;
   }
-#pragma unroll
-  for (int k = 0; k < kTileGroup; ++k)
-    if (k < nt) tile_mask[(t0 + k) * words + w] = word[k];
+  tile_mask[tile * words + w] = word;
 }
 
 // ---------------------------------------------------------------------------
@@ -866,12 +861,15 @@ int pcp_depth_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
     {
       LaunchTimer t(ctx, PCP_K_TILE_MASK);
       const int64_t groups = div_up(ctx->n_tiles, kTileGroup);
-      const int64_t items = groups * (w1 - w0);
-      hipLaunchKernelGGL(k_tile_mask, dim3(blocks_for(items)), dim3(kBlock), 0, ctx->stream,
-                         reinterpret_cast<const float4 *>(ctx->tile_sphere.p),
-                         reinterpret_cast<const float4 *>(ctx->tile_sphere.p + 4 * ctx->n_tiles), ctx->n_tiles, groups,
-                         ctx->dcam, ctx->frames.p, ctx->n_frames, w0, w1, ctx->mask_words, ctx->tile_mask.p,
+      const float4 *tile_sph = reinterpret_cast<const float4 *>(ctx->tile_sphere.p);
+      PCP_HIP_TRY(ctx, ctx->group_mask.ensure(static_cast<size_t>(groups) * ctx->mask_words + 4));
+      hipLaunchKernelGGL(k_tile_mask, dim3(blocks_for(groups * (w1 - w0))), dim3(kBlock), 0, ctx->stream,
+                         tile_sph + ctx->n_tiles, groups, ctx->dcam, ctx->frames.p, ctx->n_frames, w0, w1,
+                         ctx->mask_words, static_cast<const uint32_t *>(nullptr), 0, ctx->group_mask.p,
                          cull_tiles ? 1 : 0);
+      hipLaunchKernelGGL(k_tile_mask, dim3(blocks_for(ctx->n_tiles * (w1 - w0))), dim3(kBlock), 0, ctx->stream, tile_sph,
+                         ctx->n_tiles, ctx->dcam, ctx->frames.p, ctx->n_frames, w0, w1, ctx->mask_words,
+                         ctx->group_mask.p, 4, ctx->tile_mask.p, cull_tiles ? 1 : 0);
       PCP_HIP_TRY(ctx, hipGetLastError());
     }
     {

@@ -367,6 +367,7 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->depth.release();
   ctx->tile_sphere.release();
   ctx->tile_mask.release();
+  ctx->group_mask.release();
   ctx->top_score.release();
   ctx->top_rgb.release();
   ctx->top_frame.release();

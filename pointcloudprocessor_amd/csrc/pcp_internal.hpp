@@ -123,7 +123,7 @@ struct pcp_context {
   // (x, y, z, radius) and the tile x keyframe visibility masks [tile][mask_words]
   int64_t n_tiles = 0;
   pcp::DevBuf<float> tile_sphere;
-  pcp::DevBuf<uint32_t> tile_mask;
+  pcp::DevBuf<uint32_t> tile_mask, group_mask;
   int32_t mask_words = 0;
 
   // per-point colour state (sorted order) and packed results
