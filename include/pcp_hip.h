@@ -194,6 +194,10 @@ int pcp_colour_result_device(pcp_context *ctx, void **device_ptr, int64_t *n_wor
  * SIMPLE projection; upsampling NONE or VOXEL_GRID_DILATION).  Results stay on
  * the device; *out_count = number of output points. */
 int pcp_mls_process(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_count);
+/* Multi-GPU form: the whole cloud is uploaded on every rank and this rank fits
+ * only the queries index_begin <= i < index_end (upsampling NONE).  Outputs as pcp_mls_process. */
+int pcp_mls_process_shard(pcp_context *ctx, const pcp_mls_params *p, int64_t index_begin, int64_t index_end,
+                          int64_t *out_count);
 /* xyz / normal 3*m floats AoS, curvature m, source index m (input order for
  * NONE; ascending voxel key for VOXEL_GRID_DILATION). */
 int pcp_mls_fetch(pcp_context *ctx, int64_t capacity, float *out_xyz, float *out_normal, float *out_curvature,

@@ -355,6 +355,12 @@ class Context:
         self._check(self.lib.pcp_mls_process(self.h, C.byref(params), C.byref(cnt)))
         return cnt.value
 
+    def mls_process_shard(self, params: MLSParams, index_begin: int, index_end: int) -> int:
+        cnt = C.c_int64()
+        self._check(self.lib.pcp_mls_process_shard(self.h, C.byref(params), C.c_int64(index_begin), C.c_int64(index_end),
+                                                   C.byref(cnt)))
+        return cnt.value
+
     def cloud_smooth(self, params: MLSParams) -> int:
         cnt = C.c_int64()
         self._check(self.lib.pcp_cloud_smooth(self.h, C.byref(params), C.byref(cnt)))

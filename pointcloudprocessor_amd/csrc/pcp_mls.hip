@@ -170,6 +170,7 @@ struct MlsArgs {
   float *tmp;                    // 7 floats per input point
   uint8_t *flag;                 // per input point
   double *state;                 // kMlsState doubles per input point (nullable)
+  int32_t q_begin, q_end;        // only queries with q_begin <= input index < q_end are fitted (query sharding)
 };
 
 __device__ __forceinline__ float sqdist_f32(float ax, float ay, float az, float bx, float by, float bz) {
@@ -181,6 +182,10 @@ __global__ __launch_bounds__(kMB) void k_mls_fit(MlsArgs a) {
   const int64_t j = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
   if (j >= a.n) return;
   const int32_t i = a.order[j];
+  if (i < a.q_begin || i >= a.q_end) {  // another shard's query
+    a.flag[i] = 0;
+    return;
+  }
   const float qx = a.sx[j], qy = a.sy[j], qz = a.sz[j];
   int32_t cx, cy, cz;
   grid_coords(a.g, qx, qy, qz, cx, cy, cz);
@@ -955,7 +960,8 @@ static int check_mls_params(pcp_context *ctx, const pcp_mls_params *p) {
 }
 
 // MovingLeastSquares::process on a cloud view; results in ctx->mls_* (index = view index)
-static int mls_run(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *p, int64_t *out_count) {
+static int mls_run(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *p, int64_t *out_count,
+                   int64_t q_begin = 0, int64_t q_end = -1) {
   const int64_t n = cv.n;
   ctx->mls_count = 0;
   if (out_count) *out_count = 0;
@@ -983,6 +989,8 @@ static int mls_run(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *
   a.tmp = ctx->m_tmp.p;
   a.flag = ctx->m_flag.p;
   a.state = nullptr;
+  a.q_begin = static_cast<int32_t>(q_begin);
+  a.q_end = static_cast<int32_t>(q_end < 0 ? n : q_end);
   if (p->upsampling == 3) {
     PCP_HIP_TRY(ctx, ctx->m_state.ensure(static_cast<size_t>(kMlsState) * sn + 8));
     // points skipped by the fit (< 3 neighbours) must read as "invalid" later
@@ -1120,6 +1128,21 @@ int pcp_mls_process(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_coun
   if (!ctx->xyz.p) return set_error(ctx, PCP_ERR_STATE, "pcp_mls_process: no cloud uploaded");
   PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
   return mls_run(ctx, uploaded_view(ctx), p, out_count);
+}
+
+int pcp_mls_process_shard(pcp_context *ctx, const pcp_mls_params *p, int64_t index_begin, int64_t index_end,
+                          int64_t *out_count) {
+  if (!ctx) return PCP_ERR_INVALID;
+  int rc = check_mls_params(ctx, p);
+  if (rc != PCP_OK) return rc;
+  if (!ctx->xyz.p) return set_error(ctx, PCP_ERR_STATE, "pcp_mls_process_shard: no cloud uploaded");
+  if (p->upsampling != 0)
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_mls_process_shard: query sharding supports upsampling NONE only");
+  if (index_begin < 0 || index_end > ctx->n || index_begin > index_end)
+    return set_error(ctx, PCP_ERR_RANGE, "pcp_mls_process_shard: query range [%lld,%lld) outside 0..%lld",
+                     (long long)index_begin, (long long)index_end, (long long)ctx->n);
+  PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return mls_run(ctx, uploaded_view(ctx), p, out_count, index_begin, index_end);
 }
 
 int pcp_mls_fetch(pcp_context *ctx, int64_t capacity, float *out_xyz, float *out_normal, float *out_curvature,

@@ -146,6 +146,38 @@ class CloudSmooth:
         self.engine = engine
         self.params = params if params is not None else capi.default_mls_params()
 
+    def process_sharded(self, n_total: int, rank: int, world: int, group=None):
+        """MLS (upsampling NONE) with the queries sharded by index over `world` ranks: every rank
+        holds the whole cloud, fits its own index range, and the variable-length results are
+        all-gathered.  Returns the full result on every rank."""
+        lo, hi = shard_bounds(n_total, rank, world)
+        ctx = self.engine.ctx
+        local = ctx.mls_fetch(ctx.mls_process_shard(self.params, lo, hi))
+        if world == 1:
+            return local
+        import torch
+        import torch.distributed as dist
+
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        m = torch.tensor([len(local["index"])], dtype=torch.int64, device=dev)
+        counts = [torch.zeros_like(m) for _ in range(world)]
+        dist.all_gather(counts, m, group=group)
+        counts = [int(c.item()) for c in counts]
+        cap = max(max(counts), 1)
+        packed = np.zeros((cap, 8), np.float32)  # xyz(3) normal(3) curvature index(as int bits)
+        k = len(local["index"])
+        packed[:k, 0:3] = local["xyz"]
+        packed[:k, 3:6] = local["normal"]
+        packed[:k, 6] = local["curvature"]
+        packed[:k, 7] = local["index"].view(np.float32)
+        mine = torch.from_numpy(packed).to(dev)
+        outs = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(outs, mine, group=group)
+        parts = [outs[r].cpu().numpy()[: counts[r]] for r in range(world)]
+        allp = np.concatenate(parts, axis=0) if parts else np.zeros((0, 8), np.float32)
+        return dict(xyz=np.ascontiguousarray(allp[:, 0:3]), normal=np.ascontiguousarray(allp[:, 3:6]),
+                    curvature=np.ascontiguousarray(allp[:, 6]), index=np.ascontiguousarray(allp[:, 7]).view(np.int32))
+
     def process(self, with_outlier_removal: bool = True):
         """SOR -> MLS (+ upsampling) -> SOR as cloudSmooth.cpp:109-164; MLS alone when asked."""
         ctx = self.engine.ctx

@@ -231,3 +231,25 @@ def test_cloud_smooth_chain_matches_oracle(gpu_ctx_factory, oracle, upsampling):
     assert np.array_equal(got["index"], ref_index)
     assert np.abs(got["xyz"].astype(np.float64) - r["xyz"][k2]).max() <= 1e-4 * R
     np.testing.assert_allclose(got["curvature"], r["curvature"][k2], rtol=1e-4, atol=1e-9)
+
+
+def test_mls_query_shards_concatenate_to_the_full_result(gpu_ctx_factory):
+    """Multi-GPU form: every rank fits its own query index range on the full cloud; the
+    concatenation of the shards is the unsharded result, bit for bit."""
+    from pointcloudprocessor_amd import capi, pipeline
+
+    x, y, z = _patches(seed=11, n=3000)
+    ctx = gpu_ctx_factory()
+    ctx.upload_cloud(x, y, z)
+    mp = capi.default_mls_params()
+    mp.upsampling = 0
+    full = ctx.mls_fetch(ctx.mls_process(mp))
+    parts = []
+    for r in range(3):
+        lo, hi = pipeline.shard_bounds(len(x), r, 3)
+        parts.append(ctx.mls_fetch(ctx.mls_process_shard(mp, lo, hi)))
+        assert np.all((parts[-1]["index"] >= lo) & (parts[-1]["index"] < hi))
+    for k in ("index", "xyz", "normal", "curvature"):
+        assert np.array_equal(np.concatenate([p[k] for p in parts]), full[k]), k
+    with pytest.raises(capi.PcpError):
+        ctx.mls_process_shard(mp, 10, 5)

@@ -72,6 +72,64 @@ class OracleEngine:
         return dict(rgb=rgb, has=(rgb != 0).any(axis=1).astype(np.uint8))
 
 
+class OracleMlsCtx:
+    """mls_process_shard / mls_fetch of capi.Context, computed with the C oracle."""
+
+    def __init__(self, x, y, z):
+        self.xyz = (x, y, z)
+        self.last = None
+
+    def mls_process_shard(self, params, lo, hi):
+        from oracle import oracle_capi as oc
+
+        op = oc.default_mls_params()
+        op.upsampling = 0
+        op.threads = 2
+        r = oc.mls(*self.xyz, op)
+        sel = (r["index"] >= lo) & (r["index"] < hi)
+        self.last = {k: v[sel] for k, v in r.items()}
+        return int(sel.sum())
+
+    def mls_fetch(self, m):
+        return self.last
+
+
+class OracleMlsEngine:
+    def __init__(self, x, y, z):
+        self.ctx = OracleMlsCtx(x, y, z)
+
+
+def _mls_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+
+    from pointcloudprocessor_amd import pipeline
+    from test_sharding_gloo import OracleMlsEngine, _mls_points
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x, y, z = _mls_points()
+    smooth = pipeline.CloudSmooth.__new__(pipeline.CloudSmooth)
+    smooth.engine = OracleMlsEngine(x, y, z)
+    smooth.params = None
+    full = smooth.process_sharded(len(x), rank, world)
+    np.savez(os.path.join(out_dir, f"mls{rank}.npz"), **full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _mls_points():
+    rng = np.random.default_rng(8)
+    a = rng.uniform(-0.1, 0.1, (1500, 2))
+    z = 0.5 * a[:, 0] ** 2 + rng.normal(0, 5e-4, 1500)
+    stray = rng.uniform(-3, 3, (7, 3))
+    pts = np.concatenate([np.stack([a[:, 0], a[:, 1], z], 1), stray]).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    return pts[:, 0].copy(), pts[:, 1].copy(), pts[:, 2].copy()
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -143,3 +201,23 @@ def test_two_rank_gloo_equals_single_process(tmp_path, oracle):
     for r in (r0, r1):
         assert np.array_equal(r["rgb"], ref["rgb"]) and np.array_equal(r["has"], ref["has"])
     assert ref["has"].sum() > 100
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_mls_query_sharding(tmp_path, oracle):
+    """MLS with queries sharded by index over 2 gloo ranks: the all-gathered result equals
+    the single-process result on every rank."""
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_mls_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    x, y, z = _mls_points()
+    op = oracle.default_mls_params()
+    op.upsampling = 0
+    op.threads = 2
+    ref = oracle.mls(x, y, z, op)
+    assert 0 < len(ref["index"]) < len(x)
+    for r in range(2):
+        got = np.load(tmp_path / f"mls{r}.npz")
+        for k in ("index", "xyz", "normal", "curvature"):
+            assert np.array_equal(got[k], ref[k]), (r, k)
