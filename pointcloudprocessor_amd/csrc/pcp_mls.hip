@@ -22,6 +22,11 @@
 #include "pcp_internal.hpp"
 #include "pcp_scan.hpp"
 
+// The MLS / SOR stage is tolerance-gated (1e-4 relative, Appendix A9), not bit-gated: FMA
+// contraction is allowed here.  The decisions that must be exact (neighbour membership,
+// voxel indices, voxel positions) use explicit __f*_rn intrinsics, which never contract.
+#pragma clang fp contract(fast)
+
 namespace pcp {
 
 constexpr int kMB = 256;
