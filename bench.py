@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-points", type=int, default=1_000_000)
     ap.add_argument("--cpu-frames", type=int, default=16)
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even at world size 1")
     return ap.parse_args()
 
 
@@ -70,7 +71,7 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
@@ -93,7 +94,8 @@ def main():
     eng.ctx.synchronize()
     t_setup = time.time() - t_setup
 
-    col = pipeline.PointCloudColorizer(eng, rank, world)
+    col = pipeline.PointCloudColorizer(eng, rank, world if not args.force_dist else max(world, 2))
+    col.rank = rank
     # two pinned landing buffers: the device-to-host copy of step i (copy stream) overlaps the
     # kernels of step i + 1; every step's colours are on the host when the timed region ends
     pinned = [torch.empty(N, dtype=torch.int32).pin_memory() for _ in range(2)]
@@ -227,9 +229,9 @@ def main():
                 "single_thread_value": round(cn1 * cf1 / t_cpu1 / 1e6, 3),
             }
         result = {
-            "metric": "Mpoints*frames/sec colorized",
+            "metric": "Mpoints\u00d7frames/sec colorized",
             "value": round(value, 1),
-            "unit": "Mpoints*frames/s",
+            "unit": "Mpoints\u00d7frames/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
