@@ -178,12 +178,33 @@ def main():
                     eng.upload_cloud(x[:nm], y[:nm], z[:nm])
                 eng.ctx.mls_process(mp)  # warm-up (allocations)
                 eng.ctx.synchronize()
+                eng.ctx.timing_enable(True)
+                eng.ctx.timing_reset()
                 t1 = time.perf_counter()
                 m = eng.ctx.mls_process(mp)
                 eng.ctx.synchronize()
                 t_mls = time.perf_counter() - t1
+                eng.ctx.timing_enable(False)
                 mls = {"value": round(nm / t_mls / 1e6, 2), "unit": "Mpoints/s", "points": nm, "outputs": int(m),
-                       "radius": 0.03, "order": 2, "upsampling": "NONE", "ms": round(t_mls * 1e3, 2)}
+                       "radius": 0.03, "order": 2, "upsampling": "NONE", "ms": round(t_mls * 1e3, 2),
+                       "kernels_ms": {eng.ctx.kernel_name(k): round(eng.ctx.timing_get(k)[0], 3)
+                                      for k in (capi.K_MLS_GRID, capi.K_MLS_FIT)}}
+                if not args.no_cpu:
+                    # CPU baseline of the MLS leg: the oracle (OpenMP) on a full-density slab of the same cloud
+                    from oracle import oracle_capi as oc
+
+                    slab = (x[:nm] > 0.0) & (x[:nm] < 3.0)
+                    sx_, sy_, sz_ = x[:nm][slab], y[:nm][slab], z[:nm][slab]
+                    op = oc.default_mls_params()
+                    op.upsampling = 0
+                    op.threads = oc.hardware_threads()
+                    t1 = time.perf_counter()
+                    r = oc.mls(sx_, sy_, sz_, op)
+                    t_cpu_mls = time.perf_counter() - t1
+                    mls["cpu_baseline"] = {"value": round(len(sx_) / t_cpu_mls / 1e6, 4), "unit": "Mpoints/s",
+                                           "cores": op.threads, "kind": "port",
+                                           "sample": f"slab 0 < x < 3 of the same cloud, {len(sx_)} points, "
+                                                     f"{t_cpu_mls:.1f} s, oracle/pcp_oracle_mls.c"}
             except capi.PcpError as e:  # reported, never hidden
                 mls = {"error": str(e)}
         # ---- CPU baseline: the oracle on a bounded sample, all host cores ----

@@ -530,9 +530,7 @@ int pcp_set_camera(pcp_context *ctx, const pcp_camera *cam, const pcp_cull_param
     d.v_hi = std::max(ch, static_cast<float>(d.img_h)) + 0.5f;
   }
   if (const char *e = std::getenv("PCP_DISABLE_PRETEST")) d.pretest = (e[0] == '1') ? 0 : 1;
-  d.exp_flags = 0;
-  d.pad2_ = 0;
-  if (const char *e = std::getenv("PCP_EXP")) d.exp_flags = std::atoi(e);
+
   ctx->have_camera = true;
   // images / depth maps are sized by the camera: drop them
   ctx->image_set.assign(ctx->image_set.size(), 0);

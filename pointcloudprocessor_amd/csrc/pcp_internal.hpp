@@ -36,8 +36,6 @@ struct DevCamera {
   float ak1, ak2, ak3, ap1, ap2;
   float afx, afy, acx, acy;
   float u_lo, u_hi, v_lo, v_hi;
-  int32_t exp_flags;  // PCP_EXP experiments (profiling only)
-  int32_t pad2_;
 };
 
 // One keyframe: w2c / c2w 3x4 row-major fp32 (A1), the pose translation used by

@@ -165,7 +165,8 @@ constexpr int kMlsState = 22;  // mean3 normal3 u3 v3 c6 curvature K valid(+fitt
 
 struct MlsArgs {
   const float *sx, *sy, *sz;     // cell-sorted coordinates
-  const int32_t *order;          // cell-sorted -> input index
+  const int32_t *order;          // cell-sorted -> view index
+  const int32_t *remap;          // view index -> caller's index (nullable)
   const int32_t *start;          // cell starts (ncell + 1)
   int64_t n;
   GridDesc g;
@@ -183,10 +184,22 @@ __device__ __forceinline__ float sqdist_f32(float ax, float ay, float az, float 
   return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
 
-__global__ __launch_bounds__(kMB) void k_mls_fit(MlsArgs a) {
-  const int64_t j = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+// neighbour list of one lane: up to kMaxNbr entries (run << 12 | offset in run) in LDS, column
+// layout [entry][lane].  With the candidates compacted first, both accumulation sweeps run with
+// every lane busy (in the plain double loop only the ~35 % of lanes whose current candidate is
+// inside the radius do fp64 work).  Lanes whose neighbourhood does not fit (K > kMaxNbr, a run
+// longer than 4096 points, or a grid with reach > 1) take the plain loops.
+constexpr int kMaxNbr = 96;
+constexpr int kMaxRun = 9;
+constexpr int kFitBlock = 128;  // 28.5 KB of LDS per workgroup: LDS does not cap the occupancy the VGPRs allow
+
+__global__ __launch_bounds__(kFitBlock) void k_mls_fit(MlsArgs a) {
+  __shared__ uint16_t nbr_code[kMaxNbr][kFitBlock];
+  __shared__ int32_t run_base[kMaxRun][kFitBlock];
+  const int tid = threadIdx.x;
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * kFitBlock + threadIdx.x;
   if (j >= a.n) return;
-  const int32_t i = a.order[j];
+  const int32_t i = a.remap ? a.remap[a.order[j]] : a.order[j];
   if (i < a.q_begin || i >= a.q_end) {  // another shard's query
     a.flag[i] = 0;
     return;
@@ -198,26 +211,71 @@ __global__ __launch_bounds__(kMB) void k_mls_fit(MlsArgs a) {
   const int32_t y0 = max(cy - a.g.reach, 0), y1 = min(cy + a.g.reach, a.g.ny - 1);
   const int32_t z0 = max(cz - a.g.reach, 0), z1 = min(cz + a.g.reach, a.g.nz - 1);
 
-  // sweep 1: neighbour count and moments of (p - q)
+  // sweep 0: radius test (fp32, exact FLANN form), neighbour count, compact list
   int32_t K = 0;
-  double s1x = 0, s1y = 0, s1z = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
-  for (int32_t zz = z0; zz <= z1; ++zz)
-    for (int32_t yy = y0; yy <= y1; ++yy) {
-      const int32_t row = (zz * a.g.ny + yy) * a.g.nx;
-      const int32_t b = a.start[row + x0], e = a.start[row + x1 + 1];
-      for (int32_t k = b; k < e; ++k) {
-        const float px = a.sx[k], py = a.sy[k], pz = a.sz[k];
-        if (sqdist_f32(px, py, pz, qx, qy, qz) < a.sq_radius) {
-          const double dx = static_cast<double>(px) - static_cast<double>(qx);
-          const double dy = static_cast<double>(py) - static_cast<double>(qy);
-          const double dz = static_cast<double>(pz) - static_cast<double>(qz);
-          ++K;
-          s1x += dx; s1y += dy; s1z += dz;
-          sxx += dx * dx; sxy += dx * dy; sxz += dx * dz;
-          syy += dy * dy; syz += dy * dz; szz += dz * dz;
+  bool fast = a.g.reach == 1;
+  {
+    int32_t r = 0;
+    for (int32_t zz = z0; zz <= z1; ++zz)
+      for (int32_t yy = y0; yy <= y1; ++yy) {
+        const int32_t row = (zz * a.g.ny + yy) * a.g.nx;
+        const int32_t b = a.start[row + x0], e = a.start[row + x1 + 1];
+        if (fast) {
+          run_base[r][tid] = b;
+          if (e - b > 4096) fast = false;
         }
+        for (int32_t k = b; k < e; ++k) {
+          if (sqdist_f32(a.sx[k], a.sy[k], a.sz[k], qx, qy, qz) < a.sq_radius) {
+            if (fast && K < kMaxNbr) nbr_code[K][tid] = static_cast<uint16_t>((r << 12) | (k - b));
+            ++K;
+          }
+        }
+        ++r;
       }
+  }
+  fast = fast && K <= kMaxNbr;
+  // visit every neighbour once: body(px, py, pz)
+  auto for_each_neighbour = [&](auto &&body) {
+    if (fast) {
+      // the next neighbour's coordinates are in flight while the current one is accumulated
+      uint32_t code = nbr_code[0][tid];
+      int32_t k = run_base[code >> 12][tid] + static_cast<int32_t>(code & 4095u);
+      float nx = a.sx[k], ny = a.sy[k], nz = a.sz[k];
+      for (int32_t t = 0; t < K; ++t) {
+        const float px = nx, py = ny, pz = nz;
+        if (t + 1 < K) {
+          code = nbr_code[t + 1][tid];
+          k = run_base[code >> 12][tid] + static_cast<int32_t>(code & 4095u);
+          nx = a.sx[k];
+          ny = a.sy[k];
+          nz = a.sz[k];
+        }
+        body(px, py, pz);
+      }
+    } else {
+      for (int32_t zz = z0; zz <= z1; ++zz)
+        for (int32_t yy = y0; yy <= y1; ++yy) {
+          const int32_t row = (zz * a.g.ny + yy) * a.g.nx;
+          const int32_t b = a.start[row + x0], e = a.start[row + x1 + 1];
+          for (int32_t k = b; k < e; ++k) {
+            const float px = a.sx[k], py = a.sy[k], pz = a.sz[k];
+            if (sqdist_f32(px, py, pz, qx, qy, qz) < a.sq_radius) body(px, py, pz);
+          }
+        }
     }
+  };
+
+  // sweep 1: moments of (p - q)
+  double s1x = 0, s1y = 0, s1z = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+  if (K >= 3)
+    for_each_neighbour([&](float px, float py, float pz) {
+      const double dx = static_cast<double>(px) - static_cast<double>(qx);
+      const double dy = static_cast<double>(py) - static_cast<double>(qy);
+      const double dz = static_cast<double>(pz) - static_cast<double>(qz);
+      s1x += dx; s1y += dy; s1z += dz;
+      sxx += dx * dx; sxy += dx * dy; sxz += dx * dz;
+      syy += dy * dy; syz += dy * dz; szz += dz * dz;
+    });
   if (K < 3) {  // MovingLeastSquares::performProcessing skips the point
     a.flag[i] = 0;
     return;
@@ -270,31 +328,23 @@ __global__ __launch_bounds__(kMB) void k_mls_fit(MlsArgs a) {
     double A00 = 0, A01 = 0, A02 = 0, A03 = 0, A04 = 0, A05 = 0, A11 = 0, A12 = 0, A13 = 0, A14 = 0, A15 = 0, A22 = 0,
            A23 = 0, A24 = 0, A25 = 0, A33 = 0, A34 = 0, A35 = 0, A44 = 0, A45 = 0, A55 = 0;
     double b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0;
-    for (int32_t zz = z0; zz <= z1; ++zz)
-      for (int32_t yy = y0; yy <= y1; ++yy) {
-        const int32_t row = (zz * a.g.ny + yy) * a.g.nx;
-        const int32_t b = a.start[row + x0], e = a.start[row + x1 + 1];
-        for (int32_t k = b; k < e; ++k) {
-          const float px = a.sx[k], py = a.sy[k], pz = a.sz[k];
-          if (sqdist_f32(px, py, pz, qx, qy, qz) < a.sq_radius) {
-            const double dx = static_cast<double>(px) - meanx, dy = static_cast<double>(py) - meany,
-                         dz = static_cast<double>(pz) - meanz;
-            const double w = exp(-((dx * dx + dy * dy) + dz * dz) * a.inv_sq_radius);
-            const double uc = (dx * ux + dy * uy) + dz * uz;
-            const double vc = (dx * vx + dy * vy) + dz * vz;
-            const double f = (dx * nrm[0] + dy * nrm[1]) + dz * nrm[2];
-            const double p1 = vc, p2 = vc * vc, p3 = uc, p4 = uc * vc, p5 = uc * uc;
-            const double w1 = w * p1, w2 = w * p2, w3 = w * p3, w4 = w * p4, w5 = w * p5;
-            A00 += w; A01 += w1; A02 += w2; A03 += w3; A04 += w4; A05 += w5;
-            A11 += w1 * p1; A12 += w1 * p2; A13 += w1 * p3; A14 += w1 * p4; A15 += w1 * p5;
-            A22 += w2 * p2; A23 += w2 * p3; A24 += w2 * p4; A25 += w2 * p5;
-            A33 += w3 * p3; A34 += w3 * p4; A35 += w3 * p5;
-            A44 += w4 * p4; A45 += w4 * p5;
-            A55 += w5 * p5;
-            b0 += w * f; b1 += w1 * f; b2 += w2 * f; b3 += w3 * f; b4 += w4 * f; b5 += w5 * f;
-          }
-        }
-      }
+    for_each_neighbour([&](float px, float py, float pz) {
+      const double dx = static_cast<double>(px) - meanx, dy = static_cast<double>(py) - meany,
+                   dz = static_cast<double>(pz) - meanz;
+      const double w = exp(-((dx * dx + dy * dy) + dz * dz) * a.inv_sq_radius);
+      const double uc = (dx * ux + dy * uy) + dz * uz;
+      const double vc = (dx * vx + dy * vy) + dz * vz;
+      const double f = (dx * nrm[0] + dy * nrm[1]) + dz * nrm[2];
+      const double p1 = vc, p2 = vc * vc, p3 = uc, p4 = uc * vc, p5 = uc * uc;
+      const double w1 = w * p1, w2 = w * p2, w3 = w * p3, w4 = w * p4, w5 = w * p5;
+      A00 += w; A01 += w1; A02 += w2; A03 += w3; A04 += w4; A05 += w5;
+      A11 += w1 * p1; A12 += w1 * p2; A13 += w1 * p3; A14 += w1 * p4; A15 += w1 * p5;
+      A22 += w2 * p2; A23 += w2 * p3; A24 += w2 * p4; A25 += w2 * p5;
+      A33 += w3 * p3; A34 += w3 * p4; A35 += w3 * p5;
+      A44 += w4 * p4; A45 += w4 * p5;
+      A55 += w5 * p5;
+      b0 += w * f; b1 += w1 * f; b2 += w2 * f; b3 += w3 * f; b4 += w4 * f; b5 += w5 * f;
+    });
     // LLT (lower) + forward / backward substitution, fully unrolled in registers
     bool ok = true;
     double L00, L10, L20, L30, L40, L50, L11, L21, L31, L41, L51, L22, L32, L42, L52, L33, L43, L53, L44, L54, L55;
@@ -434,6 +484,7 @@ struct VoxelEmitArgs {
   // neighbour grid of the MLS stage (cell-sorted coordinates)
   const float *sx, *sy, *sz;
   const int32_t *order, *start;
+  const int32_t *remap;  // view index -> caller's index (nullable)
   GridDesc g;
   int32_t reach;
   const double *state;  // kMlsState doubles per input point
@@ -470,7 +521,7 @@ __global__ __launch_bounds__(kMB) void k_voxel_emit(VoxelEmitArgs a) {
         const int32_t s0 = a.start[row + max(cx - a.reach, 0)], s1 = a.start[row + min(cx + a.reach, a.g.nx - 1) + 1];
         for (int32_t k = s0; k < s1; ++k) {
           const float d = sqdist_f32(a.sx[k], a.sy[k], a.sz[k], px, py, pz);
-          const int32_t id = a.order[k];
+          const int32_t id = a.remap ? a.remap[a.order[k]] : a.order[k];
           if (d < bestd || (d == bestd && id < best)) {
             bestd = d;
             best = id;
@@ -581,6 +632,7 @@ __device__ __forceinline__ void heap_push(float *heap, int &size, int k, float d
 __global__ __launch_bounds__(kSorBlock) void k_sor_mean_distance(const float *__restrict__ sx, const float *__restrict__ sy,
                                                                  const float *__restrict__ sz,
                                                                  const int32_t *__restrict__ order,
+                                                                 const int32_t *__restrict__ remap,
                                                                  const int32_t *__restrict__ start, int64_t n, GridDesc g,
                                                                  int32_t mean_k, float *__restrict__ distances) {
   extern __shared__ float sor_heap[];
@@ -628,7 +680,7 @@ __global__ __launch_bounds__(kSorBlock) void k_sor_mean_distance(const float *__
     smallest = fminf(smallest, d);
   }
   if (size > 0) sum -= static_cast<double>(sqrtf(smallest));
-  distances[order[j]] = static_cast<float>(sum / static_cast<double>(mean_k));
+  distances[remap ? remap[order[j]] : order[j]] = static_cast<float>(sum / static_cast<double>(mean_k));
 }
 
 // sum and sum of squares (fp32 squares, as the reference) of the distances, fp64 accumulation
@@ -682,6 +734,10 @@ struct CloudView {
   const float *x, *y, *z;
   int64_t n;
   float mn[3], mx[3];
+  // nullptr, or view index -> caller's point index: the uploaded map is walked through its
+  // Morton-ordered copy (cell binning then permutes nearby memory only) and results are
+  // reported under the caller's indices
+  const int32_t *remap;
 };
 
 __device__ __forceinline__ uint32_t ordered_bits(float f) {
@@ -878,6 +934,7 @@ static int voxel_grid_dilation(pcp_context *ctx, const CloudView &cv, const pcp_
   e.sy = ctx->g_xyz.p + plane;
   e.sz = ctx->g_xyz.p + 2 * plane;
   e.order = ctx->g_order.p;
+  e.remap = cv.remap;
   e.start = ctx->g_start.p;
   e.g = g;
   // a dilated voxel's corner lies within sqrt(3) * (it + 1) voxels of the point that stamped it
@@ -937,9 +994,10 @@ static int voxel_grid_dilation(pcp_context *ctx, const CloudView &cv, const pcp_
 static CloudView uploaded_view(const pcp_context *ctx) {
   CloudView cv{};
   const size_t plane = (static_cast<size_t>(ctx->n) + 3) & ~size_t(3);
-  cv.x = ctx->xyz.p;
-  cv.y = ctx->xyz.p + plane;
-  cv.z = ctx->xyz.p + 2 * plane;
+  cv.x = ctx->sxyz.p;
+  cv.y = ctx->sxyz.p + plane;
+  cv.z = ctx->sxyz.p + 2 * plane;
+  cv.remap = ctx->perm.p;
   cv.n = ctx->n;
   for (int a = 0; a < 3; ++a) {
     cv.mn[a] = ctx->host_min[static_cast<size_t>(a)];
@@ -985,6 +1043,7 @@ static int mls_run(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *
   a.sy = ctx->g_xyz.p + plane;
   a.sz = ctx->g_xyz.p + 2 * plane;
   a.order = ctx->g_order.p;
+  a.remap = cv.remap;
   a.start = ctx->g_start.p;
   a.n = n;
   a.g = g;
@@ -1004,7 +1063,7 @@ static int mls_run(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *
   }
   {
     LaunchTimer t(ctx, PCP_K_MLS_FIT);
-    hipLaunchKernelGGL(k_mls_fit, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_mls_fit, dim3(static_cast<uint32_t>(div_up(n, kFitBlock))), dim3(kFitBlock), 0, ctx->stream, a);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   if (p->upsampling == 3) return voxel_grid_dilation(ctx, cv, p, g, out_count);
@@ -1070,7 +1129,7 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
     const size_t lds = static_cast<size_t>(mean_k + 1) * kSorBlock * sizeof(float);
     hipLaunchKernelGGL(k_sor_mean_distance, dim3(static_cast<uint32_t>(div_up(n, kSorBlock))), dim3(kSorBlock), lds,
                        ctx->stream, ctx->g_xyz.p, ctx->g_xyz.p + plane, ctx->g_xyz.p + 2 * plane, ctx->g_order.p,
-                       ctx->g_start.p, n, g, mean_k, dist);
+                       cv.remap, ctx->g_start.p, n, g, mean_k, dist);
     hipLaunchKernelGGL(k_sor_stats, dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(n, kMB), 1024))), dim3(kMB), 0,
                        ctx->stream, dist, n, ctx->m_sums.p);
     PCP_HIP_TRY(ctx, hipGetLastError());
@@ -1095,6 +1154,7 @@ static int view_of(pcp_context *ctx, const float *x, const float *y, const float
   cv->x = x;
   cv->y = y;
   cv->z = z;
+  cv->remap = nullptr;
   cv->n = n;
   for (int a = 0; a < 3; ++a) cv->mn[a] = cv->mx[a] = 0.0f;
   if (n == 0) return PCP_OK;
@@ -1213,7 +1273,10 @@ int pcp_cloud_smooth(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_cou
   const size_t plane1 = (static_cast<size_t>(n1) + 3) & ~size_t(3);
   PCP_HIP_TRY(ctx, ctx->c_xyz.ensure(3 * plane1 + 4));
   float *x1 = ctx->c_xyz.p, *y1 = ctx->c_xyz.p + plane1, *z1 = ctx->c_xyz.p + 2 * plane1;
-  hipLaunchKernelGGL(k_gather_xyz, dim3(blocks_of(n1)), dim3(kMB), 0, ctx->stream, cv0.x, cv0.y, cv0.z, ctx->c_index.p, n1,
+  // c_index holds the caller's indices: gather from the input-order copy
+  const size_t plane0 = (static_cast<size_t>(cv0.n) + 3) & ~size_t(3);
+  hipLaunchKernelGGL(k_gather_xyz, dim3(blocks_of(n1)), dim3(kMB), 0, ctx->stream, ctx->xyz.p, ctx->xyz.p + plane0,
+                     ctx->xyz.p + 2 * plane0, ctx->c_index.p, n1,
                      x1, y1, z1);
   PCP_HIP_TRY(ctx, hipGetLastError());
   CloudView cv1;
