@@ -91,7 +91,8 @@ enum {
   PCP_K_SOR = 7,        /* StatisticalOutlierRemoval kNN mean distance */
   PCP_K_MLS_VOXEL = 8,  /* VOXEL_GRID_DILATION upsampling */
   PCP_K_TILE_MASK = 9,  /* tile x keyframe visibility masks (conservative culling) */
-  PCP_K_COUNT = 10
+  PCP_K_NID = 10,       /* NID joint histograms (value + SE(3) tangent gradient) */
+  PCP_K_COUNT = 11
 };
 
 /* ---- lifecycle ---------------------------------------------------------- */
@@ -209,6 +210,26 @@ int pcp_cloud_smooth(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_cou
 /* pcl::StatisticalOutlierRemoval (k, std_mul) keep mask of the uploaded cloud,
  * cloudSmooth.cpp:109-116,160-164. */
 int pcp_sor(pcp_context *ctx, int32_t mean_k, double std_mul, uint8_t *out_keep, int64_t *out_kept);
+
+/* ---- NID extrinsic refinement (VisualLiDARCalibration::calibrate, PCP/src/calibrate.cpp:42-126) -- */
+/* per-point intensity of the uploaded cloud (pcl::PointXYZI::intensity), needed by the NID stage */
+int pcp_upload_intensity(pcp_context *ctx, const float *intensity, int64_t n);
+/* Builds every keyframe's NID input on the device: its z-buffer-culled points in camera
+ * coordinates with intensity (the content of <ts>_beforeNID.pcd, PointCloudProcessor.cpp:178-224).
+ * Needs camera, cloud, intensity, keyframes and images. */
+int pcp_nid_prepare(pcp_context *ctx, int64_t *out_points);
+/* MultiNIDCost at T = T_camera_lidar (4x4 row-major fp64): sum over keyframes of NIDCost
+ * (nid_cost.hpp:42-116), and its gradient in the SE(3) tangent of T * exp(delta),
+ * delta = (upsilon, omega).  T_init (nullable): the initial guess whose +-0.2 m / 2 deg
+ * neighbourhood bounds the domain (visual_camera_calibration.cpp:100-105); outside it, or when
+ * a keyframe's cost is not finite, *valid = 0. */
+int pcp_nid_evaluate(pcp_context *ctx, const double T[16], const double *T_init, int32_t bins, double *cost,
+                     double grad6[6], int32_t *valid);
+/* VisualCameraCalibration::calibrate (visual_camera_calibration.cpp:49-80): up to
+ * max_outer_iterations runs of a BFGS minimisation on SE(3) (stands in for ceres::Solve),
+ * stopping when the pose moves by < 1 cm and < 1 deg.  T_out feeds pcp_set_frames' T_opt. */
+int pcp_nid_optimize(pcp_context *ctx, const double T_init[16], int32_t bins, int32_t max_outer_iterations,
+                     double T_out[16], double *final_cost, int32_t *evaluations);
 
 /* ---- measurement -------------------------------------------------------- */
 /* When enabled every kernel launch is bracketed by hipEvents on the context's

@@ -49,7 +49,8 @@ class MLSParams(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the restatement with the committed Makefile (gcc, -ffp-contract=off)."""
-    srcs = [os.path.join(_HERE, f) for f in ("pcp_oracle.c", "pcp_oracle_mls.c", "pcp_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("pcp_oracle.c", "pcp_oracle_mls.c", "pcp_oracle_nid.c", "pcp_oracle.h",
+                                            "Makefile")]
     stale = force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
     )
@@ -258,6 +259,21 @@ def sor(x, y, z, mean_k: int = 60, std_mul: float = 0.7, threads: int = 0, detai
     if details:
         return keep, kept, dist, thr.value
     return keep, kept
+
+
+def nid(cam, images, offsets, x, y, z, intensity, T, bins: int = 16):
+    """MultiNIDCost value and SE(3)-tangent gradient (6,) at T (4x4)."""
+    x, y, z, intensity = _f32(x), _f32(y), _f32(z), _f32(intensity)
+    offsets = np.ascontiguousarray(offsets, np.int64)
+    F = len(offsets) - 1
+    imgs = [np.ascontiguousarray(im, np.uint8) for im in images]
+    iptr = (C.c_void_p * F)(*[im.ctypes.data for im in imgs])
+    T = np.ascontiguousarray(T, np.float64).reshape(16)
+    cost = C.c_double()
+    grad = np.zeros(6, np.float64)
+    ok = lib().orc_nid(C.byref(cam), iptr, C.c_int32(F), _p(offsets), _p(x), _p(y), _p(z), _p(intensity), _p(T),
+                       C.c_int32(bins), C.byref(cost), _p(grad))
+    return cost.value, grad, bool(ok)
 
 
 def select_keyframes(poses, dist_threshold: float = 0.1):

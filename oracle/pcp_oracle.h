@@ -141,6 +141,12 @@ int32_t orc_select_keyframes(const orc_pose *poses, int32_t n, double dist_thres
 int64_t orc_sor(const float *x, const float *y, const float *z, int64_t n, int32_t mean_k, double std_mul,
                 uint8_t *out_keep, float *out_distance, double *out_threshold, int32_t threads);
 
+/* NID cost: sum over keyframes of NIDCost (nid_cost.hpp:42-116) on the culled,
+ * camera-frame clouds, and its gradient in the SE(3) tangent of T * exp(delta).  See pcp_oracle_nid.c. */
+int orc_nid(const orc_camera *cam, const uint8_t *const *images, int32_t n_frames, const int64_t *offsets,
+            const float *x, const float *y, const float *z, const float *intensity, const double T[16], int32_t bins,
+            double *out_cost, double *out_grad);
+
 int32_t orc_hardware_threads(void);
 
 #ifdef __cplusplus

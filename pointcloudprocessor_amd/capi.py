@@ -22,8 +22,8 @@ PCP_ERR_DEVICE = -3
 PCP_ERR_NOMEM = -4
 PCP_ERR_RANGE = -5
 
-K_PROJECT, K_DEPTH, K_COLOUR, K_VISIBILITY, K_MLS_GRID, K_MLS_FIT, K_MISC, K_SOR, K_MLS_VOXEL, K_TILE_MASK = range(10)
-K_COUNT = 10
+K_PROJECT, K_DEPTH, K_COLOUR, K_VISIBILITY, K_MLS_GRID, K_MLS_FIT, K_MISC, K_SOR, K_MLS_VOXEL, K_TILE_MASK, K_NID = range(11)
+K_COUNT = 11
 
 
 class PcpError(RuntimeError):
@@ -379,6 +379,35 @@ class Context:
         kept = C.c_int64()
         self._check(self.lib.pcp_sor(self.h, C.c_int32(mean_k), C.c_double(std_mul), _ptr(keep), C.byref(kept)))
         return keep, kept.value
+
+    # -- NID extrinsic refinement -----------------------------------------
+    def upload_intensity(self, intensity):
+        a = np.ascontiguousarray(intensity, np.float32)
+        self._check(self.lib.pcp_upload_intensity(self.h, _ptr(a), C.c_int64(len(a))))
+
+    def nid_prepare(self) -> int:
+        cnt = C.c_int64()
+        self._check(self.lib.pcp_nid_prepare(self.h, C.byref(cnt)))
+        return cnt.value
+
+    def nid_evaluate(self, T, T_init=None, bins: int = 16):
+        T = np.ascontiguousarray(T, np.float64).reshape(16)
+        Ti = None if T_init is None else np.ascontiguousarray(T_init, np.float64).reshape(16)
+        cost = C.c_double()
+        grad = np.zeros(6, np.float64)
+        valid = C.c_int32()
+        self._check(self.lib.pcp_nid_evaluate(self.h, _ptr(T), _ptr(Ti), C.c_int32(bins), C.byref(cost), _ptr(grad),
+                                              C.byref(valid)))
+        return cost.value, grad, bool(valid.value)
+
+    def nid_optimize(self, T_init, bins: int = 16, max_outer_iterations: int = 10):
+        Ti = np.ascontiguousarray(T_init, np.float64).reshape(16)
+        out = np.zeros(16, np.float64)
+        cost = C.c_double()
+        evals = C.c_int32()
+        self._check(self.lib.pcp_nid_optimize(self.h, _ptr(Ti), C.c_int32(bins), C.c_int32(max_outer_iterations), _ptr(out),
+                                              C.byref(cost), C.byref(evals)))
+        return out.reshape(4, 4), cost.value, evals.value
 
     # -- measurement ------------------------------------------------------
     def timing_enable(self, on: bool = True):

@@ -641,6 +641,26 @@ static int single_frame_depth(pcp_context *ctx, int32_t frame) {
   return PCP_OK;
 }
 
+// ViewCulling::cull for one keyframe, device side: ordered index list of the kept points into
+// `d_index` (capacity entries), count to *count.  Used by pcp_cull_frame-like paths and the NID stage.
+int cull_frame_indices(pcp_context *ctx, int32_t frame, int32_t *d_index, int64_t capacity, int64_t *count) {
+  const int64_t n = ctx->n;
+  *count = 0;
+  if (n == 0) return PCP_OK;
+  int rc = single_frame_depth(ctx, frame);
+  if (rc != PCP_OK) return rc;
+  PCP_HIP_TRY(ctx, ctx->s_keep.ensure(static_cast<size_t>(n) + 16));
+  const size_t plane = plane_of(ctx);
+  {
+    LaunchTimer t(ctx, PCP_K_VISIBILITY);
+    hipLaunchKernelGGL(k_visibility, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
+                       ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, n, ctx->dcam,
+                       ctx->hframes[static_cast<size_t>(frame)], ctx->s_u32.p, ctx->perm.p, ctx->s_keep.p, 0);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  return compact_flags(ctx, ctx->s_keep.p, n, d_index, capacity, count);
+}
+
 }  // namespace pcp
 
 using namespace pcp;

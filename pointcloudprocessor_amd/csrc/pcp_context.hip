@@ -209,6 +209,8 @@ static int store_cloud(pcp_context *ctx, const float *x, const float *y, const f
   PCP_HIP_TRY(ctx, ctx->perm.ensure(sn + 4));
   ctx->n = n;
   ctx->n_tiles = 0;
+  ctx->have_intensity = false;
+  ctx->nid_chunks = 0;
   ctx->colour_state_live = false;
   ctx->colour_result_live = false;
   ctx->mls_count = 0;
@@ -396,6 +398,10 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->m_tmp.release();
   ctx->m_state.release();
   ctx->m_flag.release();
+  ctx->intensity.release();
+  ctx->nid_pts.release();
+  ctx->nid_chunk_kf.release();
+  ctx->nid_hist.release();
   ctx->m_sums.release();
   ctx->c_index.release();
   ctx->c_xyz.release();
@@ -650,7 +656,8 @@ int pcp_timing_get(pcp_context *ctx, int32_t kernel_id, double *total_ms, int64_
 
 const char *pcp_kernel_name(int32_t kernel_id) {
   static const char *names[PCP_K_COUNT] = {"project_frame", "depth_pass", "colour_pass", "visibility", "mls_grid",
-                                           "mls_fit",       "misc",       "sor",         "mls_voxel",   "tile_mask"};
+                                           "mls_fit",       "misc",       "sor",         "mls_voxel",   "tile_mask",
+                                           "nid_hist"};
   return (kernel_id >= 0 && kernel_id < PCP_K_COUNT) ? names[kernel_id] : "?";
 }
 

@@ -164,6 +164,16 @@ struct pcp_context {
   pcp::DevBuf<int32_t> mls_index;
   int64_t mls_count = 0;
 
+  // NID stage (section 8 f1): per-point intensity, per-keyframe culled clouds in camera
+  // coordinates (x, y, z, intensity), chunked so that a workgroup sees one keyframe
+  pcp::DevBuf<float> intensity;
+  bool have_intensity = false;
+  pcp::DevBuf<float> nid_pts;        // float4 per entry, NaN intensity = padding
+  pcp::DevBuf<int32_t> nid_chunk_kf; // keyframe of every chunk
+  pcp::DevBuf<double> nid_hist;      // [keyframe][bins*bins*7 + bins]
+  int64_t nid_chunks = 0, nid_points = 0;
+  int32_t nid_frames = 0;
+
   // measurement
   bool timing = false;
   pcp::TimingSlot slots[PCP_K_COUNT];
@@ -198,6 +208,9 @@ int drain_timing(pcp_context *ctx);
 // ordered compaction of a device byte-flag array (pcp_colour.hip): index list (nullable) + count
 int compact_flags(pcp_context *ctx, const uint8_t *flags, int64_t n, int32_t *out_index, int64_t capacity,
                   int64_t *count);
+
+// ViewCulling::cull of one keyframe on the device: ordered index list of kept points (pcp_colour.hip)
+int cull_frame_indices(pcp_context *ctx, int32_t frame, int32_t *d_index, int64_t capacity, int64_t *count);
 
 inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

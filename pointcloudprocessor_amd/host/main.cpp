@@ -14,8 +14,10 @@
 //     The real binary keeps cv::imread and hands the decoded cv::Mat to the shim.
 //   * the 8-bit BGR->HSV->BGR round trip of generateColorMap (:722-741, Appendix B5) is
 //     not applied (pixels are taken as already adjusted).
-//   * --enableNIDOptimize / --enableInitialGuessManual are accepted and rejected with an
-//     exception (exit -2): Ceres / the GUI are out of scope.
+//   * --enableNIDOptimize runs the NID cost on the GPU with a BFGS on SE(3) in place of
+//     ceres::Solve (same cost, gradient, domain limits and outer loop; not Ceres' line search).
+//   * --enableInitialGuessManual is accepted and rejected with an exception (exit -2): the
+//     interactive GUI is out of scope.
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -145,8 +147,8 @@ class Processor {
     setupDevice();
     if (!opt.skip_filtered_dumps) viewCullingAndSaveFilteredPcds();
     if (opt.enableNIDOptimize)
-      throw std::runtime_error("NID-based pose optimisation (Ceres) is not part of this build");
-    if (opt.enableInitialGuessManual)
+      applyNIDBasedPoseOptimization();
+    else if (opt.enableInitialGuessManual)
       throw std::runtime_error("the manual initial-guess GUI is not part of this build");
     pcdColorizationAndSmooth();
   }
@@ -158,6 +160,8 @@ class Processor {
   XYZICloud cloud;
   std::unique_ptr<Device> gpu;
   int img_w = 0, img_h = 0;
+  bool images_uploaded = false;
+  std::vector<double> T_camera_lidar_optimized;
 
   void loadImagesAndOdometry() {  // :965-1005
     std::ifstream vo(opt.odometryPath);
@@ -283,6 +287,30 @@ class Processor {
     gpu->setKeyframes(poses);
   }
 
+  void applyNIDBasedPoseOptimization() {  // :156-164 -> calibrate.cpp:42-126
+    gpu->uploadIntensity(cloud.intensity.data(), static_cast<int64_t>(cloud.size()));
+    uploadImages();
+    VisualLiDARCalibration calib(*gpu);
+    double cost = 0.0;
+    T_camera_lidar_optimized = calib.calibrate(&cost);
+    std::printf("Final cost: %.3f\n--- T_camera_lidar ---\n", cost);
+    for (int r = 0; r < 4; ++r)
+      std::printf("%g %g %g %g\n", T_camera_lidar_optimized[4 * r], T_camera_lidar_optimized[4 * r + 1],
+                  T_camera_lidar_optimized[4 * r + 2], T_camera_lidar_optimized[4 * r + 3]);
+    {  // full-precision copy of the result next to the outputs (not written by the reference)
+      std::ofstream tf(opt.outputPath + "T_camera_lidar_optimized.txt");
+      char buf[64];
+      for (int k = 0; k < 16; ++k) {
+        std::snprintf(buf, sizeof(buf), "%.17g%c", T_camera_lidar_optimized[static_cast<size_t>(k)], (k % 4 == 3) ? '\n' : ' ');
+        tf << buf;
+      }
+    }
+    std::vector<pcp_pose> poses;
+    for (const auto &k : keyframes) poses.push_back(k.pose);
+    gpu->setKeyframes(poses, T_camera_lidar_optimized.data(), 0);  // the enableNIDOptimize branch, :504-509
+    images_uploaded = false;                                        // set_frames drops the images
+  }
+
   void viewCullingAndSaveFilteredPcds() {  // :178-224
     ViewCulling vc(*gpu);
     const size_t n = cloud.size();
@@ -307,7 +335,8 @@ class Processor {
     }
   }
 
-  void pcdColorizationAndSmooth() {  // :474-602
+  void uploadImages() {
+    if (images_uploaded) return;
     std::vector<uint8_t> px, bgr;
     for (size_t k = 0; k < keyframes.size(); ++k) {
       int w = 0, h = 0;
@@ -335,6 +364,11 @@ class Processor {
           std::cout << "Failed to read image from: " << keyframes[k].maskImagePath << std::endl;  // :779, not fatal
       }
     }
+    images_uploaded = true;
+  }
+
+  void pcdColorizationAndSmooth() {  // :474-602
+    uploadImages();
     Colorizer col(*gpu);
     std::vector<float> wx, wy, wz;  // cloudInWorldWithRGBandMask
     std::vector<float> wxyz;

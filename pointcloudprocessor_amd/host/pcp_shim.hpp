@@ -39,6 +39,8 @@ class Device {
   // `cloud` of the reference: pcl::PointCloud<pcl::PointXYZI>::points.data(), stride sizeof(pcl::PointXYZI) == 32
   void uploadCloudAoS(const void *points, int64_t n, int64_t stride_bytes) { check(pcp_upload_cloud_aos(ctx_, points, n, stride_bytes)); }
   void uploadCloud(const float *x, const float *y, const float *z, int64_t n) { check(pcp_upload_cloud(ctx_, x, y, z, n)); }
+  // pcl::PointXYZI::intensity of every point (the NID stage bins it, nid_cost.hpp:55-56)
+  void uploadIntensity(const float *intensity, int64_t n) { check(pcp_upload_intensity(ctx_, intensity, n)); }
   int64_t cloudSize() const { return pcp_cloud_size(ctx_); }
 
   // K_camera_coefficients / D_camera (PointCloudProcessor.cpp:57-62) + ViewCulling image size (:525)
@@ -109,6 +111,27 @@ class Colorizer {
       dev_.check(pcp_frame_visible(dev_.get(), keyframe, m, v.index.data(), v.rgb.data(), v.mask.data(), v.xyz_cam.data(),
                                    v.xyz_world.data(), &m));
     return v;
+  }
+
+ private:
+  Device &dev_;
+};
+
+// vlcal::VisualLiDARCalibration (PCP/src/calibrate.cpp:42-126): NID-based refinement of
+// T_camera_lidar on the z-buffer-culled keyframe clouds
+class VisualLiDARCalibration {
+ public:
+  explicit VisualLiDARCalibration(Device &dev) : dev_(dev) {}
+  // returns T_camera_lidar_optimized as a 4x4 row-major matrix (identity initial guess, 16 bins,
+  // <= 10 outer iterations: calibrate.cpp:45-51, visual_camera_calibration.hpp:17,28)
+  std::vector<double> calibrate(double *final_cost = nullptr) const {
+    int64_t pts = 0;
+    dev_.check(pcp_nid_prepare(dev_.get(), &pts));
+    const double I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    std::vector<double> T(16);
+    int32_t evals = 0;
+    dev_.check(pcp_nid_optimize(dev_.get(), I, 16, 10, T.data(), final_cost, &evals));
+    return T;
   }
 
  private:

@@ -151,3 +151,40 @@ def test_cli_end_to_end_matches_oracle(tmp_path, oracle):
     total = sum(len(oracle.frame_visible(cam, cp, poses[k], x, y, z, imgs[k], masks[k])["index"]) for k in keys)
     assert len(r4) == total
     assert (tmp_path / "scans-crop.pcd").exists()
+
+
+@pytest.mark.gpu
+def test_cli_with_nid_refinement(tmp_path, oracle):
+    """--enableNIDOptimize 1: the NID stage runs on the GPU and its extrinsic feeds the colour
+    path exactly as PointCloudProcessor.cpp:504-509 (checked against the oracle with the same T)."""
+    from pointcloudprocessor_amd import synth
+
+    W, H = 1024, 750
+    x, y, z, inten = synth.make_cloud(40000, seed=4)
+    _write_pcd_binary(tmp_path / "scans.pcd", x, y, z, inten)
+    poses, ts = synth.make_trajectory(4)
+    imgs = []
+    with open(tmp_path / "odo.txt", "w") as f:
+        for k, (t, p) in enumerate(zip(ts, poses)):
+            f.write("%.6f %.6f %.6f %.6f %.8f %.8f %.8f %.8f\n" % (t, *p))
+            img = synth.make_image(k, W, H)
+            imgs.append(img)
+            with open(tmp_path / ("%f.ppm" % t), "wb") as g:
+                g.write(b"P6\n%d %d\n255\n" % (W, H) + img[:, :, ::-1].tobytes())
+    out = str(tmp_path) + "/"
+    p = subprocess.run([_exe(), "-p", str(tmp_path / "scans.pcd"), "-o", str(tmp_path / "odo.txt"), "-i", out, "-t", out,
+                        "--enableNIDOptimize", "1"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    T = np.loadtxt(tmp_path / "T_camera_lidar_optimized.txt").reshape(4, 4)
+    assert np.allclose(T[3], [0, 0, 0, 1]) and np.linalg.norm(T[:3, 3]) <= 0.2 * 10 + 1e-9
+    assert np.allclose(T[:3, :3] @ T[:3, :3].T, np.eye(3), atol=1e-9)
+    cam = oracle.default_camera()
+    cam.image_width, cam.image_height = W, H
+    ref = oracle.colorize(cam, oracle.default_cull_params(), x, y, z, poses, imgs, T_opt=T, threads=8, want_top=False)
+    header, rows = _read_pcd_ascii(tmp_path / "cloudInWorldWithRGB.pcd")
+    sel = np.nonzero(ref["has"])[0]
+    assert len(rows) == len(sel) > 50
+    got_rgb = np.array([int(r[3]) for r in rows], dtype=np.uint64)
+    packed = (0xFF000000 | (ref["rgb"][sel, 0].astype(np.uint64) << 16) | (ref["rgb"][sel, 1].astype(np.uint64) << 8)
+              | ref["rgb"][sel, 2].astype(np.uint64))
+    assert np.array_equal(got_rgb, packed)

@@ -1,0 +1,127 @@
+"""NID extrinsic refinement: the summed NID cost and its SE(3)-tangent
+gradient on the GPU against the oracle (dual-number restatement of nid_cost.hpp), and the
+host BFGS recovering a perturbed extrinsic on images rendered from the cloud's intensities."""
+import numpy as np
+import pytest
+
+from conftest import cam_struct
+
+pytestmark = pytest.mark.gpu
+
+
+def _se3_exp(d):
+    up, om = np.asarray(d[:3], float), np.asarray(d[3:], float)
+    th = np.linalg.norm(om)
+    K = np.array([[0, -om[2], om[1]], [om[2], 0, -om[0]], [-om[1], om[0], 0]])
+    if th < 1e-9:
+        R, V = np.eye(3) + K, np.eye(3) + 0.5 * K
+    else:
+        R = np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+        V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * K + (th - np.sin(th)) / th ** 3 * K @ K
+    M = np.eye(4)
+    M[:3, :3] = R
+    M[:3, 3] = V @ up
+    return M
+
+
+def _scene(oracle, n=120_000, F=4):
+    """Cloud with a smooth 'albedo' as intensity; images = that albedo splatted through the true
+    poses, so that NID is minimal at T = identity."""
+    from pointcloudprocessor_amd import synth
+
+    cd = synth.camera_dict("tiny")
+    x, y, z, _ = synth.make_cloud(n, seed=31)
+    inten = (0.5 + 0.5 * np.sin(2.1 * x) * np.sin(1.7 * y + 0.3) * np.sin(2.9 * z + 1.0)).astype(np.float32)
+    poses, _ = synth.make_trajectory(6 * F)
+    poses = poses[::6][:F]
+    cam, cp = cam_struct(oracle, cd), oracle.default_cull_params()
+    W, H = cd["image_width"], cd["image_height"]
+    images, lists = [], []
+    for f in range(F):
+        w2c, _ = oracle.pose_to_matrices(poses[f])
+        keep, _, _ = oracle.cull_frame(cam, cp, w2c, x, y, z, 8)
+        p = oracle.project_frame(cam, cp, w2c, x, y, z)
+        sel = np.nonzero(keep)[0]
+        lists.append((p["xc"][sel], p["yc"][sel], p["zc"][sel], inten[sel]))
+        vis = np.nonzero(keep & (p["pixel"] >= 0))[0]
+        g = 8  # splat on a coarse grid, then upsample: a dense, smooth image
+        acc = np.zeros(((H + g - 1) // g, (W + g - 1) // g))
+        cnt = np.zeros_like(acc)
+        v, u = np.divmod(p["pixel"][vis], W)
+        np.add.at(acc, (v // g, u // g), inten[vis])
+        np.add.at(cnt, (v // g, u // g), 1.0)
+        coarse = np.where(cnt > 0, acc / np.maximum(cnt, 1), 0.5)
+        gray = np.kron(coarse, np.ones((g, g)))[:H, :W]
+        # The reference reads its 3-channel image as if it had one channel: element x of row y of
+        # the interleaved B,G,R values (see pcp_oracle_nid.c).  Lay the rendering out so that THIS
+        # read returns gray(y, x): the first W interleaved values of every row carry the picture.
+        g8 = (np.clip(gray, 0, 1) * 255).astype(np.uint8)
+        img = np.full((H, W, 3), 128, np.uint8)
+        img.reshape(H, W * 3)[:, :W] = g8
+        images.append(np.ascontiguousarray(img))
+    return cd, x, y, z, inten, poses, images, lists
+
+
+def test_nid_cost_and_gradient_match_oracle(gpu_ctx_factory, oracle):
+    from pointcloudprocessor_amd import capi
+
+    cd, x, y, z, inten, poses, images, lists = _scene(oracle)
+    ctx = gpu_ctx_factory()
+    ctx.set_camera(cam_struct(capi, cd))
+    ctx.upload_cloud(x, y, z)
+    ctx.upload_intensity(inten)
+    ctx.set_frames(poses)
+    for f, im in enumerate(images):
+        ctx.upload_image(f, im)
+    total = ctx.nid_prepare()
+    assert total == sum(len(l[0]) for l in lists) > 1000
+    offsets = np.concatenate([[0], np.cumsum([len(l[0]) for l in lists])]).astype(np.int64)
+    cx = np.concatenate([l[0] for l in lists])
+    cy = np.concatenate([l[1] for l in lists])
+    cz = np.concatenate([l[2] for l in lists])
+    ci = np.concatenate([l[3] for l in lists])
+    ocam = cam_struct(oracle, cd)
+    for d in ([0, 0, 0, 0, 0, 0], [0.01, -0.004, 0.006, 0.002, -0.003, 0.001], [-0.05, 0.02, 0.0, -0.01, 0.008, 0.012]):
+        T = _se3_exp(d)
+        c_ref, g_ref, ok_ref = oracle.nid(ocam, images, offsets, cx, cy, cz, ci, T)
+        c_got, g_got, ok_got = ctx.nid_evaluate(T)
+        assert ok_ref and ok_got
+        assert abs(c_got - c_ref) <= 1e-9 * abs(c_ref), (c_got, c_ref)
+        assert np.abs(g_got - g_ref).max() <= 1e-6 * max(np.abs(g_ref).max(), 1e-3), (g_got, g_ref)
+    # domain limit of MultiNIDCost
+    _, _, valid = ctx.nid_evaluate(_se3_exp([0.3, 0, 0, 0, 0, 0]), T_init=np.eye(4))
+    assert not valid
+    _, _, valid = ctx.nid_evaluate(_se3_exp([0.1, 0, 0, 0, 0, 0.01]), T_init=np.eye(4))
+    assert valid
+
+
+def test_nid_optimiser_recovers_a_perturbed_extrinsic(gpu_ctx_factory, oracle):
+    from pointcloudprocessor_amd import capi
+
+    cd, x, y, z, inten, poses, images, _ = _scene(oracle, n=200_000, F=6)
+    ctx = gpu_ctx_factory()
+    ctx.set_camera(cam_struct(capi, cd))
+    ctx.upload_cloud(x, y, z)
+    ctx.upload_intensity(inten)
+    ctx.set_frames(poses)
+    for f, im in enumerate(images):
+        ctx.upload_image(f, im)
+    ctx.nid_prepare()
+    c_true, _, _ = ctx.nid_evaluate(np.eye(4))
+    T0 = _se3_exp([0.03, -0.02, 0.015, 0.006, -0.008, 0.004])  # 4 cm, 0.6 deg off
+    c0, _, _ = ctx.nid_evaluate(T0)
+    assert c_true < c0  # the rendered images are most informative at the true extrinsic
+    T, c_opt, evals = ctx.nid_optimize(T0, bins=16, max_outer_iterations=10)
+    assert c_opt < c0 and evals > 3
+    err0 = np.linalg.norm(T0[:3, 3])
+    err = np.linalg.norm(T[:3, 3])
+    ang = np.degrees(np.arccos(np.clip((np.trace(T[:3, :3]) - 1) / 2, -1, 1)))
+    assert err < 0.6 * err0 and ang < 0.6, (err, ang, c_true, c0, c_opt)
+    # the refined extrinsic plugs into the colour path (NID branch, PointCloudProcessor.cpp:504-509)
+    ctx.set_frames(poses, T_opt=T)
+    for f, im in enumerate(images):
+        ctx.upload_image(f, im)
+    out = ctx.colorize()
+    ref = oracle.colorize(cam_struct(oracle, cd), oracle.default_cull_params(), x, y, z, poses, images, T_opt=T,
+                          threads=8, want_top=False)
+    assert np.array_equal(out["rgb"], ref["rgb"]) and np.array_equal(out["has"], ref["has"])
