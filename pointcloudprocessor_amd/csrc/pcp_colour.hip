@@ -303,7 +303,8 @@ __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict_
                                                         const uint32_t *__restrict__ depth, int64_t cells,
                                                         const uint32_t *__restrict__ tile_mask, int32_t words,
                                                         const uint32_t *__restrict__ images, int64_t image_px,
-                                                        TopState st, uint32_t *__restrict__ rgba, int32_t flags) {
+                                                        TopState st, const int32_t *__restrict__ perm,
+                                                        uint32_t *__restrict__ rgba, int32_t flags) {
   const int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const bool live = j < n;
   const float px = live ? x[j] : 0.0f, py = live ? y[j] : 0.0f, pz = live ? z[j] : 0.0f;
@@ -353,11 +354,12 @@ __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict_
     st.frame[3 * n + j] = t.f3; st.frame[4 * n + j] = t.f4;
     st.count[j] = t.count;
   }
-  if (flags & 4) rgba[j] = t.finalise();
+  if (flags & 4) rgba[perm[j]] = t.finalise();  // packed result straight into input order
 }
 
 // finalise from stored state (multi-batch runs)
-__global__ __launch_bounds__(kBlock) void k_finalise(int64_t n, TopState st, uint32_t *__restrict__ rgba) {
+__global__ __launch_bounds__(kBlock) void k_finalise(int64_t n, TopState st, const int32_t *__restrict__ perm,
+                                                     uint32_t *__restrict__ rgba) {
   const int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (j >= n) return;
   Top5 t;
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(kBlock) void k_finalise(int64_t n, TopState st, uin
   t.f0 = st.frame[0 * n + j]; t.f1 = st.frame[1 * n + j]; t.f2 = st.frame[2 * n + j];
   t.f3 = st.frame[3 * n + j]; t.f4 = st.frame[4 * n + j];
   t.count = st.count[j];
-  rgba[j] = t.finalise();
+  rgba[perm[j]] = t.finalise();
 }
 
 // ---------------------------------------------------------------------------
@@ -595,7 +597,6 @@ static int ensure_state(pcp_context *ctx) {
   PCP_HIP_TRY(ctx, ctx->top_rgb.ensure(kTopM * sn + 4));
   PCP_HIP_TRY(ctx, ctx->top_frame.ensure(kTopM * sn + 4));
   PCP_HIP_TRY(ctx, ctx->view_count.ensure(sn + 4));
-  PCP_HIP_TRY(ctx, ctx->rgba_sorted.ensure(sn + 4));
   PCP_HIP_TRY(ctx, ctx->rgba2[0].ensure(sn + 4));
   PCP_HIP_TRY(ctx, ctx->rgba2[1].ensure(sn + 4));
   return PCP_OK;
@@ -934,7 +935,21 @@ int pcp_colour_reset(pcp_context *ctx) {
   return PCP_OK;
 }
 
-static int colour_pass_impl(pcp_context *ctx, int32_t frame_begin, int32_t frame_end, bool one_shot) {
+// next result buffer (input order); if an asynchronous download still reads it, the kernels wait
+// for that copy only
+static int begin_result(pcp_context *ctx, uint32_t **dst) {
+  const int32_t cur = ctx->rgba_cur ^ 1;
+  PCP_HIP_TRY(ctx, ctx->rgba2[cur].ensure(static_cast<size_t>(ctx->n) + 4));
+  if (ctx->copy_pending[cur]) {
+    PCP_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->copy_done[cur], 0));
+    ctx->copy_pending[cur] = false;
+  }
+  *dst = ctx->rgba2[cur].p;
+  return PCP_OK;
+}
+
+static int colour_pass_impl(pcp_context *ctx, int32_t frame_begin, int32_t frame_end, bool one_shot,
+                            uint32_t *result = nullptr) {
   int rc = check_ready(ctx, "pcp_colour_pass", true);
   if (rc != PCP_OK) return rc;
   if (frame_begin < 0 || frame_end > ctx->n_frames || frame_begin > frame_end)
@@ -947,7 +962,9 @@ static int colour_pass_impl(pcp_context *ctx, int32_t frame_begin, int32_t frame
       return set_error(ctx, PCP_ERR_STATE, "pcp_colour_pass: no image uploaded for keyframe %d", f);
   }
   if ((rc = ensure_state(ctx)) != PCP_OK) return rc;
-  if (ctx->n == 0 || frame_begin == frame_end) {
+  if (ctx->n == 0) return PCP_OK;
+  if (frame_begin == frame_end) {
+    if (one_shot && result) PCP_HIP_TRY(ctx, hipMemsetAsync(result, 0, static_cast<size_t>(ctx->n) * 4, ctx->stream));
     return PCP_OK;
   }
   const size_t plane = plane_of(ctx);
@@ -963,7 +980,7 @@ static int colour_pass_impl(pcp_context *ctx, int32_t frame_begin, int32_t frame
     hipLaunchKernelGGL(k_colour_pass, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
                        ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, ctx->n, ctx->dcam, ctx->frames.p, frame_begin,
                        frame_end, ctx->depth.p, cells_of(ctx), ctx->tile_mask.p, ctx->mask_words, ctx->images.p,
-                       static_cast<int64_t>(ctx->dcam.img_w) * ctx->dcam.img_h, st, ctx->rgba_sorted.p, flags);
+                       static_cast<int64_t>(ctx->dcam.img_w) * ctx->dcam.img_h, st, ctx->perm.p, result, flags);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   if (!one_shot) ctx->colour_state_live = true;
@@ -974,21 +991,10 @@ int pcp_colour_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
   return colour_pass_impl(ctx, frame_begin, frame_end, false);
 }
 
-static int publish_result(pcp_context *ctx, uint8_t *out_rgb, uint8_t *out_has) {
+static int end_result(pcp_context *ctx, uint8_t *out_rgb, uint8_t *out_has) {
   const int64_t n = ctx->n;
-  // next result buffer; if an asynchronous download still reads it, the kernels wait for that copy only
   const int32_t cur = ctx->rgba_cur ^ 1;
-  if (ctx->copy_pending[cur]) {
-    PCP_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->copy_done[cur], 0));
-    ctx->copy_pending[cur] = false;
-  }
   uint32_t *dst = ctx->rgba2[cur].p;
-  if (n > 0) {
-    LaunchTimer t(ctx, PCP_K_MISC);
-    hipLaunchKernelGGL(k_scatter_u32, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, ctx->rgba_sorted.p, ctx->perm.p,
-                       n, dst);
-    PCP_HIP_TRY(ctx, hipGetLastError());
-  }
   PCP_HIP_TRY(ctx, hipEventRecord(ctx->result_ready[cur], ctx->stream));
   ctx->rgba_cur = cur;
   ctx->colour_result_live = true;
@@ -1016,9 +1022,11 @@ int pcp_colour_finalise(pcp_context *ctx, uint8_t *out_rgb, uint8_t *out_has, in
   const int64_t n = ctx->n;
   if ((rc = ensure_state(ctx)) != PCP_OK) return rc;
   const size_t sn = static_cast<size_t>(n);
+  uint32_t *result = nullptr;
+  if ((rc = begin_result(ctx, &result)) != PCP_OK) return rc;
   if (!ctx->colour_state_live && n > 0) {
     // no keyframe processed: empty lists
-    PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->rgba_sorted.p, 0, sn * 4, ctx->stream));
+    PCP_HIP_TRY(ctx, hipMemsetAsync(result, 0, sn * 4, ctx->stream));
     if ((rc = fill_u32(ctx, reinterpret_cast<uint32_t *>(ctx->top_score.p), kTopM * n, 0xbf800000u)) != PCP_OK) return rc;
     PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->top_rgb.p, 0, kTopM * sn * 4, ctx->stream));
     PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->top_frame.p, 0xff, kTopM * sn * 4, ctx->stream));
@@ -1026,10 +1034,10 @@ int pcp_colour_finalise(pcp_context *ctx, uint8_t *out_rgb, uint8_t *out_has, in
   } else if (n > 0) {
     TopState st{ctx->top_score.p, ctx->top_rgb.p, ctx->top_frame.p, ctx->view_count.p};
     LaunchTimer t(ctx, PCP_K_COLOUR);
-    hipLaunchKernelGGL(k_finalise, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, n, st, ctx->rgba_sorted.p);
+    hipLaunchKernelGGL(k_finalise, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, n, st, ctx->perm.p, result);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
-  if ((rc = publish_result(ctx, out_rgb, out_has)) != PCP_OK) return rc;
+  if ((rc = end_result(ctx, out_rgb, out_has)) != PCP_OK) return rc;
   if ((out_count || out_top_score || out_top_rgb || out_top_frame) && n > 0) {
     std::vector<int32_t> perm(sn), cnt;
     std::vector<uint32_t> tmp(kTopM * sn);
@@ -1060,16 +1068,20 @@ int pcp_colorize(pcp_context *ctx, uint8_t *out_rgb, uint8_t *out_has) {
   if (rc != PCP_OK) return rc;
   pcp_colour_reset(ctx);
   if ((rc = pcp_depth_pass(ctx, 0, ctx->n_frames)) != PCP_OK) return rc;
-  if ((rc = colour_pass_impl(ctx, 0, ctx->n_frames, true)) != PCP_OK) return rc;
-  return publish_result(ctx, out_rgb, out_has);
+  uint32_t *result = nullptr;
+  if ((rc = begin_result(ctx, &result)) != PCP_OK) return rc;
+  if ((rc = colour_pass_impl(ctx, 0, ctx->n_frames, true, result)) != PCP_OK) return rc;
+  return end_result(ctx, out_rgb, out_has);
 }
 
 int pcp_colorize_from_depth(pcp_context *ctx, uint8_t *out_rgb, uint8_t *out_has) {
   int rc = check_ready(ctx, "pcp_colorize_from_depth", true);
   if (rc != PCP_OK) return rc;
   pcp_colour_reset(ctx);
-  if ((rc = colour_pass_impl(ctx, 0, ctx->n_frames, true)) != PCP_OK) return rc;
-  return publish_result(ctx, out_rgb, out_has);
+  uint32_t *result = nullptr;
+  if ((rc = begin_result(ctx, &result)) != PCP_OK) return rc;
+  if ((rc = colour_pass_impl(ctx, 0, ctx->n_frames, true, result)) != PCP_OK) return rc;
+  return end_result(ctx, out_rgb, out_has);
 }
 
 int pcp_download_result_packed(pcp_context *ctx, uint32_t *out_rgba) {

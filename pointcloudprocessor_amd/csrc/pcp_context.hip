@@ -374,7 +374,6 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->top_rgb.release();
   ctx->top_frame.release();
   ctx->view_count.release();
-  ctx->rgba_sorted.release();
   ctx->rgba2[0].release();
   ctx->rgba2[1].release();
   for (int k = 0; k < 2; ++k) {

@@ -129,7 +129,6 @@ struct pcp_context {
   pcp::DevBuf<uint32_t> top_rgb;    // 5*n
   pcp::DevBuf<int32_t> top_frame;   // 5*n
   pcp::DevBuf<int32_t> view_count;  // n
-  pcp::DevBuf<uint32_t> rgba_sorted;  // n, Morton order
   // packed results in input order, double-buffered so that the device-to-host copy of one
   // run (copy stream) overlaps the kernels of the next
   pcp::DevBuf<uint32_t> rgba2[2];

@@ -197,3 +197,35 @@ def test_errors_are_loud(gpu_ctx_factory, small_scene):
     with pytest.raises(capi.PcpError) as e:
         ctx.colour_pass()
     assert e.value.code == capi.PCP_ERR_STATE
+
+
+def test_optimised_extrinsic_branches(gpu_ctx_factory, oracle, small_scene):
+    """T_camera_lidar_optimized: one global matrix (NID branch, PointCloudProcessor.cpp:504-509)
+    and one per keyframe (manual-guess branch, :510-519): general fp32 affine inverse."""
+    from pointcloudprocessor_amd import capi
+
+    rng = np.random.default_rng(2)
+
+    def small_T():
+        a = rng.normal(0, 0.01, 3)
+        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        T = np.eye(4)
+        T[:3, :3] = np.eye(3) + K + 0.5 * K @ K
+        T[:3, 3] = rng.normal(0, 0.03, 3)
+        return T
+
+    F = len(small_scene["poses"])
+    cd = small_scene["cam"]
+    for T_opt in (small_T(), np.stack([small_T() for _ in range(F)])):
+        ctx = gpu_ctx_factory()
+        ctx.set_camera(cam_struct(capi, cd))
+        ctx.upload_cloud(small_scene["x"], small_scene["y"], small_scene["z"])
+        ctx.set_frames(small_scene["poses"], T_opt=T_opt)
+        for f, im in enumerate(small_scene["images"]):
+            ctx.upload_image(f, im)
+        got = ctx.colorize()
+        ref = oracle.colorize(cam_struct(oracle, cd), oracle.default_cull_params(), small_scene["x"], small_scene["y"],
+                              small_scene["z"], small_scene["poses"], small_scene["images"], T_opt=T_opt)
+        assert np.array_equal(got["rgb"], ref["rgb"]) and np.array_equal(got["has"], ref["has"])
+        assert ref["has"].sum() > 300
+        ctx.close()
