@@ -94,6 +94,8 @@ def main():
     eng.ctx.synchronize()
     t_setup = time.time() - t_setup
 
+    if dist is not None:
+        eng.use_torch_stream()  # kernels and RCCL ordered by streams / events, no host sync in a step
     col = pipeline.PointCloudColorizer(eng, rank, world if not args.force_dist else max(world, 2))
     col.rank = rank
     # two pinned landing buffers: the device-to-host copy of step i (copy stream) overlaps the

@@ -58,16 +58,30 @@ class HipEngine:
                 if m is not None:
                     self.ctx.upload_mask(f, m)
 
+    def use_torch_stream(self):
+        """Run the library's kernels on torch's current HIP stream: the collective is then
+        stream-ordered against them (RCCL waits on / is waited for through events), with no
+        host synchronisation between the depth pass, the all-reduce and the colour pass."""
+        import torch
+
+        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self._on_torch_stream = True
+
     # hooks used by the sharded driver
-    def depth_pass(self):
-        self.ctx.depth_pass()
+    @property
+    def n_frames(self):
+        return self.ctx.n_frames
+
+    def depth_pass(self, f0: int = 0, f1: int | None = None):
+        self.ctx.depth_pass(f0, f1)
 
     def depth_maps_tensor(self):
         """torch view (no copy) of the device-resident depth maps, for RCCL."""
         import torch
 
         ptr, n = self.ctx.depth_maps_device()
-        self.ctx.synchronize()
+        if not getattr(self, "_on_torch_stream", False):
+            self.ctx.synchronize()
         return torch.as_tensor(_DeviceArray(ptr, n), device=f"cuda:{self.device}")
 
     def colour_from_depth(self, download=True):
@@ -92,25 +106,40 @@ class ViewCulling:
 class PointCloudColorizer:
     """pcdColorizationAndSmooth over a (possibly sharded) map."""
 
-    def __init__(self, engine, rank: int = 0, world: int = 1, group=None):
+    def __init__(self, engine, rank: int = 0, world: int = 1, group=None, chunks: int = 4):
         self.engine = engine
         self.rank = rank
         self.world = world
         self.group = group
+        self.chunks = chunks
 
     def run(self, download: bool = True):
-        """Local points' colours: dict(rgb (n,3) uint8, has (n,) uint8)."""
-        self.engine.depth_pass()
-        if self.world > 1:
-            import torch.distributed as dist
+        """Local points' colours: dict(rgb (n,3) uint8, has (n,) uint8).
 
-            t = self.engine.depth_maps_tensor()
+        Multi-rank: the keyframes are split into `chunks` groups; the all-reduce(MIN) of one
+        group's depth maps (RCCL stream) overlaps the depth pass of the next group."""
+        if self.world == 1:
+            self.engine.depth_pass()
+            return self.engine.colour_from_depth(download=download)
+        import torch.distributed as dist
+
+        F = self.engine.n_frames
+        t = self.engine.depth_maps_tensor()
+        cells = t.numel() // max(F, 1)
+        bounds = sorted({(F * c) // self.chunks for c in range(self.chunks + 1)})
+        works = []
+        for f0, f1 in zip(bounds[:-1], bounds[1:]):
+            self.engine.depth_pass(f0, f1)
+            if not getattr(self.engine, "_on_torch_stream", False) and t.is_cuda:
+                self.engine.ctx.synchronize()
             # ranges are positive finite floats: float MIN == the uint-bits MIN the kernel used
-            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
-            if t.is_cuda:
-                import torch
+            works.append(dist.all_reduce(t[f0 * cells:f1 * cells], op=dist.ReduceOp.MIN, group=self.group, async_op=True))
+        for w in works:
+            w.wait()  # stream-level wait on GPUs, blocking on gloo
+        if t.is_cuda and not getattr(self.engine, "_on_torch_stream", False):
+            import torch
 
-                torch.cuda.current_stream().synchronize()
+            torch.cuda.current_stream().synchronize()
         return self.engine.colour_from_depth(download=download)
 
     def gather(self, local: dict, n_total: int):

@@ -22,20 +22,32 @@ class OracleEngine:
         self.depth = None
         self.proj = None
 
-    def depth_pass(self):
+    @property
+    def n_frames(self):
+        return len(self.poses)
+
+    def depth_pass(self, f0=0, f1=None):
         from oracle import np_oracle as npo
 
-        maps, self.proj = [], []
-        for pose in self.poses:
-            w2c, _ = npo.pose_to_matrices(pose)
+        f1 = len(self.poses) if f1 is None else f1
+        self._alloc()
+        cells = self.depth.size // len(self.poses)
+        for f in range(f0, f1):
+            w2c, _ = npo.pose_to_matrices(self.poses[f])
             _, dmap, p = npo.cull_frame(self.cam, w2c, self.x, self.y, self.z)
-            maps.append(dmap.reshape(-1))
-            self.proj.append(p)
-        self.depth = np.ascontiguousarray(np.concatenate(maps).astype(np.float32))
+            self.depth[f * cells:(f + 1) * cells] = dmap.reshape(-1)
+            self.proj[f] = p
+
+    def _alloc(self):
+        if self.depth is None:
+            mw, mh = self.cam["cull_width"] // 14, self.cam["cull_height"] // 14
+            self.depth = np.zeros(len(self.poses) * mw * mh, np.float32)
+            self.proj = [None] * len(self.poses)
 
     def depth_maps_tensor(self):
         import torch
 
+        self._alloc()
         return torch.from_numpy(self.depth)  # shares memory: the all-reduce lands in self.depth
 
     def colour_from_depth(self, download=True):
