@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--cpu-points", type=int, default=1_000_000)
     ap.add_argument("--cpu-frames", type=int, default=16)
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even at world size 1")
+    ap.add_argument("--dist-chunks", type=int, default=2, help="keyframe groups whose all-reduce overlaps the next depth pass")
     return ap.parse_args()
 
 
@@ -96,7 +97,7 @@ def main():
 
     if dist is not None:
         eng.use_torch_stream()  # kernels and RCCL ordered by streams / events, no host sync in a step
-    col = pipeline.PointCloudColorizer(eng, rank, world if not args.force_dist else max(world, 2))
+    col = pipeline.PointCloudColorizer(eng, rank, world if not args.force_dist else max(world, 2), chunks=args.dist_chunks)
     col.rank = rank
     # two pinned landing buffers: the device-to-host copy of step i (copy stream) overlaps the
     # kernels of step i + 1; every step's colours are on the host when the timed region ends

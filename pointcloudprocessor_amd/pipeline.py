@@ -82,7 +82,10 @@ class HipEngine:
         ptr, n = self.ctx.depth_maps_device()
         if not getattr(self, "_on_torch_stream", False):
             self.ctx.synchronize()
-        return torch.as_tensor(_DeviceArray(ptr, n), device=f"cuda:{self.device}")
+        cached = getattr(self, "_depth_tensor", None)
+        if cached is None or cached[0] != (ptr, n):
+            self._depth_tensor = ((ptr, n), torch.as_tensor(_DeviceArray(ptr, n), device=f"cuda:{self.device}"))
+        return self._depth_tensor[1]
 
     def colour_from_depth(self, download=True):
         return self.ctx.colorize_from_depth(download=download)
