@@ -8,10 +8,10 @@
 // hpp:151-191), trajectory crop (:92-136), PCD reading / ASCII writing.  Hot path on the
 // GPU through pcp_shim.hpp.
 //
-// Differences, all forced by what this image can decode (no OpenCV / libjpeg / libpng):
-//   * a keyframe's image is <images_folder><ts>.ppm (binary P6, stored BGR or RGB ->
-//     see --ppm_is_bgr) when <ts>.jpg cannot be decoded here; masks are <ts>.pgm (P5).
-//     The real binary keeps cv::imread and hands the decoded cv::Mat to the shim.
+// Differences (this image has no OpenCV):
+//   * images are decoded by host/image_io.hpp: <images_folder><ts>.jpg (baseline JPEG, libjpeg's
+//     arithmetic, bit-exact with Pillow / libjpeg-turbo here) and masks <mask_folder><ts>.png;
+//     <ts>.ppm / <ts>.pgm are accepted when the .jpg / .png is absent.
 //   * the 8-bit BGR->HSV->BGR round trip of generateColorMap (:722-741, Appendix B5) is
 //     not applied (pixels are taken as already adjusted).
 //   * --enableNIDOptimize runs the NID cost on the GPU with a BFGS on SE(3) in place of
@@ -28,6 +28,7 @@
 #include <memory>
 #include <sstream>
 
+#include "image_io.hpp"
 #include "pcd_io.hpp"
 #include "pcp_shim.hpp"
 
@@ -45,7 +46,6 @@ struct Options {
   bool have_p = false, have_o = false, have_i = false;
   bool enableMLS = false, enableNIDOptimize = false, enableInitialGuessManual = false;
   bool help = false;
-  bool ppm_is_bgr = false;
   bool skip_filtered_dumps = false;
 };
 
@@ -82,7 +82,6 @@ static Options parse(int argc, char **argv) {
     else if (a == "--enableMLS") o.enableMLS = parse_bool(next());
     else if (a == "--enableNIDOptimize") o.enableNIDOptimize = parse_bool(next());
     else if (a == "--enableInitialGuessManual") o.enableInitialGuessManual = parse_bool(next());
-    else if (a == "--ppm_is_bgr") o.ppm_is_bgr = parse_bool(next());
     else if (a == "--skip_filtered_dumps") o.skip_filtered_dumps = parse_bool(next());
     else throw std::runtime_error("unrecognised option '" + a + "'");
   }
@@ -100,39 +99,6 @@ static void usage(std::ostream &os) {
         "  --enableMLS arg (=0)                  Enable MLS smoothing\n"
         "  --enableNIDOptimize arg (=0)          Enable NID-based camera pose optimization\n"
         "  --enableInitialGuessManual arg (=0)   Enable manual pickup point based camera pose optimization\n";
-}
-
-// binary PPM (P6) / PGM (P5), maxval 255
-static bool read_pnm(const std::string &path, int expect_channels, int &w, int &h, std::vector<uint8_t> &px) {
-  std::ifstream in(path, std::ios::binary);
-  if (!in) return false;
-  std::string magic;
-  in >> magic;
-  if ((expect_channels == 3 && magic != "P6") || (expect_channels == 1 && magic != "P5")) return false;
-  auto next_int = [&]() {
-    int v = 0;
-    for (;;) {
-      int c = in.peek();
-      if (c == '#') {
-        std::string skip;
-        std::getline(in, skip);
-      } else if (std::isspace(c)) {
-        in.get();
-      } else {
-        break;
-      }
-    }
-    in >> v;
-    return v;
-  };
-  w = next_int();
-  h = next_int();
-  const int maxv = next_int();
-  in.get();
-  if (w <= 0 || h <= 0 || maxv != 255) return false;
-  px.resize(static_cast<size_t>(w) * h * expect_channels);
-  in.read(reinterpret_cast<char *>(px.data()), static_cast<std::streamsize>(px.size()));
-  return static_cast<bool>(in);
 }
 
 class Processor {
@@ -174,11 +140,14 @@ class Processor {
       f.pose = {x, y, z, qw, qx, qy, qz};
       f.imageTimestamp = ts;
       const std::string stem = opt.imagesFolder + std::to_string(ts);  // "%f": 6 decimals (:981)
-      if (fs::exists(stem + ".jpg") && !fs::exists(stem + ".ppm"))
-        throw std::runtime_error("cannot decode " + stem + ".jpg in this build (no OpenCV): provide " + stem + ".ppm");
-      f.imagePath = stem + ".ppm";
-      if (!fs::exists(f.imagePath)) continue;  // skip this frame if its image does not exist
-      if (enableMaskSegmentation) f.maskImagePath = opt.maskImageFolder + std::to_string(ts) + ".pgm";
+      f.imagePath = stem + ".jpg";
+      if (!fs::exists(f.imagePath)) f.imagePath = stem + ".ppm";
+      if (!fs::exists(f.imagePath)) continue;  // skip this frame if its image does not exist (:984-987)
+      if (enableMaskSegmentation) {
+        f.maskImagePath = opt.maskImageFolder + std::to_string(ts) + ".png";  // :991
+        if (!fs::exists(f.maskImagePath) && fs::exists(opt.maskImageFolder + std::to_string(ts) + ".pgm"))
+          f.maskImagePath = opt.maskImageFolder + std::to_string(ts) + ".pgm";
+      }
       frames.push_back(f);
     }
   }
@@ -272,9 +241,12 @@ class Processor {
     if (!gpu) gpu.reset(new Device(0));
     gpu->uploadCloud(cloud.x.data(), cloud.y.data(), cloud.z.data(), static_cast<int64_t>(cloud.size()));
     // image size from the first keyframe image; cull size stays the reference's {4096,3000} (:206,:525)
-    std::vector<uint8_t> px;
-    if (!keyframes.empty() && !read_pnm(keyframes[0].imagePath, 3, img_w, img_h, px))
-      throw std::runtime_error("Failed to read image from: " + keyframes[0].imagePath);
+    if (!keyframes.empty()) {
+      const Image8 first = read_image_bgr(keyframes[0].imagePath);
+      if (first.empty()) throw std::runtime_error("Failed to read image from: " + keyframes[0].imagePath);
+      img_w = first.width;
+      img_h = first.height;
+    }
     pcp_camera cam;
     pcp_default_camera(&cam);
     if (!keyframes.empty()) {
@@ -337,29 +309,17 @@ class Processor {
 
   void uploadImages() {
     if (images_uploaded) return;
-    std::vector<uint8_t> px, bgr;
     for (size_t k = 0; k < keyframes.size(); ++k) {
-      int w = 0, h = 0;
       std::cout << "Reading image from: " << keyframes[k].imagePath << std::endl;
-      if (!read_pnm(keyframes[k].imagePath, 3, w, h, px) || w != img_w || h != img_h)
+      const Image8 img = read_image_bgr(keyframes[k].imagePath);  // cv::imread, :716
+      if (img.empty() || img.width != img_w || img.height != img_h)
         throw std::runtime_error("Failed to read image from: " + keyframes[k].imagePath);
-      if (!opt.ppm_is_bgr) {  // PPM stores RGB; the boundary takes BGR like cv::Mat
-        bgr.resize(px.size());
-        for (size_t i = 0; i + 2 < px.size(); i += 3) {
-          bgr[i] = px[i + 2];
-          bgr[i + 1] = px[i + 1];
-          bgr[i + 2] = px[i];
-        }
-        gpu->uploadImage(static_cast<int>(k), bgr.data(), static_cast<int64_t>(w) * 3);
-      } else {
-        gpu->uploadImage(static_cast<int>(k), px.data(), static_cast<int64_t>(w) * 3);
-      }
+      gpu->uploadImage(static_cast<int>(k), img.data.data(), static_cast<int64_t>(img.width) * 3);
       if (enableMaskSegmentation) {
-        std::vector<uint8_t> gray;
-        int mw = 0, mh = 0;
         std::cout << "Reading segment mask image from: " << keyframes[k].maskImagePath << std::endl;
-        if (read_pnm(keyframes[k].maskImagePath, 1, mw, mh, gray) && mw == img_w && mh == img_h)
-          gpu->uploadMask(static_cast<int>(k), gray.data(), mw);
+        const Image8 gray = read_image_gray(keyframes[k].maskImagePath);  // cv::IMREAD_GRAYSCALE, :775
+        if (!gray.empty() && gray.width == img_w && gray.height == img_h)
+          gpu->uploadMask(static_cast<int>(k), gray.data.data(), gray.width);
         else
           std::cout << "Failed to read image from: " << keyframes[k].maskImagePath << std::endl;  // :779, not fatal
       }

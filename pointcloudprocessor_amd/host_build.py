@@ -12,6 +12,7 @@ BIN = os.path.join(HOST, "bin")
 TARGETS = {
     "pcp_shim_selftest": ["shim_selftest.cpp"],
     "PointCloudProcessor": ["main.cpp"],
+    "image_dump": ["image_dump.cpp"],
 }
 
 
@@ -20,14 +21,14 @@ def build(force: bool = False) -> dict:
     out = {}
     for name, srcs in TARGETS.items():
         exe = os.path.join(BIN, name)
-        deps = [os.path.join(HOST, s) for s in srcs] + [os.path.join(HOST, "pcp_shim.hpp"), os.path.join(HOST, "pcd_io.hpp"),
+        deps = [os.path.join(HOST, s) for s in srcs] + [os.path.join(HOST, "pcp_shim.hpp"), os.path.join(HOST, "pcd_io.hpp"), os.path.join(HOST, "image_io.hpp"),
                                                        os.path.join(_build.INCLUDE, "pcp_hip.h")]
         deps = [d for d in deps if os.path.exists(d)]
         stale = force or not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps)
         if stale:
             cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-I", _build.INCLUDE, "-I", HOST] + [
                 os.path.join(HOST, s) for s in srcs] + ["-L", _build.LIB_DIR, "-lpcp_hip",
-                                                        "-Wl,-rpath,$ORIGIN/../../lib", "-o", exe]
+                                                        "-lz", "-Wl,-rpath,$ORIGIN/../../lib", "-o", exe]
             proc = subprocess.run(cmd, capture_output=True, text=True)
             if proc.returncode != 0:
                 raise RuntimeError(f"g++ failed for {name}:\n{proc.stderr[-3000:]}")

@@ -99,14 +99,15 @@ def test_cli_end_to_end_matches_oracle(tmp_path, oracle):
             f.write("%.6f %.6f %.6f %.6f %.8f %.8f %.8f %.8f\n" % (t, *p))
             if k == 3:
                 continue  # no image for this pose: the frame is skipped (PointCloudProcessor.cpp:984-987)
-            img = synth.make_image(k, W, H)  # BGR
-            imgs[k] = img
-            with open(tmp_path / ("%f.ppm" % t), "wb") as g:
-                g.write(b"P6\n%d %d\n255\n" % (W, H) + img[:, :, ::-1].tobytes())  # PPM is RGB
+            # the reference's inputs: <ts>.jpg and <ts>.png; the oracle gets the decoded pixels
+            # (Pillow == libjpeg-turbo, which tests/test_image_io.py pins the C++ decoder to)
+            from PIL import Image
+
+            Image.fromarray(synth.make_image(k, W, H)[:, :, ::-1]).save(tmp_path / ("%f.jpg" % t), quality=92)
+            imgs[k] = np.ascontiguousarray(np.array(Image.open(tmp_path / ("%f.jpg" % t)).convert("RGB"))[:, :, ::-1])
             m = synth.make_mask(k, W, H)
             masks[k] = m
-            with open(tmp_path / ("%f.pgm" % t), "wb") as g:
-                g.write(b"P5\n%d %d\n255\n" % (W, H) + m.tobytes())
+            Image.fromarray(m).save(tmp_path / ("%f.png" % t))
         f.write("garbage line stops the parser\n")
         f.write("%.6f 0 0 0 1 0 0 0\n" % (ts[-1] + 1))
     out = str(tmp_path) + "/"
