@@ -262,3 +262,31 @@ def test_cull_parameter_variants(gpu_ctx_factory, oracle, small_scene, ds, slack
                           small_scene["images"])
     assert np.array_equal(got["rgb"], ref["rgb"]) and np.array_equal(got["has"], ref["has"])
     ctx.close()
+
+
+def test_non_finite_points_are_rejected_not_fatal(gpu_ctx_factory, oracle, small_scene):
+    """PCL clouds may carry NaN / inf points (is_dense == false): they never project
+    (z > 0 is false / projection not finite) and must not disturb their neighbours."""
+    from pointcloudprocessor_amd import capi
+
+    x, y, z = (small_scene[k].copy() for k in "xyz")
+    x[10], y[200], z[3000] = np.nan, np.inf, -np.inf
+    x[4000] = y[4000] = z[4000] = np.nan
+    z[5000] = 3.0e38
+    cd = small_scene["cam"]
+    ctx = gpu_ctx_factory()
+    ctx.set_camera(cam_struct(capi, cd))
+    ctx.upload_cloud(x, y, z)
+    ctx.set_frames(small_scene["poses"])
+    for f, im in enumerate(small_scene["images"]):
+        ctx.upload_image(f, im)
+    got = ctx.colorize()
+    ref = oracle.colorize(cam_struct(oracle, cd), oracle.default_cull_params(), x, y, z, small_scene["poses"],
+                          small_scene["images"])
+    assert np.array_equal(got["rgb"], ref["rgb"]) and np.array_equal(got["has"], ref["has"])
+    assert not got["has"][[10, 200, 3000, 4000]].any()
+    w2c, _ = oracle.pose_to_matrices(small_scene["poses"][1])
+    p_ref = oracle.project_frame(cam_struct(oracle, cd), oracle.default_cull_params(), w2c, x, y, z)
+    p_got = ctx.project_frame(1)
+    assert np.array_equal(p_got["cell"], p_ref["cell"]) and np.array_equal(p_got["pixel"], p_ref["pixel"])
+    ctx.close()
