@@ -58,6 +58,9 @@ def parse():
 
 def main():
     args = parse()
+    # stdout carries the one JSON line only: libraries that print banners (RCCL, rocprofv3) go to stderr
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -75,6 +78,8 @@ def main():
     if world > 1 or args.force_dist:
         import torch.distributed as dist
 
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29511")):
+            os.environ.setdefault(k, v)  # --force-dist outside torch.distributed.run
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     from pointcloudprocessor_amd import capi, pipeline, synth
@@ -172,7 +177,7 @@ def main():
         }
         # ---- MLS leg (Mpoints/s at r = 0.03, order 2, NONE upsampling) ----
         mls = None
-        if not args.no_mls:
+        if not args.no_mls and world == 1:  # side legs (MLS, CPU baseline) run at N = 1 only
             try:
                 mp = capi.default_mls_params()
                 mp.upsampling = 0
@@ -212,7 +217,7 @@ def main():
                 mls = {"error": str(e)}
         # ---- CPU baseline: the oracle on a bounded sample, all host cores ----
         cpu = None
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:
             from oracle import oracle_capi as oc
 
             ocam = oc.Camera()
@@ -287,7 +292,9 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
+    os.close(json_fd)
     eng.close()
 
 

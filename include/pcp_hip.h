@@ -240,6 +240,13 @@ int pcp_timing_get(pcp_context *ctx, int32_t kernel_id, double *total_ms, int64_
 const char *pcp_kernel_name(int32_t kernel_id);
 /* diagnostic: fraction of (tile, keyframe) pairs the conservative culling keeps (after pcp_depth_pass) */
 int pcp_tile_mask_density(pcp_context *ctx, double *kept_fraction);
+/* diagnostic: the kernels replace three IEEE divisions of the projection (pinhole.hpp:17-18 x/z, y/z in fp64;
+ * view_culling.cpp:88 u/14, v/14 in fp32) by shorter sequences that are proven to return the same correctly
+ * rounded quotients (pcp_device.hpp).  This runs both forms on the device and counts disagreements:
+ * `samples` pseudo-random (x, y, z) float triples (all exponents, z > 0) for the fp64 pair, and EVERY fp32 bit
+ * pattern for the division by the configured downsample factor.  Both counts must be 0. */
+int pcp_selftest_arithmetic(pcp_context *ctx, int64_t samples, uint64_t seed, int64_t *mismatches_fp64,
+                            int64_t *mismatches_fp32);
 
 #ifdef __cplusplus
 }

@@ -95,7 +95,8 @@ def load(build_if_needed: bool = True) -> C.CDLL:
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = C.CDLL(_build.LIB_PATH)
+    # PCP_HIP_LIBRARY: an alternative build of the same ABI (kernel experiments); never a CPU stand-in
+    L = C.CDLL(os.environ.get("PCP_HIP_LIBRARY") or _build.LIB_PATH)
     L.pcp_last_error.restype = C.c_char_p
     L.pcp_last_error.argtypes = [C.c_void_p]
     L.pcp_kernel_name.restype = C.c_char_p
@@ -426,6 +427,12 @@ class Context:
         v = C.c_double()
         self._check(self.lib.pcp_tile_mask_density(self.h, C.byref(v)))
         return v.value
+
+    def selftest_arithmetic(self, samples: int = 1 << 26, seed: int = 1):
+        """(fp64 mismatches, fp32 mismatches) of the short exact division sequences against `/`."""
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self.lib.pcp_selftest_arithmetic(self.h, C.c_int64(samples), C.c_uint64(seed), C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def kernel_name(self, kernel_id: int) -> str:
         return self.lib.pcp_kernel_name(C.c_int32(kernel_id)).decode()

@@ -42,7 +42,7 @@ struct ProjectOut {
 __device__ __forceinline__ void project_store_one(const DevCamera &cam, const DevFrame &fr, float x, float y, float z,
                                                   int32_t &cell, int32_t &pixel, float &range, float &xc, float &yc,
                                                   float &zc) {
-  const Projected p = project_point(cam, fr.w2c, x, y, z);
+  const Projected p = project_point<true, false>(cam, fr.w2c, x, y, z);
   cell = p.cell;
   pixel = p.pixel;
   range = p.cell != -1 ? static_cast<float>(range64(p.xc, p.yc, p.zc)) : FLT_MAX;
@@ -328,7 +328,8 @@ __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict_
       const int32_t f = (w << 5) + __builtin_ctz(todo);
       todo &= todo - 1u;
       const DevFrame &fr = frames[f];
-      const Projected p = project_point(cam, fr.w2c, px, py, pz);
+      // the refined masks only keep pairs with a candidate lane: the fp32 rejection test cannot skip the wavefront
+      const Projected p = project_point<false>(cam, fr.w2c, px, py, pz);
       const bool cand = live && p.pixel >= 0 && (cam.enable_zbuf ? p.cell >= 0 : p.cell != -1);
       if (cand) {
         // both gathers are issued before anything depends on them (one latency, not two)
@@ -371,6 +372,56 @@ __global__ __launch_bounds__(kBlock) void k_finalise(int64_t n, TopState st, con
   t.f3 = st.frame[3 * n + j]; t.f4 = st.frame[4 * n + j];
   t.count = st.count[j];
   rgba[perm[j]] = t.finalise();
+}
+
+// ---------------------------------------------------------------------------
+// arithmetic self-test (pcp_selftest_arithmetic): short exact divisions vs `/`
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t v) {  // splitmix64 finaliser
+  v += 0x9e3779b97f4a7c15ull;
+  v = (v ^ (v >> 30)) * 0xbf58476d1ce4e5b9ull;
+  v = (v ^ (v >> 27)) * 0x94d049bb133111ebull;
+  return v ^ (v >> 31);
+}
+__device__ __forceinline__ bool same_f64(double a, double b) {
+  if (a != a && b != b) return true;
+  if (a == 0.0 && b == 0.0) return true;  // the sign of a zero quotient is not observable downstream
+  return __double_as_longlong(a) == __double_as_longlong(b);
+}
+
+__global__ __launch_bounds__(kBlock) void k_selftest_div64(int64_t samples, uint64_t seed,
+                                                           unsigned long long *__restrict__ bad) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= samples) return;
+  const uint64_t a = mix64(seed ^ static_cast<uint64_t>(i) * 3u), b = mix64(a);
+  uint32_t bx = static_cast<uint32_t>(a), by = static_cast<uint32_t>(a >> 32), bz = static_cast<uint32_t>(b);
+  const uint32_t mode = static_cast<uint32_t>(b >> 32) & 3u;
+  if (mode != 0u) {
+    // exponents of a metre-scale scene (mode 0 keeps the raw patterns: every exponent, NaN, inf, denormals)
+    const uint32_t span = mode == 1u ? 12u : 40u;
+    bx = (bx & 0x807fffffu) | ((127u - span / 2u + (bx >> 23) % span) << 23);
+    by = (by & 0x807fffffu) | ((127u - span / 2u + (by >> 23) % span) << 23);
+    bz = (bz & 0x807fffffu) | ((127u - span / 2u + (bz >> 23) % span) << 23);
+  }
+  const float xc = __uint_as_float(bx), yc = __uint_as_float(by), zc = fabsf(__uint_as_float(bz));
+  if (!(zc > 0.0f)) return;  // the projection is only entered with z > 0
+  double xn, yn;
+  divide_xy_by_z(xc, yc, zc, xn, yn);
+  const double xr = static_cast<double>(xc) / static_cast<double>(zc);
+  const double yr = static_cast<double>(yc) / static_cast<double>(zc);
+  if (!same_f64(xn, xr) || !same_f64(yn, yr)) atomicAdd(bad, 1ull);
+}
+
+__global__ __launch_bounds__(kBlock) void k_selftest_div32(DevCamera cam, unsigned long long *__restrict__ bad) {
+  // 2^32 bit patterns: 2^24 lanes x 256 patterns each
+  const uint32_t lane = blockIdx.x * kBlock + threadIdx.x;
+  uint32_t wrong = 0u;
+  for (uint32_t k = 0; k < 256u; ++k) {
+    const float x = __uint_as_float((k << 24) | lane);
+    const float a = div_by_ds(cam, x), b = x / cam.ds_f;
+    if (!((a != a && b != b) || __float_as_uint(a) == __float_as_uint(b))) ++wrong;
+  }
+  if (wrong) atomicAdd(bad, static_cast<unsigned long long>(wrong));
 }
 
 // ---------------------------------------------------------------------------
@@ -1130,6 +1181,27 @@ int pcp_colour_result_device(pcp_context *ctx, void **device_ptr, int64_t *n_wor
     return set_error(ctx, PCP_ERR_STATE, "pcp_colour_result_device: no result (call pcp_colorize / pcp_colour_finalise)");
   if (device_ptr) *device_ptr = ctx->rgba2[ctx->rgba_cur].p;
   if (n_words) *n_words = ctx->n;
+  return PCP_OK;
+}
+
+int pcp_selftest_arithmetic(pcp_context *ctx, int64_t samples, uint64_t seed, int64_t *mismatches_fp64,
+                            int64_t *mismatches_fp32) {
+  if (!ctx) return PCP_ERR_INVALID;
+  if (!ctx->have_camera) return set_error(ctx, PCP_ERR_STATE, "pcp_selftest_arithmetic: pcp_set_camera has not been called");
+  PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (samples < 0) return set_error(ctx, PCP_ERR_INVALID, "pcp_selftest_arithmetic: negative sample count");
+  PCP_HIP_TRY(ctx, ctx->s_counter.ensure(4));
+  unsigned long long *bad = ctx->s_counter.p;
+  PCP_HIP_TRY(ctx, hipMemsetAsync(bad, 0, 16, ctx->stream));
+  if (samples > 0)
+    hipLaunchKernelGGL(k_selftest_div64, dim3(blocks_for(samples)), dim3(kBlock), 0, ctx->stream, samples, seed, bad);
+  hipLaunchKernelGGL(k_selftest_div32, dim3((1u << 24) / kBlock), dim3(kBlock), 0, ctx->stream, ctx->dcam, bad + 1);
+  PCP_HIP_TRY(ctx, hipGetLastError());
+  unsigned long long h[2] = {0, 0};
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(h, bad, 16, hipMemcpyDeviceToHost, ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (mismatches_fp64) *mismatches_fp64 = static_cast<int64_t>(h[0]);
+  if (mismatches_fp32) *mismatches_fp32 = static_cast<int64_t>(h[1]);
   return PCP_OK;
 }
 

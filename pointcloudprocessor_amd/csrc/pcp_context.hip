@@ -338,7 +338,14 @@ int pcp_create(int32_t device, pcp_context **out) {
     return PCP_ERR_DEVICE;
   }
   ctx->stream = ctx->own_stream;
-  e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+  {
+    // The download stream gets the highest stream priority: HIP pools its hardware queues per priority,
+    // so the device-to-host copies never share a queue with (and serialise behind) the compute stream,
+    // whichever stream pcp_set_stream later names and however many streams the host program owns.
+    int prio_least = 0, prio_greatest = 0;
+    e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, prio_greatest);
+  }
   for (int k = 0; k < 2 && e == hipSuccess; ++k) {
     e = hipEventCreateWithFlags(&ctx->result_ready[k], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->copy_done[k], hipEventDisableTiming);
@@ -496,6 +503,9 @@ int pcp_set_camera(pcp_context *ctx, const pcp_camera *cam, const pcp_cull_param
   d.slack = cp.depth_slack;
   d.ds = cp.downsample_factor;
   d.ds_f = static_cast<float>(cp.downsample_factor);
+  d.ds_rcp = 1.0f / d.ds_f;  // IEEE division on the host: the correctly rounded reciprocal
+  d.ds_fast = (d.ds_f >= 0x1p-20f && d.ds_f <= 0x1p20f) ? 1 : 0;
+  if (const char *e = std::getenv("PCP_DISABLE_FAST_EXACT")) d.ds_fast = (e[0] == '1') ? 0 : d.ds_fast;
   d.img_w = cam->image_width;
   d.img_h = cam->image_height;
   d.cull_w = cam->cull_width;

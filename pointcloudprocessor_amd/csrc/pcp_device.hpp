@@ -25,11 +25,44 @@ __device__ __forceinline__ void xform(const float *__restrict__ m, float x, floa
   zc = x * m[8] + (y * m[9] + (z * m[10] + m[11]));
 }
 
+// Correctly rounded X/Z and Y/Z (fp64) for operands that are promoted finite floats, Z > 0.
+// This is the compiler's own IEEE f64 division sequence (v_rcp_f64, two Newton steps on the
+// reciprocal, quotient, exact residual, one correction: the Markstein scheme LLVM emits for
+// fdiv double) with the two divisions sharing the reciprocal and with the range scaling
+// (v_div_scale / v_div_fixup) dropped: promoted floats have exponents in [-149, 128], far inside
+// the window in which those instructions pass their operands through unchanged.  The only
+// difference from the two `/` it replaces is the sign of a zero quotient, which no later
+// operation of the projection can observe.  Non-finite operands take the plain divisions.
+// pcp_selftest_arithmetic() compares both forms on the device.
+__device__ __forceinline__ void divide_xy_by_z(float xc, float yc, float zc, double &xn, double &yn) {
+  const double X = xc, Y = yc, Z = zc;
+  if ((xc - xc) + (yc - yc) + (zc - zc) == 0.0f) {  // all three finite
+    double r = __builtin_amdgcn_rcp(Z);
+    double e = __builtin_fma(-Z, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-Z, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double qx = X * r, qy = Y * r;
+    const double rx = __builtin_fma(-Z, qx, X), ry = __builtin_fma(-Z, qy, Y);
+    xn = __builtin_fma(rx, r, qx);
+    yn = __builtin_fma(ry, r, qy);
+  } else {
+    xn = X / Z;
+    yn = Y / Z;
+  }
+}
+
 // A3: PinholeProjection::operator() + distort, pinhole.hpp:13-51 (duplicate
 // PointCloudProcessor.hpp:100-123), fp64, left-to-right as written.
-__device__ __forceinline__ void project_uv(const DevCamera &c, double X, double Y, double Z, double &u, double &v) {
-  const double xn = X / Z;
-  const double yn = Y / Z;
+template <bool kShortDiv = true>
+__device__ __forceinline__ void project_uv(const DevCamera &c, float xc, float yc, float zc, double &u, double &v) {
+  double xn, yn;
+  if (kShortDiv && c.ds_fast) {
+    divide_xy_by_z(xc, yc, zc, xn, yn);
+  } else {
+    xn = static_cast<double>(xc) / static_cast<double>(zc);
+    yn = static_cast<double>(yc) / static_cast<double>(zc);
+  }
   const double x2 = xn * xn;
   const double y2 = yn * yn;
   const double r2 = x2 + y2;
@@ -45,13 +78,32 @@ __device__ __forceinline__ void project_uv(const DevCamera &c, double X, double 
   v = c.fy * yd + c.cy;
 }
 
+// Correctly rounded x / ds (fp32) by a constant divisor: with r = RN(1 / ds) precomputed,
+// q0 = RN(x r) is within 2 ulp, one residual correction makes it faithful, and a second one
+// (exact residual by FMA, Markstein's theorem: r correctly rounded, q faithful) returns
+// RN(x / ds).  The residuals are exact only away from the underflow / overflow ranges, hence
+// the magnitude window; everything else (zeros, denormals, huge, non-finite) divides plainly.
+// pcp_selftest_arithmetic() checks the window exhaustively against `/` for the configured ds.
+__device__ __forceinline__ float div_by_ds(const DevCamera &c, float x) {
+  const float ax = fabsf(x);
+  if (c.ds_fast && ax >= 0x1p-40f && ax <= 0x1p60f) {
+    float q = x * c.ds_rcp;
+    float e = __builtin_fmaf(-c.ds_f, q, x);
+    q = __builtin_fmaf(e, c.ds_rcp, q);
+    e = __builtin_fmaf(-c.ds_f, q, x);
+    return __builtin_fmaf(e, c.ds_rcp, q);
+  }
+  return x / c.ds_f;
+}
+
 // A4 cell: (project(p).cast<float>() / 14).cast<int>(), bounds vs the FULL cull
 // size (view_culling.cpp:86-90, sic) then vs the /14 map (:116,:155).
 // Returns cy*mw+cx, -1 (rejected) or, with the depth buffer off, -2 (candidate outside the map).
 // Values that do not fit an int32 (UB in the reference, Appendix B6) are rejected.
+template <bool kShortDiv = true>
 __device__ __forceinline__ int32_t cull_cell(const DevCamera &c, double u, double v) {
-  const float cxf = static_cast<float>(u) / c.ds_f;
-  const float cyf = static_cast<float>(v) / c.ds_f;
+  const float cxf = kShortDiv ? div_by_ds(c, static_cast<float>(u)) : static_cast<float>(u) / c.ds_f;
+  const float cyf = kShortDiv ? div_by_ds(c, static_cast<float>(v)) : static_cast<float>(v) / c.ds_f;
   if (!(cxf > -2147483648.0f && cxf < 2147483648.0f && cyf > -2147483648.0f && cyf < 2147483648.0f)) return -1;
   const int32_t cx = static_cast<int32_t>(cxf);
   const int32_t cy = static_cast<int32_t>(cyf);
@@ -118,16 +170,21 @@ struct Projected {
 };
 
 // transform + z test (B6: z <= 0 rejected) + projection + both truncation rules.
+// kPretest = false: the caller already knows the wavefront holds candidates (colour pass over
+// the refined tile masks), so the fp32 rejection test could not skip anything.
+// kShortDiv = false keeps the plain `/` (single-keyframe kernel: HBM-bound, and four points per lane
+// make the extra code paths cost more registers than the divisions save).
+template <bool kPretest = true, bool kShortDiv = true>
 __device__ __forceinline__ Projected project_point(const DevCamera &c, const float *__restrict__ m, float x, float y,
                                                    float z) {
   Projected p;
   xform(m, x, y, z, p.xc, p.yc, p.zc);
   p.cell = -1;
   p.pixel = -1;
-  if (p.zc > 0.0f && !(c.pretest && surely_rejected(c, p.xc, p.yc, p.zc))) {
+  if (p.zc > 0.0f && !(kPretest && c.pretest && surely_rejected(c, p.xc, p.yc, p.zc))) {
     double u, v;
-    project_uv(c, static_cast<double>(p.xc), static_cast<double>(p.yc), static_cast<double>(p.zc), u, v);
-    p.cell = cull_cell(c, u, v);
+    project_uv<kShortDiv>(c, p.xc, p.yc, p.zc, u, v);
+    p.cell = cull_cell<kShortDiv>(c, u, v);
     p.pixel = colour_pixel(c, u, v);
   }
   return p;

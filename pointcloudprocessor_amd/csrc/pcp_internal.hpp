@@ -22,6 +22,8 @@ struct DevCamera {
   double k1, k2, p1, p2, k3;
   double slack;  // 0.05, view_culling.cpp:157
   float ds_f;    // 14.0f
+  float ds_rcp;  // RN(1 / ds_f): exact constant division (pcp_device.hpp div_by_ds)
+  int32_t ds_fast;  // 1 when ds_f is in the range div_by_ds is proven for
   int32_t ds;
   int32_t img_w, img_h;
   int32_t cull_w, cull_h;
