@@ -127,7 +127,10 @@ __device__ __forceinline__ Interval iv_pad(Interval a) {  // absorbs the fp64 ro
   return {a.lo - e, a.hi + e};
 }
 
-__device__ __forceinline__ bool tile_surely_rejected(const DevCamera &c, const DevFrame &fr, float4 sph) {
+// Returns 1 when every point of the tile is certain to be rejected (exactness-critical, see above),
+// 2 when the whole tile images strictly inside the acceptance box (a performance hint only: the
+// per-point fp32 rejection test could not reject anything there, so the depth pass skips it), else 0.
+__device__ __forceinline__ int tile_classify(const DevCamera &c, const DevFrame &fr, float4 sph) {
   const double cx = sph.x, cy = sph.y, cz = sph.z;
   const float *m = fr.w2c;
   const double X = (m[0] * cx + m[1] * cy) + (m[2] * cz + m[3]);
@@ -137,9 +140,9 @@ __device__ __forceinline__ bool tile_surely_rejected(const DevCamera &c, const D
   const double mag = fr.norm_bound * (fabs(cx) + fabs(cy) + fabs(cz) + 3.0 * sph.w) + fabs(static_cast<double>(m[3])) +
                      fabs(static_cast<double>(m[7])) + fabs(static_cast<double>(m[11])) + 1e-3;
   const double rho = fr.norm_bound * static_cast<double>(sph.w) * (1.0 + 1e-6) + 1e-6 * mag;
-  if (!(rho >= 0.0) || !isfinite(X + Y + Z + rho)) return false;
-  if (Z + rho <= 0.0) return true;   // (a) entirely behind the camera
-  if (Z - rho <= 0.0) return false;  // straddles z = 0: no bound on x / z
+  if (!(rho >= 0.0) || !isfinite(X + Y + Z + rho)) return 0;
+  if (Z + rho <= 0.0) return 1;   // (a) entirely behind the camera
+  if (Z - rho <= 0.0) return 0;  // straddles z = 0: no bound on x / z
   const Interval zi{Z - rho, Z + rho};
   const Interval iz{1.0 / zi.hi, 1.0 / zi.lo};
   const Interval xn = iv_pad(iv_mul(Interval{X - rho, X + rho}, iz));
@@ -159,10 +162,15 @@ __device__ __forceinline__ bool tile_surely_rejected(const DevCamera &c, const D
   Interval u = iv_pad(iv_scale(c.fx, xd)), v = iv_pad(iv_scale(c.fy, yd));
   u.lo += c.cx; u.hi += c.cx;
   v.lo += c.cy; v.hi += c.cy;
-  if (!isfinite(u.lo + u.hi + v.lo + v.hi)) return false;
+  if (!isfinite(u.lo + u.hi + v.lo + v.hi)) return 0;
   // the box already carries a 0.5 px margin (pcp_set_camera)
-  return u.hi < static_cast<double>(c.u_lo) || u.lo > static_cast<double>(c.u_hi) ||
-         v.hi < static_cast<double>(c.v_lo) || v.lo > static_cast<double>(c.v_hi);
+  if (u.hi < static_cast<double>(c.u_lo) || u.lo > static_cast<double>(c.u_hi) ||
+      v.hi < static_cast<double>(c.v_lo) || v.lo > static_cast<double>(c.v_hi))
+    return 1;
+  return (u.lo > static_cast<double>(c.u_lo) + 1.0 && u.hi < static_cast<double>(c.u_hi) - 1.0 &&
+          v.lo > static_cast<double>(c.v_lo) + 1.0 && v.hi < static_cast<double>(c.v_hi) - 1.0)
+             ? 2
+             : 0;
 }
 
 // Two launches: first the spheres of groups of 16 tiles (one lane per (group, 32-keyframe
@@ -175,7 +183,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_mask(const float4 *__restrict__
                                                       const DevFrame *__restrict__ frames, int32_t n_frames,
                                                       int32_t w0, int32_t w1, int32_t words,
                                                       const uint32_t *__restrict__ parent_mask, int32_t parent_shift,
-                                                      uint32_t *__restrict__ tile_mask, int32_t cull_enabled) {
+                                                      uint32_t *__restrict__ tile_mask,
+                                                      uint32_t *__restrict__ inside_mask, int32_t cull_enabled) {
   const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const int32_t nw = w1 - w0;
   const int64_t tile = g / nw;
@@ -184,15 +193,18 @@ __global__ __launch_bounds__(kBlock) void k_tile_mask(const float4 *__restrict__
   const float4 sph = spheres[tile];
   uint32_t todo = 0xffffffffu;
   if (parent_mask) todo = parent_mask[(tile >> parent_shift) * words + w];
-  uint32_t word = 0u;
+  uint32_t word = 0u, inside = 0u;
   while (todo) {
     const int32_t b = __builtin_ctz(todo);
     todo &= todo - 1u;
     const int32_t f = (w << 5) + b;
     if (f >= n_frames) break;
-    if (!(cull_enabled && tile_surely_rejected(cam, frames[f], sph))) word |= 1u << b;
+    const int cls = cull_enabled ? tile_classify(cam, frames[f], sph) : 0;
+    if (cls != 1) word |= 1u << b;
+    if (cls == 2) inside |= 1u << b;
   }
   tile_mask[tile * words + w] = word;
+  if (inside_mask) inside_mask[tile * words + w] = inside;
 }
 
 // ---------------------------------------------------------------------------
@@ -218,7 +230,7 @@ __global__ __launch_bounds__(kBlock) void k_depth_pass(const float *__restrict__
                                                        const DevFrame *__restrict__ frames, int32_t f0, int32_t f1,
                                                        uint32_t *__restrict__ depth, int64_t cells,
                                                        int32_t depth_first_frame, uint32_t *__restrict__ tile_mask,
-                                                       int32_t words) {
+                                                       const uint32_t *__restrict__ tile_inside, int32_t words) {
   // per-wavefront combining table: slot = cell & 63 holds min over (cell << 32 | range bits)
   __shared__ unsigned long long combine[kBlock];
   const int lane = threadIdx.x & 63;
@@ -232,13 +244,15 @@ __global__ __launch_bounds__(kBlock) void k_depth_pass(const float *__restrict__
     uint32_t todo = in_range;
     if (tile_mask) todo &= tile_mask[tile * words + w];
     todo = __builtin_amdgcn_readfirstlane(todo);
+    // pairs whose tile images inside the acceptance box: the fp32 rejection test is skipped (it could not reject)
+    const uint32_t inside = tile_inside ? __builtin_amdgcn_readfirstlane(tile_inside[tile * words + w]) : 0u;
     uint32_t seen = 0u;  // keyframes in which some lane can be coloured
     while (todo) {
       const int32_t b = __builtin_ctz(todo);
       const int32_t f = (w << 5) + b;
       todo &= todo - 1u;
       const DevFrame &fr = frames[f];
-      const Projected p = project_point(cam, fr.w2c, px, py, pz);
+      const Projected p = project_point(cam, fr.w2c, px, py, pz, ((inside >> b) & 1u) == 0u);
       const bool in_map = live && p.cell >= 0;
       const bool cand = live && p.pixel >= 0 && (cam.enable_zbuf ? p.cell >= 0 : p.cell != -1);
       if (__ballot(cand)) seen |= 1u << b;
@@ -636,6 +650,7 @@ static int ensure_depth(pcp_context *ctx) {
   const size_t need_mask = static_cast<size_t>(words) * static_cast<size_t>(std::max<int64_t>(ctx->n_tiles, 1)) + 4;
   if (ctx->tile_mask.count < need_mask || ctx->mask_words != words) {
     PCP_HIP_TRY(ctx, ctx->tile_mask.ensure(need_mask));
+    PCP_HIP_TRY(ctx, ctx->tile_inside.ensure(need_mask));
     ctx->mask_words = words;
     std::fill(ctx->depth_valid.begin(), ctx->depth_valid.end(), uint8_t(0));
   }
@@ -687,7 +702,8 @@ static int single_frame_depth(pcp_context *ctx, int32_t frame) {
     LaunchTimer t(ctx, PCP_K_DEPTH);
     hipLaunchKernelGGL(k_depth_pass, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
                        ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, ctx->n, ctx->dcam, ctx->frames.p, frame, frame + 1,
-                       ctx->s_u32.p, cells, frame, static_cast<uint32_t *>(nullptr), 0);
+                       ctx->s_u32.p, cells, frame, static_cast<uint32_t *>(nullptr),
+                       static_cast<const uint32_t *>(nullptr), 0);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   return PCP_OK;
@@ -938,17 +954,17 @@ int pcp_depth_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
       hipLaunchKernelGGL(k_tile_mask, dim3(blocks_for(groups * (w1 - w0))), dim3(kBlock), 0, ctx->stream,
                          tile_sph + ctx->n_tiles, groups, ctx->dcam, ctx->frames.p, ctx->n_frames, w0, w1,
                          ctx->mask_words, static_cast<const uint32_t *>(nullptr), 0, ctx->group_mask.p,
-                         cull_tiles ? 1 : 0);
+                         static_cast<uint32_t *>(nullptr), cull_tiles ? 1 : 0);
       hipLaunchKernelGGL(k_tile_mask, dim3(blocks_for(ctx->n_tiles * (w1 - w0))), dim3(kBlock), 0, ctx->stream, tile_sph,
                          ctx->n_tiles, ctx->dcam, ctx->frames.p, ctx->n_frames, w0, w1, ctx->mask_words,
-                         ctx->group_mask.p, 4, ctx->tile_mask.p, cull_tiles ? 1 : 0);
+                         ctx->group_mask.p, 4, ctx->tile_mask.p, ctx->tile_inside.p, cull_tiles ? 1 : 0);
       PCP_HIP_TRY(ctx, hipGetLastError());
     }
     {
       LaunchTimer t(ctx, PCP_K_DEPTH);
       hipLaunchKernelGGL(k_depth_pass, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
                          ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, ctx->n, ctx->dcam, ctx->frames.p, frame_begin,
-                         frame_end, ctx->depth.p, cells, 0, ctx->tile_mask.p, ctx->mask_words);
+                         frame_end, ctx->depth.p, cells, 0, ctx->tile_mask.p, ctx->tile_inside.p, ctx->mask_words);
       PCP_HIP_TRY(ctx, hipGetLastError());
     }
   }

@@ -376,6 +376,7 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->depth.release();
   ctx->tile_sphere.release();
   ctx->tile_mask.release();
+  ctx->tile_inside.release();
   ctx->group_mask.release();
   ctx->top_score.release();
   ctx->top_rgb.release();
@@ -486,6 +487,8 @@ int pcp_set_camera(pcp_context *ctx, const pcp_camera *cam, const pcp_cull_param
   if (cam->image_width <= 0 || cam->image_height <= 0 || cam->cull_width <= 0 || cam->cull_height <= 0)
     return set_error(ctx, PCP_ERR_INVALID, "pcp_set_camera: image / cull size must be positive");
   if (cp.downsample_factor <= 0) return set_error(ctx, PCP_ERR_INVALID, "pcp_set_camera: downsample_factor must be > 0");
+  if (cam->cull_width > (1 << 24) || cam->cull_height > (1 << 24))
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_set_camera: cull size above 2^24 is not supported");
   if (static_cast<int64_t>(cam->image_width) * cam->image_height >= (int64_t(1) << 31))
     return set_error(ctx, PCP_ERR_INVALID, "pcp_set_camera: image too large for int32 pixel indices");
   ctx->camera = *cam;
@@ -510,6 +513,10 @@ int pcp_set_camera(pcp_context *ctx, const pcp_camera *cam, const pcp_cull_param
   d.img_h = cam->image_height;
   d.cull_w = cam->cull_width;
   d.cull_h = cam->cull_height;
+  d.img_wd = static_cast<double>(cam->image_width);
+  d.img_hd = static_cast<double>(cam->image_height);
+  d.cull_wf = static_cast<float>(cam->cull_width);  // exact: <= 2^24
+  d.cull_hf = static_cast<float>(cam->cull_height);
   d.mw = cam->cull_width / cp.downsample_factor;
   d.mh = cam->cull_height / cp.downsample_factor;
   d.enable_zbuf = cp.enable_depth_buffer_culling ? 1 : 0;

@@ -104,10 +104,10 @@ template <bool kShortDiv = true>
 __device__ __forceinline__ int32_t cull_cell(const DevCamera &c, double u, double v) {
   const float cxf = kShortDiv ? div_by_ds(c, static_cast<float>(u)) : static_cast<float>(u) / c.ds_f;
   const float cyf = kShortDiv ? div_by_ds(c, static_cast<float>(v)) : static_cast<float>(v) / c.ds_f;
-  if (!(cxf > -2147483648.0f && cxf < 2147483648.0f && cyf > -2147483648.0f && cyf < 2147483648.0f)) return -1;
+  // C truncation: 0 <= (int)t < W  <=>  -1 < t < W (W an integer below 2^24); NaN / inf / out-of-int32 fail
+  if (!(cxf > -1.0f && cxf < c.cull_wf && cyf > -1.0f && cyf < c.cull_hf)) return -1;
   const int32_t cx = static_cast<int32_t>(cxf);
   const int32_t cy = static_cast<int32_t>(cyf);
-  if (cx < 0 || cy < 0 || cx >= c.cull_w || cy >= c.cull_h) return -1;
   // -2 (candidate without a map cell) is only reported when the depth buffer is off
   return (cx < c.mw && cy < c.mh) ? cy * c.mw + cx : (c.enable_zbuf ? -1 : -2);
 }
@@ -115,11 +115,8 @@ __device__ __forceinline__ int32_t cull_cell(const DevCamera &c, double u, doubl
 // A5 pixel: static_cast<int>(fx*xd+cx) with C truncation, bounds vs the actual
 // image (PointCloudProcessor.cpp:752-754).  -1 when rejected.
 __device__ __forceinline__ int32_t colour_pixel(const DevCamera &c, double u, double v) {
-  if (!(u > -2147483648.0 && u < 2147483648.0 && v > -2147483648.0 && v < 2147483648.0)) return -1;
-  const int32_t ui = static_cast<int32_t>(u);
-  const int32_t vi = static_cast<int32_t>(v);
-  if (ui < 0 || ui >= c.img_w || vi < 0 || vi >= c.img_h) return -1;
-  return vi * c.img_w + ui;
+  if (!(u > -1.0 && u < c.img_wd && v > -1.0 && v < c.img_hd)) return -1;  // same equivalence as above
+  return static_cast<int32_t>(v) * c.img_w + static_cast<int32_t>(u);
 }
 
 // ||p_c|| in fp64 on the promoted fp32 camera coordinates (view_culling.cpp:102,144).
@@ -176,12 +173,13 @@ struct Projected {
 // make the extra code paths cost more registers than the divisions save).
 template <bool kPretest = true, bool kShortDiv = true>
 __device__ __forceinline__ Projected project_point(const DevCamera &c, const float *__restrict__ m, float x, float y,
-                                                   float z) {
+                                                   float z, bool pretest_here = true) {
   Projected p;
   xform(m, x, y, z, p.xc, p.yc, p.zc);
   p.cell = -1;
   p.pixel = -1;
-  if (p.zc > 0.0f && !(kPretest && c.pretest && surely_rejected(c, p.xc, p.yc, p.zc))) {
+  // pretest_here is wave-uniform (a tile-level hint); the rejection test never changes a result
+  if (p.zc > 0.0f && !(kPretest && pretest_here && c.pretest && surely_rejected(c, p.xc, p.yc, p.zc))) {
     double u, v;
     project_uv<kShortDiv>(c, p.xc, p.yc, p.zc, u, v);
     p.cell = cull_cell<kShortDiv>(c, u, v);

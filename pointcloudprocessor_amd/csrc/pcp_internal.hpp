@@ -22,6 +22,8 @@ struct DevCamera {
   double k1, k2, p1, p2, k3;
   double slack;  // 0.05, view_culling.cpp:157
   float ds_f;    // 14.0f
+  double img_wd, img_hd;  // image size as fp64 / cull size as fp32: bounds of the truncation rules
+  float cull_wf, cull_hf;
   float ds_rcp;  // RN(1 / ds_f): exact constant division (pcp_device.hpp div_by_ds)
   int32_t ds_fast;  // 1 when ds_f is in the range div_by_ds is proven for
   int32_t ds;
@@ -124,6 +126,7 @@ struct pcp_context {
   int64_t n_tiles = 0;
   pcp::DevBuf<float> tile_sphere;
   pcp::DevBuf<uint32_t> tile_mask, group_mask;
+  pcp::DevBuf<uint32_t> tile_inside;  // pairs whose whole tile images inside the acceptance box (a hint: skip the pre-test)
   int32_t mask_words = 0;
 
   // per-point colour state (sorted order) and packed results
