@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--cpu-points", type=int, default=1_000_000)
     ap.add_argument("--cpu-frames", type=int, default=16)
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even at world size 1")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the N > 1 path on fewer GPUs than ranks (ranks share devices); not a measurement")
     ap.add_argument("--dist-chunks", type=int, default=2, help="keyframe groups whose all-reduce overlaps the next depth pass")
     return ap.parse_args()
 
@@ -61,6 +63,10 @@ def main():
     # stdout carries the one JSON line only: libraries that print banners (RCCL, rocprofv3) go to stderr
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if os.environ.get("PCP_BENCH_WATCHDOG"):  # debugging aid: periodic stack dumps to stderr
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["PCP_BENCH_WATCHDOG"]), repeat=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -73,6 +79,8 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(2)
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.force_dist:
@@ -80,7 +88,10 @@ def main():
 
         for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29511")):
             os.environ.setdefault(k, v)  # --force-dist outside torch.distributed.run
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group("gloo")
 
     from pointcloudprocessor_amd import capi, pipeline, synth
 
@@ -137,12 +148,14 @@ def main():
     value = world * N * F * args.steps / dt / 1e6  # Mpoints x frames / s, whole job
 
     result = None
+    coloured = int(((pinned[(step_no[0] - 1) & 1].numpy().view(np.uint32) >> 24) & 1).sum())
+    # ---- per-kernel times of one more step (hipEvents on the launch stream).  Every rank takes the step:
+    # with N > 1 it contains the all-reduce, a collective ----
+    eng.ctx.timing_enable(True)
+    eng.ctx.timing_reset()
+    step()
+    fence()
     if rank == 0:
-        coloured = int(((pinned[(step_no[0] - 1) & 1].numpy().view(np.uint32) >> 24) & 1).sum())
-        # ---- per-kernel times of one more step (hipEvents on the launch stream) ----
-        eng.ctx.timing_enable(True)
-        eng.ctx.timing_reset()
-        step()
         kt = {eng.ctx.kernel_name(k): eng.ctx.timing_get(k) for k in (capi.K_TILE_MASK, capi.K_DEPTH, capi.K_COLOUR, capi.K_MISC)}
         # ---- roofline leg: the single-keyframe projection kernel, one launch per keyframe ----
         eng.ctx.timing_reset()
@@ -286,6 +299,8 @@ def main():
             "cpu_baseline": cpu,
             "mls": mls,
         }
+        if args.backend != "nccl":
+            result["rehearsal"] = f"backend {args.backend}: ranks share GPUs, not a measurement"
         if cpu:
             result["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
     if dist is not None:

@@ -51,3 +51,25 @@ def test_depth_maps_alias_and_rccl_allreduce(oracle, small_scene):
         eng.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_two_rank_path_runs_to_completion():
+    """bench.py launched the way the driver launches N > 1 (torch.distributed.run, one rank per process), with the
+    gloo backend so that both ranks can share this box's single GPU: every collective of the step, of the timing leg
+    and of the shutdown must be entered by all ranks (a rank-0-only step once deadlocked here)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--points", "200000",
+           "--frames", "8", "--steps", "1", "--warmup", "1"]
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=root)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    assert "rehearsal" in line
