@@ -211,26 +211,62 @@ __global__ __launch_bounds__(kFitBlock) void k_mls_fit(MlsArgs a) {
   const int32_t y0 = max(cy - a.g.reach, 0), y1 = min(cy + a.g.reach, a.g.ny - 1);
   const int32_t z0 = max(cz - a.g.reach, 0), z1 = min(cz + a.g.reach, a.g.nz - 1);
 
-  // sweep 0: radius test (fp32, exact FLANN form), neighbour count, compact list
+  // sweep 0: radius test (fp32, exact FLANN form), neighbour count, compact list.  The run bounds
+  // are fetched first (18 independent loads), and the candidates of a run are tested four at a time
+  // (12 coordinate loads in flight: this scan is latency-bound, not arithmetic-bound).
   int32_t K = 0;
   bool fast = a.g.reach == 1;
-  {
-    int32_t r = 0;
+  if (fast) {
+    int32_t rb[kMaxRun], re[kMaxRun];
+#pragma unroll
+    for (int32_t r = 0; r < kMaxRun; ++r) {
+      const int32_t zz = z0 + r / 3, yy = y0 + r % 3;
+      const bool in = zz <= z1 && yy <= y1;  // fewer rows at the grid border: empty runs keep the (z, y) order
+      const int32_t row = (min(zz, z1) * a.g.ny + min(yy, y1)) * a.g.nx;
+      rb[r] = in ? a.start[row + x0] : 0;
+      re[r] = in ? a.start[row + x1 + 1] : 0;
+    }
+#pragma unroll
+    for (int32_t r = 0; r < kMaxRun; ++r) {
+      const int32_t b = rb[r], e = re[r];
+      run_base[r][tid] = b;
+      if (e - b > 4096) fast = false;
+      for (int32_t k = b; k < e; k += 4) {
+        const int32_t k1 = min(k + 1, e - 1), k2 = min(k + 2, e - 1), k3 = min(k + 3, e - 1);
+        const float ax = a.sx[k], ay = a.sy[k], az = a.sz[k];
+        const float bx = a.sx[k1], by = a.sy[k1], bz = a.sz[k1];
+        const float cx_ = a.sx[k2], cy_ = a.sy[k2], cz_ = a.sz[k2];
+        const float dx_ = a.sx[k3], dy_ = a.sy[k3], dz_ = a.sz[k3];
+        const bool h0 = sqdist_f32(ax, ay, az, qx, qy, qz) < a.sq_radius;
+        const bool h1 = k + 1 < e && sqdist_f32(bx, by, bz, qx, qy, qz) < a.sq_radius;
+        const bool h2 = k + 2 < e && sqdist_f32(cx_, cy_, cz_, qx, qy, qz) < a.sq_radius;
+        const bool h3 = k + 3 < e && sqdist_f32(dx_, dy_, dz_, qx, qy, qz) < a.sq_radius;
+        // four straight-line appends: a loop over the set bits costs more than the tests it saves
+        if (h0) {
+          if (K < kMaxNbr) nbr_code[K][tid] = static_cast<uint16_t>((r << 12) | ((k - b) & 4095));
+          ++K;
+        }
+        if (h1) {
+          if (K < kMaxNbr) nbr_code[K][tid] = static_cast<uint16_t>((r << 12) | ((k + 1 - b) & 4095));
+          ++K;
+        }
+        if (h2) {
+          if (K < kMaxNbr) nbr_code[K][tid] = static_cast<uint16_t>((r << 12) | ((k + 2 - b) & 4095));
+          ++K;
+        }
+        if (h3) {
+          if (K < kMaxNbr) nbr_code[K][tid] = static_cast<uint16_t>((r << 12) | ((k + 3 - b) & 4095));
+          ++K;
+        }
+      }
+    }
+  } else {
     for (int32_t zz = z0; zz <= z1; ++zz)
       for (int32_t yy = y0; yy <= y1; ++yy) {
         const int32_t row = (zz * a.g.ny + yy) * a.g.nx;
         const int32_t b = a.start[row + x0], e = a.start[row + x1 + 1];
-        if (fast) {
-          run_base[r][tid] = b;
-          if (e - b > 4096) fast = false;
-        }
-        for (int32_t k = b; k < e; ++k) {
-          if (sqdist_f32(a.sx[k], a.sy[k], a.sz[k], qx, qy, qz) < a.sq_radius) {
-            if (fast && K < kMaxNbr) nbr_code[K][tid] = static_cast<uint16_t>((r << 12) | (k - b));
-            ++K;
-          }
-        }
-        ++r;
+        for (int32_t k = b; k < e; ++k)
+          if (sqdist_f32(a.sx[k], a.sy[k], a.sz[k], qx, qy, qz) < a.sq_radius) ++K;
       }
   }
   fast = fast && K <= kMaxNbr;
