@@ -1,0 +1,84 @@
+"""BASELINE.json's smaller configurations as parity cases (bench.py measures configs[2]):
+
+  configs[0]  100 k points x 1 keyframe, the reference's own camera (4096x3000, PointCloudProcessor.cpp:57-60), no MLS
+  configs[1]  1 M points x 32 keyframes @1920x1080, no MLS
+
+Every per-point output of the C ABI against the oracle on the same seeded inputs: cells, pixels, ranges, depth
+maps and keep masks bit-exact, top-5 lists and colours bit-exact.
+"""
+import numpy as np
+import pytest
+
+from conftest import cam_struct
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(n, frames, camera):
+    from pointcloudprocessor_amd import synth
+
+    cd = synth.camera_dict(camera)
+    x, y, z, _ = synth.make_cloud(n)
+    poses, _ = synth.make_trajectory(frames)
+    imgs = [synth.make_image(f, cd["image_width"], cd["image_height"]) for f in range(frames)]
+    return cd, x, y, z, poses, imgs
+
+
+def test_config0_100k_points_one_keyframe_reference_camera(gpu_ctx_factory, oracle):
+    from pointcloudprocessor_amd import capi
+
+    cd, x, y, z, poses, imgs = _scene(100_000, 1, "ref")
+    ocam, ocp = cam_struct(oracle, cd), oracle.default_cull_params()
+    ctx = gpu_ctx_factory()
+    ctx.set_camera(cam_struct(capi, cd))
+    ctx.upload_cloud(x, y, z)
+    ctx.set_frames(poses)
+    ctx.upload_image(0, imgs[0])
+    w2c, _ = oracle.pose_to_matrices(poses[0])
+    p_ref = oracle.project_frame(ocam, ocp, w2c, x, y, z)
+    p_got = ctx.project_frame(0)
+    for k in ("cell", "pixel"):
+        assert np.array_equal(p_got[k], p_ref[k]), k
+    cand = p_ref["cell"] != -1
+    assert np.array_equal(p_got["range"][cand].view(np.uint32), p_ref["range"][cand].view(np.uint32))
+    keep_r, dmap_r, _ = oracle.cull_frame(ocam, ocp, w2c, x, y, z)
+    keep_g, dmap_g, _ = ctx.cull_frame(0)
+    assert np.array_equal(keep_g, keep_r)
+    assert np.array_equal(dmap_g.view(np.uint32), dmap_r.view(np.uint32))
+    ref = oracle.colorize(ocam, ocp, x, y, z, poses, imgs, threads=4, want_top=True)
+    ctx.depth_pass()
+    ctx.colour_reset()
+    ctx.colour_pass()
+    got = ctx.colour_finalise(want_top=True)
+    for k in ("count", "top_frame", "top_rgb", "top_score", "rgb", "has"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert ref["has"].sum() > 1000
+    ctx.close()
+
+
+def test_config1_1m_points_32_keyframes(gpu_ctx_factory, oracle):
+    from pointcloudprocessor_amd import capi
+
+    cd, x, y, z, poses, imgs = _scene(1_000_000, 32, "cfg")
+    ocam, ocp = cam_struct(oracle, cd), oracle.default_cull_params()
+    ctx = gpu_ctx_factory()
+    ctx.set_camera(cam_struct(capi, cd))
+    ctx.upload_cloud(x, y, z)
+    ctx.set_frames(poses)
+    for f, im in enumerate(imgs):
+        ctx.upload_image(f, im)
+    ref = oracle.colorize(ocam, ocp, x, y, z, poses, imgs, threads=8, want_top=True)
+    ctx.depth_pass()
+    for f in (0, 7, 19, 31):
+        w2c, _ = oracle.pose_to_matrices(poses[f])
+        _, dmap_r, _ = oracle.cull_frame(ocam, ocp, w2c, x, y, z)
+        assert np.array_equal(ctx.download_depth_map(f).view(np.uint32), dmap_r.view(np.uint32)), f
+    ctx.colour_reset()
+    ctx.colour_pass()
+    got = ctx.colour_finalise(want_top=True)
+    for k in ("count", "top_frame", "top_rgb", "top_score", "rgb", "has"):
+        assert np.array_equal(got[k], ref[k]), k
+    one_shot = ctx.colorize()
+    assert np.array_equal(one_shot["rgb"], ref["rgb"]) and np.array_equal(one_shot["has"], ref["has"])
+    assert ref["has"].sum() > 100_000
+    ctx.close()
