@@ -207,6 +207,22 @@ __global__ __launch_bounds__(kBlock) void k_tile_mask(const float4 *__restrict__
   if (inside_mask) inside_mask[tile * words + w] = inside;
 }
 
+// Workgroups are handed to the 8 XCDs round-robin (workgroup b runs on XCD b % 8), and every XCD has
+// its own 4 MiB L2.  The batched passes walk the Morton-ordered cloud, so neighbouring workgroups touch
+// the same depth cells and texels: this remap makes every run of kXcdChunk consecutive workgroups of
+// the cloud execute on ONE XCD (chunk c goes to XCD c % 8), so a patch of space, and of every image it
+// projects into, is served by one L2 instead of eight.  Measured at C3: neutral to +2 % (both passes are
+// bound by VALU issue, not by L2 misses).  Whole contiguous eighths per XCD were 40 % slower: the work per
+// tile varies across the scene and the XCDs then finish far apart.
+constexpr uint32_t kXcdChunk = 16;
+__device__ __forceinline__ uint32_t xcd_chunked_block() {
+  constexpr uint32_t kXcd = 8, kSuper = kXcd * kXcdChunk;
+  const uint32_t b = blockIdx.x;
+  if (b >= (gridDim.x / kSuper) * kSuper) return b;  // ragged tail: identity
+  const uint32_t x = b % kXcd, slot = b / kXcd;
+  return ((slot / kXcdChunk) * kXcd + x) * kXcdChunk + slot % kXcdChunk;
+}
+
 // ---------------------------------------------------------------------------
 // K2: z-buffer MIN pass, keyframes [f0, f1).  One lane per point, one wavefront
 // per tile; the point stays in registers across the keyframe loop (12 B read per
@@ -235,7 +251,7 @@ __global__ __launch_bounds__(kBlock) void k_depth_pass(const float *__restrict__
   __shared__ unsigned long long combine[kBlock];
   const int lane = threadIdx.x & 63;
   unsigned long long *tbl = combine + (threadIdx.x & ~63);
-  const int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t j = static_cast<int64_t>(xcd_chunked_block()) * kBlock + threadIdx.x;
   const bool live = j < n;
   const float px = live ? x[j] : 0.0f, py = live ? y[j] : 0.0f, pz = live ? z[j] : 0.0f;
   const int64_t tile = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(j >> 6));
@@ -319,7 +335,7 @@ __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict_
                                                         const uint32_t *__restrict__ images, int64_t image_px,
                                                         TopState st, const int32_t *__restrict__ perm,
                                                         uint32_t *__restrict__ rgba, int32_t flags) {
-  const int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t j = static_cast<int64_t>(xcd_chunked_block()) * kBlock + threadIdx.x;
   const bool live = j < n;
   const float px = live ? x[j] : 0.0f, py = live ? y[j] : 0.0f, pz = live ? z[j] : 0.0f;
   const int64_t tile = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(j >> 6));
