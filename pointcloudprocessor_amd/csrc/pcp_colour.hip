@@ -207,6 +207,55 @@ __global__ __launch_bounds__(kBlock) void k_tile_mask(const float4 *__restrict__
   if (inside_mask) inside_mask[tile * words + w] = inside;
 }
 
+// Tile level, dense form: one wavefront per group of 16 tiles, lane = slot * 16 + tile-in-group.  The
+// keyframes the group survived (its parent mask) are taken four at a time, so all 64 lanes classify
+// (tile, keyframe) pairs until the group's list is exhausted (the lane-per-(tile, word) form ran at 32 %
+// lane utilisation: every lane looped over its own number of surviving keyframes).  The verdicts are
+// gathered with wave ballots; the 16 lanes of slot 0 own their tiles' mask words.
+__global__ __launch_bounds__(kBlock) void k_tile_mask_dense(const float4 *__restrict__ spheres, int64_t tiles,
+                                                            DevCamera cam, const DevFrame *__restrict__ frames,
+                                                            int32_t n_frames, int32_t w0, int32_t w1, int32_t words,
+                                                            const uint32_t *__restrict__ group_mask,
+                                                            uint32_t *__restrict__ tile_mask,
+                                                            uint32_t *__restrict__ inside_mask, int32_t cull_enabled) {
+  const int lane = threadIdx.x & 63;
+  const int64_t group = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6);
+  if (group >= (tiles + kTileGroup - 1) / kTileGroup) return;  // whole wavefronts leave together
+  const int t = lane & 15, slot = lane >> 4;
+  const int64_t tile = group * kTileGroup + t;
+  const bool have = tile < tiles;
+  const float4 sph = spheres[have ? tile : tiles - 1];
+  for (int32_t w = w0; w < w1; ++w) {
+    uint32_t todo = __builtin_amdgcn_readfirstlane(group_mask[group * words + w]);
+    const int32_t nb = n_frames - (w << 5);
+    if (nb < 32) todo &= nb <= 0 ? 0u : ((1u << nb) - 1u);
+    uint32_t word = 0u, inside = 0u;
+    while (todo) {
+      int32_t bit[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        bit[k] = todo ? __builtin_ctz(todo) : -1;
+        todo &= todo - (todo ? 1u : 0u);
+      }
+      const int32_t b = slot == 0 ? bit[0] : slot == 1 ? bit[1] : slot == 2 ? bit[2] : bit[3];
+      int cls = 1;
+      if (b >= 0 && have) cls = cull_enabled ? tile_classify(cam, frames[(w << 5) + b], sph) : 0;
+      const unsigned long long keep = __ballot(cls != 1), ins = __ballot(cls == 2);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (bit[k] >= 0) {
+          word |= static_cast<uint32_t>((keep >> (k * 16 + t)) & 1ull) << bit[k];
+          inside |= static_cast<uint32_t>((ins >> (k * 16 + t)) & 1ull) << bit[k];
+        }
+      }
+    }
+    if (slot == 0 && have) {
+      tile_mask[tile * words + w] = word;
+      if (inside_mask) inside_mask[tile * words + w] = inside;
+    }
+  }
+}
+
 // Workgroups are handed to the 8 XCDs round-robin (workgroup b runs on XCD b % 8), and every XCD has
 // its own 4 MiB L2.  The batched passes walk the Morton-ordered cloud, so neighbouring workgroups touch
 // the same depth cells and texels: this remap makes every run of kXcdChunk consecutive workgroups of
@@ -971,9 +1020,9 @@ int pcp_depth_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
                          tile_sph + ctx->n_tiles, groups, ctx->dcam, ctx->frames.p, ctx->n_frames, w0, w1,
                          ctx->mask_words, static_cast<const uint32_t *>(nullptr), 0, ctx->group_mask.p,
                          static_cast<uint32_t *>(nullptr), cull_tiles ? 1 : 0);
-      hipLaunchKernelGGL(k_tile_mask, dim3(blocks_for(ctx->n_tiles * (w1 - w0))), dim3(kBlock), 0, ctx->stream, tile_sph,
-                         ctx->n_tiles, ctx->dcam, ctx->frames.p, ctx->n_frames, w0, w1, ctx->mask_words,
-                         ctx->group_mask.p, 4, ctx->tile_mask.p, ctx->tile_inside.p, cull_tiles ? 1 : 0);
+      hipLaunchKernelGGL(k_tile_mask_dense, dim3(static_cast<uint32_t>(div_up(groups, kBlock / 64))), dim3(kBlock), 0,
+                         ctx->stream, tile_sph, ctx->n_tiles, ctx->dcam, ctx->frames.p, ctx->n_frames, w0, w1,
+                         ctx->mask_words, ctx->group_mask.p, ctx->tile_mask.p, ctx->tile_inside.p, cull_tiles ? 1 : 0);
       PCP_HIP_TRY(ctx, hipGetLastError());
     }
     {
