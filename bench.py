@@ -210,6 +210,24 @@ def main():
                        "radius": 0.03, "order": 2, "upsampling": "NONE", "ms": round(t_mls * 1e3, 2),
                        "kernels_ms": {eng.ctx.kernel_name(k): round(eng.ctx.timing_get(k)[0], 3)
                                       for k in (capi.K_MLS_GRID, capi.K_MLS_FIT)}}
+                # VOXEL_GRID_DILATION (the reference's configuration: 1 mm voxels, 4 iterations) on a thin slab of
+                # the same cloud -- at full C3 size the reference's own settings produce > 2^31 voxels
+                try:
+                    vs = (x[:nm] > 0.0) & (x[:nm] < 0.12)
+                    eng.upload_cloud(x[:nm][vs], y[:nm][vs], z[:nm][vs])
+                    vp = capi.default_mls_params()
+                    eng.ctx.mls_process(vp)  # warm-up (allocations)
+                    eng.ctx.synchronize()
+                    t1 = time.perf_counter()
+                    mv = eng.ctx.mls_process(vp)
+                    eng.ctx.synchronize()
+                    t_v = time.perf_counter() - t1
+                    mls["voxel_grid_dilation"] = {"points": int(vs.sum()), "outputs": int(mv), "voxel_size": 0.001,
+                                                  "iterations": 4, "ms": round(t_v * 1e3, 2),
+                                                  "Moutputs_per_s": round(mv / t_v / 1e6, 1)}
+                except capi.PcpError as e:
+                    mls["voxel_grid_dilation"] = {"error": str(e)}
+                eng.upload_cloud(x[:nm], y[:nm], z[:nm])
                 if not args.no_cpu:
                     # CPU baseline of the MLS leg: the oracle (OpenMP) on a full-density slab of the same cloud
                     from oracle import oracle_capi as oc

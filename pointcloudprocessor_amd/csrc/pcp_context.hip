@@ -414,6 +414,7 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->c_xyz.release();
   ctx->c_xyz2.release();
   ctx->v_bitmap.release();
+  ctx->v_vox.release();
   ctx->v_offsets.release();
   ctx->mls_xyz.release();
   ctx->mls_normal.release();

@@ -164,6 +164,7 @@ struct pcp_context {
   pcp::DevBuf<float> c_xyz, c_xyz2;  // pcp_cloud_smooth: intermediate clouds (SoA)
   pcp::DevBuf<uint32_t> v_bitmap;  // dilated voxel set, dense bitmap over the bounding box
   pcp::DevBuf<int32_t> v_offsets;  // exclusive popcount prefix per bitmap word
+  pcp::DevBuf<int64_t> v_vox;      // occupied voxels (linear index) in key order
   pcp::DevBuf<float> mls_xyz, mls_normal, mls_curv;
   pcp::DevBuf<int32_t> mls_index;
   int64_t mls_count = 0;

@@ -522,7 +522,9 @@ struct VoxelEmitArgs {
   const int32_t *order, *start;
   const int32_t *remap;  // view index -> caller's index (nullable)
   GridDesc g;
-  int32_t reach;
+  float dmax;           // upper bound of the distance from a voxel position to its nearest input point
+  const int64_t *vox;   // occupied voxels in key order (k_voxel_expand)
+  int64_t total;
   const double *state;  // kMlsState doubles per input point
   int32_t order_poly, required_neighbors;
   float *xyz, *normal, *curv;
@@ -530,76 +532,91 @@ struct VoxelEmitArgs {
   uint8_t *valid;
 };
 
-__global__ __launch_bounds__(kMB) void k_voxel_emit(VoxelEmitArgs a) {
+// the occupied voxels in key order: vox[offsets[w] + rank of bit b in word w] = (w << 5) + b.  One lane per
+// bitmap word; stores only (the bitmap is ~1 % full: the search below must not run at this granularity).
+__global__ __launch_bounds__(kMB) void k_voxel_expand(const uint32_t *__restrict__ bitmap,
+                                                      const int32_t *__restrict__ offsets, int64_t words,
+                                                      int64_t *__restrict__ vox) {
   const int64_t w = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
-  if (w >= a.v.words) return;
-  uint32_t bits = a.bitmap[w];
-  int64_t out = a.offsets[w];
+  if (w >= words) return;
+  uint32_t bits = bitmap[w];
+  int64_t out = offsets[w];
   while (bits) {
-    const int32_t b = __builtin_ctz(bits);
+    vox[out++] = (w << 5) + __builtin_ctz(bits);
     bits &= bits - 1u;
-    const int64_t L = (w << 5) + b;
-    const int32_t iz = static_cast<int32_t>(L % a.v.NZ);
-    const int64_t q = L / a.v.NZ;
-    const int32_t iy = static_cast<int32_t>(q % a.v.NY), ix = static_cast<int32_t>(q / a.v.NY);
-    // MLSVoxelGrid::getPosition: float(index) * voxel_size + bounding_min
-    const float px = __fadd_rn(__fmul_rn(static_cast<float>(ix), a.v.vs), a.v.bminx);
-    const float py = __fadd_rn(__fmul_rn(static_cast<float>(iy), a.v.vs), a.v.bminy);
-    const float pz = __fadd_rn(__fmul_rn(static_cast<float>(iz), a.v.vs), a.v.bminz);
-    // tree_->nearestKSearch(p, 1): closest input point (fp32 L2_Simple); ties -> lower index
-    int32_t cx, cy, cz;
-    grid_coords(a.g, px, py, pz, cx, cy, cz);
-    int32_t best = -1;
-    float bestd = FLT_MAX;
-    for (int32_t zz = max(cz - a.reach, 0); zz <= min(cz + a.reach, a.g.nz - 1); ++zz)
-      for (int32_t yy = max(cy - a.reach, 0); yy <= min(cy + a.reach, a.g.ny - 1); ++yy) {
-        const int32_t row = (zz * a.g.ny + yy) * a.g.nx;
-        const int32_t s0 = a.start[row + max(cx - a.reach, 0)], s1 = a.start[row + min(cx + a.reach, a.g.nx - 1) + 1];
-        for (int32_t k = s0; k < s1; ++k) {
-          const float d = sqdist_f32(a.sx[k], a.sy[k], a.sz[k], px, py, pz);
+  }
+}
+
+// one lane per occupied voxel (consecutive lanes = consecutive keys = neighbouring voxels of one z-row, so the
+// nearest-point searches of a wavefront read the same cells)
+__global__ __launch_bounds__(kMB) void k_voxel_emit(VoxelEmitArgs a) {
+  const int64_t out = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  if (out >= a.total) return;
+  const int64_t L = a.vox[out];
+  const int32_t iz = static_cast<int32_t>(L % a.v.NZ);
+  const int64_t q = L / a.v.NZ;
+  const int32_t iy = static_cast<int32_t>(q % a.v.NY), ix = static_cast<int32_t>(q / a.v.NY);
+  // MLSVoxelGrid::getPosition: float(index) * voxel_size + bounding_min
+  const float px = __fadd_rn(__fmul_rn(static_cast<float>(ix), a.v.vs), a.v.bminx);
+  const float py = __fadd_rn(__fmul_rn(static_cast<float>(iy), a.v.vs), a.v.bminy);
+  const float pz = __fadd_rn(__fmul_rn(static_cast<float>(iz), a.v.vs), a.v.bminz);
+  // tree_->nearestKSearch(p, 1): closest input point (fp32 L2_Simple); ties -> lower index.  The point that
+  // stamped this voxel lies within `a.dmax` of p, so the nearest one does too: only the cells meeting the
+  // box p +- dmax are visited (grid_coords is monotone in each coordinate).
+  int32_t x0, y0, z0, x1, y1, z1;
+  grid_coords(a.g, px - a.dmax, py - a.dmax, pz - a.dmax, x0, y0, z0);
+  grid_coords(a.g, px + a.dmax, py + a.dmax, pz + a.dmax, x1, y1, z1);
+  int32_t best = -1;
+  float bestd = FLT_MAX;
+  for (int32_t zz = z0; zz <= z1; ++zz)
+    for (int32_t yy = y0; yy <= y1; ++yy) {
+      const int32_t row = (zz * a.g.ny + yy) * a.g.nx;
+      const int32_t s0 = a.start[row + x0], s1 = a.start[row + x1 + 1];
+      for (int32_t k = s0; k < s1; ++k) {
+        const float d = sqdist_f32(a.sx[k], a.sy[k], a.sz[k], px, py, pz);
+        if (d <= bestd) {  // the index is only needed for the rare candidates that can win
           const int32_t id = a.remap ? a.remap[a.order[k]] : a.order[k];
-          if (d < bestd || (d == bestd && id < best)) {
+          if (d < bestd || id < best) {
             bestd = d;
             best = id;
           }
         }
       }
-    bool ok = best >= 0;
-    const double *st = a.state + static_cast<int64_t>(ok ? best : 0) * kMlsState;
-    ok = ok && st[20] >= 1.0;  // mls_results_[input_index].valid
-    if (ok) {
-      // MLSResult::projectPoint(pt, SIMPLE, 5 * nr_coeff)
-      const double dx = static_cast<double>(px) - st[0], dy = static_cast<double>(py) - st[1],
-                   dz = static_cast<double>(pz) - st[2];
-      const double u = (dx * st[6] + dy * st[7]) + dz * st[8];
-      const double vv = (dx * st[9] + dy * st[10]) + dz * st[11];
-      double wgt = 0.0, nx = st[3], ny = st[4], nz = st[5];
-      if (a.order_poly > 1 && st[19] >= static_cast<double>(a.required_neighbors) && st[20] >= 2.0 && isfinite(st[12])) {
-        // getPolynomialPartialDerivative: monomials 1, v, v^2, u, uv, u^2
-        const double c0 = st[12], c1 = st[13], c2 = st[14], c3 = st[15], c4 = st[16], c5 = st[17];
-        wgt = c0 + vv * c1 + (vv * vv) * c2 + u * c3 + (u * vv) * c4 + (u * u) * c5;
-        const double zu = c3 + c4 * vv + c5 * 2.0 * u;
-        const double zv = c1 + c2 * 2.0 * vv + c4 * u;
-        nx -= zu * st[6] + zv * st[9];
-        ny -= zu * st[7] + zv * st[10];
-        nz -= zu * st[8] + zv * st[11];
-        const double l = sqrt((nx * nx + ny * ny) + nz * nz);
-        if (l > 0.0) {
-          nx /= l; ny /= l; nz /= l;
-        }
-      }
-      a.xyz[3 * out + 0] = static_cast<float>(st[0] + u * st[6] + vv * st[9] + wgt * st[3]);
-      a.xyz[3 * out + 1] = static_cast<float>(st[1] + u * st[7] + vv * st[10] + wgt * st[4]);
-      a.xyz[3 * out + 2] = static_cast<float>(st[2] + u * st[8] + vv * st[11] + wgt * st[5]);
-      a.normal[3 * out + 0] = static_cast<float>(nx);
-      a.normal[3 * out + 1] = static_cast<float>(ny);
-      a.normal[3 * out + 2] = static_cast<float>(nz);
-      a.curv[out] = static_cast<float>(st[18]);
-      a.index[out] = best;
     }
-    a.valid[out] = ok ? 1 : 0;
-    ++out;
+  bool ok = best >= 0;
+  const double *st = a.state + static_cast<int64_t>(ok ? best : 0) * kMlsState;
+  ok = ok && st[20] >= 1.0;  // mls_results_[input_index].valid
+  if (ok) {
+    // MLSResult::projectPoint(pt, SIMPLE, 5 * nr_coeff)
+    const double dx = static_cast<double>(px) - st[0], dy = static_cast<double>(py) - st[1],
+                 dz = static_cast<double>(pz) - st[2];
+    const double u = (dx * st[6] + dy * st[7]) + dz * st[8];
+    const double vv = (dx * st[9] + dy * st[10]) + dz * st[11];
+    double wgt = 0.0, nx = st[3], ny = st[4], nz = st[5];
+    if (a.order_poly > 1 && st[19] >= static_cast<double>(a.required_neighbors) && st[20] >= 2.0 && isfinite(st[12])) {
+      // getPolynomialPartialDerivative: monomials 1, v, v^2, u, uv, u^2
+      const double c0 = st[12], c1 = st[13], c2 = st[14], c3 = st[15], c4 = st[16], c5 = st[17];
+      wgt = c0 + vv * c1 + (vv * vv) * c2 + u * c3 + (u * vv) * c4 + (u * u) * c5;
+      const double zu = c3 + c4 * vv + c5 * 2.0 * u;
+      const double zv = c1 + c2 * 2.0 * vv + c4 * u;
+      nx -= zu * st[6] + zv * st[9];
+      ny -= zu * st[7] + zv * st[10];
+      nz -= zu * st[8] + zv * st[11];
+      const double l = sqrt((nx * nx + ny * ny) + nz * nz);
+      if (l > 0.0) {
+        nx /= l; ny /= l; nz /= l;
+      }
+    }
+    a.xyz[3 * out + 0] = static_cast<float>(st[0] + u * st[6] + vv * st[9] + wgt * st[3]);
+    a.xyz[3 * out + 1] = static_cast<float>(st[1] + u * st[7] + vv * st[10] + wgt * st[4]);
+    a.xyz[3 * out + 2] = static_cast<float>(st[2] + u * st[8] + vv * st[11] + wgt * st[5]);
+    a.normal[3 * out + 0] = static_cast<float>(nx);
+    a.normal[3 * out + 1] = static_cast<float>(ny);
+    a.normal[3 * out + 2] = static_cast<float>(nz);
+    a.curv[out] = static_cast<float>(st[18]);
+    a.index[out] = best;
   }
+  a.valid[out] = ok ? 1 : 0;
 }
 
 // in-place style compaction of the voxel outputs when some voxels were dropped
@@ -955,7 +972,7 @@ static int voxel_grid_dilation(pcp_context *ctx, const CloudView &cv, const pcp_
     return set_error(ctx, PCP_ERR_NOMEM, "pcp_mls_process: %llu dilated voxels exceed the 2^31 output limit", total);
   const size_t st = static_cast<size_t>(total);
   PCP_HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
-  if (static_cast<double>(st) * 70.0 > static_cast<double>(free_b) + static_cast<double>(ctx->mls_xyz.count) * 4.0 * 2.4)
+  if (static_cast<double>(st) * 78.0 > static_cast<double>(free_b) + static_cast<double>(ctx->mls_xyz.count) * 4.0 * 2.4)
     return set_error(ctx, PCP_ERR_NOMEM, "pcp_mls_process: %llu upsampled points do not fit the device memory", total);
   PCP_HIP_TRY(ctx, ctx->mls_xyz.ensure(3 * st + 4));
   PCP_HIP_TRY(ctx, ctx->mls_normal.ensure(3 * st + 4));
@@ -973,8 +990,12 @@ static int voxel_grid_dilation(pcp_context *ctx, const CloudView &cv, const pcp_
   e.remap = cv.remap;
   e.start = ctx->g_start.p;
   e.g = g;
-  // a dilated voxel's corner lies within sqrt(3) * (it + 1) voxels of the point that stamped it
-  e.reach = std::max(1, static_cast<int32_t>(std::ceil(1.7321 * (v.it + 1) * static_cast<double>(v.vs) * g.inv_cell)));
+  // a dilated voxel's corner lies within sqrt(3) * (it + 1) voxels of the point that stamped it (1 % + 1 um of
+  // slack for the fp32 roundings of getCellIndex / getPosition)
+  e.dmax = static_cast<float>(1.7321 * (v.it + 1) * static_cast<double>(v.vs) * 1.01 + 1e-6);
+  PCP_HIP_TRY(ctx, ctx->v_vox.ensure(st + 4));
+  e.vox = ctx->v_vox.p;
+  e.total = static_cast<int64_t>(total);
   e.state = ctx->m_state.p;
   e.order_poly = p->polynomial_order;
   const int32_t nr_coeff = (p->polynomial_order + 1) * (p->polynomial_order + 2) / 2;
@@ -988,7 +1009,9 @@ static int voxel_grid_dilation(pcp_context *ctx, const CloudView &cv, const pcp_
   if (total > 0) {
     {
       LaunchTimer t(ctx, PCP_K_MLS_VOXEL);
-      hipLaunchKernelGGL(k_voxel_emit, dim3(blocks_of(v.words)), dim3(kMB), 0, ctx->stream, e);
+      hipLaunchKernelGGL(k_voxel_expand, dim3(blocks_of(v.words)), dim3(kMB), 0, ctx->stream, ctx->v_bitmap.p,
+                         ctx->v_offsets.p, v.words, ctx->v_vox.p);
+      hipLaunchKernelGGL(k_voxel_emit, dim3(blocks_of(static_cast<int64_t>(total))), dim3(kMB), 0, ctx->stream, e);
       PCP_HIP_TRY(ctx, hipGetLastError());
     }
     // voxels whose nearest point has no valid fit are skipped by PCL: compact if any
