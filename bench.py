@@ -210,6 +210,23 @@ def main():
                        "radius": 0.03, "order": 2, "upsampling": "NONE", "ms": round(t_mls * 1e3, 2),
                        "kernels_ms": {eng.ctx.kernel_name(k): round(eng.ctx.timing_get(k)[0], 3)
                                       for k in (capi.K_MLS_GRID, capi.K_MLS_FIT)}}
+                # the whole CloudSmooth::process of enableMLS=1 (cloudSmooth.cpp:109-164): SOR -> MLS -> SOR on the device
+                try:
+                    eng.ctx.cloud_smooth(mp)  # warm-up
+                    eng.ctx.synchronize()
+                    eng.ctx.timing_enable(True)
+                    eng.ctx.timing_reset()
+                    t1 = time.perf_counter()
+                    ms_ = eng.ctx.cloud_smooth(mp)
+                    eng.ctx.synchronize()
+                    t_s = time.perf_counter() - t1
+                    eng.ctx.timing_enable(False)
+                    mls["sor_mls_sor"] = {"points": nm, "outputs": int(ms_), "ms": round(t_s * 1e3, 2),
+                                          "Mpoints_per_s": round(nm / t_s / 1e6, 1),
+                                          "kernels_ms": {eng.ctx.kernel_name(k): round(eng.ctx.timing_get(k)[0], 3)
+                                                         for k in (capi.K_SOR, capi.K_MLS_GRID, capi.K_MLS_FIT, capi.K_MISC)}}
+                except capi.PcpError as e:
+                    mls["sor_mls_sor"] = {"error": str(e)}
                 # VOXEL_GRID_DILATION (the reference's configuration: 1 mm voxels, 4 iterations) on a thin slab of
                 # the same cloud -- at full C3 size the reference's own settings produce > 2^31 voxels
                 try:
@@ -225,6 +242,19 @@ def main():
                     mls["voxel_grid_dilation"] = {"points": int(vs.sum()), "outputs": int(mv), "voxel_size": 0.001,
                                                   "iterations": 4, "ms": round(t_v * 1e3, 2),
                                                   "Moutputs_per_s": round(mv / t_v / 1e6, 1)}
+                    if not args.no_cpu:
+                        from oracle import oracle_capi as oc
+
+                        cs = (x[:nm] > 0.0) & (x[:nm] < 0.004)  # ~1 M voxels: a few seconds of CPU work
+                        op = oc.default_mls_params()
+                        op.threads = oc.hardware_threads()
+                        t1 = time.perf_counter()
+                        r = oc.mls_voxel_dilation(x[:nm][cs], y[:nm][cs], z[:nm][cs], op)
+                        t_c = (time.perf_counter() - t1) / 2.0  # the wrapper runs the algorithm twice (size query, fill)
+                        mls["voxel_grid_dilation"]["cpu_baseline"] = {
+                            "value": round(len(r["xyz"]) / t_c / 1e6, 3), "unit": "Moutputs/s", "cores": op.threads, "kind": "port",
+                            "sample": f"slab 0 < x < 0.004 of the same cloud, {int(cs.sum())} points -> {len(r['xyz'])} voxels, "
+                                      f"{t_c:.1f} s per pass, oracle/pcp_oracle_mls.c"}
                 except capi.PcpError as e:
                     mls["voxel_grid_dilation"] = {"error": str(e)}
                 eng.upload_cloud(x[:nm], y[:nm], z[:nm])

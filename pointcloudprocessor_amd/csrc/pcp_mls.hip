@@ -705,22 +705,29 @@ __global__ __launch_bounds__(kSorBlock) void k_sor_mean_distance(const float *__
       const float reach = static_cast<float>(ring - 1) * cell * 0.999f;
       if (reach * reach > heap[0]) break;
     }
+    // candidates of one run of cells, four at a time (12 coordinate loads in flight)
+    auto scan = [&](int32_t b, int32_t e) {
+      for (int32_t q = b; q < e; q += 4) {
+        const int32_t q1 = min(q + 1, e - 1), q2 = min(q + 2, e - 1), q3 = min(q + 3, e - 1);
+        const float d0 = sqdist_f32(sx[q], sy[q], sz[q], qx, qy, qz);
+        const float d1 = sqdist_f32(sx[q1], sy[q1], sz[q1], qx, qy, qz);
+        const float d2 = sqdist_f32(sx[q2], sy[q2], sz[q2], qx, qy, qz);
+        const float d3 = sqdist_f32(sx[q3], sy[q3], sz[q3], qx, qy, qz);
+        heap_push(heap, size, k, d0);
+        if (q + 1 < e) heap_push(heap, size, k, d1);
+        if (q + 2 < e) heap_push(heap, size, k, d2);
+        if (q + 3 < e) heap_push(heap, size, k, d3);
+      }
+    };
     for (int32_t zz = max(cz - ring, 0); zz <= min(cz + ring, g.nz - 1); ++zz)
       for (int32_t yy = max(cy - ring, 0); yy <= min(cy + ring, g.ny - 1); ++yy) {
         const bool shell_yz = zz == cz - ring || zz == cz + ring || yy == cy - ring || yy == cy + ring;
         const int32_t row = (zz * g.ny + yy) * g.nx;
         if (shell_yz) {
-          const int32_t b = start[row + max(cx - ring, 0)], e = start[row + min(cx + ring, g.nx - 1) + 1];
-          for (int32_t q = b; q < e; ++q) heap_push(heap, size, k, sqdist_f32(sx[q], sy[q], sz[q], qx, qy, qz));
+          scan(start[row + max(cx - ring, 0)], start[row + min(cx + ring, g.nx - 1) + 1]);
         } else {
-          if (cx - ring >= 0) {
-            const int32_t b = start[row + cx - ring], e = start[row + cx - ring + 1];
-            for (int32_t q = b; q < e; ++q) heap_push(heap, size, k, sqdist_f32(sx[q], sy[q], sz[q], qx, qy, qz));
-          }
-          if (cx + ring < g.nx && ring > 0) {
-            const int32_t b = start[row + cx + ring], e = start[row + cx + ring + 1];
-            for (int32_t q = b; q < e; ++q) heap_push(heap, size, k, sqdist_f32(sx[q], sy[q], sz[q], qx, qy, qz));
-          }
+          if (cx - ring >= 0) scan(start[row + cx - ring], start[row + cx - ring + 1]);
+          if (cx + ring < g.nx && ring > 0) scan(start[row + cx + ring], start[row + cx + ring + 1]);
         }
       }
   }
@@ -778,6 +785,13 @@ __global__ __launch_bounds__(kMB) void k_count_occupied(const int32_t *__restric
   const int64_t c = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
   const bool occ = c < ncell && start[c + 1] > start[c];
   const unsigned long long m = __ballot(occ);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(occupied, static_cast<unsigned long long>(__popcll(m)));
+}
+// the same on a histogram (build_grid(..., histogram_only))
+__global__ __launch_bounds__(kMB) void k_count_nonzero(const int32_t *__restrict__ count, int64_t ncell,
+                                                       unsigned long long *__restrict__ occupied) {
+  const int64_t c = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  const unsigned long long m = __ballot(c < ncell && count[c] > 0);
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(occupied, static_cast<unsigned long long>(__popcll(m)));
 }
 
@@ -868,7 +882,10 @@ static int exclusive_scan(pcp_context *ctx, int32_t *counts, int64_t m) {
 }
 
 // uniform grid over a cloud view, cell edge >= `cell`; fills ctx->g_*
-static int build_grid(pcp_context *ctx, const CloudView &cv, float cell, float radius, GridDesc *out) {
+// histogram_only: stop after the per-cell counts (ctx->g_start holds counts, not starts): enough to
+// estimate the surface density without paying for the scatter and the per-cell ordering.
+static int build_grid(pcp_context *ctx, const CloudView &cv, float cell, float radius, GridDesc *out,
+                      bool histogram_only = false) {
   const int64_t n = cv.n;
   GridDesc g{};
   const float *mn = cv.mn, *mx = cv.mx;
@@ -900,6 +917,11 @@ static int build_grid(pcp_context *ctx, const CloudView &cv, float cell, float r
     LaunchTimer t(ctx, PCP_K_MLS_GRID);
     hipLaunchKernelGGL(k_grid_count, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, x, y, z, n, g, ctx->g_cell.p,
                        ctx->g_rank.p, ctx->g_start.p);
+    if (histogram_only) {
+      PCP_HIP_TRY(ctx, hipGetLastError());
+      *out = g;
+      return PCP_OK;
+    }
     int rc = exclusive_scan(ctx, ctx->g_start.p, ncell);
     if (rc != PCP_OK) return rc;
     hipLaunchKernelGGL(k_grid_scatter, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, n, ctx->g_cell.p, ctx->g_rank.p,
@@ -1157,26 +1179,26 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
   float cell = static_cast<float>(std::cbrt(vol / static_cast<double>(n) * 4.0));
   if (!(cell > 1e-4f)) cell = 1e-4f;
   GridDesc g;
-  int rc = build_grid(ctx, cv, cell, cell, &g);
+  int rc = build_grid(ctx, cv, cell, cell, &g, /*histogram_only=*/true);
   if (rc != PCP_OK) return rc;
   {
     const int64_t ncell = static_cast<int64_t>(g.nx) * g.ny * g.nz;
     PCP_HIP_TRY(ctx, ctx->s_counter.ensure(4));
     PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->s_counter.p, 0, 8, ctx->stream));
-    hipLaunchKernelGGL(k_count_occupied, dim3(blocks_of(ncell)), dim3(kMB), 0, ctx->stream, ctx->g_start.p, ncell,
+    hipLaunchKernelGGL(k_count_nonzero, dim3(blocks_of(ncell)), dim3(kMB), 0, ctx->stream, ctx->g_start.p, ncell,
                        ctx->s_counter.p);
     unsigned long long occ = 0;
     PCP_HIP_TRY(ctx, hipMemcpyAsync(&occ, ctx->s_counter.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const double c0 = 1.0 / g.inv_cell;
+    double final_cell = c0;
     if (occ > 0) {
       const double per_area = static_cast<double>(n) / (static_cast<double>(occ) * c0 * c0);  // points per unit area
       const double want = std::sqrt(2.5 * (mean_k + 1) / (9.0 * per_area));
-      if (want > 0.0 && (want < 0.7 * c0 || want > 1.4 * c0)) {
-        rc = build_grid(ctx, cv, static_cast<float>(want), static_cast<float>(want), &g);
-        if (rc != PCP_OK) return rc;
-      }
+      if (want > 0.0 && (want < 0.7 * c0 || want > 1.4 * c0)) final_cell = want;
     }
+    rc = build_grid(ctx, cv, static_cast<float>(final_cell), static_cast<float>(final_cell), &g);
+    if (rc != PCP_OK) return rc;
   }
   PCP_HIP_TRY(ctx, ctx->m_tmp.ensure(sn + 8));
   PCP_HIP_TRY(ctx, ctx->m_flag.ensure(sn + 16));
