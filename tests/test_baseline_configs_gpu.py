@@ -82,3 +82,40 @@ def test_config1_1m_points_32_keyframes(gpu_ctx_factory, oracle):
     assert np.array_equal(one_shot["rgb"], ref["rgb"]) and np.array_equal(one_shot["has"], ref["has"])
     assert ref["has"].sum() > 100_000
     ctx.close()
+
+
+def test_many_keyframes_multi_word_masks_and_unaligned_chunks(gpu_ctx_factory, oracle):
+    """300 keyframes = 10 tile-mask words with a ragged last word; depth and colour passes cut at boundaries that
+    are not multiples of 32 must give the one-shot result, which must equal the oracle's."""
+    from pointcloudprocessor_amd import capi, synth
+
+    cd = synth.camera_dict("tiny")
+    n, F = 60_000, 300
+    x, y, z, _ = synth.make_cloud(n)
+    poses, _ = synth.make_trajectory(F)
+    imgs = [synth.make_image(f, cd["image_width"], cd["image_height"]) for f in range(F)]
+    ocam, ocp = cam_struct(oracle, cd), oracle.default_cull_params()
+    ref = oracle.colorize(ocam, ocp, x, y, z, poses, imgs, threads=8, want_top=True)
+    ctx = gpu_ctx_factory()
+    ctx.set_camera(cam_struct(capi, cd))
+    ctx.upload_cloud(x, y, z)
+    ctx.set_frames(poses)
+    for f, im in enumerate(imgs):
+        ctx.upload_image(f, im)
+    one = ctx.colorize()
+    assert np.array_equal(one["rgb"], ref["rgb"]) and np.array_equal(one["has"], ref["has"])
+    cuts = [0, 17, 64, 65, 150, 255, 256, 299, 300]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        ctx.depth_pass(a, b)
+    for f in (0, 16, 17, 64, 149, 150, 299):
+        w2c, _ = oracle.pose_to_matrices(poses[f])
+        _, dmap_r, _ = oracle.cull_frame(ocam, ocp, w2c, x, y, z)
+        assert np.array_equal(ctx.download_depth_map(f).view(np.uint32), dmap_r.view(np.uint32)), f
+    ctx.colour_reset()
+    for a, b in ((0, 33), (33, 34), (34, 200), (200, 300)):
+        ctx.colour_pass(a, b)
+    got = ctx.colour_finalise(want_top=True)
+    for k in ("count", "top_frame", "top_rgb", "top_score", "rgb", "has"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert ref["has"].sum() > 5000
+    ctx.close()
