@@ -188,6 +188,26 @@ def main():
             "avg_launch_ms": round(avg_s * 1e3, 4),
             "launches": proj_launches,
         }
+        # ---- PCIe-inclusive figure (never `value`): the keyframe images start in pinned host memory ----
+        pcie = None
+        if world == 1 and not args.no_cpu:
+            try:
+                stage = torch.empty((F, H, W, 3), dtype=torch.uint8).pin_memory()
+                snp = stage.numpy()
+                for f in range(F):
+                    snp[f] = synth.make_image(f, W, H)
+                fence()
+                t1 = time.perf_counter()
+                for f in range(F):
+                    eng.ctx.upload_image_async(f, snp[f])
+                step()
+                fence()
+                t_p = time.perf_counter() - t1
+                pcie = {"ms": round(t_p * 1e3, 2), "value": round(N * F / t_p / 1e6, 1), "unit": "Mpoints*frames/s",
+                        "what": f"{F} BGR8 keyframes ({stage.numel() / 1e9:.2f} GB) from pinned host memory + one step + colours back"}
+                del stage, snp
+            except (RuntimeError, capi.PcpError) as e:
+                pcie = {"error": str(e)}
         # ---- MLS leg (Mpoints/s at r = 0.03, order 2, NONE upsampling) ----
         mls = None
         if not args.no_mls and world == 1:  # side legs (MLS, CPU baseline) run at N = 1 only
@@ -345,6 +365,7 @@ def main():
             "setup_s": round(t_setup, 1),
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "pcie_inclusive": pcie,
             "mls": mls,
         }
         if args.backend != "nccl":

@@ -134,6 +134,10 @@ int32_t pcp_frame_count(const pcp_context *ctx);
  * round trip, PointCloudProcessor.cpp:716-741), image_height rows of image_width
  * pixels, row_stride_bytes apart (cv::Mat::step). */
 int pcp_upload_image(pcp_context *ctx, int32_t frame, const uint8_t *bgr, int64_t row_stride_bytes);
+/* The same without waiting for the copy: returns once the transfer is queued on the context's stream.  The
+ * host buffer must stay valid and unchanged until pcp_synchronize (or any synchronising call) returns; from
+ * pinned memory a sequence of keyframes streams at the PCIe rate with the packing kernels in between. */
+int pcp_upload_image_async(pcp_context *ctx, int32_t frame, const uint8_t *bgr, int64_t row_stride_bytes);
 /* gray8 segmentation mask (cv::IMREAD_GRAYSCALE, PointCloudProcessor.cpp:775) */
 int pcp_upload_mask(pcp_context *ctx, int32_t frame, const uint8_t *gray, int64_t row_stride_bytes);
 

@@ -239,6 +239,12 @@ class Context:
         assert bgr.shape == (self.camera.image_height, self.camera.image_width, 3), bgr.shape
         self._check(self.lib.pcp_upload_image(self.h, C.c_int32(frame), _ptr(bgr), C.c_int64(bgr.strides[0])))
 
+    def upload_image_async(self, frame: int, bgr: np.ndarray):
+        """Queues the transfer only: `bgr` (ideally pinned) must stay alive and unchanged until synchronize()."""
+        assert bgr.dtype == np.uint8 and bgr.flags.c_contiguous
+        assert bgr.shape == (self.camera.image_height, self.camera.image_width, 3), bgr.shape
+        self._check(self.lib.pcp_upload_image_async(self.h, C.c_int32(frame), _ptr(bgr), C.c_int64(bgr.strides[0])))
+
     def upload_mask(self, frame: int, gray: np.ndarray):
         gray = np.ascontiguousarray(gray, np.uint8)
         assert gray.shape == (self.camera.image_height, self.camera.image_width), gray.shape

@@ -800,16 +800,18 @@ using namespace pcp;
 
 extern "C" {
 
-int pcp_upload_image(pcp_context *ctx, int32_t frame, const uint8_t *bgr, int64_t row_stride_bytes) {
-  int rc = check_ready(ctx, "pcp_upload_image", true);
+static int upload_image_impl(pcp_context *ctx, const char *who, int32_t frame, const uint8_t *bgr, int64_t row_stride_bytes,
+                             bool wait) {
+  int rc = check_ready(ctx, who, true);
   if (rc != PCP_OK) return rc;
-  if ((rc = check_frame(ctx, "pcp_upload_image", frame)) != PCP_OK) return rc;
+  if ((rc = check_frame(ctx, who, frame)) != PCP_OK) return rc;
   const int32_t w = ctx->dcam.img_w, h = ctx->dcam.img_h;
   if (!bgr || row_stride_bytes < 3 * static_cast<int64_t>(w))
-    return set_error(ctx, PCP_ERR_INVALID, "pcp_upload_image: NULL image or row stride < 3*width");
+    return set_error(ctx, PCP_ERR_INVALID, "%s: NULL image or row stride < 3*width", who);
   if ((rc = ensure_images(ctx)) != PCP_OK) return rc;
   const size_t bytes = static_cast<size_t>(row_stride_bytes) * h;
   PCP_HIP_TRY(ctx, ctx->s_keep.ensure(bytes + 16));
+  // one staging buffer is enough: the stream is in order, so the next copy starts after this image's pack
   PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->s_keep.p, bgr, bytes, hipMemcpyHostToDevice, ctx->stream));
   const int64_t px = static_cast<int64_t>(w) * h;
   {
@@ -818,9 +820,17 @@ int pcp_upload_image(pcp_context *ctx, int32_t frame, const uint8_t *bgr, int64_
                        w, h, ctx->images.p + static_cast<int64_t>(frame) * px, ctx->mask_set[frame] ? 0 : 1);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
-  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the host buffer may be reused by the caller
+  if (wait) PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the host buffer may be reused by the caller
   ctx->image_set[static_cast<size_t>(frame)] = 1;
   return PCP_OK;
+}
+
+int pcp_upload_image(pcp_context *ctx, int32_t frame, const uint8_t *bgr, int64_t row_stride_bytes) {
+  return upload_image_impl(ctx, "pcp_upload_image", frame, bgr, row_stride_bytes, true);
+}
+
+int pcp_upload_image_async(pcp_context *ctx, int32_t frame, const uint8_t *bgr, int64_t row_stride_bytes) {
+  return upload_image_impl(ctx, "pcp_upload_image_async", frame, bgr, row_stride_bytes, false);
 }
 
 int pcp_upload_mask(pcp_context *ctx, int32_t frame, const uint8_t *gray, int64_t row_stride_bytes) {

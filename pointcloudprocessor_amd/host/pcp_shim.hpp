@@ -51,6 +51,8 @@ class Device {
   }
   // cv::Mat rgb (CV_8UC3, after the HSV round trip): data, step
   void uploadImage(int keyframe, const uint8_t *bgr, int64_t step) { check(pcp_upload_image(ctx_, keyframe, bgr, step)); }
+  // decoded frames in pinned memory: queues the copy only; the buffer must outlive the next synchronising call
+  void uploadImageAsync(int keyframe, const uint8_t *bgr, int64_t step) { check(pcp_upload_image_async(ctx_, keyframe, bgr, step)); }
   // cv::Mat grayImg (CV_8UC1)
   void uploadMask(int keyframe, const uint8_t *gray, int64_t step) { check(pcp_upload_mask(ctx_, keyframe, gray, step)); }
 
