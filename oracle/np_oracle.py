@@ -235,21 +235,23 @@ def _eigen33_smallest(C):
     return w[0], V[:, 0]
 
 
-def mls(x, y, z, radius: float = 0.03, order: int = 2):
-    """PCL MovingLeastSquares, NONE upsampling, SIMPLE projection [upstream];
+def mls_results(x, y, z, radius: float = 0.03, order: int = 2):
+    """Per input point the MLSResult PCL caches (mean, normal, u, v, c_vec, curvature, K, fitted) or None when
+    the point has fewer than 3 neighbours (MovingLeastSquares::performProcessing skips it) [upstream];
     brute-force neighbours (small n only)."""
     x, y, z = (np.asarray(a, f32) for a in (x, y, z))
     n = len(x)
     P = np.stack([x, y, z], axis=1)
     sq_r = f32(radius * radius)
     nr_coeff = (order + 1) * (order + 2) // 2
-    out_xyz, out_n, out_c, out_i = [], [], [], []
+    res = []
     for i in range(n):
         d = P - P[i]
         d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
         nn = np.nonzero(d2 < sq_r)[0]
         K = len(nn)
         if K < 3:
+            res.append(None)
             continue
         nb = P[nn].astype(f64)
         c = nb.sum(axis=0) / K
@@ -268,7 +270,7 @@ def mls(x, y, z, radius: float = 0.03, order: int = 2):
             inv = 1.0 / np.sqrt(nrm[1] ** 2 + nrm[2] ** 2)
             v = np.array([0.0, -nrm[2] * inv, nrm[1] * inv])
         u = np.cross(nrm, v)
-        pt, nn_out = mean, nrm
+        cvec, fitted = np.zeros(nr_coeff), False
         if order > 1 and K >= nr_coeff:
             de = nb - mean
             w = np.exp(-(de * de).sum(axis=1) / (radius * radius))
@@ -285,20 +287,165 @@ def mls(x, y, z, radius: float = 0.03, order: int = 2):
                 cvec = np.linalg.solve(L.T, np.linalg.solve(L, b))
             except np.linalg.LinAlgError:
                 cvec = np.full(nr_coeff, np.nan)
-            if np.isfinite(cvec[0]):
-                pt = mean + cvec[0] * nrm
-                nn_out = nrm - cvec[order + 1] * u - cvec[1] * v
-                nn_out = nn_out / np.linalg.norm(nn_out)
+            fitted = True
+        res.append(dict(query=q, mean=mean, normal=nrm, u=u, v=v, c_vec=cvec, curvature=curv, K=K, fitted=fitted))
+    return res
+
+
+def _mls_project(r, p, order: int, required: int):
+    """MLSResult::projectPoint(p, SIMPLE, required) [upstream]: polynomial height and its gradient at the (u, v) of p
+    when the fit exists and the point had `required` neighbours, else the plane."""
+    de = p - r["mean"]
+    u, v = de @ r["u"], de @ r["v"]
+    w, nrm = 0.0, r["normal"].copy()
+    if order > 1 and r["K"] >= required and r["fitted"] and np.isfinite(r["c_vec"][0]):
+        dz = dzu = dzv = 0.0
+        j = 0
+        for ui in range(order + 1):
+            for vi in range(order - ui + 1):
+                c = r["c_vec"][j]
+                dz += u ** ui * v ** vi * c
+                if ui >= 1:
+                    dzu += c * ui * u ** (ui - 1) * v ** vi
+                if vi >= 1:
+                    dzv += c * vi * u ** ui * v ** (vi - 1)
+                j += 1
+        w = dz
+        nrm = nrm - (dzu * r["u"] + dzv * r["v"])
+        l = np.linalg.norm(nrm)
+        if l > 0:
+            nrm = nrm / l
+    return r["mean"] + u * r["u"] + v * r["v"] + w * r["normal"], nrm
+
+
+def mls(x, y, z, radius: float = 0.03, order: int = 2):
+    """PCL MovingLeastSquares, NONE upsampling, SIMPLE projection of the query point itself [upstream]."""
+    nr_coeff = (order + 1) * (order + 2) // 2
+    out_xyz, out_n, out_c, out_i = [], [], [], []
+    for i, r in enumerate(mls_results(x, y, z, radius, order)):
+        if r is None:
+            continue
+        pt, nn_out = r["mean"], r["normal"]
+        if r["fitted"] and np.isfinite(r["c_vec"][0]):  # projectQueryPoint: u = v = 0
+            pt = r["mean"] + r["c_vec"][0] * r["normal"]
+            nn_out = r["normal"] - r["c_vec"][order + 1] * r["u"] - r["c_vec"][1] * r["v"]
+            nn_out = nn_out / np.linalg.norm(nn_out)
         out_xyz.append(pt)
         out_n.append(nn_out)
-        out_c.append(curv)
+        out_c.append(r["curvature"])
         out_i.append(i)
     return dict(xyz=np.array(out_xyz, f64).reshape(-1, 3).astype(f32),
                 normal=np.array(out_n, f64).reshape(-1, 3).astype(f32),
                 curvature=np.array(out_c, f64).astype(f32), index=np.array(out_i, np.int32))
 
 
-# --------------------------------------------------------------------------- A4'
+def mls_voxel_dilation(x, y, z, radius: float = 0.03, order: int = 2, voxel: float = 0.001, iterations: int = 4):
+    """performUpsampling(VOXEL_GRID_DILATION) [upstream mls.hpp MLSVoxelGrid]: voxelise at `voxel` from the
+    bounding-box minimum, dilate the 26-neighbourhood `iterations` times (negative indices are not created,
+    SURVEY.md B16), and for every voxel in ascending key order project its position onto the polynomial of the
+    nearest input point (needs 5 * nr_coeff neighbours, else onto its plane)."""
+    x, y, z = (np.asarray(a, f32) for a in (x, y, z))
+    P = np.stack([x, y, z], axis=1)
+    res = mls_results(x, y, z, radius, order)
+    bmin, bmax = P.min(axis=0), P.max(axis=0)
+    vs = f32(voxel)
+    S = int(1.5 * float(np.max(bmax - bmin)) / float(vs))
+    cells = set()
+    for i in range(len(x)):
+        ix, iy, iz = (int(np.trunc((P[i, k] - bmin[k]) / vs)) for k in range(3))  # fp32 arithmetic, C truncation
+        cells.add((ix, iy, iz))
+    for _ in range(iterations):
+        grown = set()
+        for (ix, iy, iz) in cells:
+            for dx in (-1, 0, 1):
+                for dy in (-1, 0, 1):
+                    for dz in (-1, 0, 1):
+                        if ix + dx >= 0 and iy + dy >= 0 and iz + dz >= 0:
+                            grown.add((ix + dx, iy + dy, iz + dz))
+        cells = grown
+    nr_coeff = (order + 1) * (order + 2) // 2
+    out_xyz, out_n, out_c, out_i = [], [], [], []
+    for (ix, iy, iz) in sorted(cells, key=lambda c: (c[0] * S + c[1]) * S + c[2]):
+        p = np.array([f32(ix) * vs + bmin[0], f32(iy) * vs + bmin[1], f32(iz) * vs + bmin[2]], f32)
+        d = P - p
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]  # fp32 L2_Simple
+        best = int(np.argmin(d2))  # first minimum = lowest index
+        r = res[best]
+        if r is None:
+            continue
+        pt, nrm = _mls_project(r, p.astype(f64), order, 5 * nr_coeff)
+        out_xyz.append(pt)
+        out_n.append(nrm)
+        out_c.append(r["curvature"])
+        out_i.append(best)
+    return dict(xyz=np.array(out_xyz, f64).reshape(-1, 3).astype(f32),
+                normal=np.array(out_n, f64).reshape(-1, 3).astype(f32),
+                curvature=np.array(out_c, f64).astype(f32), index=np.array(out_i, np.int32))
+
+
+def sor(x, y, z, mean_k: int = 60, std_mul: float = 0.7):
+    """pcl::StatisticalOutlierRemoval [upstream statistical_outlier_removal.hpp]: mean distance to the mean_k nearest
+    neighbours (fp32 squared distances, the query itself is hit 0), then keep iff distance <= mean + mul * stddev.
+    Brute force (small n only).  Returns (keep, distances fp32, threshold)."""
+    x, y, z = (np.asarray(a, f32) for a in (x, y, z))
+    n = len(x)
+    P = np.stack([x, y, z], axis=1)
+    dist = np.zeros(n, f32)
+    for i in range(n):
+        d = P - P[i]
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        nn = np.sort(d2)[1:mean_k + 1]
+        dist[i] = f32(np.sqrt(nn).astype(f64).sum() / mean_k)  # sqrt(float) summed in double
+    s = dist.astype(f64).sum()
+    sq = (dist * dist).astype(f64).sum()  # fp32 squares, double accumulation
+    mean = s / n
+    var = (sq - s * s / n) / (n - 1)
+    thr = mean + std_mul * np.sqrt(var)
+    return (dist.astype(f64) <= thr).astype(np.uint8), dist, thr
+
+
+# --------------------------------------------------------------------------- f1
+_BSPLINE = np.array([[1.0, -3.0, 3.0, -1.0], [4.0, 0.0, -6.0, 3.0], [1.0, 3.0, 3.0, -3.0], [0.0, 0.0, 0.0, 1.0]]) / 6.0
+
+
+def nid_cost(cam: dict, image, x, y, z, intensity, T, bins: int = 16):
+    """NIDCost::operator() value for one keyframe (PCP/include/vlcal/costs/nid_cost.hpp:42-116): x, y, z, intensity =
+    the culled cloud, T = T_camera_lidar (4x4), image BGR8 read with the reference's channel accident (element x of
+    the interleaved row, visual_camera_calibration.cpp:171-173)."""
+    P = np.stack([np.asarray(a, f32).astype(f64) for a in (x, y, z)], axis=1)
+    T = np.asarray(T, f64).reshape(4, 4)
+    pc = P @ T[:3, :3].T + T[:3, 3]
+    u, v = project(cam, pc[:, 0], pc[:, 1], pc[:, 2])
+    W, H = cam["image_width"], cam["image_height"]
+    bin_pts = np.clip((np.asarray(intensity, f32).astype(f64) * bins).astype(np.int64), 0, bins - 1)
+    ok = np.isfinite(u) & np.isfinite(v) & (np.abs(u) <= 1e9) & (np.abs(v) <= 1e9)
+    kx, ky = np.floor(np.where(ok, u, -1.0)).astype(np.int64), np.floor(np.where(ok, v, -1.0)).astype(np.int64)
+    ok &= (kx >= 0) & (ky >= 0) & (kx < W) & (ky < H)
+    u, v, kx, ky, bin_pts = u[ok], v[ok], kx[ok], ky[ok], bin_pts[ok]
+    hist_points = np.bincount(bin_pts, minlength=bins).astype(f64)
+    su, sv = u - kx, v - ky
+    bu = _BSPLINE @ np.stack([np.ones_like(su), su, su ** 2, su ** 3])  # (4, m)
+    bv = _BSPLINE @ np.stack([np.ones_like(sv), sv, sv ** 2, sv ** 3])
+    flat = np.asarray(image, np.uint8).reshape(H, W * 3)  # the CV_64FC3 row as the reference indexes it
+    hist = np.zeros((bins, bins))
+    for a in range(4):
+        px = np.clip(kx - 1 + a, 0, W - 1)
+        for b in range(4):
+            py = np.clip(ky - 1 + b, 0, H - 1)
+            pix = flat[py, px].astype(f64) / 255.0
+            bin_img = np.minimum((pix * bins).astype(np.int64), bins - 1)
+            np.add.at(hist, (bin_img, bin_pts), bu[a] * bv[b])
+    total = hist_points.sum()
+    h_img = hist.sum(axis=1) / total
+    h_pts = hist_points / total
+    h_ip = hist / total
+    H_image = -(h_img * np.log(h_img + 1e-6)).sum()
+    H_points = -(h_pts * np.log(h_pts + 1e-6)).sum()
+    H_ip = -(h_ip * np.log(h_ip + 1e-6)).sum()
+    MI = H_image + H_points - H_ip
+    return (H_ip - MI) / H_ip
+
+
 def hpr_frame(cam: dict, w2c, x, y, z, flip_radius: float = 90000.0):
     """The ACTIVE reference cull (Katz HPR, view_culling.cpp:266-334) through
     scipy's bundled qhull_r -- CPU-only documented alternative (Appendix B1)."""

@@ -8,7 +8,8 @@ restatement against itself across languages (numpy here, C in
 oracle/pcp_oracle.c, HIP in csrc/) and across time.  Parity stays "unpinned"
 in the sense of the task statement; see DESIGN.md.
 
-    python tests/golden/make_golden.py        # rewrites the .npz files
+    python tests/golden/make_golden.py            # rewrites every .npz file
+    python tests/golden/make_golden.py g7 g8 g9   # only the named ones (zip timestamps make rewrites non-identical)
 """
 import os
 import sys
@@ -30,7 +31,12 @@ def nano_camera():
     return d
 
 
+ONLY = set(sys.argv[1:])
+
+
 def save(name, **arrays):
+    if ONLY and name.split("_")[0] not in ONLY:
+        return
     path = os.path.join(HERE, name)
     np.savez_compressed(path, **arrays)
     print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
@@ -112,6 +118,50 @@ def main():
             key.append(i)
     save("g6_odometry.npz", text=np.array("\n".join(lines) + "\n"), poses=od_poses, ts=ts,
          keyframes=np.array(key, np.int32))
+
+    # ---- the "next" rows (SURVEY.md 8 f): SOR, voxel-grid dilation, NID cost ----
+    rng = np.random.default_rng(20241009)
+    # g7: StatisticalOutlierRemoval (k = 20 on 900 points: brute-force twin) -- a bumpy sheet plus strays
+    n = 900
+    a = rng.uniform(-0.15, 0.15, (n, 2))
+    sheet = np.stack([a[:, 0] + 0.5, a[:, 1] - 1.0, 0.3 * np.sin(9 * a[:, 0]) * a[:, 1] + rng.normal(0, 8e-4, n)], 1)
+    stray = np.stack([rng.uniform(0.3, 0.7, 25), rng.uniform(-1.2, -0.8, 25), rng.uniform(-0.1, 0.1, 25)], 1)
+    pts = np.concatenate([sheet, stray]).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    keep, dist, thr = npo.sor(pts[:, 0], pts[:, 1], pts[:, 2], 20, 0.7)
+    save("g7_sor.npz", x=pts[:, 0], y=pts[:, 1], z=pts[:, 2], mean_k=np.int32(20), std_mul=np.float64(0.7), keep=keep,
+         distance=dist, threshold=np.float64(thr))
+
+    # g8: VOXEL_GRID_DILATION (4 mm voxels, 2 iterations on a 400-point quadric patch)
+    n = 400
+    a = rng.uniform(-0.06, 0.06, (n, 2))
+    pts = np.stack([a[:, 0] - 0.3, a[:, 1] + 0.2, 0.2 * a[:, 0] ** 2 - 0.1 * a[:, 0] * a[:, 1] + rng.normal(0, 3e-4, n)],
+                   1).astype(np.float32)
+    v = npo.mls_voxel_dilation(pts[:, 0], pts[:, 1], pts[:, 2], 0.03, 2, 0.004, 2)
+    save("g8_voxel_dilation.npz", x=pts[:, 0], y=pts[:, 1], z=pts[:, 2], voxel=np.float32(0.004), iterations=np.int32(2),
+         xyz=v["xyz"], normal=v["normal"], curvature=v["curvature"], index=v["index"])
+
+    # g9: NID cost of two keyframes at three extrinsics (value; the gradient is checked by finite differences of it)
+    cam = nano_camera()
+    n = 3000
+    zc = rng.uniform(1, 4, n).astype(np.float32)
+    xc = (rng.uniform(-0.4, 0.4, n) * zc).astype(np.float32)
+    yc = (rng.uniform(-0.22, 0.22, n) * zc).astype(np.float32)
+    inten = rng.random(n).astype(np.float32)
+    imgs = np.stack([synth.make_image(k, 160, 90) for k in range(2)])
+    off = np.array([0, n // 2, n], np.int64)
+    Ts, costs = [], []
+    for d in ([0, 0, 0, 0, 0, 0], [0.01, -0.02, 0.005, 0.003, -0.002, 0.004], [-0.05, 0.03, 0.02, -0.01, 0.015, -0.02]):
+        d = np.array(d, np.float64)
+        K = np.array([[0, -d[5], d[4]], [d[5], 0, -d[3]], [-d[4], d[3], 0]])
+        T = np.eye(4)
+        T[:3, :3] = np.eye(3) + K + 0.5 * K @ K
+        T[:3, 3] = (np.eye(3) + 0.5 * K) @ d[:3]
+        Ts.append(T)
+        costs.append(sum(npo.nid_cost(cam, imgs[k], xc[off[k]:off[k + 1]], yc[off[k]:off[k + 1]], zc[off[k]:off[k + 1]],
+                                      inten[off[k]:off[k + 1]], T) for k in range(2)))
+    save("g9_nid.npz", camera=cam_array(cam), x=xc, y=yc, z=zc, intensity=inten, images=imgs, offsets=off,
+         T=np.stack(Ts), cost=np.array(costs, np.float64))
 
 
 if __name__ == "__main__":

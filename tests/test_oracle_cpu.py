@@ -115,6 +115,42 @@ def test_g5_mls_golden(oracle):
     assert len(g["index"]) < len(g["x"])  # strays dropped
 
 
+def test_g7_sor_golden(oracle):
+    """C restatement of StatisticalOutlierRemoval against the brute-force numpy twin's vectors."""
+    g = load("g7_sor.npz")
+    keep, kept, dist, thr = oracle.sor(g["x"], g["y"], g["z"], int(g["mean_k"]), float(g["std_mul"]), threads=4, details=True)
+    assert np.array_equal(dist, g["distance"])
+    assert abs(thr - float(g["threshold"])) <= 1e-12 * thr
+    assert np.array_equal(keep, g["keep"]) and kept == int(g["keep"].sum())
+    assert 0.8 * len(keep) < kept < len(keep)
+
+
+def test_g8_voxel_dilation_golden(oracle):
+    g = load("g8_voxel_dilation.npz")
+    mp = oracle.default_mls_params()
+    mp.vgd_voxel_size = float(g["voxel"])
+    mp.vgd_iterations = int(g["iterations"])
+    mp.threads = 4
+    r = oracle.mls_voxel_dilation(g["x"], g["y"], g["z"], mp)
+    assert np.array_equal(r["index"], g["index"])  # voxel set, key order and nearest input point
+    assert np.abs(r["xyz"].astype(np.float64) - g["xyz"]).max() <= 3e-6
+    sgn = np.sign((r["normal"] * g["normal"]).sum(axis=1))  # the eigenvector's sign is the solver's choice
+    assert np.abs(r["normal"] * sgn[:, None] - g["normal"]).max() <= 1e-4
+    np.testing.assert_allclose(r["curvature"], g["curvature"], rtol=1e-4, atol=1e-9)
+    assert len(g["index"]) > 5 * len(g["x"])
+
+
+def test_g9_nid_cost_golden(oracle):
+    g = load("g9_nid.npz")
+    cam = oracle.Camera()
+    for (k, _), v in zip(oracle.Camera._fields_, g["camera"]):
+        setattr(cam, k, type(getattr(cam, k))(v))
+    imgs = [np.ascontiguousarray(im) for im in g["images"]]
+    for T, want in zip(g["T"], g["cost"]):
+        c, _, ok = oracle.nid(cam, imgs, g["offsets"], g["x"], g["y"], g["z"], g["intensity"], T)
+        assert ok and abs(c - want) <= 1e-12, (c, want)
+
+
 def test_g6_keyframes_golden(oracle):
     g = load("g6_odometry.npz")
     assert np.array_equal(oracle.select_keyframes(g["poses"], 0.1), g["keyframes"])
