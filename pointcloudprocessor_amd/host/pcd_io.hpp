@@ -1,6 +1,6 @@
 // pcd_io.hpp -- the PCD subset PointCloudProcessor reads and writes, without PCL.
 //
-// Reader: .pcd v0.7, DATA ascii | binary (not binary_compressed), any field list
+// Reader: .pcd v0.7, DATA ascii | binary | binary_compressed (LZF), any field list
 // that contains x y z (float32), optional intensity (float32) and rgb (packed).
 // What the reference calls: pcl::io::loadPCDFile<PointXYZI> (PCP/src/PointCloudProcessor.cpp:112,148,
 // PCP/src/cloudSmooth.cpp:92).
@@ -49,6 +49,37 @@ struct PcdField {
   int count = 1;
   int offset = 0;
 };
+
+namespace detail {
+// LZF decompression (Marc Lehmann's format, the codec of PCL's binary_compressed PCD files [upstream lzf.cpp]):
+// a control byte < 32 starts a literal run of ctrl + 1 bytes; otherwise a back reference of length
+// (ctrl >> 5) + 2 (plus an extension byte when the 3-bit length is 7) at distance ((ctrl & 31) << 8 | next) + 1.
+inline bool lzf_decompress(const unsigned char *in, size_t in_len, unsigned char *out, size_t out_len) {
+  size_t ip = 0, op = 0;
+  while (ip < in_len) {
+    unsigned ctrl = in[ip++];
+    if (ctrl < 32) {
+      const size_t run = ctrl + 1;
+      if (ip + run > in_len || op + run > out_len) return false;
+      std::memcpy(out + op, in + ip, run);
+      ip += run;
+      op += run;
+    } else {
+      size_t len = ctrl >> 5;
+      if (len == 7) {
+        if (ip >= in_len) return false;
+        len += in[ip++];
+      }
+      if (ip >= in_len) return false;
+      const size_t dist = ((ctrl & 31u) << 8 | in[ip++]) + 1;
+      len += 2;
+      if (dist > op || op + len > out_len) return false;
+      for (size_t k = 0; k < len; ++k, ++op) out[op] = out[op - dist];  // may overlap: byte by byte
+    }
+  }
+  return op == out_len;
+}
+}  // namespace detail
 
 inline int loadPCDFile(const std::string &path, XYZICloud &cloud) {
   std::ifstream in(path, std::ios::binary);
@@ -136,8 +167,27 @@ inline int loadPCDFile(const std::string &path, XYZICloud &cloud) {
       else
         cloud.intensity[p] = 0.0f;
     }
+  } else if (data_mode == "binary_compressed") {
+    // PCDWriter::writeBinaryCompressed [upstream pcd_io.cpp]: uint32 compressed size, uint32 uncompressed size,
+    // then the LZF stream of the cloud stored field by field (all x, all y, ... : SoA), each field `points`
+    // entries of size * count bytes
+    uint32_t csize = 0, usize = 0;
+    in.read(reinterpret_cast<char *>(&csize), 4);
+    in.read(reinterpret_cast<char *>(&usize), 4);
+    if (!in || usize != static_cast<uint64_t>(off) * points) return -1;
+    std::vector<unsigned char> comp(csize), raw(usize);
+    in.read(reinterpret_cast<char *>(comp.data()), csize);
+    if (!in || !detail::lzf_decompress(comp.data(), csize, raw.data(), usize)) return -1;
+    auto column = [&](int f) { return raw.data() + static_cast<size_t>(fields[static_cast<size_t>(f)].offset) * points; };
+    std::memcpy(cloud.x.data(), column(ix), points * 4);
+    std::memcpy(cloud.y.data(), column(iy), points * 4);
+    std::memcpy(cloud.z.data(), column(iz), points * 4);
+    if (ii >= 0 && fields[static_cast<size_t>(ii)].size == 4 && fields[static_cast<size_t>(ii)].count == 1)
+      std::memcpy(cloud.intensity.data(), column(ii), points * 4);
+    else
+      std::fill(cloud.intensity.begin(), cloud.intensity.end(), 0.0f);
   } else {
-    return -1;  // binary_compressed: not supported by this reader
+    return -1;
   }
   return 0;
 }
