@@ -169,7 +169,7 @@ def main():
         # MI355X_MICROARCH.md prescribes), collected with this command and committed under profiles/
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_e_pmc.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r01_f_pmc.json")) as fh:
                 pmc = json.load(fh)
             if pmc.get("points_per_launch") == N:
                 traffic = round(pmc["k_project_frame"]["traffic_bytes_per_launch"])
@@ -183,7 +183,7 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": traffic,
-            "traffic_source": "profiles/r01_e_pmc.json" if traffic else None,
+            "traffic_source": "profiles/r01_f_pmc.json" if traffic else None,
             "bytes_per_launch": PROJ_BYTES_PER_POINT * N,
             "avg_launch_ms": round(avg_s * 1e3, 4),
             "launches": proj_launches,
