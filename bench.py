@@ -208,6 +208,26 @@ def main():
                 del stage, snp
             except (RuntimeError, capi.PcpError) as e:
                 pcie = {"error": str(e)}
+        # ---- NID leg (config 5's pose refine): one cost + SE(3)-gradient evaluation over every keyframe's culled cloud ----
+        nid = None
+        if world == 1 and not args.no_mls:
+            try:
+                eng.ctx.upload_intensity(np.random.default_rng(5).random(N, dtype=np.float32))
+                t1 = time.perf_counter()
+                n_nid = eng.ctx.nid_prepare()
+                eng.ctx.synchronize()
+                t_prep = time.perf_counter() - t1
+                T_id = np.eye(4)
+                eng.ctx.nid_evaluate(T_id)  # warm-up
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    c_nid, _, ok_nid = eng.ctx.nid_evaluate(T_id)
+                t_eval = (time.perf_counter() - t1) / 3
+                nid = {"culled_points_all_keyframes": int(n_nid), "prepare_ms": round(t_prep * 1e3, 2),
+                       "evaluate_ms": round(t_eval * 1e3, 2), "Mpoints_per_s": round(n_nid / t_eval / 1e6, 1),
+                       "cost": round(c_nid, 6), "valid": bool(ok_nid), "bins": 16}
+            except capi.PcpError as e:
+                nid = {"error": str(e)}
         # ---- MLS leg (Mpoints/s at r = 0.03, order 2, NONE upsampling) ----
         mls = None
         if not args.no_mls and world == 1:  # side legs (MLS, CPU baseline) run at N = 1 only
@@ -366,6 +386,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "pcie_inclusive": pcie,
+            "nid": nid,
             "mls": mls,
         }
         if args.backend != "nccl":
