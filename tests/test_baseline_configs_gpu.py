@@ -119,3 +119,38 @@ def test_many_keyframes_multi_word_masks_and_unaligned_chunks(gpu_ctx_factory, o
         assert np.array_equal(got[k], ref[k]), k
     assert ref["has"].sum() > 5000
     ctx.close()
+
+
+def test_config4_shape_2048_keyframes_with_masks(gpu_ctx_factory, oracle):
+    """configs[4]'s keyframe count (2048 = 64 tile-mask words) and its segmentation masks on one rank's share of the
+    work, shrunk in points only: colours against the oracle, masked per-keyframe dumps for keyframes in the first,
+    a middle and the last word."""
+    from pointcloudprocessor_amd import capi, synth
+
+    cd = synth.camera_dict("tiny")
+    n, F = 40_000, 2048
+    W, H = cd["image_width"], cd["image_height"]
+    x, y, z, _ = synth.make_cloud(n)
+    poses, _ = synth.make_trajectory(F)
+    base_imgs = [synth.make_image(f, W, H) for f in range(8)]
+    base_masks = [synth.make_mask(f, W, H) for f in range(8)]
+    imgs = [base_imgs[f % 8] for f in range(F)]
+    ocam, ocp = cam_struct(oracle, cd), oracle.default_cull_params()
+    ctx = gpu_ctx_factory()
+    ctx.set_camera(cam_struct(capi, cd))
+    ctx.upload_cloud(x, y, z)
+    ctx.set_frames(poses)
+    for f in range(F):
+        ctx.upload_image(f, imgs[f])
+        ctx.upload_mask(f, base_masks[f % 8])
+    got = ctx.colorize()
+    ref = oracle.colorize(ocam, ocp, x, y, z, poses, imgs, threads=8, want_top=False)
+    assert np.array_equal(got["rgb"], ref["rgb"]) and np.array_equal(got["has"], ref["has"])
+    assert ref["has"].sum() > 5000
+    for f in (3, 1000, 2047):
+        r = oracle.frame_visible(ocam, ocp, poses[f], x, y, z, imgs[f], base_masks[f % 8])
+        g = ctx.frame_visible(f)
+        assert g["count"] == len(r["index"])
+        for k in ("index", "rgb", "mask", "xyz_cam", "xyz_world"):
+            assert np.array_equal(g[k], r[k]), (f, k)
+    ctx.close()
