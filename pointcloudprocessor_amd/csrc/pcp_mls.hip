@@ -273,19 +273,21 @@ __global__ __launch_bounds__(kFitBlock) void k_mls_fit(MlsArgs a) {
   // visit every neighbour once: body(px, py, pz)
   auto for_each_neighbour = [&](auto &&body) {
     if (fast) {
-      // the next neighbour's coordinates are in flight while the current one is accumulated
-      uint32_t code = nbr_code[0][tid];
-      int32_t k = run_base[code >> 12][tid] + static_cast<int32_t>(code & 4095u);
-      float nx = a.sx[k], ny = a.sy[k], nz = a.sz[k];
+      // the next two neighbours' coordinates are in flight while the current one is accumulated
+      auto index_of = [&](int32_t t) {
+        const uint32_t code = nbr_code[min(t, K - 1)][tid];
+        return run_base[code >> 12][tid] + static_cast<int32_t>(code & 4095u);
+      };
+      int32_t k0 = index_of(0), k1 = index_of(1);
+      float ax = a.sx[k0], ay = a.sy[k0], az = a.sz[k0];
+      float bx = a.sx[k1], by = a.sy[k1], bz = a.sz[k1];
       for (int32_t t = 0; t < K; ++t) {
-        const float px = nx, py = ny, pz = nz;
-        if (t + 1 < K) {
-          code = nbr_code[t + 1][tid];
-          k = run_base[code >> 12][tid] + static_cast<int32_t>(code & 4095u);
-          nx = a.sx[k];
-          ny = a.sy[k];
-          nz = a.sz[k];
-        }
+        const float px = ax, py = ay, pz = az;
+        ax = bx; ay = by; az = bz;
+        const int32_t k2 = index_of(t + 2);
+        bx = a.sx[k2];
+        by = a.sy[k2];
+        bz = a.sz[k2];
         body(px, py, pz);
       }
     } else {
@@ -373,44 +375,53 @@ __global__ __launch_bounds__(kFitBlock) void k_mls_fit(MlsArgs a) {
       const double f = (dx * nrm[0] + dy * nrm[1]) + dz * nrm[2];
       const double p1 = vc, p2 = vc * vc, p3 = uc, p4 = uc * vc, p5 = uc * uc;
       const double w1 = w * p1, w2 = w * p2, w3 = w * p3, w4 = w * p4, w5 = w * p5;
+      // the 21 entries of P W P^T are sums of w u^a v^b with a + b <= 4: only 15 distinct monomials
       A00 += w; A01 += w1; A02 += w2; A03 += w3; A04 += w4; A05 += w5;
-      A11 += w1 * p1; A12 += w1 * p2; A13 += w1 * p3; A14 += w1 * p4; A15 += w1 * p5;
-      A22 += w2 * p2; A23 += w2 * p3; A24 += w2 * p4; A25 += w2 * p5;
-      A33 += w3 * p3; A34 += w3 * p4; A35 += w3 * p5;
-      A44 += w4 * p4; A45 += w4 * p5;
+      A12 += w1 * p2; A14 += w1 * p4; A15 += w1 * p5;
+      A22 += w2 * p2; A24 += w2 * p4; A25 += w2 * p5;
+      A35 += w3 * p5;
+      A45 += w4 * p5;
       A55 += w5 * p5;
       b0 += w * f; b1 += w1 * f; b2 += w2 * f; b3 += w3 * f; b4 += w4 * f; b5 += w5 * f;
     });
+    A11 = A02;  // w v^2
+    A13 = A04;  // w u v
+    A33 = A05;  // w u^2
+    A23 = A14;  // w u v^2
+    A34 = A15;  // w u^2 v
+    A44 = A25;  // w u^2 v^2
     // LLT (lower) + forward / backward substitution, fully unrolled in registers
     bool ok = true;
     double L00, L10, L20, L30, L40, L50, L11, L21, L31, L41, L51, L22, L32, L42, L52, L33, L43, L53, L44, L54, L55;
     double d;
-    d = A00; ok = ok && d > 0.0; L00 = sqrt(d);
-    L10 = A01 / L00; L20 = A02 / L00; L30 = A03 / L00; L40 = A04 / L00; L50 = A05 / L00;
-    d = A11 - L10 * L10; ok = ok && d > 0.0; L11 = sqrt(d);
-    L21 = (A12 - L20 * L10) / L11; L31 = (A13 - L30 * L10) / L11; L41 = (A14 - L40 * L10) / L11;
-    L51 = (A15 - L50 * L10) / L11;
-    d = A22 - L20 * L20 - L21 * L21; ok = ok && d > 0.0; L22 = sqrt(d);
-    L32 = (A23 - L30 * L20 - L31 * L21) / L22; L42 = (A24 - L40 * L20 - L41 * L21) / L22;
-    L52 = (A25 - L50 * L20 - L51 * L21) / L22;
-    d = A33 - L30 * L30 - L31 * L31 - L32 * L32; ok = ok && d > 0.0; L33 = sqrt(d);
-    L43 = (A34 - L40 * L30 - L41 * L31 - L42 * L32) / L33; L53 = (A35 - L50 * L30 - L51 * L31 - L52 * L32) / L33;
-    d = A44 - L40 * L40 - L41 * L41 - L42 * L42 - L43 * L43; ok = ok && d > 0.0; L44 = sqrt(d);
-    L54 = (A45 - L50 * L40 - L51 * L41 - L52 * L42 - L53 * L43) / L44;
-    d = A55 - L50 * L50 - L51 * L51 - L52 * L52 - L53 * L53 - L54 * L54; ok = ok && d > 0.0; L55 = sqrt(d);
+    // the divisions by the six pivots are multiplications by their reciprocals (27 -> 6 divisions)
+    double i0, i1, i2, i3, i4, i5;
+    d = A00; ok = ok && d > 0.0; L00 = sqrt(d); i0 = 1.0 / L00;
+    L10 = A01 * i0; L20 = A02 * i0; L30 = A03 * i0; L40 = A04 * i0; L50 = A05 * i0;
+    d = A11 - L10 * L10; ok = ok && d > 0.0; L11 = sqrt(d); i1 = 1.0 / L11;
+    L21 = (A12 - L20 * L10) * i1; L31 = (A13 - L30 * L10) * i1; L41 = (A14 - L40 * L10) * i1;
+    L51 = (A15 - L50 * L10) * i1;
+    d = A22 - L20 * L20 - L21 * L21; ok = ok && d > 0.0; L22 = sqrt(d); i2 = 1.0 / L22;
+    L32 = (A23 - L30 * L20 - L31 * L21) * i2; L42 = (A24 - L40 * L20 - L41 * L21) * i2;
+    L52 = (A25 - L50 * L20 - L51 * L21) * i2;
+    d = A33 - L30 * L30 - L31 * L31 - L32 * L32; ok = ok && d > 0.0; L33 = sqrt(d); i3 = 1.0 / L33;
+    L43 = (A34 - L40 * L30 - L41 * L31 - L42 * L32) * i3; L53 = (A35 - L50 * L30 - L51 * L31 - L52 * L32) * i3;
+    d = A44 - L40 * L40 - L41 * L41 - L42 * L42 - L43 * L43; ok = ok && d > 0.0; L44 = sqrt(d); i4 = 1.0 / L44;
+    L54 = (A45 - L50 * L40 - L51 * L41 - L52 * L42 - L53 * L43) * i4;
+    d = A55 - L50 * L50 - L51 * L51 - L52 * L52 - L53 * L53 - L54 * L54; ok = ok && d > 0.0; L55 = sqrt(d); i5 = 1.0 / L55;
     if (ok) {
-      const double y0_ = b0 / L00;
-      const double y1_ = (b1 - L10 * y0_) / L11;
-      const double y2_ = (b2 - L20 * y0_ - L21 * y1_) / L22;
-      const double y3_ = (b3 - L30 * y0_ - L31 * y1_ - L32 * y2_) / L33;
-      const double y4_ = (b4 - L40 * y0_ - L41 * y1_ - L42 * y2_ - L43 * y3_) / L44;
-      const double y5_ = (b5 - L50 * y0_ - L51 * y1_ - L52 * y2_ - L53 * y3_ - L54 * y4_) / L55;
-      c[5] = y5_ / L55;
-      c[4] = (y4_ - L54 * c[5]) / L44;
-      c[3] = (y3_ - L43 * c[4] - L53 * c[5]) / L33;
-      c[2] = (y2_ - L32 * c[3] - L42 * c[4] - L52 * c[5]) / L22;
-      c[1] = (y1_ - L21 * c[2] - L31 * c[3] - L41 * c[4] - L51 * c[5]) / L11;
-      c[0] = (y0_ - L10 * c[1] - L20 * c[2] - L30 * c[3] - L40 * c[4] - L50 * c[5]) / L00;
+      const double y0_ = b0 * i0;
+      const double y1_ = (b1 - L10 * y0_) * i1;
+      const double y2_ = (b2 - L20 * y0_ - L21 * y1_) * i2;
+      const double y3_ = (b3 - L30 * y0_ - L31 * y1_ - L32 * y2_) * i3;
+      const double y4_ = (b4 - L40 * y0_ - L41 * y1_ - L42 * y2_ - L43 * y3_) * i4;
+      const double y5_ = (b5 - L50 * y0_ - L51 * y1_ - L52 * y2_ - L53 * y3_ - L54 * y4_) * i5;
+      c[5] = y5_ * i5;
+      c[4] = (y4_ - L54 * c[5]) * i4;
+      c[3] = (y3_ - L43 * c[4] - L53 * c[5]) * i3;
+      c[2] = (y2_ - L32 * c[3] - L42 * c[4] - L52 * c[5]) * i2;
+      c[1] = (y1_ - L21 * c[2] - L31 * c[3] - L41 * c[4] - L51 * c[5]) * i1;
+      c[0] = (y0_ - L10 * c[1] - L20 * c[2] - L30 * c[3] - L40 * c[4] - L50 * c[5]) * i0;
     } else {
       c[0] = c[1] = c[2] = c[3] = c[4] = c[5] = NAN;  // Eigen's LLT yields NaN; PCL then uses the plane
     }
