@@ -20,7 +20,10 @@
 #include <fstream>
 #include <sstream>
 #include <stdexcept>
+#include <algorithm>
+#include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace pcp_amd {
@@ -193,7 +196,69 @@ inline int loadPCDFile(const std::string &path, XYZICloud &cloud) {
 }
 
 namespace detail {
-inline void put_float(std::string &out, float v) {  // ostream << float at precision 8
+// "%.8g" of a float, the text `ostream << float` produces at precision 8 (PCDWriter::writeASCII [upstream]).
+// Values printed in fixed notation (decimal exponent -4 .. 7, i.e. every coordinate of a metre-scale map) are
+// formatted with exact integer arithmetic: |v| = m * 2^e, the 8 significant digits are round-half-even of
+// m * 5^k * 2^(e + k), k = 7 - exponent, which fits 128 bits.  Everything else goes through snprintf.
+// host/format_selftest.cpp compares the two on random bit patterns (tests/test_cli.py).
+inline bool put_float_fixed(std::string &out, float v) {
+  static const double kPow10[] = {1e-4, 1e-3, 1e-2, 1e-1, 1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8};
+  static const uint64_t kPow5[] = {1ull, 5ull, 25ull, 125ull, 625ull, 3125ull, 15625ull, 78125ull, 390625ull,
+                                   1953125ull, 9765625ull, 48828125ull};
+  const double a = std::fabs(static_cast<double>(v));
+  if (!(a >= 1e-4 && a < 1e8)) return false;
+  int X = -4;
+  while (a >= kPow10[X + 5]) ++X;  // 10^X <= a < 10^(X+1)
+  uint32_t bits;
+  std::memcpy(&bits, &v, 4);
+  const int be = static_cast<int>((bits >> 23) & 0xffu);
+  const uint64_t m = (bits & 0x7fffffu) | (be ? 0x800000u : 0u);
+  const int e = (be ? be : 1) - 150;  // |v| = m * 2^e
+  const int k = 7 - X;                // 0 .. 11
+  const unsigned __int128 num = static_cast<unsigned __int128>(m) * kPow5[k];
+  const int sh = e + k;
+  uint64_t N;
+  if (sh >= 0) {
+    N = static_cast<uint64_t>(num << sh);
+  } else {
+    const int r = -sh;  // at most 149 + ... in principle; a >= 1e-4 keeps it below 64 + 24
+    if (r >= 100) return false;
+    const unsigned __int128 q = num >> r, rem = num & ((static_cast<unsigned __int128>(1) << r) - 1);
+    const unsigned __int128 half = static_cast<unsigned __int128>(1) << (r - 1);
+    N = static_cast<uint64_t>(q);
+    if (rem > half || (rem == half && (N & 1u))) ++N;  // round half to even on the exact value
+  }
+  if (N >= 100000000ull) {  // carried into the next decade
+    N = 10000000ull;
+    ++X;
+    if (X >= 8) return false;  // exponent notation
+  }
+  char d[8];
+  for (int i = 7; i >= 0; --i) {
+    d[i] = static_cast<char>('0' + N % 10);
+    N /= 10;
+  }
+  int last = 7;
+  while (last > 0 && d[last] == '0') --last;  // %g strips trailing zeros
+  char buf[24];
+  int n = 0;
+  if (bits >> 31) buf[n++] = '-';
+  if (X >= 0) {
+    for (int i = 0; i <= X; ++i) buf[n++] = d[i];
+    if (last > X) {
+      buf[n++] = '.';
+      for (int i = X + 1; i <= last; ++i) buf[n++] = d[i];
+    }
+  } else {
+    buf[n++] = '0';
+    buf[n++] = '.';
+    for (int i = 0; i < -X - 1; ++i) buf[n++] = '0';
+    for (int i = 0; i <= last; ++i) buf[n++] = d[i];
+  }
+  out.append(buf, static_cast<size_t>(n));
+  return true;
+}
+inline void put_float_printf(std::string &out, float v) {
   if (std::isnan(v)) {
     out += "nan";
     return;
@@ -202,6 +267,9 @@ inline void put_float(std::string &out, float v) {  // ostream << float at preci
   std::snprintf(buf, sizeof(buf), "%.8g", static_cast<double>(v));
   out += buf;
 }
+inline void put_float(std::string &out, float v) {
+  if (!put_float_fixed(out, v)) put_float_printf(out, v);
+}
 inline std::string header(const char *fields, const char *sizes, const char *types, const char *counts, size_t n) {
   std::ostringstream h;
   h << "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS " << fields << "\nSIZE " << sizes << "\nTYPE "
@@ -209,95 +277,112 @@ inline std::string header(const char *fields, const char *sizes, const char *typ
     << "\nDATA ascii\n";
   return h.str();
 }
-inline int flush(const std::string &path, const std::string &body) {
+// Formats rows [0, n) with `row(out, i)` on all host cores (contiguous slices, one buffer per thread) and writes
+// header + slices in order: the bytes are those of a sequential writer, the wall time is not (the reference's
+// PCDWriter::writeASCII formats one value at a time on one thread and dominates its runs at scale).
+template <class Row>
+inline int write_rows(const std::string &path, const std::string &head, size_t n, size_t bytes_per_row_hint, Row row) {
+  unsigned threads = std::thread::hardware_concurrency();
+  if (const char *e = std::getenv("PCP_WRITER_THREADS")) threads = static_cast<unsigned>(std::max(1, std::atoi(e)));
+  threads = std::max(1u, std::min(threads, 32u));
+  if (n < 20000) threads = 1;
+  std::vector<std::string> part(threads);
+  auto work = [&](unsigned t) {
+    const size_t b = n * t / threads, e = n * (t + 1) / threads;
+    std::string &s = part[t];
+    s.reserve((e - b) * bytes_per_row_hint);
+    for (size_t i = b; i < e; ++i) row(s, i);
+  };
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < threads; ++t) pool.emplace_back(work, t);
+  work(0);
+  for (auto &th : pool) th.join();
   std::ofstream out(path, std::ios::binary);
   if (!out) return -1;
-  out.write(body.data(), static_cast<std::streamsize>(body.size()));
+  out.write(head.data(), static_cast<std::streamsize>(head.size()));
+  for (const auto &s : part) out.write(s.data(), static_cast<std::streamsize>(s.size()));
   return out ? 0 : -1;
+}
+inline void put_uint(std::string &s, uint32_t v) {  // "%u"
+  char buf[12];
+  int n = 12;
+  do {
+    buf[--n] = static_cast<char>('0' + v % 10u);
+    v /= 10u;
+  } while (v);
+  s.append(buf + n, static_cast<size_t>(12 - n));
+}
+inline void put_rgb(std::string &s, const uint8_t *rgb) {  // packed 0xAARRGGBB with A = 255 (PointXYZRGB ctor)
+  put_uint(s, 0xff000000u | (static_cast<uint32_t>(rgb[0]) << 16) | (static_cast<uint32_t>(rgb[1]) << 8) | rgb[2]);
 }
 }  // namespace detail
 
 // x y z intensity (pcl::PointXYZI)
 inline int writeASCII_XYZI(const std::string &path, const float *x, const float *y, const float *z, const float *intensity,
                            size_t n) {
-  std::string s = detail::header("x y z intensity", "4 4 4 4", "F F F F", "1 1 1 1", n);
-  s.reserve(s.size() + n * 48);
-  for (size_t i = 0; i < n; ++i) {
-    detail::put_float(s, x[i]);
-    s += ' ';
-    detail::put_float(s, y[i]);
-    s += ' ';
-    detail::put_float(s, z[i]);
-    s += ' ';
-    detail::put_float(s, intensity ? intensity[i] : 0.0f);
-    s += '\n';
-  }
-  return detail::flush(path, s);
+  return detail::write_rows(path, detail::header("x y z intensity", "4 4 4 4", "F F F F", "1 1 1 1", n), n, 48,
+                            [=](std::string &s, size_t i) {
+                              detail::put_float(s, x[i]);
+                              s += ' ';
+                              detail::put_float(s, y[i]);
+                              s += ' ';
+                              detail::put_float(s, z[i]);
+                              s += ' ';
+                              detail::put_float(s, intensity ? intensity[i] : 0.0f);
+                              s += '\n';
+                            });
 }
 
-// x y z rgb (pcl::PointXYZRGB): rgb as packed uint32 0xAARRGGBB with A = 255 (PointXYZRGB ctor)
+// x y z rgb (pcl::PointXYZRGB): rgb as packed uint32
 inline int writeASCII_XYZRGB(const std::string &path, const float *x, const float *y, const float *z, const uint8_t *rgb,
                              size_t n) {
-  std::string s = detail::header("x y z rgb", "4 4 4 4", "F F F U", "1 1 1 1", n);
-  s.reserve(s.size() + n * 48);
-  char buf[16];
-  for (size_t i = 0; i < n; ++i) {
-    detail::put_float(s, x[i]);
-    s += ' ';
-    detail::put_float(s, y[i]);
-    s += ' ';
-    detail::put_float(s, z[i]);
-    s += ' ';
-    const uint32_t packed = 0xff000000u | (static_cast<uint32_t>(rgb[3 * i]) << 16) |
-                            (static_cast<uint32_t>(rgb[3 * i + 1]) << 8) | rgb[3 * i + 2];
-    std::snprintf(buf, sizeof(buf), "%u", packed);
-    s += buf;
-    s += '\n';
-  }
-  return detail::flush(path, s);
+  return detail::write_rows(path, detail::header("x y z rgb", "4 4 4 4", "F F F U", "1 1 1 1", n), n, 48,
+                            [=](std::string &s, size_t i) {
+                              detail::put_float(s, x[i]);
+                              s += ' ';
+                              detail::put_float(s, y[i]);
+                              s += ' ';
+                              detail::put_float(s, z[i]);
+                              s += ' ';
+                              detail::put_rgb(s, rgb + 3 * i);
+                              s += '\n';
+                            });
 }
 
 // x y z rgb segmentMask (PointXYZRGBMask, PCP/include/FrameData.hpp:68-87)
 inline int writeASCII_XYZRGBMask(const std::string &path, const float *xyz /* 3 per point */, const uint8_t *rgb,
                                  const uint16_t *mask, size_t n) {
-  std::string s = detail::header("x y z rgb segmentMask", "4 4 4 4 2", "F F F U U", "1 1 1 1 1", n);
-  s.reserve(s.size() + n * 56);
-  char buf[32];
-  for (size_t i = 0; i < n; ++i) {
-    detail::put_float(s, xyz[3 * i]);
-    s += ' ';
-    detail::put_float(s, xyz[3 * i + 1]);
-    s += ' ';
-    detail::put_float(s, xyz[3 * i + 2]);
-    s += ' ';
-    const uint32_t packed = 0xff000000u | (static_cast<uint32_t>(rgb[3 * i]) << 16) |
-                            (static_cast<uint32_t>(rgb[3 * i + 1]) << 8) | rgb[3 * i + 2];
-    std::snprintf(buf, sizeof(buf), "%u %u", packed, static_cast<unsigned>(mask[i]));
-    s += buf;
-    s += '\n';
-  }
-  return detail::flush(path, s);
+  return detail::write_rows(path, detail::header("x y z rgb segmentMask", "4 4 4 4 2", "F F F U U", "1 1 1 1 1", n), n, 56,
+                            [=](std::string &s, size_t i) {
+                              for (int c = 0; c < 3; ++c) {
+                                detail::put_float(s, xyz[3 * i + static_cast<size_t>(c)]);
+                                s += ' ';
+                              }
+                              detail::put_rgb(s, rgb + 3 * i);
+                              s += ' ';
+                              detail::put_uint(s, mask[i]);
+                              s += '\n';
+                            });
 }
 
 // x y z normal_x normal_y normal_z curvature (pcl::PointNormal), savePCDFile default = ASCII (cloudSmooth.cpp:181)
 inline int writeASCII_PointNormal(const std::string &path, const float *xyz, const float *normal, const float *curv,
                                   size_t n) {
-  std::string s = detail::header("x y z normal_x normal_y normal_z curvature", "4 4 4 4 4 4 4", "F F F F F F F",
-                                 "1 1 1 1 1 1 1", n);
-  s.reserve(s.size() + n * 96);
-  for (size_t i = 0; i < n; ++i) {
-    for (int c = 0; c < 3; ++c) {
-      detail::put_float(s, xyz[3 * i + static_cast<size_t>(c)]);
-      s += ' ';
-    }
-    for (int c = 0; c < 3; ++c) {
-      detail::put_float(s, normal[3 * i + static_cast<size_t>(c)]);
-      s += ' ';
-    }
-    detail::put_float(s, curv[i]);
-    s += '\n';
-  }
-  return detail::flush(path, s);
+  return detail::write_rows(path,
+                            detail::header("x y z normal_x normal_y normal_z curvature", "4 4 4 4 4 4 4", "F F F F F F F",
+                                           "1 1 1 1 1 1 1", n),
+                            n, 96, [=](std::string &s, size_t i) {
+                              for (int c = 0; c < 3; ++c) {
+                                detail::put_float(s, xyz[3 * i + static_cast<size_t>(c)]);
+                                s += ' ';
+                              }
+                              for (int c = 0; c < 3; ++c) {
+                                detail::put_float(s, normal[3 * i + static_cast<size_t>(c)]);
+                                s += ' ';
+                              }
+                              detail::put_float(s, curv[i]);
+                              s += '\n';
+                            });
 }
 
 }  // namespace pcp_amd

@@ -174,6 +174,44 @@ def test_binary_compressed_pcd_input_cpu(tmp_path):
     assert outs[0] == outs[1] and len(outs[0]) > 1000
 
 
+def test_integer_float_formatter_equals_printf():
+    """host/pcd_io.hpp prints "%.8g" of fixed-notation floats with integer arithmetic; format_selftest compares it
+    with snprintf on random bit patterns and around decade / tie boundaries."""
+    from pointcloudprocessor_amd import host_build
+
+    exe = host_build.build()["format_selftest"]
+    p = subprocess.run([exe, "3000000"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert " 0 mismatches" in p.stdout and int(p.stdout.split()[0]) > 1_000_000
+
+
+def test_threaded_ascii_writer_is_byte_identical_cpu(tmp_path):
+    """The ASCII writers format slices of the cloud on several threads; the file must not depend on the count."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("the CPU-only exit path is what writes scans-crop.pcd before any device call")
+    from pointcloudprocessor_amd import synth
+
+    x, y, z, inten = synth.make_cloud(400_000, seed=9)
+    poses, ts = synth.make_trajectory(3)
+    _write_pcd_binary(tmp_path / "scans.pcd", x, y, z, inten)
+    with open(tmp_path / "odo.txt", "w") as f:
+        for t, p in zip(ts, poses):
+            f.write("%.6f %.6f %.6f %.6f %.8f %.8f %.8f %.8f\n" % (t, *p))
+            with open(tmp_path / ("%f.ppm" % t), "wb") as g:
+                g.write(b"P6\n4 2\n255\n" + bytes(24))
+    out = str(tmp_path) + "/"
+    files = []
+    for threads in ("1", "7"):
+        env = dict(os.environ, PCP_WRITER_THREADS=threads)
+        p = subprocess.run([_exe(), "-p", str(tmp_path / "scans.pcd"), "-o", str(tmp_path / "odo.txt"), "-i", out, "-t", out],
+                           capture_output=True, text=True, env=env)
+        assert p.returncode == 254, p.stderr[-500:]
+        files.append((tmp_path / "scans-crop.pcd").read_bytes())
+    assert files[0] == files[1] and files[0].count(b"\n") > 25_000  # above the writer's single-thread cut-off
+
+
 @pytest.mark.gpu
 def test_cli_end_to_end_matches_oracle(tmp_path, oracle):
     from pointcloudprocessor_amd import synth
