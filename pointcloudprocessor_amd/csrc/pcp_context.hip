@@ -5,8 +5,10 @@
 #include <cmath>
 #include <cstdlib>
 #include <new>
+#include <vector>
 
 #include "pcp_internal.hpp"
+#include "pcp_scan.hpp"
 
 namespace pcp {
 
@@ -142,8 +144,14 @@ static void matrices_from_pose(const pcp_pose &pose, const double *T, float w2c[
   invert_affine_f32(c2w, w2c);
 }
 
-// 30-bit Morton key of a point inside the cloud's bounding box.
-static inline uint32_t spread10(uint32_t v) {
+// ---------------------------------------------------------------------------
+// Cloud upload, on the device: bounding box, 30-bit Morton keys, a stable LSD radix sort (4 passes of
+// 8 bits), the Morton-ordered copy, and the bounding spheres of the 64-point tiles and of the groups of 16
+// tiles.  (The first version did all of this on one host thread: 275 ms for 10 M points.)
+// ---------------------------------------------------------------------------
+constexpr int kUpBlock = 256;
+
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {
   v &= 0x3ffu;
   v = (v | (v << 16)) & 0x030000ffu;
   v = (v | (v << 8)) & 0x0300f00fu;
@@ -152,55 +160,202 @@ static inline uint32_t spread10(uint32_t v) {
   return v;
 }
 
-// Spatial order for the batched run: 64 consecutive points (one wavefront) then
-// fall in few z-buffer cells and mostly share their keyframe visibility.
-static void spatial_permutation(const float *x, const float *y, const float *z, int64_t n, const float mn[3],
-                                const float mx[3], std::vector<int32_t> &perm) {
-  perm.resize(static_cast<size_t>(n));
-  std::vector<uint64_t> keys(static_cast<size_t>(n)), tmp(static_cast<size_t>(n));
-  float sc[3];
-  for (int a = 0; a < 3; ++a) {
-    const float ext = mx[a] - mn[a];
-    sc[a] = ext > 0.0f ? 1023.999f / ext : 0.0f;
-  }
-  for (int64_t i = 0; i < n; ++i) {
-    const uint32_t ix = static_cast<uint32_t>((x[i] - mn[0]) * sc[0]);
-    const uint32_t iy = static_cast<uint32_t>((y[i] - mn[1]) * sc[1]);
-    const uint32_t iz = static_cast<uint32_t>((z[i] - mn[2]) * sc[2]);
-    const uint64_t key = spread10(ix) | (spread10(iy) << 1) | (spread10(iz) << 2);
-    keys[static_cast<size_t>(i)] = (key << 32) | static_cast<uint32_t>(i);
-  }
-  // LSD radix sort on the 30 key bits (3 passes of 10 bits); stable, so equal keys keep input order
-  for (int pass = 0; pass < 3; ++pass) {
-    const int shift = 32 + 10 * pass;
-    size_t hist[1025] = {0};
-    for (int64_t i = 0; i < n; ++i) hist[((keys[static_cast<size_t>(i)] >> shift) & 0x3ffu) + 1]++;
-    for (int b = 0; b < 1024; ++b) hist[b + 1] += hist[b];
-    for (int64_t i = 0; i < n; ++i) {
-      const uint64_t k = keys[static_cast<size_t>(i)];
-      tmp[hist[(k >> shift) & 0x3ffu]++] = k;
+// per-workgroup min / max of the coordinates (NaN ignored, as std::min / std::max do on the host)
+__global__ __launch_bounds__(kUpBlock) void k_up_bbox(const float *__restrict__ x, const float *__restrict__ y,
+                                                     const float *__restrict__ z, int64_t n,
+                                                     float *__restrict__ partial /* [blocks][6] */) {
+  __shared__ float sh[6][kUpBlock / 64];
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kUpBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kUpBlock) {
+    const float v[3] = {x[i], y[i], z[i]};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (v[a] < lo[a]) lo[a] = v[a];
+      if (v[a] > hi[a]) hi[a] = v[a];
     }
-    keys.swap(tmp);
   }
-  for (int64_t i = 0; i < n; ++i) perm[static_cast<size_t>(i)] = static_cast<int32_t>(keys[static_cast<size_t>(i)] & 0xffffffffu);
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+    for (int o = 32; o >= 1; o >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64));
+    }
+  if ((threadIdx.x & 63) == 0)
+    for (int a = 0; a < 3; ++a) {
+      sh[a][threadIdx.x >> 6] = lo[a];
+      sh[3 + a][threadIdx.x >> 6] = hi[a];
+    }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    float v = sh[threadIdx.x][0];
+    for (int k = 1; k < kUpBlock / 64; ++k) v = threadIdx.x < 3 ? fminf(v, sh[threadIdx.x][k]) : fmaxf(v, sh[threadIdx.x][k]);
+    partial[static_cast<int64_t>(blockIdx.x) * 6 + threadIdx.x] = v;
+  }
 }
+
+// Spatial order for the batched run: 64 consecutive points (one wavefront) then fall in few z-buffer cells
+// and mostly share their keyframe visibility.
+__global__ __launch_bounds__(kUpBlock) void k_up_keys(const float *__restrict__ x, const float *__restrict__ y,
+                                                     const float *__restrict__ z, int64_t n, float mnx, float mny,
+                                                     float mnz, float scx, float scy, float scz,
+                                                     uint32_t *__restrict__ key, int32_t *__restrict__ val) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kUpBlock + threadIdx.x;
+  if (i >= n) return;
+  // non-finite coordinates convert to 0 / saturate: any key is fine, the order only affects speed
+  const uint32_t ix = static_cast<uint32_t>(fminf(fmaxf((x[i] - mnx) * scx, 0.0f), 1023.0f));
+  const uint32_t iy = static_cast<uint32_t>(fminf(fmaxf((y[i] - mny) * scy, 0.0f), 1023.0f));
+  const uint32_t iz = static_cast<uint32_t>(fminf(fmaxf((z[i] - mnz) * scz, 0.0f), 1023.0f));
+  key[i] = spread10(ix) | (spread10(iy) << 1) | (spread10(iz) << 2);
+  val[i] = static_cast<int32_t>(i);
+}
+
+// one radix pass, part 1: digit histogram of every 256-key workgroup, digit-major (hist[d][block]) so that the
+// exclusive scan of the whole table yields each (digit, workgroup) run's first output slot
+__global__ __launch_bounds__(kUpBlock) void k_up_radix_hist(const uint32_t *__restrict__ key, int64_t n, int32_t shift,
+                                                           int32_t *__restrict__ hist, int64_t blocks) {
+  __shared__ int32_t cnt[256];
+  cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kUpBlock + threadIdx.x;
+  if (i < n) atomicAdd(&cnt[(key[i] >> shift) & 0xffu], 1);
+  __syncthreads();
+  hist[static_cast<int64_t>(threadIdx.x) * blocks + blockIdx.x] = cnt[threadIdx.x];
+}
+
+// part 2: stable scatter.  A lane's rank among the equal digits of its wavefront comes from eight ballots (one
+// per digit bit); wavefronts of a workgroup are ordered through per-wavefront digit counts in LDS.
+__global__ __launch_bounds__(kUpBlock) void k_up_radix_scatter(const uint32_t *__restrict__ key_in,
+                                                              const int32_t *__restrict__ val_in, int64_t n,
+                                                              int32_t shift, const int32_t *__restrict__ offs,
+                                                              int64_t blocks, uint32_t *__restrict__ key_out,
+                                                              int32_t *__restrict__ val_out) {
+  __shared__ int32_t wcount[kUpBlock / 64][256];
+  __shared__ int32_t wbase[kUpBlock / 64][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = 0; k < kUpBlock / 64; ++k) wcount[k][threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kUpBlock + threadIdx.x;
+  const bool valid = i < n;
+  const uint32_t k = valid ? key_in[i] : 0u;
+  const int32_t v = valid ? val_in[i] : 0;
+  const uint32_t digit = (k >> shift) & 0xffu;
+  unsigned long long peers = __ballot(valid);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const bool bit = (digit >> b) & 1u;
+    const unsigned long long m = __ballot(bit);
+    peers &= bit ? m : ~m;
+  }
+  const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+  if (valid && rank == 0) wcount[wave][digit] = __popcll(peers);
+  __syncthreads();
+  {
+    int32_t run = offs[static_cast<int64_t>(threadIdx.x) * blocks + blockIdx.x];  // this thread = one digit
+    for (int w = 0; w < kUpBlock / 64; ++w) {
+      wbase[w][threadIdx.x] = run;
+      run += wcount[w][threadIdx.x];
+    }
+  }
+  __syncthreads();
+  if (valid) {
+    const int64_t pos = static_cast<int64_t>(wbase[wave][digit]) + rank;
+    key_out[pos] = k;
+    val_out[pos] = v;
+  }
+}
+
+__global__ __launch_bounds__(kUpBlock) void k_up_gather(const float *__restrict__ x, const float *__restrict__ y,
+                                                       const float *__restrict__ z, const int32_t *__restrict__ perm,
+                                                       int64_t n, float *__restrict__ sx, float *__restrict__ sy,
+                                                       float *__restrict__ sz) {
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * kUpBlock + threadIdx.x;
+  if (j >= n) return;
+  const int32_t i = perm[j];
+  sx[j] = x[i];
+  sy[j] = y[i];
+  sz[j] = z[i];
+}
+
+// bounding sphere of `span` consecutive Morton points per workgroup-slice: span = 64 (one wavefront per tile) or
+// 1024 (one workgroup per group of 16 tiles).  Centre = box centre rounded to fp32, radius = largest member
+// distance to that fp32 centre (fp64), inflated by 1e-6 and rounded up: it dominates every member's distance.
+template <int kSpan>
+__global__ __launch_bounds__(kUpBlock) void k_up_spheres(const float *__restrict__ sx, const float *__restrict__ sy,
+                                                        const float *__restrict__ sz, int64_t n,
+                                                        float4 *__restrict__ out, int64_t count) {
+  constexpr int kLanes = kSpan >= kUpBlock ? kUpBlock : kSpan;  // lanes cooperating on one sphere
+  constexpr int kPer = kSpan / kLanes;                           // points per lane
+  constexpr int kSpheresPerBlock = kUpBlock / kLanes;
+  __shared__ double red[7][kUpBlock / 64];
+  const int sub = threadIdx.x / kLanes, l = threadIdx.x % kLanes;
+  const int64_t sphere = static_cast<int64_t>(blockIdx.x) * kSpheresPerBlock + sub;
+  const int64_t b = sphere * kSpan;
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  float px[kPer], py[kPer], pz[kPer];
+  bool have[kPer];
+#pragma unroll
+  for (int q = 0; q < kPer; ++q) {
+    const int64_t j = b + static_cast<int64_t>(q) * kLanes + l;
+    have[q] = sphere < count && j < n;
+    px[q] = have[q] ? sx[j] : 0.0f;
+    py[q] = have[q] ? sy[j] : 0.0f;
+    pz[q] = have[q] ? sz[j] : 0.0f;
+    if (have[q]) {
+      lo[0] = fmin(lo[0], static_cast<double>(px[q])); hi[0] = fmax(hi[0], static_cast<double>(px[q]));
+      lo[1] = fmin(lo[1], static_cast<double>(py[q])); hi[1] = fmax(hi[1], static_cast<double>(py[q]));
+      lo[2] = fmin(lo[2], static_cast<double>(pz[q])); hi[2] = fmax(hi[2], static_cast<double>(pz[q]));
+    }
+  }
+  // reduce over the cooperating lanes: within the wavefront by shuffles, across wavefronts (kSpan = 1024) via LDS
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+    for (int o = (kLanes < 64 ? kLanes : 64) / 2; o >= 1; o >>= 1) {
+      lo[a] = fmin(lo[a], __shfl_xor(lo[a], o, 64));
+      hi[a] = fmax(hi[a], __shfl_xor(hi[a], o, 64));
+    }
+  if (kLanes > 64) {
+    if ((threadIdx.x & 63) == 0)
+      for (int a = 0; a < 3; ++a) {
+        red[a][threadIdx.x >> 6] = lo[a];
+        red[3 + a][threadIdx.x >> 6] = hi[a];
+      }
+    __syncthreads();
+    for (int a = 0; a < 3; ++a)
+      for (int k = 0; k < kUpBlock / 64; ++k) {
+        lo[a] = fmin(lo[a], red[a][k]);
+        hi[a] = fmax(hi[a], red[3 + a][k]);
+      }
+    __syncthreads();
+  }
+  float c[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) c[a] = static_cast<float>(0.5 * (lo[a] + hi[a]));
+  double r2 = 0.0;
+#pragma unroll
+  for (int q = 0; q < kPer; ++q)
+    if (have[q]) {
+      const double dx = static_cast<double>(px[q]) - static_cast<double>(c[0]);
+      const double dy = static_cast<double>(py[q]) - static_cast<double>(c[1]);
+      const double dz = static_cast<double>(pz[q]) - static_cast<double>(c[2]);
+      r2 = fmax(r2, (dx * dx + dy * dy) + dz * dz);  // fmax drops NaN members: they never project anyway
+    }
+  for (int o = (kLanes < 64 ? kLanes : 64) / 2; o >= 1; o >>= 1) r2 = fmax(r2, __shfl_xor(r2, o, 64));
+  if (kLanes > 64) {
+    if ((threadIdx.x & 63) == 0) red[6][threadIdx.x >> 6] = r2;
+    __syncthreads();
+    for (int k = 0; k < kUpBlock / 64; ++k) r2 = fmax(r2, red[6][k]);
+  }
+  if (l == 0 && sphere < count) {
+    float r = static_cast<float>(sqrt(r2) * (1.0 + 1e-6));
+    r = isfinite(r) ? __uint_as_float(__float_as_uint(r) + 1u) : r;  // next float up
+    out[sphere] = make_float4(c[0], c[1], c[2], r);
+  }
+}
+
+static inline uint32_t up_blocks(int64_t n) { return static_cast<uint32_t>(std::max<int64_t>(1, (n + kUpBlock - 1) / kUpBlock)); }
 
 static int store_cloud(pcp_context *ctx, const float *x, const float *y, const float *z, int64_t n) {
   PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (int64_t i = 0; i < n; ++i) {
-    mn[0] = std::min(mn[0], x[i]);
-    mx[0] = std::max(mx[0], x[i]);
-    mn[1] = std::min(mn[1], y[i]);
-    mx[1] = std::max(mx[1], y[i]);
-    mn[2] = std::min(mn[2], z[i]);
-    mx[2] = std::max(mx[2], z[i]);
-  }
-  if (n == 0) mn[0] = mn[1] = mn[2] = mx[0] = mx[1] = mx[2] = 0.0f;
-  for (int a = 0; a < 3; ++a) {
-    ctx->host_min[a] = mn[a];
-    ctx->host_max[a] = mx[a];
-  }
   const size_t sn = static_cast<size_t>(n);
   // pad every SoA plane to a multiple of 4 floats so float4 loads stay aligned
   const size_t plane = (sn + 3) & ~size_t(3);
@@ -215,83 +370,84 @@ static int store_cloud(pcp_context *ctx, const float *x, const float *y, const f
   ctx->colour_result_live = false;
   ctx->mls_count = 0;
   std::fill(ctx->depth_valid.begin(), ctx->depth_valid.end(), uint8_t(0));
+  for (int a = 0; a < 3; ++a) ctx->host_min[a] = ctx->host_max[a] = 0.0f;
   if (n == 0) return PCP_OK;
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->xyz.p, x, sn * 4, hipMemcpyHostToDevice, ctx->stream));
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->xyz.p + plane, y, sn * 4, hipMemcpyHostToDevice, ctx->stream));
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->xyz.p + 2 * plane, z, sn * 4, hipMemcpyHostToDevice, ctx->stream));
-  std::vector<int32_t> perm;
-  spatial_permutation(x, y, z, n, mn, mx, perm);
-  std::vector<float> sorted(3 * plane, 0.0f);
-  for (int64_t j = 0; j < n; ++j) {
-    const int32_t i = perm[static_cast<size_t>(j)];
-    sorted[static_cast<size_t>(j)] = x[i];
-    sorted[plane + static_cast<size_t>(j)] = y[i];
-    sorted[2 * plane + static_cast<size_t>(j)] = z[i];
-  }
-  // bounding sphere of every 64-point tile (one wavefront of the batched kernels)
-  const int64_t tiles = (n + 63) / 64;
-  std::vector<float> spheres(static_cast<size_t>(tiles) * 4);
-  for (int64_t t = 0; t < tiles; ++t) {
-    const int64_t b = t * 64, e = std::min<int64_t>(n, b + 64);
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (int64_t j = b; j < e; ++j)
-      for (int a = 0; a < 3; ++a) {
-        const double v = sorted[static_cast<size_t>(a) * plane + static_cast<size_t>(j)];
-        lo[a] = std::min(lo[a], v);
-        hi[a] = std::max(hi[a], v);
-      }
-    float c[3];
-    for (int a = 0; a < 3; ++a) c[a] = static_cast<float>(0.5 * (lo[a] + hi[a]));
-    double r2 = 0.0;
-    for (int64_t j = b; j < e; ++j) {
-      double d2 = 0.0;
-      for (int a = 0; a < 3; ++a) {
-        const double d = static_cast<double>(sorted[static_cast<size_t>(a) * plane + static_cast<size_t>(j)]) - static_cast<double>(c[a]);
-        d2 += d * d;
-      }
-      r2 = std::max(r2, d2);
+  hipStream_t st = ctx->stream;
+  float *dx = ctx->xyz.p, *dy = ctx->xyz.p + plane, *dz = ctx->xyz.p + 2 * plane;
+  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->sxyz.p, 0, (3 * plane + 4) * 4, st));  // plane padding reads as zeros
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(dx, x, sn * 4, hipMemcpyHostToDevice, st));
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(dy, y, sn * 4, hipMemcpyHostToDevice, st));
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(dz, z, sn * 4, hipMemcpyHostToDevice, st));
+  // ---- bounding box ----
+  const uint32_t bb_blocks = std::min<uint32_t>(up_blocks(n), 1024u);
+  DevBuf<float> partial;
+  PCP_HIP_TRY(ctx, partial.ensure(static_cast<size_t>(bb_blocks) * 6));
+  hipLaunchKernelGGL(k_up_bbox, dim3(bb_blocks), dim3(kUpBlock), 0, st, dx, dy, dz, n, partial.p);
+  std::vector<float> hp(static_cast<size_t>(bb_blocks) * 6);
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(hp.data(), partial.p, hp.size() * 4, hipMemcpyDeviceToHost, st));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(st));
+  partial.release();
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (uint32_t b = 0; b < bb_blocks; ++b)
+    for (int a = 0; a < 3; ++a) {
+      mn[a] = std::min(mn[a], hp[static_cast<size_t>(b) * 6 + a]);
+      mx[a] = std::max(mx[a], hp[static_cast<size_t>(b) * 6 + 3 + a]);
     }
-    spheres[static_cast<size_t>(t) * 4 + 0] = c[0];
-    spheres[static_cast<size_t>(t) * 4 + 1] = c[1];
-    spheres[static_cast<size_t>(t) * 4 + 2] = c[2];
-    // rounded up: the radius must dominate every member's distance to the fp32 centre
-    spheres[static_cast<size_t>(t) * 4 + 3] = std::nextafter(static_cast<float>(std::sqrt(r2) * (1.0 + 1e-6)), FLT_MAX);
+  float sc[3];
+  for (int a = 0; a < 3; ++a) {
+    ctx->host_min[a] = mn[a];
+    ctx->host_max[a] = mx[a];
+    const float ext = mx[a] - mn[a];
+    sc[a] = (ext > 0.0f && ext < FLT_MAX) ? 1023.999f / ext : 0.0f;
   }
-  // spheres of groups of 16 tiles (tested first by k_tile_mask), appended after the tile spheres
-  const int64_t groups = (tiles + 15) / 16;
-  spheres.resize(static_cast<size_t>(tiles + groups) * 4);
-  for (int64_t gi = 0; gi < groups; ++gi) {
-    const int64_t b = gi * 1024, e = std::min<int64_t>(n, b + 1024);
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (int64_t j = b; j < e; ++j)
-      for (int a = 0; a < 3; ++a) {
-        const double v = sorted[static_cast<size_t>(a) * plane + static_cast<size_t>(j)];
-        lo[a] = std::min(lo[a], v);
-        hi[a] = std::max(hi[a], v);
-      }
-    float c[3];
-    for (int a = 0; a < 3; ++a) c[a] = static_cast<float>(0.5 * (lo[a] + hi[a]));
-    double r2 = 0.0;
-    for (int64_t j = b; j < e; ++j) {
-      double d2 = 0.0;
-      for (int a = 0; a < 3; ++a) {
-        const double d = static_cast<double>(sorted[static_cast<size_t>(a) * plane + static_cast<size_t>(j)]) - static_cast<double>(c[a]);
-        d2 += d * d;
-      }
-      r2 = std::max(r2, d2);
-    }
-    float *o = &spheres[static_cast<size_t>(tiles + gi) * 4];
-    o[0] = c[0];
-    o[1] = c[1];
-    o[2] = c[2];
-    o[3] = std::nextafter(static_cast<float>(std::sqrt(r2) * (1.0 + 1e-6)), FLT_MAX);
+  // ---- Morton keys + stable LSD radix sort (key, input index) ----
+  const int64_t blocks = up_blocks(n);
+  DevBuf<uint32_t> key_a, key_b;
+  DevBuf<int32_t> val_b, hist;
+  PCP_HIP_TRY(ctx, key_a.ensure(sn + 4));
+  PCP_HIP_TRY(ctx, key_b.ensure(sn + 4));
+  PCP_HIP_TRY(ctx, val_b.ensure(sn + 4));
+  const int64_t hm = 256 * blocks;
+  PCP_HIP_TRY(ctx, hist.ensure(static_cast<size_t>(hm) + 8));
+  const int64_t scan_tiles = std::max<int64_t>(1, (hm + 1 + kScanTile - 1) / kScanTile);
+  PCP_HIP_TRY(ctx, ctx->s_tiles.ensure(static_cast<size_t>(scan_tiles) + 4));
+  hipLaunchKernelGGL(k_up_keys, dim3(up_blocks(n)), dim3(kUpBlock), 0, st, dx, dy, dz, n, mn[0], mn[1], mn[2], sc[0], sc[1],
+                     sc[2], key_a.p, ctx->perm.p);
+  uint32_t *kin = key_a.p, *kout = key_b.p;
+  int32_t *vin = ctx->perm.p, *vout = val_b.p;
+  for (int pass = 0; pass < 4; ++pass) {  // 30 key bits: 4 passes of 8 (an even count: the result lands in perm)
+    const int32_t shift = 8 * pass;
+    hipLaunchKernelGGL(k_up_radix_hist, dim3(static_cast<uint32_t>(blocks)), dim3(kUpBlock), 0, st, kin, n, shift, hist.p, blocks);
+    PCP_HIP_TRY(ctx, hipMemsetAsync(hist.p + hm, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(static_cast<uint32_t>(scan_tiles)), dim3(kScanBlock), 0, st, hist.p, hm + 1,
+                       ctx->s_tiles.p);
+    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kScanBlock), 0, st, ctx->s_tiles.p, scan_tiles,
+                       static_cast<unsigned long long *>(nullptr));
+    hipLaunchKernelGGL(k_scan_apply, dim3(static_cast<uint32_t>(scan_tiles)), dim3(kScanBlock), 0, st, hist.p, hm + 1,
+                       ctx->s_tiles.p, hist.p);
+    hipLaunchKernelGGL(k_up_radix_scatter, dim3(static_cast<uint32_t>(blocks)), dim3(kUpBlock), 0, st, kin, vin, n, shift,
+                       hist.p, blocks, kout, vout);
+    std::swap(kin, kout);
+    std::swap(vin, vout);
   }
-  ctx->n_tiles = tiles;
+  PCP_HIP_TRY(ctx, hipGetLastError());
+  // ---- Morton-ordered copy and the bounding spheres ----
+  hipLaunchKernelGGL(k_up_gather, dim3(up_blocks(n)), dim3(kUpBlock), 0, st, dx, dy, dz, ctx->perm.p, n, ctx->sxyz.p,
+                     ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane);
+  const int64_t tiles = (n + 63) / 64, groups = (tiles + 15) / 16;
   PCP_HIP_TRY(ctx, ctx->tile_sphere.ensure(static_cast<size_t>(tiles + groups) * 4 + 4));
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->tile_sphere.p, spheres.data(), static_cast<size_t>(tiles + groups) * 16, hipMemcpyHostToDevice, ctx->stream));
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->sxyz.p, sorted.data(), 3 * plane * 4, hipMemcpyHostToDevice, ctx->stream));
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->perm.p, perm.data(), sn * 4, hipMemcpyHostToDevice, ctx->stream));
-  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  float4 *sph = reinterpret_cast<float4 *>(ctx->tile_sphere.p);
+  hipLaunchKernelGGL(k_up_spheres<64>, dim3(static_cast<uint32_t>((tiles + 3) / 4)), dim3(kUpBlock), 0, st, ctx->sxyz.p,
+                     ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, n, sph, tiles);
+  hipLaunchKernelGGL(k_up_spheres<1024>, dim3(static_cast<uint32_t>(groups)), dim3(kUpBlock), 0, st, ctx->sxyz.p,
+                     ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, n, sph + tiles, groups);
+  PCP_HIP_TRY(ctx, hipGetLastError());
+  ctx->n_tiles = tiles;
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(st));  // the host arrays may be reused by the caller
+  key_a.release();
+  key_b.release();
+  val_b.release();
+  hist.release();
   return PCP_OK;
 }
 
