@@ -506,6 +506,18 @@ __global__ __launch_bounds__(kBlock) void k_selftest_div32(DevCamera cam, unsign
 // ---------------------------------------------------------------------------
 // small utility kernels
 // ---------------------------------------------------------------------------
+// packed result r | g<<8 | b<<16 | has<<24  ->  rgb[3n] (r, g, b) and has[n]
+__global__ __launch_bounds__(kBlock) void k_unpack_result(const uint32_t *__restrict__ packed, int64_t n,
+                                                         uint8_t *__restrict__ rgb, uint8_t *__restrict__ has) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t v = packed[i];
+  rgb[3 * i + 0] = static_cast<uint8_t>(v & 0xffu);
+  rgb[3 * i + 1] = static_cast<uint8_t>((v >> 8) & 0xffu);
+  rgb[3 * i + 2] = static_cast<uint8_t>((v >> 16) & 0xffu);
+  has[i] = static_cast<uint8_t>(v >> 24);
+}
+
 __global__ __launch_bounds__(kBlock) void k_fill_u32(uint32_t *__restrict__ p, int64_t n, uint32_t v) {
   int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
@@ -1141,18 +1153,15 @@ static int end_result(pcp_context *ctx, uint8_t *out_rgb, uint8_t *out_has) {
   ctx->rgba_cur = cur;
   ctx->colour_result_live = true;
   if ((out_rgb || out_has) && n > 0) {
-    std::vector<uint32_t> h(static_cast<size_t>(n));
-    PCP_HIP_TRY(ctx, hipMemcpyAsync(h.data(), dst, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    // split the packed words on the device: 3 + 1 bytes per point cross PCIe, and no host loop over the points
+    const size_t sn = static_cast<size_t>(n);
+    PCP_HIP_TRY(ctx, ctx->s_keep.ensure(4 * sn + 16));
+    uint8_t *d_rgb = ctx->s_keep.p, *d_has = ctx->s_keep.p + 3 * sn;
+    hipLaunchKernelGGL(k_unpack_result, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, dst, n, d_rgb, d_has);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+    if (out_rgb) PCP_HIP_TRY(ctx, hipMemcpyAsync(out_rgb, d_rgb, 3 * sn, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_has) PCP_HIP_TRY(ctx, hipMemcpyAsync(out_has, d_has, sn, hipMemcpyDeviceToHost, ctx->stream));
     PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (int64_t i = 0; i < n; ++i) {
-      const uint32_t v = h[static_cast<size_t>(i)];
-      if (out_rgb) {
-        out_rgb[3 * i + 0] = static_cast<uint8_t>(v & 0xffu);
-        out_rgb[3 * i + 1] = static_cast<uint8_t>((v >> 8) & 0xffu);
-        out_rgb[3 * i + 2] = static_cast<uint8_t>((v >> 16) & 0xffu);
-      }
-      if (out_has) out_has[i] = static_cast<uint8_t>(v >> 24);
-    }
   }
   return PCP_OK;
 }
