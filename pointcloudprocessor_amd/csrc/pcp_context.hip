@@ -354,7 +354,21 @@ __global__ __launch_bounds__(kUpBlock) void k_up_spheres(const float *__restrict
 
 static inline uint32_t up_blocks(int64_t n) { return static_cast<uint32_t>(std::max<int64_t>(1, (n + kUpBlock - 1) / kUpBlock)); }
 
-static int store_cloud(pcp_context *ctx, const float *x, const float *y, const float *z, int64_t n) {
+// x y z of `points + i * stride` -> SoA planes (stride % 4 == 0)
+__global__ __launch_bounds__(kUpBlock) void k_up_deinterleave(const uint32_t *__restrict__ aos, int64_t stride_words,
+                                                             int64_t n, float *__restrict__ x, float *__restrict__ y,
+                                                             float *__restrict__ z) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kUpBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t *p = aos + i * stride_words;
+  x[i] = __uint_as_float(p[0]);
+  y[i] = __uint_as_float(p[1]);
+  z[i] = __uint_as_float(p[2]);
+}
+
+// Either (x, y, z) SoA host arrays, or `aos` = n records of `stride` bytes starting with x y z (fp32).
+static int store_cloud(pcp_context *ctx, const float *x, const float *y, const float *z, int64_t n,
+                       const void *aos = nullptr, int64_t stride = 0) {
   PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t sn = static_cast<size_t>(n);
   // pad every SoA plane to a multiple of 4 floats so float4 loads stay aligned
@@ -375,9 +389,17 @@ static int store_cloud(pcp_context *ctx, const float *x, const float *y, const f
   hipStream_t st = ctx->stream;
   float *dx = ctx->xyz.p, *dy = ctx->xyz.p + plane, *dz = ctx->xyz.p + 2 * plane;
   PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->sxyz.p, 0, (3 * plane + 4) * 4, st));  // plane padding reads as zeros
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(dx, x, sn * 4, hipMemcpyHostToDevice, st));
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(dy, y, sn * 4, hipMemcpyHostToDevice, st));
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(dz, z, sn * 4, hipMemcpyHostToDevice, st));
+  DevBuf<uint32_t> raw;
+  if (aos) {
+    // the records cross PCIe as they are and are taken apart on the device
+    PCP_HIP_TRY(ctx, raw.ensure(static_cast<size_t>(n) * static_cast<size_t>(stride) / 4 + 4));
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(raw.p, aos, static_cast<size_t>(n) * static_cast<size_t>(stride), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_up_deinterleave, dim3(up_blocks(n)), dim3(kUpBlock), 0, st, raw.p, stride / 4, n, dx, dy, dz);
+  } else {
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(dx, x, sn * 4, hipMemcpyHostToDevice, st));
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(dy, y, sn * 4, hipMemcpyHostToDevice, st));
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(dz, z, sn * 4, hipMemcpyHostToDevice, st));
+  }
   // ---- bounding box ----
   const uint32_t bb_blocks = std::min<uint32_t>(up_blocks(n), 1024u);
   DevBuf<float> partial;
@@ -387,6 +409,7 @@ static int store_cloud(pcp_context *ctx, const float *x, const float *y, const f
   PCP_HIP_TRY(ctx, hipMemcpyAsync(hp.data(), partial.p, hp.size() * 4, hipMemcpyDeviceToHost, st));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(st));
   partial.release();
+  raw.release();
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   for (uint32_t b = 0; b < bb_blocks; ++b)
     for (int a = 0; a < 3; ++a) {
@@ -732,6 +755,9 @@ int pcp_upload_cloud_aos(pcp_context *ctx, const void *points, int64_t n, int64_
   if (n < 0 || n >= (int64_t(1) << 31)) return set_error(ctx, PCP_ERR_INVALID, "pcp_upload_cloud_aos: n out of range");
   if (stride_bytes < 12) return set_error(ctx, PCP_ERR_INVALID, "pcp_upload_cloud_aos: stride must be >= 12 bytes");
   if (n > 0 && !points) return set_error(ctx, PCP_ERR_INVALID, "pcp_upload_cloud_aos: NULL points");
+  if (stride_bytes % 4 == 0 && (reinterpret_cast<uintptr_t>(points) & 3u) == 0)
+    return store_cloud(ctx, nullptr, nullptr, nullptr, n, points, stride_bytes);
+  // odd strides / unaligned records: take them apart on the host
   std::vector<float> x(static_cast<size_t>(n)), y(static_cast<size_t>(n)), z(static_cast<size_t>(n));
   const uint8_t *base = static_cast<const uint8_t *>(points);
   for (int64_t i = 0; i < n; ++i) {

@@ -290,3 +290,31 @@ def test_non_finite_points_are_rejected_not_fatal(gpu_ctx_factory, oracle, small
     p_got = ctx.project_frame(1)
     assert np.array_equal(p_got["cell"], p_ref["cell"]) and np.array_equal(p_got["pixel"], p_ref["pixel"])
     ctx.close()
+
+
+@pytest.mark.parametrize("stride", [12, 16, 32, 13])
+def test_upload_aos_equals_soa(gpu_ctx_factory, small_scene, stride):
+    """pcl::PointXYZI records (x y z first, any stride) uploaded as they are give the same cloud as SoA arrays;
+    strides that are not a multiple of 4 take the host path."""
+    from pointcloudprocessor_amd import capi
+
+    x, y, z = small_scene["x"], small_scene["y"], small_scene["z"]
+    n = len(x)
+    raw = np.zeros((n, stride), np.uint8)
+    raw[:, 0:4] = x.view(np.uint8).reshape(n, 4)
+    raw[:, 4:8] = y.view(np.uint8).reshape(n, 4)
+    raw[:, 8:12] = z.view(np.uint8).reshape(n, 4)
+    raw[:, 12:] = 0xAB
+    outs = []
+    for aos in (False, True):
+        ctx = gpu_ctx_factory()
+        ctx.set_camera(cam_struct(capi, small_scene["cam"]))
+        if aos:
+            ctx.upload_cloud_aos(raw)
+        else:
+            ctx.upload_cloud(x, y, z)
+        ctx.set_frames(small_scene["poses"])
+        outs.append(ctx.project_frame(2))
+        ctx.close()
+    for k in ("cell", "pixel", "xc", "yc", "zc"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
