@@ -268,6 +268,7 @@ def main():
                     eng.ctx.timing_enable(False)
                     mls["sor_mls_sor"] = {"points": nm, "outputs": int(ms_), "ms": round(t_s * 1e3, 2),
                                           "Mpoints_per_s": round(nm / t_s / 1e6, 1),
+                                          "sor_heap_fallback_fraction": round(eng.ctx.sor_redo_fraction(), 5),
                                           "kernels_ms": {eng.ctx.kernel_name(k): round(eng.ctx.timing_get(k)[0], 3)
                                                          for k in (capi.K_SOR, capi.K_MLS_GRID, capi.K_MLS_FIT, capi.K_MISC)}}
                 except capi.PcpError as e:

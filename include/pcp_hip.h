@@ -244,6 +244,9 @@ int pcp_timing_get(pcp_context *ctx, int32_t kernel_id, double *total_ms, int64_
 const char *pcp_kernel_name(int32_t kernel_id);
 /* diagnostic: fraction of (tile, keyframe) pairs the conservative culling keeps (after pcp_depth_pass) */
 int pcp_tile_mask_density(pcp_context *ctx, double *kept_fraction);
+/* diagnostic: share of the points of the last pcp_sor / pcp_cloud_smooth SOR pass that the selection kernel handed
+ * to the heap kernel (fewer than mean_k + 1 neighbours within one grid cell, or a crowded boundary bin) */
+int pcp_sor_redo_fraction(pcp_context *ctx, double *fraction);
 /* diagnostic: the kernels replace three IEEE divisions of the projection (pinhole.hpp:17-18 x/z, y/z in fp64;
  * view_culling.cpp:88 u/14, v/14 in fp32) by shorter sequences that are proven to return the same correctly
  * rounded quotients (pcp_device.hpp).  This runs both forms on the device and counts disagreements:

@@ -388,6 +388,11 @@ class Context:
         return keep, kept.value
 
     # -- NID extrinsic refinement -----------------------------------------
+    def sor_redo_fraction(self) -> float:
+        v = C.c_double()
+        self._check(self.lib.pcp_sor_redo_fraction(self.h, C.byref(v)))
+        return v.value
+
     def upload_intensity(self, intensity):
         a = np.ascontiguousarray(intensity, np.float32)
         self._check(self.lib.pcp_upload_intensity(self.h, _ptr(a), C.c_int64(len(a))))

@@ -168,6 +168,7 @@ struct pcp_context {
   pcp::DevBuf<float> mls_xyz, mls_normal, mls_curv;
   pcp::DevBuf<int32_t> mls_index;
   int64_t mls_count = 0;
+  double sor_redo_fraction = 0.0;  // diagnostic: share of points the SOR selection kernel handed to the heap kernel
 
   // NID stage (section 8 f1): per-point intensity, per-keyframe culled clouds in camera
   // coordinates (x, y, z, intensity), chunked so that a workgroup sees one keyframe

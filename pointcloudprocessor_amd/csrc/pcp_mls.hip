@@ -705,10 +705,13 @@ __global__ __launch_bounds__(kSorBlock) void k_sor_mean_distance(const float *__
                                                                  const int32_t *__restrict__ order,
                                                                  const int32_t *__restrict__ remap,
                                                                  const int32_t *__restrict__ start, int64_t n, GridDesc g,
-                                                                 int32_t mean_k, float *__restrict__ distances) {
+                                                                 int32_t mean_k, float *__restrict__ distances,
+                                                                 const int32_t *__restrict__ list, int64_t list_n) {
   extern __shared__ float sor_heap[];
-  const int64_t j = static_cast<int64_t>(blockIdx.x) * kSorBlock + threadIdx.x;
-  if (j >= n) return;
+  // list == nullptr: every point; else only the cell-sorted positions named by the list (k_sor_select's leftovers)
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kSorBlock + threadIdx.x;
+  if (t >= (list ? list_n : n)) return;
+  const int64_t j = list ? list[t] : t;
   float *heap = sor_heap + threadIdx.x;
   const int k = mean_k + 1;
   const float qx = sx[j], qy = sy[j], qz = sz[j];
@@ -759,6 +762,128 @@ __global__ __launch_bounds__(kSorBlock) void k_sor_mean_distance(const float *__
   }
   if (size > 0) sum -= static_cast<double>(sqrtf(smallest));
   distances[remap ? remap[order[j]] : order[j]] = static_cast<float>(sum / static_cast<double>(mean_k));
+}
+
+// Selection without a heap (the common case).  All points closer than `limit` (= 0.999 grid cells) lie in the
+// 3x3x3 cells around the query, and the cell size is chosen so that this ball holds ~1.35 (k + 1) points.  Pass 1
+// counts the candidates inside the ball in 32 equal-width bins of the squared distance (8-bit counters in LDS,
+// [bin][lane]); the bin in which the count reaches k + 1 is the boundary bin.  Pass 2 adds sqrt(d) of every
+// candidate below the boundary bin and lists the boundary bin's members (a handful), of which the smallest
+// missing ones are then picked.  A lane whose ball holds fewer than k + 1 points, whose boundary bin overflows
+// the list, or whose counter saturates is flagged and redone by the heap kernel: the result is always the exact
+// sum over the k + 1 nearest, minus the nearest (the query itself).
+constexpr int kSelBins = 32;
+constexpr int kSelList = 16;
+__global__ __launch_bounds__(kSorBlock) void k_sor_select(const float *__restrict__ sx, const float *__restrict__ sy,
+                                                          const float *__restrict__ sz,
+                                                          const int32_t *__restrict__ order,
+                                                          const int32_t *__restrict__ remap,
+                                                          const int32_t *__restrict__ start, int64_t n, GridDesc g,
+                                                          int32_t mean_k, float *__restrict__ distances,
+                                                          uint8_t *__restrict__ redo) {
+  __shared__ uint8_t bins[kSelBins][kSorBlock];
+  __shared__ float list[kSelList][kSorBlock];
+  const int tid = threadIdx.x;
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * kSorBlock + tid;
+  if (j >= n) return;
+  const int k = mean_k + 1;
+  const float qx = sx[j], qy = sy[j], qz = sz[j];
+  int32_t cx, cy, cz;
+  grid_coords(g, qx, qy, qz, cx, cy, cz);
+  const float cell = 1.0f / g.inv_cell;
+  const float limit = cell * 0.999f, limit2 = limit * limit;  // 0.999: fp32 slop of the cell assignment
+  const float bin_scale = static_cast<float>(kSelBins) / limit2;
+#pragma unroll
+  for (int b = 0; b < kSelBins; ++b) bins[b][tid] = 0;
+  const int32_t x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+  const int32_t y0 = max(cy - 1, 0), y1 = min(cy + 1, g.ny - 1);
+  const int32_t z0 = max(cz - 1, 0), z1 = min(cz + 1, g.nz - 1);
+  bool bad = false;
+  // pass 1: histogram of the squared distances inside the ball
+  for (int32_t zz = z0; zz <= z1; ++zz)
+    for (int32_t yy = y0; yy <= y1; ++yy) {
+      const int32_t row = (zz * g.ny + yy) * g.nx;
+      const int32_t b = start[row + x0], e = start[row + x1 + 1];
+      for (int32_t q = b; q < e; q += 2) {
+        const int32_t q1 = min(q + 1, e - 1);
+        const float d0 = sqdist_f32(sx[q], sy[q], sz[q], qx, qy, qz);
+        const float d1 = sqdist_f32(sx[q1], sy[q1], sz[q1], qx, qy, qz);
+        if (d0 < limit2) {
+          const int bi = min(static_cast<int>(d0 * bin_scale), kSelBins - 1);
+          const uint8_t c = bins[bi][tid];
+          bad = bad || c == 255;
+          bins[bi][tid] = static_cast<uint8_t>(c + 1);
+        }
+        if (q + 1 < e && d1 < limit2) {
+          const int bi = min(static_cast<int>(d1 * bin_scale), kSelBins - 1);
+          const uint8_t c = bins[bi][tid];
+          bad = bad || c == 255;
+          bins[bi][tid] = static_cast<uint8_t>(c + 1);
+        }
+      }
+    }
+  int below = 0, boundary = -1;
+  for (int b = 0; b < kSelBins; ++b) {
+    const int c = bins[b][tid];
+    if (boundary < 0) {
+      if (below + c >= k)
+        boundary = b;
+      else
+        below += c;
+    }
+  }
+  bad = bad || boundary < 0;  // fewer than k + 1 points inside the ball
+  // pass 2: sum below the boundary bin, list the boundary bin
+  double sum = 0.0;
+  float smallest = FLT_MAX;
+  int listed = 0;
+  if (!bad) {
+    for (int32_t zz = z0; zz <= z1; ++zz)
+      for (int32_t yy = y0; yy <= y1; ++yy) {
+        const int32_t row = (zz * g.ny + yy) * g.nx;
+        const int32_t b = start[row + x0], e = start[row + x1 + 1];
+        for (int32_t q = b; q < e; q += 2) {
+          const int32_t q1 = min(q + 1, e - 1);
+          const float dd[2] = {sqdist_f32(sx[q], sy[q], sz[q], qx, qy, qz),
+                               q + 1 < e ? sqdist_f32(sx[q1], sy[q1], sz[q1], qx, qy, qz) : FLT_MAX};
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const float d = dd[u];
+            if (d < limit2) {
+              const int bi = min(static_cast<int>(d * bin_scale), kSelBins - 1);
+              if (bi < boundary) {
+                sum += static_cast<double>(sqrtf(d));
+                smallest = fminf(smallest, d);
+              } else if (bi == boundary) {
+                if (listed < kSelList) list[listed][tid] = d;
+                ++listed;
+              }
+            }
+          }
+        }
+      }
+    bad = listed > kSelList;
+  }
+  if (!bad) {
+    // the k - below smallest members of the boundary bin
+    for (int need = k - below; need > 0; --need) {
+      int at = 0;
+      float best = list[0][tid];
+      for (int e = 1; e < listed; ++e) {
+        const float v = list[e][tid];
+        if (v < best) {
+          best = v;
+          at = e;
+        }
+      }
+      sum += static_cast<double>(sqrtf(best));
+      smallest = fminf(smallest, best);
+      list[at][tid] = FLT_MAX;
+    }
+    sum -= static_cast<double>(sqrtf(smallest));  // hit 0 of nearestKSearch(k + 1) is the query itself
+    distances[remap ? remap[order[j]] : order[j]] = static_cast<float>(sum / static_cast<double>(mean_k));
+  }
+  redo[j] = bad ? 1 : 0;
 }
 
 // sum and sum of squares (fp32 squares, as the reference) of the distances, fp64 accumulation
@@ -1212,8 +1337,11 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
     double final_cell = c0;
     if (occ > 0) {
       const double per_area = static_cast<double>(n) / (static_cast<double>(occ) * c0 * c0);  // points per unit area
-      const double want = std::sqrt(2.5 * (mean_k + 1) / (9.0 * per_area));
-      if (want > 0.0 && (want < 0.7 * c0 || want > 1.4 * c0)) final_cell = want;
+      // cell edge such that the ball of one cell radius holds ~1.35 (k + 1) points of a surface of this density
+      double ball = 1.35;
+      if (const char *e = std::getenv("PCP_SOR_BALL")) ball = atof(e);
+      const double want = std::sqrt(ball * (mean_k + 1) / (3.14159265358979 * per_area));
+      if (want > 0.0 && want < 1e30) final_cell = want;
     }
     rc = build_grid(ctx, cv, static_cast<float>(final_cell), static_cast<float>(final_cell), &g);
     if (rc != PCP_OK) return rc;
@@ -1223,12 +1351,40 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
   PCP_HIP_TRY(ctx, ctx->m_sums.ensure(4));
   PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->m_sums.p, 0, 2 * sizeof(double), ctx->stream));
   float *dist = ctx->m_tmp.p;
+  const size_t heap_lds = static_cast<size_t>(mean_k + 1) * kSorBlock * sizeof(float);
+  static const bool use_select = [] {
+    const char *e = std::getenv("PCP_SOR_HEAP_ONLY");
+    return !(e && e[0] == '1');
+  }();
+  if (use_select && mean_k + 1 <= 250) {
+    // selection kernel for every point, heap kernel for the few it flags (sparse spots, borders of a surface)
+    PCP_HIP_TRY(ctx, ctx->s_cell.ensure(sn + 8));
+    {
+      LaunchTimer t(ctx, PCP_K_SOR);
+      hipLaunchKernelGGL(k_sor_select, dim3(static_cast<uint32_t>(div_up(n, kSorBlock))), dim3(kSorBlock), 0, ctx->stream,
+                         ctx->g_xyz.p, ctx->g_xyz.p + plane, ctx->g_xyz.p + 2 * plane, ctx->g_order.p, cv.remap,
+                         ctx->g_start.p, n, g, mean_k, dist, ctx->m_flag.p);
+      PCP_HIP_TRY(ctx, hipGetLastError());
+    }
+    int64_t redo = 0;
+    if ((rc = compact_flags(ctx, ctx->m_flag.p, n, ctx->s_cell.p, n, &redo)) != PCP_OK) return rc;
+    ctx->sor_redo_fraction = static_cast<double>(redo) / static_cast<double>(n);
+    if (redo > 0) {
+      LaunchTimer t(ctx, PCP_K_SOR);
+      hipLaunchKernelGGL(k_sor_mean_distance, dim3(static_cast<uint32_t>(div_up(redo, kSorBlock))), dim3(kSorBlock), heap_lds,
+                         ctx->stream, ctx->g_xyz.p, ctx->g_xyz.p + plane, ctx->g_xyz.p + 2 * plane, ctx->g_order.p,
+                         cv.remap, ctx->g_start.p, n, g, mean_k, dist, ctx->s_cell.p, redo);
+      PCP_HIP_TRY(ctx, hipGetLastError());
+    }
+  } else {
+    LaunchTimer t(ctx, PCP_K_SOR);
+    hipLaunchKernelGGL(k_sor_mean_distance, dim3(static_cast<uint32_t>(div_up(n, kSorBlock))), dim3(kSorBlock), heap_lds,
+                       ctx->stream, ctx->g_xyz.p, ctx->g_xyz.p + plane, ctx->g_xyz.p + 2 * plane, ctx->g_order.p,
+                       cv.remap, ctx->g_start.p, n, g, mean_k, dist, static_cast<const int32_t *>(nullptr), int64_t(0));
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
   {
     LaunchTimer t(ctx, PCP_K_SOR);
-    const size_t lds = static_cast<size_t>(mean_k + 1) * kSorBlock * sizeof(float);
-    hipLaunchKernelGGL(k_sor_mean_distance, dim3(static_cast<uint32_t>(div_up(n, kSorBlock))), dim3(kSorBlock), lds,
-                       ctx->stream, ctx->g_xyz.p, ctx->g_xyz.p + plane, ctx->g_xyz.p + 2 * plane, ctx->g_order.p,
-                       cv.remap, ctx->g_start.p, n, g, mean_k, dist);
     hipLaunchKernelGGL(k_sor_stats, dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(n, kMB), 1024))), dim3(kMB), 0,
                        ctx->stream, dist, n, ctx->m_sums.p);
     PCP_HIP_TRY(ctx, hipGetLastError());
@@ -1424,6 +1580,12 @@ int pcp_cloud_smooth(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_cou
   }
   ctx->mls_count = kept;
   if (out_count) *out_count = kept;
+  return PCP_OK;
+}
+
+int pcp_sor_redo_fraction(pcp_context *ctx, double *fraction) {
+  if (!ctx || !fraction) return PCP_ERR_INVALID;
+  *fraction = ctx->sor_redo_fraction;
   return PCP_OK;
 }
 
