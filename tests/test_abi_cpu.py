@@ -83,3 +83,18 @@ def test_kernel_names():
     lib = capi.load()
     names = [lib.pcp_kernel_name(C.c_int32(k)).decode() for k in range(capi.K_COUNT)]
     assert names[0] == "project_frame" and len(set(names)) == capi.K_COUNT
+
+
+def test_every_entry_point_is_documented():
+    """INTEGRATION.md names every symbol include/pcp_hip.h declares (with the reference call site it replaces)."""
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "pcp_hip.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    names = sorted(set(re.findall(r"\b(pcp_[a-z0-9_]+)\s*\(", header)))
+    assert len(names) > 40
+    missing = [n for n in names if n not in doc and not n.startswith(("pcp_timing_", "pcp_default_"))]
+    assert not missing, missing
+    assert "pcp_timing_" in doc and "pcp_default_" in doc
