@@ -79,8 +79,10 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(2)
-    if args.backend == "gloo":
-        local_rank = local_rank % torch.cuda.device_count()
+    ndev = torch.cuda.device_count()
+    if args.backend == "gloo" or local_rank >= ndev:
+        # gloo rehearsal (ranks share GPUs), or a launcher that shows every rank only its own device
+        local_rank = local_rank % max(ndev, 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.force_dist:
