@@ -765,15 +765,18 @@ __global__ __launch_bounds__(kSorBlock) void k_sor_mean_distance(const float *__
 }
 
 // Selection without a heap (the common case).  All points closer than `limit` (= 0.999 grid cells) lie in the
-// 3x3x3 cells around the query, and the cell size is chosen so that this ball holds ~1.35 (k + 1) points.  Pass 1
-// counts the candidates inside the ball in 32 equal-width bins of the squared distance (8-bit counters in LDS,
-// [bin][lane]); the bin in which the count reaches k + 1 is the boundary bin.  Pass 2 adds sqrt(d) of every
-// candidate below the boundary bin and lists the boundary bin's members (a handful), of which the smallest
-// missing ones are then picked.  A lane whose ball holds fewer than k + 1 points, whose boundary bin overflows
-// the list, or whose counter saturates is flagged and redone by the heap kernel: the result is always the exact
-// sum over the k + 1 nearest, minus the nearest (the query itself).
+// 3x3x3 cells around the query, and the cell size is chosen so that this ball holds ~1.35 (k + 1) points on
+// average.  A histogram pass counts the candidates inside the ball in 32 equal-width bins of the squared distance
+// (16-bit counters in LDS, [bin][lane]); the bin in which the count reaches k + 1 is the boundary bin.  Where the
+// cloud is denser than average that bin is crowded: it is then histogrammed again into 32 sub-bins (up to two
+// refinements), every level classifying a candidate with the same arithmetic.  The last pass adds sqrt(d) of every
+// candidate below the boundary and lists the boundary bin's members (at most 16), of which the smallest missing
+// ones are picked.  A lane whose ball holds fewer than k + 1 points, or whose boundary stays crowded (many equal
+// distances), is flagged and redone by the heap kernel: the result is always the exact sum over the k + 1
+// nearest, minus the nearest (the query itself).
 constexpr int kSelBins = 32;
 constexpr int kSelList = 16;
+constexpr int kSelLevels = 3;
 __global__ __launch_bounds__(kSorBlock) void k_sor_select(const float *__restrict__ sx, const float *__restrict__ sy,
                                                           const float *__restrict__ sz,
                                                           const int32_t *__restrict__ order,
@@ -781,7 +784,7 @@ __global__ __launch_bounds__(kSorBlock) void k_sor_select(const float *__restric
                                                           const int32_t *__restrict__ start, int64_t n, GridDesc g,
                                                           int32_t mean_k, float *__restrict__ distances,
                                                           uint8_t *__restrict__ redo) {
-  __shared__ uint8_t bins[kSelBins][kSorBlock];
+  __shared__ uint16_t bins[kSelBins][kSorBlock];
   __shared__ float list[kSelList][kSorBlock];
   const int tid = threadIdx.x;
   const int64_t j = static_cast<int64_t>(blockIdx.x) * kSorBlock + tid;
@@ -792,80 +795,146 @@ __global__ __launch_bounds__(kSorBlock) void k_sor_select(const float *__restric
   grid_coords(g, qx, qy, qz, cx, cy, cz);
   const float cell = 1.0f / g.inv_cell;
   const float limit = cell * 0.999f, limit2 = limit * limit;  // 0.999: fp32 slop of the cell assignment
-  const float bin_scale = static_cast<float>(kSelBins) / limit2;
-#pragma unroll
-  for (int b = 0; b < kSelBins; ++b) bins[b][tid] = 0;
   const int32_t x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
   const int32_t y0 = max(cy - 1, 0), y1 = min(cy + 1, g.ny - 1);
   const int32_t z0 = max(cz - 1, 0), z1 = min(cz + 1, g.nz - 1);
-  bool bad = false;
-  // pass 1: histogram of the squared distances inside the ball
-  for (int32_t zz = z0; zz <= z1; ++zz)
-    for (int32_t yy = y0; yy <= y1; ++yy) {
-      const int32_t row = (zz * g.ny + yy) * g.nx;
-      const int32_t b = start[row + x0], e = start[row + x1 + 1];
-      for (int32_t q = b; q < e; q += 2) {
-        const int32_t q1 = min(q + 1, e - 1);
-        const float d0 = sqdist_f32(sx[q], sy[q], sz[q], qx, qy, qz);
-        const float d1 = sqdist_f32(sx[q1], sy[q1], sz[q1], qx, qy, qz);
-        if (d0 < limit2) {
-          const int bi = min(static_cast<int>(d0 * bin_scale), kSelBins - 1);
-          const uint8_t c = bins[bi][tid];
-          bad = bad || c == 255;
-          bins[bi][tid] = static_cast<uint8_t>(c + 1);
-        }
-        if (q + 1 < e && d1 < limit2) {
-          const int bi = min(static_cast<int>(d1 * bin_scale), kSelBins - 1);
-          const uint8_t c = bins[bi][tid];
-          bad = bad || c == 255;
-          bins[bi][tid] = static_cast<uint8_t>(c + 1);
-        }
+  // level l splits [lo[l], lo[l] + 32 / sc[l]) into 32 bins; bnd[l] = its boundary bin (levels > `level` unused)
+  float lo[kSelLevels] = {0.0f, 0.0f, 0.0f}, sc[kSelLevels] = {static_cast<float>(kSelBins) / limit2, 0.0f, 0.0f};
+  int bnd[kSelLevels] = {0, 0, 0};
+  // -1 below the boundary, +1 above it (or outside the ball), 0 in the boundary bin of the deepest level so far;
+  // `deepest` returns that level's bin for the histogram pass
+  auto classify = [&](float d, int levels, int &deepest) -> int {
+    if (!(d < limit2)) return 1;
+#pragma unroll
+    for (int l = 0; l < kSelLevels; ++l) {  // static indices: lo / sc / bnd stay in registers
+      if (l >= levels) break;
+      const int b = min(max(static_cast<int>((d - lo[l]) * sc[l]), 0), kSelBins - 1);
+      if (l == levels - 1) {
+        deepest = b;
+        return 0;
       }
+      if (b < bnd[l]) return -1;
+      if (b > bnd[l]) return 1;
     }
-  int below = 0, boundary = -1;
-  for (int b = 0; b < kSelBins; ++b) {
-    const int c = bins[b][tid];
-    if (boundary < 0) {
-      if (below + c >= k)
-        boundary = b;
-      else
-        below += c;
-    }
-  }
-  bad = bad || boundary < 0;  // fewer than k + 1 points inside the ball
-  // pass 2: sum below the boundary bin, list the boundary bin
-  double sum = 0.0;
-  float smallest = FLT_MAX;
-  int listed = 0;
-  if (!bad) {
+    return 0;
+  };
+  auto for_candidates = [&](auto &&body) {
     for (int32_t zz = z0; zz <= z1; ++zz)
       for (int32_t yy = y0; yy <= y1; ++yy) {
         const int32_t row = (zz * g.ny + yy) * g.nx;
         const int32_t b = start[row + x0], e = start[row + x1 + 1];
         for (int32_t q = b; q < e; q += 2) {
           const int32_t q1 = min(q + 1, e - 1);
-          const float dd[2] = {sqdist_f32(sx[q], sy[q], sz[q], qx, qy, qz),
-                               q + 1 < e ? sqdist_f32(sx[q1], sy[q1], sz[q1], qx, qy, qz) : FLT_MAX};
+          const float d0 = sqdist_f32(sx[q], sy[q], sz[q], qx, qy, qz);
+          const float d1 = sqdist_f32(sx[q1], sy[q1], sz[q1], qx, qy, qz);
+          body(d0);
+          if (q + 1 < e) body(d1);
+        }
+      }
+  };
+  bool bad = false;
+  int below = 0, level = 0, crowd = 0;
+  // level 0 with the plain bin arithmetic (on a uniform cloud no lane needs more)
+  {
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const float d = dd[u];
-            if (d < limit2) {
-              const int bi = min(static_cast<int>(d * bin_scale), kSelBins - 1);
-              if (bi < boundary) {
-                sum += static_cast<double>(sqrtf(d));
-                smallest = fminf(smallest, d);
-              } else if (bi == boundary) {
-                if (listed < kSelList) list[listed][tid] = d;
-                ++listed;
-              }
-            }
+    for (int b = 0; b < kSelBins; ++b) bins[b][tid] = 0;
+    const float sc0 = sc[0];
+    for_candidates([&](float d) {
+      if (d < limit2) {
+        const int b = min(static_cast<int>(d * sc0), kSelBins - 1);
+        const uint16_t c = bins[b][tid];
+        bad = bad || c == 0xffffu;
+        bins[b][tid] = static_cast<uint16_t>(c + 1);
+      }
+    });
+    int boundary = -1;
+    for (int b = 0; b < kSelBins; ++b) {
+      const int c = bins[b][tid];
+      if (boundary < 0) {
+        if (below + c >= k) {
+          boundary = b;
+          crowd = c;
+        } else {
+          below += c;
+        }
+      }
+    }
+    if (boundary < 0) bad = true;  // fewer than k + 1 points inside the ball
+    bnd[0] = boundary;
+  }
+  // refinements, only in wavefronts that hold a lane with a crowded boundary bin
+  while (__any(!bad && crowd > kSelList)) {
+    const bool mine = !bad && crowd > kSelList;
+    if (mine && level + 1 == kSelLevels) bad = true;  // still crowded after the refinements (many equal distances)
+    const bool go = mine && !bad;
+    if (go) {
+#pragma unroll
+      for (int l = 0; l + 1 < kSelLevels; ++l)
+        if (l == level) {
+          lo[l + 1] = lo[l] + static_cast<float>(bnd[l]) / sc[l];
+          sc[l + 1] = sc[l] * static_cast<float>(kSelBins);
+        }
+      ++level;
+#pragma unroll
+      for (int b = 0; b < kSelBins; ++b) bins[b][tid] = 0;
+    }
+    for_candidates([&](float d) {
+      int b = 0;
+      if (go && classify(d, level + 1, b) == 0) bins[b][tid] = static_cast<uint16_t>(bins[b][tid] + 1);
+    });
+    if (go) {
+      int boundary = -1;
+      for (int b = 0; b < kSelBins; ++b) {
+        const int c = bins[b][tid];
+        if (boundary < 0) {
+          if (below + c >= k) {
+            boundary = b;
+            crowd = c;
+          } else {
+            below += c;
           }
         }
       }
-    bad = listed > kSelList;
+#pragma unroll
+      for (int l = 0; l < kSelLevels; ++l)
+        if (l == level) bnd[l] = boundary;
+    }
   }
+  int last_bnd = 0;
+#pragma unroll
+  for (int l = 0; l < kSelLevels; ++l)
+    if (l == level) last_bnd = bnd[l];
   if (!bad) {
-    // the k - below smallest members of the boundary bin
+    // last pass: sum below the boundary, list the boundary bin's members
+    double sum = 0.0;
+    float smallest = FLT_MAX;
+    int listed = 0;
+    auto take = [&](float d, int c) {
+      if (c < 0) {
+        sum += static_cast<double>(sqrtf(d));
+        smallest = fminf(smallest, d);
+      } else if (c == 0) {
+        if (listed < kSelList) list[listed][tid] = d;
+        ++listed;
+      }
+    };
+    if (!__any(level > 0)) {
+      const float sc0 = sc[0];
+      for_candidates([&](float d) {
+        if (d < limit2) {
+          const int b = min(static_cast<int>(d * sc0), kSelBins - 1);
+          take(d, b < last_bnd ? -1 : (b > last_bnd ? 1 : 0));
+        }
+      });
+    } else {
+      for_candidates([&](float d) {
+        int b = 0;
+        int c = classify(d, level + 1, b);
+        if (c == 0) c = b < last_bnd ? -1 : (b > last_bnd ? 1 : 0);
+        take(d, c);
+      });
+    }
+    // the k - below smallest members of the boundary bin (listed == crowd <= kSelList)
     for (int need = k - below; need > 0; --need) {
       int at = 0;
       float best = list[0][tid];
@@ -1352,10 +1421,8 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
   PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->m_sums.p, 0, 2 * sizeof(double), ctx->stream));
   float *dist = ctx->m_tmp.p;
   const size_t heap_lds = static_cast<size_t>(mean_k + 1) * kSorBlock * sizeof(float);
-  static const bool use_select = [] {
-    const char *e = std::getenv("PCP_SOR_HEAP_ONLY");
-    return !(e && e[0] == '1');
-  }();
+  const char *heap_only = std::getenv("PCP_SOR_HEAP_ONLY");
+  const bool use_select = !(heap_only && heap_only[0] == '1');
   if (use_select && mean_k + 1 <= 250) {
     // selection kernel for every point, heap kernel for the few it flags (sparse spots, borders of a surface)
     PCP_HIP_TRY(ctx, ctx->s_cell.ensure(sn + 8));
@@ -1377,6 +1444,7 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
       PCP_HIP_TRY(ctx, hipGetLastError());
     }
   } else {
+    ctx->sor_redo_fraction = 0.0;
     LaunchTimer t(ctx, PCP_K_SOR);
     hipLaunchKernelGGL(k_sor_mean_distance, dim3(static_cast<uint32_t>(div_up(n, kSorBlock))), dim3(kSorBlock), heap_lds,
                        ctx->stream, ctx->g_xyz.p, ctx->g_xyz.p + plane, ctx->g_xyz.p + 2 * plane, ctx->g_order.p,

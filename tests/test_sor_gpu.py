@@ -53,3 +53,25 @@ def test_sor_edge_cases(gpu_ctx_factory):
     ctx.upload_cloud(np.float32([0, 1, 2]), np.float32([0, 0, 0]), np.float32([0, 0, 0]))
     with pytest.raises(capi.PcpError):
         ctx.sor(mean_k=0)
+
+
+@pytest.mark.parametrize("heap_only", ["0", "1"])
+def test_sor_selection_and_heap_kernels_agree_with_oracle(gpu_ctx_factory, oracle, monkeypatch, heap_only):
+    """The selection kernel (+ heap kernel for the lanes it flags) and the heap kernel alone are both the exact
+    k + 1 nearest: each is checked against the oracle on a cloud with dense, sparse and border regions."""
+    monkeypatch.setenv("PCP_SOR_HEAP_ONLY", heap_only)
+    rng = np.random.default_rng(11)
+    dense = np.stack([rng.uniform(0, 0.5, 60000), rng.uniform(0, 0.5, 60000), rng.normal(0, 5e-4, 60000)], 1)
+    sparse = np.stack([rng.uniform(0.5, 2.0, 6000), rng.uniform(0, 1.5, 6000), rng.normal(0, 5e-4, 6000)], 1)
+    stray = rng.uniform(-1, 3, (200, 3))
+    pts = np.concatenate([dense, sparse, stray]).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    ctx = gpu_ctx_factory()
+    from pointcloudprocessor_amd import capi
+
+    ctx.set_camera(capi.default_camera())
+    kept = _check(ctx, oracle, pts[:, 0].copy(), pts[:, 1].copy(), pts[:, 2].copy(), 60, 0.7)
+    frac = ctx.sor_redo_fraction()
+    assert (frac == 0.0) if heap_only == "1" else (0.0 < frac < 0.6)
+    assert 0.5 * len(pts) < kept < len(pts)
+    ctx.close()
