@@ -244,6 +244,9 @@ int pcp_timing_get(pcp_context *ctx, int32_t kernel_id, double *total_ms, int64_
 const char *pcp_kernel_name(int32_t kernel_id);
 /* diagnostic: fraction of (tile, keyframe) pairs the conservative culling keeps (after pcp_depth_pass) */
 int pcp_tile_mask_density(pcp_context *ctx, double *kept_fraction);
+/* diagnostic: the (tile, keyframe) masks themselves, tiles x mask_words uint32 (bit f & 31 of word f >> 5); either
+ * output may be NULL to query the sizes */
+int pcp_tile_masks(pcp_context *ctx, int64_t *tiles, int32_t *mask_words, uint32_t *out_words);
 /* diagnostic: share of the points of the last pcp_sor / pcp_cloud_smooth SOR pass that the selection kernel handed
  * to the heap kernel (fewer than mean_k + 1 neighbours within one grid cell, or a crowded boundary bin) */
 int pcp_sor_redo_fraction(pcp_context *ctx, double *fraction);

@@ -445,5 +445,13 @@ class Context:
         self._check(self.lib.pcp_selftest_arithmetic(self.h, C.c_int64(samples), C.c_uint64(seed), C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def tile_masks(self) -> np.ndarray:
+        """(tiles, mask_words) uint32: the tile x keyframe masks as the last depth pass left them."""
+        t, w = C.c_int64(), C.c_int32()
+        self._check(self.lib.pcp_tile_masks(self.h, C.byref(t), C.byref(w), None))
+        out = np.empty((t.value, w.value), np.uint32)
+        self._check(self.lib.pcp_tile_masks(self.h, None, None, _ptr(out)))
+        return out
+
     def kernel_name(self, kernel_id: int) -> str:
         return self.lib.pcp_kernel_name(C.c_int32(kernel_id)).decode()

@@ -217,7 +217,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_mask_dense(const float4 *__rest
                                                             int32_t n_frames, int32_t w0, int32_t w1, int32_t words,
                                                             const uint32_t *__restrict__ group_mask,
                                                             uint32_t *__restrict__ tile_mask,
-                                                            uint32_t *__restrict__ inside_mask, int32_t cull_enabled) {
+                                                            uint32_t *__restrict__ inside_mask,
+                                                            int32_t *__restrict__ tile_work, int32_t cull_enabled) {
   const int lane = threadIdx.x & 63;
   const int64_t group = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6);
   if (group >= (tiles + kTileGroup - 1) / kTileGroup) return;  // whole wavefronts leave together
@@ -225,6 +226,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_mask_dense(const float4 *__rest
   const int64_t tile = group * kTileGroup + t;
   const bool have = tile < tiles;
   const float4 sph = spheres[have ? tile : tiles - 1];
+  int32_t visits = 0;  // keyframes this tile will walk: the scheduling weight of its wavefront
   for (int32_t w = w0; w < w1; ++w) {
     uint32_t todo = __builtin_amdgcn_readfirstlane(group_mask[group * words + w]);
     const int32_t nb = n_frames - (w << 5);
@@ -253,16 +255,76 @@ __global__ __launch_bounds__(kBlock) void k_tile_mask_dense(const float4 *__rest
       tile_mask[tile * words + w] = word;
       if (inside_mask) inside_mask[tile * words + w] = inside;
     }
+    visits += __builtin_popcount(word);
   }
+  if (tile_work && slot == 0 && have) tile_work[tile] = visits;
 }
 
-// Workgroups are handed to the 8 XCDs round-robin (workgroup b runs on XCD b % 8), and every XCD has
-// its own 4 MiB L2.  The batched passes walk the Morton-ordered cloud, so neighbouring workgroups touch
-// the same depth cells and texels: this remap makes every run of kXcdChunk consecutive workgroups of
-// the cloud execute on ONE XCD (chunk c goes to XCD c % 8), so a patch of space, and of every image it
-// projects into, is served by one L2 instead of eight.  Measured at C3: neutral to +2 % (both passes are
-// bound by VALU issue, not by L2 misses).  Whole contiguous eighths per XCD were 40 % slower: the work per
-// tile varies across the scene and the XCDs then finish far apart.
+// Longest-work-first order of the tiles (counting sort on the number of keyframes a tile walks, descending).  The
+// batched passes run one wavefront-sized workgroup per tile in this order: the number of keyframes per tile ranges
+// from 0 to several times the mean, and in cloud order the last heavy tiles leave most of the chip idle at the end
+// of a pass (list-scheduling the measured C3 weights: 1.14x the ideal makespan in cloud order with 4-tile
+// workgroups, 1.0003x longest-first with 1-tile workgroups).  Ties are placed in arrival order: any permutation is
+// correct, the results do not depend on it.
+constexpr int kWorkBins = 1024;
+constexpr int kWorkPerBlock = 1024;  // tiles per workgroup of the two sorting kernels (4 per lane)
+// workgroup-local histogram in LDS, then one global atomic per occupied bin (many tiles share a weight: per-tile
+// global atomics on the same few addresses serialise)
+__global__ __launch_bounds__(kBlock) void k_work_hist(const int32_t *__restrict__ work, int64_t tiles,
+                                                     int32_t *__restrict__ hist) {
+  __shared__ int32_t cnt[kWorkBins];
+  for (int b = threadIdx.x; b < kWorkBins; b += kBlock) cnt[b] = 0;
+  __syncthreads();
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kWorkPerBlock;
+  for (int q = 0; q < kWorkPerBlock / kBlock; ++q) {
+    const int64_t t = base + q * kBlock + threadIdx.x;
+    if (t < tiles) atomicAdd(&cnt[min(work[t], kWorkBins - 1)], 1);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < kWorkBins; b += kBlock)
+    if (cnt[b]) atomicAdd(&hist[b], cnt[b]);
+}
+// cursor[b] = number of tiles with more work than bin b (single workgroup of kWorkBins threads)
+__global__ __launch_bounds__(kWorkBins) void k_work_offsets(const int32_t *__restrict__ hist, int32_t *__restrict__ cursor) {
+  __shared__ int32_t sh[kWorkBins];
+  const int b = threadIdx.x;
+  sh[b] = hist[kWorkBins - 1 - b];  // reversed: heaviest bin first
+  __syncthreads();
+  for (int o = 1; o < kWorkBins; o <<= 1) {
+    const int32_t v = b >= o ? sh[b - o] : 0;
+    __syncthreads();
+    sh[b] += v;
+    __syncthreads();
+  }
+  cursor[kWorkBins - 1 - b] = sh[b] - hist[kWorkBins - 1 - b];  // exclusive
+}
+__global__ __launch_bounds__(kBlock) void k_work_scatter(const int32_t *__restrict__ work, int64_t tiles,
+                                                        int32_t *__restrict__ cursor, int32_t *__restrict__ order) {
+  __shared__ int32_t cnt[kWorkBins];  // local count, then the workgroup's first slot of the bin
+  for (int b = threadIdx.x; b < kWorkBins; b += kBlock) cnt[b] = 0;
+  __syncthreads();
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kWorkPerBlock;
+  int32_t bin[kWorkPerBlock / kBlock], rank[kWorkPerBlock / kBlock];
+#pragma unroll
+  for (int q = 0; q < kWorkPerBlock / kBlock; ++q) {
+    const int64_t t = base + q * kBlock + threadIdx.x;
+    bin[q] = t < tiles ? min(work[t], kWorkBins - 1) : -1;
+    rank[q] = bin[q] >= 0 ? atomicAdd(&cnt[bin[q]], 1) : 0;
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < kWorkBins; b += kBlock)
+    if (cnt[b]) cnt[b] = atomicAdd(&cursor[b], cnt[b]);
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kWorkPerBlock / kBlock; ++q)
+    if (bin[q] >= 0) order[cnt[bin[q]] + rank[q]] = static_cast<int32_t>(base + q * kBlock + threadIdx.x);
+}
+
+// 256-thread launches without a tile order (single-keyframe calls, culling switched off): workgroups are handed
+// to the 8 XCDs round-robin (workgroup b runs on XCD b % 8) and every XCD has its own 4 MiB L2; this remap makes
+// every run of kXcdChunk consecutive workgroups of the Morton-ordered cloud execute on ONE XCD, so a patch of space,
+// and of every image it projects into, is served by one L2 instead of eight.  Measured at C3: neutral to +2 %.
+// Whole contiguous eighths per XCD were 40 % slower (the work per tile varies, the XCDs finish far apart).
 constexpr uint32_t kXcdChunk = 16;
 __device__ __forceinline__ uint32_t xcd_chunked_block() {
   constexpr uint32_t kXcd = 8, kSuper = kXcd * kXcdChunk;
@@ -295,12 +357,15 @@ __global__ __launch_bounds__(kBlock) void k_depth_pass(const float *__restrict__
                                                        const DevFrame *__restrict__ frames, int32_t f0, int32_t f1,
                                                        uint32_t *__restrict__ depth, int64_t cells,
                                                        int32_t depth_first_frame, uint32_t *__restrict__ tile_mask,
-                                                       const uint32_t *__restrict__ tile_inside, int32_t words) {
+                                                       const uint32_t *__restrict__ tile_inside, int32_t words,
+                                                       const int32_t *__restrict__ tile_order) {
   // per-wavefront combining table: slot = cell & 63 holds min over (cell << 32 | range bits)
   __shared__ unsigned long long combine[kBlock];
   const int lane = threadIdx.x & 63;
   unsigned long long *tbl = combine + (threadIdx.x & ~63);
-  const int64_t j = static_cast<int64_t>(xcd_chunked_block()) * kBlock + threadIdx.x;
+  // tile_order: wavefront-sized workgroups, longest-work-first; else 256-thread workgroups in (XCD-chunked) cloud order
+  const int64_t j = tile_order ? static_cast<int64_t>(tile_order[blockIdx.x]) * 64 + threadIdx.x
+                               : static_cast<int64_t>(xcd_chunked_block()) * kBlock + threadIdx.x;
   const bool live = j < n;
   const float px = live ? x[j] : 0.0f, py = live ? y[j] : 0.0f, pz = live ? z[j] : 0.0f;
   const int64_t tile = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(j >> 6));
@@ -383,8 +448,10 @@ __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict_
                                                         const uint32_t *__restrict__ tile_mask, int32_t words,
                                                         const uint32_t *__restrict__ images, int64_t image_px,
                                                         TopState st, const int32_t *__restrict__ perm,
-                                                        uint32_t *__restrict__ rgba, int32_t flags) {
-  const int64_t j = static_cast<int64_t>(xcd_chunked_block()) * kBlock + threadIdx.x;
+                                                        uint32_t *__restrict__ rgba, int32_t flags,
+                                                        const int32_t *__restrict__ tile_order) {
+  const int64_t j = tile_order ? static_cast<int64_t>(tile_order[blockIdx.x]) * 64 + threadIdx.x
+                               : static_cast<int64_t>(xcd_chunked_block()) * kBlock + threadIdx.x;
   const bool live = j < n;
   const float px = live ? x[j] : 0.0f, py = live ? y[j] : 0.0f, pz = live ? z[j] : 0.0f;
   const int64_t tile = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(j >> 6));
@@ -717,6 +784,19 @@ static int ensure_images(pcp_context *ctx) {
   return PCP_OK;
 }
 
+// counting sort of the tiles by ctx->tile_work, heaviest first, into `order`
+static int sort_tiles_by_work(pcp_context *ctx, int32_t *order) {
+  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->work_hist.p, 0, 2 * kWorkBins * sizeof(int32_t), ctx->stream));
+  const uint32_t sort_blocks = static_cast<uint32_t>(div_up(ctx->n_tiles, static_cast<int64_t>(kWorkPerBlock)));
+  hipLaunchKernelGGL(k_work_hist, dim3(sort_blocks), dim3(kBlock), 0, ctx->stream, ctx->tile_work.p, ctx->n_tiles,
+                     ctx->work_hist.p);
+  hipLaunchKernelGGL(k_work_offsets, dim3(1), dim3(kWorkBins), 0, ctx->stream, ctx->work_hist.p, ctx->work_hist.p + kWorkBins);
+  hipLaunchKernelGGL(k_work_scatter, dim3(sort_blocks), dim3(kBlock), 0, ctx->stream, ctx->tile_work.p, ctx->n_tiles,
+                     ctx->work_hist.p + kWorkBins, order);
+  PCP_HIP_TRY(ctx, hipGetLastError());
+  return PCP_OK;
+}
+
 static int ensure_depth(pcp_context *ctx) {
   const size_t need = static_cast<size_t>(cells_of(ctx)) * ctx->n_frames + 4;
   if (ctx->depth.count < need) {
@@ -728,6 +808,10 @@ static int ensure_depth(pcp_context *ctx) {
   if (ctx->tile_mask.count < need_mask || ctx->mask_words != words) {
     PCP_HIP_TRY(ctx, ctx->tile_mask.ensure(need_mask));
     PCP_HIP_TRY(ctx, ctx->tile_inside.ensure(need_mask));
+    PCP_HIP_TRY(ctx, ctx->tile_work.ensure(static_cast<size_t>(std::max<int64_t>(ctx->n_tiles, 1)) + 4));
+    PCP_HIP_TRY(ctx, ctx->tile_order.ensure(static_cast<size_t>(std::max<int64_t>(ctx->n_tiles, 1)) + 4));
+    PCP_HIP_TRY(ctx, ctx->work_hist.ensure(2 * kWorkBins + 4));
+    ctx->tile_order_live = false;
     ctx->mask_words = words;
     std::fill(ctx->depth_valid.begin(), ctx->depth_valid.end(), uint8_t(0));
   }
@@ -780,7 +864,7 @@ static int single_frame_depth(pcp_context *ctx, int32_t frame) {
     hipLaunchKernelGGL(k_depth_pass, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
                        ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, ctx->n, ctx->dcam, ctx->frames.p, frame, frame + 1,
                        ctx->s_u32.p, cells, frame, static_cast<uint32_t *>(nullptr),
-                       static_cast<const uint32_t *>(nullptr), 0);
+                       static_cast<const uint32_t *>(nullptr), 0, static_cast<const int32_t *>(nullptr));
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   return PCP_OK;
@@ -1044,14 +1128,18 @@ int pcp_depth_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
                          static_cast<uint32_t *>(nullptr), cull_tiles ? 1 : 0);
       hipLaunchKernelGGL(k_tile_mask_dense, dim3(static_cast<uint32_t>(div_up(groups, kBlock / 64))), dim3(kBlock), 0,
                          ctx->stream, tile_sph, ctx->n_tiles, ctx->dcam, ctx->frames.p, ctx->n_frames, w0, w1,
-                         ctx->mask_words, ctx->group_mask.p, ctx->tile_mask.p, ctx->tile_inside.p, cull_tiles ? 1 : 0);
-      PCP_HIP_TRY(ctx, hipGetLastError());
+                         ctx->mask_words, ctx->group_mask.p, ctx->tile_mask.p, ctx->tile_inside.p, ctx->tile_work.p,
+                         cull_tiles ? 1 : 0);
+      // longest-work-first order of the tiles for this pass
+      if ((rc = sort_tiles_by_work(ctx, ctx->tile_order.p)) != PCP_OK) return rc;
+      ctx->tile_order_live = true;
     }
     {
       LaunchTimer t(ctx, PCP_K_DEPTH);
-      hipLaunchKernelGGL(k_depth_pass, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
+      hipLaunchKernelGGL(k_depth_pass, dim3(static_cast<uint32_t>(ctx->n_tiles)), dim3(64), 0, ctx->stream, ctx->sxyz.p,
                          ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, ctx->n, ctx->dcam, ctx->frames.p, frame_begin,
-                         frame_end, ctx->depth.p, cells, 0, ctx->tile_mask.p, ctx->tile_inside.p, ctx->mask_words);
+                         frame_end, ctx->depth.p, cells, 0, ctx->tile_mask.p, ctx->tile_inside.p, ctx->mask_words,
+                         ctx->tile_order.p);
       PCP_HIP_TRY(ctx, hipGetLastError());
     }
   }
@@ -1131,10 +1219,15 @@ static int colour_pass_impl(pcp_context *ctx, int32_t frame_begin, int32_t frame
     flags |= 2;
   {
     LaunchTimer t(ctx, PCP_K_COLOUR);
-    hipLaunchKernelGGL(k_colour_pass, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
-                       ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, ctx->n, ctx->dcam, ctx->frames.p, frame_begin,
-                       frame_end, ctx->depth.p, cells_of(ctx), ctx->tile_mask.p, ctx->mask_words, ctx->images.p,
-                       static_cast<int64_t>(ctx->dcam.img_w) * ctx->dcam.img_h, st, ctx->perm.p, result, flags);
+    // the depth pass's longest-first order serves the colour pass too (an order of its own, from the refined masks,
+    // was measured and made no difference: the colour pass does not end in a tail of heavy tiles)
+    const bool ordered = ctx->tile_order_live && ctx->tile_order.p;
+    hipLaunchKernelGGL(k_colour_pass, dim3(ordered ? static_cast<uint32_t>(ctx->n_tiles) : blocks_for(ctx->n)),
+                       dim3(ordered ? 64 : kBlock), 0, ctx->stream, ctx->sxyz.p, ctx->sxyz.p + plane,
+                       ctx->sxyz.p + 2 * plane, ctx->n, ctx->dcam, ctx->frames.p, frame_begin, frame_end, ctx->depth.p,
+                       cells_of(ctx), ctx->tile_mask.p, ctx->mask_words, ctx->images.p,
+                       static_cast<int64_t>(ctx->dcam.img_w) * ctx->dcam.img_h, st, ctx->perm.p, result, flags,
+                       ordered ? ctx->tile_order.p : static_cast<const int32_t *>(nullptr));
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   if (!one_shot) ctx->colour_state_live = true;
@@ -1272,6 +1365,20 @@ int pcp_tile_mask_density(pcp_context *ctx, double *kept_fraction) {
   uint64_t bits = 0;
   for (uint32_t w : h) bits += static_cast<uint64_t>(__builtin_popcount(w));
   *kept_fraction = static_cast<double>(bits) / (static_cast<double>(ctx->n_tiles) * ctx->n_frames);
+  return PCP_OK;
+}
+
+int pcp_tile_masks(pcp_context *ctx, int64_t *tiles, int32_t *mask_words, uint32_t *out_words) {
+  if (!ctx) return PCP_ERR_INVALID;
+  if (!ctx->tile_mask.p || ctx->n_tiles == 0 || ctx->n_frames == 0)
+    return set_error(ctx, PCP_ERR_STATE, "pcp_tile_masks: no masks (call pcp_depth_pass)");
+  if (tiles) *tiles = ctx->n_tiles;
+  if (mask_words) *mask_words = ctx->mask_words;
+  if (out_words) {
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(out_words, ctx->tile_mask.p, static_cast<size_t>(ctx->n_tiles) * ctx->mask_words * 4,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
   return PCP_OK;
 }
 

@@ -378,6 +378,7 @@ static int store_cloud(pcp_context *ctx, const float *x, const float *y, const f
   PCP_HIP_TRY(ctx, ctx->perm.ensure(sn + 4));
   ctx->n = n;
   ctx->n_tiles = 0;
+  ctx->tile_order_live = false;
   ctx->have_intensity = false;
   ctx->nid_chunks = 0;
   ctx->colour_state_live = false;
@@ -556,6 +557,9 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->tile_sphere.release();
   ctx->tile_mask.release();
   ctx->tile_inside.release();
+  ctx->tile_work.release();
+  ctx->tile_order.release();
+  ctx->work_hist.release();
   ctx->group_mask.release();
   ctx->top_score.release();
   ctx->top_rgb.release();

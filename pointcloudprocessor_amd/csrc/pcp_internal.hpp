@@ -128,6 +128,9 @@ struct pcp_context {
   pcp::DevBuf<uint32_t> tile_mask, group_mask;
   pcp::DevBuf<uint32_t> tile_inside;  // pairs whose whole tile images inside the acceptance box (a hint: skip the pre-test)
   int32_t mask_words = 0;
+  // longest-work-first order of the tiles for the batched passes (pcp_colour.hip k_work_*)
+  pcp::DevBuf<int32_t> tile_work, tile_order, work_hist;
+  bool tile_order_live = false;
 
   // per-point colour state (sorted order) and packed results
   pcp::DevBuf<float> top_score;     // 5*n
