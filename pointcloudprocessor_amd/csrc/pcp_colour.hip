@@ -1219,9 +1219,10 @@ static int colour_pass_impl(pcp_context *ctx, int32_t frame_begin, int32_t frame
     flags |= 2;
   {
     LaunchTimer t(ctx, PCP_K_COLOUR);
-    // the depth pass's longest-first order serves the colour pass too (an order of its own, from the refined masks,
-    // was measured and made no difference: the colour pass does not end in a tail of heavy tiles)
-    const bool ordered = ctx->tile_order_live && ctx->tile_order.p;
+    // the colour pass keeps the cloud order (256-thread workgroups, XCD-chunked): it does not end in a tail of heavy
+    // tiles (longest-first order: no gain at 1920x1080), and its texel gathers want neighbouring tiles on the same L2
+    // (longest-first order at 4096x3000: 1.96 -> 2.18 ms)
+    const bool ordered = false;
     hipLaunchKernelGGL(k_colour_pass, dim3(ordered ? static_cast<uint32_t>(ctx->n_tiles) : blocks_for(ctx->n)),
                        dim3(ordered ? 64 : kBlock), 0, ctx->stream, ctx->sxyz.p, ctx->sxyz.p + plane,
                        ctx->sxyz.p + 2 * plane, ctx->n, ctx->dcam, ctx->frames.p, frame_begin, frame_end, ctx->depth.p,
