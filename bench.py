@@ -54,7 +54,8 @@ def parse():
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even at world size 1")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 path on fewer GPUs than ranks (ranks share devices); not a measurement")
-    ap.add_argument("--dist-chunks", type=int, default=2, help="keyframe groups whose all-reduce overlaps the next depth pass")
+    ap.add_argument("--dist-chunks", type=int, default=0,
+                    help="keyframe groups whose all-reduce overlaps the next depth pass (0 = by the size of the depth maps)")
     return ap.parse_args()
 
 

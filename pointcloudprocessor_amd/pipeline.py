@@ -109,7 +109,7 @@ class ViewCulling:
 class PointCloudColorizer:
     """pcdColorizationAndSmooth over a (possibly sharded) map."""
 
-    def __init__(self, engine, rank: int = 0, world: int = 1, group=None, chunks: int = 4):
+    def __init__(self, engine, rank: int = 0, world: int = 1, group=None, chunks: int = 0):
         self.engine = engine
         self.rank = rank
         self.world = world
@@ -119,8 +119,8 @@ class PointCloudColorizer:
     def run(self, download: bool = True):
         """Local points' colours: dict(rgb (n,3) uint8, has (n,) uint8).
 
-        Multi-rank: the keyframes are split into `chunks` groups; the all-reduce(MIN) of one
-        group's depth maps (RCCL stream) overlaps the depth pass of the next group."""
+        Multi-rank: the keyframes are split into `chunks` groups (0 = chosen from the size of the maps); the
+        all-reduce(MIN) of one group's depth maps (RCCL stream) overlaps the depth pass of the next group."""
         if self.world == 1:
             self.engine.depth_pass()
             return self.engine.colour_from_depth(download=download)
@@ -129,7 +129,12 @@ class PointCloudColorizer:
         F = self.engine.n_frames
         t = self.engine.depth_maps_tensor()
         cells = t.numel() // max(F, 1)
-        bounds = sorted({(F * c) // self.chunks for c in range(self.chunks + 1)})
+        # chunks = 0: one all-reduce for small maps (splitting the depth pass costs ~0.1 ms per extra chunk at C3,
+        # more than overlapping a ~10 MB all-reduce saves), two keyframe groups from 32 MB of maps up
+        chunks = self.chunks if self.chunks > 0 else (1 if t.numel() * 4 < (32 << 20) else 2)
+        # group boundaries on multiples of 32 keyframes (whole tile-mask words) when there are enough keyframes
+        align = 32 if F >= 64 * chunks else 1
+        bounds = sorted({min(F, ((F * c) // chunks + align - 1) // align * align) for c in range(chunks)} | {0, F})
         works = []
         for f0, f1 in zip(bounds[:-1], bounds[1:]):
             self.engine.depth_pass(f0, f1)
