@@ -41,8 +41,8 @@ PROJ_BYTES_PER_POINT = 20  # 12 B xyz read + 4 B cell + 4 B rang
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=10_000_000, help="points per GPU")
     ap.add_argument("--frames", type=int, default=256)
     ap.add_argument("--camera", default="cfg", choices=["cfg", "ref", "tiny"])
@@ -126,6 +126,9 @@ def main():
     def step():
         col.run(download=False)
         eng.ctx.download_result_packed_async(pinned[step_no[0] & 1].data_ptr())
+        # the other landing buffer is about to be reused: its colours (the previous step's) must have arrived.
+        # Waits for that copy only, never for a kernel; it also keeps the host one step ahead instead of hundreds
+        eng.ctx.download_wait_previous()
         step_no[0] += 1
 
     def fence():
@@ -172,7 +175,7 @@ def main():
         # MI355X_MICROARCH.md prescribes), collected with this command and committed under profiles/
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_f_pmc.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r01_g_pmc.json")) as fh:
                 pmc = json.load(fh)
             if pmc.get("points_per_launch") == N:
                 traffic = round(pmc["k_project_frame"]["traffic_bytes_per_launch"])
@@ -186,7 +189,7 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": traffic,
-            "traffic_source": "profiles/r01_f_pmc.json" if traffic else None,
+            "traffic_source": "profiles/r01_g_pmc.json" if traffic else None,
             "bytes_per_launch": PROJ_BYTES_PER_POINT * N,
             "avg_launch_ms": round(avg_s * 1e3, 4),
             "launches": proj_launches,

@@ -190,6 +190,11 @@ int pcp_download_result_packed(pcp_context *ctx, uint32_t *out_rgba);
  * double-buffered so the next run's kernels overlap this transfer; out_rgba (pinned
  * memory for a real overlap) is valid after pcp_synchronize(). */
 int pcp_download_result_packed_async(pcp_context *ctx, uint32_t *out_rgba);
+/* Blocks the host until the asynchronous download issued BEFORE the latest one has landed (no-op when there is
+ * none): the consumer of a two-buffer ring calls it before reusing the older buffer.  It does not wait for any
+ * kernel, so the device stays busy, and it keeps the host at most one run ahead of the device -- an unbounded
+ * lead (hundreds of queued commands) was measured to slow the steps by 13 %. */
+int pcp_download_wait_previous(pcp_context *ctx);
 /* device address of the packed per-point result (r | g<<8 | b<<16 | has<<24),
  * valid after pcp_colour_finalise / pcp_colorize, for device-side gathers */
 int pcp_colour_result_device(pcp_context *ctx, void **device_ptr, int64_t *n_words);

@@ -350,6 +350,9 @@ class Context:
         """Enqueue the device-to-host copy on the copy stream; valid after synchronize()."""
         self._check(self.lib.pcp_download_result_packed_async(self.h, C.c_void_p(out_ptr)))
 
+    def download_wait_previous(self):
+        self._check(self.lib.pcp_download_wait_previous(self.h))
+
     def colour_result_device(self):
         p = C.c_void_p()
         n = C.c_int64()

@@ -1361,6 +1361,13 @@ int pcp_download_result_packed_async(pcp_context *ctx, uint32_t *out_rgba) {
   return PCP_OK;
 }
 
+int pcp_download_wait_previous(pcp_context *ctx) {
+  if (!ctx) return PCP_ERR_INVALID;
+  const int32_t prev = ctx->rgba_cur ^ 1;
+  if (ctx->copy_pending[prev]) PCP_HIP_TRY(ctx, hipEventSynchronize(ctx->copy_done[prev]));
+  return PCP_OK;
+}
+
 int pcp_tile_mask_density(pcp_context *ctx, double *kept_fraction) {
   if (!ctx || !kept_fraction) return PCP_ERR_INVALID;
   if (!ctx->tile_mask.p || ctx->n_tiles == 0 || ctx->n_frames == 0)
