@@ -141,24 +141,39 @@ __global__ __launch_bounds__(kNB) void k_nid_hist(NidArgs a) {
     double bx[4], dbx[4], by[4], dby[4];
     bspline(u - static_cast<double>(kx), bx, dbx);
     bspline(v - static_cast<double>(ky), by, dby);
+    // The 16 taps of a point share its point bin and its du / dv, and neighbouring taps mostly fall in the same image
+    // bin: the weights (w, dw/du, dw/dv) of a run of equal bins are summed in registers and flushed as 7 atomics per
+    // run instead of 7 per tap (hist_k += du_k * sum(wu) + dv_k * sum(wv)).
+    int run_bin = -1;
+    double rw = 0.0, rwu = 0.0, rwv = 0.0;
+    auto flush = [&]() {
+      if (run_bin < 0) return;
+      double *cell = lh + (run_bin * a.bins + bp) * kNidComp;
+      atomicAdd(cell, rw);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int sx = max(0, min(a.W - 1, kx - 1 + i));
+      for (int k = 0; k < 6; ++k) atomicAdd(cell + 1 + k, rwu * du[k] + rwv * dv[k]);
+    };
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int sy = max(0, min(a.H - 1, ky - 1 + j));
+    for (int j = 0; j < 4; ++j) {  // rows outermost: the four taps of a row are horizontal neighbours
+      const int sy = max(0, min(a.H - 1, ky - 1 + j));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int sx = max(0, min(a.W - 1, kx - 1 + i));
         // normalized_image.at<double>(sy, sx) of a CV_64FC3 matrix: channel sx % 3 of pixel sx / 3
         const uint32_t texel = img[static_cast<int64_t>(sy) * a.W + sx / 3];
         const double pix = static_cast<double>((texel >> (8 * (sx % 3))) & 0xffu) / 255.0;
         const int bi = min(static_cast<int>(pix * a.bins), a.bins - 1);
-        double *cell = lh + (bi * a.bins + bp) * kNidComp;
-        const double w = bx[i] * by[j];
-        const double wu = dbx[i] * by[j], wv = bx[i] * dby[j];
-        atomicAdd(cell, w);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) atomicAdd(cell + 1 + k, wu * du[k] + wv * dv[k]);
+        if (bi != run_bin) {
+          flush();
+          run_bin = bi;
+          rw = rwu = rwv = 0.0;
+        }
+        rw += bx[i] * by[j];
+        rwu += dbx[i] * by[j];
+        rwv += bx[i] * dby[j];
       }
     }
+    flush();
   }
   __syncthreads();
   double *gh = a.hist + static_cast<int64_t>(kf) * lsize;
