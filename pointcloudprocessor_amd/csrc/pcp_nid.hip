@@ -361,25 +361,28 @@ int pcp_nid_prepare(pcp_context *ctx, int64_t *out_points) {
   const int64_t n = ctx->n;
   const size_t plane = (static_cast<size_t>(n) + 3) & ~size_t(3);
   PCP_HIP_TRY(ctx, ctx->s_cell.ensure(plane + 4));
-  // pass 1: kept counts per keyframe (the culls are repeated in pass 2; this runs once per calibration)
-  std::vector<int64_t> counts(static_cast<size_t>(ctx->n_frames));
-  int64_t chunks = 0, total = 0;
-  for (int32_t f = 0; f < ctx->n_frames; ++f) {
-    int rc = cull_frame_indices(ctx, f, nullptr, 0, &counts[static_cast<size_t>(f)]);
-    if (rc != PCP_OK) return rc;
-    chunks += div_up(counts[static_cast<size_t>(f)], kNidChunk);
-    total += counts[static_cast<size_t>(f)];
-  }
-  PCP_HIP_TRY(ctx, ctx->nid_pts.ensure(static_cast<size_t>(chunks) * kNidChunk * 4 + 16));
-  PCP_HIP_TRY(ctx, ctx->nid_chunk_kf.ensure(static_cast<size_t>(chunks) + 4));
+  // one cull per keyframe; the point buffer is sized from the first keyframe and grown (contents kept) if the
+  // estimate falls short
   std::vector<int32_t> chunk_kf;
-  chunk_kf.reserve(static_cast<size_t>(chunks));
-  int64_t at = 0;
+  int64_t at = 0, total = 0;
+  size_t capacity = ctx->nid_pts.count / 4;  // points (float4)
   for (int32_t f = 0; f < ctx->n_frames; ++f) {
     int64_t m = 0;
     int rc = cull_frame_indices(ctx, f, ctx->s_cell.p, n, &m);
     if (rc != PCP_OK) return rc;
     const int64_t padded = div_up(m, kNidChunk) * kNidChunk;
+    if (static_cast<size_t>(at + padded) > capacity) {
+      const size_t want = std::max<size_t>(static_cast<size_t>(at + padded),
+                                           static_cast<size_t>((at + padded) * 1.3 * ctx->n_frames / (f + 1)) + kNidChunk);
+      DevBuf<float> bigger;
+      PCP_HIP_TRY(ctx, bigger.ensure(want * 4 + 16));
+      if (at > 0)
+        PCP_HIP_TRY(ctx, hipMemcpyAsync(bigger.p, ctx->nid_pts.p, static_cast<size_t>(at) * 16, hipMemcpyDeviceToDevice, ctx->stream));
+      PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      std::swap(ctx->nid_pts, bigger);
+      bigger.release();
+      capacity = want;
+    }
     if (padded > 0) {
       hipLaunchKernelGGL(k_nid_gather, dim3(static_cast<uint32_t>(div_up(padded, kNB))), dim3(kNB), 0, ctx->stream,
                          ctx->xyz.p, ctx->xyz.p + plane, ctx->xyz.p + 2 * plane, ctx->intensity.p, ctx->s_cell.p, m,
@@ -390,7 +393,9 @@ int pcp_nid_prepare(pcp_context *ctx, int64_t *out_points) {
     }
     for (int64_t c = 0; c < padded / kNidChunk; ++c) chunk_kf.push_back(f);
     at += padded;
+    total += m;
   }
+  PCP_HIP_TRY(ctx, ctx->nid_chunk_kf.ensure(chunk_kf.size() + 4));
   if (!chunk_kf.empty())
     PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->nid_chunk_kf.p, chunk_kf.data(), chunk_kf.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
