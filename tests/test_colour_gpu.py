@@ -318,3 +318,30 @@ def test_upload_aos_equals_soa(gpu_ctx_factory, small_scene, stride):
         ctx.close()
     for k in ("cell", "pixel", "xc", "yc", "zc"):
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_async_download_ring_and_mask_diagnostics(gpu_ctx_factory, small_scene):
+    """Two-buffer consumer: async downloads of consecutive runs, pcp_download_wait_previous before a buffer is reused,
+    equal to the synchronous download; pcp_tile_masks agrees with pcp_tile_mask_density."""
+    import torch
+
+    from pointcloudprocessor_amd import capi
+
+    ctx = gpu_ctx_factory()
+    _setup(ctx, capi, small_scene)
+    n = len(small_scene["x"])
+    ctx.download_wait_previous()  # nothing pending: a no-op
+    ring = [torch.empty(n, dtype=torch.int32).pin_memory() for _ in range(2)]
+    for s in range(5):
+        ctx.colorize(download=False)
+        ctx.download_result_packed_async(ring[s & 1].data_ptr())
+        ctx.download_wait_previous()
+    ctx.synchronize()
+    ref = ctx.download_result_packed()
+    assert np.array_equal(ring[0].numpy().view(np.uint32), ref) and np.array_equal(ring[1].numpy().view(np.uint32), ref)
+    masks = ctx.tile_masks()
+    assert masks.shape == ((n + 63) // 64, 1) and masks.dtype == np.uint32
+    bits = np.unpackbits(masks.view(np.uint8)).sum()
+    assert abs(bits / (masks.shape[0] * len(small_scene["poses"])) - ctx.tile_mask_density()) < 1e-12
+    assert (masks >> len(small_scene["poses"])).max() == 0  # no bits beyond the keyframe count
+    ctx.close()
