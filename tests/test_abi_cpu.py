@@ -98,3 +98,18 @@ def test_every_entry_point_is_documented():
     missing = [n for n in names if n not in doc and not n.startswith(("pcp_timing_", "pcp_default_"))]
     assert not missing, missing
     assert "pcp_timing_" in doc and "pcp_default_" in doc
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """include/pcp_hip.h is the FFI surface: it must compile as C99 (cgo / ctypes / JNI generators) and as C++11."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text('#include "pcp_hip.h"\nint main(void) { return pcp_abi_version() > 0 ? 0 : 1; }\n')
+    inc = os.path.join(root, "include")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-c", str(src), "-o",
+                    str(tmp_path / "abi_c.o")], check=True, capture_output=True)
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-I", inc, "-x", "c++", "-c", str(src), "-o",
+                    str(tmp_path / "abi_cpp.o")], check=True, capture_output=True)
