@@ -66,7 +66,8 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(_LIB_PATH)
+        # PCP_ORACLE_LIBRARY: e.g. the sanitizer build (make -C oracle libpcp_oracle_asan.so)
+        L = C.CDLL(os.environ.get("PCP_ORACLE_LIBRARY") or _LIB_PATH)
         fp = C.POINTER(C.c_float)
         L.orc_cull_frame.restype = C.c_int64
         L.orc_frame_visible.restype = C.c_int64

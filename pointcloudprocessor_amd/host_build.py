@@ -27,7 +27,8 @@ def build(force: bool = False) -> dict:
         deps = [d for d in deps if os.path.exists(d)]
         stale = force or not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps)
         if stale:
-            cmd = ["g++", "-std=c++17", "-O2", "-pthread", "-Wall", "-Wextra", "-I", _build.INCLUDE, "-I", HOST] + [
+            extra = os.environ.get("PCP_HOST_CXXFLAGS", "").split()  # e.g. -fsanitize=address,undefined (CPU-side checks)
+            cmd = ["g++", "-std=c++17", "-O2", "-pthread", "-Wall", "-Wextra"] + extra + ["-I", _build.INCLUDE, "-I", HOST] + [
                 os.path.join(HOST, s) for s in srcs] + ["-L", _build.LIB_DIR, "-lpcp_hip",
                                                         "-lz", "-Wl,-rpath,$ORIGIN/../../lib", "-o", exe]
             proc = subprocess.run(cmd, capture_output=True, text=True)
