@@ -35,6 +35,12 @@ def main():
         cd["cy"] += rng.uniform(-40, 40)
         W, H = cd["image_width"], cd["image_height"]
         x, y, z, _ = synth.make_cloud(n, seed=77 + case)
+        if case % 4 == 3:  # a sprinkle of non-finite and far-away points (PCL clouds with is_dense == false)
+            bad = rng.choice(n, n // 1000, replace=False)
+            x[bad[0::4]] = np.nan
+            y[bad[1::4]] = np.inf
+            z[bad[2::4]] = -np.inf
+            x[bad[3::4]] *= 1e6
         poses, _ = synth.make_trajectory(F)
         poses = poses[rng.permutation(F)]  # keyframe order must not matter to the machinery
         imgs = [synth.make_image(int(rng.integers(0, 64)), W, H) for _ in range(8)]
