@@ -36,6 +36,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PROJ_BYTES_PER_POINT = 20  # 12 B xyz read + 4 B cell + 4 B range written
+PMC_SUMMARY = "r02_pmc.json"  # profiles/: summary of the rocprofv3 --pmc passes of this command (profiles/summarise_pmc.py)
 
 
 def parse():
@@ -47,6 +48,9 @@ def parse():
     ap.add_argument("--frames", type=int, default=256)
     ap.add_argument("--camera", default="cfg", choices=["cfg", "ref", "tiny"])
     ap.add_argument("--mls-points", type=int, default=10_000_000)
+    ap.add_argument("--roofline-points", type=int, default=40_000_000,
+                    help="cloud size of the HBM roofline leg (20 B x this = working set per launch; > 256 MiB defeats the Infinity Cache)")
+    ap.add_argument("--roofline-launches", type=int, default=64)
     ap.add_argument("--no-mls", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-points", type=int, default=1_000_000)
@@ -164,21 +168,48 @@ def main():
     if rank == 0:
         kt = {eng.ctx.kernel_name(k): eng.ctx.timing_get(k) for k in (capi.K_TILE_MASK, capi.K_DEPTH, capi.K_COLOUR, capi.K_MISC)}
         # ---- roofline leg: the single-keyframe projection kernel, one launch per keyframe ----
-        eng.ctx.timing_reset()
-        for f in range(F):
-            eng.ctx.project_frame(f, device_only=True)
-        proj_ms, proj_launches = eng.ctx.timing_get(capi.K_PROJECT)
+        def project_leg(ctx, npts, frames):
+            ctx.timing_enable(True)
+            ctx.timing_reset()
+            for f in frames:
+                ctx.project_frame(f, device_only=True)
+            ms, launches = ctx.timing_get(capi.K_PROJECT)
+            ctx.timing_enable(False)
+            avg = ms / max(launches, 1) / 1e3
+            return avg, launches, PROJ_BYTES_PER_POINT * npts / avg / 1e9
+
+        # (a) on the workload's own cloud: 120 MB read + 80 MB written per launch, the same buffers every launch --
+        # the working set fits the 256 MiB Infinity Cache, so this figure is NOT an HBM rate
+        avg_ic, launches_ic, achieved_ic = project_leg(eng.ctx, N, range(F))
         eng.ctx.timing_enable(False)
-        avg_s = proj_ms / max(proj_launches, 1) / 1e3
-        achieved = PROJ_BYTES_PER_POINT * N / avg_s / 1e9
+        # (b) the HBM figure: a cloud large enough that more than 256 MiB pass between two uses of any line
+        # (MI355X_MICROARCH.md, Infinity Cache residency rule): 12 B x Nr read + 8 B x Nr written per launch
+        Nr = max(args.roofline_points, N)
+        rctx = capi.Context(local_rank)
+        rctx.set_camera(capi.camera_from_dict(cam))
+        reps = -(-Nr // N)
+        # the same scene, replicated with sub-millimetre offsets (same share of in-frustum points per keyframe)
+        rx = np.concatenate([x + np.float32(k * 1e-4) for k in range(reps)])[:Nr]
+        ry = np.concatenate([y + np.float32(k * 1e-4) for k in range(reps)])[:Nr]
+        rz = np.concatenate([z + np.float32(k * 1e-4) for k in range(reps)])[:Nr]
+        rctx.upload_cloud(rx, ry, rz)
+        del rx, ry, rz
+        rctx.set_frames(poses)
+        rframes = list(range(F))[: max(8, min(F, args.roofline_launches))]
+        project_leg(rctx, Nr, rframes[:4])  # warm-up (scratch allocation)
+        avg_s, proj_launches, achieved = project_leg(rctx, Nr, rframes)
+        rctx.close()
         # HBM traffic of the same kernel from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as
-        # MI355X_MICROARCH.md prescribes), collected with this command and committed under profiles/
-        traffic = None
+        # MI355X_MICROARCH.md prescribes), collected with this command and committed under profiles/; it is a
+        # recorded figure of that profile run, not measured in this one
+        traffic = traffic_src = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_g_pmc.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", PMC_SUMMARY)) as fh:
                 pmc = json.load(fh)
-            if pmc.get("points_per_launch") == N:
-                traffic = round(pmc["k_project_frame"]["traffic_bytes_per_launch"])
+            ent = pmc.get("k_project_frame_hbm", {})
+            if ent.get("points_per_launch") == Nr:
+                traffic = round(ent["traffic_bytes_per_launch"])
+                traffic_src = f"profiles/{PMC_SUMMARY} (recorded rocprofv3 PMC passes of this command)"
         except (OSError, KeyError, ValueError):
             pass
         roofline = {
@@ -189,10 +220,17 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": traffic,
-            "traffic_source": "profiles/r01_g_pmc.json" if traffic else None,
-            "bytes_per_launch": PROJ_BYTES_PER_POINT * N,
+            "traffic_source": traffic_src,
+            "points_per_launch": Nr,
+            "bytes_per_launch": PROJ_BYTES_PER_POINT * Nr,
+            "working_set_MiB": round(PROJ_BYTES_PER_POINT * Nr / 2**20, 1),
             "avg_launch_ms": round(avg_s * 1e3, 4),
             "launches": proj_launches,
+            "frac_hbm": round(achieved / HBM_PEAK_GBPS, 4),
+            "ic_resident": {"points_per_launch": N, "working_set_MiB": round(PROJ_BYTES_PER_POINT * N / 2**20, 1),
+                            "avg_launch_ms": round(avg_ic * 1e3, 4), "launches": launches_ic,
+                            "achieved": round(achieved_ic, 1), "frac_ic_resident": round(achieved_ic / HBM_PEAK_GBPS, 4),
+                            "note": "working set below the 256 MiB Infinity Cache and reused by every launch: not an HBM rate"},
         }
         # ---- PCIe-inclusive figure (never `value`): the keyframe images start in pinned host memory ----
         pcie = None

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PCP_ABI_VERSION 1
+#define PCP_ABI_VERSION 2 /* 2: pcp_cull_params grew cull_mode / match_mode; pcp_image_params */
 
 #define PCP_OK 0
 #define PCP_ERR_INVALID (-1) /* bad argument */
@@ -57,12 +57,32 @@ typedef struct pcp_camera {
   int32_t cull_width, cull_height;
 } pcp_camera;
 
+/* Which of ViewCulling's two routines decides the candidates (pcp_cull_params.cull_mode). */
+#define PCP_CULL_ZBUFFER 0 /* ViewCulling::view_culling, view_culling.cpp:52-174 (the routine north_star names; its
+                              call is commented out at :43) */
+#define PCP_CULL_HPR_CANDIDATES 1 /* the candidate filter of ViewCulling::hidden_points_removal, view_culling.cpp:
+                              276-288 (the routine the reference binary calls, :46): z > 0 and 0 <= (int)u < cull_width
+                              and 0 <= (int)v < cull_height, every candidate kept.  qhull's convex hull of the
+                              spherically flipped candidates (:291-329) is NOT run: with the hard-coded flip radius
+                              90000 (view_culling.hpp:14) it keeps every candidate on non-degenerate data and drops
+                              a handful on near-collinear ones ("HPR"). */
+
+/* How a visible sample is credited to map points (pcp_cull_params.match_mode), PointCloudProcessor.cpp:554-592. */
+#define PCP_MATCH_IDENTITY 0 /* the sample of point i is credited to point i, scores from the transform output p_c */
+#define PCP_MATCH_ROUNDTRIP 1 /* the reference's arithmetic: p_w = c2w p_c in fp32 (:555), the sample is dropped unless
+                              |p_w - p_i|^2 < f32(1e-5^2) in fp32 (what radiusSearch(1e-5) tests for point i itself,
+                              :571), scores from p_c' = c2w.inverse() p_w in fp32 (:578-579).  Samples that the
+                              reference's kd-tree would ALSO credit to other map points closer than 10 um to p_w are
+                              not replicated (needs map points < ~20 um apart). */
+
 /* vlcal::ViewCullingParams, PCP/include/vlcal/calib/view_culling.hpp:10-19, plus
  * the constants 14 (view_culling.cpp:63) and 0.05 (:157). */
 typedef struct pcp_cull_params {
   int32_t enable_depth_buffer_culling;
   int32_t downsample_factor;
   double depth_slack;
+  int32_t cull_mode;  /* PCP_CULL_ZBUFFER (default) / PCP_CULL_HPR_CANDIDATES */
+  int32_t match_mode; /* PCP_MATCH_IDENTITY (default) / PCP_MATCH_ROUNDTRIP */
 } pcp_cull_params;
 
 /* MLSParameters, PCP/include/cloudSmooth.hpp:21-36; values

@@ -367,6 +367,8 @@ __global__ __launch_bounds__(kBlock) void k_depth_pass(const float *__restrict__
   const int64_t j = tile_order ? static_cast<int64_t>(tile_order[blockIdx.x]) * 64 + threadIdx.x
                                : static_cast<int64_t>(xcd_chunked_block()) * kBlock + threadIdx.x;
   const bool live = j < n;
+  // a wavefront wholly past the cloud (tail of a 256-thread workgroup) has no tile: its mask words do not exist
+  if (!__ballot(live)) return;
   const float px = live ? x[j] : 0.0f, py = live ? y[j] : 0.0f, pz = live ? z[j] : 0.0f;
   const int64_t tile = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(j >> 6));
   for (int32_t w = f0 >> 5; w <= (f1 - 1) >> 5; ++w) {
@@ -455,6 +457,8 @@ __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict_
   const int64_t j = tile_order ? static_cast<int64_t>(tile_order[blockIdx.x]) * 64 + threadIdx.x
                                : static_cast<int64_t>(xcd_chunked_block()) * kBlock + threadIdx.x;
   const bool live = j < n;
+  // a wavefront wholly past the cloud (tail of a 256-thread workgroup) has no tile: its mask words do not exist
+  if (!__ballot(live)) return;
   const float px = live ? x[j] : 0.0f, py = live ? y[j] : 0.0f, pz = live ? z[j] : 0.0f;
   const int64_t tile = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(j >> 6));
   Top5 t;

@@ -646,6 +646,8 @@ void pcp_default_cull_params(pcp_cull_params *p) {
   p->enable_depth_buffer_culling = 1;
   p->downsample_factor = 14;
   p->depth_slack = 0.05;
+  p->cull_mode = PCP_CULL_ZBUFFER;
+  p->match_mode = PCP_MATCH_IDENTITY;
 }
 
 // PointCloudProcessor.cpp:67-86
@@ -671,6 +673,10 @@ int pcp_set_camera(pcp_context *ctx, const pcp_camera *cam, const pcp_cull_param
   if (cam->image_width <= 0 || cam->image_height <= 0 || cam->cull_width <= 0 || cam->cull_height <= 0)
     return set_error(ctx, PCP_ERR_INVALID, "pcp_set_camera: image / cull size must be positive");
   if (cp.downsample_factor <= 0) return set_error(ctx, PCP_ERR_INVALID, "pcp_set_camera: downsample_factor must be > 0");
+  if (cp.cull_mode != PCP_CULL_ZBUFFER && cp.cull_mode != PCP_CULL_HPR_CANDIDATES)
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_set_camera: unknown cull_mode %d", cp.cull_mode);
+  if (cp.match_mode != PCP_MATCH_IDENTITY && cp.match_mode != PCP_MATCH_ROUNDTRIP)
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_set_camera: unknown match_mode %d", cp.match_mode);
   if (cam->cull_width > (1 << 24) || cam->cull_height > (1 << 24))
     return set_error(ctx, PCP_ERR_INVALID, "pcp_set_camera: cull size above 2^24 is not supported");
   if (static_cast<int64_t>(cam->image_width) * cam->image_height >= (int64_t(1) << 31))
@@ -703,7 +709,18 @@ int pcp_set_camera(pcp_context *ctx, const pcp_camera *cam, const pcp_cull_param
   d.cull_hf = static_cast<float>(cam->cull_height);
   d.mw = cam->cull_width / cp.downsample_factor;
   d.mh = cam->cull_height / cp.downsample_factor;
-  d.enable_zbuf = cp.enable_depth_buffer_culling ? 1 : 0;
+  d.cull_mode = cp.cull_mode;
+  d.match_mode = cp.match_mode;
+  d.cull_wd = static_cast<double>(cam->cull_width);
+  d.cull_hd = static_cast<double>(cam->cull_height);
+  {
+    // kdtree.radiusSearch(searchPoint, epsilon = 1e-5f): PCL squares the radius in fp64 and hands FLANN the fp32
+    // value [upstream KdTreeFLANN::radiusSearch], PointCloudProcessor.cpp:482,571
+    const double eps = static_cast<double>(1e-5f);
+    d.match_r2 = static_cast<float>(eps * eps);
+  }
+  // hidden_points_removal has no depth buffer: every candidate is kept
+  d.enable_zbuf = (cp.enable_depth_buffer_culling && cp.cull_mode == PCP_CULL_ZBUFFER) ? 1 : 0;
   // conservative fp32 rejection test (pcp_device.hpp): parameters
   d.pretest = 1;
   d.qfx = static_cast<float>(cam->fx);
@@ -727,9 +744,11 @@ int pcp_set_camera(pcp_context *ctx, const pcp_camera *cam, const pcp_cull_param
   {
     // cell rule accepts trunc(f32(u)/ds) in [0, mw) (depth buffer on) or [0, cull_w) (off);
     // pixel rule accepts (int)u in [0, img_w).  Box = union, +-0.5 px.
+    // (hidden_points_removal's rule accepts (int)u in [0, cull_w): inside the same box with cw = cull_w)
     const float ds = static_cast<float>(cp.downsample_factor);
-    const float cw = ds * static_cast<float>(d.enable_zbuf ? d.mw : d.cull_w);
-    const float ch = ds * static_cast<float>(d.enable_zbuf ? d.mh : d.cull_h);
+    const bool hpr = cp.cull_mode == PCP_CULL_HPR_CANDIDATES;
+    const float cw = hpr ? static_cast<float>(d.cull_w) : ds * static_cast<float>(d.enable_zbuf ? d.mw : d.cull_w);
+    const float ch = hpr ? static_cast<float>(d.cull_h) : ds * static_cast<float>(d.enable_zbuf ? d.mh : d.cull_h);
     d.u_lo = -(ds + 0.5f);
     d.v_lo = -(ds + 0.5f);
     d.u_hi = std::max(cw, static_cast<float>(d.img_w)) + 0.5f;

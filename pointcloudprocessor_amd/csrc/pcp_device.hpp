@@ -102,6 +102,11 @@ __device__ __forceinline__ float div_by_ds(const DevCamera &c, float x) {
 // Values that do not fit an int32 (UB in the reference, Appendix B6) are rejected.
 template <bool kShortDiv = true>
 __device__ __forceinline__ int32_t cull_cell(const DevCamera &c, double u, double v) {
+  if (c.cull_mode == PCP_CULL_HPR_CANDIDATES) {
+    // hidden_points_removal's filter, view_culling.cpp:284-288: project(p).cast<int>() against the FULL cull size.
+    // There is no map in this mode: a candidate is reported as -2 ("candidate without a map cell") and kept.
+    return (u > -1.0 && u < c.cull_wd && v > -1.0 && v < c.cull_hd) ? -2 : -1;
+  }
   const float cxf = kShortDiv ? div_by_ds(c, static_cast<float>(u)) : static_cast<float>(u) / c.ds_f;
   const float cyf = kShortDiv ? div_by_ds(c, static_cast<float>(v)) : static_cast<float>(v) / c.ds_f;
   // C truncation: 0 <= (int)t < W  <=>  -1 < t < W (W an integer below 2^24); NaN / inf / out-of-int32 fail

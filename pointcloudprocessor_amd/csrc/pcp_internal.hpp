@@ -31,6 +31,10 @@ struct DevCamera {
   int32_t cull_w, cull_h;
   int32_t mw, mh;  // cull_w/ds, cull_h/ds
   int32_t enable_zbuf;
+  int32_t cull_mode;   // PCP_CULL_ZBUFFER / PCP_CULL_HPR_CANDIDATES (enable_zbuf is 0 with the latter)
+  int32_t match_mode;  // PCP_MATCH_IDENTITY / PCP_MATCH_ROUNDTRIP
+  double cull_wd, cull_hd;  // cull size as fp64: bounds of hidden_points_removal's (int)u, (int)v rule
+  float match_r2;      // f32(1e-5 * 1e-5): radiusSearch(epsilon) squared radius, PointCloudProcessor.cpp:482,571
   int32_t pretest;  // 1: run the conservative fp32 rejection test before the fp64 projection
   // fp32 copies for the rejection test (pcp_device.hpp surely_rejected): signed and
   // absolute coefficients, and the (u, v) box outside of which BOTH the cell rule and

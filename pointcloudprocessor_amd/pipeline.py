@@ -82,9 +82,12 @@ class HipEngine:
         ptr, n = self.ctx.depth_maps_device()
         if not getattr(self, "_on_torch_stream", False):
             self.ctx.synchronize()
+        # the view is rebuilt whenever the library may have reallocated or re-shaped the maps (new address, length,
+        # keyframe count or cull geometry); otherwise one wrapper per step would cost ~50 us of host time
+        key = (ptr, n, self.ctx.n_frames, self.ctx.map_shape)
         cached = getattr(self, "_depth_tensor", None)
-        if cached is None or cached[0] != (ptr, n):
-            self._depth_tensor = ((ptr, n), torch.as_tensor(_DeviceArray(ptr, n), device=f"cuda:{self.device}"))
+        if cached is None or cached[0] != key:
+            self._depth_tensor = (key, torch.as_tensor(_DeviceArray(ptr, n), device=f"cuda:{self.device}"))
         return self._depth_tensor[1]
 
     def colour_from_depth(self, download=True):

@@ -345,3 +345,27 @@ def test_async_download_ring_and_mask_diagnostics(gpu_ctx_factory, small_scene):
     assert abs(bits / (masks.shape[0] * len(small_scene["poses"])) - ctx.tile_mask_density()) < 1e-12
     assert (masks >> len(small_scene["poses"])).max() == 0  # no bits beyond the keyframe count
     ctx.close()
+
+
+@pytest.mark.parametrize("n", [256 * 7 + 1, 256 * 11 + 64, 256 * 3 + 33])
+def test_tail_workgroup_with_dead_wavefronts(gpu_ctx_factory, oracle, small_scene, n):
+    """n % 256 in (0, 64] leaves up to three wavefronts of the last 256-thread workgroup without a tile; with more than
+    32 keyframes (several mask words per tile) they once read tile-mask words past the allocation."""
+    from pointcloudprocessor_amd import capi, synth
+
+    F = 70
+    ctx = gpu_ctx_factory()
+    cd = small_scene["cam"]
+    ctx.set_camera(cam_struct(capi, cd))
+    x, y, z = (small_scene[k][:n] for k in "xyz")
+    ctx.upload_cloud(x, y, z)
+    poses, _ = synth.make_trajectory(F)
+    ctx.set_frames(poses)
+    imgs = [synth.make_image(f, cd["image_width"], cd["image_height"]) for f in range(F)]
+    for f, im in enumerate(imgs):
+        ctx.upload_image(f, im)
+    got = ctx.colorize()
+    ref = oracle.colorize(cam_struct(oracle, cd), oracle.default_cull_params(), x, y, z, poses, imgs)
+    assert ref["has"].sum() > 100
+    _colour_close(got["rgb"], ref)
+    assert np.array_equal(got["has"] > 0, ref["has"] > 0)
