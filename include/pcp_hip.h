@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PCP_ABI_VERSION 2 /* 2: pcp_cull_params grew cull_mode / match_mode; pcp_image_params */
+#define PCP_ABI_VERSION 2 /* 2: pcp_cull_params grew cull_mode / match_mode; pcp_set_image_adjust */
 
 #define PCP_OK 0
 #define PCP_ERR_INVALID (-1) /* bad argument */
@@ -158,6 +158,21 @@ int pcp_upload_image(pcp_context *ctx, int32_t frame, const uint8_t *bgr, int64_
  * host buffer must stay valid and unchanged until pcp_synchronize (or any synchronising call) returns; from
  * pinned memory a sequence of keyframes streams at the PCIe rate with the packing kernels in between. */
 int pcp_upload_image_async(pcp_context *ctx, int32_t frame, const uint8_t *bgr, int64_t row_stride_bytes);
+/* The image adjustment generateColorMap applies to every keyframe before sampling it
+ * (PointCloudProcessor.cpp:722-741): cv::cvtColor(BGR2HSV) on 8-bit pixels, S and V multiplied by
+ * saturation_scale / brightness_scale (both 1.0 in the reference, :728-729) with saturate_cast<uchar>, and
+ * cv::cvtColor(HSV2BGR).  8-bit HSV is lossy, so this is not the identity even at scale 1.0.
+ * enable != 0: images handed to pcp_upload_image / _async afterwards are RAW decoded pixels (cv::imread output)
+ * and the library applies the round trip while packing them (fused into the pack kernel, no extra pass).
+ * enable == 0 (default): the caller passes what generateColorMap holds AFTER its own cvtColor calls.
+ * Arithmetic: the forward half is OpenCV 4.2's integer routine (RGB2HSV_b, hdiv / sdiv tables, h range 180),
+ * restated exactly; the backward half is OpenCV 4.2's scalar float routine (HSV2RGB_native, no FMA), whose
+ * SIMD / FMA builds may differ from it by one level on some pixels [upstream, parity unpinned: DESIGN.md]. */
+int pcp_set_image_adjust(pcp_context *ctx, int32_t enable, float saturation_scale, float brightness_scale);
+/* diagnostic: the pixels of one keyframe as the kernels sample them (after pcp_set_image_adjust's round trip when it
+ * was enabled at upload): out_bgr image_height*image_width*3 tightly packed, out_mask image_height*image_width
+ * (either nullable) */
+int pcp_download_image(pcp_context *ctx, int32_t frame, uint8_t *out_bgr, uint8_t *out_mask);
 /* gray8 segmentation mask (cv::IMREAD_GRAYSCALE, PointCloudProcessor.cpp:775) */
 int pcp_upload_mask(pcp_context *ctx, int32_t frame, const uint8_t *gray, int64_t row_stride_bytes);
 

@@ -55,25 +55,28 @@ def pose_to_matrices(pose, T_opt=None):
 
 
 def affine_inverse_f32(m):
-    """General fp32 affine inverse (Eigen Affine3f::inverse) [upstream, op order unverified]."""
+    """General fp32 affine inverse, Eigen Transform<float,3,Affine>::inverse() [upstream Eigen 3.3.7
+    LU/InverseImpl.h compute_inverse<3>: cofactors, det expanded along COLUMN 0; a 3-term fp32 sum goes through
+    Redux.h's scalar unroller as p0 + (p1 + p2); translation = (-Linv) * t with the same 3-term sums]."""
     m = np.asarray(m, f32).reshape(3, 4)
-    a, b, c = m[0, 0], m[0, 1], m[0, 2]
-    d, e, f = m[1, 0], m[1, 1], m[1, 2]
-    g, h, i = m[2, 0], m[2, 1], m[2, 2]
-    c00 = e * i - f * h
-    c01 = f * g - d * i
-    c02 = d * h - e * g
-    det = (a * c00 + b * c01) + c * c02
+
+    def cof(i, j):
+        i1, i2, j1, j2 = (i + 1) % 3, (i + 2) % 3, (j + 1) % 3, (j + 2) % 3
+        return m[i1, j1] * m[i2, j2] - m[i1, j2] * m[i2, j1]
+
+    col0 = [cof(0, 0), cof(1, 0), cof(2, 0)]
+    det = col0[0] * m[0, 0] + (col0[1] * m[1, 0] + col0[2] * m[2, 0])
     inv = f32(1.0) / det
-    L = np.array([
-        [c00 * inv, (c * h - b * i) * inv, (b * f - c * e) * inv],
-        [c01 * inv, (a * i - c * g) * inv, (c * d - a * f) * inv],
-        [c02 * inv, (b * g - a * h) * inv, (a * e - b * d) * inv],
-    ], f32)
+    L = np.zeros((3, 3), f32)
+    for j in range(3):
+        L[0, j] = col0[j] * inv
+    for j in range(3):
+        L[1, j] = cof(j, 1) * inv
+        L[2, j] = cof(j, 2) * inv
     t = m[:, 3]
     out = np.zeros((3, 4), f32)
     out[:, :3] = L
-    out[:, 3] = -((L[:, 0] * t[0] + L[:, 1] * t[1]) + L[:, 2] * t[2])
+    out[:, 3] = (-L[:, 0]) * t[0] + ((-L[:, 1]) * t[1] + (-L[:, 2]) * t[2])
     return out
 
 
@@ -226,6 +229,163 @@ def colorize(cam: dict, x, y, z, poses, images, ds: int = 14, slack: float = 0.0
             rgb[i, c] = np.uint8(int(acc[c] / tot))
     has = (rgb != 0).any(axis=1).astype(np.uint8)
     return dict(rgb=rgb, has=has, count=count, top_score=top_score, top_rgb=top_rgb, top_frame=top_frame)
+
+
+def hpr_candidates(cam: dict, w2c, x, y, z):
+    """The candidate filter of hidden_points_removal (view_culling.cpp:276-288): z > 0 and
+    0 <= (int)u < W, 0 <= (int)v < H against the full cull size.  Returns the mask and the projection."""
+    p = project_frame(cam, w2c, x, y, z)
+    u, v = p["u"], p["v"]
+    ok = (p["zc"] > 0) & _trunc_ok(u) & _trunc_ok(v)
+    ui = np.where(ok, np.trunc(np.where(ok, u, 0)), -1)
+    vi = np.where(ok, np.trunc(np.where(ok, v, 0)), -1)
+    return ok & (ui >= 0) & (ui < cam["cull_width"]) & (vi >= 0) & (vi < cam["cull_height"]), p
+
+
+def affine_times_point_eigen(m, x, y, z):
+    """Eigen Affine3f * Vector4f (PointCloudProcessor.cpp:579): per row (m0 x + m1 y) + (m2 z + m3 * 1) in fp32
+    [upstream Eigen 3.3.7: coefficient-based 3x4 * 4x1 product, 4-term sum split 2 + 2 by Redux.h]."""
+    m = np.asarray(m, f32).reshape(3, 4)
+    x, y, z = (np.asarray(a, f32) for a in (x, y, z))
+    return [(m[r, 0] * x + m[r, 1] * y) + (m[r, 2] * z + m[r, 3] * f32(1.0)) for r in range(3)]
+
+
+def colorize_faithful(cam: dict, x, y, z, poses, images, ds: int = 14, slack: float = 0.05, T_opt=None,
+                      hpr_candidates_mode: bool = False):
+    """pcdColorizationAndSmooth with the reference's own match-back (Appendix B3 faithful mode,
+    PointCloudProcessor.cpp:554-592): p_w = c2w p_c (fp32, PCL association), radiusSearch(1e-5) over the original
+    cloud (fp32 L2_Simple distance, strict <, ascending distance), every match credited with scores from
+    c2w.inverse() p_w.  Neighbour candidates come from scipy's cKDTree (a superset within a padded radius) and are
+    filtered with the fp32 rule, so the result set does not depend on the tree."""
+    from scipy.spatial import cKDTree
+
+    x, y, z = (np.asarray(a, f32) for a in (x, y, z))
+    n = len(x)
+    P64 = np.stack([x, y, z], axis=1).astype(f64)
+    tree = cKDTree(P64)
+    eps = f64(f32(1e-5))
+    r2 = f32(eps * eps)
+    lists = [[] for _ in range(n)]
+    stats = dict(samples=0, unmatched=0, self_missed=0, cross_credits=0)
+    for f, pose in enumerate(poses):
+        T = None
+        if T_opt is not None:
+            T = np.asarray(T_opt, f64).reshape(-1, 16)
+            T = T[f if len(T) > 1 else 0]
+        w2c, c2w = pose_to_matrices(pose, T)
+        inv = affine_inverse_f32(c2w)
+        if hpr_candidates_mode:
+            keep, p = hpr_candidates(cam, w2c, x, y, z)
+        else:
+            keep, _, p = cull_frame(cam, w2c, x, y, z, ds, slack, True)
+        sel = np.nonzero(keep & (p["pixel"] >= 0))[0]
+        if len(sel) == 0:
+            continue
+        img = np.asarray(images[f], np.uint8).reshape(-1, 3)
+        bgr = img[p["pixel"][sel]]
+        wx, wy, wz = transform(c2w, p["xc"][sel], p["yc"][sel], p["zc"][sel])
+        sx, sy, sz = affine_times_point_eigen(inv, wx, wy, wz)
+        _, _, fin = scores(sx, sy, sz, pose)
+        near = tree.query_ball_point(np.stack([wx, wy, wz], axis=1).astype(f64), float(eps) * 1.01 + 1e-9)
+        for k, i in enumerate(sel):
+            stats["samples"] += 1
+            cand = np.array(sorted(near[k]), np.int64)
+            if len(cand):
+                dx, dy, dz = wx[k] - x[cand], wy[k] - y[cand], wz[k] - z[cand]
+                d = dx * dx
+                d = d + dy * dy
+                d = d + dz * dz
+                hit = d < r2
+                cand, d = cand[hit], d[hit]
+                cand = cand[np.lexsort((cand, d))]
+            if len(cand) == 0:
+                stats["unmatched"] += 1
+                stats["self_missed"] += 1
+                continue
+            if i not in cand:
+                stats["self_missed"] += 1
+            for j in cand:
+                if j != i:
+                    stats["cross_credits"] += 1
+                lists[j].append((float(fin[k]), int(bgr[k, 2]), int(bgr[k, 1]), int(bgr[k, 0]), f))
+    out = _finalise_lists(lists, n)
+    out["stats"] = stats
+    return out
+
+
+def _finalise_lists(lists, n):
+    """smoothColors + removePointsWithNoColor on collected (score, r, g, b, frame) lists (cpp:604-631)."""
+    rgb = np.zeros((n, 3), np.uint8)
+    count = np.zeros(n, np.int32)
+    top_score = np.full((n, 5), -1.0, f32)
+    top_rgb = np.zeros((n, 5), np.uint32)
+    top_frame = np.full((n, 5), -1, np.int32)
+    for i, lst in enumerate(lists):
+        count[i] = len(lst)
+        if not lst:
+            continue
+        lst = sorted(lst, key=lambda e: -e[0])[:5]  # stable: ties keep arrival order (B8)
+        tot = f32(0)
+        acc = [f32(0), f32(0), f32(0)]
+        for k, (s, r, g, b, fr) in enumerate(lst):
+            s = f32(s)
+            acc[0] = acc[0] + f32(r) * s
+            acc[1] = acc[1] + f32(g) * s
+            acc[2] = acc[2] + f32(b) * s
+            tot = tot + s
+            top_score[i, k] = s
+            top_rgb[i, k] = (r << 16) | (g << 8) | b
+            top_frame[i, k] = fr
+        for c in range(3):
+            rgb[i, c] = np.uint8(int(acc[c] / tot))
+    has = (rgb != 0).any(axis=1).astype(np.uint8)
+    return dict(rgb=rgb, has=has, count=count, top_score=top_score, top_rgb=top_rgb, top_frame=top_frame)
+
+
+# --------------------------------------------------------------------------- f4
+def hsv_round_trip(bgr, saturation_scale: float = 1.0, brightness_scale: float = 1.0):
+    """generateColorMap's image adjustment (PointCloudProcessor.cpp:722-741): 8-bit BGR2HSV (OpenCV 4.2 RGB2HSV_b,
+    integer), S / V scaling through saturate_cast<uchar>, HSV2BGR (HSV2RGB_native, scalar fp32, no FMA)
+    [upstream OpenCV 4.2.0, color_hsv.simd.hpp].  Vectorised over an (..., 3) uint8 array."""
+    a = np.asarray(bgr, np.uint8)
+    shape = a.shape
+    a = a.reshape(-1, 3).astype(np.int64)
+    b, g, r = a[:, 0], a[:, 1], a[:, 2]
+    idx = np.arange(1, 256, dtype=f64)
+    sdiv = np.concatenate([[0], np.rint((255 << 12) / (1.0 * idx)).astype(np.int64)])
+    hdiv = np.concatenate([[0], np.rint((180 << 12) / (6.0 * idx)).astype(np.int64)])
+    v = np.maximum(np.maximum(b, g), r)
+    diff = v - np.minimum(np.minimum(b, g), r)
+    s = (diff * sdiv[v] + 2048) >> 12
+    h = np.where(v == r, g - b, np.where(v == g, b - r + 2 * diff, r - g + 4 * diff))
+    h = (h * hdiv[diff] + 2048) >> 12  # arithmetic shift of a negative product = floor, as in C
+    h = np.where(h < 0, h + 180, h)
+    H = np.clip(h, 0, 255)
+
+    def sat(x):  # saturate_cast<uchar>(float): round half to even, clamp
+        return np.clip(np.rint(x.astype(f32)).astype(np.int64), 0, 255)
+
+    S = sat(s.astype(f32) * f32(saturation_scale))
+    V = sat(v.astype(f32) * f32(brightness_scale))
+    inv255 = f32(1.0) / f32(255.0)
+    fs = S.astype(f32) * inv255
+    fv = V.astype(f32) * inv255
+    fh = H.astype(f32) * (f32(6.0) / f32(180.0))
+    fh = np.fmod(fh, f32(6.0)).astype(f32)
+    sector = np.floor(fh).astype(np.int64)
+    fh = fh - sector.astype(f32)
+    bad = (sector < 0) | (sector >= 6)
+    sector = np.where(bad, 0, sector)
+    fh = np.where(bad, f32(0), fh).astype(f32)
+    one = f32(1.0)
+    tab = np.stack([fv, fv * (one - fs), fv * (one - fs * fh), fv * (one - fs * (one - fh))], axis=1).astype(f32)
+    sector_data = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])
+    pick = sector_data[sector]
+    rows = np.arange(len(tab))
+    out = np.stack([tab[rows, pick[:, c]] for c in range(3)], axis=1)
+    grey = fs == 0
+    out[grey] = fv[grey, None]
+    return sat(out * f32(255.0)).astype(np.uint8).reshape(shape)
 
 
 # --------------------------------------------------------------------------- A7

@@ -31,7 +31,13 @@ class CullParams(C.Structure):
         ("enable_depth_buffer_culling", C.c_int32),
         ("downsample_factor", C.c_int32),
         ("depth_slack", C.c_double),
+        ("cull_mode", C.c_int32),   # 0 z-buffer, 1 hidden_points_removal's candidate filter
+        ("match_mode", C.c_int32),  # 0 identity, 1 fp32 world round trip + self-match
     ]
+
+
+CULL_ZBUFFER, CULL_HPR_CANDIDATES = 0, 1
+MATCH_IDENTITY, MATCH_ROUNDTRIP = 0, 1
 
 
 class MLSParams(C.Structure):
@@ -77,6 +83,8 @@ def lib() -> C.CDLL:
         L.orc_select_keyframes.restype = C.c_int32
         L.orc_hardware_threads.restype = C.c_int32
         L.orc_colorize.restype = C.c_int
+        L.orc_colorize_faithful.restype = C.c_int
+        L.orc_affine_inverse_f32.restype = None
         _ = fp
         _lib = L
     return _lib
@@ -200,6 +208,56 @@ def colorize(cam, cp, x, y, z, poses, images, T_opt=None, threads: int = 1, want
     if rc != 0:
         raise RuntimeError("orc_colorize failed")
     return dict(rgb=rgb, has=has, count=cnt, top_score=ts, top_rgb=tr, top_frame=tf)
+
+
+def colorize_faithful(cam, cp, x, y, z, poses, images, T_opt=None, threads: int = 1):
+    """The reference's own match-back (Appendix B3): fp32 world round trip, radiusSearch(1e-5) over the original
+    cloud, scores from c2w.inverse() * p_w.  Adds `stats` = dict(samples, unmatched, self_missed, cross_credits)."""
+    x, y, z = _f32(x), _f32(y), _f32(z)
+    n = len(x)
+    poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)
+    F = len(poses)
+    parr = poses_array(poses)
+    imgs = [np.ascontiguousarray(im, np.uint8) for im in images]
+    assert len(imgs) == F
+    iptr = (C.c_void_p * F)(*[im.ctypes.data for im in imgs])
+    rgb = np.zeros((n, 3), np.uint8)
+    has = np.zeros(n, np.uint8)
+    cnt = np.zeros(n, np.int32)
+    ts = np.zeros((n, 5), np.float32)
+    tr = np.zeros((n, 5), np.uint32)
+    tf = np.zeros((n, 5), np.int32)
+    st = np.zeros(4, np.int64)
+    T = None
+    stride = 0
+    if T_opt is not None:
+        T = np.ascontiguousarray(T_opt, np.float64)
+        stride = 16 if T.size == 16 * F and F > 1 else 0
+        T = T.reshape(-1)
+    rc = lib().orc_colorize_faithful(C.byref(cam), C.byref(cp), _p(x), _p(y), _p(z), C.c_int64(n), parr, C.c_int32(F),
+                                     _p(T), C.c_int32(stride), iptr, _p(rgb), _p(has), _p(cnt), _p(ts), _p(tr), _p(tf),
+                                     _p(st), C.c_int32(threads))
+    if rc != 0:
+        raise RuntimeError("orc_colorize_faithful failed")
+    return dict(rgb=rgb, has=has, count=cnt, top_score=ts, top_rgb=tr, top_frame=tf,
+                stats=dict(samples=int(st[0]), unmatched=int(st[1]), self_missed=int(st[2]), cross_credits=int(st[3])))
+
+
+def affine_inverse(m):
+    m = _f32(m).reshape(12)
+    out = np.zeros(12, np.float32)
+    lib().orc_affine_inverse_f32(_p(m), _p(out))
+    return out
+
+
+def hsv_round_trip(bgr, saturation_scale: float = 1.0, brightness_scale: float = 1.0):
+    """generateColorMap's 8-bit BGR -> HSV -> BGR round trip (PointCloudProcessor.cpp:722-741) of an (..., 3) image."""
+    a = np.ascontiguousarray(bgr, np.uint8)
+    out = np.empty_like(a)
+    lib().orc_hsv_round_trip.restype = None
+    lib().orc_hsv_round_trip(_p(a), _p(out), C.c_int64(a.size // 3), C.c_float(saturation_scale),
+                             C.c_float(brightness_scale))
+    return out
 
 
 def frame_visible(cam, cp, pose, x, y, z, image, mask=None, T_opt=None):

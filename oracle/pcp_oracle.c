@@ -42,6 +42,8 @@ void orc_default_cull_params(orc_cull_params *p) {
   p->enable_depth_buffer_culling = 1;
   p->downsample_factor = 14;
   p->depth_slack = 0.05;
+  p->cull_mode = ORC_CULL_ZBUFFER;
+  p->match_mode = ORC_MATCH_IDENTITY;
 }
 
 /* PCP/src/PointCloudProcessor.cpp:67-86 */
@@ -97,36 +99,45 @@ static void quat_to_rot(const orc_pose *p, double R[9]) {
   R[8] = 1.0 - (txx + tyy);
 }
 
-/* General fp32 affine inverse: Eigen Transform<float,3,Affine>::inverse()
- * = [L^-1 | -L^-1 t] with the 3x3 cofactor inverse [upstream, op order
- * unverified here].  PCP/src/PointCloudProcessor.cpp:509,518. */
+/* General fp32 affine inverse: Eigen Transform<float,3,Affine>::inverse(Affine)
+ * = [L^-1 | -L^-1 t]  (PCP/src/PointCloudProcessor.cpp:509,518; again at :578 for
+ * every match).  [upstream Eigen 3.3.7] LU/InverseImpl.h compute_inverse<.,.,3>:
+ * cofactor_3x3<i,j> = m(i1,j1) m(i2,j2) - m(i1,j2) m(i2,j1), i1 = (i+1)%3 ...;
+ * det = (cofactors_col0 .* m.col(0)).sum(); inverse(j,i) = cofactor<i,j> * (1/det).
+ * A 3-element fp32 sum has no SSE packet (4 floats): Redux.h's redux_novec_unroller
+ * <0,3> splits 1 + 2, i.e. p0 + (p1 + p2).  The translation is
+ * (-L^-1) * t, a 3x3 * 3x1 coefficient-based product whose 3 fp32 coefficients are
+ * each such a sum: (-l0 t0) + ((-l1 t1) + (-l2 t2)). */
 static void affine_inverse_f32(const float m[12], float out[12]) {
   const float a = m[0], b = m[1], c = m[2];
   const float d = m[4], e = m[5], f = m[6];
   const float g = m[8], h = m[9], i = m[10];
-  const float c00 = e * i - f * h;
-  const float c01 = f * g - d * i;
-  const float c02 = d * h - e * g;
-  const float det = (a * c00 + b * c01) + c * c02;
+  const float c00 = e * i - f * h; /* cofactor<0,0> */
+  const float c10 = h * c - i * b; /* cofactor<1,0> */
+  const float c20 = b * f - c * e; /* cofactor<2,0> */
+  const float det = c00 * a + (c10 * d + c20 * g);
   const float inv = 1.0f / det;
   float L[9];
   L[0] = c00 * inv;
-  L[1] = (c * h - b * i) * inv;
-  L[2] = (b * f - c * e) * inv;
-  L[3] = c01 * inv;
-  L[4] = (a * i - c * g) * inv;
-  L[5] = (c * d - a * f) * inv;
-  L[6] = c02 * inv;
-  L[7] = (b * g - a * h) * inv;
-  L[8] = (a * e - b * d) * inv;
+  L[1] = c10 * inv;
+  L[2] = c20 * inv;
+  L[3] = (f * g - d * i) * inv; /* cofactor<0,1> */
+  L[4] = (i * a - g * c) * inv; /* cofactor<1,1> */
+  L[5] = (c * d - a * f) * inv; /* cofactor<2,1> */
+  L[6] = (d * h - e * g) * inv; /* cofactor<0,2> */
+  L[7] = (g * b - h * a) * inv; /* cofactor<1,2> */
+  L[8] = (a * e - b * d) * inv; /* cofactor<2,2> */
   const float t0 = m[3], t1 = m[7], t2 = m[11];
   for (int r = 0; r < 3; ++r) {
     out[4 * r + 0] = L[3 * r + 0];
     out[4 * r + 1] = L[3 * r + 1];
     out[4 * r + 2] = L[3 * r + 2];
-    out[4 * r + 3] = -((L[3 * r + 0] * t0 + L[3 * r + 1] * t1) + L[3 * r + 2] * t2);
+    out[4 * r + 3] = (-L[3 * r + 0]) * t0 + ((-L[3 * r + 1]) * t1 + (-L[3 * r + 2]) * t2);
   }
 }
+
+/* exported for the tests (oracle_capi.affine_inverse) */
+void orc_affine_inverse_f32(const float m[12], float out[12]) { affine_inverse_f32(m, out); }
 
 /* PCP/src/PointCloudProcessor.cpp:495-519 (same at :186-194). */
 void orc_pose_to_matrices(const orc_pose *pose, const double *T_opt, float w2c[12], float c2w[12]) {
@@ -237,6 +248,13 @@ static inline void project_one(const orc_camera *cam, const orc_cull_params *cp,
   o->range = sqrt((X * X + Y * Y) + Z * Z);
   double u, v;
   orc_project_point(cam, X, Y, Z, &u, &v);
+  /* A4' hidden_points_removal's candidate filter, view_culling.cpp:284-288:
+   * project(p).cast<int>() against the full image_size; no map, reported as -2 */
+  if (cp->cull_mode == ORC_CULL_HPR_CANDIDATES) {
+    int32_t ui, vi;
+    if (trunc_d(u, &ui) && trunc_d(v, &vi) && ui >= 0 && ui < cam->cull_width && vi >= 0 && vi < cam->cull_height)
+      o->cell = -2;
+  } else
   /* A4 cell */
   {
     const float ds = (float)cp->downsample_factor;
@@ -327,9 +345,13 @@ static void depth_pass(const orc_camera *cam, const orc_cull_params *cp, const f
  * !(dist > (double)map + 0.05); without depth-buffer culling every candidate
  * (cell >= 0 or -2) is kept (:92-93, indices.emplace_back). */
 static inline int keep_rule(const orc_cull_params *cp, const projected *p, const float *map) {
-  if (!cp->enable_depth_buffer_culling) return p->cell != -1;
+  if (!cp->enable_depth_buffer_culling || cp->cull_mode == ORC_CULL_HPR_CANDIDATES) return p->cell != -1;
   if (p->cell < 0) return 0;
   return !(p->range > (double)map[p->cell] + cp->depth_slack);
+}
+
+static inline int zbuf_on(const orc_cull_params *cp) {
+  return cp->enable_depth_buffer_culling && cp->cull_mode == ORC_CULL_ZBUFFER;
 }
 
 int64_t orc_cull_frame(const orc_camera *cam, const orc_cull_params *cp, const float w2c[12], const float *x,
@@ -338,7 +360,10 @@ int64_t orc_cull_frame(const orc_camera *cam, const orc_cull_params *cp, const f
   const int nt = threads == 1 ? 1 : resolve_threads(threads);
   const int64_t cells = (int64_t)(cam->cull_width / cp->downsample_factor) * (cam->cull_height / cp->downsample_factor);
   float *map = depth_map ? depth_map : (float *)malloc((size_t)(cells > 0 ? cells : 1) * sizeof(float));
-  depth_pass(cam, cp, w2c, x, y, z, n, map, nt);
+  if (zbuf_on(cp))
+    depth_pass(cam, cp, w2c, x, y, z, n, map, nt);
+  else
+    depth_map_fill(map, cells);
   int64_t kept = 0;
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static) num_threads(nt) reduction(+ : kept)
@@ -379,6 +404,41 @@ void orc_scores(float xc, float yc, float zc, const orc_pose *pose, float *orien
   if (orientation) *orientation = o;
   if (distance) *distance = d;
   if (final_score) *final_score = (float)((double)(o + d) / 2.0);
+}
+
+/* ------------------------------------------------------------------ */
+/* A6 / B3: the reference's camera -> world -> camera round trip        */
+/* ------------------------------------------------------------------ */
+
+/* kdtree.radiusSearch(searchPoint, epsilon) with `const float epsilon = 1e-5`
+ * (PCP/src/PointCloudProcessor.cpp:482,571): pcl::KdTreeFLANN::radiusSearch takes the
+ * radius as double and hands FLANN static_cast<float>(radius * radius) [upstream PCL 1.10
+ * kdtree_flann.hpp]. */
+static inline float match_radius_sq(void) {
+  const double eps = (double)1e-5f;
+  return (float)(eps * eps);
+}
+
+/* flann::L2_Simple<float> [upstream FLANN 1.9.1 dist.h]: result = 0; result += diff*diff per
+ * dimension, fp32; a point is reported iff dist < radius (strict). */
+static inline float l2_simple_f32(float ax, float ay, float az, float bx, float by, float bz) {
+  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  float r = dx * dx;
+  r += dy * dy;
+  r += dz * dz;
+  return r;
+}
+
+/* PCP/src/PointCloudProcessor.cpp:578-579: Eigen::Vector4f ptCamera =
+ * transformation_c2w_optimized.inverse() * ptWorld.  [upstream Eigen 3.3.7 Transform.h]
+ * Affine * 4-vector = T.affine() (3x4 block, column-major) * v: a coefficient-based
+ * product whose rows have no packet access, so each coefficient is a 4-term fp32 sum
+ * through Redux.h's redux_novec_unroller<0,4>: (p0 + p1) + (p2 + p3), p3 = m3 * 1.0f. */
+static inline void affine_times_point_eigen(const float m[12], float x, float y, float z, float *ox, float *oy,
+                                            float *oz) {
+  *ox = (m[0] * x + m[1] * y) + (m[2] * z + m[3] * 1.0f);
+  *oy = (m[4] * x + m[5] * y) + (m[6] * z + m[7] * 1.0f);
+  *oz = (m[8] * x + m[9] * y) + (m[10] * z + m[11] * 1.0f);
 }
 
 /* ------------------------------------------------------------------ */
@@ -465,10 +525,12 @@ int orc_colorize(const orc_camera *cam, const orc_cull_params *cp, const float *
     }
   }
   for (int32_t f = 0; f < n_frames; ++f) { /* PCP/src/PointCloudProcessor.cpp:488 */
-    float w2c[12], c2w[12];
+    float w2c[12], c2w[12], c2w_inv[12];
     const double *T = T_opt ? T_opt + (int64_t)T_opt_stride * f : NULL;
     orc_pose_to_matrices(&poses[f], T, w2c, c2w);
-    if (cp->enable_depth_buffer_culling) depth_pass(cam, cp, w2c, x, y, z, n, map, nt);
+    affine_inverse_f32(c2w, c2w_inv); /* transformation_c2w_optimized.inverse(), :578 */
+    const float r2 = match_radius_sq();
+    if (zbuf_on(cp)) depth_pass(cam, cp, w2c, x, y, z, n, map, nt);
     const uint8_t *img = images[f];
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static) num_threads(nt)
@@ -480,9 +542,16 @@ int orc_colorize(const orc_camera *cam, const orc_cull_params *cp, const float *
       if (p.pixel < 0) continue;             /* generateColorMap bounds, :748-754 */
       const uint8_t *px = img + (int64_t)p.pixel * 3; /* BGR, :760-762 */
       const uint32_t rgb = ((uint32_t)px[2] << 16) | ((uint32_t)px[1] << 8) | (uint32_t)px[0];
+      float sx = p.xc, sy = p.yc, sz = p.zc;
+      if (cp->match_mode == ORC_MATCH_ROUNDTRIP) {
+        float wx, wy, wz;
+        xform_point(c2w, p.xc, p.yc, p.zc, &wx, &wy, &wz);            /* :555 */
+        if (!(l2_simple_f32(wx, wy, wz, x[i], y[i], z[i]) < r2)) continue; /* :571: point i does not find itself */
+        affine_times_point_eigen(c2w_inv, wx, wy, wz, &sx, &sy, &sz);  /* :578-579 */
+      }
       float fs;
-      orc_scores(p.xc, p.yc, p.zc, &poses[f], NULL, NULL, &fs); /* :584-588 */
-      top5_insert(&state[i], fs, rgb, f);                      /* :590-591 */
+      orc_scores(sx, sy, sz, &poses[f], NULL, NULL, &fs); /* :584-588 */
+      top5_insert(&state[i], fs, rgb, f);                /* :590-591 */
     }
   }
 #ifdef _OPENMP
@@ -508,6 +577,184 @@ int orc_colorize(const orc_camera *cam, const orc_cull_params *cp, const float *
   return 0;
 }
 
+/* ------------------------------------------------------------------ */
+/* B3 faithful mode: the reference's own match-back                     */
+/* ------------------------------------------------------------------ */
+
+/* Spatial hash over the map points for radiusSearch(1e-5): cells of 4e-5 m, so the ball
+ * of one query touches at most 2 cells per axis.  Stands in for pcl::KdTreeFLANN (exact
+ * search, eps = 0): the result SET of a radius search does not depend on the index
+ * structure, only on the distance functor and the strict comparison. */
+typedef struct cell_entry {
+  uint64_t key;
+  int32_t index;
+} cell_entry;
+
+static const double kMatchCell = 4e-5;
+
+static inline uint64_t cell_key(int64_t ix, int64_t iy, int64_t iz) {
+  /* 21 bits per axis after an offset of 2^20 cells (+-41.9 m at 4e-5 m); larger maps alias cells,
+   * which only costs extra distance tests */
+  const uint64_t m = (1ull << 21) - 1;
+  return (((uint64_t)(ix + (1 << 20)) & m) << 42) | (((uint64_t)(iy + (1 << 20)) & m) << 21) |
+         ((uint64_t)(iz + (1 << 20)) & m);
+}
+
+static int cmp_cell_entry(const void *a, const void *b) {
+  const cell_entry *x = (const cell_entry *)a, *y = (const cell_entry *)b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  return x->index < y->index ? -1 : (x->index > y->index);
+}
+
+typedef struct match {
+  float dist;
+  int32_t index;
+} match;
+
+static int cmp_match(const void *a, const void *b) {
+  const match *x = (const match *)a, *y = (const match *)b;
+  if (x->dist != y->dist) return x->dist < y->dist ? -1 : 1;
+  return x->index < y->index ? -1 : (x->index > y->index);
+}
+
+/* pcdColorizationAndSmooth exactly as PCP/src/PointCloudProcessor.cpp:474-602 runs it, with the
+ * z-buffer (or HPR-candidate) cull of cp: every kept and coloured sample goes to world coordinates in
+ * fp32 (:555), is matched back by radiusSearch(1e-5) over the ORIGINAL cloud (:571) -- to no point, to
+ * its own point, or to several points -- and every match receives the sample with scores computed from
+ * c2w.inverse() * p_w (:578-588).  Matches are visited in FLANN's sorted order (ascending distance).
+ * stats (nullable, 4 values): samples, samples without any match, samples whose own point is not among
+ * the matches, credits to points other than the sample's own. */
+int orc_colorize_faithful(const orc_camera *cam, const orc_cull_params *cp, const float *x, const float *y,
+                          const float *z, int64_t n, const orc_pose *poses, int32_t n_frames, const double *T_opt,
+                          int32_t T_opt_stride, const uint8_t *const *images, uint8_t *out_rgb, uint8_t *out_has,
+                          int32_t *out_count, float *out_top_score, uint32_t *out_top_rgb, int32_t *out_top_frame,
+                          int64_t *stats, int32_t threads) {
+  const int nt = threads == 1 ? 1 : resolve_threads(threads);
+  const int64_t cells = (int64_t)(cam->cull_width / cp->downsample_factor) * (cam->cull_height / cp->downsample_factor);
+  float *map = (float *)malloc((size_t)(cells > 0 ? cells : 1) * sizeof(float));
+  top5 *state = (top5 *)malloc((size_t)(n > 0 ? n : 1) * sizeof(top5));
+  cell_entry *grid = (cell_entry *)malloc((size_t)(n > 0 ? n : 1) * sizeof(cell_entry));
+  uint8_t *vis = (uint8_t *)malloc((size_t)(n > 0 ? n : 1));
+  if (!map || !state || !grid || !vis) {
+    free(map);
+    free(state);
+    free(grid);
+    free(vis);
+    return -1;
+  }
+  for (int64_t i = 0; i < n; ++i) {
+    state[i].count = 0;
+    for (int k = 0; k < ORC_TOPM; ++k) {
+      state[i].score[k] = -1.0f;
+      state[i].rgb[k] = 0;
+      state[i].frame[k] = -1;
+    }
+    grid[i].key = cell_key((int64_t)floor((double)x[i] / kMatchCell), (int64_t)floor((double)y[i] / kMatchCell),
+                           (int64_t)floor((double)z[i] / kMatchCell));
+    grid[i].index = (int32_t)i;
+  }
+  qsort(grid, (size_t)n, sizeof(cell_entry), cmp_cell_entry); /* kdtree.setInputCloud(cloud), :481 */
+  const float r2 = match_radius_sq();
+  const double reach = sqrt((double)r2) * 1.0001 + 1e-9; /* per-axis reach of the ball, padded */
+  int64_t st[4] = {0, 0, 0, 0};
+  for (int32_t f = 0; f < n_frames; ++f) {
+    float w2c[12], c2w[12], c2w_inv[12];
+    const double *T = T_opt ? T_opt + (int64_t)T_opt_stride * f : NULL;
+    orc_pose_to_matrices(&poses[f], T, w2c, c2w);
+    affine_inverse_f32(c2w, c2w_inv);
+    if (zbuf_on(cp)) depth_pass(cam, cp, w2c, x, y, z, n, map, nt);
+    const uint8_t *img = images[f];
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nt)
+#endif
+    for (int64_t i = 0; i < n; ++i) { /* cull + generateColorMap: which points are in coloredCloud */
+      projected p;
+      project_one(cam, cp, w2c, x[i], y[i], z[i], &p);
+      vis[i] = (uint8_t)(keep_rule(cp, &p, map) && p.pixel >= 0);
+    }
+    for (int64_t i = 0; i < n; ++i) { /* the loop at :559-594, in coloredCloudInWorld order */
+      if (!vis[i]) continue;
+      projected p;
+      project_one(cam, cp, w2c, x[i], y[i], z[i], &p);
+      const uint8_t *px = img + (int64_t)p.pixel * 3;
+      const uint32_t rgb = ((uint32_t)px[2] << 16) | ((uint32_t)px[1] << 8) | (uint32_t)px[0];
+      float wx, wy, wz;
+      xform_point(c2w, p.xc, p.yc, p.zc, &wx, &wy, &wz); /* :555 */
+      match found[64];
+      int nf = 0;
+      const int64_t x0 = (int64_t)floor(((double)wx - reach) / kMatchCell), x1 = (int64_t)floor(((double)wx + reach) / kMatchCell);
+      const int64_t y0 = (int64_t)floor(((double)wy - reach) / kMatchCell), y1 = (int64_t)floor(((double)wy + reach) / kMatchCell);
+      const int64_t z0 = (int64_t)floor(((double)wz - reach) / kMatchCell), z1 = (int64_t)floor(((double)wz + reach) / kMatchCell);
+      for (int64_t cx = x0; cx <= x1; ++cx)
+        for (int64_t cy = y0; cy <= y1; ++cy)
+          for (int64_t cz = z0; cz <= z1; ++cz) {
+            const uint64_t key = cell_key(cx, cy, cz);
+            int64_t lo = 0, hi = n;
+            while (lo < hi) {
+              const int64_t mid = (lo + hi) >> 1;
+              if (grid[mid].key < key)
+                lo = mid + 1;
+              else
+                hi = mid;
+            }
+            for (int64_t e = lo; e < n && grid[e].key == key; ++e) {
+              const int32_t j = grid[e].index;
+              const float d = l2_simple_f32(wx, wy, wz, x[j], y[j], z[j]);
+              if (d < r2 && nf < 64) {
+                int dup = 0; /* aliased cell keys could list a point twice */
+                for (int q = 0; q < nf; ++q) dup |= found[q].index == j;
+                if (!dup) {
+                  found[nf].dist = d;
+                  found[nf].index = j;
+                  ++nf;
+                }
+              }
+            }
+          }
+      st[0] += 1;
+      if (nf == 0) {
+        st[1] += 1;
+        st[2] += 1;
+        continue; /* radiusSearch(...) > 0 fails, :571 */
+      }
+      qsort(found, (size_t)nf, sizeof(match), cmp_match);
+      float sx, sy, sz;
+      affine_times_point_eigen(c2w_inv, wx, wy, wz, &sx, &sy, &sz); /* :578-579 */
+      float fs;
+      orc_scores(sx, sy, sz, &poses[f], NULL, NULL, &fs);
+      int self = 0;
+      for (int q = 0; q < nf; ++q) {
+        top5_insert(&state[found[q].index], fs, rgb, f); /* rgbCloud.addPointData(pointIndex, ...), :591 */
+        if (found[q].index == (int32_t)i)
+          self = 1;
+        else
+          st[3] += 1;
+      }
+      if (!self) st[2] += 1;
+    }
+  }
+  for (int64_t i = 0; i < n; ++i) {
+    uint8_t rgb[3];
+    top5_finalise(&state[i], rgb);
+    out_rgb[3 * i + 0] = rgb[0];
+    out_rgb[3 * i + 1] = rgb[1];
+    out_rgb[3 * i + 2] = rgb[2];
+    if (out_has) out_has[i] = (uint8_t)(rgb[0] != 0 || rgb[1] != 0 || rgb[2] != 0);
+    if (out_count) out_count[i] = state[i].count;
+    for (int k = 0; k < ORC_TOPM; ++k) {
+      if (out_top_score) out_top_score[ORC_TOPM * i + k] = state[i].score[k];
+      if (out_top_rgb) out_top_rgb[ORC_TOPM * i + k] = state[i].rgb[k];
+      if (out_top_frame) out_top_frame[ORC_TOPM * i + k] = state[i].frame[k];
+    }
+  }
+  if (stats) memcpy(stats, st, sizeof(st));
+  free(map);
+  free(state);
+  free(grid);
+  free(vis);
+  return 0;
+}
+
 /* generateColorMap + generateSegmentMap + transform to world,
  * PCP/src/PointCloudProcessor.cpp:531-551,743-766,783-815. */
 int64_t orc_frame_visible(const orc_camera *cam, const orc_cull_params *cp, const orc_pose *pose,
@@ -518,7 +765,7 @@ int64_t orc_frame_visible(const orc_camera *cam, const orc_cull_params *cp, cons
   orc_pose_to_matrices(pose, T_opt, w2c, c2w);
   const int64_t cells = (int64_t)(cam->cull_width / cp->downsample_factor) * (cam->cull_height / cp->downsample_factor);
   float *map = (float *)malloc((size_t)(cells > 0 ? cells : 1) * sizeof(float));
-  if (cp->enable_depth_buffer_culling) depth_pass(cam, cp, w2c, x, y, z, n, map, 1);
+  if (zbuf_on(cp)) depth_pass(cam, cp, w2c, x, y, z, n, map, 1);
   int64_t m = 0;
   for (int64_t i = 0; i < n; ++i) {
     projected p;
@@ -561,6 +808,82 @@ int64_t orc_frame_visible(const orc_camera *cam, const orc_cull_params *cp, cons
   }
   free(map);
   return m;
+}
+
+/* ------------------------------------------------------------------ */
+/* f4: generateColorMap's 8-bit BGR -> HSV -> BGR round trip            */
+/* ------------------------------------------------------------------ */
+
+/* PCP/src/PointCloudProcessor.cpp:722-741: cv::cvtColor(rgb, hsv, COLOR_BGR2HSV); S and V times
+ * saturation_scale / brightness_scale (1.0, :728-729) through saturate_cast<uchar>;
+ * cv::cvtColor(hsv, out, COLOR_HSV2BGR).  [upstream OpenCV 4.2.0 (osrf/ros:noetic),
+ * imgproc/src/color_hsv.simd.hpp: RGB2HSV_b (integer, exact) and HSV2RGB_b -> HSV2RGB_native, the
+ * scalar fp32 routine without FMA; OpenCV's SIMD build of the backward half re-associates
+ * (v - v*s instead of v*(1 - s)) and may differ by one level on some pixels: parity unpinned.]
+ * cvRound = round half to even (lrint under the default rounding mode). */
+static inline uint8_t sat_u8_f(float x) {
+  long v = lrintf(x);
+  return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+void orc_hsv_round_trip(const uint8_t *bgr_in, uint8_t *bgr_out, int64_t n_pixels, float saturation_scale,
+                        float brightness_scale) {
+  enum { hsv_shift = 12 };
+  int sdiv_table[256], hdiv_table180[256];
+  sdiv_table[0] = hdiv_table180[0] = 0;
+  for (int i = 1; i < 256; i++) {
+    sdiv_table[i] = (int)lrint((255 << hsv_shift) / (1. * i));
+    hdiv_table180[i] = (int)lrint((180 << hsv_shift) / (6. * i));
+  }
+  static const int sector_data[][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+  const float hscale = 6.f / 180.f;
+  for (int64_t k = 0; k < n_pixels; ++k) {
+    /* RGB2HSV_b::operator(), blueIdx = 0, hrange = 180 */
+    const int b = bgr_in[3 * k + 0], g = bgr_in[3 * k + 1], r = bgr_in[3 * k + 2];
+    int h, s, v = b, vmin = b, vr, vg;
+    if (g > v) v = g;
+    if (r > v) v = r;
+    if (g < vmin) vmin = g;
+    if (r < vmin) vmin = r;
+    const int diff = v - vmin; /* saturate_cast<uchar>(v - vmin): already in range */
+    vr = v == r ? -1 : 0;
+    vg = v == g ? -1 : 0;
+    s = (diff * sdiv_table[v] + (1 << (hsv_shift - 1))) >> hsv_shift;
+    h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+    h = (h * hdiv_table180[diff] + (1 << (hsv_shift - 1))) >> hsv_shift;
+    h += h < 0 ? 180 : 0;
+    const uint8_t H = (uint8_t)(h < 0 ? 0 : (h > 255 ? 255 : h));
+    /* :733-734 */
+    const uint8_t S = sat_u8_f((float)(uint8_t)s * saturation_scale);
+    const uint8_t V = sat_u8_f((float)(uint8_t)v * brightness_scale);
+    /* HSV2RGB_b: buf = {h, s/255, v/255}; HSV2RGB_native */
+    float fh = (float)H;
+    const float fs = (float)S * (1.0f / 255.0f), fv = (float)V * (1.0f / 255.0f);
+    float fb, fg, fr;
+    if (fs == 0) {
+      fb = fg = fr = fv;
+    } else {
+      float tab[4];
+      fh *= hscale;
+      fh = fmodf(fh, 6.f);
+      int sector = (int)floorf(fh);
+      fh -= (float)sector;
+      if ((unsigned)sector >= 6u) {
+        sector = 0;
+        fh = 0.f;
+      }
+      tab[0] = fv;
+      tab[1] = fv * (1.f - fs);
+      tab[2] = fv * (1.f - fs * fh);
+      tab[3] = fv * (1.f - fs * (1.f - fh));
+      fb = tab[sector_data[sector][0]];
+      fg = tab[sector_data[sector][1]];
+      fr = tab[sector_data[sector][2]];
+    }
+    bgr_out[3 * k + 0] = sat_u8_f(fb * 255.0f);
+    bgr_out[3 * k + 1] = sat_u8_f(fg * 255.0f);
+    bgr_out[3 * k + 2] = sat_u8_f(fr * 255.0f);
+  }
 }
 
 /* ------------------------------------------------------------------ */

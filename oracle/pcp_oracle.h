@@ -41,10 +41,17 @@ typedef struct orc_camera {
 } orc_camera;
 
 /* PCP/include/vlcal/calib/view_culling.hpp:10-19, view_culling.cpp:63,157 */
+#define ORC_CULL_ZBUFFER 0        /* ViewCulling::view_culling, view_culling.cpp:52-174 */
+#define ORC_CULL_HPR_CANDIDATES 1 /* candidate filter of hidden_points_removal, view_culling.cpp:276-288, keep all */
+#define ORC_MATCH_IDENTITY 0      /* Appendix B3: the sample of point i goes to point i, scores from p_c */
+#define ORC_MATCH_ROUNDTRIP 1     /* fp32 world round trip + the 10 um self-match test + scores from
+                                     c2w.inverse() * p_w (PointCloudProcessor.cpp:555,571-579), no cross-credit */
 typedef struct orc_cull_params {
   int32_t enable_depth_buffer_culling; /* ref: true */
   int32_t downsample_factor;           /* ref: 14 */
   double depth_slack;                  /* ref: 0.05 */
+  int32_t cull_mode;                   /* ORC_CULL_* */
+  int32_t match_mode;                  /* ORC_MATCH_* (orc_colorize; orc_colorize_faithful ignores it) */
 } orc_cull_params;
 
 /* PCP/include/cloudSmooth.hpp:21-36, values PCP/src/PointCloudProcessor.cpp:67-86 */
@@ -111,6 +118,19 @@ int orc_colorize(const orc_camera *cam, const orc_cull_params *cp, const float *
                  int32_t *out_count, float *out_top_score, uint32_t *out_top_rgb, int32_t *out_top_frame,
                  int32_t threads);
 
+/* The same with the reference's own match-back (Appendix B3 "faithful mode"): fp32 world round trip,
+ * radiusSearch(1e-5) over the original cloud (every match is credited, including other points and
+ * none at all), scores from c2w.inverse() * p_w.  stats (nullable): {samples, without any match,
+ * own point not matched, credits to other points}. */
+int orc_colorize_faithful(const orc_camera *cam, const orc_cull_params *cp, const float *x, const float *y,
+                          const float *z, int64_t n, const orc_pose *poses, int32_t n_frames, const double *T_opt,
+                          int32_t T_opt_stride, const uint8_t *const *images, uint8_t *out_rgb, uint8_t *out_has,
+                          int32_t *out_count, float *out_top_score, uint32_t *out_top_rgb, int32_t *out_top_frame,
+                          int64_t *stats, int32_t threads);
+
+/* Eigen Transform<float,3,Affine>::inverse() of a 3x4 row-major fp32 matrix (tests) */
+void orc_affine_inverse_f32(const float m[12], float out[12]);
+
 /* A5 mask branch + per-frame visible list (generateColorMap + generateSegmentMap,
  * cpp:531-551).  For one frame: for every kept & coloured point, in input order,
  * emits index, rgb (after the 255 -> (255,0,0) override when mask given), mask
@@ -131,6 +151,11 @@ int64_t orc_mls(const float *x, const float *y, const float *z, int64_t n, const
 int64_t orc_mls_voxel_dilation(const float *x, const float *y, const float *z, int64_t n,
                                const orc_mls_params *p, int64_t capacity, float *out_xyz, float *out_normal,
                                float *out_curv, int32_t *out_index);
+
+/* f4: the 8-bit BGR -> HSV -> BGR round trip of generateColorMap (PCP/src/PointCloudProcessor.cpp:722-741),
+ * OpenCV 4.2 arithmetic [upstream]: n_pixels tightly packed BGR8 pixels in, the adjusted pixels out. */
+void orc_hsv_round_trip(const uint8_t *bgr_in, uint8_t *bgr_out, int64_t n_pixels, float saturation_scale,
+                        float brightness_scale);
 
 /* keyframe rule, PCP/include/PointCloudProcessor.hpp:151-191, cpp:1050-1075 */
 int32_t orc_select_keyframes(const orc_pose *poses, int32_t n, double dist_threshold, int32_t *out_indices);

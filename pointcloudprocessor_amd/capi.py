@@ -47,7 +47,13 @@ class CullParams(C.Structure):
         ("enable_depth_buffer_culling", C.c_int32),
         ("downsample_factor", C.c_int32),
         ("depth_slack", C.c_double),
+        ("cull_mode", C.c_int32),   # CULL_ZBUFFER / CULL_HPR_CANDIDATES
+        ("match_mode", C.c_int32),  # MATCH_IDENTITY / MATCH_ROUNDTRIP
     ]
+
+
+CULL_ZBUFFER, CULL_HPR_CANDIDATES = 0, 1
+MATCH_IDENTITY, MATCH_ROUNDTRIP = 0, 1
 
 
 class MLSParams(C.Structure):
@@ -244,6 +250,19 @@ class Context:
         assert bgr.dtype == np.uint8 and bgr.flags.c_contiguous
         assert bgr.shape == (self.camera.image_height, self.camera.image_width, 3), bgr.shape
         self._check(self.lib.pcp_upload_image_async(self.h, C.c_int32(frame), _ptr(bgr), C.c_int64(bgr.strides[0])))
+
+    def set_image_adjust(self, enable: bool = True, saturation_scale: float = 1.0, brightness_scale: float = 1.0):
+        """generateColorMap's 8-bit BGR -> HSV -> BGR round trip applied to the images uploaded from now on."""
+        self._check(self.lib.pcp_set_image_adjust(self.h, C.c_int32(1 if enable else 0), C.c_float(saturation_scale),
+                                                  C.c_float(brightness_scale)))
+
+    def download_image(self, frame: int):
+        """(bgr (H, W, 3), mask (H, W)) of one keyframe as the kernels sample it."""
+        hh, ww = self.camera.image_height, self.camera.image_width
+        bgr = np.empty((hh, ww, 3), np.uint8)
+        mask = np.empty((hh, ww), np.uint8)
+        self._check(self.lib.pcp_download_image(self.h, C.c_int32(frame), _ptr(bgr), _ptr(mask)))
+        return bgr, mask
 
     def upload_mask(self, frame: int, gray: np.ndarray):
         gray = np.ascontiguousarray(gray, np.uint8)

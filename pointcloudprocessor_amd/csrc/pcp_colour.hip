@@ -7,7 +7,7 @@
 // Data layout in HBM
 //   cloud        SoA fp32 x[n] y[n] z[n] (12 B/point), twice: input order for the
 //                per-keyframe calls, Morton order for the batched run
-//   frames       DevFrame[F], 128 B each, read through the scalar cache
+//   frames       DevFrame[F], 192 B each, read through the scalar cache
 //   images       uint32 per pixel  B | G<<8 | R<<16 | mask<<24  (one gather
 //                fetches colour and segmentation mask)
 //   depth maps   uint32[F][mh*mw], the bit pattern of a positive fp32 range:
@@ -21,6 +21,7 @@
 #include <cstdlib>
 
 #include "pcp_device.hpp"
+#include "pcp_hsv.hpp"
 
 namespace pcp {
 
@@ -488,12 +489,13 @@ __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict_
         const uint32_t dbits = cam.enable_zbuf ? depth[static_cast<int64_t>(f) * cells + p.cell] : 0u;
         // texel = B | G<<8 | R<<16 | mask<<24; its low 24 bits are 0x00RRGGBB (PointCloudProcessor.cpp:760-762)
         const uint32_t texel = images[static_cast<int64_t>(f) * image_px + p.pixel];
-        const float s = final_score(p.xc, p.yc, p.zc, fr.px, fr.py, fr.pz);
         // A4 keep rule (view_culling.cpp:135-171)
         bool keep = true;
         if (cam.enable_zbuf)
           keep = !(range64(p.xc, p.yc, p.zc) > static_cast<double>(__uint_as_float(dbits)) + cam.slack);
-        if (keep) t.insert(s, texel & 0xffffffu, f);
+        float sx = p.xc, sy = p.yc, sz = p.zc;
+        if (cam.match_mode == PCP_MATCH_ROUNDTRIP && keep) keep = roundtrip_sample(cam, fr, px, py, pz, sx, sy, sz);
+        if (keep) t.insert(final_score(sx, sy, sz, fr.px, fr.py, fr.pz), texel & 0xffffffu, f);
       }
     }
   }
@@ -606,14 +608,19 @@ __global__ __launch_bounds__(kBlock) void k_scatter_u32(const uint32_t *__restri
 }
 
 // BGR8 rows -> packed texels, keeping the mask byte
+// hsv_tables != nullptr: generateColorMap's 8-bit BGR -> HSV -> BGR round trip on the way (pcp_hsv.hpp)
 __global__ __launch_bounds__(kBlock) void k_pack_bgr(const uint8_t *__restrict__ bgr, int64_t row_stride, int32_t w,
-                                                     int32_t h, uint32_t *__restrict__ texels, int32_t clear_mask) {
+                                                     int32_t h, uint32_t *__restrict__ texels, int32_t clear_mask,
+                                                     const int32_t *__restrict__ hsv_tables, float sat_scale,
+                                                     float val_scale) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (i >= static_cast<int64_t>(w) * h) return;
   const int32_t v = static_cast<int32_t>(i / w), u = static_cast<int32_t>(i - static_cast<int64_t>(v) * w);
   const uint8_t *p = bgr + static_cast<int64_t>(v) * row_stride + 3 * u;
   const uint32_t keep = clear_mask ? 0u : (texels[i] & 0xff000000u);
-  texels[i] = keep | p[0] | (static_cast<uint32_t>(p[1]) << 8) | (static_cast<uint32_t>(p[2]) << 16);
+  uint32_t b = p[0], g = p[1], r = p[2];
+  if (hsv_tables) hsv_round_trip(hsv_tables, hsv_tables + 256, sat_scale, val_scale, b, g, r);
+  texels[i] = keep | b | (g << 8) | (r << 16);
 }
 
 __global__ __launch_bounds__(kBlock) void k_pack_mask(const uint8_t *__restrict__ gray, int64_t row_stride, int32_t w,
@@ -920,7 +927,9 @@ static int upload_image_impl(pcp_context *ctx, const char *who, int32_t frame, c
   {
     LaunchTimer t(ctx, PCP_K_MISC);
     hipLaunchKernelGGL(k_pack_bgr, dim3(blocks_for(px)), dim3(kBlock), 0, ctx->stream, ctx->s_keep.p, row_stride_bytes,
-                       w, h, ctx->images.p + static_cast<int64_t>(frame) * px, ctx->mask_set[frame] ? 0 : 1);
+                       w, h, ctx->images.p + static_cast<int64_t>(frame) * px, ctx->mask_set[frame] ? 0 : 1,
+                       ctx->adjust_images ? ctx->hsv_tables.p : static_cast<const int32_t *>(nullptr),
+                       ctx->saturation_scale, ctx->brightness_scale);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   if (wait) PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the host buffer may be reused by the caller
@@ -934,6 +943,48 @@ int pcp_upload_image(pcp_context *ctx, int32_t frame, const uint8_t *bgr, int64_
 
 int pcp_upload_image_async(pcp_context *ctx, int32_t frame, const uint8_t *bgr, int64_t row_stride_bytes) {
   return upload_image_impl(ctx, "pcp_upload_image_async", frame, bgr, row_stride_bytes, false);
+}
+
+int pcp_set_image_adjust(pcp_context *ctx, int32_t enable, float saturation_scale, float brightness_scale) {
+  if (!ctx) return PCP_ERR_INVALID;
+  if (!(saturation_scale >= 0.0f) || !(brightness_scale >= 0.0f))
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_set_image_adjust: scales must be >= 0");
+  PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (enable && !ctx->hsv_tables.p) {
+    int32_t tab[512];
+    hsv_build_tables(tab, tab + 256);
+    PCP_HIP_TRY(ctx, ctx->hsv_tables.ensure(512));
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->hsv_tables.p, tab, sizeof(tab), hipMemcpyHostToDevice, ctx->stream));
+    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `tab` lives on this stack frame
+  }
+  ctx->adjust_images = enable != 0;
+  ctx->saturation_scale = saturation_scale;
+  ctx->brightness_scale = brightness_scale;
+  return PCP_OK;
+}
+
+int pcp_download_image(pcp_context *ctx, int32_t frame, uint8_t *out_bgr, uint8_t *out_mask) {
+  int rc = check_ready(ctx, "pcp_download_image", true);
+  if (rc != PCP_OK) return rc;
+  if ((rc = check_frame(ctx, "pcp_download_image", frame)) != PCP_OK) return rc;
+  if (!ctx->images.p || !(ctx->image_set[static_cast<size_t>(frame)] || ctx->mask_set[static_cast<size_t>(frame)]))
+    return set_error(ctx, PCP_ERR_STATE, "pcp_download_image: nothing uploaded for keyframe %d", frame);
+  const int32_t w = ctx->dcam.img_w, h = ctx->dcam.img_h;
+  const size_t px = static_cast<size_t>(w) * h;
+  std::vector<uint32_t> texels(px);
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(texels.data(), ctx->images.p + static_cast<int64_t>(frame) * static_cast<int64_t>(px),
+                                  px * 4, hipMemcpyDeviceToHost, ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < px; ++i) {
+    const uint32_t t = texels[i];
+    if (out_bgr) {
+      out_bgr[3 * i + 0] = static_cast<uint8_t>(t & 0xffu);
+      out_bgr[3 * i + 1] = static_cast<uint8_t>((t >> 8) & 0xffu);
+      out_bgr[3 * i + 2] = static_cast<uint8_t>((t >> 16) & 0xffu);
+    }
+    if (out_mask) out_mask[i] = static_cast<uint8_t>(t >> 24);
+  }
+  return PCP_OK;
 }
 
 int pcp_upload_mask(pcp_context *ctx, int32_t frame, const uint8_t *gray, int64_t row_stride_bytes) {

@@ -95,23 +95,26 @@ static void rotation_from_quaternion(const pcp_pose &p, double R[3][3]) {
   R[2][2] = 1.0 - (txx + tyy);
 }
 
-// Eigen Transform<float,3,Affine>::inverse(): cofactor inverse of the linear part
-// and -L^-1 t, all fp32 (PointCloudProcessor.cpp:509,518).
+// Eigen Transform<float,3,Affine>::inverse(): [L^-1 | -L^-1 t], all fp32 (PointCloudProcessor.cpp:509,518,578).
+// Eigen 3.3.7 LU/InverseImpl.h compute_inverse<3>: cofactor_3x3<i,j> = m(i1,j1) m(i2,j2) - m(i1,j2) m(i2,j1),
+// det = (cofactors_col0 .* m.col(0)).sum(), inverse(j,i) = cofactor<i,j> / det; a 3-term fp32 sum has no SSE
+// packet and goes through Redux.h's scalar unroller as p0 + (p1 + p2); the translation is the coefficient-based
+// product (-L^-1) * t with the same 3-term sums.
 static void invert_affine_f32(const float in[12], float out[12]) {
   const float a = in[0], b = in[1], c = in[2];
   const float d = in[4], e = in[5], f = in[6];
   const float g = in[8], h = in[9], i = in[10];
-  const float k00 = e * i - f * h, k01 = f * g - d * i, k02 = d * h - e * g;
-  const float det = (a * k00 + b * k01) + c * k02;
+  const float k00 = e * i - f * h, k10 = h * c - i * b, k20 = b * f - c * e;  // cofactors of column 0
+  const float det = k00 * a + (k10 * d + k20 * g);
   const float inv = 1.0f / det;
-  const float L[3][3] = {{k00 * inv, (c * h - b * i) * inv, (b * f - c * e) * inv},
-                         {k01 * inv, (a * i - c * g) * inv, (c * d - a * f) * inv},
-                         {k02 * inv, (b * g - a * h) * inv, (a * e - b * d) * inv}};
+  const float L[3][3] = {{k00 * inv, k10 * inv, k20 * inv},
+                         {(f * g - d * i) * inv, (i * a - g * c) * inv, (c * d - a * f) * inv},
+                         {(d * h - e * g) * inv, (g * b - h * a) * inv, (a * e - b * d) * inv}};
   for (int r = 0; r < 3; ++r) {
     out[4 * r + 0] = L[r][0];
     out[4 * r + 1] = L[r][1];
     out[4 * r + 2] = L[r][2];
-    out[4 * r + 3] = -((L[r][0] * in[3] + L[r][1] * in[7]) + L[r][2] * in[11]);
+    out[4 * r + 3] = (-L[r][0]) * in[3] + ((-L[r][1]) * in[7] + (-L[r][2]) * in[11]);
   }
 }
 
@@ -553,6 +556,7 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->perm.release();
   ctx->frames.release();
   ctx->images.release();
+  ctx->hsv_tables.release();
   ctx->depth.release();
   ctx->tile_sphere.release();
   ctx->tile_mask.release();
@@ -817,6 +821,8 @@ int pcp_set_frames(pcp_context *ctx, const pcp_pose *poses, int32_t n_frames, co
     DevFrame &d = ctx->hframes[static_cast<size_t>(f)];
     const double *T = T_opt ? T_opt + static_cast<int64_t>(T_opt_stride) * f : nullptr;
     matrices_from_pose(poses[f], T, d.w2c, d.c2w);
+    invert_affine_f32(d.c2w, d.c2w_inv);  // transformation_c2w_optimized.inverse(), PointCloudProcessor.cpp:578
+    d.pad_[0] = d.pad_[1] = d.pad_[2] = d.pad_[3] = 0.0f;
     d.px = poses[f].x;
     d.py = poses[f].y;
     d.pz = poses[f].z;

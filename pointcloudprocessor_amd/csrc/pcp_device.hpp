@@ -202,8 +202,33 @@ __device__ __forceinline__ bool keep_rule(const DevCamera &c, const Projected &p
   return !(r > lim);
 }
 
+// B3: what the reference does to a coloured sample before scoring it (PointCloudProcessor.cpp:555,571-579).
+//   p_w  = transformPointCloud(c2w) p_c            fp32, PCL SSE association (:555)
+//   kdtree.radiusSearch(p_w, 1e-5) over the ORIGINAL cloud: flann::L2_Simple<float> distance
+//          ((dx^2 + dy^2) + dz^2, fp32), reported iff < f32(1e-5^2) -- evaluated here for the sample's own map
+//          point (wx0, wy0, wz0), which is the one match the reference finds unless map points lie < ~20 um apart
+//   p_c' = c2w.inverse() * (p_w, 1)                Eigen 3.3.7 Affine3f * Vector4f: per row a 4-term fp32 sum
+//          split 2 + 2 by Redux.h's scalar unroller: (m0 x + m1 y) + (m2 z + m3 * 1)
+// Returns false when the point does not find itself (the reference then drops the sample); else (xc, yc, zc)
+// become p_c'.
+__device__ __forceinline__ bool roundtrip_sample(const DevCamera &c, const DevFrame &fr, float wx0, float wy0, float wz0,
+                                                 float &xc, float &yc, float &zc) {
+  float wx, wy, wz;
+  xform(fr.c2w, xc, yc, zc, wx, wy, wz);
+  const float dx = wx - wx0, dy = wy - wy0, dz = wz - wz0;
+  float d2 = dx * dx;
+  d2 += dy * dy;
+  d2 += dz * dz;
+  if (!(d2 < c.match_r2)) return false;
+  const float *m = fr.c2w_inv;
+  xc = (m[0] * wx + m[1] * wy) + (m[2] * wz + m[3]);
+  yc = (m[4] * wx + m[5] * wy) + (m[6] * wz + m[7]);
+  zc = (m[8] * wx + m[9] * wy) + (m[10] * wz + m[11]);
+  return true;
+}
+
 // A6 scores: computeOrientationScore hpp:205-220 (B4 reproduced),
-// computeDistanceScore hpp:222-236, final cpp:588 (identity mode, B3).
+// computeDistanceScore hpp:222-236, final cpp:588; (xc, yc, zc) is p_c (PCP_MATCH_IDENTITY) or p_c' (PCP_MATCH_ROUNDTRIP).
 __device__ __forceinline__ float final_score(float xc, float yc, float zc, double px, double py, double pz) {
   const double dx = static_cast<double>(xc) - px;
   const double dy = static_cast<double>(yc) - py;

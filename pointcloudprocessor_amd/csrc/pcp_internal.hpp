@@ -48,14 +48,17 @@ struct DevCamera {
 
 // One keyframe: w2c / c2w 3x4 row-major fp32 (A1), the pose translation used by
 // computeOrientationScore (hpp:207, B4) and an upper bound of the spectral norm of
-// w2c's linear part (tile culling).  128 B so a frame is two cache lines.
+// w2c's linear part (tile culling), and c2w.inverse() as the reference recomputes it in fp32 for every
+// match (PointCloudProcessor.cpp:578).  192 B: three 64-B scalar-cache lines.
 struct DevFrame {
   float w2c[12];
   float c2w[12];
   double px, py, pz;
   double norm_bound;
+  float c2w_inv[12];
+  float pad_[4];
 };
-static_assert(sizeof(DevFrame) == 128, "DevFrame layout");
+static_assert(sizeof(DevFrame) == 192, "DevFrame layout");
 
 // Per-point top-5 state, SoA over points: score[k][n], rgb[k][n], frame[k][n], count[n].
 constexpr int kTopM = 5;  // PointCloudProcessor.cpp:615
@@ -120,6 +123,10 @@ struct pcp_context {
   pcp::DevBuf<pcp::DevFrame> frames;
   pcp::DevBuf<uint32_t> images;  // n_frames * img_h * img_w  (B | G<<8 | R<<16 | mask<<24)
   std::vector<uint8_t> image_set, mask_set;
+  // generateColorMap's 8-bit BGR -> HSV -> BGR round trip, fused into the pack kernel (pcp_set_image_adjust)
+  bool adjust_images = false;
+  float saturation_scale = 1.0f, brightness_scale = 1.0f;
+  pcp::DevBuf<int32_t> hsv_tables;  // sdiv_table[256], hdiv_table180[256] (OpenCV RGB2HSV_b)
 
   // depth maps [n_frames][mh*mw] as uint view of positive floats
   pcp::DevBuf<uint32_t> depth;

@@ -12,8 +12,9 @@
 //   * images are decoded by host/image_io.hpp: <images_folder><ts>.jpg (baseline JPEG, libjpeg's
 //     arithmetic, bit-exact with Pillow / libjpeg-turbo here) and masks <mask_folder><ts>.png;
 //     <ts>.ppm / <ts>.pgm are accepted when the .jpg / .png is absent.
-//   * the 8-bit BGR->HSV->BGR round trip of generateColorMap (:722-741, Appendix B5) is
-//     not applied (pixels are taken as already adjusted).
+//   * the 8-bit BGR->HSV->BGR round trip of generateColorMap (:722-741, Appendix B5) is applied by the
+//     library while it packs the decoded image (pcp_set_image_adjust: OpenCV 4.2's integer forward routine
+//     exactly, its scalar float backward routine); the NID stage reads the raw pixels, as calibrate.cpp does.
 //   * --enableNIDOptimize runs the NID cost on the GPU with a BFGS on SE(3) in place of
 //     ceres::Solve (same cost, gradient, domain limits and outer loop; not Ceres' line search).
 //   * --enableInitialGuessManual is accepted and rejected with an exception (exit -2): the
@@ -126,7 +127,8 @@ class Processor {
   XYZICloud cloud;
   std::unique_ptr<Device> gpu;
   int img_w = 0, img_h = 0;
-  bool images_uploaded = false;
+  bool images_uploaded = false, images_adjusted = false;
+  std::vector<uint8_t> mask_missing;
   std::vector<double> T_camera_lidar_optimized;
 
   void loadImagesAndOdometry() {  // :965-1005
@@ -261,7 +263,7 @@ class Processor {
 
   void applyNIDBasedPoseOptimization() {  // :156-164 -> calibrate.cpp:42-126
     gpu->uploadIntensity(cloud.intensity.data(), static_cast<int64_t>(cloud.size()));
-    uploadImages();
+    uploadImages(false);  // VisualLiDARCalibration reads the images itself, without generateColorMap's adjustment
     VisualLiDARCalibration calib(*gpu);
     double cost = 0.0;
     T_camera_lidar_optimized = calib.calibrate(&cost);
@@ -307,8 +309,10 @@ class Processor {
     }
   }
 
-  void uploadImages() {
-    if (images_uploaded) return;
+  void uploadImages(bool adjusted) {
+    if (images_uploaded && images_adjusted == adjusted) return;
+    gpu->setImageAdjust(adjusted);  // cvtColor(BGR2HSV) ... cvtColor(HSV2BGR), :722-741, fused into the upload
+    mask_missing.assign(keyframes.size(), 0);
     for (size_t k = 0; k < keyframes.size(); ++k) {
       std::cout << "Reading image from: " << keyframes[k].imagePath << std::endl;
       const Image8 img = read_image_bgr(keyframes[k].imagePath);  // cv::imread, :716
@@ -321,14 +325,15 @@ class Processor {
         if (!gray.empty() && gray.width == img_w && gray.height == img_h)
           gpu->uploadMask(static_cast<int>(k), gray.data.data(), gray.width);
         else
-          std::cout << "Failed to read image from: " << keyframes[k].maskImagePath << std::endl;  // :779, not fatal
+          mask_missing[k] = 1;  // generateSegmentMap logs it and returns an empty cloud, :776-781
       }
     }
     images_uploaded = true;
+    images_adjusted = adjusted;
   }
 
   void pcdColorizationAndSmooth() {  // :474-602
-    uploadImages();
+    uploadImages(true);
     Colorizer col(*gpu);
     std::vector<float> wx, wy, wz;  // cloudInWorldWithRGBandMask
     std::vector<float> wxyz;
@@ -336,7 +341,11 @@ class Processor {
     std::vector<uint16_t> wmask;
     if (enableMaskSegmentation) {
       for (size_t k = 0; k < keyframes.size(); ++k) {
-        const VisiblePoints v = col.frameVisible(static_cast<int>(k));
+        VisiblePoints v;
+        if (mask_missing[k])  // :779-780: message, empty scanInBodyWithRGBandMask -> PCDWriter throws below (exit -2)
+          std::cout << "Failed to read image from: " << keyframes[k].maskImagePath << std::endl;
+        else
+          v = col.frameVisible(static_cast<int>(k));
         const std::string path =
             opt.outputPath + "filtered_pcd/" + std::to_string(keyframes[k].imageTimestamp) + "_rgb-mask" + ".pcd";
         if (writeASCII_XYZRGBMask(path, v.xyz_cam.data(), v.rgb.data(), v.mask.data(), v.index.size()) == -1)

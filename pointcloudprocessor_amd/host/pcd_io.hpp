@@ -282,6 +282,10 @@ inline std::string header(const char *fields, const char *sizes, const char *typ
 // PCDWriter::writeASCII formats one value at a time on one thread and dominates its runs at scale).
 template <class Row>
 inline int write_rows(const std::string &path, const std::string &head, size_t n, size_t bytes_per_row_hint, Row row) {
+  // pcl::PCDWriter::writeASCII (PCL 1.10 pcd_io.hpp) throws pcl::IOException on an empty cloud before touching the
+  // file; PCLException's what() is ": <description>" when no file / function / line is attached.  The reference's
+  // main catches it and exits with -2 (main.cpp:64-68) -- e.g. a keyframe whose mask image is missing.
+  if (n == 0) throw std::runtime_error(": [pcl::PCDWriter::writeASCII] Input point cloud has no data!");
   unsigned threads = std::thread::hardware_concurrency();
   if (const char *e = std::getenv("PCP_WRITER_THREADS")) threads = static_cast<unsigned>(std::max(1, std::atoi(e)));
   threads = std::max(1u, std::min(threads, 32u));

@@ -49,7 +49,13 @@ class Device {
   void setKeyframes(const std::vector<pcp_pose> &poses, const double *T_opt = nullptr, int T_opt_stride = 0) {
     check(pcp_set_frames(ctx_, poses.data(), static_cast<int32_t>(poses.size()), T_opt, T_opt_stride));
   }
-  // cv::Mat rgb (CV_8UC3, after the HSV round trip): data, step
+  // generateColorMap's cvtColor(BGR2HSV) -> S, V scaling -> cvtColor(HSV2BGR) (PointCloudProcessor.cpp:722-741) done
+  // by the library while it packs an uploaded image: enable it and hand over cv::imread's pixels, or leave it off
+  // and hand over `adjusted_image`
+  void setImageAdjust(bool enable, float saturation_scale = 1.0f, float brightness_scale = 1.0f) {
+    check(pcp_set_image_adjust(ctx_, enable ? 1 : 0, saturation_scale, brightness_scale));
+  }
+  // cv::Mat rgb (CV_8UC3; after the HSV round trip unless setImageAdjust(true)): data, step
   void uploadImage(int keyframe, const uint8_t *bgr, int64_t step) { check(pcp_upload_image(ctx_, keyframe, bgr, step)); }
   // decoded frames in pinned memory: queues the copy only; the buffer must outlive the next synchronising call
   void uploadImageAsync(int keyframe, const uint8_t *bgr, int64_t step) { check(pcp_upload_image_async(ctx_, keyframe, bgr, step)); }
@@ -99,19 +105,25 @@ class Colorizer {
     has.resize(n);
     dev_.check(pcp_colorize(dev_.get(), rgb.data(), has.data()));
   }
+  // one cull per keyframe: the outputs are sized for the whole cloud (the library writes only the first `count`
+  // records of each) and shrunk afterwards
   VisiblePoints frameVisible(int keyframe) const {
-    int64_t m = 0;
-    dev_.check(pcp_frame_visible(dev_.get(), keyframe, 0, nullptr, nullptr, nullptr, nullptr, nullptr, &m));
+    const size_t n = static_cast<size_t>(dev_.cloudSize());
     VisiblePoints v;
+    v.index.resize(n);
+    v.rgb.resize(3 * n);
+    v.mask.resize(n);
+    v.xyz_cam.resize(3 * n);
+    v.xyz_world.resize(3 * n);
+    int64_t m = 0;
+    dev_.check(pcp_frame_visible(dev_.get(), keyframe, static_cast<int64_t>(n), v.index.data(), v.rgb.data(), v.mask.data(),
+                                 v.xyz_cam.data(), v.xyz_world.data(), &m));
     const size_t sm = static_cast<size_t>(m);
     v.index.resize(sm);
     v.rgb.resize(3 * sm);
     v.mask.resize(sm);
     v.xyz_cam.resize(3 * sm);
     v.xyz_world.resize(3 * sm);
-    if (m > 0)
-      dev_.check(pcp_frame_visible(dev_.get(), keyframe, m, v.index.data(), v.rgb.data(), v.mask.data(), v.xyz_cam.data(),
-                                   v.xyz_world.data(), &m));
     return v;
   }
 

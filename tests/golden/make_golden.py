@@ -80,8 +80,9 @@ def main():
     # g3: HPR (the cull that is ACTIVE in the reference) on the same points, frame 0
     w2c, _ = npo.pose_to_matrices(poses[0])
     hpr = npo.hpr_frame(cam, w2c, x, y, z)
+    cand, _ = npo.hpr_candidates(cam, w2c, x, y, z)  # the filter in front of qhull (view_culling.cpp:276-288)
     save("g3_hpr.npz", camera=cam_array(cam), pose=poses[0], x=x, y=y, z=z, visible=hpr.astype(np.int32),
-         zbuffer_keep=np.nonzero(keeps[0])[0].astype(np.int32))
+         zbuffer_keep=np.nonzero(keeps[0])[0].astype(np.int32), candidates=np.nonzero(cand)[0].astype(np.int32))
 
     # g4: 6-keyframe colour run, procedural images
     imgs = [synth.make_image(f, cam["image_width"], cam["image_height"], seed=5) for f in range(6)]
@@ -89,6 +90,24 @@ def main():
     save("g4_colour.npz", camera=cam_array(cam), poses=poses, x=x, y=y, z=z, images=np.array(imgs), rgb=col["rgb"],
          has=col["has"], count=col["count"], top_score=col["top_score"], top_rgb=col["top_rgb"],
          top_frame=col["top_frame"])
+
+    # g4b: the reference's own match-back (Appendix B3 faithful mode) on g4's scene, and on a variant built to make
+    # it differ from index identity: the map moved 150 m away (fp32 ulp 15 um > the 10 um match radius: samples get
+    # lost) with 300 points duplicated 4 um beside their originals (cross-credits).  Inputs of (a) are g4's.
+    fa = npo.colorize_faithful(cam, x, y, z, poses, imgs)
+    xs = (x.astype(np.float64) + 150.0).astype(np.float32)
+    dup = np.random.default_rng(4242).choice(len(x), 300, replace=False)  # own generator: g5+ keep their streams
+    xs2 = np.concatenate([xs, xs[dup]])
+    ys2 = np.concatenate([y, (y[dup].astype(np.float64) + 4e-6).astype(np.float32)])
+    zs2 = np.concatenate([z, z[dup]])
+    poses_s = poses.copy()
+    poses_s[:, 0] += 150.0
+    fs = npo.colorize_faithful(cam, xs2, ys2, zs2, poses_s, imgs)
+    st = lambda d: np.array([d["stats"][k] for k in ("samples", "unmatched", "self_missed", "cross_credits")], np.int64)
+    save("g4b_faithful.npz", rgb=fa["rgb"], has=fa["has"], count=fa["count"], top_score=fa["top_score"],
+         top_rgb=fa["top_rgb"], top_frame=fa["top_frame"], stats=st(fa),
+         far_x=xs2, far_y=ys2, far_z=zs2, far_poses=poses_s, far_rgb=fs["rgb"], far_has=fs["has"], far_count=fs["count"],
+         far_top_score=fs["top_score"], far_top_rgb=fs["top_rgb"], far_top_frame=fs["top_frame"], far_stats=st(fs))
 
     # g5: MLS on plane / sphere / saddle patches
     n = 700

@@ -253,6 +253,8 @@ def test_cli_end_to_end_matches_oracle(tmp_path, oracle):
     cam.image_width, cam.image_height = W, H  # cull size stays 4096x3000
     cp = oracle.default_cull_params()
     kposes = poses[keys]
+    # generateColorMap samples the image AFTER its 8-bit BGR -> HSV -> BGR round trip (:722-741)
+    imgs = {k: oracle.hsv_round_trip(im) for k, im in imgs.items()}
     ref = oracle.colorize(cam, cp, x, y, z, kposes, [imgs[k] for k in keys], threads=8)
     header, rows = _read_pcd_ascii(tmp_path / "cloudInWorldWithRGB.pcd")
     assert header["FIELDS"] == ["x", "y", "z", "rgb"] and header["TYPE"] == ["F", "F", "F", "U"]
@@ -275,10 +277,19 @@ def test_cli_end_to_end_matches_oracle(tmp_path, oracle):
         assert h3["FIELDS"] == ["x", "y", "z", "rgb", "segmentMask"] and len(r3) == len(vis["index"])
         if len(r3):
             assert np.array_equal(np.array([int(r[4]) for r in r3]), vis["mask"])
+            want = (vis["rgb"][:, 0].astype(np.uint64) << 16) | (vis["rgb"][:, 1].astype(np.uint64) << 8) | vis["rgb"][:, 2]
+            assert np.array_equal(np.array([int(r[3]) for r in r3], dtype=np.uint64) & 0xFFFFFF, want)
     h4, r4 = _read_pcd_ascii(tmp_path / "cloudInWorldWithRGBandMask.pcd")
     total = sum(len(oracle.frame_visible(cam, cp, poses[k], x, y, z, imgs[k], masks[k])["index"]) for k in keys)
     assert len(r4) == total
     assert (tmp_path / "scans-crop.pcd").exists()
+    # a keyframe whose mask image is missing: generateSegmentMap logs it and leaves the cloud empty (:776-781), and
+    # pcl::PCDWriter::writeASCII throws on an empty cloud -> the reference exits with -2 (main.cpp:64-68)
+    os.remove(tmp_path / ("%f.png" % ts[keys[1]]))
+    p = subprocess.run([_exe(), "-p", str(tmp_path / "scans.pcd"), "-o", str(tmp_path / "odo.txt"), "-i", out, "-m", out,
+                        "-t", out], capture_output=True, text=True)
+    assert p.returncode == 254 and "Input point cloud has no data" in p.stderr
+    assert "Failed to read image from: " + out + ("%f.png" % ts[keys[1]]) in p.stdout
 
 
 @pytest.mark.gpu
@@ -308,6 +319,7 @@ def test_cli_with_nid_refinement(tmp_path, oracle):
     assert np.allclose(T[:3, :3] @ T[:3, :3].T, np.eye(3), atol=1e-9)
     cam = oracle.default_camera()
     cam.image_width, cam.image_height = W, H
+    imgs = [oracle.hsv_round_trip(im) for im in imgs]  # the colour path samples the adjusted image; the NID stage did not
     ref = oracle.colorize(cam, oracle.default_cull_params(), x, y, z, poses, imgs, T_opt=T, threads=8, want_top=False)
     header, rows = _read_pcd_ascii(tmp_path / "cloudInWorldWithRGB.pcd")
     sel = np.nonzero(ref["has"])[0]

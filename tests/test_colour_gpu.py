@@ -369,3 +369,41 @@ def test_tail_workgroup_with_dead_wavefronts(gpu_ctx_factory, oracle, small_scen
     assert ref["has"].sum() > 100
     _colour_close(got["rgb"], ref)
     assert np.array_equal(got["has"] > 0, ref["has"] > 0)
+
+
+@pytest.mark.parametrize("cull_mode,match_mode", [(1, 0), (0, 1), (1, 1)])
+def test_hpr_candidates_and_roundtrip_modes_match_oracle(gpu_ctx_factory, oracle, small_scene, cull_mode, match_mode):
+    """PCP_CULL_HPR_CANDIDATES (view_culling.cpp:276-288) and PCP_MATCH_ROUNDTRIP (PointCloudProcessor.cpp:555,
+    571-579): keep masks, per-keyframe visible lists and the whole colour run against the oracle in the same modes --
+    everything bit-equal, scores included."""
+    from pointcloudprocessor_amd import capi
+
+    ctx = gpu_ctx_factory()
+    cull = capi.default_cull_params()
+    cull.cull_mode, cull.match_mode = cull_mode, match_mode
+    cd = _setup(ctx, capi, small_scene, cull=cull, with_masks=True)
+    ocam, ocp = cam_struct(oracle, cd), oracle.default_cull_params()
+    ocp.cull_mode, ocp.match_mode = cull_mode, match_mode
+    s = small_scene
+    for f in (0, 4):
+        w2c, _ = oracle.pose_to_matrices(s["poses"][f])
+        keep_r, _, kept_r = oracle.cull_frame(ocam, ocp, w2c, s["x"], s["y"], s["z"])
+        keep_g, _, kept_g = ctx.cull_frame(f)
+        assert np.array_equal(keep_g, keep_r) and kept_g == kept_r > 100
+        ref = oracle.frame_visible(ocam, ocp, s["poses"][f], s["x"], s["y"], s["z"], s["images"][f], s["masks"][f])
+        got = ctx.frame_visible(f)
+        for k in ("index", "rgb", "mask", "xyz_cam", "xyz_world"):
+            assert np.array_equal(got[k], ref[k]), (f, k)
+    ref = oracle.colorize(ocam, ocp, s["x"], s["y"], s["z"], s["poses"], s["images"])
+    ctx.colour_reset()
+    ctx.depth_pass()
+    ctx.colour_pass()
+    got = ctx.colour_finalise(want_top=True)
+    for k in ("count", "top_frame", "top_rgb", "top_score", "rgb", "has"):
+        assert np.array_equal(got[k], ref[k]), k
+    one = ctx.colorize()
+    assert np.array_equal(one["rgb"], ref["rgb"])
+    if cull_mode == 1:  # no occlusion test: more samples than the z-buffer run
+        zb = oracle.colorize(ocam, oracle.default_cull_params(), s["x"], s["y"], s["z"], s["poses"], s["images"],
+                             want_top=False)
+        assert ref["count"].sum() > zb["count"].sum()
