@@ -68,8 +68,9 @@ typedef struct pcp_camera {
                               a handful on near-collinear ones ("HPR"). */
 
 /* How a visible sample is credited to map points (pcp_cull_params.match_mode), PointCloudProcessor.cpp:554-592. */
-#define PCP_MATCH_IDENTITY 0 /* the sample of point i is credited to point i, scores from the transform output p_c */
-#define PCP_MATCH_ROUNDTRIP 1 /* the reference's arithmetic: p_w = c2w p_c in fp32 (:555), the sample is dropped unless
+#define PCP_MATCH_IDENTITY 0 /* the sample of point i is credited to point i, scores from the transform output p_c
+                              (SURVEY.md Appendix B3 "identity mode"; ~2 % faster steps) */
+#define PCP_MATCH_ROUNDTRIP 1 /* (default) the reference's arithmetic: p_w = c2w p_c in fp32 (:555), the sample is dropped unless
                               |p_w - p_i|^2 < f32(1e-5^2) in fp32 (what radiusSearch(1e-5) tests for point i itself,
                               :571), scores from p_c' = c2w.inverse() p_w in fp32 (:578-579).  Samples that the
                               reference's kd-tree would ALSO credit to other map points closer than 10 um to p_w are
@@ -82,7 +83,7 @@ typedef struct pcp_cull_params {
   int32_t downsample_factor;
   double depth_slack;
   int32_t cull_mode;  /* PCP_CULL_ZBUFFER (default) / PCP_CULL_HPR_CANDIDATES */
-  int32_t match_mode; /* PCP_MATCH_IDENTITY (default) / PCP_MATCH_ROUNDTRIP */
+  int32_t match_mode; /* PCP_MATCH_ROUNDTRIP (default) / PCP_MATCH_IDENTITY */
 } pcp_cull_params;
 
 /* MLSParameters, PCP/include/cloudSmooth.hpp:21-36; values

@@ -184,23 +184,40 @@ def scores(xc, yc, zc, pose):
 
 # --------------------------------------------------------------------------- A8
 def colorize(cam: dict, x, y, z, poses, images, ds: int = 14, slack: float = 0.05, enable_zbuffer: bool = True,
-             T_opt=None):
-    """Collect-all + stable sort (the reference's shape, cpp:590-591,604-631)."""
+             T_opt=None, roundtrip: bool = False):
+    """Collect-all + stable sort (the reference's shape, cpp:590-591,604-631).  roundtrip: the reference's fp32
+    world round trip, 10 um self-match test and scores from c2w.inverse() p_w (cpp:555,571-579) instead of the
+    identity mode of Appendix B3 (no neighbour search: see colorize_faithful for that)."""
     n = len(x)
+    x, y, z = (np.asarray(a, f32) for a in (x, y, z))
+    eps = f64(f32(1e-5))
+    r2 = f32(eps * eps)
     lists = [[] for _ in range(n)]
     for f, pose in enumerate(poses):
         T = None
         if T_opt is not None:
             T = np.asarray(T_opt, f64).reshape(-1, 16)
             T = T[f if len(T) > 1 else 0]
-        w2c, _ = pose_to_matrices(pose, T)
+        w2c, c2w = pose_to_matrices(pose, T)
         keep, _, p = cull_frame(cam, w2c, x, y, z, ds, slack, enable_zbuffer)
         sel = np.nonzero(keep & (p["pixel"] >= 0))[0]
         if len(sel) == 0:
             continue
+        sx, sy, sz = p["xc"][sel], p["yc"][sel], p["zc"][sel]
+        if roundtrip:
+            wx, wy, wz = transform(c2w, sx, sy, sz)
+            dx, dy, dz = wx - x[sel], wy - y[sel], wz - z[sel]
+            d = dx * dx
+            d = d + dy * dy
+            d = d + dz * dz
+            found = d < r2
+            sel, wx, wy, wz = sel[found], wx[found], wy[found], wz[found]
+            if len(sel) == 0:
+                continue
+            sx, sy, sz = affine_times_point_eigen(affine_inverse_f32(c2w), wx, wy, wz)
         img = np.asarray(images[f], np.uint8).reshape(-1, 3)
         bgr = img[p["pixel"][sel]]
-        _, _, fin = scores(p["xc"][sel], p["yc"][sel], p["zc"][sel], pose)
+        _, _, fin = scores(sx, sy, sz, pose)
         for k, i in enumerate(sel):
             lists[i].append((float(fin[k]), int(bgr[k, 2]), int(bgr[k, 1]), int(bgr[k, 0]), f))
     rgb = np.zeros((n, 3), np.uint8)

@@ -43,7 +43,7 @@ void orc_default_cull_params(orc_cull_params *p) {
   p->downsample_factor = 14;
   p->depth_slack = 0.05;
   p->cull_mode = ORC_CULL_ZBUFFER;
-  p->match_mode = ORC_MATCH_IDENTITY;
+  p->match_mode = ORC_MATCH_ROUNDTRIP;
 }
 
 /* PCP/src/PointCloudProcessor.cpp:67-86 */

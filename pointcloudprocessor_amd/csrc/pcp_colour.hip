@@ -797,6 +797,22 @@ static int ensure_images(pcp_context *ctx) {
   return PCP_OK;
 }
 
+int wait_images(pcp_context *ctx, int32_t f0, int32_t f1) {
+  ctx->texels_touched = true;
+  if (ctx->image_pending.empty()) return PCP_OK;
+  // the upload stream is in order: waiting for the range's most recently queued keyframe covers the others
+  int32_t last = -1;
+  for (int32_t f = std::max(f0, 0); f < f1 && f < static_cast<int32_t>(ctx->image_pending.size()); ++f)
+    if (ctx->image_pending[static_cast<size_t>(f)] && (last < 0 || ctx->image_seq[static_cast<size_t>(f)] > ctx->image_seq[static_cast<size_t>(last)]))
+      last = f;
+  if (last < 0) return PCP_OK;
+  PCP_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->image_event[static_cast<size_t>(last)], 0));
+  const uint64_t seq = ctx->image_seq[static_cast<size_t>(last)];
+  for (size_t f = 0; f < ctx->image_pending.size(); ++f)
+    if (ctx->image_pending[f] && ctx->image_seq[f] <= seq) ctx->image_pending[f] = 0;
+  return PCP_OK;
+}
+
 // counting sort of the tiles by ctx->tile_work, heaviest first, into `order`
 static int sort_tiles_by_work(pcp_context *ctx, int32_t *order) {
   PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->work_hist.p, 0, 2 * kWorkBins * sizeof(int32_t), ctx->stream));
@@ -910,6 +926,9 @@ using namespace pcp;
 
 extern "C" {
 
+// Both forms run on the upload stream: copy into the staging buffer, pack kernel (with the HSV round trip when
+// pcp_set_image_adjust enabled it), event.  `bgr` may be a host pointer (pinned for a real overlap) or a device
+// pointer (hipMemcpyDefault: e.g. frames all-gathered over xGMI by the multi-GPU driver).
 static int upload_image_impl(pcp_context *ctx, const char *who, int32_t frame, const uint8_t *bgr, int64_t row_stride_bytes,
                              bool wait) {
   int rc = check_ready(ctx, who, true);
@@ -918,21 +937,45 @@ static int upload_image_impl(pcp_context *ctx, const char *who, int32_t frame, c
   const int32_t w = ctx->dcam.img_w, h = ctx->dcam.img_h;
   if (!bgr || row_stride_bytes < 3 * static_cast<int64_t>(w))
     return set_error(ctx, PCP_ERR_INVALID, "%s: NULL image or row stride < 3*width", who);
+  const bool fresh = ctx->images.count < static_cast<size_t>(w) * h * static_cast<size_t>(ctx->n_frames) + 4;
   if ((rc = ensure_images(ctx)) != PCP_OK) return rc;
-  const size_t bytes = static_cast<size_t>(row_stride_bytes) * h;
-  PCP_HIP_TRY(ctx, ctx->s_keep.ensure(bytes + 16));
-  // one staging buffer is enough: the stream is in order, so the next copy starts after this image's pack
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->s_keep.p, bgr, bytes, hipMemcpyHostToDevice, ctx->stream));
-  const int64_t px = static_cast<int64_t>(w) * h;
-  {
-    LaunchTimer t(ctx, PCP_K_MISC);
-    hipLaunchKernelGGL(k_pack_bgr, dim3(blocks_for(px)), dim3(kBlock), 0, ctx->stream, ctx->s_keep.p, row_stride_bytes,
-                       w, h, ctx->images.p + static_cast<int64_t>(frame) * px, ctx->mask_set[frame] ? 0 : 1,
-                       ctx->adjust_images ? ctx->hsv_tables.p : static_cast<const int32_t *>(nullptr),
-                       ctx->saturation_scale, ctx->brightness_scale);
-    PCP_HIP_TRY(ctx, hipGetLastError());
+  if (!ctx->upload_stream) {
+    PCP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
+    PCP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->texels_idle, hipEventDisableTiming));
   }
-  if (wait) PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the host buffer may be reused by the caller
+  const size_t nf = static_cast<size_t>(ctx->n_frames);
+  if (ctx->image_event.size() < nf) {
+    const size_t old = ctx->image_event.size();
+    ctx->image_event.resize(nf, nullptr);
+    for (size_t k = old; k < nf; ++k) PCP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->image_event[k], hipEventDisableTiming));
+  }
+  if (ctx->image_pending.size() != nf) {
+    ctx->image_pending.assign(nf, 0);
+    ctx->image_seq.assign(nf, 0);
+  }
+  // kernels of the compute stream that read or write texels (a colour pass still sampling the previous image of this
+  // keyframe, a mask pack, the clearing of a fresh buffer) come first
+  if (fresh || ctx->texels_touched) {
+    PCP_HIP_TRY(ctx, hipEventRecord(ctx->texels_idle, ctx->stream));
+    PCP_HIP_TRY(ctx, hipStreamWaitEvent(ctx->upload_stream, ctx->texels_idle, 0));
+    ctx->texels_touched = false;
+  }
+  const size_t bytes = static_cast<size_t>(row_stride_bytes) * h;
+  PCP_HIP_TRY(ctx, ctx->upload_stage.ensure(bytes + 16));
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->upload_stage.p, bgr, bytes, hipMemcpyDefault, ctx->upload_stream));
+  const int64_t px = static_cast<int64_t>(w) * h;
+  hipLaunchKernelGGL(k_pack_bgr, dim3(blocks_for(px)), dim3(kBlock), 0, ctx->upload_stream, ctx->upload_stage.p,
+                     row_stride_bytes, w, h, ctx->images.p + static_cast<int64_t>(frame) * px, ctx->mask_set[frame] ? 0 : 1,
+                     ctx->adjust_images ? ctx->hsv_tables.p : static_cast<const int32_t *>(nullptr),
+                     ctx->saturation_scale, ctx->brightness_scale);
+  PCP_HIP_TRY(ctx, hipGetLastError());
+  PCP_HIP_TRY(ctx, hipEventRecord(ctx->image_event[static_cast<size_t>(frame)], ctx->upload_stream));
+  ctx->image_pending[static_cast<size_t>(frame)] = 1;
+  ctx->image_seq[static_cast<size_t>(frame)] = ++ctx->upload_seq;
+  if (wait) {  // the host buffer may be reused by the caller; nothing is left pending
+    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->upload_stream));
+    std::fill(ctx->image_pending.begin(), ctx->image_pending.end(), uint8_t(0));
+  }
   ctx->image_set[static_cast<size_t>(frame)] = 1;
   return PCP_OK;
 }
@@ -969,6 +1012,7 @@ int pcp_download_image(pcp_context *ctx, int32_t frame, uint8_t *out_bgr, uint8_
   if ((rc = check_frame(ctx, "pcp_download_image", frame)) != PCP_OK) return rc;
   if (!ctx->images.p || !(ctx->image_set[static_cast<size_t>(frame)] || ctx->mask_set[static_cast<size_t>(frame)]))
     return set_error(ctx, PCP_ERR_STATE, "pcp_download_image: nothing uploaded for keyframe %d", frame);
+  if ((rc = wait_images(ctx, frame, frame + 1)) != PCP_OK) return rc;
   const int32_t w = ctx->dcam.img_w, h = ctx->dcam.img_h;
   const size_t px = static_cast<size_t>(w) * h;
   std::vector<uint32_t> texels(px);
@@ -995,9 +1039,10 @@ int pcp_upload_mask(pcp_context *ctx, int32_t frame, const uint8_t *gray, int64_
   if (!gray || row_stride_bytes < static_cast<int64_t>(w))
     return set_error(ctx, PCP_ERR_INVALID, "pcp_upload_mask: NULL mask or row stride < width");
   if ((rc = ensure_images(ctx)) != PCP_OK) return rc;
+  if ((rc = wait_images(ctx, frame, frame + 1)) != PCP_OK) return rc;  // the mask byte shares its word with the colour
   const size_t bytes = static_cast<size_t>(row_stride_bytes) * h;
   PCP_HIP_TRY(ctx, ctx->s_keep.ensure(bytes + 16));
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->s_keep.p, gray, bytes, hipMemcpyHostToDevice, ctx->stream));
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->s_keep.p, gray, bytes, hipMemcpyDefault, ctx->stream));
   const int64_t px = static_cast<int64_t>(w) * h;
   {
     LaunchTimer t(ctx, PCP_K_MISC);
@@ -1103,6 +1148,7 @@ int pcp_frame_visible(pcp_context *ctx, int32_t frame, int64_t capacity, int32_t
   if (out_count) *out_count = 0;
   if (n == 0) return PCP_OK;
   if ((rc = ensure_images(ctx)) != PCP_OK) return rc;
+  if ((rc = wait_images(ctx, frame, frame + 1)) != PCP_OK) return rc;
   if ((rc = single_frame_depth(ctx, frame)) != PCP_OK) return rc;
   const size_t plane = plane_of(ctx);
   PCP_HIP_TRY(ctx, ctx->s_keep.ensure(static_cast<size_t>(n) + 16));
@@ -1264,6 +1310,7 @@ static int colour_pass_impl(pcp_context *ctx, int32_t frame_begin, int32_t frame
       return set_error(ctx, PCP_ERR_STATE, "pcp_colour_pass: no image uploaded for keyframe %d", f);
   }
   if ((rc = ensure_state(ctx)) != PCP_OK) return rc;
+  if ((rc = wait_images(ctx, frame_begin, frame_end)) != PCP_OK) return rc;
   if (ctx->n == 0) return PCP_OK;
   if (frame_begin == frame_end) {
     if (one_shot && result) PCP_HIP_TRY(ctx, hipMemsetAsync(result, 0, static_cast<size_t>(ctx->n) * 4, ctx->stream));

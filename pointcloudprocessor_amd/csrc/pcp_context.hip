@@ -549,6 +549,14 @@ void pcp_destroy(pcp_context *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+  if (ctx->upload_stream) {
+    (void)hipStreamSynchronize(ctx->upload_stream);
+    (void)hipStreamDestroy(ctx->upload_stream);
+  }
+  for (auto e : ctx->image_event)
+    if (e) (void)hipEventDestroy(e);
+  if (ctx->texels_idle) (void)hipEventDestroy(ctx->texels_idle);
+  ctx->upload_stage.release();
   drain_timing(ctx);
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   ctx->xyz.release();
@@ -622,6 +630,8 @@ int pcp_set_stream(pcp_context *ctx, void *hip_stream) {
 
 int pcp_synchronize(pcp_context *ctx) {
   if (!ctx) return PCP_ERR_INVALID;
+  if (ctx->upload_stream) PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->upload_stream));
+  std::fill(ctx->image_pending.begin(), ctx->image_pending.end(), uint8_t(0));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
   ctx->copy_pending[0] = ctx->copy_pending[1] = false;
@@ -651,7 +661,7 @@ void pcp_default_cull_params(pcp_cull_params *p) {
   p->downsample_factor = 14;
   p->depth_slack = 0.05;
   p->cull_mode = PCP_CULL_ZBUFFER;
-  p->match_mode = PCP_MATCH_IDENTITY;
+  p->match_mode = PCP_MATCH_ROUNDTRIP;  // the reference's arithmetic (PointCloudProcessor.cpp:555,571-579); +2 % of a step
 }
 
 // PointCloudProcessor.cpp:67-86
@@ -761,6 +771,8 @@ int pcp_set_camera(pcp_context *ctx, const pcp_camera *cam, const pcp_cull_param
   if (const char *e = std::getenv("PCP_DISABLE_PRETEST")) d.pretest = (e[0] == '1') ? 0 : 1;
 
   ctx->have_camera = true;
+  if (ctx->upload_stream) (void)hipStreamSynchronize(ctx->upload_stream);  // uploads sized by the previous camera
+  std::fill(ctx->image_pending.begin(), ctx->image_pending.end(), uint8_t(0));
   // images / depth maps are sized by the camera: drop them
   ctx->image_set.assign(ctx->image_set.size(), 0);
   ctx->mask_set.assign(ctx->mask_set.size(), 0);
@@ -815,6 +827,8 @@ int pcp_set_frames(pcp_context *ctx, const pcp_pose *poses, int32_t n_frames, co
   if (T_opt && T_opt_stride != 0 && T_opt_stride != 16)
     return set_error(ctx, PCP_ERR_INVALID, "pcp_set_frames: T_opt_stride must be 0 (global) or 16 (per keyframe)");
   PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->upload_stream) PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->upload_stream));  // uploads of the previous keyframe set
+  std::fill(ctx->image_pending.begin(), ctx->image_pending.end(), uint8_t(0));
   ctx->poses.assign(poses, poses + n_frames);
   ctx->hframes.resize(static_cast<size_t>(n_frames));
   for (int32_t f = 0; f < n_frames; ++f) {

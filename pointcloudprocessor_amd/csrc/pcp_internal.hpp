@@ -123,6 +123,17 @@ struct pcp_context {
   pcp::DevBuf<pcp::DevFrame> frames;
   pcp::DevBuf<uint32_t> images;  // n_frames * img_h * img_w  (B | G<<8 | R<<16 | mask<<24)
   std::vector<uint8_t> image_set, mask_set;
+  // pcp_upload_image_async: its own stream (copies + pack kernels overlap the compute stream), one staging buffer
+  // (the stream is in order), an event per keyframe for the consumers, and an event of the compute stream that the
+  // next upload waits for when kernels that touch the texels were queued since the last one
+  hipStream_t upload_stream = nullptr;
+  pcp::DevBuf<uint8_t> upload_stage;
+  std::vector<hipEvent_t> image_event;   // per keyframe, recorded on upload_stream after its pack kernel
+  std::vector<uint8_t> image_pending;    // 1: the consumer has not yet made its stream wait for image_event[f]
+  std::vector<uint64_t> image_seq;       // queue position of the keyframe's latest upload
+  uint64_t upload_seq = 0;
+  hipEvent_t texels_idle = nullptr;      // recorded on the compute stream
+  bool texels_touched = false;           // compute-stream work on the texel buffer since the last wait
   // generateColorMap's 8-bit BGR -> HSV -> BGR round trip, fused into the pack kernel (pcp_set_image_adjust)
   bool adjust_images = false;
   float saturation_scale = 1.0f, brightness_scale = 1.0f;
@@ -224,6 +235,10 @@ struct LaunchTimer {
 };
 
 int drain_timing(pcp_context *ctx);
+
+// make ctx->stream wait for the asynchronous uploads of keyframes [f0, f1) that are still in flight, and note that
+// the compute stream is about to touch the texel buffer (pcp_colour.hip)
+int wait_images(pcp_context *ctx, int32_t f0, int32_t f1);
 
 // ordered compaction of a device byte-flag array (pcp_colour.hip): index list (nullable) + count
 int compact_flags(pcp_context *ctx, const uint8_t *flags, int64_t n, int32_t *out_index, int64_t capacity,

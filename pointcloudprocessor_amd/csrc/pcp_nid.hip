@@ -358,6 +358,10 @@ int pcp_nid_prepare(pcp_context *ctx, int64_t *out_points) {
     if (!ctx->images.p || !ctx->image_set[static_cast<size_t>(f)])
       return set_error(ctx, PCP_ERR_STATE, "pcp_nid_prepare: no image uploaded for keyframe %d", f);
   PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  {
+    const int rcw = pcp::wait_images(ctx, 0, ctx->n_frames);  // asynchronous uploads still in flight
+    if (rcw != PCP_OK) return rcw;
+  }
   const int64_t n = ctx->n;
   const size_t plane = (static_cast<size_t>(n) + 3) & ~size_t(3);
   PCP_HIP_TRY(ctx, ctx->s_cell.ensure(plane + 4));

@@ -151,9 +151,9 @@ def _rot_to_quat(R):
 
 
 def make_trajectory(n_frames: int, seed: int = SEED, spacing: float = 0.12):
-    """F poses (x,y,z,qw,qx,qy,qz) as the odometry file stores them: positions
-    rounded to 6 decimals, quaternions to 8 (make_vo_odom_for_fastlio.py:126);
-    timestamps (6 decimals).  Every pose passes the 0.1 m keyframe rule."""
+    """F poses (x,y,z,qw,qx,qy,qz) as the odometry file stores them: positions and
+    quaternions rounded to 8 decimals, timestamps to 6 (the producer's format,
+    PCP/scripts/make_vo_odom_for_fastlio.py:126).  Every pose passes the 0.1 m keyframe rule."""
     rng = np.random.Generator(np.random.PCG64(seed + 1))
     # fine sampling, then arc-length resampling
     ds = 1e-4
@@ -189,10 +189,22 @@ def make_trajectory(n_frames: int, seed: int = SEED, spacing: float = 0.12):
         down = np.cross(fwd, right)
         R = np.stack([right, down, fwd], axis=1)  # camera axes as world columns (x right, y down, z fwd)
         q = _rot_to_quat(R)
-        poses[i, :3] = np.round(pos[i], 6)
+        poses[i, :3] = np.round(pos[i], 8)
         poses[i, 3:] = np.round(q, 8)
     ts = np.round(1700000000.0 + 0.1 * np.arange(n_frames), 6)
     return poses, ts
+
+
+def odometry_line(t: float, pose) -> str:
+    """One line of vo_interpolated_odom.txt exactly as the reference's producer writes it
+    (PCP/scripts/make_vo_odom_for_fastlio.py:126): `ts x y z qw qx qy qz`, 6 / 8 decimals."""
+    return "%.6f %.8f %.8f %.8f %.8f %.8f %.8f %.8f\n" % (t, *[float(v) for v in pose])
+
+
+def write_odometry(path, ts, poses) -> None:
+    with open(path, "w") as f:
+        for t, p in zip(ts, poses):
+            f.write(odometry_line(t, p))
 
 
 # ---------------------------------------------------------------------------

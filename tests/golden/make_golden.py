@@ -130,7 +130,7 @@ def main():
     od_poses, ts = synth.make_trajectory(12, spacing=0.06)  # every second pose passes the 0.1 m rule
     lines = []
     for t, p_ in zip(ts, od_poses):
-        lines.append("%.6f %.6f %.6f %.6f %.8f %.8f %.8f %.8f" % (t, p_[0], p_[1], p_[2], p_[3], p_[4], p_[5], p_[6]))
+        lines.append(synth.odometry_line(t, p_).rstrip("\n"))
     key = [0]
     for i in range(1, len(od_poses)):
         if np.linalg.norm(od_poses[i, :3] - od_poses[key[-1], :3]) >= 0.1:

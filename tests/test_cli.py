@@ -121,7 +121,7 @@ def test_pcd_writer_format_roundtrip_cpu(tmp_path):
     poses, ts = synth.make_trajectory(3)
     with open(tmp_path / "odo.txt", "w") as f:
         for t, p in zip(ts, poses):
-            f.write("%.6f %.6f %.6f %.6f %.8f %.8f %.8f %.8f\n" % (t, *p))
+            f.write(synth.odometry_line(t, p))
             with open(tmp_path / ("%f.ppm" % t), "wb") as g:
                 g.write(b"P6\n4 2\n255\n" + bytes(24))
     out = str(tmp_path) + "/"
@@ -163,7 +163,7 @@ def test_binary_compressed_pcd_input_cpu(tmp_path):
             assert r[0] < 0.95 * r[1]  # the encoder found back references
         with open(d / "odo.txt", "w") as f:
             for t, p in zip(ts, poses):
-                f.write("%.6f %.6f %.6f %.6f %.8f %.8f %.8f %.8f\n" % (t, *p))
+                f.write(synth.odometry_line(t, p))
                 with open(d / ("%f.ppm" % t), "wb") as g:
                     g.write(b"P6\n4 2\n255\n" + bytes(24))
         out = str(d) + "/"
@@ -198,7 +198,7 @@ def test_threaded_ascii_writer_is_byte_identical_cpu(tmp_path):
     _write_pcd_binary(tmp_path / "scans.pcd", x, y, z, inten)
     with open(tmp_path / "odo.txt", "w") as f:
         for t, p in zip(ts, poses):
-            f.write("%.6f %.6f %.6f %.6f %.8f %.8f %.8f %.8f\n" % (t, *p))
+            f.write(synth.odometry_line(t, p))
             with open(tmp_path / ("%f.ppm" % t), "wb") as g:
                 g.write(b"P6\n4 2\n255\n" + bytes(24))
     out = str(tmp_path) + "/"
@@ -223,7 +223,7 @@ def test_cli_end_to_end_matches_oracle(tmp_path, oracle):
     imgs, masks = {}, {}
     with open(tmp_path / "odo.txt", "w") as f:
         for k, (t, p) in enumerate(zip(ts, poses)):
-            f.write("%.6f %.6f %.6f %.6f %.8f %.8f %.8f %.8f\n" % (t, *p))
+            f.write(synth.odometry_line(t, p))
             if k == 3:
                 continue  # no image for this pose: the frame is skipped (PointCloudProcessor.cpp:984-987)
             # the reference's inputs: <ts>.jpg and <ts>.png; the oracle gets the decoded pixels
@@ -305,7 +305,7 @@ def test_cli_with_nid_refinement(tmp_path, oracle):
     imgs = []
     with open(tmp_path / "odo.txt", "w") as f:
         for k, (t, p) in enumerate(zip(ts, poses)):
-            f.write("%.6f %.6f %.6f %.6f %.8f %.8f %.8f %.8f\n" % (t, *p))
+            f.write(synth.odometry_line(t, p))
             img = synth.make_image(k, W, H)
             imgs.append(img)
             with open(tmp_path / ("%f.ppm" % t), "wb") as g:

@@ -93,9 +93,10 @@ def test_g3_hpr_regenerates(oracle):
 def test_g4_colour_golden(oracle):
     g = load("g4_colour.npz")
     cam, _ = cam_from_array(oracle, g["camera"])
+    cp = oracle.default_cull_params()
+    cp.match_mode = oracle.MATCH_IDENTITY  # g4 is the identity-mode golden; the default (round trip) is pinned by g4b
     for threads in (1, 4):
-        r = oracle.colorize(cam, oracle.default_cull_params(), g["x"], g["y"], g["z"], g["poses"], list(g["images"]),
-                            threads=threads)
+        r = oracle.colorize(cam, cp, g["x"], g["y"], g["z"], g["poses"], list(g["images"]), threads=threads)
         for k in ("rgb", "has", "count", "top_score", "top_rgb", "top_frame"):
             assert np.array_equal(r[k], g[k]), (threads, k)
     assert g["has"].sum() > 200 and g["count"].max() >= 3
@@ -170,10 +171,12 @@ def test_c_and_numpy_twins_agree_on_fresh_data(oracle, small_scene):
         pn = npo.project_frame(cd, w2c_n, x, y, z)
         for k in ("cell", "pixel", "range", "xc", "yc", "zc"):
             assert np.array_equal(pc[k], pn[k]), k
-    rc = oracle.colorize(cam, cp, x, y, z, small_scene["poses"], small_scene["images"])
-    rn = npo.colorize(cd, x, y, z, small_scene["poses"], small_scene["images"])
-    for k in rc:
-        assert np.array_equal(rc[k], rn[k]), k
+    for mode in (oracle.MATCH_ROUNDTRIP, oracle.MATCH_IDENTITY):
+        cp.match_mode = mode
+        rc = oracle.colorize(cam, cp, x, y, z, small_scene["poses"], small_scene["images"])
+        rn = npo.colorize(cd, x, y, z, small_scene["poses"], small_scene["images"], roundtrip=mode == oracle.MATCH_ROUNDTRIP)
+        for k in rc:
+            assert np.array_equal(rc[k], rn[k]), (mode, k)
 
 
 # ---- analytic known answers ------------------------------------------------------
