@@ -4,25 +4,31 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the whole hot path (z-buffer MIN pass over every
-keyframe -> [all-reduce(MIN) of depth maps across point shards] -> visibility +
-colour + scores + top-5 + smoothColors -> packed colours on the host) over the
-synthetic scene of SURVEY.md 8(d).  Default workload: BASELINE.json configs[2]
-without the MLS leg timed inside the step (10 M points x 256 keyframes @
-1920x1080 per GPU; north_star quotes its targets on it); MLS throughput is
-reported beside it as "mls".  Inputs (cloud, poses, images) are resident in HBM
-before the timed region starts.  Multi-GPU: weak scaling, every rank owns its
-own 10 M-point slice of an N x 10 M map, keyframes and images replicated.
+A "step" is one pass of the whole hot path (tile masks + z-buffer MIN pass over every keyframe ->
+[all-reduce(MIN) of the depth maps across point shards] -> visibility + colour + scores + top-5 +
+smoothColors -> packed colours in pinned host memory) over the synthetic scene of SURVEY.md 8(d).
 
-One JSON line on rank 0.  `roofline` is the single-keyframe projection kernel
-(20 B per point: 12 read + 4 + 4 written), timed with hipEvents on the stream
-it is launched on (pcp_timing_*), one launch per keyframe.  `cpu_baseline` is
-the oracle (CPU restatement, OpenMP, all host cores) on a bounded sample.
+Workload (named in config.workload):
+  N = 1   BASELINE.json configs[2], colourisation leg: 10 M points x 256 keyframes @1920x1080 (the
+          configuration north_star quotes its targets on); the MLS leg is reported beside it as "mls".
+  N > 1   BASELINE.json configs[3]: ONE 50 M-point map x 1024 keyframes, points sharded by index over the
+          ranks (50 M / N each: strong scaling), keyframes and images replicated -- every rank decodes
+          1024 / N keyframes and the ranks all-gather them over xGMI instead of N uploads of each.
+
+`value` = points x keyframes x steps / wall, with cloud, poses and images resident in HBM when the timed
+region starts (the bench contract).  The same line carries, on rank 0:
+  roofline        k_project_frame on a 40 M-point cloud (763 MiB per launch: outside the Infinity Cache),
+                  hipEvents on the launch stream; + the figure on the 10 M-point cloud (cache resident)
+  roofline_step   the kernels of the timed step: VALU-issue bound, from the recorded PMC passes
+  host_images     SURVEY 8(d)(i)'s boundary: images start in pinned HOST memory and stream in on the
+                  upload stream while the passes run (never `value`; PCIe floor beside it)
+  camera_ref      the same step with the reference's own camera (4096x3000, PointCloudProcessor.cpp:57-60)
+  cpu_baseline    the oracle (CPU restatement, OpenMP, all host cores) on a bounded sample, N = 1 only
+  mls, nid        the enableMLS chain and the NID cost, N = 1 only
 """
 from __future__ import annotations
 
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -37,15 +43,17 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PROJ_BYTES_PER_POINT = 20  # 12 B xyz read + 4 B cell + 4 B range written
 PMC_SUMMARY = "r02_pmc.json"  # profiles/: summary of the rocprofv3 --pmc passes of this command (profiles/summarise_pmc.py)
+SIMDS, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md max clock
+C3_POINTS, C3_FRAMES = 50_000_000, 1024  # BASELINE.json configs[3]
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=0, help="0: 100 at N = 1, 20 at N > 1")
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--points", type=int, default=10_000_000, help="points per GPU")
-    ap.add_argument("--frames", type=int, default=256)
+    ap.add_argument("--points", type=int, default=0, help="points per GPU (0: 10 M at N = 1, 50 M / N at N > 1)")
+    ap.add_argument("--frames", type=int, default=0, help="keyframes (0: 256 at N = 1, 1024 at N > 1)")
     ap.add_argument("--camera", default="cfg", choices=["cfg", "ref", "tiny"])
     ap.add_argument("--mls-points", type=int, default=10_000_000)
     ap.add_argument("--roofline-points", type=int, default=40_000_000,
@@ -53,6 +61,7 @@ def parse():
     ap.add_argument("--roofline-launches", type=int, default=64)
     ap.add_argument("--no-mls", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-side-legs", action="store_true", help="only the timed step and the roofline leg")
     ap.add_argument("--cpu-points", type=int, default=1_000_000)
     ap.add_argument("--cpu-frames", type=int, default=16)
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even at world size 1")
@@ -60,7 +69,41 @@ def parse():
                     help="gloo: rehearsal of the N > 1 path on fewer GPUs than ranks (ranks share devices); not a measurement")
     ap.add_argument("--dist-chunks", type=int, default=0,
                     help="keyframe groups whose all-reduce overlaps the next depth pass (0 = by the size of the depth maps)")
+    ap.add_argument("--match-mode", default="roundtrip", choices=["roundtrip", "identity"],
+                    help="pcp_cull_params.match_mode (default: the reference's fp32 round-trip arithmetic)")
     return ap.parse_args()
+
+
+def upload_keyframes(eng, dist, torch, synth, cam, F, rank, world, device):
+    """Every keyframe's image into this rank's texel buffer.  N = 1: straight from host memory.  N > 1: rank r
+    produces keyframes r, r + N, ... and the ranks all-gather the decoded BGR frames on the device (RCCL over xGMI)
+    in groups; the library then packs them from device pointers (no N-fold PCIe traffic through one host)."""
+    W, H = cam["image_width"], cam["image_height"]
+    if dist is None or world == 1:
+        for f in range(F):
+            eng.ctx.upload_image(f, synth.make_image(f, W, H))
+        return
+    group = 8  # keyframes per rank and all-gather: 8 x 6.2 MB x N per collective
+    per_rank = (F + world - 1) // world
+    mine = torch.empty((group, H, W, 3), dtype=torch.uint8).pin_memory()
+    on_gpu = dist.get_backend() == "nccl"
+    dev = device if on_gpu else "cpu"
+    for g0 in range(0, per_rank, group):
+        for k in range(group):
+            f = (g0 + k) * world + rank  # round-robin ownership
+            mine.numpy()[k] = synth.make_image(min(f, F - 1), W, H)
+        send = mine.to(dev)
+        recv = torch.empty((world, group, H, W, 3), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
+        if not on_gpu:
+            recv = recv.to(device)
+        torch.cuda.synchronize()
+        for r in range(world):
+            for k in range(group):
+                f = (g0 + k) * world + r
+                if f < F:
+                    eng.ctx.upload_image_async_ptr(f, recv[r, k].data_ptr(), W * 3)
+        eng.ctx.synchronize()  # recv is released next
 
 
 def main():
@@ -102,19 +145,31 @@ def main():
 
     from pointcloudprocessor_amd import capi, pipeline, synth
 
+    # ---- workload ----
+    sharded = world > 1
+    F = args.frames or (C3_FRAMES if sharded else 256)
+    N = args.points or (C3_POINTS // world if sharded else 10_000_000)
+    steps = args.steps or (20 if sharded else 100)
     cam = synth.camera_dict(args.camera)
-    N, F = args.points, args.frames
+    W, H = cam["image_width"], cam["image_height"]
+    if sharded:
+        workload = (f"BASELINE configs[3]: {N * world} points x {F} keyframes @{W}x{H}, points sharded by index over {world} "
+                    f"GPUs ({N} each), all-reduce(MIN) of the depth maps, z-buffer cull /14, top-5 colour mean")
+    else:
+        workload = (f"BASELINE configs[2] colourisation leg: {N} points x {F} keyframes @{W}x{H}, z-buffer cull /14, "
+                    f"top-5 colour mean")
+    cull = capi.default_cull_params()
+    cull.match_mode = capi.MATCH_ROUNDTRIP if args.match_mode == "roundtrip" else capi.MATCH_IDENTITY
+
     t_setup = time.time()
     eng = pipeline.HipEngine(local_rank)
-    eng.configure(cam)
-    # every rank samples its own slice of the (world x N)-point map
+    eng.configure(cam, cull)
+    # every rank samples its own share of the map (the seeds differ: together the shares are one N x world-point map)
     x, y, z, _ = synth.make_cloud(N, seed=synth.SEED + 1000 * rank)
     eng.upload_cloud(x, y, z)
     poses, _ = synth.make_trajectory(F)
     eng.ctx.set_frames(poses)
-    W, H = cam["image_width"], cam["image_height"]
-    for f in range(F):
-        eng.ctx.upload_image(f, synth.make_image(f, W, H))
+    upload_keyframes(eng, dist, torch, synth, cam, F, rank, world, f"cuda:{local_rank}")
     eng.ctx.synchronize()
     t_setup = time.time() - t_setup
 
@@ -127,13 +182,17 @@ def main():
     pinned = [torch.empty(N, dtype=torch.int32).pin_memory() for _ in range(2)]
     step_no = [0]
 
-    def step():
-        col.run(download=False)
-        eng.ctx.download_result_packed_async(pinned[step_no[0] & 1].data_ptr())
-        # the other landing buffer is about to be reused: its colours (the previous step's) must have arrived.
-        # Waits for that copy only, never for a kernel; it also keeps the host one step ahead instead of hundreds
-        eng.ctx.download_wait_previous()
-        step_no[0] += 1
+    def make_step(colorizer, engine, landing):
+        def step():
+            colorizer.run(download=False)
+            engine.ctx.download_result_packed_async(landing[step_no[0] & 1].data_ptr())
+            # the other landing buffer is about to be reused: its colours (the previous step's) must have arrived.
+            # Waits for that copy only, never for a kernel; it also keeps the host one step ahead instead of hundreds
+            engine.ctx.download_wait_previous()
+            step_no[0] += 1
+        return step
+
+    step = make_step(col, eng, pinned)
 
     def fence():
         eng.ctx.synchronize()
@@ -146,7 +205,7 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     fence()
     dt = time.perf_counter() - t0
@@ -154,8 +213,8 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    ms_per_step = dt / max(args.steps, 1) * 1e3
-    value = world * N * F * args.steps / dt / 1e6  # Mpoints x frames / s, whole job
+    ms_per_step = dt / max(steps, 1) * 1e3
+    value = world * N * F * steps / dt / 1e6  # Mpoints x frames / s, whole job
 
     result = None
     coloured = int(((pinned[(step_no[0] - 1) & 1].numpy().view(np.uint32) >> 24) & 1).sum())
@@ -165,8 +224,18 @@ def main():
     eng.ctx.timing_reset()
     step()
     fence()
+    kt = {eng.ctx.kernel_name(k): eng.ctx.timing_get(k)
+          for k in (capi.K_TILE_MASK, capi.K_DEPTH, capi.K_COLOUR, capi.K_MISC)}
+    eng.ctx.timing_enable(False)
     if rank == 0:
-        kt = {eng.ctx.kernel_name(k): eng.ctx.timing_get(k) for k in (capi.K_TILE_MASK, capi.K_DEPTH, capi.K_COLOUR, capi.K_MISC)}
+        pairs_kept = round(eng.ctx.tile_mask_density(), 4)
+        pmc = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", PMC_SUMMARY)) as fh:
+                pmc = json.load(fh)
+        except (OSError, ValueError):
+            pass
+
         # ---- roofline leg: the single-keyframe projection kernel, one launch per keyframe ----
         def project_leg(ctx, npts, frames):
             ctx.timing_enable(True)
@@ -178,10 +247,9 @@ def main():
             avg = ms / max(launches, 1) / 1e3
             return avg, launches, PROJ_BYTES_PER_POINT * npts / avg / 1e9
 
-        # (a) on the workload's own cloud: 120 MB read + 80 MB written per launch, the same buffers every launch --
-        # the working set fits the 256 MiB Infinity Cache, so this figure is NOT an HBM rate
-        avg_ic, launches_ic, achieved_ic = project_leg(eng.ctx, N, range(F))
-        eng.ctx.timing_enable(False)
+        # (a) on the workload's own cloud: the same buffers every launch -- at 10 M points the 191 MiB working set
+        # fits the 256 MiB Infinity Cache, so this figure is NOT an HBM rate
+        avg_ic, launches_ic, achieved_ic = project_leg(eng.ctx, N, range(min(F, 256)))
         # (b) the HBM figure: a cloud large enough that more than 256 MiB pass between two uses of any line
         # (MI355X_MICROARCH.md, Infinity Cache residency rule): 12 B x Nr read + 8 B x Nr written per launch
         Nr = max(args.roofline_points, N)
@@ -203,15 +271,10 @@ def main():
         # MI355X_MICROARCH.md prescribes), collected with this command and committed under profiles/; it is a
         # recorded figure of that profile run, not measured in this one
         traffic = traffic_src = None
-        try:
-            with open(os.path.join(ROOT, "profiles", PMC_SUMMARY)) as fh:
-                pmc = json.load(fh)
-            ent = pmc.get("k_project_frame_hbm", {})
-            if ent.get("points_per_launch") == Nr:
-                traffic = round(ent["traffic_bytes_per_launch"])
-                traffic_src = f"profiles/{PMC_SUMMARY} (recorded rocprofv3 PMC passes of this command)"
-        except (OSError, KeyError, ValueError):
-            pass
+        ent = pmc.get("k_project_frame_hbm", {})
+        if ent.get("points_per_launch") == Nr:
+            traffic = round(ent["traffic_bytes_per_launch"])
+            traffic_src = f"profiles/{PMC_SUMMARY} (recorded rocprofv3 PMC passes of this command)"
         roofline = {
             "kernel": "k_project_frame",
             "bound": "hbm",
@@ -232,34 +295,123 @@ def main():
                             "achieved": round(achieved_ic, 1), "frac_ic_resident": round(achieved_ic / HBM_PEAK_GBPS, 4),
                             "note": "working set below the 256 MiB Infinity Cache and reused by every launch: not an HBM rate"},
         }
-        # ---- PCIe-inclusive figure (never `value`): the keyframe images start in pinned host memory ----
-        pcie = None
-        if world == 1 and not args.no_cpu:
+        # ---- what bounds the kernels of the timed step: VALU issue (SQ_ACTIVE_INST_VALU x 4 cycles per wave
+        # instruction / (1024 SIMDs x 2.4 GHz)) against the kernel's duration in THIS run; counters from the
+        # recorded PMC passes of this command (same workload), HBM traffic beside it ----
+        roofline_step = None
+        step_pmc = pmc.get("step", {})
+        if step_pmc.get("points") == N and step_pmc.get("keyframes") == F:
+            roofline_step = {"bound": "valu_issue", "source": f"profiles/{PMC_SUMMARY}", "kernels": {}}
+            for kname, tkey in (("pcp::k_depth_pass", "depth_pass"), ("pcp::k_colour_pass", "colour_pass")):
+                k = step_pmc.get("kernels", {}).get(kname, {})
+                if "SQ_ACTIVE_INST_VALU_mean" in k and kt.get(tkey, (0, 0))[0] > 0:
+                    issue_ms = k["SQ_ACTIVE_INST_VALU_mean"] * 4.0 / (SIMDS * CLOCK_GHZ * 1e9) * 1e3
+                    e2 = {"valu_issue_ms": round(issue_ms, 3), "kernel_ms": round(kt[tkey][0], 3),
+                          "frac": round(issue_ms / kt[tkey][0], 3)}
+                    if "FETCH_SIZE_KB_mean" in k and "WRITE_SIZE_KB_mean" in k:
+                        hbm = (2 * k["FETCH_SIZE_KB_mean"] + k["WRITE_SIZE_KB_mean"]) * 1024
+                        e2["hbm_bytes"] = round(hbm)
+                        e2["hbm_frac_of_peak"] = round(hbm / (kt[tkey][0] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 3)
+                    roofline_step["kernels"][tkey] = e2
+        side = world == 1 and not args.no_side_legs
+        # ---- SURVEY 8(d)(i)'s boundary (never `value`): cloud resident, the keyframe images start in pinned HOST
+        # memory; they stream in on the upload stream while the depth pass and the colour pass of earlier batches
+        # run (per-keyframe events), colours back on the host at the end ----
+        host_images = None
+        if side and not args.no_cpu:
             try:
                 stage = torch.empty((F, H, W, 3), dtype=torch.uint8).pin_memory()
                 snp = stage.numpy()
                 for f in range(F):
                     snp[f] = synth.make_image(f, W, H)
-                fence()
+                dev_probe = torch.empty(stage.shape, dtype=torch.uint8, device=f"cuda:{local_rank}")
+                dev_probe.copy_(stage, non_blocking=True)  # warm-up
+                torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                eng.upload_cloud(x, y, z)  # 120 MB from pageable host memory, Morton sort and tile spheres on the device
+                dev_probe.copy_(stage, non_blocking=True)
+                torch.cuda.synchronize()
+                h2d = stage.numel() / (time.perf_counter() - t1) / 1e9
+                del dev_probe
+                batch = 32
+
+                def pipelined():
+                    eng.ctx.colour_reset()
+                    for f in range(F):
+                        eng.ctx.upload_image_async(f, snp[f])
+                    eng.ctx.depth_pass()  # needs no image: overlaps the first uploads
+                    for f0 in range(0, F, batch):
+                        eng.ctx.colour_pass(f0, min(F, f0 + batch))  # waits for its own keyframes only
+                    eng.ctx.colour_finalise(download=False)
+                    eng.ctx.download_result_packed(out_ptr=pinned[0].data_ptr())
+
+                fence()
+                pipelined()  # warm-up (top-5 state allocation)
+                fence()
+                reps = 3
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    pipelined()
+                fence()
+                t_p = (time.perf_counter() - t1) / reps
+                t1 = time.perf_counter()
+                eng.upload_cloud(x, y, z)  # 120 MB from pageable host memory + Morton sort and tile spheres on the device
+                eng.ctx.synchronize()
                 t_cloud = time.perf_counter() - t1
                 eng.ctx.set_frames(poses)
                 for f in range(F):
                     eng.ctx.upload_image_async(f, snp[f])
-                step()
-                fence()
-                t_p = time.perf_counter() - t1
-                pcie = {"ms": round(t_p * 1e3, 2), "value": round(N * F / t_p / 1e6, 1), "unit": "Mpoints*frames/s",
-                        "cloud_upload_ms": round(t_cloud * 1e3, 2),
-                        "what": f"cold run: cloud ({N * 12 / 1e6:.0f} MB) + {F} BGR8 keyframes ({stage.numel() / 1e9:.2f} GB, pinned) "
-                                f"to the device, one step, colours back"}
+                eng.ctx.synchronize()
+                host_images = {
+                    "value": round(N * F / t_p / 1e6, 1), "unit": "Mpoints*frames/s", "ms": round(t_p * 1e3, 2),
+                    "image_bytes": int(stage.numel()), "h2d_GBps": round(h2d, 1),
+                    "pcie_floor_ms": round(stage.numel() / h2d / 1e6, 2), "colour_batches": -(-F // batch),
+                    "cloud_upload_ms": round(t_cloud * 1e3, 2),
+                    "what": f"SURVEY 8(d)(i): cloud resident, {F} BGR8 keyframes ({stage.numel() / 1e9:.2f} GB) from pinned host "
+                            f"memory on the upload stream, depth pass + {-(-F // batch)} colour batches behind per-keyframe "
+                            f"events, colours on the host; pcie_floor_ms = image bytes / measured pinned H2D rate"}
                 del stage, snp
             except (RuntimeError, capi.PcpError) as e:
-                pcie = {"error": str(e)}
+                host_images = {"error": str(e)}
+        # ---- the reference's own camera (K / D of PointCloudProcessor.cpp:57-60, 4096x3000 images and cull size) ----
+        camera_ref = None
+        if side and args.camera == "cfg":
+            try:
+                rcam = synth.camera_dict("ref")
+                reng = pipeline.HipEngine(local_rank)
+                reng.configure(rcam, cull)
+                reng.upload_cloud(x, y, z)
+                reng.ctx.set_frames(poses)
+                distinct = [synth.make_image(f, rcam["image_width"], rcam["image_height"]) for f in range(8)]
+                for f in range(F):
+                    reng.ctx.upload_image(f, distinct[f % len(distinct)])
+                del distinct
+                rcol = pipeline.PointCloudColorizer(reng, 0, 1)
+                rstep = make_step(rcol, reng, pinned)
+                for _ in range(3):
+                    rstep()
+                reng.ctx.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(20):
+                    rstep()
+                reng.ctx.synchronize()
+                t_r = (time.perf_counter() - t1) / 20
+                reng.ctx.timing_enable(True)
+                reng.ctx.timing_reset()
+                rstep()
+                reng.ctx.synchronize()
+                rk = {reng.ctx.kernel_name(k): round(reng.ctx.timing_get(k)[0], 3)
+                      for k in (capi.K_TILE_MASK, capi.K_DEPTH, capi.K_COLOUR, capi.K_MISC)}
+                camera_ref = {"value": round(N * F / t_r / 1e6, 1), "unit": "Mpoints*frames/s", "ms_per_step": round(t_r * 1e3, 3),
+                              "kernels_ms": rk, "image": "4096x3000", "cull": "4096x3000 /14",
+                              "texel_bytes": int(F) * 4096 * 3000 * 4,
+                              "what": f"{N} points x {F} keyframes, K / D of PointCloudProcessor.cpp:57-60 (8 distinct "
+                                      f"procedural images cycled over the {F} keyframe slots)"}
+                reng.close()
+            except (RuntimeError, capi.PcpError) as e:
+                camera_ref = {"error": str(e)}
         # ---- NID leg (config 5's pose refine): one cost + SE(3)-gradient evaluation over every keyframe's culled cloud ----
         nid = None
-        if world == 1 and not args.no_mls:
+        if side and not args.no_mls:
             try:
                 eng.ctx.upload_intensity(np.random.default_rng(5).random(N, dtype=np.float32))
                 t1 = time.perf_counter()
@@ -279,7 +431,7 @@ def main():
                 nid = {"error": str(e)}
         # ---- MLS leg (Mpoints/s at r = 0.03, order 2, NONE upsampling) ----
         mls = None
-        if not args.no_mls and world == 1:  # side legs (MLS, CPU baseline) run at N = 1 only
+        if side and not args.no_mls:  # side legs (MLS, CPU baseline) run at N = 1 only
             try:
                 mp = capi.default_mls_params()
                 mp.upsampling = 0
@@ -366,7 +518,7 @@ def main():
                                                      f"{t_cpu_mls:.1f} s, oracle/pcp_oracle_mls.c"}
             except capi.PcpError as e:  # reported, never hidden
                 mls = {"error": str(e)}
-        # ---- CPU baseline: the oracle on a bounded sample, all host cores ----
+        # ---- CPU baseline: the oracle on a bounded sample, all host cores (rank 0, N = 1 only) ----
         cpu = None
         if not args.no_cpu and world == 1:
             from oracle import oracle_capi as oc
@@ -375,6 +527,7 @@ def main():
             for k, _ in oc.Camera._fields_:
                 setattr(ocam, k, cam[k])
             ocp = oc.default_cull_params()
+            ocp.match_mode = cull.match_mode
             cores = oc.hardware_threads()
             oc.colorize(ocam, ocp, x[:1000], y[:1000], z[:1000], poses[:1], [synth.make_image(0, W, H)], threads=cores,
                         want_top=False)  # thread-pool warm-up
@@ -409,33 +562,36 @@ def main():
                 "single_thread_value": round(cn1 * cf1 / t_cpu1 / 1e6, 3),
             }
         result = {
-            "metric": "Mpoints\u00d7frames/sec colorized",
+            "metric": "Mpoints×frames/sec colorized",
             "value": round(value, 1),
-            "unit": "Mpoints\u00d7frames/s",
+            "unit": "Mpoints×frames/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,
             "dtype": "f32/f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{N} points/GPU x {F} keyframes @{W}x{H}, z-buffer cull /14, top-5 colour mean "
-                            f"(BASELINE configs[2] colourisation leg)",
+                "workload": workload,
+                "points_total": N * world,
                 "points_per_gpu": N,
                 "keyframes": F,
                 "camera": args.camera,
+                "match_mode": args.match_mode,
                 "parallelism": f"point-index shards x{world}, all-reduce(MIN) of depth maps",
             },
             "coloured_points_rank0": coloured,
             "kernels_ms": {k: round(v[0], 3) for k, v in kt.items()},
-            "tile_pairs_kept": round(eng.ctx.tile_mask_density(), 4),
+            "tile_pairs_kept": pairs_kept,
             "setup_s": round(t_setup, 1),
             "roofline": roofline,
+            "roofline_step": roofline_step,
             "cpu_baseline": cpu,
-            "pcie_inclusive": pcie,
+            "host_images": host_images,
+            "camera_ref": camera_ref,
             "nid": nid,
             "mls": mls,
         }
@@ -443,6 +599,8 @@ def main():
             result["rehearsal"] = f"backend {args.backend}: ranks share GPUs, not a measurement"
         if cpu:
             result["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
+            if host_images and "value" in host_images:
+                result["speedup_vs_cpu_baseline_host_images"] = round(host_images["value"] / cpu["value"], 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -251,6 +251,10 @@ class Context:
         assert bgr.shape == (self.camera.image_height, self.camera.image_width, 3), bgr.shape
         self._check(self.lib.pcp_upload_image_async(self.h, C.c_int32(frame), _ptr(bgr), C.c_int64(bgr.strides[0])))
 
+    def upload_image_async_ptr(self, frame: int, ptr: int, row_stride_bytes: int):
+        """The same from a raw address: pinned host memory or DEVICE memory (e.g. frames all-gathered over xGMI)."""
+        self._check(self.lib.pcp_upload_image_async(self.h, C.c_int32(frame), C.c_void_p(ptr), C.c_int64(row_stride_bytes)))
+
     def set_image_adjust(self, enable: bool = True, saturation_scale: float = 1.0, brightness_scale: float = 1.0):
         """generateColorMap's 8-bit BGR -> HSV -> BGR round trip applied to the images uploaded from now on."""
         self._check(self.lib.pcp_set_image_adjust(self.h, C.c_int32(1 if enable else 0), C.c_float(saturation_scale),

@@ -65,11 +65,13 @@ def test_bench_two_rank_path_runs_to_completion():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--points", "200000",
-           "--frames", "8", "--steps", "1", "--warmup", "1"]
+           "--frames", "8", "--steps", "1", "--warmup", "1", "--roofline-points", "2000000"]
     proc = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=root)
     assert proc.returncode == 0, proc.stderr[-2000:]
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, proc.stdout[-2000:]
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "strong"
+    assert line["config"]["points_total"] == 400000 and "configs[3]" in line["config"]["workload"]
+    assert line["roofline"]["frac"] > 0  # the roofline leg stays on rank 0 at N > 1
     assert "rehearsal" in line
