@@ -623,6 +623,78 @@ __global__ __launch_bounds__(kBlock) void k_pack_bgr(const uint8_t *__restrict__
   texels[i] = keep | b | (g << 8) | (r << 16);
 }
 
+// The same, 16 pixels per lane: three 16-B loads (48 B of BGR) -> four 16-B stores (16 texels).  Needs 16-B aligned
+// rows and a width that is a multiple of 16.  The source may be device memory or PINNED HOST memory mapped into the
+// device's address space: the loads then cross PCIe themselves (no staging copy, no DMA engine, one launch per image),
+// 1 KiB per wave-instruction.
+__global__ __launch_bounds__(kBlock) void k_pack_bgr16(const uint8_t *__restrict__ bgr, int64_t row_stride, int32_t w,
+                                                       int32_t h, uint32_t *__restrict__ texels, int32_t clear_mask,
+                                                       const int32_t *__restrict__ hsv_tables, float sat_scale,
+                                                       float val_scale) {
+  const int32_t groups = w >> 4;  // 16-pixel groups per row
+  const int64_t n_groups = static_cast<int64_t>(groups) * h;
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  uint4 a, b, c;
+  if (row_stride == 3 * static_cast<int64_t>(w)) {
+    // tightly packed rows: the workgroup's 256 groups are 12 KiB of consecutive bytes.  Consecutive lanes load
+    // consecutive 16-B pieces (every 64-B request fully used -- this matters when the bytes cross PCIe) and the
+    // pieces are dealt out through LDS.
+    __shared__ uint4 piece[3 * kBlock];
+    const int64_t base = static_cast<int64_t>(blockIdx.x) * (3 * kBlock);
+    const int64_t pieces = 3 * n_groups;
+    const uint4 *src = reinterpret_cast<const uint4 *>(bgr);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int64_t i = base + q * kBlock + threadIdx.x;
+      if (i < pieces) piece[q * kBlock + threadIdx.x] = src[i];
+    }
+    __syncthreads();
+    if (g >= n_groups) return;
+    a = piece[3 * threadIdx.x];
+    b = piece[3 * threadIdx.x + 1];
+    c = piece[3 * threadIdx.x + 2];
+  } else {
+    if (g >= n_groups) return;
+    const int32_t vr = static_cast<int32_t>(g / groups), gr = static_cast<int32_t>(g - static_cast<int64_t>(vr) * groups);
+    const uint4 *src = reinterpret_cast<const uint4 *>(bgr + static_cast<int64_t>(vr) * row_stride + static_cast<int64_t>(gr) * 48);
+    a = src[0];
+    b = src[1];
+    c = src[2];
+  }
+  const int32_t v = static_cast<int32_t>(g / groups), gu = static_cast<int32_t>(g - static_cast<int64_t>(v) * groups);
+  const uint32_t in[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+  uint4 *dst = reinterpret_cast<uint4 *>(texels + static_cast<int64_t>(v) * w + static_cast<int64_t>(gu) * 16);
+  uint32_t out[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {  // 4 pixels = 3 dwords: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+    const uint32_t d0 = in[3 * q], d1 = in[3 * q + 1], d2 = in[3 * q + 2];
+    out[4 * q + 0] = d0 & 0xffffffu;
+    out[4 * q + 1] = (d0 >> 24) | ((d1 & 0xffffu) << 8);
+    out[4 * q + 2] = (d1 >> 16) | ((d2 & 0xffu) << 16);
+    out[4 * q + 3] = d2 >> 8;
+  }
+  if (hsv_tables) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      uint32_t bb = out[k] & 0xffu, gg = (out[k] >> 8) & 0xffu, rr = out[k] >> 16;
+      hsv_round_trip(hsv_tables, hsv_tables + 256, sat_scale, val_scale, bb, gg, rr);
+      out[k] = bb | (gg << 8) | (rr << 16);
+    }
+  }
+  if (!clear_mask) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint4 old = dst[q];
+      out[4 * q + 0] |= old.x & 0xff000000u;
+      out[4 * q + 1] |= old.y & 0xff000000u;
+      out[4 * q + 2] |= old.z & 0xff000000u;
+      out[4 * q + 3] |= old.w & 0xff000000u;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dst[q] = make_uint4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+}
+
 __global__ __launch_bounds__(kBlock) void k_pack_mask(const uint8_t *__restrict__ gray, int64_t row_stride, int32_t w,
                                                       int32_t h, uint32_t *__restrict__ texels) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
@@ -800,16 +872,21 @@ static int ensure_images(pcp_context *ctx) {
 int wait_images(pcp_context *ctx, int32_t f0, int32_t f1) {
   ctx->texels_touched = true;
   if (ctx->image_pending.empty()) return PCP_OK;
-  // the upload stream is in order: waiting for the range's most recently queued keyframe covers the others
-  int32_t last = -1;
-  for (int32_t f = std::max(f0, 0); f < f1 && f < static_cast<int32_t>(ctx->image_pending.size()); ++f)
-    if (ctx->image_pending[static_cast<size_t>(f)] && (last < 0 || ctx->image_seq[static_cast<size_t>(f)] > ctx->image_seq[static_cast<size_t>(last)]))
-      last = f;
-  if (last < 0) return PCP_OK;
-  PCP_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->image_event[static_cast<size_t>(last)], 0));
-  const uint64_t seq = ctx->image_seq[static_cast<size_t>(last)];
-  for (size_t f = 0; f < ctx->image_pending.size(); ++f)
-    if (ctx->image_pending[f] && ctx->image_seq[f] <= seq) ctx->image_pending[f] = 0;
+  // every lane is in order: per lane, waiting for the range's most recently queued keyframe covers the others
+  for (int lane = 0; lane < pcp_context::kUploadLanes; ++lane) {
+    int32_t last = -1;
+    for (int32_t f = std::max(f0, 0); f < f1 && f < static_cast<int32_t>(ctx->image_pending.size()); ++f) {
+      const size_t sf = static_cast<size_t>(f);
+      if (ctx->image_pending[sf] && ctx->image_lane[sf] == lane &&
+          (last < 0 || ctx->image_seq[sf] > ctx->image_seq[static_cast<size_t>(last)]))
+        last = f;
+    }
+    if (last < 0) continue;
+    PCP_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->image_event[static_cast<size_t>(last)], 0));
+    const uint64_t seq = ctx->image_seq[static_cast<size_t>(last)];
+    for (size_t f = 0; f < ctx->image_pending.size(); ++f)
+      if (ctx->image_pending[f] && ctx->image_lane[f] == lane && ctx->image_seq[f] <= seq) ctx->image_pending[f] = 0;
+  }
   return PCP_OK;
 }
 
@@ -939,8 +1016,9 @@ static int upload_image_impl(pcp_context *ctx, const char *who, int32_t frame, c
     return set_error(ctx, PCP_ERR_INVALID, "%s: NULL image or row stride < 3*width", who);
   const bool fresh = ctx->images.count < static_cast<size_t>(w) * h * static_cast<size_t>(ctx->n_frames) + 4;
   if ((rc = ensure_images(ctx)) != PCP_OK) return rc;
-  if (!ctx->upload_stream) {
-    PCP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
+  if (!ctx->upload_stream[0]) {
+    for (int l = 0; l < pcp_context::kUploadLanes; ++l)
+      PCP_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->upload_stream[l], hipStreamNonBlocking));
     PCP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->texels_idle, hipEventDisableTiming));
   }
   const size_t nf = static_cast<size_t>(ctx->n_frames);
@@ -951,30 +1029,65 @@ static int upload_image_impl(pcp_context *ctx, const char *who, int32_t frame, c
   }
   if (ctx->image_pending.size() != nf) {
     ctx->image_pending.assign(nf, 0);
+    ctx->image_lane.assign(nf, 0);
     ctx->image_seq.assign(nf, 0);
   }
+  const size_t sf = static_cast<size_t>(frame);
+  // a keyframe uploaded again goes to the lane of its previous upload while that one may still be in flight (two
+  // lanes writing the same texels would race); otherwise the lanes take turns
+  const int lane = ctx->image_pending[sf] ? ctx->image_lane[sf] : static_cast<int>(ctx->upload_seq % pcp_context::kUploadLanes);
   // kernels of the compute stream that read or write texels (a colour pass still sampling the previous image of this
-  // keyframe, a mask pack, the clearing of a fresh buffer) come first
+  // keyframe, a mask pack, the clearing of a fresh buffer) come first, on every lane
   if (fresh || ctx->texels_touched) {
     PCP_HIP_TRY(ctx, hipEventRecord(ctx->texels_idle, ctx->stream));
-    PCP_HIP_TRY(ctx, hipStreamWaitEvent(ctx->upload_stream, ctx->texels_idle, 0));
+    for (int l = 0; l < pcp_context::kUploadLanes; ++l) ctx->lane_must_wait[l] = true;
     ctx->texels_touched = false;
   }
+  if (ctx->lane_must_wait[lane]) {
+    PCP_HIP_TRY(ctx, hipStreamWaitEvent(ctx->upload_stream[lane], ctx->texels_idle, 0));
+    ctx->lane_must_wait[lane] = false;
+  }
+  hipStream_t us = ctx->upload_stream[lane];
   const size_t bytes = static_cast<size_t>(row_stride_bytes) * h;
-  PCP_HIP_TRY(ctx, ctx->upload_stage.ensure(bytes + 16));
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->upload_stage.p, bgr, bytes, hipMemcpyDefault, ctx->upload_stream));
   const int64_t px = static_cast<int64_t>(w) * h;
-  hipLaunchKernelGGL(k_pack_bgr, dim3(blocks_for(px)), dim3(kBlock), 0, ctx->upload_stream, ctx->upload_stage.p,
-                     row_stride_bytes, w, h, ctx->images.p + static_cast<int64_t>(frame) * px, ctx->mask_set[frame] ? 0 : 1,
-                     ctx->adjust_images ? ctx->hsv_tables.p : static_cast<const int32_t *>(nullptr),
-                     ctx->saturation_scale, ctx->brightness_scale);
+  // Where do the pack kernel's loads go?  Device memory and pinned (device-mapped) host memory are read in place;
+  // pageable host memory goes through the lane's staging buffer.
+  const uint8_t *src = nullptr;
+  {
+    static const bool direct = [] {
+      const char *e = std::getenv("PCP_UPLOAD_DIRECT");
+      return !(e && e[0] == '0');
+    }();
+    hipPointerAttribute_t attr{};
+    if (direct && hipPointerGetAttributes(&attr, bgr) == hipSuccess &&
+        (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeHost) && attr.devicePointer)
+      src = static_cast<const uint8_t *>(attr.devicePointer);
+    else
+      (void)hipGetLastError();  // an unregistered host pointer is not an error here
+  }
+  if (!src) {
+    PCP_HIP_TRY(ctx, ctx->upload_stage[lane].ensure(bytes + 16));
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->upload_stage[lane].p, bgr, bytes, hipMemcpyDefault, us));
+    src = ctx->upload_stage[lane].p;
+  }
+  const int32_t *tables = ctx->adjust_images ? ctx->hsv_tables.p : static_cast<const int32_t *>(nullptr);
+  uint32_t *dst = ctx->images.p + static_cast<int64_t>(frame) * px;
+  const int32_t clear_mask = ctx->mask_set[frame] ? 0 : 1;
+  if ((w & 15) == 0 && (row_stride_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0)
+    hipLaunchKernelGGL(k_pack_bgr16, dim3(blocks_for(px / 16)), dim3(kBlock), 0, us, src, row_stride_bytes, w, h, dst,
+                       clear_mask, tables, ctx->saturation_scale, ctx->brightness_scale);
+  else
+    hipLaunchKernelGGL(k_pack_bgr, dim3(blocks_for(px)), dim3(kBlock), 0, us, src, row_stride_bytes, w, h, dst, clear_mask,
+                       tables, ctx->saturation_scale, ctx->brightness_scale);
   PCP_HIP_TRY(ctx, hipGetLastError());
-  PCP_HIP_TRY(ctx, hipEventRecord(ctx->image_event[static_cast<size_t>(frame)], ctx->upload_stream));
-  ctx->image_pending[static_cast<size_t>(frame)] = 1;
-  ctx->image_seq[static_cast<size_t>(frame)] = ++ctx->upload_seq;
-  if (wait) {  // the host buffer may be reused by the caller; nothing is left pending
-    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->upload_stream));
-    std::fill(ctx->image_pending.begin(), ctx->image_pending.end(), uint8_t(0));
+  PCP_HIP_TRY(ctx, hipEventRecord(ctx->image_event[sf], us));
+  ctx->image_pending[sf] = 1;
+  ctx->image_lane[sf] = static_cast<uint8_t>(lane);
+  ctx->image_seq[sf] = ++ctx->upload_seq;
+  if (wait) {  // the host buffer may be reused by the caller
+    PCP_HIP_TRY(ctx, hipStreamSynchronize(us));
+    for (size_t f = 0; f < nf; ++f)
+      if (ctx->image_lane[f] == lane) ctx->image_pending[f] = 0;
   }
   ctx->image_set[static_cast<size_t>(frame)] = 1;
   return PCP_OK;

@@ -549,14 +549,15 @@ void pcp_destroy(pcp_context *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
-  if (ctx->upload_stream) {
-    (void)hipStreamSynchronize(ctx->upload_stream);
-    (void)hipStreamDestroy(ctx->upload_stream);
-  }
+  for (hipStream_t us : ctx->upload_stream)
+    if (us) {
+      (void)hipStreamSynchronize(us);
+      (void)hipStreamDestroy(us);
+    }
   for (auto e : ctx->image_event)
     if (e) (void)hipEventDestroy(e);
   if (ctx->texels_idle) (void)hipEventDestroy(ctx->texels_idle);
-  ctx->upload_stage.release();
+  for (auto &b : ctx->upload_stage) b.release();
   drain_timing(ctx);
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   ctx->xyz.release();
@@ -630,7 +631,8 @@ int pcp_set_stream(pcp_context *ctx, void *hip_stream) {
 
 int pcp_synchronize(pcp_context *ctx) {
   if (!ctx) return PCP_ERR_INVALID;
-  if (ctx->upload_stream) PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->upload_stream));
+  for (hipStream_t us : ctx->upload_stream)
+    if (us) PCP_HIP_TRY(ctx, hipStreamSynchronize(us));
   std::fill(ctx->image_pending.begin(), ctx->image_pending.end(), uint8_t(0));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
@@ -771,7 +773,8 @@ int pcp_set_camera(pcp_context *ctx, const pcp_camera *cam, const pcp_cull_param
   if (const char *e = std::getenv("PCP_DISABLE_PRETEST")) d.pretest = (e[0] == '1') ? 0 : 1;
 
   ctx->have_camera = true;
-  if (ctx->upload_stream) (void)hipStreamSynchronize(ctx->upload_stream);  // uploads sized by the previous camera
+  for (hipStream_t us : ctx->upload_stream)
+    if (us) (void)hipStreamSynchronize(us);  // uploads sized by the previous camera
   std::fill(ctx->image_pending.begin(), ctx->image_pending.end(), uint8_t(0));
   // images / depth maps are sized by the camera: drop them
   ctx->image_set.assign(ctx->image_set.size(), 0);
@@ -827,7 +830,8 @@ int pcp_set_frames(pcp_context *ctx, const pcp_pose *poses, int32_t n_frames, co
   if (T_opt && T_opt_stride != 0 && T_opt_stride != 16)
     return set_error(ctx, PCP_ERR_INVALID, "pcp_set_frames: T_opt_stride must be 0 (global) or 16 (per keyframe)");
   PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (ctx->upload_stream) PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->upload_stream));  // uploads of the previous keyframe set
+  for (hipStream_t us : ctx->upload_stream)
+    if (us) PCP_HIP_TRY(ctx, hipStreamSynchronize(us));  // uploads of the previous keyframe set
   std::fill(ctx->image_pending.begin(), ctx->image_pending.end(), uint8_t(0));
   ctx->poses.assign(poses, poses + n_frames);
   ctx->hframes.resize(static_cast<size_t>(n_frames));

@@ -123,14 +123,18 @@ struct pcp_context {
   pcp::DevBuf<pcp::DevFrame> frames;
   pcp::DevBuf<uint32_t> images;  // n_frames * img_h * img_w  (B | G<<8 | R<<16 | mask<<24)
   std::vector<uint8_t> image_set, mask_set;
-  // pcp_upload_image_async: its own stream (copies + pack kernels overlap the compute stream), one staging buffer
-  // (the stream is in order), an event per keyframe for the consumers, and an event of the compute stream that the
-  // next upload waits for when kernels that touch the texels were queued since the last one
-  hipStream_t upload_stream = nullptr;
-  pcp::DevBuf<uint8_t> upload_stage;
-  std::vector<hipEvent_t> image_event;   // per keyframe, recorded on upload_stream after its pack kernel
+  // pcp_upload_image_async: kUploadLanes streams of their own, taken in turn, each with one staging buffer (a stream
+  // is in order): the copy of keyframe i + 1 crosses PCIe while keyframe i is packed, and both overlap the compute
+  // stream.  An event per keyframe for the consumers, and an event of the compute stream that the next uploads wait
+  // for when kernels that touch the texels were queued since the last one.
+  static constexpr int kUploadLanes = 2;
+  hipStream_t upload_stream[kUploadLanes] = {nullptr, nullptr};
+  pcp::DevBuf<uint8_t> upload_stage[kUploadLanes];
+  std::vector<hipEvent_t> image_event;   // per keyframe, recorded on its lane after its pack kernel
   std::vector<uint8_t> image_pending;    // 1: the consumer has not yet made its stream wait for image_event[f]
+  std::vector<uint8_t> image_lane;       // lane of the keyframe's latest upload
   std::vector<uint64_t> image_seq;       // queue position of the keyframe's latest upload
+  bool lane_must_wait[kUploadLanes] = {false, false};  // texels_idle not yet waited for on this lane
   uint64_t upload_seq = 0;
   hipEvent_t texels_idle = nullptr;      // recorded on the compute stream
   bool texels_touched = false;           // compute-stream work on the texel buffer since the last wait
