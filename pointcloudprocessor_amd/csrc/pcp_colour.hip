@@ -485,17 +485,29 @@ __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict_
       const Projected p = project_point<false>(cam, fr.w2c, px, py, pz);
       const bool cand = live && p.pixel >= 0 && (cam.enable_zbuf ? p.cell >= 0 : p.cell != -1);
       if (cand) {
+#ifndef PCP_TEXEL_AFTER_KEEP
         // both gathers are issued before anything depends on them (one latency, not two)
         const uint32_t dbits = cam.enable_zbuf ? depth[static_cast<int64_t>(f) * cells + p.cell] : 0u;
         // texel = B | G<<8 | R<<16 | mask<<24; its low 24 bits are 0x00RRGGBB (PointCloudProcessor.cpp:760-762)
         const uint32_t texel = images[static_cast<int64_t>(f) * image_px + p.pixel];
+#else
+        const uint32_t dbits = cam.enable_zbuf ? depth[static_cast<int64_t>(f) * cells + p.cell] : 0u;
+#endif
         // A4 keep rule (view_culling.cpp:135-171)
         bool keep = true;
         if (cam.enable_zbuf)
           keep = !(range64(p.xc, p.yc, p.zc) > static_cast<double>(__uint_as_float(dbits)) + cam.slack);
         float sx = p.xc, sy = p.yc, sz = p.zc;
         if (cam.match_mode == PCP_MATCH_ROUNDTRIP && keep) keep = roundtrip_sample(cam, fr, px, py, pz, sx, sy, sz);
+#ifdef PCP_TEXEL_AFTER_KEEP
+        // experiment: only samples that pass the keep rule fetch their texel (fewer bytes, one more dependent latency)
+        if (keep) {
+          const uint32_t texel = images[static_cast<int64_t>(f) * image_px + p.pixel];
+          t.insert(final_score(sx, sy, sz, fr.px, fr.py, fr.pz), texel & 0xffffffu, f);
+        }
+#else
         if (keep) t.insert(final_score(sx, sy, sz, fr.px, fr.py, fr.pz), texel & 0xffffffu, f);
+#endif
       }
     }
   }
@@ -509,7 +521,22 @@ __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict_
     st.frame[3 * n + j] = t.f3; st.frame[4 * n + j] = t.f4;
     st.count[j] = t.count;
   }
-  if (flags & 4) rgba[perm[j]] = t.finalise();  // packed result straight into input order
+  // packed result in Morton order (coalesced 4-B stores; scattering it to input order from here cost a 32-B partial
+  // write per point: 8x the bytes) -- k_unpermute brings it to input order
+  if (flags & 4) rgba[j] = t.finalise();
+}
+
+// out[i] = sorted[inv_perm[i]]: coalesced index loads and result stores; the gathers hit a 4n-byte buffer that the
+// producing kernel has just written (L2 / Infinity Cache)
+__global__ __launch_bounds__(kBlock) void k_unpermute(const uint32_t *__restrict__ sorted, const int32_t *__restrict__ inv_perm,
+                                                      int64_t n, uint32_t *__restrict__ out) {
+  const int64_t q = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * 4;
+  if (q + 3 < n) {
+    const int4 k = *reinterpret_cast<const int4 *>(inv_perm + q);
+    *reinterpret_cast<uint4 *>(out + q) = make_uint4(sorted[k.x], sorted[k.y], sorted[k.z], sorted[k.w]);
+  } else {
+    for (int64_t i = q; i < n; ++i) out[i] = sorted[inv_perm[i]];
+  }
 }
 
 // finalise from stored state (multi-batch runs)
@@ -525,7 +552,7 @@ __global__ __launch_bounds__(kBlock) void k_finalise(int64_t n, TopState st, con
   t.f0 = st.frame[0 * n + j]; t.f1 = st.frame[1 * n + j]; t.f2 = st.frame[2 * n + j];
   t.f3 = st.frame[3 * n + j]; t.f4 = st.frame[4 * n + j];
   t.count = st.count[j];
-  rgba[perm[j]] = t.finalise();
+  rgba[j] = t.finalise();  // Morton order, see k_colour_pass
 }
 
 // ---------------------------------------------------------------------------
@@ -932,6 +959,7 @@ static int ensure_state(pcp_context *ctx) {
   PCP_HIP_TRY(ctx, ctx->view_count.ensure(sn + 4));
   PCP_HIP_TRY(ctx, ctx->rgba2[0].ensure(sn + 4));
   PCP_HIP_TRY(ctx, ctx->rgba2[1].ensure(sn + 4));
+  PCP_HIP_TRY(ctx, ctx->rgba_sorted.ensure(sn + 4));
   return PCP_OK;
 }
 
@@ -1447,8 +1475,12 @@ static int colour_pass_impl(pcp_context *ctx, int32_t frame_begin, int32_t frame
                        dim3(ordered ? 64 : kBlock), 0, ctx->stream, ctx->sxyz.p, ctx->sxyz.p + plane,
                        ctx->sxyz.p + 2 * plane, ctx->n, ctx->dcam, ctx->frames.p, frame_begin, frame_end, ctx->depth.p,
                        cells_of(ctx), ctx->tile_mask.p, ctx->mask_words, ctx->images.p,
-                       static_cast<int64_t>(ctx->dcam.img_w) * ctx->dcam.img_h, st, ctx->perm.p, result, flags,
+                       static_cast<int64_t>(ctx->dcam.img_w) * ctx->dcam.img_h, st, ctx->perm.p,
+                       one_shot ? ctx->rgba_sorted.p : result, flags,
                        ordered ? ctx->tile_order.p : static_cast<const int32_t *>(nullptr));
+    if (one_shot)
+      hipLaunchKernelGGL(k_unpermute, dim3(blocks_for(div_up(ctx->n, 4))), dim3(kBlock), 0, ctx->stream, ctx->rgba_sorted.p,
+                         ctx->inv_perm.p, ctx->n, result);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   if (!one_shot) ctx->colour_state_live = true;
@@ -1499,7 +1531,9 @@ int pcp_colour_finalise(pcp_context *ctx, uint8_t *out_rgb, uint8_t *out_has, in
   } else if (n > 0) {
     TopState st{ctx->top_score.p, ctx->top_rgb.p, ctx->top_frame.p, ctx->view_count.p};
     LaunchTimer t(ctx, PCP_K_COLOUR);
-    hipLaunchKernelGGL(k_finalise, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, n, st, ctx->perm.p, result);
+    hipLaunchKernelGGL(k_finalise, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, n, st, ctx->perm.p, ctx->rgba_sorted.p);
+    hipLaunchKernelGGL(k_unpermute, dim3(blocks_for(div_up(n, 4))), dim3(kBlock), 0, ctx->stream, ctx->rgba_sorted.p,
+                       ctx->inv_perm.p, n, result);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   if ((rc = end_result(ctx, out_rgb, out_has)) != PCP_OK) return rc;

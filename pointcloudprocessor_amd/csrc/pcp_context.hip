@@ -270,13 +270,14 @@ __global__ __launch_bounds__(kUpBlock) void k_up_radix_scatter(const uint32_t *_
 __global__ __launch_bounds__(kUpBlock) void k_up_gather(const float *__restrict__ x, const float *__restrict__ y,
                                                        const float *__restrict__ z, const int32_t *__restrict__ perm,
                                                        int64_t n, float *__restrict__ sx, float *__restrict__ sy,
-                                                       float *__restrict__ sz) {
+                                                       float *__restrict__ sz, int32_t *__restrict__ inv_perm) {
   const int64_t j = static_cast<int64_t>(blockIdx.x) * kUpBlock + threadIdx.x;
   if (j >= n) return;
   const int32_t i = perm[j];
   sx[j] = x[i];
   sy[j] = y[i];
   sz[j] = z[i];
+  inv_perm[i] = static_cast<int32_t>(j);
 }
 
 // bounding sphere of `span` consecutive Morton points per workgroup-slice: span = 64 (one wavefront per tile) or
@@ -459,8 +460,9 @@ static int store_cloud(pcp_context *ctx, const float *x, const float *y, const f
   }
   PCP_HIP_TRY(ctx, hipGetLastError());
   // ---- Morton-ordered copy and the bounding spheres ----
+  PCP_HIP_TRY(ctx, ctx->inv_perm.ensure(plane + 4));
   hipLaunchKernelGGL(k_up_gather, dim3(up_blocks(n)), dim3(kUpBlock), 0, st, dx, dy, dz, ctx->perm.p, n, ctx->sxyz.p,
-                     ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane);
+                     ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, ctx->inv_perm.p);
   const int64_t tiles = (n + 63) / 64, groups = (tiles + 15) / 16;
   PCP_HIP_TRY(ctx, ctx->tile_sphere.ensure(static_cast<size_t>(tiles + groups) * 4 + 4));
   float4 *sph = reinterpret_cast<float4 *>(ctx->tile_sphere.p);
@@ -563,6 +565,8 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->xyz.release();
   ctx->sxyz.release();
   ctx->perm.release();
+  ctx->inv_perm.release();
+  ctx->rgba_sorted.release();
   ctx->frames.release();
   ctx->images.release();
   ctx->hsv_tables.release();

@@ -114,6 +114,8 @@ struct pcp_context {
   pcp::DevBuf<float> xyz;    // x[n] y[n] z[n]
   pcp::DevBuf<float> sxyz;   // sorted x[n] y[n] z[n]
   pcp::DevBuf<int32_t> perm; // n
+  pcp::DevBuf<int32_t> inv_perm;  // n: inv_perm[perm[j]] = j (un-permutes per-point results with coalesced stores)
+  pcp::DevBuf<uint32_t> rgba_sorted;  // packed result in Morton order, before the un-permute
   std::vector<float> host_min = {0, 0, 0}, host_max = {0, 0, 0};
 
   // frames
