@@ -485,29 +485,22 @@ __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict_
       const Projected p = project_point<false>(cam, fr.w2c, px, py, pz);
       const bool cand = live && p.pixel >= 0 && (cam.enable_zbuf ? p.cell >= 0 : p.cell != -1);
       if (cand) {
-#ifndef PCP_TEXEL_AFTER_KEEP
-        // both gathers are issued before anything depends on them (one latency, not two)
         const uint32_t dbits = cam.enable_zbuf ? depth[static_cast<int64_t>(f) * cells + p.cell] : 0u;
-        // texel = B | G<<8 | R<<16 | mask<<24; its low 24 bits are 0x00RRGGBB (PointCloudProcessor.cpp:760-762)
-        const uint32_t texel = images[static_cast<int64_t>(f) * image_px + p.pixel];
-#else
-        const uint32_t dbits = cam.enable_zbuf ? depth[static_cast<int64_t>(f) * cells + p.cell] : 0u;
-#endif
         // A4 keep rule (view_culling.cpp:135-171)
         bool keep = true;
         if (cam.enable_zbuf)
           keep = !(range64(p.xc, p.yc, p.zc) > static_cast<double>(__uint_as_float(dbits)) + cam.slack);
         float sx = p.xc, sy = p.yc, sz = p.zc;
         if (cam.match_mode == PCP_MATCH_ROUNDTRIP && keep) keep = roundtrip_sample(cam, fr, px, py, pz, sx, sy, sz);
-#ifdef PCP_TEXEL_AFTER_KEEP
-        // experiment: only samples that pass the keep rule fetch their texel (fewer bytes, one more dependent latency)
+        // only samples that pass the keep rule fetch their texel: every fetch is a 64-B sector of its own (points
+        // image ~7 px apart at 1920x1080, ~15 px at 4096x3000), and about a third of the candidates are occluded.
+        // Issuing both gathers up front (one latency instead of two) was slower: colour pass 1.01 -> 0.96 ms at
+        // 1920x1080, 1.70 -> 1.48 ms at 4096x3000 with the dependent fetch (enough wavefronts hide the latency).
         if (keep) {
+          // texel = B | G<<8 | R<<16 | mask<<24; its low 24 bits are 0x00RRGGBB (PointCloudProcessor.cpp:760-762)
           const uint32_t texel = images[static_cast<int64_t>(f) * image_px + p.pixel];
           t.insert(final_score(sx, sy, sz, fr.px, fr.py, fr.pz), texel & 0xffffffu, f);
         }
-#else
-        if (keep) t.insert(final_score(sx, sy, sz, fr.px, fr.py, fr.pz), texel & 0xffffffu, f);
-#endif
       }
     }
   }
@@ -521,9 +514,11 @@ __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict_
     st.frame[3 * n + j] = t.f3; st.frame[4 * n + j] = t.f4;
     st.count[j] = t.count;
   }
-  // packed result in Morton order (coalesced 4-B stores; scattering it to input order from here cost a 32-B partial
-  // write per point: 8x the bytes) -- k_unpermute brings it to input order
-  if (flags & 4) rgba[j] = t.finalise();
+  // Packed result straight into input order: a scattered 4-B store per point, each a 32-B partial write in HBM (8x the
+  // bytes: WRITE_SIZE 316 MB for 40 MB of results), but it retires under this VALU-bound kernel for free.  The
+  // alternative (flags & 8: coalesced stores in Morton order + k_unpermute) writes 45 MB and costs 35 us more per step:
+  // the un-permute is a kernel of its own.  PCP_RESULT_UNPERMUTE=1 selects it (results identical).
+  if (flags & 4) rgba[(flags & 8) ? j : static_cast<int64_t>(perm[j])] = t.finalise();
 }
 
 // out[i] = sorted[inv_perm[i]]: coalesced index loads and result stores; the gathers hit a 4n-byte buffer that the
@@ -541,7 +536,7 @@ __global__ __launch_bounds__(kBlock) void k_unpermute(const uint32_t *__restrict
 
 // finalise from stored state (multi-batch runs)
 __global__ __launch_bounds__(kBlock) void k_finalise(int64_t n, TopState st, const int32_t *__restrict__ perm,
-                                                     uint32_t *__restrict__ rgba) {
+                                                     uint32_t *__restrict__ rgba, int32_t sorted_out) {
   const int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (j >= n) return;
   Top5 t;
@@ -552,7 +547,7 @@ __global__ __launch_bounds__(kBlock) void k_finalise(int64_t n, TopState st, con
   t.f0 = st.frame[0 * n + j]; t.f1 = st.frame[1 * n + j]; t.f2 = st.frame[2 * n + j];
   t.f3 = st.frame[3 * n + j]; t.f4 = st.frame[4 * n + j];
   t.count = st.count[j];
-  rgba[j] = t.finalise();  // Morton order, see k_colour_pass
+  rgba[sorted_out ? j : static_cast<int64_t>(perm[j])] = t.finalise();  // see k_colour_pass
 }
 
 // ---------------------------------------------------------------------------
@@ -949,6 +944,11 @@ static int ensure_depth(pcp_context *ctx) {
     std::fill(ctx->depth_valid.begin(), ctx->depth_valid.end(), uint8_t(0));
   }
   return PCP_OK;
+}
+
+static bool unpermute_results() {  // read per call: tests flip it inside one process
+  const char *e = std::getenv("PCP_RESULT_UNPERMUTE");
+  return e && e[0] == '1';
 }
 
 static int ensure_state(pcp_context *ctx) {
@@ -1476,9 +1476,10 @@ static int colour_pass_impl(pcp_context *ctx, int32_t frame_begin, int32_t frame
                        ctx->sxyz.p + 2 * plane, ctx->n, ctx->dcam, ctx->frames.p, frame_begin, frame_end, ctx->depth.p,
                        cells_of(ctx), ctx->tile_mask.p, ctx->mask_words, ctx->images.p,
                        static_cast<int64_t>(ctx->dcam.img_w) * ctx->dcam.img_h, st, ctx->perm.p,
-                       one_shot ? ctx->rgba_sorted.p : result, flags,
+                       (one_shot && unpermute_results()) ? ctx->rgba_sorted.p : result,
+                       flags | ((one_shot && unpermute_results()) ? 8 : 0),
                        ordered ? ctx->tile_order.p : static_cast<const int32_t *>(nullptr));
-    if (one_shot)
+    if (one_shot && unpermute_results())
       hipLaunchKernelGGL(k_unpermute, dim3(blocks_for(div_up(ctx->n, 4))), dim3(kBlock), 0, ctx->stream, ctx->rgba_sorted.p,
                          ctx->inv_perm.p, ctx->n, result);
     PCP_HIP_TRY(ctx, hipGetLastError());
@@ -1531,9 +1532,12 @@ int pcp_colour_finalise(pcp_context *ctx, uint8_t *out_rgb, uint8_t *out_has, in
   } else if (n > 0) {
     TopState st{ctx->top_score.p, ctx->top_rgb.p, ctx->top_frame.p, ctx->view_count.p};
     LaunchTimer t(ctx, PCP_K_COLOUR);
-    hipLaunchKernelGGL(k_finalise, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, n, st, ctx->perm.p, ctx->rgba_sorted.p);
-    hipLaunchKernelGGL(k_unpermute, dim3(blocks_for(div_up(n, 4))), dim3(kBlock), 0, ctx->stream, ctx->rgba_sorted.p,
-                       ctx->inv_perm.p, n, result);
+    const bool un = unpermute_results();
+    hipLaunchKernelGGL(k_finalise, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, n, st, ctx->perm.p,
+                       un ? ctx->rgba_sorted.p : result, un ? 1 : 0);
+    if (un)
+      hipLaunchKernelGGL(k_unpermute, dim3(blocks_for(div_up(n, 4))), dim3(kBlock), 0, ctx->stream, ctx->rgba_sorted.p,
+                         ctx->inv_perm.p, n, result);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   if ((rc = end_result(ctx, out_rgb, out_has)) != PCP_OK) return rc;

@@ -407,3 +407,28 @@ def test_hpr_candidates_and_roundtrip_modes_match_oracle(gpu_ctx_factory, oracle
         zb = oracle.colorize(ocam, oracle.default_cull_params(), s["x"], s["y"], s["z"], s["poses"], s["images"],
                              want_top=False)
         assert ref["count"].sum() > zb["count"].sum()
+
+
+def test_result_unpermute_switch_gives_identical_results(gpu_ctx_factory, small_scene, monkeypatch):
+    """PCP_RESULT_UNPERMUTE=1: the colour pass stores its packed result in Morton order with coalesced stores and a
+    second kernel un-permutes it (8x fewer bytes written, 35 us slower per step at 10 M points): same bits."""
+    from pointcloudprocessor_amd import capi
+
+    ctx = gpu_ctx_factory()
+    _setup(ctx, capi, small_scene)
+    base = ctx.colorize()
+    ctx.colour_reset()
+    ctx.depth_pass()
+    ctx.colour_pass(0, 3)
+    ctx.colour_pass(3, 6)
+    base2 = ctx.colour_finalise()
+    monkeypatch.setenv("PCP_RESULT_UNPERMUTE", "1")
+    alt = ctx.colorize()
+    ctx.colour_reset()
+    ctx.depth_pass()
+    ctx.colour_pass(0, 3)
+    ctx.colour_pass(3, 6)
+    alt2 = ctx.colour_finalise()
+    for a, b in ((base, alt), (base2, alt2), (base, base2)):
+        assert np.array_equal(a["rgb"], b["rgb"]) and np.array_equal(a["has"], b["has"])
+    assert base["has"].sum() > 500
