@@ -159,6 +159,10 @@ int pcp_upload_image(pcp_context *ctx, int32_t frame, const uint8_t *bgr, int64_
  * host buffer must stay valid and unchanged until pcp_synchronize (or any synchronising call) returns; from
  * pinned memory a sequence of keyframes streams at the PCIe rate with the packing kernels in between. */
 int pcp_upload_image_async(pcp_context *ctx, int32_t frame, const uint8_t *bgr, int64_t row_stride_bytes);
+/* Both upload calls also take a DEVICE pointer for `bgr` (e.g. frames broadcast or all-gathered over xGMI by a
+ * multi-GPU host): the transfer is then ordered after everything already queued on the context's stream
+ * (pcp_set_stream), so a collective that produced the bytes on that stream needs no host synchronisation.  Pinned
+ * (device-mapped) host memory is read in place by the pack kernel; pageable memory goes through a staging copy. */
 /* The image adjustment generateColorMap applies to every keyframe before sampling it
  * (PointCloudProcessor.cpp:722-741): cv::cvtColor(BGR2HSV) on 8-bit pixels, S and V multiplied by
  * saturation_scale / brightness_scale (both 1.0 in the reference, :728-729) with saturate_cast<uchar>, and
@@ -206,6 +210,14 @@ int pcp_depth_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end);
  * all-reduce(MIN) across point shards (multi-GPU), and its length in floats */
 int pcp_depth_maps_device(pcp_context *ctx, void **device_ptr, int64_t *n_floats);
 int pcp_download_depth_map(pcp_context *ctx, int32_t frame, float *out_depth_map);
+/* Where the single-keyframe calls (pcp_cull_frame, pcp_frame_visible, pcp_nid_prepare) take a keyframe's depth map
+ * from.  PCP_DEPTH_OWN (default): each call builds it from the uploaded points, as ViewCulling::view_culling does.
+ * PCP_DEPTH_BATCHED: they use the maps pcp_depth_pass left behind -- for a context that holds one index shard of the
+ * map, after the caller's all-reduce(MIN) across shards, these ARE the maps of the whole cloud, so the per-keyframe
+ * outputs of the shards concatenate to the single-GPU result.  The keyframe must have been covered by pcp_depth_pass. */
+#define PCP_DEPTH_OWN 0
+#define PCP_DEPTH_BATCHED 1
+int pcp_set_depth_source(pcp_context *ctx, int32_t source);
 int pcp_colour_reset(pcp_context *ctx);
 /* visibility + colour lookup + scores + per-point top-5 for [frame_begin, frame_end) */
 int pcp_colour_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end);

@@ -990,6 +990,15 @@ int compact_flags(pcp_context *ctx, const uint8_t *flags, int64_t n, int32_t *ou
 static int single_frame_depth(pcp_context *ctx, int32_t frame) {
   const int64_t cells = cells_of(ctx);
   PCP_HIP_TRY(ctx, ctx->s_u32.ensure(static_cast<size_t>(cells) + 4));
+  if (ctx->depth_from_batch) {
+    // one index shard of a larger map: the batched maps, MIN-merged across the shards by the caller, are the maps
+    // of the whole cloud (pcp_set_depth_source)
+    if (!ctx->depth.p || static_cast<size_t>(frame) >= ctx->depth_valid.size() || !ctx->depth_valid[static_cast<size_t>(frame)])
+      return set_error(ctx, PCP_ERR_STATE, "PCP_DEPTH_BATCHED: pcp_depth_pass has not covered keyframe %d", frame);
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->s_u32.p, ctx->depth.p + static_cast<int64_t>(frame) * cells,
+                                    static_cast<size_t>(cells) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    return PCP_OK;
+  }
   int rc = fill_u32(ctx, ctx->s_u32.p, cells, kFltMaxBits);
   if (rc != PCP_OK) return rc;
   if (ctx->n > 0 && ctx->dcam.enable_zbuf) {
@@ -1087,11 +1096,17 @@ static int upload_image_impl(pcp_context *ctx, const char *who, int32_t frame, c
       return !(e && e[0] == '0');
     }();
     hipPointerAttribute_t attr{};
-    if (direct && hipPointerGetAttributes(&attr, bgr) == hipSuccess &&
-        (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeHost) && attr.devicePointer)
+    if (hipPointerGetAttributes(&attr, bgr) == hipSuccess &&
+        (attr.type == hipMemoryTypeDevice || (direct && attr.type == hipMemoryTypeHost)) && attr.devicePointer) {
       src = static_cast<const uint8_t *>(attr.devicePointer);
-    else
+      if (attr.type == hipMemoryTypeDevice) {
+        // bytes produced on the device (a collective on the context's stream): this lane starts after that work
+        PCP_HIP_TRY(ctx, hipEventRecord(ctx->texels_idle, ctx->stream));
+        PCP_HIP_TRY(ctx, hipStreamWaitEvent(us, ctx->texels_idle, 0));
+      }
+    } else {
       (void)hipGetLastError();  // an unregistered host pointer is not an error here
+    }
   }
   if (!src) {
     PCP_HIP_TRY(ctx, ctx->upload_stage[lane].ensure(bytes + 16));
@@ -1400,6 +1415,14 @@ int pcp_depth_maps_device(pcp_context *ctx, void **device_ptr, int64_t *n_floats
   if ((rc = ensure_depth(ctx)) != PCP_OK) return rc;
   if (device_ptr) *device_ptr = ctx->depth.p;
   if (n_floats) *n_floats = cells_of(ctx) * ctx->n_frames;
+  return PCP_OK;
+}
+
+int pcp_set_depth_source(pcp_context *ctx, int32_t source) {
+  if (!ctx) return PCP_ERR_INVALID;
+  if (source != PCP_DEPTH_OWN && source != PCP_DEPTH_BATCHED)
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_set_depth_source: unknown source %d", source);
+  ctx->depth_from_batch = source == PCP_DEPTH_BATCHED;
   return PCP_OK;
 }
 

@@ -148,6 +148,7 @@ struct pcp_context {
   // depth maps [n_frames][mh*mw] as uint view of positive floats
   pcp::DevBuf<uint32_t> depth;
   std::vector<uint8_t> depth_valid;
+  bool depth_from_batch = false;  // pcp_set_depth_source: single-keyframe calls use the batched (merged) maps
 
   // tiles = wavefront-sized runs of 64 Morton-ordered points: bounding spheres
   // (x, y, z, radius) and the tile x keyframe visibility masks [tile][mask_words]

@@ -19,6 +19,9 @@
 //     ceres::Solve (same cost, gradient, domain limits and outer loop; not Ceres' line search).
 //   * --enableInitialGuessManual is accepted and rejected with an exception (exit -2): the
 //     interactive GUI is out of scope.
+//   * --gpus N (new, default 1): the map is sharded by point index over N GPUs of this node (pcp_multi.hpp: one
+//     process, N contexts, RCCL all-reduce(MIN) of the depth maps over xGMI, images broadcast over xGMI); every
+//     output file is identical to the one-GPU run.  MLS and the NID refinement run on GPU 0.
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -31,6 +34,7 @@
 
 #include "image_io.hpp"
 #include "pcd_io.hpp"
+#include "pcp_multi.hpp"
 #include "pcp_shim.hpp"
 
 namespace fs = std::filesystem;
@@ -48,6 +52,7 @@ struct Options {
   bool enableMLS = false, enableNIDOptimize = false, enableInitialGuessManual = false;
   bool help = false;
   bool skip_filtered_dumps = false;
+  int gpus = 1;
 };
 
 static bool parse_bool(const std::string &v) {  // boost::program_options bool semantics
@@ -84,6 +89,7 @@ static Options parse(int argc, char **argv) {
     else if (a == "--enableNIDOptimize") o.enableNIDOptimize = parse_bool(next());
     else if (a == "--enableInitialGuessManual") o.enableInitialGuessManual = parse_bool(next());
     else if (a == "--skip_filtered_dumps") o.skip_filtered_dumps = parse_bool(next());
+    else if (a == "--gpus") o.gpus = std::stoi(next());
     else throw std::runtime_error("unrecognised option '" + a + "'");
   }
   return o;
@@ -125,7 +131,7 @@ class Processor {
   bool enableMaskSegmentation;
   std::vector<Frame> frames, keyframes;
   XYZICloud cloud;
-  std::unique_ptr<Device> gpu;
+  std::unique_ptr<MultiDevice> gpu;
   int img_w = 0, img_h = 0;
   bool images_uploaded = false, images_adjusted = false;
   std::vector<uint8_t> mask_missing;
@@ -193,9 +199,9 @@ class Processor {
         std::cerr << "Couldn't read file " << cropPath << std::endl;
         return;
       }
-      gpu.reset(new Device(0));
-      gpu->uploadCloud(crop8.x.data(), crop8.y.data(), crop8.z.data(), static_cast<int64_t>(crop8.size()));
-      CloudSmooth smooth(*gpu);
+      Device mls_gpu(0);
+      mls_gpu.uploadCloud(crop8.x.data(), crop8.y.data(), crop8.z.data(), static_cast<int64_t>(crop8.size()));
+      CloudSmooth smooth(mls_gpu);
       pcp_mls_params mp;
       pcp_default_mls_params(&mp);  // PointCloudProcessor.cpp:67-86
       smooth.initialize(mp);
@@ -240,7 +246,7 @@ class Processor {
   }
 
   void setupDevice() {
-    if (!gpu) gpu.reset(new Device(0));
+    if (!gpu) gpu.reset(new MultiDevice(opt.gpus));
     gpu->uploadCloud(cloud.x.data(), cloud.y.data(), cloud.z.data(), static_cast<int64_t>(cloud.size()));
     // image size from the first keyframe image; cull size stays the reference's {4096,3000} (:206,:525)
     if (!keyframes.empty()) {
@@ -262,11 +268,34 @@ class Processor {
   }
 
   void applyNIDBasedPoseOptimization() {  // :156-164 -> calibrate.cpp:42-126
-    gpu->uploadIntensity(cloud.intensity.data(), static_cast<int64_t>(cloud.size()));
-    uploadImages(false);  // VisualLiDARCalibration reads the images itself, without generateColorMap's adjustment
-    VisualLiDARCalibration calib(*gpu);
     double cost = 0.0;
-    T_camera_lidar_optimized = calib.calibrate(&cost);
+    if (gpu->size() == 1) {
+      gpu->device(0).uploadIntensity(cloud.intensity.data(), static_cast<int64_t>(cloud.size()));
+      uploadImages(false);  // VisualLiDARCalibration reads the images itself, without generateColorMap's adjustment
+      VisualLiDARCalibration calib(gpu->device(0));
+      T_camera_lidar_optimized = calib.calibrate(&cost);
+    } else {
+      // the NID cost is a function of whole-cloud joint histograms: the stage runs on GPU 0 with the whole map
+      Device nid_gpu(0);
+      nid_gpu.uploadCloud(cloud.x.data(), cloud.y.data(), cloud.z.data(), static_cast<int64_t>(cloud.size()));
+      nid_gpu.uploadIntensity(cloud.intensity.data(), static_cast<int64_t>(cloud.size()));
+      pcp_camera cam;
+      pcp_default_camera(&cam);
+      cam.image_width = img_w;
+      cam.image_height = img_h;
+      nid_gpu.setCamera(cam);
+      std::vector<pcp_pose> kposes;
+      for (const auto &k : keyframes) kposes.push_back(k.pose);
+      nid_gpu.setKeyframes(kposes);
+      for (size_t k = 0; k < keyframes.size(); ++k) {
+        const Image8 img = read_image_bgr(keyframes[k].imagePath);
+        if (img.empty() || img.width != img_w || img.height != img_h)
+          throw std::runtime_error("Failed to read image from: " + keyframes[k].imagePath);
+        nid_gpu.uploadImage(static_cast<int>(k), img.data.data(), static_cast<int64_t>(img.width) * 3);
+      }
+      VisualLiDARCalibration calib(nid_gpu);
+      T_camera_lidar_optimized = calib.calibrate(&cost);
+    }
     std::printf("Final cost: %.3f\n--- T_camera_lidar ---\n", cost);
     for (int r = 0; r < 4; ++r)
       std::printf("%g %g %g %g\n", T_camera_lidar_optimized[4 * r], T_camera_lidar_optimized[4 * r + 1],
@@ -286,12 +315,11 @@ class Processor {
   }
 
   void viewCullingAndSaveFilteredPcds() {  // :178-224
-    ViewCulling vc(*gpu);
     const size_t n = cloud.size();
     std::vector<float> cam(3 * n);
     for (size_t k = 0; k < keyframes.size(); ++k) {
-      const std::vector<int32_t> kept = vc.cull(static_cast<int>(k));
-      gpu->check(pcp_project_frame(gpu->get(), static_cast<int>(k), nullptr, nullptr, nullptr, cam.data()));
+      const std::vector<int32_t> kept = gpu->cull(static_cast<int>(k));
+      gpu->cameraCoordinates(static_cast<int>(k), cam);
       std::vector<float> x(kept.size()), y(kept.size()), z(kept.size()), in(kept.size());
       for (size_t q = 0; q < kept.size(); ++q) {
         const size_t i = static_cast<size_t>(kept[q]);
@@ -334,7 +362,6 @@ class Processor {
 
   void pcdColorizationAndSmooth() {  // :474-602
     uploadImages(true);
-    Colorizer col(*gpu);
     std::vector<float> wx, wy, wz;  // cloudInWorldWithRGBandMask
     std::vector<float> wxyz;
     std::vector<uint8_t> wrgb;
@@ -345,7 +372,7 @@ class Processor {
         if (mask_missing[k])  // :779-780: message, empty scanInBodyWithRGBandMask -> PCDWriter throws below (exit -2)
           std::cout << "Failed to read image from: " << keyframes[k].maskImagePath << std::endl;
         else
-          v = col.frameVisible(static_cast<int>(k));
+          v = gpu->frameVisible(static_cast<int>(k));
         const std::string path =
             opt.outputPath + "filtered_pcd/" + std::to_string(keyframes[k].imageTimestamp) + "_rgb-mask" + ".pcd";
         if (writeASCII_XYZRGBMask(path, v.xyz_cam.data(), v.rgb.data(), v.mask.data(), v.index.size()) == -1)
@@ -357,7 +384,7 @@ class Processor {
       }
     }
     std::vector<uint8_t> rgb, has;
-    col.colorize(rgb, has);  // smoothColors + removePointsWithNoColor flag
+    gpu->colorize(rgb, has);  // smoothColors + removePointsWithNoColor flag
     XYZICloud out;
     std::vector<uint8_t> out_rgb;
     for (size_t i = 0; i < cloud.size(); ++i)

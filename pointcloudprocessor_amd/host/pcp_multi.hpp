@@ -1,0 +1,287 @@
+// pcp_multi.hpp -- the N GPUs of one node behind the operator names of pcp_shim.hpp (C++ host, one process).
+//
+// BASELINE.json north_star / SURVEY.md 8(e): the map is sharded by contiguous point-index range, keyframes and
+// images are replicated, per-point results (top-5 lists, colours) never leave their GPU, and the ONE exchange on the
+// data path is an all-reduce(MIN) of the per-keyframe depth maps -- here a grouped ncclAllReduce(ncclFloat, ncclMin)
+// over xGMI on the device pointers pcp_depth_maps_device() hands out (ranges are positive finite floats, so the float
+// MIN equals the uint-bits MIN the kernels used).  Keyframe images cross PCIe ONCE (to GPU 0) and reach the other
+// GPUs by ncclBroadcast; every GPU packs them from its own device buffer.
+//
+// Everything the reference's per-keyframe stages need follows from the merged maps: with PCP_DEPTH_BATCHED the
+// single-keyframe calls of every shard use them, so cull() / frameVisible() / cameraCoordinates() concatenate the
+// shards' outputs (contiguous index ranges: input order is preserved) into exactly the single-GPU result.
+//
+// With one GPU nothing of RCCL is touched: the calls go straight to the one Device.
+//
+// PCP_MULTI_REHEARSAL=1 (tests on a one-GPU box; not a measurement): the N shards are N contexts on GPU 0 and the
+// two collectives are emulated through the host (MIN of the downloaded maps written back to every shard; device
+// copies for the broadcast).  Everything else -- sharding, PCP_DEPTH_BATCHED, the stitching of the outputs -- is the
+// code that runs on N GPUs.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "pcp_shim.hpp"
+
+namespace pcp_amd {
+
+class MultiDevice {
+ public:
+  explicit MultiDevice(int n_gpus) {
+    if (n_gpus < 1) throw std::runtime_error("pcp_multi: --gpus must be >= 1");
+    if (const char *e = std::getenv("PCP_MULTI_REHEARSAL")) rehearsal_ = e[0] == '1' && n_gpus > 1;
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess || have < (rehearsal_ ? 1 : n_gpus))
+      throw std::runtime_error("pcp_multi: " + std::to_string(n_gpus) + " GPUs requested, " + std::to_string(have) +
+                               " visible; libpcp_hip has no CPU fallback");
+    for (int i = 0; i < n_gpus; ++i) dev_.emplace_back(new Device(ordinal(i)));
+    if (n_gpus == 1) return;
+    stream_.resize(static_cast<size_t>(n_gpus));
+    stage_.assign(static_cast<size_t>(n_gpus), nullptr);
+    std::vector<int> ids(static_cast<size_t>(n_gpus));
+    for (int i = 0; i < n_gpus; ++i) {
+      ids[static_cast<size_t>(i)] = i;
+      hip(hipSetDevice(ordinal(i)), "hipSetDevice");
+      hip(hipStreamCreateWithFlags(&stream_[static_cast<size_t>(i)], hipStreamNonBlocking), "hipStreamCreate");
+      // the library's kernels and RCCL share one stream per GPU: ordered without host synchronisation
+      dev_[static_cast<size_t>(i)]->check(pcp_set_stream(dev_[static_cast<size_t>(i)]->get(), stream_[static_cast<size_t>(i)]));
+      dev_[static_cast<size_t>(i)]->check(pcp_set_depth_source(dev_[static_cast<size_t>(i)]->get(), PCP_DEPTH_BATCHED));
+    }
+    if (rehearsal_) return;
+    comm_.resize(static_cast<size_t>(n_gpus));
+    nccl(ncclCommInitAll(comm_.data(), n_gpus, ids.data()), "ncclCommInitAll");
+  }
+  ~MultiDevice() {
+    for (size_t i = 0; i < comm_.size(); ++i) (void)ncclCommDestroy(comm_[i]);
+    for (size_t i = 0; i < stage_.size(); ++i)
+      if (stage_[i]) {
+        (void)hipSetDevice(ordinal(static_cast<int>(i)));
+        (void)hipFree(stage_[i]);
+      }
+    dev_.clear();  // the contexts go before their streams
+    for (size_t i = 0; i < stream_.size(); ++i) {
+      (void)hipSetDevice(ordinal(static_cast<int>(i)));
+      (void)hipStreamDestroy(stream_[i]);
+    }
+  }
+  MultiDevice(const MultiDevice &) = delete;
+  MultiDevice &operator=(const MultiDevice &) = delete;
+
+  int size() const { return static_cast<int>(dev_.size()); }
+  Device &device(int i) { return *dev_[static_cast<size_t>(i)]; }
+  int64_t cloudSize() const { return n_; }
+  // contiguous index range of shard r: the first n % N shards hold one point more (= pipeline.shard_bounds)
+  int64_t shardBegin(int r) const {
+    const int64_t N = size(), base = n_ / N, rem = n_ % N;
+    return r * base + std::min<int64_t>(r, rem);
+  }
+
+  void uploadCloud(const float *x, const float *y, const float *z, int64_t n) {
+    n_ = n;
+    for (int r = 0; r < size(); ++r) {
+      const int64_t lo = shardBegin(r), hi = shardBegin(r + 1);
+      device(r).uploadCloud(x + lo, y + lo, z + lo, hi - lo);
+    }
+    depth_ready_ = false;
+  }
+  void setCamera(const pcp_camera &cam, const pcp_cull_params *cull = nullptr) {
+    cam_ = cam;
+    for (auto &d : dev_) d->setCamera(cam, cull);
+    depth_ready_ = false;
+  }
+  void setKeyframes(const std::vector<pcp_pose> &poses, const double *T_opt = nullptr, int T_opt_stride = 0) {
+    n_frames_ = static_cast<int>(poses.size());
+    for (auto &d : dev_) d->setKeyframes(poses, T_opt, T_opt_stride);
+    depth_ready_ = false;
+  }
+  void setImageAdjust(bool enable, float saturation_scale = 1.0f, float brightness_scale = 1.0f) {
+    for (auto &d : dev_) d->setImageAdjust(enable, saturation_scale, brightness_scale);
+  }
+  // cv::Mat rgb / grayImg of one keyframe: over PCIe once, to the other GPUs over xGMI
+  void uploadImage(int keyframe, const uint8_t *bgr, int64_t step) { replicate(keyframe, bgr, step, cam_.image_height, false); }
+  void uploadMask(int keyframe, const uint8_t *gray, int64_t step) { replicate(keyframe, gray, step, cam_.image_height, true); }
+
+  // z-buffer MIN pass of every shard over all keyframes + the all-reduce(MIN) across the shards
+  void depthPassAll() {
+    if (size() == 1) return;  // pcp_colorize / pcp_cull_frame build their own maps
+    for (int r = 0; r < size(); ++r) device(r).check(pcp_depth_pass(device(r).get(), 0, n_frames_));
+    if (rehearsal_) {
+      std::vector<uint32_t> merged, part;
+      std::vector<void *> ptr(static_cast<size_t>(size()));
+      int64_t count = 0;
+      for (int r = 0; r < size(); ++r) {
+        device(r).check(pcp_depth_maps_device(device(r).get(), &ptr[static_cast<size_t>(r)], &count));
+        device(r).check(pcp_synchronize(device(r).get()));
+        part.resize(static_cast<size_t>(count));
+        hip(hipMemcpy(part.data(), ptr[static_cast<size_t>(r)], part.size() * 4, hipMemcpyDeviceToHost), "hipMemcpy(depth maps)");
+        if (r == 0)
+          merged = part;
+        else
+          for (size_t k = 0; k < merged.size(); ++k) merged[k] = std::min(merged[k], part[k]);  // positive floats: uint order
+      }
+      for (int r = 0; r < size(); ++r)
+        hip(hipMemcpy(ptr[static_cast<size_t>(r)], merged.data(), merged.size() * 4, hipMemcpyHostToDevice), "hipMemcpy(depth maps)");
+      depth_ready_ = true;
+      return;
+    }
+    nccl(ncclGroupStart(), "ncclGroupStart");
+    for (int r = 0; r < size(); ++r) {
+      void *p = nullptr;
+      int64_t count = 0;
+      device(r).check(pcp_depth_maps_device(device(r).get(), &p, &count));
+      nccl(ncclAllReduce(p, p, static_cast<size_t>(count), ncclFloat, ncclMin, comm_[static_cast<size_t>(r)],
+                         stream_[static_cast<size_t>(r)]),
+           "ncclAllReduce(depth maps, MIN)");
+    }
+    nccl(ncclGroupEnd(), "ncclGroupEnd");
+    depth_ready_ = true;
+  }
+
+  // pcdColorizationAndSmooth: rgb (3 per input point) and the removePointsWithNoColor flag, input order
+  void colorize(std::vector<uint8_t> &rgb, std::vector<uint8_t> &has) {
+    rgb.resize(3 * static_cast<size_t>(n_));
+    has.resize(static_cast<size_t>(n_));
+    if (size() == 1) {
+      device(0).check(pcp_colorize(device(0).get(), rgb.data(), has.data()));
+      return;
+    }
+    if (!depth_ready_) depthPassAll();
+    for (int r = 0; r < size(); ++r)  // queued on every GPU before any host wait
+      device(r).check(pcp_colorize_from_depth(device(r).get(), nullptr, nullptr));
+    std::vector<uint32_t> packed;
+    for (int r = 0; r < size(); ++r) {
+      const int64_t lo = shardBegin(r), m = shardBegin(r + 1) - lo;
+      packed.resize(static_cast<size_t>(m));
+      device(r).check(pcp_download_result_packed(device(r).get(), packed.data()));
+      for (int64_t i = 0; i < m; ++i) {
+        const uint32_t v = packed[static_cast<size_t>(i)];
+        uint8_t *o = rgb.data() + 3 * (lo + i);
+        o[0] = static_cast<uint8_t>(v & 0xffu);
+        o[1] = static_cast<uint8_t>((v >> 8) & 0xffu);
+        o[2] = static_cast<uint8_t>((v >> 16) & 0xffu);
+        has[static_cast<size_t>(lo + i)] = static_cast<uint8_t>(v >> 24);
+      }
+    }
+  }
+
+  // ViewCulling::cull of one keyframe: kept indices into the whole cloud, input order
+  std::vector<int32_t> cull(int keyframe) {
+    if (size() > 1 && !depth_ready_) depthPassAll();
+    std::vector<int32_t> idx;
+    std::vector<uint8_t> keep;
+    for (int r = 0; r < size(); ++r) {
+      const int64_t lo = shardBegin(r), m = shardBegin(r + 1) - lo;
+      keep.resize(static_cast<size_t>(m));
+      int64_t kept = 0;
+      device(r).check(pcp_cull_frame(device(r).get(), keyframe, keep.data(), &kept, nullptr));
+      for (int64_t i = 0; i < m; ++i)
+        if (keep[static_cast<size_t>(i)]) idx.push_back(static_cast<int32_t>(lo + i));
+    }
+    return idx;
+  }
+
+  // transformPointCloud(*cloud, *cloudInCameraPose, w2c) of one keyframe: SoA x[n] y[n] z[n]
+  void cameraCoordinates(int keyframe, std::vector<float> &cam) {
+    const size_t n = static_cast<size_t>(n_);
+    cam.resize(3 * n);
+    std::vector<float> part;
+    for (int r = 0; r < size(); ++r) {
+      const int64_t lo = shardBegin(r), m = shardBegin(r + 1) - lo;
+      part.resize(3 * static_cast<size_t>(m));
+      device(r).check(pcp_project_frame(device(r).get(), keyframe, nullptr, nullptr, nullptr, part.data()));
+      for (int a = 0; a < 3; ++a)
+        std::copy(part.begin() + a * m, part.begin() + (a + 1) * m, cam.begin() + static_cast<int64_t>(a * n) + lo);
+    }
+  }
+
+  // one keyframe's coloredCloud / scanInBodyWithRGBandMask over the whole map, input order
+  VisiblePoints frameVisible(int keyframe) {
+    if (size() > 1 && !depth_ready_) depthPassAll();
+    VisiblePoints all;
+    for (int r = 0; r < size(); ++r) {
+      Colorizer c(device(r));
+      VisiblePoints v = c.frameVisible(keyframe);
+      const int32_t lo = static_cast<int32_t>(shardBegin(r));
+      for (int32_t i : v.index) all.index.push_back(lo + i);
+      all.rgb.insert(all.rgb.end(), v.rgb.begin(), v.rgb.end());
+      all.mask.insert(all.mask.end(), v.mask.begin(), v.mask.end());
+      all.xyz_cam.insert(all.xyz_cam.end(), v.xyz_cam.begin(), v.xyz_cam.end());
+      all.xyz_world.insert(all.xyz_world.end(), v.xyz_world.begin(), v.xyz_world.end());
+    }
+    return all;
+  }
+
+ private:
+  static void hip(hipError_t e, const char *what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string("pcp_multi: ") + what + ": " + hipGetErrorString(e));
+  }
+  static void nccl(ncclResult_t r, const char *what) {
+    if (r != ncclSuccess) throw std::runtime_error(std::string("pcp_multi: ") + what + ": " + ncclGetErrorString(r));
+  }
+
+  void replicate(int keyframe, const uint8_t *host, int64_t step, int rows, bool mask) {
+    if (size() == 1) {
+      if (mask)
+        device(0).uploadMask(keyframe, host, step);
+      else
+        device(0).uploadImage(keyframe, host, step);
+      return;
+    }
+    const size_t bytes = static_cast<size_t>(step) * static_cast<size_t>(rows);
+    if (bytes > stage_bytes_) {
+      for (int r = 0; r < size(); ++r) {
+        hip(hipSetDevice(ordinal(r)), "hipSetDevice");
+        if (stage_[static_cast<size_t>(r)]) hip(hipFree(stage_[static_cast<size_t>(r)]), "hipFree");
+        hip(hipMalloc(reinterpret_cast<void **>(&stage_[static_cast<size_t>(r)]), bytes), "hipMalloc(image staging)");
+      }
+      stage_bytes_ = bytes;
+    }
+    hip(hipSetDevice(ordinal(0)), "hipSetDevice");
+    hip(hipMemcpyAsync(stage_[0], host, bytes, hipMemcpyHostToDevice, stream_[0]), "hipMemcpyAsync(image)");
+    if (rehearsal_) {
+      hip(hipStreamSynchronize(stream_[0]), "hipStreamSynchronize");
+      for (int r = 1; r < size(); ++r)
+        hip(hipMemcpyAsync(stage_[static_cast<size_t>(r)], stage_[0], bytes, hipMemcpyDeviceToDevice, stream_[static_cast<size_t>(r)]),
+            "hipMemcpyAsync(image, rehearsal)");
+    } else {
+      nccl(ncclGroupStart(), "ncclGroupStart");
+      for (int r = 0; r < size(); ++r)
+        nccl(ncclBroadcast(stage_[0], stage_[static_cast<size_t>(r)], bytes, ncclUint8, 0, comm_[static_cast<size_t>(r)],
+                           stream_[static_cast<size_t>(r)]),
+             "ncclBroadcast(image)");
+      nccl(ncclGroupEnd(), "ncclGroupEnd");
+    }
+    // device pointers: the library orders its pack kernel after the broadcast queued on the same stream, and the
+    // synchronous form returns once the staging buffer may be overwritten by the next keyframe
+    for (int r = 0; r < size(); ++r) {
+      if (mask)
+        device(r).uploadMask(keyframe, stage_[static_cast<size_t>(r)], step);
+      else
+        device(r).uploadImage(keyframe, stage_[static_cast<size_t>(r)], step);
+    }
+  }
+
+  int ordinal(int shard) const { return rehearsal_ ? 0 : shard; }
+
+  bool rehearsal_ = false;
+  std::vector<std::unique_ptr<Device>> dev_;
+  std::vector<hipStream_t> stream_;
+  std::vector<ncclComm_t> comm_;
+  std::vector<uint8_t *> stage_;
+  size_t stage_bytes_ = 0;
+  pcp_camera cam_{};
+  int64_t n_ = 0;
+  int n_frames_ = 0;
+  bool depth_ready_ = false;
+};
+
+}  // namespace pcp_amd

@@ -328,3 +328,61 @@ def test_cli_with_nid_refinement(tmp_path, oracle):
     packed = (0xFF000000 | (ref["rgb"][sel, 0].astype(np.uint64) << 16) | (ref["rgb"][sel, 1].astype(np.uint64) << 8)
               | ref["rgb"][sel, 2].astype(np.uint64))
     assert np.array_equal(got_rgb, packed)
+
+
+def test_cli_gpus_flag_without_gpus_is_loud(tmp_path):
+    """--gpus N (the C++ multi-GPU host, host/pcp_multi.hpp, linked against RCCL): the binary builds here, and without
+    that many devices it fails like every other device error: message, exit -2."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without GPUs")
+    from pointcloudprocessor_amd import synth
+
+    x, y, z, inten = synth.make_cloud(500, seed=2)
+    _write_pcd_binary(tmp_path / "scans.pcd", x, y, z, inten)
+    poses, ts = synth.make_trajectory(3)
+    with open(tmp_path / "odo.txt", "w") as f:
+        for t, p in zip(ts, poses):
+            f.write(synth.odometry_line(t, p))
+            with open(tmp_path / ("%f.ppm" % t), "wb") as g:
+                g.write(b"P6\n4 2\n255\n" + bytes(24))
+    out = str(tmp_path) + "/"
+    p = subprocess.run([_exe(), "-p", str(tmp_path / "scans.pcd"), "-o", str(tmp_path / "odo.txt"), "-i", out, "-t", out,
+                        "--gpus", "2"], capture_output=True, text=True)
+    assert p.returncode == 254 and "2 GPUs requested" in p.stderr
+
+
+@pytest.mark.gpu
+def test_cli_sharded_run_equals_single_gpu_run(tmp_path):
+    """The C++ multi-GPU host (--gpus 3) against the one-GPU run, every output file byte for byte: index shards,
+    MIN-merged depth maps (PCP_DEPTH_BATCHED), stitched per-keyframe dumps, stitched colours.  On this one-GPU box the
+    three shards share the device and the two collectives go through the host (PCP_MULTI_REHEARSAL=1); the rest is the
+    code that runs on 3 GPUs with RCCL."""
+    from pointcloudprocessor_amd import synth
+
+    W, H = 640, 470
+    x, y, z, inten = synth.make_cloud(50_001, seed=21)
+    _write_pcd_binary(tmp_path / "scans.pcd", x, y, z, inten)
+    poses, ts = synth.make_trajectory(5)
+    with open(tmp_path / "odo.txt", "w") as f:
+        for k, (t, p) in enumerate(zip(ts, poses)):
+            f.write(synth.odometry_line(t, p))
+            with open(tmp_path / ("%f.ppm" % t), "wb") as g:
+                g.write(b"P6\n%d %d\n255\n" % (W, H) + synth.make_image(k, W, H)[:, :, ::-1].tobytes())
+            with open(tmp_path / ("%f.pgm" % t), "wb") as g:
+                g.write(b"P5\n%d %d\n255\n" % (W, H) + synth.make_mask(k, W, H).tobytes())
+    outs = {}
+    for gpus in ("1", "3"):
+        d = tmp_path / ("out" + gpus)
+        d.mkdir()
+        env = dict(os.environ, PCP_MULTI_REHEARSAL="1")
+        p = subprocess.run([_exe(), "-p", str(tmp_path / "scans.pcd"), "-o", str(tmp_path / "odo.txt"), "-i", str(tmp_path) + "/",
+                            "-m", str(tmp_path) + "/", "-t", str(d) + "/", "--gpus", gpus], capture_output=True, text=True, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        files = sorted(str(q.relative_to(d)) for q in d.rglob("*.pcd"))
+        outs[gpus] = {name: (d / name).read_bytes() for name in files}
+    assert set(outs["1"]) == set(outs["3"]) and len(outs["1"]) == 3 + 2 * 5
+    for name in outs["1"]:
+        assert outs["1"][name] == outs["3"][name], name
+    assert outs["1"]["cloudInWorldWithRGB.pcd"].count(b"\n") > 1000
