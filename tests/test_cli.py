@@ -361,8 +361,8 @@ def test_cli_sharded_run_equals_single_gpu_run(tmp_path):
     code that runs on 3 GPUs with RCCL."""
     from pointcloudprocessor_amd import synth
 
-    W, H = 640, 470
-    x, y, z, inten = synth.make_cloud(50_001, seed=21)
+    W, H = 2400, 1800  # the CLI keeps the reference's K (cx = 2032, cy = 1535): the image must reach the optical axis
+    x, y, z, inten = synth.make_cloud(200_001, seed=21)
     _write_pcd_binary(tmp_path / "scans.pcd", x, y, z, inten)
     poses, ts = synth.make_trajectory(5)
     with open(tmp_path / "odo.txt", "w") as f:
