@@ -322,6 +322,10 @@ class Context:
         self._check(self.lib.pcp_depth_maps_device(self.h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def set_depth_source(self, batched: bool):
+        """PCP_DEPTH_BATCHED: the single-keyframe calls use the maps pcp_depth_pass left (MIN-merged across shards)."""
+        self._check(self.lib.pcp_set_depth_source(self.h, C.c_int32(1 if batched else 0)))
+
     def download_depth_map(self, frame: int):
         mh, mw = self.map_shape
         d = np.empty(mh * mw, np.float32)
