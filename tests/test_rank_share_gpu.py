@@ -76,7 +76,7 @@ def _sharding_properties(cd, x, y, z, poses, images, masks, probe_frames):
 
 
 def test_config3_rank_share_6M25_x_1024(oracle):
-    """One rank's share of configs[3] (50 M x 1024 over 8 GPUs): properties at full size, and a 300 k-point
+    """One rank's share of configs[3] (50 M x 1024 over 8 GPUs): properties at full size, and a 200 k-point
     sub-sample x all 1024 keyframes against the oracle (depth maps of a sub-sample are its own: bit-exact colours)."""
     from pointcloudprocessor_amd import capi, synth
 
@@ -86,7 +86,7 @@ def test_config3_rank_share_6M25_x_1024(oracle):
     poses, _ = synth.make_trajectory(F)
     images = [synth.make_image(f, cd["image_width"], cd["image_height"]) for f in range(8)]
     _sharding_properties(cd, x, y, z, poses, images, None, [0, 517, 1023])
-    n = 300_000
+    n = 200_000
     ctx = capi.Context(0)
     ctx.set_camera(cam_struct(capi, cd))
     ctx.upload_cloud(x[:n], y[:n], z[:n])
@@ -95,9 +95,10 @@ def test_config3_rank_share_6M25_x_1024(oracle):
         ctx.upload_image(f, images[f % 8])
     got = ctx.colorize()
     ref = oracle.colorize(cam_struct(oracle, cd), oracle.default_cull_params(), x[:n], y[:n], z[:n], poses,
-                          [images[f % 8] for f in range(F)], threads=0, want_top=False)
+                          [images[f % 8] for f in range(F)], threads=4, want_top=False)  # 3 x 1024 short OpenMP regions:
+    # more threads than the box's CPU share turn every barrier into a scheduler wait (260 s with 16 threads)
     assert np.array_equal(got["rgb"], ref["rgb"]) and np.array_equal(got["has"], ref["has"])
-    assert ref["has"].sum() > 100_000
+    assert ref["has"].sum() > 60_000
     ctx.close()
 
 
