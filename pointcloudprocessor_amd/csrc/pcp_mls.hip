@@ -58,6 +58,22 @@ __global__ __launch_bounds__(kMB) void k_grid_count(const float *__restrict__ x,
   rank[i] = atomicAdd(count + c, 1);
 }
 
+// surface-density probe: every `stride`-th point is binned and the cells that receive their first point are counted
+// (the estimate only sizes the SOR grid: any value gives the same, exact, result)
+__global__ __launch_bounds__(kMB) void k_grid_probe(const float *__restrict__ x, const float *__restrict__ y,
+                                                    const float *__restrict__ z, int64_t n, int64_t stride, GridDesc g,
+                                                    int32_t *__restrict__ count, unsigned long long *__restrict__ occupied) {
+  const int64_t i = (static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x) * stride;
+  bool first = false;
+  if (i < n) {
+    int32_t ix, iy, iz;
+    grid_coords(g, x[i], y[i], z[i], ix, iy, iz);
+    first = atomicAdd(count + ((iz * g.ny + iy) * g.nx + ix), 1) == 0;
+  }
+  const unsigned long long m = __ballot(first);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(occupied, static_cast<unsigned long long>(__popcll(m)));
+}
+
 __global__ __launch_bounds__(kMB) void k_grid_scatter(int64_t n, const int32_t *__restrict__ cell,
                                                       const int32_t *__restrict__ rank,
                                                       const int32_t *__restrict__ start,
@@ -69,21 +85,33 @@ __global__ __launch_bounds__(kMB) void k_grid_scatter(int64_t n, const int32_t *
 
 // make the order inside every cell ascending in the input index (deterministic
 // neighbour order), then gather the coordinates into cell order.  One lane per
-// point: it counts how many members of its cell precede it.
+// slot p of the scattered array: its point i = order_in[p] counts the members of
+// its cell [b, e) that precede it.  The workgroup's 256 slots sit in LDS, and a
+// cell holds a few dozen points, so nearly every comparison is an LDS read; the
+// parts of a cell outside the window come from memory.  (The first version went
+// through global memory for every member: 1.4 ms per 10 M-point SOR grid.)
 __global__ __launch_bounds__(kMB) void k_grid_order(const float *__restrict__ x, const float *__restrict__ y,
                                                     const float *__restrict__ z, int64_t n, int64_t plane,
                                                     const int32_t *__restrict__ cell,
                                                     const int32_t *__restrict__ start,
                                                     const int32_t *__restrict__ order_in,
                                                     int32_t *__restrict__ order_out, float *__restrict__ sxyz) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
-  if (i >= n) return;
+  __shared__ int32_t win[kMB];
+  const int64_t w0 = static_cast<int64_t>(blockIdx.x) * kMB;
+  const int64_t p = w0 + threadIdx.x;
+  const int32_t i = p < n ? order_in[p] : 0x7fffffff;
+  win[threadIdx.x] = i;
+  __syncthreads();
+  if (p >= n) return;
   const int32_t c = cell[i];
-  const int32_t b = start[c], e = start[c + 1];
+  const int64_t b = start[c], e = start[c + 1];
   int32_t before = 0;
-  for (int32_t k = b; k < e; ++k) before += order_in[k] < static_cast<int32_t>(i) ? 1 : 0;
+  const int64_t lb = max(b, w0), le = min(e, w0 + kMB);  // the part of the cell inside the window
+  for (int64_t k = b; k < lb; ++k) before += order_in[k] < i ? 1 : 0;
+  for (int64_t k = lb; k < le; ++k) before += win[k - w0] < i ? 1 : 0;
+  for (int64_t k = max(le, b); k < e; ++k) before += order_in[k] < i ? 1 : 0;
   const int64_t j = b + before;
-  order_out[j] = static_cast<int32_t>(i);
+  order_out[j] = i;
   sxyz[j] = x[i];
   sxyz[plane + j] = y[i];
   sxyz[2 * plane + j] = z[i];
@@ -783,21 +811,26 @@ __global__ __launch_bounds__(kSorBlock) void k_sor_select(const float *__restric
                                                           const int32_t *__restrict__ remap,
                                                           const int32_t *__restrict__ start, int64_t n, GridDesc g,
                                                           int32_t mean_k, float *__restrict__ distances,
-                                                          uint8_t *__restrict__ redo) {
+                                                          uint8_t *__restrict__ redo, int32_t reach,
+                                                          const int32_t *__restrict__ todo, int64_t todo_n) {
   __shared__ uint16_t bins[kSelBins][kSorBlock];
   __shared__ float list[kSelList][kSorBlock];
   const int tid = threadIdx.x;
-  const int64_t j = static_cast<int64_t>(blockIdx.x) * kSorBlock + tid;
-  if (j >= n) return;
+  // todo == nullptr: every point; else only the cell-sorted positions it names (the lanes the first pass, with a ball
+  // of one cell, flagged: borders and thin spots of the surface -- a ball of `reach` = 2 cells holds 4x the points)
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kSorBlock + tid;
+  if (t >= (todo ? todo_n : n)) return;
+  const int64_t j = todo ? todo[t] : t;
   const int k = mean_k + 1;
   const float qx = sx[j], qy = sy[j], qz = sz[j];
   int32_t cx, cy, cz;
   grid_coords(g, qx, qy, qz, cx, cy, cz);
   const float cell = 1.0f / g.inv_cell;
-  const float limit = cell * 0.999f, limit2 = limit * limit;  // 0.999: fp32 slop of the cell assignment
-  const int32_t x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
-  const int32_t y0 = max(cy - 1, 0), y1 = min(cy + 1, g.ny - 1);
-  const int32_t z0 = max(cz - 1, 0), z1 = min(cz + 1, g.nz - 1);
+  // every point closer than reach cells lies in the (2 reach + 1)^3 block; 0.999: fp32 slop of the cell assignment
+  const float limit = static_cast<float>(reach) * cell * 0.999f, limit2 = limit * limit;
+  const int32_t x0 = max(cx - reach, 0), x1 = min(cx + reach, g.nx - 1);
+  const int32_t y0 = max(cy - reach, 0), y1 = min(cy + reach, g.ny - 1);
+  const int32_t z0 = max(cz - reach, 0), z1 = min(cz + reach, g.nz - 1);
   // level l splits [lo[l], lo[l] + 32 / sc[l]) into 32 bins; bnd[l] = its boundary bin (levels > `level` unused)
   float lo[kSelLevels] = {0.0f, 0.0f, 0.0f}, sc[kSelLevels] = {static_cast<float>(kSelBins) / limit2, 0.0f, 0.0f};
   int bnd[kSelLevels] = {0, 0, 0};
@@ -991,22 +1024,6 @@ __global__ __launch_bounds__(kMB) void k_sor_classify(const float *__restrict__ 
   if (i < n) keep[i] = !(static_cast<double>(distances[i]) > threshold) ? 1 : 0;
 }
 
-// occupied cells of the current grid (surface density estimate)
-__global__ __launch_bounds__(kMB) void k_count_occupied(const int32_t *__restrict__ start, int64_t ncell,
-                                                        unsigned long long *__restrict__ occupied) {
-  const int64_t c = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
-  const bool occ = c < ncell && start[c + 1] > start[c];
-  const unsigned long long m = __ballot(occ);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(occupied, static_cast<unsigned long long>(__popcll(m)));
-}
-// the same on a histogram (build_grid(..., histogram_only))
-__global__ __launch_bounds__(kMB) void k_count_nonzero(const int32_t *__restrict__ count, int64_t ncell,
-                                                       unsigned long long *__restrict__ occupied) {
-  const int64_t c = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
-  const unsigned long long m = __ballot(c < ncell && count[c] > 0);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(occupied, static_cast<unsigned long long>(__popcll(m)));
-}
-
 // a cloud on the device the smoothing stages operate on (the uploaded map, or an
 // intermediate of pcp_cloud_smooth); mn/mx = its bounding box
 struct CloudView {
@@ -1028,7 +1045,24 @@ __device__ __forceinline__ uint32_t ordered_bits(float f) {
 __global__ __launch_bounds__(kMB) void k_bbox(const float *__restrict__ x, const float *__restrict__ y,
                                               const float *__restrict__ z, int64_t n, uint32_t *__restrict__ box) {
   uint32_t lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kMB) {
+  // four points per lane and step (16-B loads: the planes are 16-B aligned); the first version's one dword per lane
+  // and 38 dependent trips per lane took 293 us for 10 M points
+  const int64_t quads = n >> 2;
+  for (int64_t q = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x; q < quads; q += static_cast<int64_t>(gridDim.x) * kMB) {
+    const float4 vx = reinterpret_cast<const float4 *>(x)[q], vy = reinterpret_cast<const float4 *>(y)[q],
+                 vz = reinterpret_cast<const float4 *>(z)[q];
+    const float px[4] = {vx.x, vx.y, vx.z, vx.w}, py[4] = {vy.x, vy.y, vy.z, vy.w}, pz[4] = {vz.x, vz.y, vz.z, vz.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t k[3] = {ordered_bits(px[e]), ordered_bits(py[e]), ordered_bits(pz[e])};
+      for (int a = 0; a < 3; ++a) {
+        lo[a] = min(lo[a], k[a]);
+        hi[a] = max(hi[a], k[a]);
+      }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // ragged tail
+    const int64_t i = (quads << 2) + threadIdx.x;
     const uint32_t k[3] = {ordered_bits(x[i]), ordered_bits(y[i]), ordered_bits(z[i])};
     for (int a = 0; a < 3; ++a) {
       lo[a] = min(lo[a], k[a]);
@@ -1094,10 +1128,9 @@ static int exclusive_scan(pcp_context *ctx, int32_t *counts, int64_t m) {
 }
 
 // uniform grid over a cloud view, cell edge >= `cell`; fills ctx->g_*
-// histogram_only: stop after the per-cell counts (ctx->g_start holds counts, not starts): enough to
-// estimate the surface density without paying for the scatter and the per-cell ordering.
+// geometry_only: just the grid description and a large enough cell table (the density probe of sor_run fills it).
 static int build_grid(pcp_context *ctx, const CloudView &cv, float cell, float radius, GridDesc *out,
-                      bool histogram_only = false) {
+                      bool geometry_only = false) {
   const int64_t n = cv.n;
   GridDesc g{};
   const float *mn = cv.mn, *mx = cv.mx;
@@ -1123,17 +1156,16 @@ static int build_grid(pcp_context *ctx, const CloudView &cv, float cell, float r
   PCP_HIP_TRY(ctx, ctx->g_order.ensure(2 * sn + 8));
   PCP_HIP_TRY(ctx, ctx->g_start.ensure(static_cast<size_t>(ncell) + 8));
   PCP_HIP_TRY(ctx, ctx->g_xyz.ensure(3 * plane + 4));
+  if (geometry_only) {
+    *out = g;
+    return PCP_OK;
+  }
   PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->g_start.p, 0, (static_cast<size_t>(ncell) + 8) * 4, ctx->stream));
   const float *x = cv.x, *y = cv.y, *z = cv.z;
   {
     LaunchTimer t(ctx, PCP_K_MLS_GRID);
     hipLaunchKernelGGL(k_grid_count, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, x, y, z, n, g, ctx->g_cell.p,
                        ctx->g_rank.p, ctx->g_start.p);
-    if (histogram_only) {
-      PCP_HIP_TRY(ctx, hipGetLastError());
-      *out = g;
-      return PCP_OK;
-    }
     int rc = exclusive_scan(ctx, ctx->g_start.p, ncell);
     if (rc != PCP_OK) return rc;
     hipLaunchKernelGGL(k_grid_scatter, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, n, ctx->g_cell.p, ctx->g_rank.p,
@@ -1391,21 +1423,33 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
   float cell = static_cast<float>(std::cbrt(vol / static_cast<double>(n) * 4.0));
   if (!(cell > 1e-4f)) cell = 1e-4f;
   GridDesc g;
-  int rc = build_grid(ctx, cv, cell, cell, &g, /*histogram_only=*/true);
-  if (rc != PCP_OK) return rc;
+  int rc = PCP_OK;
   {
+    // density probe on every 8th point (cell edge from the sub-sample's own volume guess): occupied cells -> points
+    // per unit area of the surface.  It only sizes the grid; the kNN result does not depend on it.
+    const int64_t stride = n >= 400000 ? 8 : 1;
+    const int64_t probe_n = div_up(n, stride);
+    float pcell = static_cast<float>(std::cbrt(vol / static_cast<double>(probe_n) * 4.0));
+    if (!(pcell > 1e-4f)) pcell = 1e-4f;
+    if ((rc = build_grid(ctx, cv, pcell, pcell, &g, /*geometry_only=*/true)) != PCP_OK) return rc;
     const int64_t ncell = static_cast<int64_t>(g.nx) * g.ny * g.nz;
     PCP_HIP_TRY(ctx, ctx->s_counter.ensure(4));
     PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->s_counter.p, 0, 8, ctx->stream));
-    hipLaunchKernelGGL(k_count_nonzero, dim3(blocks_of(ncell)), dim3(kMB), 0, ctx->stream, ctx->g_start.p, ncell,
-                       ctx->s_counter.p);
+    PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->g_start.p, 0, (static_cast<size_t>(ncell) + 8) * 4, ctx->stream));
+    {
+      LaunchTimer t(ctx, PCP_K_MLS_GRID);
+      hipLaunchKernelGGL(k_grid_probe, dim3(blocks_of(probe_n)), dim3(kMB), 0, ctx->stream, cv.x, cv.y, cv.z, n, stride, g,
+                         ctx->g_start.p, ctx->s_counter.p);
+      PCP_HIP_TRY(ctx, hipGetLastError());
+    }
     unsigned long long occ = 0;
     PCP_HIP_TRY(ctx, hipMemcpyAsync(&occ, ctx->s_counter.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const double c0 = 1.0 / g.inv_cell;
-    double final_cell = c0;
+    double final_cell = static_cast<double>(cell);
     if (occ > 0) {
-      const double per_area = static_cast<double>(n) / (static_cast<double>(occ) * c0 * c0);  // points per unit area
+      const double per_area = static_cast<double>(probe_n) * static_cast<double>(stride) /
+                              (static_cast<double>(occ) * c0 * c0);  // points per unit area
       // cell edge such that the ball of one cell radius holds ~1.35 (k + 1) points of a surface of this density
       double ball = 1.35;
       if (const char *e = std::getenv("PCP_SOR_BALL")) ball = atof(e);
@@ -1430,11 +1474,14 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
       LaunchTimer t(ctx, PCP_K_SOR);
       hipLaunchKernelGGL(k_sor_select, dim3(static_cast<uint32_t>(div_up(n, kSorBlock))), dim3(kSorBlock), 0, ctx->stream,
                          ctx->g_xyz.p, ctx->g_xyz.p + plane, ctx->g_xyz.p + 2 * plane, ctx->g_order.p, cv.remap,
-                         ctx->g_start.p, n, g, mean_k, dist, ctx->m_flag.p);
+                         ctx->g_start.p, n, g, mean_k, dist, ctx->m_flag.p, 1, static_cast<const int32_t *>(nullptr),
+                         int64_t(0));
       PCP_HIP_TRY(ctx, hipGetLastError());
     }
     int64_t redo = 0;
     if ((rc = compact_flags(ctx, ctx->m_flag.p, n, ctx->s_cell.p, n, &redo)) != PCP_OK) return rc;
+    // (a second selection pass over the flagged lanes with a ball of two cells -- reach = 2, 125 cells -- left nothing
+    // for the heap kernel but took 2.5 ms per pass against the heap kernel's 1.5 ms for these 6 % of the points)
     ctx->sor_redo_fraction = static_cast<double>(redo) / static_cast<double>(n);
     if (redo > 0) {
       LaunchTimer t(ctx, PCP_K_SOR);
@@ -1484,8 +1531,8 @@ static int view_of(pcp_context *ctx, const float *x, const float *y, const float
   PCP_HIP_TRY(ctx, ctx->s_u32.ensure(8));
   const uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
   PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->s_u32.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_bbox, dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(n, kMB), 1024))), dim3(kMB), 0, ctx->stream,
-                     x, y, z, n, ctx->s_u32.p);
+  hipLaunchKernelGGL(k_bbox, dim3(static_cast<uint32_t>(std::max<int64_t>(1, std::min<int64_t>(div_up(n, 4 * kMB), 4096)))),
+                     dim3(kMB), 0, ctx->stream, x, y, z, n, ctx->s_u32.p);
   PCP_HIP_TRY(ctx, hipGetLastError());
   uint32_t box[6];
   PCP_HIP_TRY(ctx, hipMemcpyAsync(box, ctx->s_u32.p, sizeof(box), hipMemcpyDeviceToHost, ctx->stream));
