@@ -293,7 +293,8 @@ def main():
             "ic_resident": {"points_per_launch": N, "working_set_MiB": round(PROJ_BYTES_PER_POINT * N / 2**20, 1),
                             "avg_launch_ms": round(avg_ic * 1e3, 4), "launches": launches_ic,
                             "achieved": round(achieved_ic, 1), "frac_ic_resident": round(achieved_ic / HBM_PEAK_GBPS, 4),
-                            "note": "working set below the 256 MiB Infinity Cache and reused by every launch: not an HBM rate"},
+                            "note": "working set below the 256 MiB Infinity Cache and reused by every launch (the kernel's "
+                                    "accesses are non-temporal, so little of it stays): a short launch, not the HBM figure"},
         }
         # ---- what bounds the kernels of the timed step: VALU issue (SQ_ACTIVE_INST_VALU x 4 cycles per wave
         # instruction / (1024 SIMDs x 2.4 GHz)) against the kernel's duration in THIS run; counters from the

@@ -59,17 +59,30 @@ __global__ __launch_bounds__(kBlock) void k_project_frame(const float *__restric
   const int64_t i0 = q * 4;
   if (i0 >= n) return;
   if (i0 + 3 < n) {
-    const float4 vx = *reinterpret_cast<const float4 *>(x + i0);
-    const float4 vy = *reinterpret_cast<const float4 *>(y + i0);
-    const float4 vz = *reinterpret_cast<const float4 *>(z + i0);
+    // Non-temporal loads and stores: every byte of this kernel is touched once per launch (12 B read, 8 B written per
+    // point), so keeping lines in L2 / the Infinity Cache only evicts what other kernels could reuse.  On a 40 M-point
+    // cloud (763 MiB per launch): 142 -> 132 us, 5.63 -> 6.04 TB/s (loads alone: no gain; stores alone: 139 us).
+    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+    typedef int nt_i4 __attribute__((ext_vector_type(4)));
+    const nt_f4 ax = __builtin_nontemporal_load(reinterpret_cast<const nt_f4 *>(x + i0));
+    const nt_f4 ay = __builtin_nontemporal_load(reinterpret_cast<const nt_f4 *>(y + i0));
+    const nt_f4 az = __builtin_nontemporal_load(reinterpret_cast<const nt_f4 *>(z + i0));
+    const float4 vx = make_float4(ax.x, ax.y, ax.z, ax.w), vy = make_float4(ay.x, ay.y, ay.z, ay.w),
+                 vz = make_float4(az.x, az.y, az.z, az.w);
     int4 cell, pixel;
     float4 range, xc, yc, zc;
     project_store_one(cam, fr, vx.x, vy.x, vz.x, cell.x, pixel.x, range.x, xc.x, yc.x, zc.x);
     project_store_one(cam, fr, vx.y, vy.y, vz.y, cell.y, pixel.y, range.y, xc.y, yc.y, zc.y);
     project_store_one(cam, fr, vx.z, vy.z, vz.z, cell.z, pixel.z, range.z, xc.z, yc.z, zc.z);
     project_store_one(cam, fr, vx.w, vy.w, vz.w, cell.w, pixel.w, range.w, xc.w, yc.w, zc.w);
-    if (out.cell) *reinterpret_cast<int4 *>(out.cell + i0) = cell;
-    if (out.range) *reinterpret_cast<float4 *>(out.range + i0) = range;
+    if (out.cell) {
+      const nt_i4 c4 = {cell.x, cell.y, cell.z, cell.w};
+      __builtin_nontemporal_store(c4, reinterpret_cast<nt_i4 *>(out.cell + i0));
+    }
+    if (out.range) {
+      const nt_f4 r4 = {range.x, range.y, range.z, range.w};
+      __builtin_nontemporal_store(r4, reinterpret_cast<nt_f4 *>(out.range + i0));
+    }
     if (out.pixel) *reinterpret_cast<int4 *>(out.pixel + i0) = pixel;
     if (out.xc) {
       *reinterpret_cast<float4 *>(out.xc + i0) = xc;
