@@ -505,10 +505,11 @@ __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict_
           keep = !(range64(p.xc, p.yc, p.zc) > static_cast<double>(__uint_as_float(dbits)) + cam.slack);
         float sx = p.xc, sy = p.yc, sz = p.zc;
         if (cam.match_mode == PCP_MATCH_ROUNDTRIP && keep) keep = roundtrip_sample(cam, fr, px, py, pz, sx, sy, sz);
-        // only samples that pass the keep rule fetch their texel: every fetch is a 64-B sector of its own (points
-        // image ~7 px apart at 1920x1080, ~15 px at 4096x3000), and about a third of the candidates are occluded.
-        // Issuing both gathers up front (one latency instead of two) was slower: colour pass 1.01 -> 0.96 ms at
-        // 1920x1080, 1.70 -> 1.48 ms at 4096x3000 with the dependent fetch (enough wavefronts hide the latency).
+        // only samples that pass the keep rule fetch their texel: nearly every fetch is a 64-B sector of its own
+        // (neighbouring candidates image a median 4 px apart at 1920x1080, 11 px at 4096x3000), and the depth test
+        // drops 51 % / 37 % of the candidates (profiles/r02_candidates.json).  Issuing both gathers up front (one
+        // latency instead of two) was slower: colour pass 1.01 -> 0.96 ms at 1920x1080, 1.70 -> 1.48 ms at 4096x3000
+        // with the dependent fetch (enough wavefronts hide the latency).
         if (keep) {
           // texel = B | G<<8 | R<<16 | mask<<24; its low 24 bits are 0x00RRGGBB (PointCloudProcessor.cpp:760-762)
           const uint32_t texel = images[static_cast<int64_t>(f) * image_px + p.pixel];
