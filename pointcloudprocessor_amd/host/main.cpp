@@ -31,6 +31,9 @@
 #include <iostream>
 #include <memory>
 #include <sstream>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
 
 #include "image_io.hpp"
 #include "pcd_io.hpp"
@@ -337,25 +340,85 @@ class Processor {
     }
   }
 
+  // cv::imread of every keyframe (and mask) on all host cores -- the decoders are pure functions of the file -- while
+  // this thread uploads them in keyframe order; at most `window` decoded keyframes are held at a time (a 4096x3000
+  // frame is 37 MB).  The reference decodes one image per keyframe iteration on its one thread.
   void uploadImages(bool adjusted) {
     if (images_uploaded && images_adjusted == adjusted) return;
     gpu->setImageAdjust(adjusted);  // cvtColor(BGR2HSV) ... cvtColor(HSV2BGR), :722-741, fused into the upload
-    mask_missing.assign(keyframes.size(), 0);
-    for (size_t k = 0; k < keyframes.size(); ++k) {
-      std::cout << "Reading image from: " << keyframes[k].imagePath << std::endl;
-      const Image8 img = read_image_bgr(keyframes[k].imagePath);  // cv::imread, :716
-      if (img.empty() || img.width != img_w || img.height != img_h)
-        throw std::runtime_error("Failed to read image from: " + keyframes[k].imagePath);
-      gpu->uploadImage(static_cast<int>(k), img.data.data(), static_cast<int64_t>(img.width) * 3);
-      if (enableMaskSegmentation) {
-        std::cout << "Reading segment mask image from: " << keyframes[k].maskImagePath << std::endl;
-        const Image8 gray = read_image_gray(keyframes[k].maskImagePath);  // cv::IMREAD_GRAYSCALE, :775
-        if (!gray.empty() && gray.width == img_w && gray.height == img_h)
-          gpu->uploadMask(static_cast<int>(k), gray.data.data(), gray.width);
-        else
-          mask_missing[k] = 1;  // generateSegmentMap logs it and returns an empty cloud, :776-781
+    const size_t n = keyframes.size();
+    mask_missing.assign(n, 0);
+    unsigned threads = std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
+    if (const char *e = std::getenv("PCP_DECODE_THREADS")) threads = static_cast<unsigned>(std::max(1, std::atoi(e)));
+    threads = static_cast<unsigned>(std::min<size_t>(threads, std::max<size_t>(n, 1)));
+    const size_t window = 2 * static_cast<size_t>(threads) + 2;
+    std::vector<Image8> img(n), gray(n);
+    std::vector<uint8_t> ready(n, 0);
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t next = 0, uploaded = 0;
+    bool stop = false;
+    auto worker = [&]() {
+      for (;;) {
+        size_t k;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return stop || next >= n || next < uploaded + window; });
+          if (stop || next >= n) return;
+          k = next++;
+        }
+        Image8 a = read_image_bgr(keyframes[k].imagePath);  // cv::imread, :716
+        Image8 b;
+        if (enableMaskSegmentation) b = read_image_gray(keyframes[k].maskImagePath);  // cv::IMREAD_GRAYSCALE, :775
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          img[k] = std::move(a);
+          gray[k] = std::move(b);
+          ready[k] = 1;
+        }
+        cv.notify_all();
       }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t) pool.emplace_back(worker);
+    auto finish = [&]() {
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        stop = true;
+      }
+      cv.notify_all();
+      for (auto &th : pool) th.join();
+    };
+    try {
+      for (size_t k = 0; k < n; ++k) {
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return ready[k] != 0; });
+        }
+        std::cout << "Reading image from: " << keyframes[k].imagePath << std::endl;
+        if (img[k].empty() || img[k].width != img_w || img[k].height != img_h)
+          throw std::runtime_error("Failed to read image from: " + keyframes[k].imagePath);
+        gpu->uploadImage(static_cast<int>(k), img[k].data.data(), static_cast<int64_t>(img[k].width) * 3);
+        if (enableMaskSegmentation) {
+          std::cout << "Reading segment mask image from: " << keyframes[k].maskImagePath << std::endl;
+          if (!gray[k].empty() && gray[k].width == img_w && gray[k].height == img_h)
+            gpu->uploadMask(static_cast<int>(k), gray[k].data.data(), gray[k].width);
+          else
+            mask_missing[k] = 1;  // generateSegmentMap logs it and returns an empty cloud, :776-781
+        }
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          img[k] = Image8();
+          gray[k] = Image8();
+          uploaded = k + 1;
+        }
+        cv.notify_all();
+      }
+    } catch (...) {
+      finish();
+      throw;
     }
+    finish();
     images_uploaded = true;
     images_adjusted = adjusted;
   }

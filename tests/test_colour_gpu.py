@@ -432,3 +432,50 @@ def test_result_unpermute_switch_gives_identical_results(gpu_ctx_factory, small_
     for a, b in ((base, alt), (base2, alt2), (base, base2)):
         assert np.array_equal(a["rgb"], b["rgb"]) and np.array_equal(a["has"], b["has"])
     assert base["has"].sum() > 500
+
+
+def test_async_uploads_from_pinned_memory_are_ordered_against_the_passes(gpu_ctx_factory, oracle, small_scene):
+    """pcp_upload_image_async from pinned host memory (read in place by the pack kernel, two upload lanes, an event per
+    keyframe): colour batches wait for their own keyframes only, and a re-upload of a keyframe waits for the colour
+    pass that still samples its previous image.  Results equal the synchronous path / the oracle bit for bit."""
+    import torch
+
+    from pointcloudprocessor_amd import capi
+
+    s = small_scene
+    cd = s["cam"]
+    F = len(s["poses"])
+    H, W = cd["image_height"], cd["image_width"]
+    ctx = gpu_ctx_factory()
+    ctx.set_camera(cam_struct(capi, cd))
+    ctx.upload_cloud(s["x"], s["y"], s["z"])
+    ctx.set_frames(s["poses"])
+    stage = torch.empty((2 * F, H, W, 3), dtype=torch.uint8).pin_memory()
+    snp = stage.numpy()
+    for f in range(F):
+        snp[f] = s["images"][f]
+        snp[F + f] = s["images"][(f + 1) % F][::-1, ::-1]  # a second, different set
+    ocam, ocp = cam_struct(oracle, cd), oracle.default_cull_params()
+    refs = [oracle.colorize(ocam, ocp, s["x"], s["y"], s["z"], s["poses"], [snp[k * F + f] for f in range(F)], want_top=False)
+            for k in range(2)]
+    assert (refs[0]["rgb"] != refs[1]["rgb"]).any()
+    for rep in range(3):
+        for k in range(2):
+            ctx.colour_reset()
+            for f in range(F):  # queued back to back; the set of the previous round may still be sampled
+                ctx.upload_image_async(f, snp[k * F + f])
+            ctx.depth_pass()
+            for f0 in range(0, F, 2):
+                ctx.colour_pass(f0, min(F, f0 + 2))
+            got = ctx.colour_finalise()
+            assert np.array_equal(got["rgb"], refs[k]["rgb"]) and np.array_equal(got["has"], refs[k]["has"]), (rep, k)
+            one = ctx.colorize()  # one-shot pass over the same texels
+            assert np.array_equal(one["rgb"], refs[k]["rgb"])
+    # device pointers are accepted too (frames gathered over xGMI by a multi-GPU host)
+    dev = stage[:F].to("cuda:0")
+    torch.cuda.synchronize()
+    for f in range(F):
+        ctx.upload_image_async_ptr(f, dev[f].data_ptr(), W * 3)
+    got = ctx.colorize()
+    assert np.array_equal(got["rgb"], refs[0]["rgb"])
+    ctx.synchronize()
