@@ -288,6 +288,16 @@ int pcp_nid_evaluate(pcp_context *ctx, const double T[16], const double *T_init,
 int pcp_nid_optimize(pcp_context *ctx, const double T_init[16], int32_t bins, int32_t max_outer_iterations,
                      double T_out[16], double *final_cost, int32_t *evaluations);
 
+/* ---- precondition of the match-back (PointCloudProcessor.cpp:480-482,571) ------------------------------- */
+/* Number of map points that have ANOTHER map point closer than `radius` (fp32 squared distance, strict <, as
+ * kdtree.radiusSearch compares).  The reference credits a visible sample to every map point within 1e-5 m of the
+ * sample's fp32 world position; libpcp_hip credits the sample's own point only (PCP_MATCH_ROUNDTRIP / _IDENTITY).  The
+ * two agree when no two map points can both lie within 1e-5 m of one sample: call this with radius = 2.5e-5 (the
+ * match radius plus twice the largest fp32 round-trip error of maps within +-50 m) and expect 0; a non-zero count
+ * (duplicated or near-duplicated points, e.g. un-deduplicated scan accumulations) names how many points may receive
+ * a neighbour's samples in the reference and not here. */
+int pcp_close_pairs(pcp_context *ctx, double radius, int64_t *points_with_close_neighbour);
+
 /* ---- measurement -------------------------------------------------------- */
 /* When enabled every kernel launch is bracketed by hipEvents on the context's
  * stream; totals are read back with pcp_timing_get (which synchronises). */

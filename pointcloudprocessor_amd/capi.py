@@ -417,6 +417,12 @@ class Context:
         self._check(self.lib.pcp_sor(self.h, C.c_int32(mean_k), C.c_double(std_mul), _ptr(keep), C.byref(kept)))
         return keep, kept.value
 
+    def close_pairs(self, radius: float = 2.5e-5) -> int:
+        """Map points with another map point closer than `radius` (precondition of the index match-back: expect 0)."""
+        cnt = C.c_int64()
+        self._check(self.lib.pcp_close_pairs(self.h, C.c_double(radius), C.byref(cnt)))
+        return cnt.value
+
     # -- NID extrinsic refinement -----------------------------------------
     def sor_redo_fraction(self) -> float:
         v = C.c_double()

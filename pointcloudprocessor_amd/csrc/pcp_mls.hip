@@ -490,6 +490,29 @@ __global__ __launch_bounds__(kFitBlock) void k_mls_fit(MlsArgs a) {
   }
 }
 
+// pcp_close_pairs: per point, is there ANOTHER map point closer than r (fp32 L2_Simple distance, strict <)?
+__global__ __launch_bounds__(kMB) void k_close_pairs(const float *__restrict__ sx, const float *__restrict__ sy,
+                                                     const float *__restrict__ sz, const int32_t *__restrict__ start,
+                                                     int64_t n, GridDesc g, float sq_radius,
+                                                     unsigned long long *__restrict__ count) {
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  bool close = false;
+  if (j < n) {
+    const float qx = sx[j], qy = sy[j], qz = sz[j];
+    int32_t cx, cy, cz;
+    grid_coords(g, qx, qy, qz, cx, cy, cz);
+    for (int32_t zz = max(cz - g.reach, 0); zz <= min(cz + g.reach, g.nz - 1) && !close; ++zz)
+      for (int32_t yy = max(cy - g.reach, 0); yy <= min(cy + g.reach, g.ny - 1) && !close; ++yy) {
+        const int32_t row = (zz * g.ny + yy) * g.nx;
+        const int32_t b = start[row + max(cx - g.reach, 0)], e = start[row + min(cx + g.reach, g.nx - 1) + 1];
+        for (int32_t k = b; k < e; ++k)
+          if (k != j && sqdist_f32(sx[k], sy[k], sz[k], qx, qy, qz) < sq_radius) close = true;
+      }
+  }
+  const unsigned long long m = __ballot(close);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, static_cast<unsigned long long>(__popcll(m)));
+}
+
 // dense outputs by compacted index list
 __global__ __launch_bounds__(kMB) void k_mls_gather(const float *__restrict__ tmp, const int32_t *__restrict__ index,
                                                     int64_t m, float *__restrict__ xyz, float *__restrict__ normal,
@@ -1699,6 +1722,31 @@ int pcp_cloud_smooth(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_cou
   }
   ctx->mls_count = kept;
   if (out_count) *out_count = kept;
+  return PCP_OK;
+}
+
+int pcp_close_pairs(pcp_context *ctx, double radius, int64_t *points_with_close_neighbour) {
+  if (!ctx || !points_with_close_neighbour) return PCP_ERR_INVALID;
+  if (!ctx->xyz.p) return set_error(ctx, PCP_ERR_STATE, "pcp_close_pairs: no cloud uploaded");
+  if (!(radius > 0.0)) return set_error(ctx, PCP_ERR_INVALID, "pcp_close_pairs: radius must be > 0");
+  PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  *points_with_close_neighbour = 0;
+  const CloudView cv = uploaded_view(ctx);
+  if (cv.n < 2) return PCP_OK;
+  GridDesc g;
+  // the grid builder grows the cell until the table fits; reach = ceil(radius / cell) stays 1 for micrometre radii
+  int rc = build_grid(ctx, cv, static_cast<float>(radius) * 1.001f, static_cast<float>(radius), &g);
+  if (rc != PCP_OK) return rc;
+  const size_t plane = (static_cast<size_t>(cv.n) + 3) & ~size_t(3);
+  PCP_HIP_TRY(ctx, ctx->s_counter.ensure(4));
+  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->s_counter.p, 0, 8, ctx->stream));
+  hipLaunchKernelGGL(k_close_pairs, dim3(blocks_of(cv.n)), dim3(kMB), 0, ctx->stream, ctx->g_xyz.p, ctx->g_xyz.p + plane,
+                     ctx->g_xyz.p + 2 * plane, ctx->g_start.p, cv.n, g, static_cast<float>(radius * radius), ctx->s_counter.p);
+  PCP_HIP_TRY(ctx, hipGetLastError());
+  unsigned long long c = 0;
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(&c, ctx->s_counter.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  *points_with_close_neighbour = static_cast<int64_t>(c);
   return PCP_OK;
 }
 
