@@ -878,35 +878,60 @@ __global__ __launch_bounds__(kSorBlock) void k_sor_select(const float *__restric
     }
     return 0;
   };
+  // The candidate coordinates come through buffer descriptors (one per coordinate plane: uniform base in SGPRs,
+  // 32-bit byte offset per lane), so a candidate costs one shift instead of a 64-bit address per plane; four
+  // candidates per trip (12 loads in flight).  The planes hold n < 2^30 floats: offsets and sizes fit 32 bits.
+  const uint32_t plane_bytes = static_cast<uint32_t>(n) * 4u;
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sx), 0, plane_bytes, 0x00020000);
+  const auto ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sy), 0, plane_bytes, 0x00020000);
+  const auto rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sz), 0, plane_bytes, 0x00020000);
+  auto cand_d2 = [&](uint32_t q) {
+    const uint32_t off = q * 4u;
+    const float px = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
+    const float py = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, off, 0, 0));
+    const float pz = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rz, off, 0, 0));
+    return sqdist_f32(px, py, pz, qx, qy, qz);
+  };
   auto for_candidates = [&](auto &&body) {
     for (int32_t zz = z0; zz <= z1; ++zz)
       for (int32_t yy = y0; yy <= y1; ++yy) {
         const int32_t row = (zz * g.ny + yy) * g.nx;
-        const int32_t b = start[row + x0], e = start[row + x1 + 1];
-        for (int32_t q = b; q < e; q += 2) {
-          const int32_t q1 = min(q + 1, e - 1);
-          const float d0 = sqdist_f32(sx[q], sy[q], sz[q], qx, qy, qz);
-          const float d1 = sqdist_f32(sx[q1], sy[q1], sz[q1], qx, qy, qz);
+        const uint32_t b = static_cast<uint32_t>(start[row + x0]), e = static_cast<uint32_t>(start[row + x1 + 1]);
+        for (uint32_t q = b; q < e; q += 4) {
+          const uint32_t q1 = min(q + 1, e - 1), q2 = min(q + 2, e - 1), q3 = min(q + 3, e - 1);
+          const float d0 = cand_d2(q), d1 = cand_d2(q1), d2 = cand_d2(q2), d3 = cand_d2(q3);
           body(d0);
           if (q + 1 < e) body(d1);
+          if (q + 2 < e) body(d2);
+          if (q + 3 < e) body(d3);
         }
       }
   };
+  // 16-bit counters, two lanes to a dword, bumped by one no-return LDS atomic (no read - wait - write round trip)
+  auto bump = [&](int b) {
+    atomicAdd(reinterpret_cast<uint32_t *>(&bins[b][tid & ~1]), (tid & 1) ? 0x10000u : 1u);
+  };
   bool bad = false;
+  {
+    // a counter cannot wrap: the 27 cells hold fewer candidates than it can count (else the heap kernel takes the lane)
+    uint32_t total = 0;
+    for (int32_t zz = z0; zz <= z1; ++zz)
+      for (int32_t yy = y0; yy <= y1; ++yy) {
+        const int32_t row = (zz * g.ny + yy) * g.nx;
+        total += static_cast<uint32_t>(start[row + x1 + 1] - start[row + x0]);
+      }
+    bad = total > 60000u;
+  }
   int below = 0, level = 0, crowd = 0;
   // level 0 with the plain bin arithmetic (on a uniform cloud no lane needs more)
   {
 #pragma unroll
     for (int b = 0; b < kSelBins; ++b) bins[b][tid] = 0;
     const float sc0 = sc[0];
-    for_candidates([&](float d) {
-      if (d < limit2) {
-        const int b = min(static_cast<int>(d * sc0), kSelBins - 1);
-        const uint16_t c = bins[b][tid];
-        bad = bad || c == 0xffffu;
-        bins[b][tid] = static_cast<uint16_t>(c + 1);
-      }
-    });
+    if (!bad)
+      for_candidates([&](float d) {
+        if (d < limit2) bump(min(static_cast<int>(d * sc0), kSelBins - 1));
+      });
     int boundary = -1;
     for (int b = 0; b < kSelBins; ++b) {
       const int c = bins[b][tid];
@@ -940,7 +965,7 @@ __global__ __launch_bounds__(kSorBlock) void k_sor_select(const float *__restric
     }
     for_candidates([&](float d) {
       int b = 0;
-      if (go && classify(d, level + 1, b) == 0) bins[b][tid] = static_cast<uint16_t>(bins[b][tid] + 1);
+      if (go && classify(d, level + 1, b) == 0) bump(b);
     });
     if (go) {
       int boundary = -1;
@@ -1493,7 +1518,8 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
   float *dist = ctx->m_tmp.p;
   const size_t heap_lds = static_cast<size_t>(mean_k + 1) * kSorBlock * sizeof(float);
   const char *heap_only = std::getenv("PCP_SOR_HEAP_ONLY");
-  const bool use_select = !(heap_only && heap_only[0] == '1');
+  // the selection kernel addresses the coordinate planes through buffer descriptors (32-bit byte offsets)
+  const bool use_select = !(heap_only && heap_only[0] == '1') && n < (int64_t(1) << 30);
   if (use_select && mean_k + 1 <= 250) {
     // selection kernel for every point, heap kernel for the few it flags (sparse spots, borders of a surface)
     PCP_HIP_TRY(ctx, ctx->s_cell.ensure(sn + 8));
