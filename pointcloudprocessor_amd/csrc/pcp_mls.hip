@@ -221,9 +221,28 @@ constexpr int kMaxNbr = 96;
 constexpr int kMaxRun = 9;
 constexpr int kFitBlock = 128;  // 28.5 KB of LDS per workgroup: LDS does not cap the occupancy the VGPRs allow
 
+// kBuf: the cell-sorted coordinate planes are read through buffer descriptors (uniform base, 32-bit byte offset per
+// lane: one shift per candidate instead of three 64-bit addresses); needs n < 2^30 points.
+template <bool kBuf>
 __global__ __launch_bounds__(kFitBlock) void k_mls_fit(MlsArgs a) {
   __shared__ uint16_t nbr_code[kMaxNbr][kFitBlock];
   __shared__ int32_t run_base[kMaxRun][kFitBlock];
+  const uint32_t plane_bytes = kBuf ? static_cast<uint32_t>(a.n) * 4u : 0u;
+  const auto rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.sx), 0, plane_bytes, 0x00020000);
+  const auto rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.sy), 0, plane_bytes, 0x00020000);
+  const auto rsz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.sz), 0, plane_bytes, 0x00020000);
+  auto fetch = [&](int32_t k, float &x, float &y, float &z) {
+    if constexpr (kBuf) {
+      const uint32_t off = static_cast<uint32_t>(k) * 4u;
+      x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsx, off, 0, 0));
+      y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsy, off, 0, 0));
+      z = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsz, off, 0, 0));
+    } else {
+      x = a.sx[k];
+      y = a.sy[k];
+      z = a.sz[k];
+    }
+  };
   const int tid = threadIdx.x;
   const int64_t j = static_cast<int64_t>(blockIdx.x) * kFitBlock + threadIdx.x;
   if (j >= a.n) return;
@@ -261,10 +280,11 @@ __global__ __launch_bounds__(kFitBlock) void k_mls_fit(MlsArgs a) {
       if (e - b > 4096) fast = false;
       for (int32_t k = b; k < e; k += 4) {
         const int32_t k1 = min(k + 1, e - 1), k2 = min(k + 2, e - 1), k3 = min(k + 3, e - 1);
-        const float ax = a.sx[k], ay = a.sy[k], az = a.sz[k];
-        const float bx = a.sx[k1], by = a.sy[k1], bz = a.sz[k1];
-        const float cx_ = a.sx[k2], cy_ = a.sy[k2], cz_ = a.sz[k2];
-        const float dx_ = a.sx[k3], dy_ = a.sy[k3], dz_ = a.sz[k3];
+        float ax, ay, az, bx, by, bz, cx_, cy_, cz_, dx_, dy_, dz_;
+        fetch(k, ax, ay, az);
+        fetch(k1, bx, by, bz);
+        fetch(k2, cx_, cy_, cz_);
+        fetch(k3, dx_, dy_, dz_);
         const bool h0 = sqdist_f32(ax, ay, az, qx, qy, qz) < a.sq_radius;
         const bool h1 = k + 1 < e && sqdist_f32(bx, by, bz, qx, qy, qz) < a.sq_radius;
         const bool h2 = k + 2 < e && sqdist_f32(cx_, cy_, cz_, qx, qy, qz) < a.sq_radius;
@@ -306,16 +326,13 @@ __global__ __launch_bounds__(kFitBlock) void k_mls_fit(MlsArgs a) {
         const uint32_t code = nbr_code[min(t, K - 1)][tid];
         return run_base[code >> 12][tid] + static_cast<int32_t>(code & 4095u);
       };
-      int32_t k0 = index_of(0), k1 = index_of(1);
-      float ax = a.sx[k0], ay = a.sy[k0], az = a.sz[k0];
-      float bx = a.sx[k1], by = a.sy[k1], bz = a.sz[k1];
+      float ax, ay, az, bx, by, bz;
+      fetch(index_of(0), ax, ay, az);
+      fetch(index_of(1), bx, by, bz);
       for (int32_t t = 0; t < K; ++t) {
         const float px = ax, py = ay, pz = az;
         ax = bx; ay = by; az = bz;
-        const int32_t k2 = index_of(t + 2);
-        bx = a.sx[k2];
-        by = a.sy[k2];
-        bz = a.sz[k2];
+        fetch(index_of(t + 2), bx, by, bz);
         body(px, py, pz);
       }
     } else {
@@ -1440,7 +1457,10 @@ static int mls_run(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *
   }
   {
     LaunchTimer t(ctx, PCP_K_MLS_FIT);
-    hipLaunchKernelGGL(k_mls_fit, dim3(static_cast<uint32_t>(div_up(n, kFitBlock))), dim3(kFitBlock), 0, ctx->stream, a);
+    if (n < (int64_t(1) << 30))
+      hipLaunchKernelGGL(k_mls_fit<true>, dim3(static_cast<uint32_t>(div_up(n, kFitBlock))), dim3(kFitBlock), 0, ctx->stream, a);
+    else
+      hipLaunchKernelGGL(k_mls_fit<false>, dim3(static_cast<uint32_t>(div_up(n, kFitBlock))), dim3(kFitBlock), 0, ctx->stream, a);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   if (p->upsampling == 3) return voxel_grid_dilation(ctx, cv, p, g, out_count);
