@@ -51,6 +51,10 @@ def main():
         slack = float(rng.choice([0.05, 0.05, 0.0, 0.2]))
         cull.downsample_factor = ocull.downsample_factor = ds
         cull.depth_slack = ocull.depth_slack = slack
+        # the cull routine and the match-back arithmetic: mostly the defaults (z-buffer, fp32 round trip)
+        cull.cull_mode = ocull.cull_mode = int(rng.choice([0, 0, 0, 1]))
+        cull.match_mode = ocull.match_mode = int(rng.choice([1, 1, 0]))
+        adjust = bool(rng.integers(0, 2))  # generateColorMap's HSV round trip inside the upload
         T_opt = None
         if case % 3 == 2:
             T_opt = np.eye(4)
@@ -59,8 +63,12 @@ def main():
         ctx.set_camera(cam_struct(capi, cd), cull)
         ctx.upload_cloud(x, y, z)
         ctx.set_frames(poses, T_opt)
+        ctx.set_image_adjust(adjust)
         for f, im in enumerate(imgs):
             ctx.upload_image(f, im)
+        if adjust:
+            adj = {id(im): oc.hsv_round_trip(im) for im in imgs[:8]}
+            imgs = [adj[id(im)] for im in imgs]
         ref = oc.colorize(cam_struct(oc, cd), ocull, x, y, z, poses, imgs, T_opt=T_opt, threads=oc.hardware_threads(), want_top=True)
         ctx.depth_pass()
         ctx.colour_reset()
@@ -71,11 +79,13 @@ def main():
         ok = ok and np.array_equal(one["rgb"], ref["rgb"]) and np.array_equal(one["has"], ref["has"])
         for f in (0, F // 2, F - 1):
             w2c, _ = oc.pose_to_matrices(poses[f], T_opt)
-            _, dmap, _ = oc.cull_frame(cam_struct(oc, cd), ocull, w2c, x, y, z)
-            ok = ok and np.array_equal(ctx.download_depth_map(f).view(np.uint32), dmap.view(np.uint32))
+            keep_r, dmap, _ = oc.cull_frame(cam_struct(oc, cd), ocull, w2c, x, y, z)
+            if ocull.cull_mode == 0:  # the HPR-candidate mode has no depth maps
+                ok = ok and np.array_equal(ctx.download_depth_map(f).view(np.uint32), dmap.view(np.uint32))
+            ok = ok and np.array_equal(ctx.cull_frame(f)[0], keep_r)
         ctx.close()
         print(f"case {case:3d} cam={'tiny' if case % 2 == 0 else 'cfg '} dist={case % len(DIST)} ds={ds:2d} slack={slack:.2f} "
-              f"T_opt={'y' if T_opt is not None else 'n'} coloured={int(ref['has'].sum()):7d}  {'ok' if ok else 'MISMATCH'}", flush=True)
+              f"T_opt={'y' if T_opt is not None else 'n'} cull={ocull.cull_mode} match={ocull.match_mode} hsv={int(adjust)} coloured={int(ref['has'].sum()):7d}  {'ok' if ok else 'MISMATCH'}", flush=True)
         if not ok:
             sys.exit(1)
     print("all cases identical")
