@@ -620,6 +620,10 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->mls_normal.release();
   ctx->mls_curv.release();
   ctx->mls_index.release();
+  ctx->mls_alt_xyz.release();
+  ctx->mls_alt_normal.release();
+  ctx->mls_alt_curv.release();
+  ctx->mls_alt_index.release();
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }

@@ -199,6 +199,9 @@ struct pcp_context {
   pcp::DevBuf<int64_t> v_vox;      // occupied voxels (linear index) in key order
   pcp::DevBuf<float> mls_xyz, mls_normal, mls_curv;
   pcp::DevBuf<int32_t> mls_index;
+  // second set: pcp_cloud_smooth compacts the survivors of its last SOR into it and swaps the sets
+  pcp::DevBuf<float> mls_alt_xyz, mls_alt_normal, mls_alt_curv;
+  pcp::DevBuf<int32_t> mls_alt_index;
   int64_t mls_count = 0;
   double sor_redo_fraction = 0.0;  // diagnostic: share of points the SOR selection kernel handed to the heap kernel
 

@@ -1110,7 +1110,8 @@ __device__ __forceinline__ uint32_t ordered_bits(float f) {
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
-// bounding box as order-preserving uint keys: box[0..2] = min, box[3..5] = max
+// bounding box as order-preserving uint keys: box[a * kBoxStride] = min of axis a, box[(3 + a) * kBoxStride] = max
+constexpr int kBoxStride = 64;
 __global__ __launch_bounds__(kMB) void k_bbox(const float *__restrict__ x, const float *__restrict__ y,
                                               const float *__restrict__ z, int64_t n, uint32_t *__restrict__ box) {
   uint32_t lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
@@ -1138,15 +1139,28 @@ __global__ __launch_bounds__(kMB) void k_bbox(const float *__restrict__ x, const
       hi[a] = max(hi[a], k[a]);
     }
   }
+  // wavefront, then workgroup, then one atomic per workgroup and bound on a cache line of its own (kBoxStride words
+  // apart): the first version's 6 atomics per wavefront on one line -- 98 k of them, serialised at the L2 -- took
+  // 1.1 ms of the kernel's 1.12 ms at 10 M points
+  __shared__ uint32_t part[6][kMB / 64];
   for (int a = 0; a < 3; ++a) {
     for (int o = 32; o >= 1; o >>= 1) {
       lo[a] = min(lo[a], static_cast<uint32_t>(__shfl_xor(static_cast<int>(lo[a]), o, 64)));
       hi[a] = max(hi[a], static_cast<uint32_t>(__shfl_xor(static_cast<int>(hi[a]), o, 64)));
     }
     if ((threadIdx.x & 63) == 0) {
-      atomicMin(box + a, lo[a]);
-      atomicMax(box + 3 + a, hi[a]);
+      part[a][threadIdx.x >> 6] = lo[a];
+      part[3 + a][threadIdx.x >> 6] = hi[a];
     }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    uint32_t v = part[threadIdx.x][0];
+    for (int w = 1; w < kMB / 64; ++w) v = threadIdx.x < 3 ? min(v, part[threadIdx.x][w]) : max(v, part[threadIdx.x][w]);
+    if (threadIdx.x < 3)
+      atomicMin(box + threadIdx.x * kBoxStride, v);
+    else
+      atomicMax(box + threadIdx.x * kBoxStride, v);
   }
 }
 
@@ -1245,6 +1259,28 @@ static int build_grid(pcp_context *ctx, const CloudView &cv, float cell, float r
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   *out = g;
+  return PCP_OK;
+}
+
+// keep the `kept` result rows (of m) that keep_index names, in order.  They go into the context's second set of result
+// buffers, sized like the first (m, not kept), and the sets are swapped: either set then serves the next run without a
+// hipMalloc / hipFree pair (fresh buffers per call cost the enableMLS chain 1.5 ms).
+static int compact_results(pcp_context *ctx, const int32_t *keep_index, int64_t m, int64_t kept) {
+  const size_t sm = static_cast<size_t>(m);
+  PCP_HIP_TRY(ctx, ctx->mls_alt_xyz.ensure(std::max(3 * sm + 4, ctx->mls_xyz.count)));
+  PCP_HIP_TRY(ctx, ctx->mls_alt_normal.ensure(std::max(3 * sm + 4, ctx->mls_normal.count)));
+  PCP_HIP_TRY(ctx, ctx->mls_alt_curv.ensure(std::max(sm + 4, ctx->mls_curv.count)));
+  PCP_HIP_TRY(ctx, ctx->mls_alt_index.ensure(std::max(sm + 4, ctx->mls_index.count)));
+  if (kept > 0) {
+    hipLaunchKernelGGL(k_voxel_compact, dim3(blocks_of(kept)), dim3(kMB), 0, ctx->stream, keep_index, kept, ctx->mls_xyz.p,
+                       ctx->mls_normal.p, ctx->mls_curv.p, ctx->mls_index.p, ctx->mls_alt_xyz.p, ctx->mls_alt_normal.p,
+                       ctx->mls_alt_curv.p, ctx->mls_alt_index.p);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  std::swap(ctx->mls_xyz, ctx->mls_alt_xyz);
+  std::swap(ctx->mls_normal, ctx->mls_alt_normal);
+  std::swap(ctx->mls_curv, ctx->mls_alt_curv);
+  std::swap(ctx->mls_index, ctx->mls_alt_index);
   return PCP_OK;
 }
 
@@ -1355,28 +1391,8 @@ static int voxel_grid_dilation(pcp_context *ctx, const CloudView &cv, const pcp_
     int rc = compact_flags(ctx, ctx->m_flag.p, static_cast<int64_t>(total), ctx->s_cell.p, static_cast<int64_t>(total), &kept);
     if (rc != PCP_OK) return rc;
     if (kept != static_cast<int64_t>(total)) {
-      const size_t sk = static_cast<size_t>(kept);
-      DevBuf<float> nx_, nn_, nc_;
-      DevBuf<int32_t> ni_;
-      PCP_HIP_TRY(ctx, nx_.ensure(3 * sk + 4));
-      PCP_HIP_TRY(ctx, nn_.ensure(3 * sk + 4));
-      PCP_HIP_TRY(ctx, nc_.ensure(sk + 4));
-      PCP_HIP_TRY(ctx, ni_.ensure(sk + 4));
-      if (kept > 0) {
-        LaunchTimer t(ctx, PCP_K_MLS_VOXEL);
-        hipLaunchKernelGGL(k_voxel_compact, dim3(blocks_of(kept)), dim3(kMB), 0, ctx->stream, ctx->s_cell.p, kept,
-                           ctx->mls_xyz.p, ctx->mls_normal.p, ctx->mls_curv.p, ctx->mls_index.p, nx_.p, nn_.p, nc_.p, ni_.p);
-        PCP_HIP_TRY(ctx, hipGetLastError());
-      }
-      PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-      std::swap(ctx->mls_xyz, nx_);
-      std::swap(ctx->mls_normal, nn_);
-      std::swap(ctx->mls_curv, nc_);
-      std::swap(ctx->mls_index, ni_);
-      nx_.release();
-      nn_.release();
-      nc_.release();
-      ni_.release();
+      LaunchTimer t(ctx, PCP_K_MLS_VOXEL);
+      if ((rc = compact_results(ctx, ctx->s_cell.p, static_cast<int64_t>(total), kept)) != PCP_OK) return rc;
       m = kept;
     }
   }
@@ -1601,13 +1617,14 @@ static int view_of(pcp_context *ctx, const float *x, const float *y, const float
   cv->n = n;
   for (int a = 0; a < 3; ++a) cv->mn[a] = cv->mx[a] = 0.0f;
   if (n == 0) return PCP_OK;
-  PCP_HIP_TRY(ctx, ctx->s_u32.ensure(8));
-  const uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->s_u32.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_bbox, dim3(static_cast<uint32_t>(std::max<int64_t>(1, std::min<int64_t>(div_up(n, 4 * kMB), 4096)))),
+  PCP_HIP_TRY(ctx, ctx->s_u32.ensure(6 * kBoxStride));
+  uint32_t box[6 * kBoxStride];
+  for (int a = 0; a < 6; ++a)
+    for (int w = 0; w < kBoxStride; ++w) box[a * kBoxStride + w] = a < 3 ? 0xffffffffu : 0u;
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->s_u32.p, box, sizeof(box), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_bbox, dim3(static_cast<uint32_t>(std::max<int64_t>(1, std::min<int64_t>(div_up(n, 8 * kMB), 2048)))),
                      dim3(kMB), 0, ctx->stream, x, y, z, n, ctx->s_u32.p);
   PCP_HIP_TRY(ctx, hipGetLastError());
-  uint32_t box[6];
   PCP_HIP_TRY(ctx, hipMemcpyAsync(box, ctx->s_u32.p, sizeof(box), hipMemcpyDeviceToHost, ctx->stream));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   auto decode = [](uint32_t k) {
@@ -1617,8 +1634,8 @@ static int view_of(pcp_context *ctx, const float *x, const float *y, const float
     return f;
   };
   for (int a = 0; a < 3; ++a) {
-    cv->mn[a] = decode(box[a]);
-    cv->mx[a] = decode(box[3 + a]);
+    cv->mn[a] = decode(box[a * kBoxStride]);
+    cv->mx[a] = decode(box[(3 + a) * kBoxStride]);
   }
   return PCP_OK;
 }
@@ -1743,29 +1760,7 @@ int pcp_cloud_smooth(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_cou
   PCP_HIP_TRY(ctx, ctx->s_cell.ensure(static_cast<size_t>(m) + 4));
   int64_t kept = 0;
   if ((rc = compact_flags(ctx, ctx->m_flag.p, m, ctx->s_cell.p, m, &kept)) != PCP_OK) return rc;
-  if (kept != m) {
-    const size_t sk = static_cast<size_t>(kept);
-    DevBuf<float> nx_, nn_, nc_;
-    DevBuf<int32_t> ni_;
-    PCP_HIP_TRY(ctx, nx_.ensure(3 * sk + 4));
-    PCP_HIP_TRY(ctx, nn_.ensure(3 * sk + 4));
-    PCP_HIP_TRY(ctx, nc_.ensure(sk + 4));
-    PCP_HIP_TRY(ctx, ni_.ensure(sk + 4));
-    if (kept > 0) {
-      hipLaunchKernelGGL(k_voxel_compact, dim3(blocks_of(kept)), dim3(kMB), 0, ctx->stream, ctx->s_cell.p, kept, ctx->mls_xyz.p,
-                         ctx->mls_normal.p, ctx->mls_curv.p, ctx->mls_index.p, nx_.p, nn_.p, nc_.p, ni_.p);
-      PCP_HIP_TRY(ctx, hipGetLastError());
-    }
-    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    std::swap(ctx->mls_xyz, nx_);
-    std::swap(ctx->mls_normal, nn_);
-    std::swap(ctx->mls_curv, nc_);
-    std::swap(ctx->mls_index, ni_);
-    nx_.release();
-    nn_.release();
-    nc_.release();
-    ni_.release();
-  }
+  if (kept != m && (rc = compact_results(ctx, ctx->s_cell.p, m, kept)) != PCP_OK) return rc;
   ctx->mls_count = kept;
   if (out_count) *out_count = kept;
   return PCP_OK;
