@@ -612,6 +612,8 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->m_sums.release();
   ctx->c_index.release();
   ctx->c_xyz.release();
+  ctx->c_mark.release();
+  ctx->c_where.release();
   ctx->c_xyz2.release();
   ctx->v_bitmap.release();
   ctx->v_vox.release();

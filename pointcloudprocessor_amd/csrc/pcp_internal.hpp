@@ -193,6 +193,8 @@ struct pcp_context {
   pcp::DevBuf<uint8_t> m_flag;   // n
   pcp::DevBuf<double> m_sums;    // SOR statistics
   pcp::DevBuf<int32_t> c_index;  // pcp_cloud_smooth: survivors of the 1st SOR (indices into the uploaded cloud)
+  pcp::DevBuf<uint8_t> c_mark;    // pcp_cloud_smooth: per uploaded point, survives the whole chain
+  pcp::DevBuf<int32_t> c_where;   // ... and the result row that holds it
   pcp::DevBuf<float> c_xyz, c_xyz2;  // pcp_cloud_smooth: intermediate clouds (SoA)
   pcp::DevBuf<uint32_t> v_bitmap;  // dilated voxel set, dense bitmap over the bounding box
   pcp::DevBuf<int32_t> v_offsets;  // exclusive popcount prefix per bitmap word

@@ -6,7 +6,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402,F401
 
 from pointcloudprocessor_amd import capi, synth  # noqa: E402

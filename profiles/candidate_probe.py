@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """How many (point, keyframe) pairs are cull candidates with a colour pixel, and how many of them survive the depth
 test (the samples that fetch a texel): 10 M points, 16 keyframes sampled from the 256, both cameras."""
+import os
 import json
 import sys
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402,F401
 
 from pointcloudprocessor_amd import capi, synth  # noqa: E402

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """enableMLS=1 chain (SOR -> MLS -> SOR, cloudSmooth.cpp:109-164) at 10 M points: wall time and per-kernel-group
 times.  python profiles/chain_probe.py [points]"""
+import os
 import json
 import sys
 import time
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402,F401
 
 from pointcloudprocessor_amd import capi, synth  # noqa: E402

@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """SURVEY 8(d)(i) boundary, pieces timed separately: images from pinned host memory -> colours on the host.
 python profiles/pipeline_probe.py"""
+import os
 import json
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from pointcloudprocessor_amd import capi, synth  # noqa: E402

@@ -1,8 +1,9 @@
 """List-scheduling simulation behind the longest-work-first tile order: downloads the tile x keyframe
 masks of the C3 scene (pcp_tile_masks) and compares the makespan of cloud order with 4-tile workgroups against
 longest-first order with 1-tile workgroups.   python profiles/sched_sim.py   (on an MI355X)"""
+import os
 import sys, heapq, numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pointcloudprocessor_amd import capi, synth
 ctx = capi.Context(0)
 ctx.set_camera(capi.camera_from_dict(synth.camera_dict("cfg")))

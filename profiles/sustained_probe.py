@@ -1,11 +1,12 @@
 """Step time over a long run (clock / power behaviour under sustained load): prints the mean step time of
 consecutive 20-step blocks, with and without the result download.   python profiles/sustained_probe.py"""
+import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from pointcloudprocessor_amd import pipeline, synth  # noqa: E402

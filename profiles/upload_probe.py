@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Upload path probe: 256 BGR8 keyframes from pinned host memory through pcp_upload_image_async (copy + pack per
 keyframe on the upload lanes), against one plain pinned H2D copy of the same bytes.  python profiles/upload_probe.py [cfg|ref]"""
+import os
 import json
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from pointcloudprocessor_amd import capi, synth  # noqa: E402
