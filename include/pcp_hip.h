@@ -313,6 +313,10 @@ int pcp_tile_masks(pcp_context *ctx, int64_t *tiles, int32_t *mask_words, uint32
 /* diagnostic: share of the points of the last pcp_sor / pcp_cloud_smooth SOR pass that the selection kernel handed
  * to the heap kernel (fewer than mean_k + 1 neighbours within one grid cell, or a crowded boundary bin) */
 int pcp_sor_redo_fraction(pcp_context *ctx, double *fraction);
+/* diagnostic: the mean distance to the mean_k nearest neighbours of every uploaded point, as the last pcp_sor computed
+ * it (the quantity StatisticalOutlierRemoval thresholds; statistical_outlier_removal.hpp [upstream] keeps it private).
+ * Valid until the next call that smooths or filters; capacity >= the number of uploaded points. */
+int pcp_sor_distances(pcp_context *ctx, int64_t capacity, float *out_distance);
 /* diagnostic: the kernels replace three IEEE divisions of the projection (pinhole.hpp:17-18 x/z, y/z in fp64;
  * view_culling.cpp:88 u/14, v/14 in fp32) by shorter sequences that are proven to return the same correctly
  * rounded quotients (pcp_device.hpp).  This runs both forms on the device and counts disagreements:

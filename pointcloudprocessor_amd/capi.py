@@ -424,6 +424,12 @@ class Context:
         return cnt.value
 
     # -- NID extrinsic refinement -----------------------------------------
+    def sor_distances(self) -> np.ndarray:
+        """mean distance to the mean_k nearest neighbours per uploaded point, from the last sor() call"""
+        out = np.empty(self.n, np.float32)
+        self._check(self.lib.pcp_sor_distances(self.h, C.c_int64(len(out)), _ptr(out)))
+        return out
+
     def sor_redo_fraction(self) -> float:
         v = C.c_double()
         self._check(self.lib.pcp_sor_redo_fraction(self.h, C.byref(v)))

@@ -381,6 +381,7 @@ static int store_cloud(pcp_context *ctx, const float *x, const float *y, const f
   PCP_HIP_TRY(ctx, ctx->sxyz.ensure(3 * plane + 4));
   PCP_HIP_TRY(ctx, ctx->perm.ensure(sn + 4));
   ctx->n = n;
+  ctx->sor_distances_live = false;
   ctx->n_tiles = 0;
   ctx->tile_order_live = false;
   ctx->have_intensity = false;

@@ -193,6 +193,7 @@ struct pcp_context {
   pcp::DevBuf<uint8_t> m_flag;   // n
   pcp::DevBuf<double> m_sums;    // SOR statistics
   pcp::DevBuf<int32_t> c_index;  // pcp_cloud_smooth: survivors of the 1st SOR (indices into the uploaded cloud)
+  bool sor_distances_live = false;  // m_tmp holds the mean distances of the last pcp_sor (caller's order)
   pcp::DevBuf<uint8_t> c_mark;    // pcp_cloud_smooth: per uploaded point, survives the whole chain
   pcp::DevBuf<int32_t> c_where;   // ... and the result row that holds it
   pcp::DevBuf<float> c_xyz, c_xyz2;  // pcp_cloud_smooth: intermediate clouds (SoA)

@@ -861,56 +861,76 @@ __global__ __launch_bounds__(kSorBlock) void k_sor_mean_distance(const float *__
   distances[remap ? remap[order[j]] : order[j]] = static_cast<float>(sum / static_cast<double>(mean_k));
 }
 
-// Selection without a heap (the common case).  All points closer than `limit` (= 0.999 grid cells) lie in the
-// 3x3x3 cells around the query, and the cell size is chosen so that this ball holds ~1.35 (k + 1) points on
-// average.  A histogram pass counts the candidates inside the ball in 32 equal-width bins of the squared distance
-// (16-bit counters in LDS, [bin][lane]); the bin in which the count reaches k + 1 is the boundary bin.  Where the
-// cloud is denser than average that bin is crowded: it is then histogrammed again into 32 sub-bins (up to two
-// refinements), every level classifying a candidate with the same arithmetic.  The last pass adds sqrt(d) of every
-// candidate below the boundary and lists the boundary bin's members (at most 16), of which the smallest missing
-// ones are picked.  A lane whose ball holds fewer than k + 1 points, or whose boundary stays crowded (many equal
-// distances), is flagged and redone by the heap kernel: the result is always the exact sum over the k + 1
-// nearest, minus the nearest (the query itself).
-constexpr int kSelBins = 32;
-constexpr int kSelList = 16;
+// Selection without a heap (the common case), one wavefront per 64 consecutive cell-sorted points.
+//
+// All points closer than `limit` (= 0.999 grid cells) lie in the 3x3x3 cells around the query, and the cell size is
+// chosen so that this ball holds ~1.35 (k + 1) points on average.  A histogram pass counts the candidates inside the
+// ball in 32 equal-width bins of the squared distance (16-bit counters in LDS, [bin][lane]; a 33rd row takes the
+// candidates outside the ball, so the pass has no test and no branch per candidate); the bin in which the count reaches
+// k + 1 is the boundary bin.  Where the cloud is denser than average that bin is crowded: it is then histogrammed
+// again into 32 sub-bins (up to two refinements), every level classifying a candidate with the same arithmetic.  The
+// last pass appends every candidate up to and including the boundary bin to a short per-lane list in LDS; whenever a
+// list is nearly full the wavefront drains the lists in a dense loop (sqrt and the fp64 sum of the entries below the
+// boundary with every lane busy; the boundary bin's members, at most kSelList, move to a second list), and at the
+// end the smallest missing members are picked.  A lane whose ball holds fewer than k + 1 points, or whose boundary
+// stays crowded (many equal distances), is flagged and redone by the heap kernel: the result is always the exact sum
+// over the k + 1 nearest, minus the nearest (the query itself).  (The fp64 additions are exact -- 24-bit significands
+// within a few binades, < 2^8 terms -- so the order of the terms does not matter.)
+//
+// Each lane walks the 9 runs of its own 27 cells, four candidates per trip: three 16-byte buffer loads (one per
+// coordinate plane; the descriptor keeps the base in SGPRs), packed fp32 arithmetic on two candidates at a time (each
+// component rounded as the scalar form: (dx dx + dy dy) + dz dz, no contraction).  A run's ragged end is one more trip
+// whose missing candidates sit at infinity (outside every ball).  ~9 VALU instructions per candidate and pass; the
+// first version (one dword load per coordinate, scalar arithmetic, a test and a branch per candidate, sqrt inside the
+// candidate loop) issued 25.
+constexpr int kSelBins = 32;    // + 1 row for candidates outside the ball
+constexpr int kSelList = 16;    // members of the boundary bin a lane can pick from
+constexpr int kSelDrain = 9;    // entries of the per-lane list of the last pass
 constexpr int kSelLevels = 3;
-__global__ __launch_bounds__(kSorBlock) void k_sor_select(const float *__restrict__ sx, const float *__restrict__ sy,
-                                                          const float *__restrict__ sz,
-                                                          const int32_t *__restrict__ order,
-                                                          const int32_t *__restrict__ remap,
-                                                          const int32_t *__restrict__ start, int64_t n, GridDesc g,
-                                                          int32_t mean_k, float *__restrict__ distances,
-                                                          uint8_t *__restrict__ redo, int32_t reach,
-                                                          const int32_t *__restrict__ todo, int64_t todo_n) {
-  __shared__ uint16_t bins[kSelBins][kSorBlock];
-  __shared__ float list[kSelList][kSorBlock];
-  const int tid = threadIdx.x;
-  // todo == nullptr: every point; else only the cell-sorted positions it names (the lanes the first pass, with a ball
-  // of one cell, flagged: borders and thin spots of the surface -- a ball of `reach` = 2 cells holds 4x the points)
-  const int64_t t = static_cast<int64_t>(blockIdx.x) * kSorBlock + tid;
-  if (t >= (todo ? todo_n : n)) return;
-  const int64_t j = todo ? todo[t] : t;
+constexpr int kSelWave = 64;
+constexpr int kSelLdsWords = (kSelDrain + kSelList) * kSelWave;  // the bins (33 x 32 words) share the list's space
+typedef float sel_v2f __attribute__((ext_vector_type(2)));
+typedef float sel_v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t sel_v4u __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(kSelWave) void k_sor_select(const float *__restrict__ sx, const float *__restrict__ sy,
+                                                         const float *__restrict__ sz,
+                                                         const int32_t *__restrict__ order,
+                                                         const int32_t *__restrict__ remap,
+                                                         const int32_t *__restrict__ start, int64_t n, GridDesc g,
+                                                         int32_t mean_k, float *__restrict__ distances,
+                                                         uint8_t *__restrict__ redo) {
+#pragma clang fp contract(off)
+  __shared__ uint32_t sel_lds[kSelLdsWords];
+  float *list = reinterpret_cast<float *>(sel_lds);            // [kSelDrain][64]
+  float *members = list + kSelDrain * kSelWave;                // [kSelList][64]
+  const int lane = threadIdx.x;
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kSelWave + lane;
+  const bool live = t < n;
+  const int64_t j = min(t, n - 1);  // lanes past the end shadow the last point and write nothing
   const int k = mean_k + 1;
   const float qx = sx[j], qy = sy[j], qz = sz[j];
   int32_t cx, cy, cz;
   grid_coords(g, qx, qy, qz, cx, cy, cz);
   const float cell = 1.0f / g.inv_cell;
-  // every point closer than reach cells lies in the (2 reach + 1)^3 block; 0.999: fp32 slop of the cell assignment
-  const float limit = static_cast<float>(reach) * cell * 0.999f, limit2 = limit * limit;
-  const int32_t x0 = max(cx - reach, 0), x1 = min(cx + reach, g.nx - 1);
-  const int32_t y0 = max(cy - reach, 0), y1 = min(cy + reach, g.ny - 1);
-  const int32_t z0 = max(cz - reach, 0), z1 = min(cz + reach, g.nz - 1);
+  // every point closer than one cell lies in the 27 cells; 0.999: fp32 slop of the cell assignment
+  const float limit = cell * 0.999f, limit2 = limit * limit;
+  const int32_t x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+  const int32_t y0 = max(cy - 1, 0), y1 = min(cy + 1, g.ny - 1);
+  const int32_t z0 = max(cz - 1, 0), z1 = min(cz + 1, g.nz - 1);
   // level l splits [lo[l], lo[l] + 32 / sc[l]) into 32 bins; bnd[l] = its boundary bin (levels > `level` unused)
   float lo[kSelLevels] = {0.0f, 0.0f, 0.0f}, sc[kSelLevels] = {static_cast<float>(kSelBins) / limit2, 0.0f, 0.0f};
   int bnd[kSelLevels] = {0, 0, 0};
+  const float sc0 = sc[0];
   // -1 below the boundary, +1 above it (or outside the ball), 0 in the boundary bin of the deepest level so far;
   // `deepest` returns that level's bin for the histogram pass
   auto classify = [&](float d, int levels, int &deepest) -> int {
-    if (!(d < limit2)) return 1;
+    const float t0 = d * sc0;
+    if (!(t0 < static_cast<float>(kSelBins))) return 1;
 #pragma unroll
     for (int l = 0; l < kSelLevels; ++l) {  // static indices: lo / sc / bnd stay in registers
       if (l >= levels) break;
-      const int b = min(max(static_cast<int>((d - lo[l]) * sc[l]), 0), kSelBins - 1);
+      const int b = l == 0 ? static_cast<int>(t0) : min(max(static_cast<int>((d - lo[l]) * sc[l]), 0), kSelBins - 1);
       if (l == levels - 1) {
         deepest = b;
         return 0;
@@ -920,42 +940,73 @@ __global__ __launch_bounds__(kSorBlock) void k_sor_select(const float *__restric
     }
     return 0;
   };
-  // The candidate coordinates come through buffer descriptors (one per coordinate plane: uniform base in SGPRs,
-  // 32-bit byte offset per lane), so a candidate costs one shift instead of a 64-bit address per plane; four
-  // candidates per trip (12 loads in flight).  The planes hold n < 2^30 floats: offsets and sizes fit 32 bits.
+  // The candidate coordinates come through buffer descriptors (one per coordinate plane: uniform base in SGPRs, 32-bit
+  // byte offset per lane; a 16-byte load needs dword alignment only).  The planes hold n < 2^30 floats.
   const uint32_t plane_bytes = static_cast<uint32_t>(n) * 4u;
   const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sx), 0, plane_bytes, 0x00020000);
   const auto ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sy), 0, plane_bytes, 0x00020000);
   const auto rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sz), 0, plane_bytes, 0x00020000);
-  auto cand_d2 = [&](uint32_t q) {
-    const uint32_t off = q * 4u;
-    const float px = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
-    const float py = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, off, 0, 0));
-    const float pz = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rz, off, 0, 0));
-    return sqdist_f32(px, py, pz, qx, qy, qz);
+  const sel_v2f qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+  auto d2_of = [&](sel_v2f px, sel_v2f py, sel_v2f pz) {
+    const sel_v2f dx = px - qx2, dy = py - qy2, dz = pz - qz2;
+    return (dx * dx + dy * dy) + dz * dz;
   };
-  auto for_candidates = [&](auto &&body) {
+  auto load4 = [&](decltype(rx) r, uint32_t q) {
+    const sel_v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, q * 4u, 0, 0);
+    return sel_v4f{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+  };
+  // squared distances of this lane's candidates, four per call: four(d of candidates 0 1, d of candidates 2 3)
+  auto for_candidates = [&](bool active, auto &&four) {
+    if (!active) return;
     for (int32_t zz = z0; zz <= z1; ++zz)
       for (int32_t yy = y0; yy <= y1; ++yy) {
         const int32_t row = (zz * g.ny + yy) * g.nx;
-        const uint32_t b = static_cast<uint32_t>(start[row + x0]), e = static_cast<uint32_t>(start[row + x1 + 1]);
-        for (uint32_t q = b; q < e; q += 4) {
-          const uint32_t q1 = min(q + 1, e - 1), q2 = min(q + 2, e - 1), q3 = min(q + 3, e - 1);
-          const float d0 = cand_d2(q), d1 = cand_d2(q1), d2 = cand_d2(q2), d3 = cand_d2(q3);
-          body(d0);
-          if (q + 1 < e) body(d1);
-          if (q + 2 < e) body(d2);
-          if (q + 3 < e) body(d3);
+        uint32_t q = static_cast<uint32_t>(start[row + x0]);
+        const uint32_t e = static_cast<uint32_t>(start[row + x1 + 1]);
+        if (q + 4 <= e) {
+          // the next four candidates are on their way while these four are tested
+          sel_v4f X = load4(rx, q), Y = load4(ry, q), Z = load4(rz, q);
+          for (;;) {
+            q += 4;
+            const bool more = q + 4 <= e;
+            sel_v4f Xn = X, Yn = Y, Zn = Z;
+            if (more) {
+              Xn = load4(rx, q);
+              Yn = load4(ry, q);
+              Zn = load4(rz, q);
+            }
+            four(d2_of(sel_v2f{X[0], X[1]}, sel_v2f{Y[0], Y[1]}, sel_v2f{Z[0], Z[1]}),
+                 d2_of(sel_v2f{X[2], X[3]}, sel_v2f{Y[2], Y[3]}, sel_v2f{Z[2], Z[3]}));
+            if (!more) break;
+            X = Xn;
+            Y = Yn;
+            Z = Zn;
+          }
+        }
+        if (q < e) {  // 1..3 candidates left: the others at infinity (loads past the planes' end read zeros)
+          const uint32_t rem = e - q;
+          const sel_v4f X = load4(rx, q), Y = load4(ry, q), Z = load4(rz, q);
+          four(d2_of(sel_v2f{X[0], rem > 1 ? X[1] : INFINITY}, sel_v2f{Y[0], Y[1]}, sel_v2f{Z[0], Z[1]}),
+               d2_of(sel_v2f{rem > 2 ? X[2] : INFINITY, INFINITY}, sel_v2f{Y[2], Y[3]}, sel_v2f{Z[2], Z[3]}));
         }
       }
   };
-  // 16-bit counters, two lanes to a dword, bumped by one no-return LDS atomic (no read - wait - write round trip)
-  auto bump = [&](int b) {
-    atomicAdd(reinterpret_cast<uint32_t *>(&bins[b][tid & ~1]), (tid & 1) ? 0x10000u : 1u);
+  // 16-bit counters: lanes l and l + 32 share a dword (a row of 32 dwords: conflict-free whatever the bins)
+  const uint32_t bump_by = lane < 32 ? 1u : 0x10000u, bump_at = static_cast<uint32_t>(lane & 31) * 4u;
+  auto bump = [&](uint32_t b) {  // one no-return LDS atomic
+    atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(sel_lds) + b * 128u + bump_at), bump_by);
+  };
+  auto clear_bins = [&]() {
+    for (int w = lane; w < (kSelBins + 1) * 32; w += kSelWave) sel_lds[w] = 0;
+  };
+  auto bin_count = [&](int b) -> int {
+    const uint32_t v = sel_lds[b * 32 + (lane & 31)];
+    return static_cast<int>(lane < 32 ? (v & 0xffffu) : (v >> 16));
   };
   bool bad = false;
   {
-    // a counter cannot wrap: the 27 cells hold fewer candidates than it can count (else the heap kernel takes the lane)
+    // a counter cannot wrap (and carry into the lane it shares a dword with): the 27 cells hold fewer candidates than
+    // it can count, else the heap kernel takes the lane
     uint32_t total = 0;
     for (int32_t zz = z0; zz <= z1; ++zz)
       for (int32_t yy = y0; yy <= y1; ++yy) {
@@ -967,16 +1018,18 @@ __global__ __launch_bounds__(kSorBlock) void k_sor_select(const float *__restric
   int below = 0, level = 0, crowd = 0;
   // level 0 with the plain bin arithmetic (on a uniform cloud no lane needs more)
   {
-#pragma unroll
-    for (int b = 0; b < kSelBins; ++b) bins[b][tid] = 0;
-    const float sc0 = sc[0];
-    if (!bad)
-      for_candidates([&](float d) {
-        if (d < limit2) bump(min(static_cast<int>(d * sc0), kSelBins - 1));
-      });
+    clear_bins();
+    const sel_v2f sc2 = {sc0, sc0}, top2 = {static_cast<float>(kSelBins), static_cast<float>(kSelBins)};
+    for_candidates(!bad, [&](sel_v2f da, sel_v2f db) {
+      const sel_v2f ta = __builtin_elementwise_min(da * sc2, top2), tb = __builtin_elementwise_min(db * sc2, top2);  // NaN -> 32
+      bump(static_cast<uint32_t>(ta[0]));
+      bump(static_cast<uint32_t>(ta[1]));
+      bump(static_cast<uint32_t>(tb[0]));
+      bump(static_cast<uint32_t>(tb[1]));
+    });
     int boundary = -1;
     for (int b = 0; b < kSelBins; ++b) {
-      const int c = bins[b][tid];
+      const int c = bin_count(b);
       if (boundary < 0) {
         if (below + c >= k) {
           boundary = b;
@@ -987,7 +1040,7 @@ __global__ __launch_bounds__(kSorBlock) void k_sor_select(const float *__restric
       }
     }
     if (boundary < 0) bad = true;  // fewer than k + 1 points inside the ball
-    bnd[0] = boundary;
+    bnd[0] = max(boundary, 0);
   }
   // refinements, only in wavefronts that hold a lane with a crowded boundary bin
   while (__any(!bad && crowd > kSelList)) {
@@ -1002,17 +1055,22 @@ __global__ __launch_bounds__(kSorBlock) void k_sor_select(const float *__restric
           sc[l + 1] = sc[l] * static_cast<float>(kSelBins);
         }
       ++level;
-#pragma unroll
-      for (int b = 0; b < kSelBins; ++b) bins[b][tid] = 0;
     }
-    for_candidates([&](float d) {
-      int b = 0;
-      if (go && classify(d, level + 1, b) == 0) bump(b);
+    clear_bins();
+    auto one = [&](float d) {
+      int bb = 0;
+      if (classify(d, level + 1, bb) == 0) bump(static_cast<uint32_t>(bb));
+    };
+    for_candidates(go, [&](sel_v2f da, sel_v2f db) {
+      one(da[0]);
+      one(da[1]);
+      one(db[0]);
+      one(db[1]);
     });
     if (go) {
       int boundary = -1;
       for (int b = 0; b < kSelBins; ++b) {
-        const int c = bins[b][tid];
+        const int c = bin_count(b);
         if (boundary < 0) {
           if (below + c >= k) {
             boundary = b;
@@ -1031,55 +1089,98 @@ __global__ __launch_bounds__(kSorBlock) void k_sor_select(const float *__restric
 #pragma unroll
   for (int l = 0; l < kSelLevels; ++l)
     if (l == level) last_bnd = bnd[l];
-  if (!bad) {
-    // last pass: sum below the boundary, list the boundary bin's members
-    double sum = 0.0;
-    float smallest = FLT_MAX;
-    int listed = 0;
-    auto take = [&](float d, int c) {
-      if (c < 0) {
-        sum += static_cast<double>(sqrtf(d));
-        smallest = fminf(smallest, d);
-      } else if (c == 0) {
-        if (listed < kSelList) list[listed][tid] = d;
-        ++listed;
+  // last pass: candidates up to and including the boundary bin go to the list; drained when a lane's list fills up
+  double sum = 0.0;
+  float smallest = FLT_MAX;
+  int listed = 0, picked = 0;
+  const bool plain = !__any(level > 0);  // wave-uniform
+  const float below_t = static_cast<float>(bnd[0]);  // plain: bin < bnd[0]  <=>  d sc0 < bnd[0]
+  // correctly rounded sqrt of d == 0 or d >= 2^-96: the hardware estimate (1 ulp) moved to the neighbour the exact
+  // residuals ask for -- sqrtf() without its rescaling of tiny arguments and its class test (9 instructions, not 22);
+  // a lane that meets 0 < d < 2^-96 goes to the heap kernel, which calls sqrtf()
+  bool tiny = false;
+  auto sqrt_rn = [&](float d) {
+    tiny = tiny || (__float_as_uint(d) - 1u) < 0x0F7FFFFFu;
+    float r = __builtin_amdgcn_sqrtf(d);
+    const float r_dn = __uint_as_float(__float_as_uint(r) - 1u), r_up = __uint_as_float(__float_as_uint(r) + 1u);
+    const float e_dn = __fmaf_rn(-r_dn, r, d), e_up = __fmaf_rn(-r_up, r, d);
+    r = e_dn <= 0.0f ? r_dn : r;
+    r = e_up > 0.0f ? r_up : r;
+    return r;
+  };
+  auto drain = [&]() {
+    for (int e = 0; e < listed; ++e) {
+      const float d = list[e * kSelWave + lane];
+      bool is_below;
+      if (plain) {
+        is_below = d * sc0 < below_t;
+      } else {
+        int bb = 0;
+        const int c = classify(d, level + 1, bb);
+        is_below = c < 0 || (c == 0 && bb < last_bnd);
       }
-    };
-    if (!__any(level > 0)) {
-      const float sc0 = sc[0];
-      for_candidates([&](float d) {
-        if (d < limit2) {
-          const int b = min(static_cast<int>(d * sc0), kSelBins - 1);
-          take(d, b < last_bnd ? -1 : (b > last_bnd ? 1 : 0));
-        }
-      });
-    } else {
-      for_candidates([&](float d) {
-        int b = 0;
-        int c = classify(d, level + 1, b);
-        if (c == 0) c = b < last_bnd ? -1 : (b > last_bnd ? 1 : 0);
-        take(d, c);
-      });
+      if (is_below) {
+        sum += static_cast<double>(sqrt_rn(d));
+        smallest = fminf(smallest, d);
+      } else {
+        if (picked < kSelList) members[picked * kSelWave + lane] = d;
+        ++picked;
+      }
     }
-    // the k - below smallest members of the boundary bin (listed == crowd <= kSelList)
+    listed = 0;
+  };
+  auto append = [&](float d) {
+    list[listed * kSelWave + lane] = d;
+    ++listed;
+  };
+  if (plain) {
+    const sel_v2f sc2 = {sc0, sc0};
+    const float keep_below = static_cast<float>(bnd[0] + 1);  // bin <= bnd[0]  <=>  d sc0 < bnd[0] + 1
+    for_candidates(!bad, [&](sel_v2f da, sel_v2f db) {
+      const sel_v2f ta = da * sc2, tb = db * sc2;
+      if (ta[0] < keep_below) append(da[0]);
+      if (ta[1] < keep_below) append(da[1]);
+      if (tb[0] < keep_below) append(db[0]);
+      if (tb[1] < keep_below) append(db[1]);
+      if (__any(listed > kSelDrain - 4)) drain();
+    });
+  } else {
+    auto one = [&](float d) {
+      int bb = 0;
+      int c = classify(d, level + 1, bb);
+      if (c == 0 && bb > last_bnd) c = 1;
+      if (c <= 0) append(d);
+    };
+    for_candidates(!bad, [&](sel_v2f da, sel_v2f db) {
+      one(da[0]);
+      one(da[1]);
+      one(db[0]);
+      one(db[1]);
+      if (__any(listed > kSelDrain - 4)) drain();
+    });
+  }
+  drain();
+  if (picked > kSelList) bad = true;  // cannot happen (the passes classify alike); never trust a list that overflowed
+  if (!bad) {  // (`tiny` is settled inside)
+    // the k - below smallest members of the boundary bin (picked == crowd <= kSelList)
     for (int need = k - below; need > 0; --need) {
       int at = 0;
-      float best = list[0][tid];
-      for (int e = 1; e < listed; ++e) {
-        const float v = list[e][tid];
+      float best = members[lane];
+      for (int e = 1; e < picked; ++e) {
+        const float v = members[e * kSelWave + lane];
         if (v < best) {
           best = v;
           at = e;
         }
       }
-      sum += static_cast<double>(sqrtf(best));
+      sum += static_cast<double>(sqrt_rn(best));
       smallest = fminf(smallest, best);
-      list[at][tid] = FLT_MAX;
+      members[at * kSelWave + lane] = FLT_MAX;
     }
-    sum -= static_cast<double>(sqrtf(smallest));  // hit 0 of nearestKSearch(k + 1) is the query itself
-    distances[remap ? remap[order[j]] : order[j]] = static_cast<float>(sum / static_cast<double>(mean_k));
+    sum -= static_cast<double>(sqrt_rn(smallest));  // hit 0 of nearestKSearch(k + 1) is the query itself
+    if (live && !tiny) distances[remap ? remap[order[j]] : order[j]] = static_cast<float>(sum / static_cast<double>(mean_k));
   }
-  redo[j] = bad ? 1 : 0;
+  if (live) redo[j] = (bad || tiny) ? 1 : 0;
 }
 
 // sum and sum of squares (fp32 squares, as the reference) of the distances, fp64 accumulation
@@ -1493,6 +1594,7 @@ static int mls_run(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *
                    int64_t q_begin = 0, int64_t q_end = -1) {
   const int64_t n = cv.n;
   ctx->mls_count = 0;
+  ctx->sor_distances_live = false;  // m_tmp is reused
   if (out_count) *out_count = 0;
   if (n == 0) return PCP_OK;
   const size_t sn = static_cast<size_t>(n);
@@ -1619,16 +1721,13 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
     PCP_HIP_TRY(ctx, ctx->s_cell.ensure(sn + 8));
     {
       LaunchTimer t(ctx, PCP_K_SOR);
-      hipLaunchKernelGGL(k_sor_select, dim3(static_cast<uint32_t>(div_up(n, kSorBlock))), dim3(kSorBlock), 0, ctx->stream,
+      hipLaunchKernelGGL(k_sor_select, dim3(static_cast<uint32_t>(div_up(n, kSelWave))), dim3(kSelWave), 0, ctx->stream,
                          ctx->g_xyz.p, ctx->g_xyz.p + plane, ctx->g_xyz.p + 2 * plane, ctx->g_order.p, remap,
-                         ctx->g_start.p, n, g, mean_k, dist, ctx->m_flag.p, 1, static_cast<const int32_t *>(nullptr),
-                         int64_t(0));
+                         ctx->g_start.p, n, g, mean_k, dist, ctx->m_flag.p);
       PCP_HIP_TRY(ctx, hipGetLastError());
     }
     int64_t redo = 0;
     if ((rc = compact_flags(ctx, ctx->m_flag.p, n, ctx->s_cell.p, n, &redo)) != PCP_OK) return rc;
-    // (a second selection pass over the flagged lanes with a ball of two cells -- reach = 2, 125 cells -- left nothing
-    // for the heap kernel but took 2.5 ms per pass against the heap kernel's 1.5 ms for these 6 % of the points)
     ctx->sor_redo_fraction = static_cast<double>(redo) / static_cast<double>(n);
     if (redo > 0) {
       LaunchTimer t(ctx, PCP_K_SOR);
@@ -1754,8 +1853,10 @@ int pcp_sor(pcp_context *ctx, int32_t mean_k, double std_mul, uint8_t *out_keep,
   const int64_t n = ctx->n;
   if (out_kept) *out_kept = 0;
   if (n == 0) return PCP_OK;
+  ctx->sor_distances_live = false;
   int rc = sor_run(ctx, uploaded_view(ctx), mean_k, std_mul);
   if (rc != PCP_OK) return rc;
+  ctx->sor_distances_live = true;
   if (out_kept) {
     int64_t kept = 0;
     if ((rc = compact_flags(ctx, ctx->m_flag.p, n, nullptr, 0, &kept)) != PCP_OK) return rc;
@@ -1779,6 +1880,7 @@ int pcp_cloud_smooth(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_cou
     return set_error(ctx, PCP_ERR_INVALID, "pcp_cloud_smooth: sor_mean_k %d out of range (1..254)", p->sor_mean_k);
   PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
   ctx->mls_count = 0;
+  ctx->sor_distances_live = false;
   if (out_count) *out_count = 0;
   const CloudView cv0 = uploaded_view(ctx);
   if (cv0.n == 0) return PCP_OK;
@@ -1867,6 +1969,18 @@ int pcp_close_pairs(pcp_context *ctx, double radius, int64_t *points_with_close_
   PCP_HIP_TRY(ctx, hipMemcpyAsync(&c, ctx->s_counter.p, 8, hipMemcpyDeviceToHost, ctx->stream));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   *points_with_close_neighbour = static_cast<int64_t>(c);
+  return PCP_OK;
+}
+
+int pcp_sor_distances(pcp_context *ctx, int64_t capacity, float *out_distance) {
+  if (!ctx || !out_distance) return PCP_ERR_INVALID;
+  if (!ctx->sor_distances_live) return set_error(ctx, PCP_ERR_STATE, "pcp_sor_distances: no pcp_sor result to read");
+  if (capacity < ctx->n) return set_error(ctx, PCP_ERR_RANGE, "pcp_sor_distances: capacity %lld < %lld points", (long long)capacity, (long long)ctx->n);
+  PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->n > 0) {
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(out_distance, ctx->m_tmp.p, static_cast<size_t>(ctx->n) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
   return PCP_OK;
 }
 

@@ -15,6 +15,9 @@ def _check(ctx, oracle, x, y, z, mean_k, mul):
     assert np.all(np.abs(dist[diff] - thr) <= 1e-6 * thr), (len(diff), dist[diff][:5], thr)
     assert abs(kept_g - kept_r) <= len(diff)
     assert kept_g == int(keep_g.sum())
+    # the thresholded quantity itself, bit for bit: the k + 1 nearest are selected exactly, each sqrt is correctly
+    # rounded and the fp64 sum of <= 255 fp32 terms within a few binades is exact in any order
+    assert np.array_equal(ctx.sor_distances().view(np.uint32), dist.astype(np.float32).view(np.uint32))
     return kept_r
 
 
@@ -75,3 +78,19 @@ def test_sor_selection_and_heap_kernels_agree_with_oracle(gpu_ctx_factory, oracl
     assert (frac == 0.0) if heap_only == "1" else (0.0 < frac < 0.6)
     assert 0.5 * len(pts) < kept < len(pts)
     ctx.close()
+
+
+def test_sor_tiny_and_zero_distances(gpu_ctx_factory, oracle):
+    """Duplicates (d = 0) and a cluster around the origin whose squared distances are subnormal in fp32: the selection
+    kernel's short sqrt does not cover 0 < d < 2^-96 and must hand those lanes to the heap kernel (sqrtf)."""
+    rng = np.random.default_rng(21)
+    n = 30000
+    a = rng.uniform(-0.5, 0.5, (n, 2))
+    pts = np.stack([a[:, 0], a[:, 1], rng.normal(0, 1e-3, n)], 1)
+    pts[:400] = pts[400:800]  # exact duplicates
+    tiny = rng.normal(0, 1e-21, (300, 3))  # squared distances ~1e-42 .. 1e-40
+    pts = np.concatenate([pts, tiny]).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    ctx = gpu_ctx_factory()
+    _check(ctx, oracle, pts[:, 0].copy(), pts[:, 1].copy(), pts[:, 2].copy(), 60, 0.7)
+    assert ctx.sor_redo_fraction() > 0.0
