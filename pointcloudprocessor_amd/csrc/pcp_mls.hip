@@ -803,12 +803,15 @@ __global__ __launch_bounds__(kSorBlock) void k_sor_mean_distance(const float *__
                                                                  const int32_t *__restrict__ remap,
                                                                  const int32_t *__restrict__ start, int64_t n, GridDesc g,
                                                                  int32_t mean_k, float *__restrict__ distances,
-                                                                 const int32_t *__restrict__ list, int64_t list_n) {
+                                                                 const int32_t *__restrict__ list, int64_t list_n,
+                                                                 const uint8_t *__restrict__ only_flagged) {
   extern __shared__ float sor_heap[];
-  // list == nullptr: every point; else only the cell-sorted positions named by the list (k_sor_select's leftovers)
+  // list == nullptr: every point; else only the cell-sorted positions named by the list (k_sor_select's leftovers),
+  // and of those only the ones k_sor_wave left flagged (only_flagged[j] == 2) when that array is given
   const int64_t t = static_cast<int64_t>(blockIdx.x) * kSorBlock + threadIdx.x;
   if (t >= (list ? list_n : n)) return;
   const int64_t j = list ? list[t] : t;
+  if (only_flagged && only_flagged[j] != 2) return;
   float *heap = sor_heap + threadIdx.x;
   const int k = mean_k + 1;
   const float qx = sx[j], qy = sy[j], qz = sz[j];
@@ -1181,6 +1184,152 @@ __global__ __launch_bounds__(kSelWave) void k_sor_select(const float *__restrict
     if (live && !tiny) distances[remap ? remap[order[j]] : order[j]] = static_cast<float>(sum / static_cast<double>(mean_k));
   }
   if (live) redo[j] = (bad || tiny) ? 1 : 0;
+}
+
+// The lanes k_sor_select flags (sparse spots and borders of a surface: fewer than k + 1 points within one cell; dense
+// spots: a crowded boundary bin), one WAVEFRONT per point.  The heap kernel gives such a point one lane, and its
+// ring-by-ring walk with a dependent LDS heap update per candidate makes a wavefront as slow as its slowest lane
+// (1.1 ms for 0.35 % of a 10 M-point cloud).  Here the 64 lanes share the point's candidates:
+//   1. a block of (2R + 1)^3 cells, R = 1, 2, 3, 4, 6, 9 ...: lane r fetches the bounds of row r, the rows that hold
+//      points are walked four at a time (lane i tests candidate b + i: coalesced loads, twelve in flight), and the
+//      squared distances below (0.999 R cells)^2 -- every point that close lies inside the block -- are packed into
+//      LDS.  Fewer than k + 1 of them: next R.
+//   2. the (k + 1)-th smallest of the cached values bit by bit (non-negative floats order as unsigned integers): per
+//      bit one ballot count over the entries that still match the prefix; it stops as soon as the entries still in
+//      play are exactly the ones missing.
+//   3. sqrt of the entries below the prefix (+ the ones in play, or the missing multiple of the one remaining value),
+//      exact fp64 wave sum, minus the nearest (the point itself).
+// A point whose block holds more values than the cache stays flagged (2) for the heap kernel.
+constexpr int kWsCap = 2048;
+constexpr int kWsRows = 4;
+__global__ __launch_bounds__(kSelWave) void k_sor_wave(const float *__restrict__ sx, const float *__restrict__ sy,
+                                                       const float *__restrict__ sz, const int32_t *__restrict__ order,
+                                                       const int32_t *__restrict__ remap,
+                                                       const int32_t *__restrict__ start, int64_t n, GridDesc g,
+                                                       int32_t mean_k, float *__restrict__ distances,
+                                                       uint8_t *__restrict__ redo, const int32_t *__restrict__ list,
+                                                       int64_t list_n) {
+#pragma clang fp contract(off)
+  __shared__ float cache[kWsCap];
+  const int lane = threadIdx.x;
+  if (static_cast<int64_t>(blockIdx.x) >= list_n) return;
+  const int32_t j = list[blockIdx.x];
+  const int k = mean_k + 1;
+  const float qx = sx[j], qy = sy[j], qz = sz[j];
+  int32_t cx, cy, cz;
+  grid_coords(g, qx, qy, qz, cx, cy, cz);
+  const float cell = 1.0f / g.inv_cell;
+  const int32_t maxr = max(g.nx, max(g.ny, g.nz));
+  const unsigned long long lanes_below = (1ull << lane) - 1ull;
+  int32_t M = 0;
+  for (int32_t R = 1;; R = R < 4 ? R + 1 : R + R / 2) {
+    const bool whole = R >= maxr;  // the block is the grid: every point is a candidate
+    const float lim = static_cast<float>(R) * cell * 0.999f;  // 0.999: fp32 slop of the cell assignment
+    const float T0 = whole ? INFINITY : lim * lim;
+    const int32_t x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
+    const int32_t y0 = max(cy - R, 0), y1 = min(cy + R, g.ny - 1);
+    const int32_t z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
+    const int32_t wy = y1 - y0 + 1, nrows = wy * (z1 - z0 + 1);
+    M = 0;
+    auto take = [&](float d) {  // d = +inf for lanes without a candidate
+      const bool in = d < T0;
+      const unsigned long long m = __ballot(in);
+      const int32_t at = M + static_cast<int32_t>(__popcll(m & lanes_below));
+      if (in && at < kWsCap) cache[at] = d;
+      M += static_cast<int32_t>(__popcll(m));
+    };
+    for (int32_t r0 = 0; r0 < nrows; r0 += kSelWave) {
+      const int32_t r = r0 + lane;
+      int32_t b = 0, len = 0;
+      if (r < nrows) {
+        const int32_t zz = z0 + r / wy, yy = y0 + r % wy;
+        const int32_t row = (zz * g.ny + yy) * g.nx;
+        b = start[row + x0];
+        len = start[row + x1 + 1] - b;
+      }
+      unsigned long long todo = __ballot(len > 0);
+      while (todo) {
+        int32_t rb[kWsRows], rl[kWsRows];
+#pragma unroll
+        for (int u = 0; u < kWsRows; ++u) {
+          rb[u] = 0;
+          rl[u] = 0;
+          if (todo) {
+            const int src = __ffsll(todo) - 1;
+            todo &= todo - 1;
+            rb[u] = __builtin_amdgcn_readlane(b, src);
+            rl[u] = __builtin_amdgcn_readlane(len, src);
+          }
+        }
+        float d[kWsRows];
+#pragma unroll
+        for (int u = 0; u < kWsRows; ++u) {
+          d[u] = INFINITY;
+          if (lane < rl[u]) d[u] = sqdist_f32(sx[rb[u] + lane], sy[rb[u] + lane], sz[rb[u] + lane], qx, qy, qz);
+        }
+#pragma unroll
+        for (int u = 0; u < kWsRows; ++u)
+          if (rl[u] > 0) take(d[u]);
+#pragma unroll
+        for (int u = 0; u < kWsRows; ++u)  // long rows: the rest, 64 at a time
+          for (int32_t off = kSelWave; off < rl[u]; off += kSelWave) {
+            const int32_t q = rb[u] + off + lane;
+            take(off + lane < rl[u] ? sqdist_f32(sx[q], sy[q], sz[q], qx, qy, qz) : INFINITY);
+          }
+      }
+    }
+    if (M >= k || whole) break;
+  }
+  if (M > kWsCap) {  // uniform
+    if (lane == 0) redo[j] = 2;
+    return;
+  }
+  // the k-th smallest cached value (1-based; the query itself is among them), bit by bit from the top
+  uint32_t prefix = 0, decided = 0;  // bits of the value fixed so far, and which bits those are
+  __builtin_amdgcn_wave_barrier();  // the cache is complete: no LDS access moves across this point
+  int32_t need = min(k, M), in_play = M;  // fewer than k values (a cloud of < k points): all of them
+  if (M > k)
+    for (int bit = 30; bit >= 0 && in_play != need; --bit) {
+      const uint32_t probe = decided | (1u << bit);
+      int32_t zeros = 0;  // entries matching the prefix whose `bit` is 0
+      for (int32_t e0 = 0; e0 < M; e0 += kSelWave) {
+        const int32_t e = e0 + lane;
+        const uint32_t u = e < M ? __float_as_uint(cache[e]) : 0xffffffffu;  // finite values never match all-ones
+        zeros += static_cast<int32_t>(__popcll(__ballot((u & probe) == prefix)));
+      }
+      if (need <= zeros) {
+        in_play = zeros;
+      } else {
+        prefix |= 1u << bit;
+        need -= zeros;
+        in_play -= zeros;
+      }
+      decided = probe;
+    }
+  // entries below the prefix are among the k nearest; of the entries in play, all (in_play == need), or `need` copies
+  // of the one value they share (every bit decided)
+  const bool all_in_play = in_play == need;
+  double sum = 0.0;
+  float smallest = FLT_MAX;
+  for (int32_t e0 = 0; e0 < M; e0 += kSelWave) {
+    const int32_t e = e0 + lane;
+    if (e < M) {
+      const float d = cache[e];
+      const uint32_t u = __float_as_uint(d) & decided;
+      if (u < prefix || (u == prefix && all_in_play)) sum += static_cast<double>(sqrtf(d));
+      smallest = fminf(smallest, d);
+    }
+  }
+  for (int o = 32; o >= 1; o >>= 1) {
+    sum += __shfl_xor(sum, o, 64);
+    smallest = fminf(smallest, __shfl_xor(smallest, o, 64));
+  }
+  if (!all_in_play) sum += static_cast<double>(need) * static_cast<double>(sqrtf(__uint_as_float(prefix)));
+  sum -= static_cast<double>(sqrtf(smallest));  // hit 0 of nearestKSearch(k + 1) is the query itself
+  if (lane == 0) {
+    distances[remap ? remap[order[j]] : order[j]] = static_cast<float>(sum / static_cast<double>(mean_k));
+    redo[j] = 0;
+  }
 }
 
 // sum and sum of squares (fp32 squares, as the reference) of the distances, fp64 accumulation
@@ -1730,10 +1879,19 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
     if ((rc = compact_flags(ctx, ctx->m_flag.p, n, ctx->s_cell.p, n, &redo)) != PCP_OK) return rc;
     ctx->sor_redo_fraction = static_cast<double>(redo) / static_cast<double>(n);
     if (redo > 0) {
+      // one wavefront per flagged point; the heap kernel (one lane per point) for the few whose block of cells
+      // overflows the wavefront's cache
       LaunchTimer t(ctx, PCP_K_SOR);
+      const char *no_wave = std::getenv("PCP_SOR_NO_WAVE");
+      const bool wave = !(no_wave && no_wave[0] == '1');
+      if (wave)
+        hipLaunchKernelGGL(k_sor_wave, dim3(static_cast<uint32_t>(redo)), dim3(kSelWave), 0, ctx->stream, ctx->g_xyz.p,
+                           ctx->g_xyz.p + plane, ctx->g_xyz.p + 2 * plane, ctx->g_order.p, remap, ctx->g_start.p, n, g, mean_k,
+                           dist, ctx->m_flag.p, ctx->s_cell.p, redo);
       hipLaunchKernelGGL(k_sor_mean_distance, dim3(static_cast<uint32_t>(div_up(redo, kSorBlock))), dim3(kSorBlock), heap_lds,
                          ctx->stream, ctx->g_xyz.p, ctx->g_xyz.p + plane, ctx->g_xyz.p + 2 * plane, ctx->g_order.p,
-                         remap, ctx->g_start.p, n, g, mean_k, dist, ctx->s_cell.p, redo);
+                         remap, ctx->g_start.p, n, g, mean_k, dist, ctx->s_cell.p, redo,
+                         wave ? ctx->m_flag.p : static_cast<const uint8_t *>(nullptr));
       PCP_HIP_TRY(ctx, hipGetLastError());
     }
   } else {
@@ -1741,7 +1899,8 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
     LaunchTimer t(ctx, PCP_K_SOR);
     hipLaunchKernelGGL(k_sor_mean_distance, dim3(static_cast<uint32_t>(div_up(n, kSorBlock))), dim3(kSorBlock), heap_lds,
                        ctx->stream, ctx->g_xyz.p, ctx->g_xyz.p + plane, ctx->g_xyz.p + 2 * plane, ctx->g_order.p,
-                       remap, ctx->g_start.p, n, g, mean_k, dist, static_cast<const int32_t *>(nullptr), int64_t(0));
+                       remap, ctx->g_start.p, n, g, mean_k, dist, static_cast<const int32_t *>(nullptr), int64_t(0),
+                       static_cast<const uint8_t *>(nullptr));
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   {
