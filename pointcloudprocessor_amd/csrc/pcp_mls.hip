@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(kSelWave) void k_sor_select(const float *__restrict
     const uint32_t v = sel_lds[b * 32 + (lane & 31)];
     return static_cast<int>(lane < 32 ? (v & 0xffffu) : (v >> 16));
   };
-  bool bad = false;
+  bool bad = false, sparse = false;
   {
     // a counter cannot wrap (and carry into the lane it shares a dword with): the 27 cells hold fewer candidates than
     // it can count, else the heap kernel takes the lane
@@ -1042,7 +1042,7 @@ __global__ __launch_bounds__(kSelWave) void k_sor_select(const float *__restrict
         }
       }
     }
-    if (boundary < 0) bad = true;  // fewer than k + 1 points inside the ball
+    if (boundary < 0 && !bad) sparse = bad = true;  // fewer than k + 1 points inside the ball
     bnd[0] = max(boundary, 0);
   }
   // refinements, only in wavefronts that hold a lane with a crowded boundary bin
@@ -1183,7 +1183,8 @@ __global__ __launch_bounds__(kSelWave) void k_sor_select(const float *__restrict
     sum -= static_cast<double>(sqrt_rn(smallest));  // hit 0 of nearestKSearch(k + 1) is the query itself
     if (live && !tiny) distances[remap ? remap[order[j]] : order[j]] = static_cast<float>(sum / static_cast<double>(mean_k));
   }
-  if (live) redo[j] = (bad || tiny) ? 1 : 0;
+  // 1: the ball of one cell holds too few points (k_sor_wave starts with two cells); 3: any other reason
+  if (live) redo[j] = sparse ? 1 : ((bad || tiny) ? 3 : 0);
 }
 
 // The lanes k_sor_select flags (sparse spots and borders of a surface: fewer than k + 1 points within one cell; dense
@@ -1191,7 +1192,7 @@ __global__ __launch_bounds__(kSelWave) void k_sor_select(const float *__restrict
 // ring-by-ring walk with a dependent LDS heap update per candidate makes a wavefront as slow as its slowest lane
 // (1.1 ms for 0.35 % of a 10 M-point cloud).  Here the 64 lanes share the point's candidates:
 //   1. a block of (2R + 1)^3 cells, R = 1, 2, 3, 4, 6, 9 ...: lane r fetches the bounds of row r, the rows that hold
-//      points are walked four at a time (lane i tests candidate b + i: coalesced loads, twelve in flight), and the
+//      points are walked eight at a time (lane i tests candidate b + i: coalesced loads, 24 in flight), and the
 //      squared distances below (0.999 R cells)^2 -- every point that close lies inside the block -- are packed into
 //      LDS.  Fewer than k + 1 of them: next R.
 //   2. the (k + 1)-th smallest of the cached values bit by bit (non-negative floats order as unsigned integers): per
@@ -1201,7 +1202,7 @@ __global__ __launch_bounds__(kSelWave) void k_sor_select(const float *__restrict
 //      exact fp64 wave sum, minus the nearest (the point itself).
 // A point whose block holds more values than the cache stays flagged (2) for the heap kernel.
 constexpr int kWsCap = 2048;
-constexpr int kWsRows = 4;
+constexpr int kWsRows = 8;
 __global__ __launch_bounds__(kSelWave) void k_sor_wave(const float *__restrict__ sx, const float *__restrict__ sy,
                                                        const float *__restrict__ sz, const int32_t *__restrict__ order,
                                                        const int32_t *__restrict__ remap,
@@ -1222,7 +1223,8 @@ __global__ __launch_bounds__(kSelWave) void k_sor_wave(const float *__restrict__
   const int32_t maxr = max(g.nx, max(g.ny, g.nz));
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
   int32_t M = 0;
-  for (int32_t R = 1;; R = R < 4 ? R + 1 : R + R / 2) {
+  // (a point k_sor_select found too few neighbours for within one cell starts with two)
+  for (int32_t R = redo[j] == 1 ? 2 : 1;; R = R < 4 ? R + 1 : R + R / 2) {
     const bool whole = R >= maxr;  // the block is the grid: every point is a candidate
     const float lim = static_cast<float>(R) * cell * 0.999f;  // 0.999: fp32 slop of the cell assignment
     const float T0 = whole ? INFINITY : lim * lim;
@@ -1288,24 +1290,40 @@ __global__ __launch_bounds__(kSelWave) void k_sor_wave(const float *__restrict__
   uint32_t prefix = 0, decided = 0;  // bits of the value fixed so far, and which bits those are
   __builtin_amdgcn_wave_barrier();  // the cache is complete: no LDS access moves across this point
   int32_t need = min(k, M), in_play = M;  // fewer than k values (a cloud of < k points): all of them
-  if (M > k)
+  auto decide = [&](int bit, int32_t zeros) {  // zeros: entries matching the prefix whose `bit` is 0
+    if (need <= zeros) {
+      in_play = zeros;
+    } else {
+      prefix |= 1u << bit;
+      need -= zeros;
+      in_play -= zeros;
+    }
+    decided |= 1u << bit;
+  };
+  if (M > k && M <= 4 * kSelWave) {
+    // the usual case: at most four entries per lane, kept in registers (finite values never match all-ones)
+    uint32_t u[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = i * kSelWave + lane < M ? __float_as_uint(cache[i * kSelWave + lane]) : 0xffffffffu;
     for (int bit = 30; bit >= 0 && in_play != need; --bit) {
       const uint32_t probe = decided | (1u << bit);
-      int32_t zeros = 0;  // entries matching the prefix whose `bit` is 0
+      int32_t zeros = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) zeros += static_cast<int32_t>(__popcll(__ballot((u[i] & probe) == prefix)));
+      decide(bit, zeros);
+    }
+  } else if (M > k) {
+    for (int bit = 30; bit >= 0 && in_play != need; --bit) {
+      const uint32_t probe = decided | (1u << bit);
+      int32_t zeros = 0;
       for (int32_t e0 = 0; e0 < M; e0 += kSelWave) {
         const int32_t e = e0 + lane;
-        const uint32_t u = e < M ? __float_as_uint(cache[e]) : 0xffffffffu;  // finite values never match all-ones
+        const uint32_t u = e < M ? __float_as_uint(cache[e]) : 0xffffffffu;
         zeros += static_cast<int32_t>(__popcll(__ballot((u & probe) == prefix)));
       }
-      if (need <= zeros) {
-        in_play = zeros;
-      } else {
-        prefix |= 1u << bit;
-        need -= zeros;
-        in_play -= zeros;
-      }
-      decided = probe;
+      decide(bit, zeros);
     }
+  }
   // entries below the prefix are among the k nearest; of the entries in play, all (in_play == need), or `need` copies
   // of the one value they share (every bit decided)
   const bool all_in_play = in_play == need;
