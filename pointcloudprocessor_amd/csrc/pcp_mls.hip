@@ -867,7 +867,7 @@ __global__ __launch_bounds__(kSorBlock) void k_sor_mean_distance(const float *__
 // Selection without a heap (the common case), one wavefront per 64 consecutive cell-sorted points.
 //
 // All points closer than `limit` (= 0.999 grid cells) lie in the 3x3x3 cells around the query, and the cell size is
-// chosen so that this ball holds ~1.35 (k + 1) points on average.  A histogram pass counts the candidates inside the
+// chosen so that this ball holds ~1.5 (k + 1) points on average.   A histogram pass counts the candidates inside the
 // ball in 32 equal-width bins of the squared distance (16-bit counters in LDS, [bin][lane]; a 33rd row takes the
 // candidates outside the ball, so the pass has no test and no branch per candidate); the bin in which the count reaches
 // k + 1 is the boundary bin.  Where the cloud is denser than average that bin is crowded: it is then histogrammed
@@ -1865,8 +1865,9 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
     if (occ > 0) {
       const double per_area = static_cast<double>(probe_n) * static_cast<double>(stride) /
                               (static_cast<double>(occ) * c0 * c0);  // points per unit area
-      // cell edge such that the ball of one cell radius holds ~1.35 (k + 1) points of a surface of this density
-      double ball = 1.35;
+      // cell edge such that the ball of one cell radius holds ~1.5 (k + 1) points of a surface of this density (a flat
+      // optimum: 1.35 .. 1.8 within 2 %; smaller balls flag more points for k_sor_wave, larger ones test more candidates)
+      double ball = 1.5;
       if (const char *e = std::getenv("PCP_SOR_BALL")) ball = atof(e);
       const double want = std::sqrt(ball * (mean_k + 1) / (3.14159265358979 * per_area));
       if (want > 0.0 && want < 1e30) final_cell = want;
