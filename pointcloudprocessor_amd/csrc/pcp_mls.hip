@@ -303,33 +303,66 @@ __global__ __launch_bounds__(kFitBlock) void k_mls_fit(MlsArgs a) {
       const int32_t b = rb[r], e = re[r];
       run_base[r][tid] = b;
       if (e - b > 4096) fast = false;
-      for (int32_t k = b; k < e; k += 4) {
-        const int32_t k1 = min(k + 1, e - 1), k2 = min(k + 2, e - 1), k3 = min(k + 3, e - 1);
-        float ax, ay, az, bx, by, bz, cx_, cy_, cz_, dx_, dy_, dz_;
-        fetch(k, ax, ay, az);
-        fetch(k1, bx, by, bz);
-        fetch(k2, cx_, cy_, cz_);
-        fetch(k3, dx_, dy_, dz_);
-        const bool h0 = sqdist_f32(ax, ay, az, qx, qy, qz) < a.sq_radius;
-        const bool h1 = k + 1 < e && sqdist_f32(bx, by, bz, qx, qy, qz) < a.sq_radius;
-        const bool h2 = k + 2 < e && sqdist_f32(cx_, cy_, cz_, qx, qy, qz) < a.sq_radius;
-        const bool h3 = k + 3 < e && sqdist_f32(dx_, dy_, dz_, qx, qy, qz) < a.sq_radius;
-        // four straight-line appends: a loop over the set bits costs more than the tests it saves
-        if (h0) {
+      auto append = [&](bool hit, int32_t k) {
+        if (hit) {
           if (K < kMaxNbr) nbr_code[K][tid] = static_cast<uint16_t>((r << 12) | ((k - b) & 4095));
           ++K;
         }
-        if (h1) {
-          if (K < kMaxNbr) nbr_code[K][tid] = static_cast<uint16_t>((r << 12) | ((k + 1 - b) & 4095));
-          ++K;
+      };
+      if constexpr (kBuf) {
+        // four candidates per trip: one 16-byte load per coordinate plane (dword alignment suffices for buffer loads),
+        // packed fp32 arithmetic on two candidates at a time, each component rounded as sqdist_f32 does; the ragged
+        // end of a run is one more trip whose missing candidates sit at infinity
+#pragma clang fp contract(off)
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+        const v2f qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+        auto d2_of = [&](v2f px, v2f py, v2f pz) {
+          const v2f dx = px - qx2, dy = py - qy2, dz = pz - qz2;
+          return (dx * dx + dy * dy) + dz * dz;
+        };
+        auto load4 = [&](decltype(rsx) rs, int32_t k, float (&v)[4]) {
+          const v4u w = __builtin_amdgcn_raw_buffer_load_b128(rs, static_cast<uint32_t>(k) * 4u, 0, 0);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = __uint_as_float(w[c]);
+        };
+        int32_t k = b;
+        for (; k + 4 <= e; k += 4) {
+          float X[4], Y[4], Z[4];
+          load4(rsx, k, X);
+          load4(rsy, k, Y);
+          load4(rsz, k, Z);
+          const v2f da = d2_of(v2f{X[0], X[1]}, v2f{Y[0], Y[1]}, v2f{Z[0], Z[1]});
+          const v2f db = d2_of(v2f{X[2], X[3]}, v2f{Y[2], Y[3]}, v2f{Z[2], Z[3]});
+          append(da[0] < a.sq_radius, k);
+          append(da[1] < a.sq_radius, k + 1);
+          append(db[0] < a.sq_radius, k + 2);
+          append(db[1] < a.sq_radius, k + 3);
         }
-        if (h2) {
-          if (K < kMaxNbr) nbr_code[K][tid] = static_cast<uint16_t>((r << 12) | ((k + 2 - b) & 4095));
-          ++K;
+        if (k < e) {
+          const int32_t rem = e - k;
+          float X[4], Y[4], Z[4];
+          load4(rsx, k, X);
+          load4(rsy, k, Y);
+          load4(rsz, k, Z);
+          const v2f da = d2_of(v2f{X[0], rem > 1 ? X[1] : INFINITY}, v2f{Y[0], Y[1]}, v2f{Z[0], Z[1]});
+          const v2f db = d2_of(v2f{rem > 2 ? X[2] : INFINITY, INFINITY}, v2f{Y[2], Y[3]}, v2f{Z[2], Z[3]});
+          append(da[0] < a.sq_radius, k);
+          append(da[1] < a.sq_radius, k + 1);
+          append(db[0] < a.sq_radius, k + 2);
         }
-        if (h3) {
-          if (K < kMaxNbr) nbr_code[K][tid] = static_cast<uint16_t>((r << 12) | ((k + 3 - b) & 4095));
-          ++K;
+      } else {
+        for (int32_t k = b; k < e; k += 4) {
+          const int32_t k1 = min(k + 1, e - 1), k2 = min(k + 2, e - 1), k3 = min(k + 3, e - 1);
+          float ax, ay, az, bx, by, bz, cx_, cy_, cz_, dx_, dy_, dz_;
+          fetch(k, ax, ay, az);
+          fetch(k1, bx, by, bz);
+          fetch(k2, cx_, cy_, cz_);
+          fetch(k3, dx_, dy_, dz_);
+          append(sqdist_f32(ax, ay, az, qx, qy, qz) < a.sq_radius, k);
+          append(k + 1 < e && sqdist_f32(bx, by, bz, qx, qy, qz) < a.sq_radius, k + 1);
+          append(k + 2 < e && sqdist_f32(cx_, cy_, cz_, qx, qy, qz) < a.sq_radius, k + 2);
+          append(k + 3 < e && sqdist_f32(dx_, dy_, dz_, qx, qy, qz) < a.sq_radius, k + 3);
         }
       }
     }
