@@ -94,3 +94,31 @@ def test_sor_tiny_and_zero_distances(gpu_ctx_factory, oracle):
     ctx = gpu_ctx_factory()
     _check(ctx, oracle, pts[:, 0].copy(), pts[:, 1].copy(), pts[:, 2].copy(), 60, 0.7)
     assert ctx.sor_redo_fraction() > 0.0
+
+
+def test_sor_flagged_point_paths(gpu_ctx_factory, oracle):
+    """The three ways out of the selection kernel: a stray point whose block of cells grows to the whole grid, a pile
+    of identical points that overflows the wavefront kernel's cache (heap kernel), and thin spots that need two or three
+    cells -- every distance bit-equal to the oracle's."""
+    rng = np.random.default_rng(33)
+    n = 30000
+    a = rng.uniform(-0.5, 0.5, (n, 2))
+    sheet = np.stack([a[:, 0], a[:, 1], rng.normal(0, 1e-3, n)], 1)
+    thin = np.stack([rng.uniform(0.5, 1.5, 1500), rng.uniform(-0.5, 0.5, 1500), rng.normal(0, 1e-3, 1500)], 1)
+    pile = np.repeat(sheet[:1], 3000, axis=0)  # 3000 copies of one point: a boundary bin no refinement can thin out
+    stray = np.array([[40.0, -35.0, 12.0], [-60.0, 3.0, -7.0]])
+    pts = np.concatenate([sheet, thin, pile, stray]).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    ctx = gpu_ctx_factory()
+    _check(ctx, oracle, pts[:, 0].copy(), pts[:, 1].copy(), pts[:, 2].copy(), 60, 0.7)
+    assert ctx.sor_redo_fraction() > 0.05
+
+
+def test_sor_fewer_points_than_neighbours(gpu_ctx_factory, oracle):
+    """A cloud of 25 points with mean_k = 60: nearestKSearch returns what there is; every point is flagged and its
+    block is the whole grid."""
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-1, 1, (25, 3)).astype(np.float32)
+    ctx = gpu_ctx_factory()
+    _check(ctx, oracle, pts[:, 0].copy(), pts[:, 1].copy(), pts[:, 2].copy(), 60, 0.7)
+    _check(ctx, oracle, pts[:, 0].copy(), pts[:, 1].copy(), pts[:, 2].copy(), 24, 1.0)
