@@ -288,6 +288,23 @@ int pcp_nid_evaluate(pcp_context *ctx, const double T[16], const double *T_init,
 int pcp_nid_optimize(pcp_context *ctx, const double T_init[16], int32_t bins, int32_t max_outer_iterations,
                      double T_out[16], double *final_cost, int32_t *evaluations);
 
+/* The same cost over an index-sharded map (one context per GPU, each holding a slice of the cloud and of the
+ * intensities; keyframes and images replicated; depth maps MIN-merged, PCP_DEPTH_BATCHED).  A keyframe's joint histogram
+ * (nid_cost.hpp:55-93) is a sum over its points, so: every shard accumulates its own histograms at T
+ * (pcp_nid_accumulate), the shards' histograms are added in place -- an all-reduce(SUM) over the `count` doubles at
+ * pcp_nid_histograms_device, queued on the context's stream or completed before the next call -- and pcp_nid_finish
+ * turns the summed histograms into cost and gradient, the same numbers on every shard.  On one context
+ * pcp_nid_evaluate == pcp_nid_accumulate + pcp_nid_finish (plus the domain test against T_init). */
+int pcp_nid_accumulate(pcp_context *ctx, const double T[16], int32_t bins);
+int pcp_nid_histograms_device(pcp_context *ctx, void **device_ptr, int64_t *count);
+int pcp_nid_finish(pcp_context *ctx, int32_t bins, double *cost, double grad6[6], int32_t *valid);
+/* pcp_nid_optimize with the cost supplied by the caller (the sharded evaluation above, driven by the host that owns the
+ * shards): eval returns PCP_OK and fills cost / grad6 / valid for a T inside the domain; the loop, its tolerances and the
+ * domain test are those of pcp_nid_optimize.  ctx only carries the error text. */
+typedef int (*pcp_nid_eval_fn)(void *user, const double T[16], int32_t bins, double *cost, double grad6[6], int32_t *valid);
+int pcp_nid_optimize_with(pcp_context *ctx, pcp_nid_eval_fn eval, void *user, const double T_init[16], int32_t bins,
+                          int32_t max_outer_iterations, double T_out[16], double *final_cost, int32_t *evaluations);
+
 /* ---- precondition of the match-back (PointCloudProcessor.cpp:480-482,571) ------------------------------- */
 /* Number of map points that have ANOTHER map point closer than `radius` (fp32 squared distance, strict <, as
  * kdtree.radiusSearch compares).  The reference credits a visible sample to every map point within 1e-5 m of the

@@ -22,6 +22,8 @@ PCP_ERR_DEVICE = -3
 PCP_ERR_NOMEM = -4
 PCP_ERR_RANGE = -5
 
+NID_EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                          C.POINTER(C.c_int32))
 K_PROJECT, K_DEPTH, K_COLOUR, K_VISIBILITY, K_MLS_GRID, K_MLS_FIT, K_MISC, K_SOR, K_MLS_VOXEL, K_TILE_MASK, K_NID = range(11)
 K_COUNT = 11
 
@@ -461,6 +463,52 @@ class Context:
         evals = C.c_int32()
         self._check(self.lib.pcp_nid_optimize(self.h, _ptr(Ti), C.c_int32(bins), C.c_int32(max_outer_iterations), _ptr(out),
                                               C.byref(cost), C.byref(evals)))
+        return out.reshape(4, 4), cost.value, evals.value
+
+    # NID over an index-sharded map: accumulate -> all-reduce(SUM) of the histograms -> finish
+    def nid_accumulate(self, T, bins: int = 16):
+        T = np.ascontiguousarray(T, np.float64).reshape(16)
+        self._check(self.lib.pcp_nid_accumulate(self.h, _ptr(T), C.c_int32(bins)))
+
+    def nid_histograms_device(self):
+        p = C.c_void_p()
+        n = C.c_int64()
+        self._check(self.lib.pcp_nid_histograms_device(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def nid_finish(self, bins: int = 16):
+        cost = C.c_double()
+        grad = np.zeros(6, np.float64)
+        valid = C.c_int32()
+        self._check(self.lib.pcp_nid_finish(self.h, C.c_int32(bins), C.byref(cost), _ptr(grad), C.byref(valid)))
+        return cost.value, grad, bool(valid.value)
+
+    def nid_optimize_with(self, evaluate, T_init, bins: int = 16, max_outer_iterations: int = 10):
+        """pcp_nid_optimize_with: evaluate(T 4x4, bins) -> (cost, grad6, valid), e.g. the sharded evaluation."""
+        errors = []
+
+        @NID_EVAL_FN
+        def trampoline(_user, T, b, cost, grad, valid):
+            try:
+                c, g, ok = evaluate(np.ctypeslib.as_array(T, (16,)).copy().reshape(4, 4), int(b))
+                cost[0] = float(c)
+                for k in range(6):
+                    grad[k] = float(g[k])
+                valid[0] = 1 if ok else 0
+                return 0
+            except Exception as e:  # noqa: BLE001 -- reported through the status code, re-raised below
+                errors.append(e)
+                return -3
+
+        Ti = np.ascontiguousarray(T_init, np.float64).reshape(16)
+        out = np.zeros(16, np.float64)
+        cost = C.c_double()
+        evals = C.c_int32()
+        rc = self.lib.pcp_nid_optimize_with(self.h, trampoline, None, _ptr(Ti), C.c_int32(bins), C.c_int32(max_outer_iterations),
+                                            _ptr(out), C.byref(cost), C.byref(evals))
+        if errors:
+            raise errors[0]
+        self._check(rc)
         return out.reshape(4, 4), cost.value, evals.value
 
     # -- measurement ------------------------------------------------------

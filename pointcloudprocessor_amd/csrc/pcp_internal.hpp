@@ -217,6 +217,7 @@ struct pcp_context {
   pcp::DevBuf<double> nid_hist;      // [keyframe][bins*bins*7 + bins]
   int64_t nid_chunks = 0, nid_points = 0;
   int32_t nid_frames = 0;
+  int32_t nid_hist_bins = 0;  // bins of the histograms pcp_nid_accumulate left in nid_hist
 
   // measurement
   bool timing = false;

@@ -245,8 +245,8 @@ static bool inside_limits(const double init[16], const double T[16], double *dt 
   return !(t > 0.2 || ang > 2.0 * M_PI / 180.0);
 }
 
-// one evaluation of the summed cost and tangent gradient at T
-static int nid_eval(pcp_context *ctx, const double T[16], int32_t bins, double *cost, double grad[6], bool *finite) {
+// the keyframes' joint histograms of this context's points at T, into ctx->nid_hist
+static int nid_accumulate(pcp_context *ctx, const double T[16], int32_t bins) {
   const int cells = bins * bins;
   const int lsize = cells * kNidComp + bins;
   const size_t hsize = static_cast<size_t>(ctx->nid_frames) * lsize;
@@ -277,6 +277,15 @@ static int nid_eval(pcp_context *ctx, const double T[16], int32_t bins, double *
                        ctx->stream, a);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
+  ctx->nid_hist_bins = bins;
+  return PCP_OK;
+}
+
+// cost and tangent gradient from the histograms in ctx->nid_hist (this context's, or the sum over the shards)
+static int nid_finish(pcp_context *ctx, int32_t bins, double *cost, double grad[6], bool *finite) {
+  const int cells = bins * bins;
+  const int lsize = cells * kNidComp + bins;
+  const size_t hsize = static_cast<size_t>(ctx->nid_frames) * lsize;
   std::vector<double> h(hsize);
   PCP_HIP_TRY(ctx, hipMemcpyAsync(h.data(), ctx->nid_hist.p, hsize * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -325,6 +334,13 @@ static int nid_eval(pcp_context *ctx, const double T[16], int32_t bins, double *
   for (int k = 0; k < 6; ++k) grad[k] = g[k];
   *finite = ok;
   return PCP_OK;
+}
+
+// one evaluation of the summed cost and tangent gradient at T
+static int nid_eval(pcp_context *ctx, const double T[16], int32_t bins, double *cost, double grad[6], bool *finite) {
+  int rc = nid_accumulate(ctx, T, bins);
+  if (rc != PCP_OK) return rc;
+  return nid_finish(ctx, bins, cost, grad, finite);
 }
 
 }  // namespace pcp
@@ -433,14 +449,13 @@ int pcp_nid_evaluate(pcp_context *ctx, const double T[16], const double *T_init,
   return PCP_OK;
 }
 
-int pcp_nid_optimize(pcp_context *ctx, const double T_init[16], int32_t bins, int32_t max_outer_iterations,
-                     double T_out[16], double *final_cost, int32_t *evaluations) {
-  if (!ctx) return PCP_ERR_INVALID;
-  if (!T_init || !T_out) return set_error(ctx, PCP_ERR_INVALID, "pcp_nid_optimize: NULL argument");
-  if (bins < 2 || bins > 16) return set_error(ctx, PCP_ERR_INVALID, "pcp_nid_optimize: bins %d out of range (2..16)", bins);
-  if (ctx->nid_frames <= 0 || ctx->nid_frames != ctx->n_frames)
-    return set_error(ctx, PCP_ERR_STATE, "pcp_nid_optimize: pcp_nid_prepare has not been called for these keyframes");
-  PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+}  // extern "C"
+
+namespace pcp {
+// VisualCameraCalibration::calibrate's loop around any evaluator of the cost (one context, or the host that owns the shards)
+template <class Eval>
+static int nid_optimize_loop(pcp_context *ctx, Eval &&nid_eval_at, const double T_init[16], int32_t bins,
+                             int32_t max_outer_iterations, double T_out[16], double *final_cost, int32_t *evaluations) {
   double T[16];
   std::memcpy(T, T_init, sizeof(T));
   int32_t evals = 0;
@@ -452,7 +467,7 @@ int pcp_nid_optimize(pcp_context *ctx, const double T_init[16], int32_t bins, in
     std::memcpy(x, T, sizeof(T));
     double f, g[6];
     bool fin;
-    int rc = nid_eval(ctx, x, bins, &f, g, &fin);
+    int rc = nid_eval_at(x, &f, g, &fin);
     if (rc != PCP_OK) return rc;
     ++evals;
     if (!fin) return set_error(ctx, PCP_ERR_STATE, "pcp_nid_optimize: the cost is not finite at the initial guess");
@@ -488,7 +503,7 @@ int pcp_nid_optimize(pcp_context *ctx, const double T_init[16], int32_t bins, in
         mat_mul(x, E, xn);
         bool fin2 = false;
         if (inside_limits(init, xn)) {
-          rc = nid_eval(ctx, xn, bins, &fn, gn, &fin2);
+          rc = nid_eval_at(xn, &fn, gn, &fin2);
           if (rc != PCP_OK) return rc;
           ++evals;
         }
@@ -534,6 +549,74 @@ int pcp_nid_optimize(pcp_context *ctx, const double T_init[16], int32_t bins, in
   std::memcpy(T_out, T, sizeof(T));
   if (final_cost) *final_cost = fbest;
   if (evaluations) *evaluations = evals;
+  (void)bins;
+  return PCP_OK;
+}
+}  // namespace pcp
+
+extern "C" {
+
+int pcp_nid_optimize(pcp_context *ctx, const double T_init[16], int32_t bins, int32_t max_outer_iterations,
+                     double T_out[16], double *final_cost, int32_t *evaluations) {
+  if (!ctx) return PCP_ERR_INVALID;
+  if (!T_init || !T_out) return set_error(ctx, PCP_ERR_INVALID, "pcp_nid_optimize: NULL argument");
+  if (bins < 2 || bins > 16) return set_error(ctx, PCP_ERR_INVALID, "pcp_nid_optimize: bins %d out of range (2..16)", bins);
+  if (ctx->nid_frames <= 0 || ctx->nid_frames != ctx->n_frames)
+    return set_error(ctx, PCP_ERR_STATE, "pcp_nid_optimize: pcp_nid_prepare has not been called for these keyframes");
+  PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return nid_optimize_loop(
+      ctx, [&](const double *T, double *f, double *g, bool *fin) { return nid_eval(ctx, T, bins, f, g, fin); }, T_init, bins,
+      max_outer_iterations, T_out, final_cost, evaluations);
+}
+
+int pcp_nid_optimize_with(pcp_context *ctx, pcp_nid_eval_fn eval, void *user, const double T_init[16], int32_t bins,
+                          int32_t max_outer_iterations, double T_out[16], double *final_cost, int32_t *evaluations) {
+  if (!ctx) return PCP_ERR_INVALID;
+  if (!eval || !T_init || !T_out) return set_error(ctx, PCP_ERR_INVALID, "pcp_nid_optimize_with: NULL argument");
+  if (bins < 2 || bins > 16) return set_error(ctx, PCP_ERR_INVALID, "pcp_nid_optimize_with: bins %d out of range (2..16)", bins);
+  return nid_optimize_loop(
+      ctx,
+      [&](const double *T, double *f, double *g, bool *fin) {
+        int32_t valid = 0;
+        const int rc = eval(user, T, bins, f, g, &valid);
+        *fin = valid != 0;
+        if (rc != PCP_OK) return set_error(ctx, rc, "pcp_nid_optimize_with: the evaluator failed (%d)", rc);
+        return PCP_OK;
+      },
+      T_init, bins, max_outer_iterations, T_out, final_cost, evaluations);
+}
+
+int pcp_nid_accumulate(pcp_context *ctx, const double T[16], int32_t bins) {
+  if (!ctx) return PCP_ERR_INVALID;
+  if (!T) return set_error(ctx, PCP_ERR_INVALID, "pcp_nid_accumulate: NULL argument");
+  if (bins < 2 || bins > 16) return set_error(ctx, PCP_ERR_INVALID, "pcp_nid_accumulate: bins %d out of range (2..16)", bins);
+  if (ctx->nid_frames <= 0 || ctx->nid_frames != ctx->n_frames)
+    return set_error(ctx, PCP_ERR_STATE, "pcp_nid_accumulate: pcp_nid_prepare has not been called for these keyframes");
+  PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return nid_accumulate(ctx, T, bins);
+}
+
+int pcp_nid_histograms_device(pcp_context *ctx, void **device_ptr, int64_t *count) {
+  if (!ctx || !device_ptr || !count) return PCP_ERR_INVALID;
+  if (ctx->nid_frames <= 0 || ctx->nid_hist_bins <= 0 || !ctx->nid_hist.p)
+    return set_error(ctx, PCP_ERR_STATE, "pcp_nid_histograms_device: pcp_nid_accumulate has not been called");
+  *device_ptr = ctx->nid_hist.p;
+  *count = static_cast<int64_t>(ctx->nid_frames) * (ctx->nid_hist_bins * ctx->nid_hist_bins * kNidComp + ctx->nid_hist_bins);
+  return PCP_OK;
+}
+
+int pcp_nid_finish(pcp_context *ctx, int32_t bins, double *cost, double grad6[6], int32_t *valid) {
+  if (!ctx) return PCP_ERR_INVALID;
+  if (!cost) return set_error(ctx, PCP_ERR_INVALID, "pcp_nid_finish: NULL argument");
+  if (ctx->nid_frames <= 0 || ctx->nid_hist_bins != bins || !ctx->nid_hist.p)
+    return set_error(ctx, PCP_ERR_STATE, "pcp_nid_finish: no histograms accumulated with %d bins", bins);
+  PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  double g[6];
+  bool finite = true;
+  int rc = nid_finish(ctx, bins, cost, g, &finite);
+  if (rc != PCP_OK) return rc;
+  if (grad6) std::memcpy(grad6, g, sizeof(g));
+  if (valid) *valid = finite ? 1 : 0;
   return PCP_OK;
 }
 

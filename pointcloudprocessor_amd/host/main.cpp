@@ -21,7 +21,8 @@
 //     interactive GUI is out of scope.
 //   * --gpus N (new, default 1): the map is sharded by point index over N GPUs of this node (pcp_multi.hpp: one
 //     process, N contexts, RCCL all-reduce(MIN) of the depth maps over xGMI, images broadcast over xGMI); every
-//     output file is identical to the one-GPU run.  MLS and the NID refinement run on GPU 0.
+//     output file is identical to the one-GPU run.  The NID refinement sums its joint histograms over the shards
+//     (same optimum, last-digit differences in the printed cost); MLS runs on GPU 0.
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -281,33 +282,11 @@ class Processor {
 
   void applyNIDBasedPoseOptimization() {  // :156-164 -> calibrate.cpp:42-126
     double cost = 0.0;
-    if (gpu->size() == 1) {
-      gpu->device(0).uploadIntensity(cloud.intensity.data(), static_cast<int64_t>(cloud.size()));
-      uploadImages(false);  // VisualLiDARCalibration reads the images itself, without generateColorMap's adjustment
-      VisualLiDARCalibration calib(gpu->device(0));
-      T_camera_lidar_optimized = calib.calibrate(&cost);
-    } else {
-      // the NID cost is a function of whole-cloud joint histograms: the stage runs on GPU 0 with the whole map
-      Device nid_gpu(0);
-      nid_gpu.uploadCloud(cloud.x.data(), cloud.y.data(), cloud.z.data(), static_cast<int64_t>(cloud.size()));
-      nid_gpu.uploadIntensity(cloud.intensity.data(), static_cast<int64_t>(cloud.size()));
-      pcp_camera cam;
-      pcp_default_camera(&cam);
-      cam.image_width = img_w;
-      cam.image_height = img_h;
-      nid_gpu.setCamera(cam);
-      std::vector<pcp_pose> kposes;
-      for (const auto &k : keyframes) kposes.push_back(k.pose);
-      nid_gpu.setKeyframes(kposes);
-      for (size_t k = 0; k < keyframes.size(); ++k) {
-        const Image8 img = read_image_bgr(keyframes[k].imagePath);
-        if (img.empty() || img.width != img_w || img.height != img_h)
-          throw std::runtime_error("Failed to read image from: " + keyframes[k].imagePath);
-        nid_gpu.uploadImage(static_cast<int>(k), img.data.data(), static_cast<int64_t>(img.width) * 3);
-      }
-      VisualLiDARCalibration calib(nid_gpu);
-      T_camera_lidar_optimized = calib.calibrate(&cost);
-    }
+    // one GPU: VisualLiDARCalibration on the context; several: the keyframes' joint histograms are summed over the point
+    // shards (MultiDevice::calibrate), no GPU ever holds the whole map
+    gpu->uploadIntensity(cloud.intensity.data(), static_cast<int64_t>(cloud.size()));
+    uploadImages(false);  // VisualLiDARCalibration reads the images itself, without generateColorMap's adjustment
+    T_camera_lidar_optimized = gpu->calibrate(&cost);
     std::printf("Final cost: %.3f\n--- T_camera_lidar ---\n", cost);
     for (int r = 0; r < 4; ++r)
       std::printf("%g %g %g %g\n", T_camera_lidar_optimized[4 * r], T_camera_lidar_optimized[4 * r + 1],

@@ -146,6 +146,33 @@ class MultiDevice {
     depth_ready_ = true;
   }
 
+  // pcl::PointXYZI::intensity of every point, sharded like the cloud
+  void uploadIntensity(const float *intensity, int64_t n) {
+    if (n != n_) throw std::runtime_error("pcp_multi: intensity for " + std::to_string(n) + " points, cloud has " + std::to_string(n_));
+    for (int r = 0; r < size(); ++r) device(r).uploadIntensity(intensity + shardBegin(r), shardBegin(r + 1) - shardBegin(r));
+  }
+
+  // VisualLiDARCalibration::calibrate (calibrate.cpp:42-126) over the shards: every GPU accumulates the keyframes' joint
+  // histograms of its points, one all-reduce(SUM) per cost evaluation adds them (8 B x F x 1808 at 16 bins), GPU 0's
+  // context turns the sums into cost and gradient for the BFGS loop.  Identity initial guess, 16 bins, <= 10 outer
+  // iterations as the one-GPU shim.
+  std::vector<double> calibrate(double *final_cost = nullptr) {
+    if (size() == 1) return VisualLiDARCalibration(device(0)).calibrate(final_cost);
+    if (!depth_ready_) depthPassAll();  // the shards' culls read the merged maps
+    for (int r = 0; r < size(); ++r) {
+      int64_t pts = 0;
+      device(r).check(pcp_nid_prepare(device(r).get(), &pts));
+    }
+    const double I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    std::vector<double> T(16);
+    int32_t evals = 0;
+    nid_error_.clear();
+    const int rc = pcp_nid_optimize_with(device(0).get(), &MultiDevice::nidEvaluate, this, I, 16, 10, T.data(), final_cost, &evals);
+    if (!nid_error_.empty()) throw std::runtime_error(nid_error_);
+    device(0).check(rc);
+    return T;
+  }
+
   // pcdColorizationAndSmooth: rgb (3 per input point) and the removePointsWithNoColor flag, input order
   void colorize(std::vector<uint8_t> &rgb, std::vector<uint8_t> &has) {
     rgb.resize(3 * static_cast<size_t>(n_));
@@ -221,6 +248,41 @@ class MultiDevice {
   }
 
  private:
+  // pcp_nid_eval_fn: the sharded MultiNIDCost at T
+  static int nidEvaluate(void *user, const double T[16], int32_t bins, double *cost, double grad6[6], int32_t *valid) {
+    MultiDevice &m = *static_cast<MultiDevice *>(user);
+    try {
+      for (int r = 0; r < m.size(); ++r) m.device(r).check(pcp_nid_accumulate(m.device(r).get(), T, bins));
+      std::vector<void *> ptr(static_cast<size_t>(m.size()));
+      int64_t count = 0;
+      for (int r = 0; r < m.size(); ++r)
+        m.device(r).check(pcp_nid_histograms_device(m.device(r).get(), &ptr[static_cast<size_t>(r)], &count));
+      if (m.rehearsal_) {
+        std::vector<double> sum(static_cast<size_t>(count), 0.0), part(static_cast<size_t>(count));
+        for (int r = 0; r < m.size(); ++r) {
+          m.device(r).check(pcp_synchronize(m.device(r).get()));
+          hip(hipMemcpy(part.data(), ptr[static_cast<size_t>(r)], part.size() * 8, hipMemcpyDeviceToHost), "hipMemcpy(NID histograms)");
+          for (size_t k = 0; k < sum.size(); ++k) sum[k] += part[k];
+        }
+        for (int r = 0; r < m.size(); ++r)
+          hip(hipMemcpy(ptr[static_cast<size_t>(r)], sum.data(), sum.size() * 8, hipMemcpyHostToDevice), "hipMemcpy(NID histograms)");
+      } else {
+        nccl(ncclGroupStart(), "ncclGroupStart");
+        for (int r = 0; r < m.size(); ++r)
+          nccl(ncclAllReduce(ptr[static_cast<size_t>(r)], ptr[static_cast<size_t>(r)], static_cast<size_t>(count), ncclDouble, ncclSum,
+                             m.comm_[static_cast<size_t>(r)], m.stream_[static_cast<size_t>(r)]),
+               "ncclAllReduce(NID histograms, SUM)");
+        nccl(ncclGroupEnd(), "ncclGroupEnd");
+      }
+      // the contexts' streams carry the all-reduce: pcp_nid_finish's copy is ordered behind it
+      m.device(0).check(pcp_nid_finish(m.device(0).get(), bins, cost, grad6, valid));
+      return PCP_OK;
+    } catch (const std::exception &e) {
+      m.nid_error_ = e.what();
+      return PCP_ERR_STATE;
+    }
+  }
+
   static void hip(hipError_t e, const char *what) {
     if (e != hipSuccess) throw std::runtime_error(std::string("pcp_multi: ") + what + ": " + hipGetErrorString(e));
   }
@@ -282,6 +344,7 @@ class MultiDevice {
   int64_t n_ = 0;
   int n_frames_ = 0;
   bool depth_ready_ = false;
+  std::string nid_error_;
 };
 
 }  // namespace pcp_amd

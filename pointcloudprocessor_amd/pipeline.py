@@ -179,6 +179,60 @@ class PointCloudColorizer:
         return dict(rgb=rgb, has=has)
 
 
+class VisualLiDARCalibration:
+    """vlcal::VisualLiDARCalibration::calibrate (calibrate.cpp:42-126) over an index-sharded map.
+
+    A keyframe's joint histogram is a sum over its points: every rank accumulates the histograms of its shard, the ranks
+    add them (all-reduce SUM, 8 B x F x (7 bins^2 + bins): 0.9 MB at 64 keyframes) and turn the sums into cost and
+    gradient -- identical numbers everywhere, so the BFGS loops of all ranks walk in lockstep without a broadcast.  The
+    shards' single-keyframe culls need the MIN-merged depth maps (PointCloudColorizer.run or depth pass + all-reduce
+    first, then ctx.set_depth_source(True))."""
+
+    def __init__(self, engine: HipEngine, rank: int = 0, world: int = 1, group=None):
+        self.engine = engine
+        self.rank = rank
+        self.world = world
+        self.group = group
+
+    def prepare(self) -> int:
+        return self.engine.ctx.nid_prepare()
+
+    def _hist_tensor(self):
+        import torch
+
+        ptr, n = self.engine.ctx.nid_histograms_device()
+        return torch.as_tensor(_DeviceArray(ptr, n, "<f8"), device=f"cuda:{self.engine.device}")
+
+    def evaluate(self, T, bins: int = 16):
+        ctx = self.engine.ctx
+        ctx.nid_accumulate(T, bins)
+        if self.world > 1:
+            import torch.distributed as dist
+
+            ctx.synchronize()
+            t = self._hist_tensor()
+            if dist.get_backend(self.group) == "nccl":
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                import torch
+
+                torch.cuda.current_stream().synchronize()
+            else:  # gloo rehearsal: through the host
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+                import torch
+
+                torch.cuda.synchronize()
+        return ctx.nid_finish(bins)
+
+    def calibrate(self, T_init=None, bins: int = 16, max_outer_iterations: int = 10):
+        """T_camera_lidar_optimized (4x4), final cost, evaluations -- identity initial guess as calibrate.cpp:45-51"""
+        Ti = np.eye(4) if T_init is None else np.asarray(T_init, np.float64)
+        if self.world == 1:
+            return self.engine.ctx.nid_optimize(Ti, bins, max_outer_iterations)
+        return self.engine.ctx.nid_optimize_with(self.evaluate, Ti, bins, max_outer_iterations)
+
+
 class CloudSmooth:
     """CloudSmooth::process: MovingLeastSquares (+ optional SOR brackets)."""
 

@@ -386,3 +386,38 @@ def test_cli_sharded_run_equals_single_gpu_run(tmp_path):
     for name in outs["1"]:
         assert outs["1"][name] == outs["3"][name], name
     assert outs["1"]["cloudInWorldWithRGB.pcd"].count(b"\n") > 1000
+
+
+@pytest.mark.gpu
+def test_cli_sharded_nid_refinement(tmp_path):
+    """--enableNIDOptimize 1 with --gpus 2 (rehearsal on one GPU: the shards' joint histograms are added through the
+    host where RCCL's all-reduce(SUM) would run): the refined extrinsic equals the one-GPU run's to rounding, and so do
+    the colours it leads to."""
+    from pointcloudprocessor_amd import synth
+
+    W, H = 1024, 750
+    x, y, z, inten = synth.make_cloud(40001, seed=4)
+    _write_pcd_binary(tmp_path / "scans.pcd", x, y, z, inten)
+    poses, ts = synth.make_trajectory(4)
+    with open(tmp_path / "odo.txt", "w") as f:
+        for k, (t, p) in enumerate(zip(ts, poses)):
+            f.write(synth.odometry_line(t, p))
+            with open(tmp_path / ("%f.ppm" % t), "wb") as g:
+                g.write(b"P6\n%d %d\n255\n" % (W, H) + synth.make_image(k, W, H)[:, :, ::-1].tobytes())
+    T, rgb = {}, {}
+    for gpus in ("1", "2"):
+        d = tmp_path / ("out" + gpus)
+        d.mkdir()
+        env = dict(os.environ, PCP_MULTI_REHEARSAL="1")
+        p = subprocess.run([_exe(), "-p", str(tmp_path / "scans.pcd"), "-o", str(tmp_path / "odo.txt"), "-i", str(tmp_path) + "/",
+                            "-t", str(d) + "/", "--enableNIDOptimize", "1", "--gpus", gpus], capture_output=True, text=True, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        T[gpus] = np.loadtxt(d / "T_camera_lidar_optimized.txt").reshape(4, 4)
+        rgb[gpus] = (d / "cloudInWorldWithRGB.pcd").read_bytes()
+    assert not np.array_equal(T["1"], np.eye(4))  # the optimiser moved
+    np.testing.assert_allclose(T["2"], T["1"], atol=1e-7)
+    if np.array_equal(T["1"], T["2"]):
+        assert rgb["1"] == rgb["2"]
+    else:  # a last-digit difference of the pose may flip a handful of samples
+        a, b = rgb["1"].split(b"\n"), rgb["2"].split(b"\n")
+        assert abs(len(a) - len(b)) <= 5

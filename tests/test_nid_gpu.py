@@ -125,3 +125,79 @@ def test_nid_optimiser_recovers_a_perturbed_extrinsic(gpu_ctx_factory, oracle):
     ref = oracle.colorize(cam_struct(oracle, cd), oracle.default_cull_params(), x, y, z, poses, images, T_opt=T,
                           threads=8, want_top=False)
     assert np.array_equal(out["rgb"], ref["rgb"]) and np.array_equal(out["has"], ref["has"])
+
+
+def test_nid_over_index_shards(oracle):
+    """The multi-GPU scheme of the NID stage on one GPU: two contexts hold the halves of the map, their depth maps are
+    MIN-merged, each accumulates its own joint histograms, the histograms are added (what the all-reduce(SUM) does) and
+    either context turns the sums into the cost: == the unsharded cost and gradient to rounding, and the evaluator-driven
+    optimiser lands where pcp_nid_optimize lands."""
+    import torch
+
+    from pointcloudprocessor_amd import capi, pipeline
+
+    cd, x, y, z, inten, poses, images, _ = _scene(oracle)
+    n = len(x)
+
+    def make(lo, hi, batched):
+        c = capi.Context(0)
+        c.set_camera(cam_struct(capi, cd))
+        c.upload_cloud(x[lo:hi], y[lo:hi], z[lo:hi])
+        c.upload_intensity(inten[lo:hi])
+        c.set_frames(poses)
+        for f, im in enumerate(images):
+            c.upload_image(f, im)
+        if batched:
+            c.set_depth_source(True)
+            c.depth_pass()
+        return c
+
+    full = make(0, n, False)
+    total = full.nid_prepare()
+    shards = [make(*pipeline.shard_bounds(n, r, 2), True) for r in range(2)]
+
+    def view(ptr, count, typestr):
+        return torch.as_tensor(pipeline._DeviceArray(ptr, count, typestr), device="cuda:0")
+
+    maps = [view(*c.depth_maps_device(), "<f4") for c in shards]
+    for c in shards:
+        c.synchronize()
+    merged = torch.minimum(maps[0], maps[1])
+    for t in maps:
+        t.copy_(merged)
+    torch.cuda.synchronize()
+    assert sum(c.nid_prepare() for c in shards) == total
+
+    def evaluate(T, bins=16):
+        for c in shards:
+            c.nid_accumulate(T, bins)
+            c.synchronize()
+        hists = [view(*c.nid_histograms_device(), "<f8") for c in shards]
+        s = hists[0] + hists[1]
+        for h in hists:
+            h.copy_(s)
+        torch.cuda.synchronize()
+        a, b = shards[0].nid_finish(bins), shards[1].nid_finish(bins)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[2] == b[2]
+        return a
+
+    for d in (np.zeros(6), np.array([0.01, -0.02, 0.015, 0.004, -0.006, 0.003])):
+        T = _se3_exp(d)
+        c0, g0, ok0 = full.nid_evaluate(T)
+        c1, g1, ok1 = evaluate(T)
+        assert ok0 and ok1
+        assert abs(c1 - c0) <= 1e-12 * abs(c0)
+        np.testing.assert_allclose(g1, g0, rtol=1e-9, atol=1e-12)
+    T_true = _se3_exp(np.array([0.012, -0.008, 0.01, 0.003, -0.004, 0.002]))
+    Ta, fa, ea = full.nid_optimize(T_true)
+    Tb, fb, eb = shards[0].nid_optimize_with(evaluate, T_true)
+    assert ea > 1 and eb > 1
+    assert abs(fa - fb) <= 1e-9 * abs(fa)
+    np.testing.assert_allclose(Tb, Ta, atol=1e-7)
+    # an evaluator that fails surfaces as the Python exception, not as a wrong pose
+    def broken(T, bins):
+        raise ValueError("boom")
+    with pytest.raises(ValueError):
+        shards[0].nid_optimize_with(broken, T_true)
+    for c in shards + [full]:
+        c.close()
