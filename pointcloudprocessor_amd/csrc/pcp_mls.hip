@@ -929,7 +929,7 @@ typedef float sel_v2f __attribute__((ext_vector_type(2)));
 typedef float sel_v4f __attribute__((ext_vector_type(4)));
 typedef uint32_t sel_v4u __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(kSelWave) void k_sor_select(const float *__restrict__ sx, const float *__restrict__ sy,
+__global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_sor_select(const float *__restrict__ sx, const float *__restrict__ sy,
                                                          const float *__restrict__ sz,
                                                          const int32_t *__restrict__ order,
                                                          const int32_t *__restrict__ remap,
@@ -1234,7 +1234,7 @@ __global__ __launch_bounds__(kSelWave) void k_sor_select(const float *__restrict
 //   3. sqrt of the entries below the prefix (+ the ones in play, or the missing multiple of the one remaining value),
 //      exact fp64 wave sum, minus the nearest (the point itself).
 // A point whose block holds more values than the cache stays flagged (2) for the heap kernel.
-constexpr int kWsCap = 2048;
+constexpr int kWsCap = 1024;
 constexpr int kWsRows = 8;
 __global__ __launch_bounds__(kSelWave) void k_sor_wave(const float *__restrict__ sx, const float *__restrict__ sy,
                                                        const float *__restrict__ sz, const int32_t *__restrict__ order,
