@@ -244,7 +244,7 @@ __device__ __forceinline__ float sqdist_f32(float ax, float ay, float az, float 
 // longer than 4096 points, or a grid with reach > 1) take the plain loops.
 constexpr int kMaxNbr = 96;
 constexpr int kMaxRun = 9;
-constexpr int kFitBlock = 128;  // 28.5 KB of LDS per workgroup: LDS does not cap the occupancy the VGPRs allow
+constexpr int kFitBlock = 64;  // 14.3 KB of LDS per wavefront: 11 wavefronts per CU (the 140 VGPRs would allow 12)
 
 // kBuf: the cell-sorted coordinate planes are read through buffer descriptors (uniform base, 32-bit byte offset per
 // lane: one shift per candidate instead of three 64-bit addresses); needs n < 2^30 points.
