@@ -122,3 +122,16 @@ def test_sor_fewer_points_than_neighbours(gpu_ctx_factory, oracle):
     ctx = gpu_ctx_factory()
     _check(ctx, oracle, pts[:, 0].copy(), pts[:, 1].copy(), pts[:, 2].copy(), 60, 0.7)
     _check(ctx, oracle, pts[:, 0].copy(), pts[:, 1].copy(), pts[:, 2].copy(), 24, 1.0)
+
+
+@pytest.mark.parametrize("mean_k", [127, 200, 254])
+def test_sor_large_neighbour_counts(gpu_ctx_factory, oracle, mean_k):
+    """mean_k up to the ABI's limit: the selection kernel's lists do not depend on k (<= 250 neighbours), beyond that the
+    heap kernel runs alone with 130 KB of LDS per workgroup."""
+    rng = np.random.default_rng(1)
+    n = 20000
+    a = rng.uniform(-0.5, 0.5, (n, 2))
+    pts = np.stack([a[:, 0], a[:, 1], rng.normal(0, 1e-3, n)], 1).astype(np.float32)
+    ctx = gpu_ctx_factory()
+    _check(ctx, oracle, pts[:, 0].copy(), pts[:, 1].copy(), pts[:, 2].copy(), mean_k, 1.0)
+    assert (ctx.sor_redo_fraction() == 0.0) == (mean_k + 1 > 250)
