@@ -389,22 +389,44 @@ def test_cli_sharded_run_equals_single_gpu_run(tmp_path):
 
 
 @pytest.mark.gpu
-def test_cli_sharded_nid_refinement(tmp_path):
+def test_cli_sharded_nid_refinement(tmp_path, oracle):
     """--enableNIDOptimize 1 with --gpus 2 (rehearsal on one GPU: the shards' joint histograms are added through the
-    host where RCCL's all-reduce(SUM) would run): the refined extrinsic equals the one-GPU run's to rounding, and so do
-    the colours it leads to."""
+    host where RCCL's all-reduce(SUM) would run) against the one-GPU run.  The images are rendered from the cloud's
+    intensities through a slightly displaced extrinsic, so the cost has a real minimum away from the identity the CLI
+    starts at (on unrelated images the landscape is noise and rounding decides where BFGS stops); the exact equality of
+    the sharded and the unsharded cost is tests/test_nid_gpu.py::test_nid_over_index_shards."""
     from pointcloudprocessor_amd import synth
 
-    W, H = 1024, 750
-    x, y, z, inten = synth.make_cloud(40001, seed=4)
+    W, H = 2400, 1800  # the CLI keeps the reference's K (cx = 2032, cy = 1535): the image must reach the optical axis
+    n = 300_001
+    x, y, z, _ = synth.make_cloud(n, seed=8)
+    inten = (0.5 + 0.5 * np.sin(2.1 * x) * np.sin(1.7 * y + 0.3) * np.sin(2.9 * z + 1.0)).astype(np.float32)
     _write_pcd_binary(tmp_path / "scans.pcd", x, y, z, inten)
     poses, ts = synth.make_trajectory(4)
+    cam, cp = oracle.default_camera(), oracle.default_cull_params()
+    cam.image_width, cam.image_height = W, H
+    T_true = np.eye(4)
+    T_true[:3, 3] = [0.012, -0.008, 0.01]
+    g = 16
     with open(tmp_path / "odo.txt", "w") as f:
         for k, (t, p) in enumerate(zip(ts, poses)):
             f.write(synth.odometry_line(t, p))
-            with open(tmp_path / ("%f.ppm" % t), "wb") as g:
-                g.write(b"P6\n%d %d\n255\n" % (W, H) + synth.make_image(k, W, H)[:, :, ::-1].tobytes())
-    T, rgb = {}, {}
+            w2c, _ = oracle.pose_to_matrices(p, T_true)
+            keep, _, _ = oracle.cull_frame(cam, cp, w2c, x, y, z, 8)
+            pr = oracle.project_frame(cam, cp, w2c, x, y, z)
+            vis = np.nonzero(keep & (pr["pixel"] >= 0))[0]
+            acc = np.zeros(((H + g - 1) // g, (W + g - 1) // g))
+            cnt = np.zeros_like(acc)
+            v, u = np.divmod(pr["pixel"][vis], W)
+            np.add.at(acc, (v // g, u // g), inten[vis])
+            np.add.at(cnt, (v // g, u // g), 1.0)
+            gray = np.kron(np.where(cnt > 0, acc / np.maximum(cnt, 1), 0.5), np.ones((g, g)))[:H, :W]
+            g8 = (np.clip(gray, 0, 1) * 255).astype(np.uint8)
+            img = np.full((H, W, 3), 128, np.uint8)  # the reference reads the interleaved row as one channel (nid_cost.hpp:87)
+            img.reshape(H, W * 3)[:, :W] = g8
+            with open(tmp_path / ("%f.ppm" % t), "wb") as gf:
+                gf.write(b"P6\n%d %d\n255\n" % (W, H) + img[:, :, ::-1].tobytes())
+    T, cost, rows = {}, {}, {}
     for gpus in ("1", "2"):
         d = tmp_path / ("out" + gpus)
         d.mkdir()
@@ -413,11 +435,9 @@ def test_cli_sharded_nid_refinement(tmp_path):
                             "-t", str(d) + "/", "--enableNIDOptimize", "1", "--gpus", gpus], capture_output=True, text=True, env=env)
         assert p.returncode == 0, p.stderr[-2000:]
         T[gpus] = np.loadtxt(d / "T_camera_lidar_optimized.txt").reshape(4, 4)
-        rgb[gpus] = (d / "cloudInWorldWithRGB.pcd").read_bytes()
-    assert not np.array_equal(T["1"], np.eye(4))  # the optimiser moved
-    np.testing.assert_allclose(T["2"], T["1"], atol=1e-7)
-    if np.array_equal(T["1"], T["2"]):
-        assert rgb["1"] == rgb["2"]
-    else:  # a last-digit difference of the pose may flip a handful of samples
-        a, b = rgb["1"].split(b"\n"), rgb["2"].split(b"\n")
-        assert abs(len(a) - len(b)) <= 5
+        cost[gpus] = float([l for l in p.stdout.splitlines() if l.startswith("Final cost:")][0].split(":")[1])
+        rows[gpus] = (d / "cloudInWorldWithRGB.pcd").read_bytes().count(b"\n")
+    assert np.abs(T["1"] - np.eye(4)).max() > 1e-3, "the optimiser did not move"
+    np.testing.assert_allclose(T["2"], T["1"], atol=5e-4)
+    assert abs(cost["1"] - cost["2"]) <= 1e-3 * abs(cost["1"]) + 1e-3  # printed with 3 decimals
+    assert abs(rows["1"] - rows["2"]) <= 0.01 * rows["1"] and rows["1"] > 1000
