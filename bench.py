@@ -599,6 +599,11 @@ def main():
         }
         if args.backend != "nccl":
             result["rehearsal"] = f"backend {args.backend}: ranks share GPUs, not a measurement"
+        # the two boundaries side by side: `value` is the contract's -- inputs resident in HBM when the
+        # timed region starts --, `value_host_images` SURVEY 8(d)(i)'s: keyframes start in pinned host memory
+        result["value_resident"] = round(value, 1)
+        if host_images and "value" in host_images:
+            result["value_host_images"] = host_images["value"]
         if cpu:
             result["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
             if host_images and "value" in host_images:
