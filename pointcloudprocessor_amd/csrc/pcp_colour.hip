@@ -187,38 +187,28 @@ __device__ __forceinline__ int tile_classify(const DevCamera &c, const DevFrame 
              : 0;
 }
 
-// Two launches: first the spheres of groups of 16 tiles (one lane per (group, 32-keyframe
-// word)), then the tiles (one lane per (tile, word)), which only test keyframes their group
-// survived -- most groups are rejected as a whole, and a wavefront of the second launch
-// covers just 4 groups, so it skips most keyframes altogether.
+// Two launches: first the spheres of groups of 16 tiles against every keyframe, then the tiles, which only test
+// keyframes their group survived -- most groups are rejected as a whole.
 constexpr int kTileGroup = 16;
 
-__global__ __launch_bounds__(kBlock) void k_tile_mask(const float4 *__restrict__ spheres, int64_t tiles, DevCamera cam,
-                                                      const DevFrame *__restrict__ frames, int32_t n_frames,
-                                                      int32_t w0, int32_t w1, int32_t words,
-                                                      const uint32_t *__restrict__ parent_mask, int32_t parent_shift,
-                                                      uint32_t *__restrict__ tile_mask,
-                                                      uint32_t *__restrict__ inside_mask, int32_t cull_enabled) {
-  const int64_t g = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+// Group level, flat form: one lane per (group, keyframe); the 32 lanes of a half wavefront are the bits of one mask
+// word, gathered by a ballot.  (A lane per (group, word) gives 1 224 wavefronts at C3, each looping over
+// 32 keyframes: barely more than one wavefront per SIMD, 48 us of pure latency; this form has 32 times the lanes.)
+__global__ __launch_bounds__(kBlock) void k_group_mask_flat(const float4 *__restrict__ spheres, int64_t groups, DevCamera cam,
+                                                            const DevFrame *__restrict__ frames, int32_t n_frames,
+                                                            int32_t w0, int32_t w1, int32_t words,
+                                                            uint32_t *__restrict__ group_mask, int32_t cull_enabled) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const int32_t nw = w1 - w0;
-  const int64_t tile = g / nw;
-  if (tile >= tiles) return;
-  const int32_t w = w0 + static_cast<int32_t>(g - tile * nw);
-  const float4 sph = spheres[tile];
-  uint32_t todo = 0xffffffffu;
-  if (parent_mask) todo = parent_mask[(tile >> parent_shift) * words + w];
-  uint32_t word = 0u, inside = 0u;
-  while (todo) {
-    const int32_t b = __builtin_ctz(todo);
-    todo &= todo - 1u;
-    const int32_t f = (w << 5) + b;
-    if (f >= n_frames) break;
-    const int cls = cull_enabled ? tile_classify(cam, frames[f], sph) : 0;
-    if (cls != 1) word |= 1u << b;
-    if (cls == 2) inside |= 1u << b;
-  }
-  tile_mask[tile * words + w] = word;
-  if (inside_mask) inside_mask[tile * words + w] = inside;
+  const int64_t gw = idx >> 5;  // word of this half wavefront, counted over the launch
+  const int64_t group = gw / nw;
+  const bool live = group < groups;
+  const int32_t w = w0 + static_cast<int32_t>(gw - group * nw);
+  const int32_t f = (w << 5) + static_cast<int32_t>(idx & 31);
+  bool keep = false;
+  if (live && f < n_frames) keep = !cull_enabled || tile_classify(cam, frames[f], spheres[group]) != 1;
+  const unsigned long long m = __ballot(keep);
+  if (live && (idx & 31) == 0) group_mask[group * words + w] = static_cast<uint32_t>((threadIdx.x & 32) ? (m >> 32) : m);
 }
 
 // Tile level, dense form: one wavefront per group of 16 tiles, lane = slot * 16 + tile-in-group.  The
@@ -1401,10 +1391,9 @@ int pcp_depth_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
       const int64_t groups = div_up(ctx->n_tiles, kTileGroup);
       const float4 *tile_sph = reinterpret_cast<const float4 *>(ctx->tile_sphere.p);
       PCP_HIP_TRY(ctx, ctx->group_mask.ensure(static_cast<size_t>(groups) * ctx->mask_words + 4));
-      hipLaunchKernelGGL(k_tile_mask, dim3(blocks_for(groups * (w1 - w0))), dim3(kBlock), 0, ctx->stream,
+      hipLaunchKernelGGL(k_group_mask_flat, dim3(blocks_for(groups * (w1 - w0) * 32)), dim3(kBlock), 0, ctx->stream,
                          tile_sph + ctx->n_tiles, groups, ctx->dcam, ctx->frames.p, ctx->n_frames, w0, w1,
-                         ctx->mask_words, static_cast<const uint32_t *>(nullptr), 0, ctx->group_mask.p,
-                         static_cast<uint32_t *>(nullptr), cull_tiles ? 1 : 0);
+                         ctx->mask_words, ctx->group_mask.p, cull_tiles ? 1 : 0);
       hipLaunchKernelGGL(k_tile_mask_dense, dim3(static_cast<uint32_t>(div_up(groups, kBlock / 64))), dim3(kBlock), 0,
                          ctx->stream, tile_sph, ctx->n_tiles, ctx->dcam, ctx->frames.p, ctx->n_frames, w0, w1,
                          ctx->mask_words, ctx->group_mask.p, ctx->tile_mask.p, ctx->tile_inside.p, ctx->tile_work.p,
