@@ -211,31 +211,33 @@ __global__ __launch_bounds__(kBlock) void k_group_mask_flat(const float4 *__rest
   if (live && (idx & 31) == 0) group_mask[group * words + w] = static_cast<uint32_t>((threadIdx.x & 32) ? (m >> 32) : m);
 }
 
-// Tile level, dense form: one wavefront per group of 16 tiles, lane = slot * 16 + tile-in-group.  The
-// keyframes the group survived (its parent mask) are taken four at a time, so all 64 lanes classify
-// (tile, keyframe) pairs until the group's list is exhausted (the lane-per-(tile, word) form ran at 32 %
-// lane utilisation: every lane looped over its own number of surviving keyframes).  The verdicts are
+// Tile level, dense form: one wavefront per (group of 16 tiles, 32-keyframe word), lane = slot * 16 + tile-in-group.
+// The keyframes of the word that the group survived (its parent mask) are taken four at a time, so all 64 lanes
+// classify (tile, keyframe) pairs until the word is exhausted (a lane per (tile, word) ran at 32 % lane utilisation:
+// every lane looped over its own number of surviving keyframes; a wavefront per group with all its words: 9 768
+// wavefronts at C3, barely more than the chip holds at once, the longest deciding the kernel).  The verdicts are
 // gathered with wave ballots; the 16 lanes of slot 0 own their tiles' mask words.
 __global__ __launch_bounds__(kBlock) void k_tile_mask_dense(const float4 *__restrict__ spheres, int64_t tiles,
                                                             DevCamera cam, const DevFrame *__restrict__ frames,
                                                             int32_t n_frames, int32_t w0, int32_t w1, int32_t words,
                                                             const uint32_t *__restrict__ group_mask,
                                                             uint32_t *__restrict__ tile_mask,
-                                                            uint32_t *__restrict__ inside_mask,
-                                                            int32_t *__restrict__ tile_work, int32_t cull_enabled) {
+                                                            uint32_t *__restrict__ inside_mask, int32_t cull_enabled) {
   const int lane = threadIdx.x & 63;
-  const int64_t group = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6);
+  const int32_t nw = w1 - w0;
+  const int64_t gw = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6);
+  const int64_t group = gw / nw;
   if (group >= (tiles + kTileGroup - 1) / kTileGroup) return;  // whole wavefronts leave together
+  const int32_t w = w0 + static_cast<int32_t>(gw - group * nw);
   const int t = lane & 15, slot = lane >> 4;
   const int64_t tile = group * kTileGroup + t;
   const bool have = tile < tiles;
-  const float4 sph = spheres[have ? tile : tiles - 1];
-  int32_t visits = 0;  // keyframes this tile will walk: the scheduling weight of its wavefront
-  for (int32_t w = w0; w < w1; ++w) {
-    uint32_t todo = __builtin_amdgcn_readfirstlane(group_mask[group * words + w]);
-    const int32_t nb = n_frames - (w << 5);
-    if (nb < 32) todo &= nb <= 0 ? 0u : ((1u << nb) - 1u);
-    uint32_t word = 0u, inside = 0u;
+  uint32_t todo = __builtin_amdgcn_readfirstlane(group_mask[group * words + w]);
+  const int32_t nb = n_frames - (w << 5);
+  if (nb < 32) todo &= nb <= 0 ? 0u : ((1u << nb) - 1u);
+  uint32_t word = 0u, inside = 0u;
+  if (todo) {
+    const float4 sph = spheres[have ? tile : tiles - 1];
     while (todo) {
       int32_t bit[4];
 #pragma unroll
@@ -255,13 +257,21 @@ __global__ __launch_bounds__(kBlock) void k_tile_mask_dense(const float4 *__rest
         }
       }
     }
-    if (slot == 0 && have) {
-      tile_mask[tile * words + w] = word;
-      if (inside_mask) inside_mask[tile * words + w] = inside;
-    }
-    visits += __builtin_popcount(word);
   }
-  if (tile_work && slot == 0 && have) tile_work[tile] = visits;
+  if (slot == 0 && have) {
+    tile_mask[tile * words + w] = word;
+    if (inside_mask) inside_mask[tile * words + w] = inside;
+  }
+}
+
+// keyframes a tile will walk in this pass: the scheduling weight of its wavefront
+__global__ __launch_bounds__(kBlock) void k_tile_work(const uint32_t *__restrict__ tile_mask, int64_t tiles, int32_t w0,
+                                                      int32_t w1, int32_t words, int32_t *__restrict__ tile_work) {
+  const int64_t tile = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (tile >= tiles) return;
+  int32_t visits = 0;
+  for (int32_t w = w0; w < w1; ++w) visits += __builtin_popcount(tile_mask[tile * words + w]);
+  tile_work[tile] = visits;
 }
 
 // Longest-work-first order of the tiles (counting sort on the number of keyframes a tile walks, descending).  The
@@ -1394,10 +1404,11 @@ int pcp_depth_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
       hipLaunchKernelGGL(k_group_mask_flat, dim3(blocks_for(groups * (w1 - w0) * 32)), dim3(kBlock), 0, ctx->stream,
                          tile_sph + ctx->n_tiles, groups, ctx->dcam, ctx->frames.p, ctx->n_frames, w0, w1,
                          ctx->mask_words, ctx->group_mask.p, cull_tiles ? 1 : 0);
-      hipLaunchKernelGGL(k_tile_mask_dense, dim3(static_cast<uint32_t>(div_up(groups, kBlock / 64))), dim3(kBlock), 0,
-                         ctx->stream, tile_sph, ctx->n_tiles, ctx->dcam, ctx->frames.p, ctx->n_frames, w0, w1,
-                         ctx->mask_words, ctx->group_mask.p, ctx->tile_mask.p, ctx->tile_inside.p, ctx->tile_work.p,
-                         cull_tiles ? 1 : 0);
+      hipLaunchKernelGGL(k_tile_mask_dense, dim3(static_cast<uint32_t>(div_up(groups * (w1 - w0), kBlock / 64))), dim3(kBlock),
+                         0, ctx->stream, tile_sph, ctx->n_tiles, ctx->dcam, ctx->frames.p, ctx->n_frames, w0, w1,
+                         ctx->mask_words, ctx->group_mask.p, ctx->tile_mask.p, ctx->tile_inside.p, cull_tiles ? 1 : 0);
+      hipLaunchKernelGGL(k_tile_work, dim3(blocks_for(ctx->n_tiles)), dim3(kBlock), 0, ctx->stream, ctx->tile_mask.p,
+                         ctx->n_tiles, w0, w1, ctx->mask_words, ctx->tile_work.p);
       // longest-work-first order of the tiles for this pass
       if ((rc = sort_tiles_by_work(ctx, ctx->tile_order.p)) != PCP_OK) return rc;
       ctx->tile_order_live = true;
