@@ -604,6 +604,7 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->g_order.release();
   ctx->g_xyz.release();
   ctx->m_tmp.release();
+  ctx->s_dist.release();
   ctx->m_state.release();
   ctx->m_flag.release();
   ctx->intensity.release();

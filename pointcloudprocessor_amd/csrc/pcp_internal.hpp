@@ -189,11 +189,12 @@ struct pcp_context {
   pcp::DevBuf<int32_t> g_cell, g_rank, g_start, g_order;
   pcp::DevBuf<float> g_xyz;      // cell-sorted x[n] y[n] z[n]
   pcp::DevBuf<float> m_tmp;      // 7 floats per input point (xyz, normal, curvature), input order
+  pcp::DevBuf<float> s_dist;     // StatisticalOutlierRemoval: mean kNN distance per point
   pcp::DevBuf<double> m_state;   // per-point MLSResult (mean, axes, c_vec ...) for upsampling
   pcp::DevBuf<uint8_t> m_flag;   // n
   pcp::DevBuf<double> m_sums;    // SOR statistics
   pcp::DevBuf<int32_t> c_index;  // pcp_cloud_smooth: survivors of the 1st SOR (indices into the uploaded cloud)
-  bool sor_distances_live = false;  // m_tmp holds the mean distances of the last pcp_sor (caller's order)
+  bool sor_distances_live = false;  // s_dist holds the mean distances of the last pcp_sor (caller's order)
   pcp::DevBuf<uint8_t> c_mark;    // pcp_cloud_smooth: per uploaded point, survives the whole chain
   pcp::DevBuf<int32_t> c_where;   // ... and the result row that holds it
   pcp::DevBuf<float> c_xyz, c_xyz2;  // pcp_cloud_smooth: intermediate clouds (SoA)

@@ -1515,10 +1515,38 @@ __global__ __launch_bounds__(kMB) void k_mark_rows(const uint8_t *__restrict__ f
   where[i] = static_cast<int32_t>(r);
 }
 
-// list[t] = where[list[t]]
-__global__ __launch_bounds__(kMB) void k_lookup_rows(int32_t *__restrict__ list, int64_t m, const int32_t *__restrict__ where) {
+// positions of the fitted rows as SoA planes: out[k] = rows[index[k]].xyz
+__global__ __launch_bounds__(kMB) void k_rows_xyz(const float *__restrict__ rows, const int32_t *__restrict__ index, int64_t m,
+                                                  float *__restrict__ ox, float *__restrict__ oy, float *__restrict__ oz) {
+  const int64_t k = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  if (k >= m) return;
+  const float *t = rows + static_cast<int64_t>(index[k]) * 7;
+  ox[k] = t[0];
+  oy[k] = t[1];
+  oz[k] = t[2];
+}
+
+// out[k] = map[in[k]]
+__global__ __launch_bounds__(kMB) void k_remap_index_to(const int32_t *__restrict__ in, int64_t m, const int32_t *__restrict__ map,
+                                                        int32_t *__restrict__ out) {
+  const int64_t k = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  if (k < m) out[k] = map[in[k]];
+}
+
+// the chain's survivors in the caller's order: result t is the point list[t]; where[] names its row among the fitted
+// rows, row_view[] that row's place in rows[]
+__global__ __launch_bounds__(kMB) void k_final_rows(const int32_t *__restrict__ list, int64_t kept, const int32_t *__restrict__ where,
+                                                    const int32_t *__restrict__ row_view, const float *__restrict__ rows,
+                                                    float *__restrict__ xyz, float *__restrict__ normal, float *__restrict__ curv,
+                                                    int32_t *__restrict__ index) {
   const int64_t t = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
-  if (t < m) list[t] = where[list[t]];
+  if (t >= kept) return;
+  const int32_t i = list[t];
+  const float *r = rows + static_cast<int64_t>(row_view[where[i]]) * 7;
+  xyz[3 * t + 0] = r[0]; xyz[3 * t + 1] = r[1]; xyz[3 * t + 2] = r[2];
+  normal[3 * t + 0] = r[3]; normal[3 * t + 1] = r[4]; normal[3 * t + 2] = r[5];
+  curv[t] = r[6];
+  index[t] = i;
 }
 
 // out[k] = in[index[k]] for three SoA planes
@@ -1790,11 +1818,12 @@ static int check_mls_params(pcp_context *ctx, const pcp_mls_params *p) {
 }
 
 // MovingLeastSquares::process on a cloud view; results in ctx->mls_* (index = view index)
+// keep_rows: leave the fitted rows in ctx->m_tmp (7 floats at the view index mls_index names) instead of gathering them
+// into the result arrays -- pcp_cloud_smooth picks the survivors of its last filter straight from there
 static int mls_run(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *p, int64_t *out_count,
-                   int64_t q_begin = 0, int64_t q_end = -1) {
+                   int64_t q_begin = 0, int64_t q_end = -1, bool keep_rows = false) {
   const int64_t n = cv.n;
   ctx->mls_count = 0;
-  ctx->sor_distances_live = false;  // m_tmp is reused
   if (out_count) *out_count = 0;
   if (n == 0) return PCP_OK;
   const size_t sn = static_cast<size_t>(n);
@@ -1845,7 +1874,7 @@ static int mls_run(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *
   PCP_HIP_TRY(ctx, ctx->mls_xyz.ensure(3 * static_cast<size_t>(m) + 4));
   PCP_HIP_TRY(ctx, ctx->mls_normal.ensure(3 * static_cast<size_t>(m) + 4));
   PCP_HIP_TRY(ctx, ctx->mls_curv.ensure(static_cast<size_t>(m) + 4));
-  if (m > 0) {
+  if (m > 0 && !keep_rows) {
     LaunchTimer t(ctx, PCP_K_MLS_FIT);
     hipLaunchKernelGGL(k_mls_gather, dim3(blocks_of(m)), dim3(kMB), 0, ctx->stream, ctx->m_tmp.p, ctx->mls_index.p, m,
                        ctx->mls_xyz.p, ctx->mls_normal.p, ctx->mls_curv.p);
@@ -1908,11 +1937,11 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
     rc = build_grid(ctx, cv, static_cast<float>(final_cell), static_cast<float>(final_cell), &g);
     if (rc != PCP_OK) return rc;
   }
-  PCP_HIP_TRY(ctx, ctx->m_tmp.ensure(sn + 8));
+  PCP_HIP_TRY(ctx, ctx->s_dist.ensure(sn + 8));
   PCP_HIP_TRY(ctx, ctx->m_flag.ensure(sn + 16));
   PCP_HIP_TRY(ctx, ctx->m_sums.ensure(4));
   PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->m_sums.p, 0, 2 * sizeof(double), ctx->stream));
-  float *dist = ctx->m_tmp.p;
+  float *dist = ctx->s_dist.p;
   const size_t heap_lds = static_cast<size_t>(mean_k + 1) * kSorBlock * sizeof(float);
   const char *heap_only = std::getenv("PCP_SOR_HEAP_ONLY");
   // the selection kernel addresses the coordinate planes through buffer descriptors (32-bit byte offsets)
@@ -2113,24 +2142,32 @@ int pcp_cloud_smooth(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_cou
   PCP_HIP_TRY(ctx, hipGetLastError());
   CloudView cv1;
   if ((rc = view_of(ctx, x1, y1, z1, n1, &cv1)) != PCP_OK) return rc;
-  // MLS (cloudSmooth.cpp:124-154)
+  // MLS (cloudSmooth.cpp:124-154).  Without upsampling the fitted rows stay where the fit wrote them (7 floats per point
+  // of cloud 1): the second filter only needs their positions, and the survivors are picked from there at the end.
+  const bool plain = p->upsampling == 0;
   int64_t m = 0;
-  if ((rc = mls_run(ctx, cv1, p, &m)) != PCP_OK) return rc;
+  if ((rc = mls_run(ctx, cv1, p, &m, 0, -1, /*keep_rows=*/plain)) != PCP_OK) return rc;
   if (m == 0) return PCP_OK;
-  // source indices back to the uploaded cloud
-  hipLaunchKernelGGL(k_remap_index, dim3(blocks_of(m)), dim3(kMB), 0, ctx->stream, ctx->mls_index.p, m, ctx->c_index.p);
-  PCP_HIP_TRY(ctx, hipGetLastError());
-  // 2nd SOR on the MLS output (cloudSmooth.cpp:160-164)
   const size_t plane2 = (static_cast<size_t>(m) + 3) & ~size_t(3);
   PCP_HIP_TRY(ctx, ctx->c_xyz2.ensure(3 * plane2 + 4));
   float *x2 = ctx->c_xyz2.p, *y2 = ctx->c_xyz2.p + plane2, *z2 = ctx->c_xyz2.p + 2 * plane2;
-  hipLaunchKernelGGL(k_deinterleave, dim3(blocks_of(m)), dim3(kMB), 0, ctx->stream, ctx->mls_xyz.p, m, x2, y2, z2);
+  int32_t *row_caller = c_pos;  // the caller's index of every fitted row (c_pos is free again)
+  if (plain) {
+    hipLaunchKernelGGL(k_remap_index_to, dim3(blocks_of(m)), dim3(kMB), 0, ctx->stream, ctx->mls_index.p, m, ctx->c_index.p,
+                       row_caller);
+    hipLaunchKernelGGL(k_rows_xyz, dim3(blocks_of(m)), dim3(kMB), 0, ctx->stream, ctx->m_tmp.p, ctx->mls_index.p, m, x2, y2, z2);
+  } else {
+    // source indices back to the uploaded cloud
+    hipLaunchKernelGGL(k_remap_index, dim3(blocks_of(m)), dim3(kMB), 0, ctx->stream, ctx->mls_index.p, m, ctx->c_index.p);
+    hipLaunchKernelGGL(k_deinterleave, dim3(blocks_of(m)), dim3(kMB), 0, ctx->stream, ctx->mls_xyz.p, m, x2, y2, z2);
+  }
   PCP_HIP_TRY(ctx, hipGetLastError());
+  // 2nd SOR on the MLS output (cloudSmooth.cpp:160-164)
   CloudView cv2;
   if ((rc = view_of(ctx, x2, y2, z2, m, &cv2)) != PCP_OK) return rc;
   if ((rc = sor_run(ctx, cv2, p->sor_mean_k, p->sor_std_mul)) != PCP_OK) return rc;
   int64_t kept = 0;
-  if (p->upsampling == 0) {
+  if (plain) {
     // survivors back in the caller's order (ascending index, as a filter chain on the input cloud leaves them): every
     // surviving row marks its index; the ordered compaction of the marks lists the indices, `where` names their rows
     const size_t sn0 = static_cast<size_t>(cv0.n);
@@ -2138,15 +2175,22 @@ int pcp_cloud_smooth(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_cou
     PCP_HIP_TRY(ctx, ctx->c_where.ensure(sn0 + 4));
     PCP_HIP_TRY(ctx, ctx->s_cell.ensure(sn0 + 4));
     PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->c_mark.p, 0, sn0, ctx->stream));
-    hipLaunchKernelGGL(k_mark_rows, dim3(blocks_of(m)), dim3(kMB), 0, ctx->stream, ctx->m_flag.p, ctx->mls_index.p, m,
-                       ctx->c_mark.p, ctx->c_where.p);
+    hipLaunchKernelGGL(k_mark_rows, dim3(blocks_of(m)), dim3(kMB), 0, ctx->stream, ctx->m_flag.p, row_caller, m, ctx->c_mark.p,
+                       ctx->c_where.p);
     PCP_HIP_TRY(ctx, hipGetLastError());
     if ((rc = compact_flags(ctx, ctx->c_mark.p, cv0.n, ctx->s_cell.p, cv0.n, &kept)) != PCP_OK) return rc;
+    const size_t sk = static_cast<size_t>(kept);
+    PCP_HIP_TRY(ctx, ctx->mls_xyz.ensure(3 * sk + 4));
+    PCP_HIP_TRY(ctx, ctx->mls_normal.ensure(3 * sk + 4));
+    PCP_HIP_TRY(ctx, ctx->mls_curv.ensure(sk + 4));
+    PCP_HIP_TRY(ctx, ctx->mls_alt_index.ensure(std::max(sk + 4, ctx->mls_index.count)));
     if (kept > 0) {
-      hipLaunchKernelGGL(k_lookup_rows, dim3(blocks_of(kept)), dim3(kMB), 0, ctx->stream, ctx->s_cell.p, kept, ctx->c_where.p);
+      hipLaunchKernelGGL(k_final_rows, dim3(blocks_of(kept)), dim3(kMB), 0, ctx->stream, ctx->s_cell.p, kept, ctx->c_where.p,
+                         ctx->mls_index.p, ctx->m_tmp.p, ctx->mls_xyz.p, ctx->mls_normal.p, ctx->mls_curv.p,
+                         ctx->mls_alt_index.p);
       PCP_HIP_TRY(ctx, hipGetLastError());
     }
-    if ((rc = compact_results(ctx, ctx->s_cell.p, m, kept)) != PCP_OK) return rc;
+    std::swap(ctx->mls_index, ctx->mls_alt_index);
   } else {
     // upsampled clouds: voxel order, rows dropped by the 2nd SOR removed
     PCP_HIP_TRY(ctx, ctx->s_cell.ensure(static_cast<size_t>(m) + 4));
@@ -2189,7 +2233,7 @@ int pcp_sor_distances(pcp_context *ctx, int64_t capacity, float *out_distance) {
   if (capacity < ctx->n) return set_error(ctx, PCP_ERR_RANGE, "pcp_sor_distances: capacity %lld < %lld points", (long long)capacity, (long long)ctx->n);
   PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (ctx->n > 0) {
-    PCP_HIP_TRY(ctx, hipMemcpyAsync(out_distance, ctx->m_tmp.p, static_cast<size_t>(ctx->n) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(out_distance, ctx->s_dist.p, static_cast<size_t>(ctx->n) * 4, hipMemcpyDeviceToHost, ctx->stream));
     PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   }
   return PCP_OK;
