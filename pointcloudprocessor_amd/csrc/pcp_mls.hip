@@ -2140,8 +2140,15 @@ int pcp_cloud_smooth(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_cou
   hipLaunchKernelGGL(k_gather_view, dim3(blocks_of(n1)), dim3(kMB), 0, ctx->stream, cv0.x, cv0.y, cv0.z, cv0.remap, c_pos, n1,
                      x1, y1, z1, ctx->c_index.p);  // c_index: the caller's indices of cloud 1
   PCP_HIP_TRY(ctx, hipGetLastError());
-  CloudView cv1;
-  if ((rc = view_of(ctx, x1, y1, z1, n1, &cv1)) != PCP_OK) return rc;
+  // cloud 1 is a subset of the upload: without upsampling the upload's box serves (any enclosing box gives the same grid
+  // searches); the voxel dilation counts its voxels from the cloud's own box (getMinMax3D, mls.hpp [upstream])
+  CloudView cv1 = cv0;
+  cv1.x = x1;
+  cv1.y = y1;
+  cv1.z = z1;
+  cv1.n = n1;
+  cv1.remap = nullptr;
+  if (p->upsampling != 0 && (rc = view_of(ctx, x1, y1, z1, n1, &cv1)) != PCP_OK) return rc;
   // MLS (cloudSmooth.cpp:124-154).  Without upsampling the fitted rows stay where the fit wrote them (7 floats per point
   // of cloud 1): the second filter only needs their positions, and the survivors are picked from there at the end.
   const bool plain = p->upsampling == 0;
