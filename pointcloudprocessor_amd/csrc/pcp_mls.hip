@@ -1413,10 +1413,21 @@ __global__ __launch_bounds__(kMB) void k_sor_stats(const float *__restrict__ dis
   }
 }
 
-__global__ __launch_bounds__(kMB) void k_sor_classify(const float *__restrict__ distances, int64_t n, double threshold,
-                                                      uint8_t *__restrict__ keep) {
+// mean + std_mul * stddev of the distances from their two sums (statistical_outlier_removal.hpp [upstream]), on the device:
+// the host does not have to wait for the sums between the two kernels.  Individually rounded IEEE operations, as the
+// host form compiles.
+__global__ void k_sor_threshold(const double *__restrict__ sums, int64_t n, double std_mul, double *__restrict__ threshold) {
+#pragma clang fp contract(off)
+  const double dn = static_cast<double>(n);
+  const double mean = sums[0] / dn;
+  const double variance = (sums[1] - sums[0] * sums[0] / dn) / (dn - 1.0);
+  *threshold = mean + std_mul * sqrt(variance);
+}
+
+__global__ __launch_bounds__(kMB) void k_sor_classify(const float *__restrict__ distances, int64_t n,
+                                                      const double *__restrict__ threshold, uint8_t *__restrict__ keep) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
-  if (i < n) keep[i] = !(static_cast<double>(distances[i]) > threshold) ? 1 : 0;
+  if (i < n) keep[i] = !(static_cast<double>(distances[i]) > *threshold) ? 1 : 0;
 }
 
 // a cloud on the device the smoothing stages operate on (the uploaded map, or an
@@ -1990,16 +2001,10 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
                        ctx->stream, dist, n, ctx->m_sums.p);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
-  double sums[2] = {0, 0};
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(sums, ctx->m_sums.p, sizeof(sums), hipMemcpyDeviceToHost, ctx->stream));
-  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  const double dn = static_cast<double>(n);
-  const double mean = sums[0] / dn;
-  const double variance = (sums[1] - sums[0] * sums[0] / dn) / (dn - 1.0);
-  const double threshold = mean + std_mul * std::sqrt(variance);
   {
     LaunchTimer t(ctx, PCP_K_SOR);
-    hipLaunchKernelGGL(k_sor_classify, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, dist, n, threshold, ctx->m_flag.p);
+    hipLaunchKernelGGL(k_sor_threshold, dim3(1), dim3(1), 0, ctx->stream, ctx->m_sums.p, n, std_mul, ctx->m_sums.p + 2);
+    hipLaunchKernelGGL(k_sor_classify, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, dist, n, ctx->m_sums.p + 2, ctx->m_flag.p);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   return PCP_OK;
