@@ -166,15 +166,30 @@ __device__ __forceinline__ uint32_t spread10(uint32_t v) {
 // per-workgroup min / max of the coordinates (NaN ignored, as std::min / std::max do on the host)
 __global__ __launch_bounds__(kUpBlock) void k_up_bbox(const float *__restrict__ x, const float *__restrict__ y,
                                                      const float *__restrict__ z, int64_t n,
-                                                     float *__restrict__ partial /* [blocks][6] */) {
+                                                     float *__restrict__ partial /* [blocks][6] */,
+                                                     unsigned long long *__restrict__ nonfinite) {
   __shared__ float sh[6][kUpBlock / 64];
   float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  // the box of the finite coordinates (the projection takes non-finite points as they come; the smoothing stages
+  // refuse a cloud that has any: their count goes to *nonfinite)
+  uint32_t bad = 0;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kUpBlock + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kUpBlock) {
     const float v[3] = {x[i], y[i], z[i]};
+    bool fin = true;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      if (v[a] < lo[a]) lo[a] = v[a];
-      if (v[a] > hi[a]) hi[a] = v[a];
+      const bool f = fabsf(v[a]) <= FLT_MAX;  // false for NaN and +-inf
+      fin = fin && f;
+      if (f && v[a] < lo[a]) lo[a] = v[a];
+      if (f && v[a] > hi[a]) hi[a] = v[a];
+    }
+    bad += fin ? 0u : 1u;
+  }
+  {
+    const unsigned long long any = __ballot(bad != 0);
+    if (any) {  // rare
+      for (int o = 32; o >= 1; o >>= 1) bad += __shfl_xor(bad, o, 64);
+      if ((threadIdx.x & 63) == 0) atomicAdd(nonfinite, static_cast<unsigned long long>(bad));
     }
   }
 #pragma unroll
@@ -381,6 +396,7 @@ static int store_cloud(pcp_context *ctx, const float *x, const float *y, const f
   PCP_HIP_TRY(ctx, ctx->sxyz.ensure(3 * plane + 4));
   PCP_HIP_TRY(ctx, ctx->perm.ensure(sn + 4));
   ctx->n = n;
+  ctx->nonfinite_points = 0;
   ctx->sor_distances_live = false;
   ctx->n_tiles = 0;
   ctx->tile_order_live = false;
@@ -410,10 +426,15 @@ static int store_cloud(pcp_context *ctx, const float *x, const float *y, const f
   const uint32_t bb_blocks = std::min<uint32_t>(up_blocks(n), 1024u);
   DevBuf<float> partial;
   PCP_HIP_TRY(ctx, partial.ensure(static_cast<size_t>(bb_blocks) * 6));
-  hipLaunchKernelGGL(k_up_bbox, dim3(bb_blocks), dim3(kUpBlock), 0, st, dx, dy, dz, n, partial.p);
+  PCP_HIP_TRY(ctx, ctx->s_counter.ensure(4));
+  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->s_counter.p, 0, 8, st));
+  hipLaunchKernelGGL(k_up_bbox, dim3(bb_blocks), dim3(kUpBlock), 0, st, dx, dy, dz, n, partial.p, ctx->s_counter.p);
   std::vector<float> hp(static_cast<size_t>(bb_blocks) * 6);
+  unsigned long long nonfinite = 0;
   PCP_HIP_TRY(ctx, hipMemcpyAsync(hp.data(), partial.p, hp.size() * 4, hipMemcpyDeviceToHost, st));
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(&nonfinite, ctx->s_counter.p, 8, hipMemcpyDeviceToHost, st));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(st));
+  ctx->nonfinite_points = static_cast<int64_t>(nonfinite);
   partial.release();
   raw.release();
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
@@ -424,6 +445,7 @@ static int store_cloud(pcp_context *ctx, const float *x, const float *y, const f
     }
   float sc[3];
   for (int a = 0; a < 3; ++a) {
+    if (mn[a] > mx[a]) mn[a] = mx[a] = 0.0f;  // no finite coordinate at all
     ctx->host_min[a] = mn[a];
     ctx->host_max[a] = mx[a];
     const float ext = mx[a] - mn[a];

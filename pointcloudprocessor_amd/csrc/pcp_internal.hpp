@@ -111,6 +111,7 @@ struct pcp_context {
   // cloud: original order (per-keyframe drop-in calls) and spatially sorted copy
   // (batched run + MLS); perm[j] = original index of sorted point j.
   int64_t n = 0;
+  int64_t nonfinite_points = 0;  // uploaded points with a NaN or infinite coordinate (the smoothing stages refuse them)
   pcp::DevBuf<float> xyz;    // x[n] y[n] z[n]
   pcp::DevBuf<float> sxyz;   // sorted x[n] y[n] z[n]
   pcp::DevBuf<int32_t> perm; // n

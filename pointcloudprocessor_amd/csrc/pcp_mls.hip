@@ -1613,10 +1613,15 @@ static int build_grid(pcp_context *ctx, const CloudView &cv, float cell, float r
   const int64_t n = cv.n;
   GridDesc g{};
   const float *mn = cv.mn, *mx = cv.mx;
-  for (;;) {  // bound the table: grow the cell until it fits 2^27 cells
+  for (int a = 0; a < 3; ++a)
+    if (!(std::fabs(mn[a]) <= FLT_MAX) || !(std::fabs(mx[a]) <= FLT_MAX) || !(cell > 0.0f))
+      return set_error(ctx, PCP_ERR_INVALID, "the smoothing stages need finite coordinates (bounding box %g .. %g on axis %d)",
+                       static_cast<double>(mn[a]), static_cast<double>(mx[a]), a);
+  for (int doubling = 0;; ++doubling) {  // bound the table: grow the cell until it fits 2^27 cells
     const double ex = static_cast<double>(mx[0] - mn[0]) / cell + 1.0, ey = static_cast<double>(mx[1] - mn[1]) / cell + 1.0,
                  ez = static_cast<double>(mx[2] - mn[2]) / cell + 1.0;
     if (ex * ey * ez <= 134217728.0) break;
+    if (doubling > 300) return set_error(ctx, PCP_ERR_INVALID, "no uniform grid fits this cloud's bounding box");
     cell *= 2.0f;
   }
   g.minx = mn[0];
@@ -1794,6 +1799,15 @@ static int voxel_grid_dilation(pcp_context *ctx, const CloudView &cv, const pcp_
   }
   ctx->mls_count = m;
   if (out_count) *out_count = m;
+  return PCP_OK;
+}
+
+// pcl::StatisticalOutlierRemoval / MovingLeastSquares skip non-finite points one by one; this library refuses the cloud
+// (the reference's maps come out of a PCD file of a LiDAR odometry: finite)
+static int require_finite_cloud(pcp_context *ctx, const char *who) {
+  if (ctx->nonfinite_points > 0)
+    return set_error(ctx, PCP_ERR_INVALID, "%s: %lld uploaded points have a NaN or infinite coordinate", who,
+                     (long long)ctx->nonfinite_points);
   return PCP_OK;
 }
 
@@ -2053,6 +2067,7 @@ int pcp_mls_process(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_coun
   int rc = check_mls_params(ctx, p);
   if (rc != PCP_OK) return rc;
   if (!ctx->xyz.p) return set_error(ctx, PCP_ERR_STATE, "pcp_mls_process: no cloud uploaded");
+  if (int rcf = require_finite_cloud(ctx, "pcp_mls_process")) return rcf;
   PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
   return mls_run(ctx, uploaded_view(ctx), p, out_count);
 }
@@ -2063,6 +2078,7 @@ int pcp_mls_process_shard(pcp_context *ctx, const pcp_mls_params *p, int64_t ind
   int rc = check_mls_params(ctx, p);
   if (rc != PCP_OK) return rc;
   if (!ctx->xyz.p) return set_error(ctx, PCP_ERR_STATE, "pcp_mls_process_shard: no cloud uploaded");
+  if (int rcf = require_finite_cloud(ctx, "pcp_mls_process_shard")) return rcf;
   if (p->upsampling != 0)
     return set_error(ctx, PCP_ERR_INVALID, "pcp_mls_process_shard: query sharding supports upsampling NONE only");
   if (index_begin < 0 || index_end > ctx->n || index_begin > index_end)
@@ -2093,6 +2109,7 @@ int pcp_mls_fetch(pcp_context *ctx, int64_t capacity, float *out_xyz, float *out
 int pcp_sor(pcp_context *ctx, int32_t mean_k, double std_mul, uint8_t *out_keep, int64_t *out_kept) {
   if (!ctx) return PCP_ERR_INVALID;
   if (!ctx->xyz.p) return set_error(ctx, PCP_ERR_STATE, "pcp_sor: no cloud uploaded");
+  if (int rcf = require_finite_cloud(ctx, "pcp_sor")) return rcf;
   if (mean_k < 1 || mean_k > 254) return set_error(ctx, PCP_ERR_INVALID, "pcp_sor: mean_k %d out of range (1..254)", mean_k);
   PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int64_t n = ctx->n;
@@ -2121,6 +2138,7 @@ int pcp_cloud_smooth(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_cou
   int rc = check_mls_params(ctx, p);
   if (rc != PCP_OK) return rc;
   if (!ctx->xyz.p) return set_error(ctx, PCP_ERR_STATE, "pcp_cloud_smooth: no cloud uploaded");
+  if (int rcf = require_finite_cloud(ctx, "pcp_cloud_smooth")) return rcf;
   if (p->sor_mean_k < 1 || p->sor_mean_k > 254)
     return set_error(ctx, PCP_ERR_INVALID, "pcp_cloud_smooth: sor_mean_k %d out of range (1..254)", p->sor_mean_k);
   PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -2217,6 +2235,7 @@ int pcp_cloud_smooth(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_cou
 int pcp_close_pairs(pcp_context *ctx, double radius, int64_t *points_with_close_neighbour) {
   if (!ctx || !points_with_close_neighbour) return PCP_ERR_INVALID;
   if (!ctx->xyz.p) return set_error(ctx, PCP_ERR_STATE, "pcp_close_pairs: no cloud uploaded");
+  if (int rcf = require_finite_cloud(ctx, "pcp_close_pairs")) return rcf;
   if (!(radius > 0.0)) return set_error(ctx, PCP_ERR_INVALID, "pcp_close_pairs: radius must be > 0");
   PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
   *points_with_close_neighbour = 0;

@@ -273,7 +273,8 @@ class Processor {
       // the reference credits a sample to EVERY map point within 10 um of it (radiusSearch, :571); the library to the
       // sample's own point.  Say so when the map holds points that close together (duplicates of merged scans).
       int64_t close = 0;
-      gpu->device(0).check(pcp_close_pairs(gpu->device(0).get(), 2.5e-5, &close));
+      if (pcp_close_pairs(gpu->device(0).get(), 2.5e-5, &close) != PCP_OK)  // a map with NaN / infinite points: no grid
+        std::cerr << "Warning: " << pcp_last_error(gpu->device(0).get()) << "; the close-pair check is skipped." << std::endl;
       if (close > 0)
         std::cerr << "Warning: " << close << " map points have another point within 25 um; the reference would let them "
                   << "share colour samples (PointCloudProcessor.cpp:571), this build does not." << std::endl;

@@ -56,6 +56,20 @@ def test_sor_edge_cases(gpu_ctx_factory):
     ctx.upload_cloud(np.float32([0, 1, 2]), np.float32([0, 0, 0]), np.float32([0, 0, 0]))
     with pytest.raises(capi.PcpError):
         ctx.sor(mean_k=0)
+    # a cloud with NaN / infinite coordinates: PCL's filters skip such points one by one, this library refuses the cloud
+    # (and must not spin on an infinite bounding box); the colour path takes the same upload
+    rng = np.random.default_rng(2)
+    pts = rng.uniform(-1, 1, (5000, 3)).astype(np.float32)
+    for bad in (np.nan, np.inf, -np.inf):
+        q = pts.copy()
+        q[17, 1] = bad
+        ctx.upload_cloud(q[:, 0].copy(), q[:, 1].copy(), q[:, 2].copy())
+        for call in (lambda: ctx.sor(), lambda: ctx.mls_process(capi.default_mls_params()),
+                     lambda: ctx.cloud_smooth(capi.default_mls_params()), lambda: ctx.close_pairs(1e-5)):
+            with pytest.raises(capi.PcpError, match="NaN or infinite"):
+                call()
+    ctx.upload_cloud(pts[:, 0].copy(), pts[:, 1].copy(), pts[:, 2].copy())
+    assert ctx.sor()[1] > 0
 
 
 @pytest.mark.parametrize("heap_only", ["0", "1"])
