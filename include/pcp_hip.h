@@ -265,7 +265,10 @@ int pcp_mls_fetch(pcp_context *ctx, int64_t capacity, float *out_xyz, float *out
  * pcp_mls_fetch; out_index refers to the uploaded cloud. */
 int pcp_cloud_smooth(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_count);
 /* pcl::StatisticalOutlierRemoval (k, std_mul) keep mask of the uploaded cloud,
- * cloudSmooth.cpp:109-116,160-164. */
+ * cloudSmooth.cpp:109-116,160-164.
+ * The smoothing entry points (pcp_sor, pcp_mls_process[_shard], pcp_cloud_smooth, pcp_close_pairs) need finite
+ * coordinates: a cloud with NaN or infinite points is refused with PCP_ERR_INVALID (PCL's filters skip such points one
+ * by one; the projection / colour entry points accept them and reject the points, Appendix B6). */
 int pcp_sor(pcp_context *ctx, int32_t mean_k, double std_mul, uint8_t *out_keep, int64_t *out_kept);
 
 /* ---- NID extrinsic refinement (VisualLiDARCalibration::calibrate, PCP/src/calibrate.cpp:42-126) -- */
