@@ -30,6 +30,7 @@
 namespace pcp {
 
 constexpr int kMB = 256;
+constexpr double kMaxGridCells = 536870912.0;  // 2^29
 
 struct GridDesc {
   float minx, miny, minz, inv_cell;
@@ -1617,10 +1618,13 @@ static int build_grid(pcp_context *ctx, const CloudView &cv, float cell, float r
     if (!(std::fabs(mn[a]) <= FLT_MAX) || !(std::fabs(mx[a]) <= FLT_MAX) || !(cell > 0.0f))
       return set_error(ctx, PCP_ERR_INVALID, "the smoothing stages need finite coordinates (bounding box %g .. %g on axis %d)",
                        static_cast<double>(mn[a]), static_cast<double>(mx[a]), a);
-  for (int doubling = 0;; ++doubling) {  // bound the table: grow the cell until it fits 2^27 cells
+  // The table of cell starts is dense: kMaxGridCells entries (2 GiB of the 288 GB; the bound keeps a cell id in int32).
+  // A box that needs more cells at the wanted edge gets a coarser grid: the searches stay exact, every doubling of the
+  // edge multiplies the candidates per query by up to 8 (maps beyond ~25 m at r = 0.03, or a far stray point).
+  for (int doubling = 0;; ++doubling) {  // bound the table: grow the cell until it fits
     const double ex = static_cast<double>(mx[0] - mn[0]) / cell + 1.0, ey = static_cast<double>(mx[1] - mn[1]) / cell + 1.0,
                  ez = static_cast<double>(mx[2] - mn[2]) / cell + 1.0;
-    if (ex * ey * ez <= 134217728.0) break;
+    if (ex * ey * ez <= kMaxGridCells) break;
     if (doubling > 300) return set_error(ctx, PCP_ERR_INVALID, "no uniform grid fits this cloud's bounding box");
     cell *= 2.0f;
   }
