@@ -1384,9 +1384,11 @@ __global__ __launch_bounds__(kSelWave) void k_sor_wave(const float *__restrict__
   }
 }
 
-// sum and sum of squares (fp32 squares, as the reference) of the distances, fp64 accumulation
+// sum and sum of squares (fp32 squares, as the reference) of the distances, fp64 accumulation: one pair of partial sums
+// per workgroup, added up in a fixed order by k_sor_threshold (no atomics: the threshold is the same on every run)
+constexpr int kStatsBlocks = 1024;
 __global__ __launch_bounds__(kMB) void k_sor_stats(const float *__restrict__ distances, int64_t n,
-                                                   double *__restrict__ sums /* [2] */) {
+                                                   double *__restrict__ partial /* [kStatsBlocks][2] */) {
   __shared__ double sh[2][kMB / 64];
   double s = 0.0, q = 0.0;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kMB) {
@@ -1409,20 +1411,32 @@ __global__ __launch_bounds__(kMB) void k_sor_stats(const float *__restrict__ dis
       ts += sh[0][k];
       tq += sh[1][k];
     }
-    atomicAdd(sums, ts);
-    atomicAdd(sums + 1, tq);
+    partial[2 * blockIdx.x] = ts;
+    partial[2 * blockIdx.x + 1] = tq;
   }
 }
 
-// mean + std_mul * stddev of the distances from their two sums (statistical_outlier_removal.hpp [upstream]), on the device:
+// mean + std_mul * stddev of the distances from the workgroups' partial sums (statistical_outlier_removal.hpp [upstream]), on the device:
 // the host does not have to wait for the sums between the two kernels.  Individually rounded IEEE operations, as the
 // host form compiles.
-__global__ void k_sor_threshold(const double *__restrict__ sums, int64_t n, double std_mul, double *__restrict__ threshold) {
+__global__ __launch_bounds__(64) void k_sor_threshold(const double *__restrict__ partial, int blocks, int64_t n, double std_mul,
+                                                      double *__restrict__ threshold) {
 #pragma clang fp contract(off)
-  const double dn = static_cast<double>(n);
-  const double mean = sums[0] / dn;
-  const double variance = (sums[1] - sums[0] * sums[0] / dn) / (dn - 1.0);
-  *threshold = mean + std_mul * sqrt(variance);
+  double s = 0.0, q = 0.0;
+  for (int b = threadIdx.x; b < blocks; b += 64) {
+    s += partial[2 * b];
+    q += partial[2 * b + 1];
+  }
+  for (int o = 32; o >= 1; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    q += __shfl_xor(q, o, 64);
+  }
+  if (threadIdx.x == 0) {
+    const double dn = static_cast<double>(n);
+    const double mean = s / dn;
+    const double variance = (q - s * s / dn) / (dn - 1.0);
+    *threshold = mean + std_mul * sqrt(variance);
+  }
 }
 
 __global__ __launch_bounds__(kMB) void k_sor_classify(const float *__restrict__ distances, int64_t n,
@@ -1968,8 +1982,7 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
   }
   PCP_HIP_TRY(ctx, ctx->s_dist.ensure(sn + 8));
   PCP_HIP_TRY(ctx, ctx->m_flag.ensure(sn + 16));
-  PCP_HIP_TRY(ctx, ctx->m_sums.ensure(4));
-  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->m_sums.p, 0, 2 * sizeof(double), ctx->stream));
+  PCP_HIP_TRY(ctx, ctx->m_sums.ensure(4 + 2 * kStatsBlocks));
   float *dist = ctx->s_dist.p;
   const size_t heap_lds = static_cast<size_t>(mean_k + 1) * kSorBlock * sizeof(float);
   const char *heap_only = std::getenv("PCP_SOR_HEAP_ONLY");
@@ -2015,14 +2028,11 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
   }
   {
     LaunchTimer t(ctx, PCP_K_SOR);
-    hipLaunchKernelGGL(k_sor_stats, dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(n, kMB), 1024))), dim3(kMB), 0,
-                       ctx->stream, dist, n, ctx->m_sums.p);
-    PCP_HIP_TRY(ctx, hipGetLastError());
-  }
-  {
-    LaunchTimer t(ctx, PCP_K_SOR);
-    hipLaunchKernelGGL(k_sor_threshold, dim3(1), dim3(1), 0, ctx->stream, ctx->m_sums.p, n, std_mul, ctx->m_sums.p + 2);
-    hipLaunchKernelGGL(k_sor_classify, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, dist, n, ctx->m_sums.p + 2, ctx->m_flag.p);
+    const int blocks = static_cast<int>(std::min<int64_t>(div_up(n, kMB), kStatsBlocks));
+    double *partial = ctx->m_sums.p + 4, *threshold = ctx->m_sums.p;
+    hipLaunchKernelGGL(k_sor_stats, dim3(static_cast<uint32_t>(blocks)), dim3(kMB), 0, ctx->stream, dist, n, partial);
+    hipLaunchKernelGGL(k_sor_threshold, dim3(1), dim3(64), 0, ctx->stream, partial, blocks, n, std_mul, threshold);
+    hipLaunchKernelGGL(k_sor_classify, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, dist, n, threshold, ctx->m_flag.p);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   return PCP_OK;
