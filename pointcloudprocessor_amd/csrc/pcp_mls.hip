@@ -1575,19 +1575,6 @@ __global__ __launch_bounds__(kMB) void k_final_rows(const int32_t *__restrict__ 
   index[t] = i;
 }
 
-// out[k] = in[index[k]] for three SoA planes
-__global__ __launch_bounds__(kMB) void k_gather_xyz(const float *__restrict__ x, const float *__restrict__ y,
-                                                    const float *__restrict__ z, const int32_t *__restrict__ index,
-                                                    int64_t m, float *__restrict__ ox, float *__restrict__ oy,
-                                                    float *__restrict__ oz) {
-  const int64_t k = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
-  if (k >= m) return;
-  const int32_t i = index[k];
-  ox[k] = x[i];
-  oy[k] = y[i];
-  oz[k] = z[i];
-}
-
 // AoS xyz[3m] -> SoA planes
 __global__ __launch_bounds__(kMB) void k_deinterleave(const float *__restrict__ xyz, int64_t m, float *__restrict__ ox,
                                                       float *__restrict__ oy, float *__restrict__ oz) {
