@@ -623,6 +623,8 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->g_cell.release();
   ctx->g_rank.release();
   ctx->g_start.release();
+  ctx->g_occ.release();
+  ctx->g_occ_rank.release();
   ctx->g_order.release();
   ctx->g_xyz.release();
   ctx->m_tmp.release();

@@ -188,6 +188,8 @@ struct pcp_context {
   // MLS: uniform grid (cell id / in-cell rank per point, cell starts, cell-sorted
   // order + coordinates), per-input-point results, compacted outputs
   pcp::DevBuf<int32_t> g_cell, g_rank, g_start, g_order;
+  pcp::DevBuf<unsigned long long> g_occ;  // sparse grids: one bit per cell
+  pcp::DevBuf<int32_t> g_occ_rank;        // ... and the set bits before each 64-bit word
   pcp::DevBuf<float> g_xyz;      // cell-sorted x[n] y[n] z[n]
   pcp::DevBuf<float> m_tmp;      // 7 floats per input point (xyz, normal, curvature), input order
   pcp::DevBuf<float> s_dist;     // StatisticalOutlierRemoval: mean kNN distance per point

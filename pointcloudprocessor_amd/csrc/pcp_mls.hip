@@ -30,13 +30,34 @@
 namespace pcp {
 
 constexpr int kMB = 256;
-constexpr double kMaxGridCells = 536870912.0;  // 2^29
+constexpr double kMaxGridCells = 536870912.0;      // 2^29: dense table of cell starts
+constexpr double kMaxSparseCells = 34359738368.0;  // 2^35: bitmap (4 GiB) + running popcounts (2 GiB)
 
 struct GridDesc {
   float minx, miny, minz, inv_cell;
   int32_t nx, ny, nz;
   int32_t reach;  // cells to visit on each side: ceil(r / cell)
+  // Sparse form (nullptr: dense form, the table of cell starts has one entry per cell).  Grids of more than 2^29 cells keep
+  // table entries for the OCCUPIED cells only; a bitmap with one bit per cell and the running popcount per 64-bit word
+  // give the number of occupied cells before a cell -- its place in the table (1.5 bits per cell instead of 32).
+  const unsigned long long *occ;
+  const int32_t *occ_rank;
 };
+
+// number of occupied cells before cell c (sparse form)
+__device__ __forceinline__ int32_t cell_rank(const GridDesc &g, int64_t c) {
+  const unsigned long long bits = g.occ[c >> 6];
+  return g.occ_rank[c >> 6] + static_cast<int32_t>(__popcll(bits & ((1ull << (c & 63)) - 1ull)));
+}
+
+// Entry (zz, yy, xx) of the table of cell starts = number of points in the cells before that cell (xx may be nx: the
+// first cell of the next row).  The cells of a row are consecutive in either form, so start(x0) .. start(x1 + 1) is the
+// run of candidates of the cells x0 .. x1 of a row.
+__device__ __forceinline__ int32_t cell_start(const GridDesc &g, const int32_t *__restrict__ start, int32_t zz, int32_t yy,
+                                              int32_t xx) {
+  if (!g.occ) return start[(zz * g.ny + yy) * g.nx + xx];
+  return start[cell_rank(g, (static_cast<int64_t>(zz) * g.ny + yy) * g.nx + xx)];
+}
 
 __device__ __forceinline__ void grid_coords(const GridDesc &g, float x, float y, float z, int32_t &ix, int32_t &iy,
                                             int32_t &iz) {
@@ -75,6 +96,59 @@ __global__ __launch_bounds__(kMB) void k_grid_count(const float *__restrict__ x,
     if (mine) {
       int32_t base = 0;
       if ((same & below) == 0) base = atomicAdd(count + c0, static_cast<int32_t>(__popcll(same)));  // lowest lane of the cell
+      base = __builtin_amdgcn_readfirstlane(base);
+      r = base + static_cast<int32_t>(__popcll(same & below));
+      todo = false;
+    }
+  }
+  if (todo) r = atomicAdd(count + c, 1);
+  if (i < n) rank[i] = r;
+}
+
+// Sparse form, step 1: one bit per occupied cell
+__global__ __launch_bounds__(kMB) void k_grid_mark(const float *__restrict__ x, const float *__restrict__ y,
+                                                   const float *__restrict__ z, int64_t n, GridDesc g,
+                                                   unsigned long long *__restrict__ occ) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  if (i >= n) return;
+  int32_t ix, iy, iz;
+  grid_coords(g, x[i], y[i], z[i], ix, iy, iz);
+  const int64_t c = (static_cast<int64_t>(iz) * g.ny + iy) * g.nx + ix;
+  const unsigned long long bit = 1ull << (c & 63);
+  if (!(occ[c >> 6] & bit)) atomicOr(occ + (c >> 6), bit);  // spatially ordered views: most bits are set already
+}
+// step 2: set bits per word (scanned in place into the running popcount)
+__global__ __launch_bounds__(kMB) void k_grid_popc(const unsigned long long *__restrict__ occ, int64_t words,
+                                                   int32_t *__restrict__ count) {
+  const int64_t w = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  if (w < words) count[w] = static_cast<int32_t>(__popcll(occ[w]));
+}
+// step 3: as k_grid_count, with the cell's place among the occupied cells as its id
+__global__ __launch_bounds__(kMB) void k_grid_count_sparse(const float *__restrict__ x, const float *__restrict__ y,
+                                                           const float *__restrict__ z, int64_t n, GridDesc g,
+                                                           int32_t *__restrict__ cell, int32_t *__restrict__ rank,
+                                                           int32_t *__restrict__ count) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  int32_t c = -1;
+  if (i < n) {
+    int32_t ix, iy, iz;
+    grid_coords(g, x[i], y[i], z[i], ix, iy, iz);
+    c = cell_rank(g, (static_cast<int64_t>(iz) * g.ny + iy) * g.nx + ix);
+    cell[i] = c;
+  }
+  const int lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  bool todo = c >= 0;
+  int32_t r = 0;
+  for (int round = 0; round < kAggRounds; ++round) {
+    const unsigned long long open = __ballot(todo);
+    if (!open) break;
+    const int32_t c0 = __shfl(c, __ffsll(open) - 1, 64);
+    const bool mine = todo && c == c0;
+    const unsigned long long same = __ballot(mine);
+    if (mine) {
+      int32_t base = 0;
+      if ((same & below) == 0) base = atomicAdd(count + c0, static_cast<int32_t>(__popcll(same)));
       base = __builtin_amdgcn_readfirstlane(base);
       r = base + static_cast<int32_t>(__popcll(same & below));
       todo = false;
@@ -295,9 +369,8 @@ __global__ __launch_bounds__(kFitBlock) void k_mls_fit(MlsArgs a) {
     for (int32_t r = 0; r < kMaxRun; ++r) {
       const int32_t zz = z0 + r / 3, yy = y0 + r % 3;
       const bool in = zz <= z1 && yy <= y1;  // fewer rows at the grid border: empty runs keep the (z, y) order
-      const int32_t row = (min(zz, z1) * a.g.ny + min(yy, y1)) * a.g.nx;
-      rb[r] = in ? a.start[row + x0] : 0;
-      re[r] = in ? a.start[row + x1 + 1] : 0;
+      rb[r] = in ? cell_start(a.g, a.start, min(zz, z1), min(yy, y1), x0) : 0;
+      re[r] = in ? cell_start(a.g, a.start, min(zz, z1), min(yy, y1), x1 + 1) : 0;
     }
 #pragma unroll
     for (int32_t r = 0; r < kMaxRun; ++r) {
@@ -370,8 +443,7 @@ __global__ __launch_bounds__(kFitBlock) void k_mls_fit(MlsArgs a) {
   } else {
     for (int32_t zz = z0; zz <= z1; ++zz)
       for (int32_t yy = y0; yy <= y1; ++yy) {
-        const int32_t row = (zz * a.g.ny + yy) * a.g.nx;
-        const int32_t b = a.start[row + x0], e = a.start[row + x1 + 1];
+        const int32_t b = cell_start(a.g, a.start, zz, yy, x0), e = cell_start(a.g, a.start, zz, yy, x1 + 1);
         for (int32_t k = b; k < e; ++k)
           if (sqdist_f32(a.sx[k], a.sy[k], a.sz[k], qx, qy, qz) < a.sq_radius) ++K;
       }
@@ -397,8 +469,7 @@ __global__ __launch_bounds__(kFitBlock) void k_mls_fit(MlsArgs a) {
     } else {
       for (int32_t zz = z0; zz <= z1; ++zz)
         for (int32_t yy = y0; yy <= y1; ++yy) {
-          const int32_t row = (zz * a.g.ny + yy) * a.g.nx;
-          const int32_t b = a.start[row + x0], e = a.start[row + x1 + 1];
+          const int32_t b = cell_start(a.g, a.start, zz, yy, x0), e = cell_start(a.g, a.start, zz, yy, x1 + 1);
           for (int32_t k = b; k < e; ++k) {
             const float px = a.sx[k], py = a.sy[k], pz = a.sz[k];
             if (sqdist_f32(px, py, pz, qx, qy, qz) < a.sq_radius) body(px, py, pz);
@@ -579,8 +650,7 @@ __global__ __launch_bounds__(kMB) void k_close_pairs(const float *__restrict__ s
     grid_coords(g, qx, qy, qz, cx, cy, cz);
     for (int32_t zz = max(cz - g.reach, 0); zz <= min(cz + g.reach, g.nz - 1) && !close; ++zz)
       for (int32_t yy = max(cy - g.reach, 0); yy <= min(cy + g.reach, g.ny - 1) && !close; ++yy) {
-        const int32_t row = (zz * g.ny + yy) * g.nx;
-        const int32_t b = start[row + max(cx - g.reach, 0)], e = start[row + min(cx + g.reach, g.nx - 1) + 1];
+        const int32_t b = cell_start(g, start, zz, yy, max(cx - g.reach, 0)), e = cell_start(g, start, zz, yy, min(cx + g.reach, g.nx - 1) + 1);
         for (int32_t k = b; k < e; ++k)
           if (k != j && sqdist_f32(sx[k], sy[k], sz[k], qx, qy, qz) < sq_radius) close = true;
       }
@@ -712,8 +782,7 @@ __global__ __launch_bounds__(kMB) void k_voxel_emit(VoxelEmitArgs a) {
   float bestd = FLT_MAX;
   for (int32_t zz = z0; zz <= z1; ++zz)
     for (int32_t yy = y0; yy <= y1; ++yy) {
-      const int32_t row = (zz * a.g.ny + yy) * a.g.nx;
-      const int32_t s0 = a.start[row + x0], s1 = a.start[row + x1 + 1];
+      const int32_t s0 = cell_start(a.g, a.start, zz, yy, x0), s1 = cell_start(a.g, a.start, zz, yy, x1 + 1);
       for (int32_t k = s0; k < s1; ++k) {
         const float d = sqdist_f32(a.sx[k], a.sy[k], a.sz[k], px, py, pz);
         if (d <= bestd) {  // the index is only needed for the rare candidates that can win
@@ -877,12 +946,11 @@ __global__ __launch_bounds__(kSorBlock) void k_sor_mean_distance(const float *__
     for (int32_t zz = max(cz - ring, 0); zz <= min(cz + ring, g.nz - 1); ++zz)
       for (int32_t yy = max(cy - ring, 0); yy <= min(cy + ring, g.ny - 1); ++yy) {
         const bool shell_yz = zz == cz - ring || zz == cz + ring || yy == cy - ring || yy == cy + ring;
-        const int32_t row = (zz * g.ny + yy) * g.nx;
         if (shell_yz) {
-          scan(start[row + max(cx - ring, 0)], start[row + min(cx + ring, g.nx - 1) + 1]);
+          scan(cell_start(g, start, zz, yy, max(cx - ring, 0)), cell_start(g, start, zz, yy, min(cx + ring, g.nx - 1) + 1));
         } else {
-          if (cx - ring >= 0) scan(start[row + cx - ring], start[row + cx - ring + 1]);
-          if (cx + ring < g.nx && ring > 0) scan(start[row + cx + ring], start[row + cx + ring + 1]);
+          if (cx - ring >= 0) scan(cell_start(g, start, zz, yy, cx - ring), cell_start(g, start, zz, yy, cx - ring + 1));
+          if (cx + ring < g.nx && ring > 0) scan(cell_start(g, start, zz, yy, cx + ring), cell_start(g, start, zz, yy, cx + ring + 1));
         }
       }
   }
@@ -997,9 +1065,8 @@ __global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(6, 8))
     if (!active) return;
     for (int32_t zz = z0; zz <= z1; ++zz)
       for (int32_t yy = y0; yy <= y1; ++yy) {
-        const int32_t row = (zz * g.ny + yy) * g.nx;
-        uint32_t q = static_cast<uint32_t>(start[row + x0]);
-        const uint32_t e = static_cast<uint32_t>(start[row + x1 + 1]);
+        uint32_t q = static_cast<uint32_t>(cell_start(g, start, zz, yy, x0));
+        const uint32_t e = static_cast<uint32_t>(cell_start(g, start, zz, yy, x1 + 1));
         if (q + 4 <= e) {
           // the next four candidates are on their way while these four are tested
           sel_v4f X = load4(rx, q), Y = load4(ry, q), Z = load4(rz, q);
@@ -1047,8 +1114,7 @@ __global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(6, 8))
     uint32_t total = 0;
     for (int32_t zz = z0; zz <= z1; ++zz)
       for (int32_t yy = y0; yy <= y1; ++yy) {
-        const int32_t row = (zz * g.ny + yy) * g.nx;
-        total += static_cast<uint32_t>(start[row + x1 + 1] - start[row + x0]);
+        total += static_cast<uint32_t>(cell_start(g, start, zz, yy, x1 + 1) - cell_start(g, start, zz, yy, x0));
       }
     bad = total > 60000u;
   }
@@ -1234,7 +1300,8 @@ __global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(6, 8))
 //      play are exactly the ones missing.
 //   3. sqrt of the entries below the prefix (+ the ones in play, or the missing multiple of the one remaining value),
 //      exact fp64 wave sum, minus the nearest (the point itself).
-// A point whose block holds more values than the cache stays flagged (2) for the heap kernel.
+// A point whose block holds more values than the cache stays flagged (2) for the heap kernel.  A stray point -- its block
+// grows until walking the rows costs more than reading the whole cloud -- takes every point as a candidate instead.
 constexpr int kWsCap = 1024;
 constexpr int kWsRows = 8;
 __global__ __launch_bounds__(kSelWave) void k_sor_wave(const float *__restrict__ sx, const float *__restrict__ sy,
@@ -1257,31 +1324,36 @@ __global__ __launch_bounds__(kSelWave) void k_sor_wave(const float *__restrict__
   const int32_t maxr = max(g.nx, max(g.ny, g.nz));
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
   int32_t M = 0;
+  float T0 = 0.0f;   // squared distance below which the current pass caches a candidate
+  bool far = false;  // the block of cells has grown past the point where walking its rows beats reading every point
+  auto take = [&](float d) {  // d = +inf for lanes without a candidate
+    const bool in = d < T0;
+    const unsigned long long m = __ballot(in);
+    const int32_t at = M + static_cast<int32_t>(__popcll(m & lanes_below));
+    if (in && at < kWsCap) cache[at] = d;
+    M += static_cast<int32_t>(__popcll(m));
+  };
   // (a point k_sor_select found too few neighbours for within one cell starts with two)
   for (int32_t R = redo[j] == 1 ? 2 : 1;; R = R < 4 ? R + 1 : R + R / 2) {
     const bool whole = R >= maxr;  // the block is the grid: every point is a candidate
     const float lim = static_cast<float>(R) * cell * 0.999f;  // 0.999: fp32 slop of the cell assignment
-    const float T0 = whole ? INFINITY : lim * lim;
+    T0 = whole ? INFINITY : lim * lim;
+    if (!whole && static_cast<int64_t>(2 * R + 1) * (2 * R + 1) > n / 32) {  // a stray point far from the rest of the cloud
+      far = true;
+      break;
+    }
     const int32_t x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
     const int32_t y0 = max(cy - R, 0), y1 = min(cy + R, g.ny - 1);
     const int32_t z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
     const int32_t wy = y1 - y0 + 1, nrows = wy * (z1 - z0 + 1);
     M = 0;
-    auto take = [&](float d) {  // d = +inf for lanes without a candidate
-      const bool in = d < T0;
-      const unsigned long long m = __ballot(in);
-      const int32_t at = M + static_cast<int32_t>(__popcll(m & lanes_below));
-      if (in && at < kWsCap) cache[at] = d;
-      M += static_cast<int32_t>(__popcll(m));
-    };
     for (int32_t r0 = 0; r0 < nrows; r0 += kSelWave) {
       const int32_t r = r0 + lane;
       int32_t b = 0, len = 0;
       if (r < nrows) {
         const int32_t zz = z0 + r / wy, yy = y0 + r % wy;
-        const int32_t row = (zz * g.ny + yy) * g.nx;
-        b = start[row + x0];
-        len = start[row + x1 + 1] - b;
+        b = cell_start(g, start, zz, yy, x0);
+        len = cell_start(g, start, zz, yy, x1 + 1) - b;
       }
       unsigned long long todo = __ballot(len > 0);
       while (todo) {
@@ -1315,6 +1387,49 @@ __global__ __launch_bounds__(kSelWave) void k_sor_wave(const float *__restrict__
       }
     }
     if (M >= k || whole) break;
+  }
+  if (far) {
+    // Every point is a candidate (a linear, coalesced sweep of the cell-sorted planes: cheaper than visiting millions of
+    // empty rows one pair of table entries at a time).  The radius of the last block is doubled until at least k points lie
+    // within it; should that hold more values than the cache, the radius is bisected down.
+    auto count_within = [&](float t) {
+      int32_t c = 0;
+      for (int64_t i0 = 0; i0 < n; i0 += 4 * kSelWave) {
+        float d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t i = i0 + u * kSelWave + lane;
+          d[u] = i < n ? sqdist_f32(sx[i], sy[i], sz[i], qx, qy, qz) : INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c += d[u] < t ? 1 : 0;
+      }
+      for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+      return c;
+    };
+    float lo = 0.0f;  // fewer than k points within lo
+    int32_t c = count_within(T0);
+    while (c < k && T0 < INFINITY) {
+      lo = T0;
+      T0 = T0 * 4.0f;  // overflows to +inf: every point
+      c = count_within(T0);
+    }
+    for (int it = 0; it < 40 && c > kWsCap; ++it) {
+      const float mid = T0 < INFINITY ? lo + (T0 - lo) * 0.5f : fmaxf(lo * 4.0f, 1.0f);
+      if (!(mid > lo && mid < T0)) break;  // no float in between: many equal distances (the heap kernel's case)
+      const int32_t cm = count_within(mid);
+      if (cm < k) {
+        lo = mid;
+      } else {
+        T0 = mid;
+        c = cm;
+      }
+    }
+    M = 0;
+    for (int64_t i0 = 0; i0 < n; i0 += kSelWave) {
+      const int64_t i = i0 + lane;
+      take(i < n ? sqdist_f32(sx[i], sy[i], sz[i], qx, qy, qz) : INFINITY);
+    }
   }
   if (M > kWsCap) {  // uniform
     if (lane == 0) redo[j] = 2;
@@ -1619,16 +1734,24 @@ static int build_grid(pcp_context *ctx, const CloudView &cv, float cell, float r
     if (!(std::fabs(mn[a]) <= FLT_MAX) || !(std::fabs(mx[a]) <= FLT_MAX) || !(cell > 0.0f))
       return set_error(ctx, PCP_ERR_INVALID, "the smoothing stages need finite coordinates (bounding box %g .. %g on axis %d)",
                        static_cast<double>(mn[a]), static_cast<double>(mx[a]), a);
-  // The table of cell starts is dense: kMaxGridCells entries (2 GiB of the 288 GB; the bound keeps a cell id in int32).
-  // A box that needs more cells at the wanted edge gets a coarser grid: the searches stay exact, every doubling of the
-  // edge multiplies the candidates per query by up to 8 (maps beyond ~25 m at r = 0.03, or a far stray point).
+  // Up to kMaxGridCells cells the table of cell starts is dense (one int32 per cell, 2 GiB at most); up to
+  // kMaxSparseCells it holds the occupied cells only, found through a bitmap with running popcounts (GridDesc; 6 GiB at
+  // most).  A box that needs more cells than that at the wanted edge gets a coarser grid: the searches stay exact, every
+  // doubling of the edge multiplies the candidates per query by up to 8 (a map with a stray point kilometres away).
+  // PCP_GRID_SPARSE=1 / 0 forces the sparse / dense form (tests).
+  const char *form_env = std::getenv("PCP_GRID_SPARSE");  // read per call: the tests flip it inside one process
+  const int force_form = form_env ? (form_env[0] == '1' ? 1 : 0) : -1;
+  const double cap = (force_form == 0 || geometry_only) ? kMaxGridCells : kMaxSparseCells;
+  double cells = 0.0;
   for (int doubling = 0;; ++doubling) {  // bound the table: grow the cell until it fits
     const double ex = static_cast<double>(mx[0] - mn[0]) / cell + 1.0, ey = static_cast<double>(mx[1] - mn[1]) / cell + 1.0,
                  ez = static_cast<double>(mx[2] - mn[2]) / cell + 1.0;
-    if (ex * ey * ez <= kMaxGridCells) break;
+    cells = ex * ey * ez;
+    if (cells <= cap) break;
     if (doubling > 300) return set_error(ctx, PCP_ERR_INVALID, "no uniform grid fits this cloud's bounding box");
     cell *= 2.0f;
   }
+  const bool sparse = !geometry_only && (force_form == 1 || cells > kMaxGridCells);
   g.minx = mn[0];
   g.miny = mn[1];
   g.minz = mn[2];
@@ -1643,19 +1766,45 @@ static int build_grid(pcp_context *ctx, const CloudView &cv, float cell, float r
   PCP_HIP_TRY(ctx, ctx->g_cell.ensure(sn + 4));
   PCP_HIP_TRY(ctx, ctx->g_rank.ensure(sn + 4));
   PCP_HIP_TRY(ctx, ctx->g_order.ensure(2 * sn + 8));
-  PCP_HIP_TRY(ctx, ctx->g_start.ensure(static_cast<size_t>(ncell) + 8));
   PCP_HIP_TRY(ctx, ctx->g_xyz.ensure(3 * plane + 4));
   if (geometry_only) {
+    PCP_HIP_TRY(ctx, ctx->g_start.ensure(static_cast<size_t>(ncell) + 8));
     *out = g;
     return PCP_OK;
   }
-  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->g_start.p, 0, (static_cast<size_t>(ncell) + 8) * 4, ctx->stream));
   const float *x = cv.x, *y = cv.y, *z = cv.z;
+  int64_t entries = ncell;  // entries of the table of cell starts (+ 1 for the total)
+  if (sparse) {
+    // occupied cells: one bit each; running popcount per word; the table gets one entry per set bit
+    const int64_t words = ncell / 64 + 2;  // the lookups reach cell id ncell (one past the last)
+    PCP_HIP_TRY(ctx, ctx->g_occ.ensure(static_cast<size_t>(words) + 2));
+    PCP_HIP_TRY(ctx, ctx->g_occ_rank.ensure(static_cast<size_t>(words) + 8));
+    PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->g_occ.p, 0, (static_cast<size_t>(words) + 2) * 8, ctx->stream));
+    g.occ = ctx->g_occ.p;
+    g.occ_rank = ctx->g_occ_rank.p;
+    {
+      LaunchTimer t(ctx, PCP_K_MLS_GRID);
+      hipLaunchKernelGGL(k_grid_mark, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, x, y, z, n, g, ctx->g_occ.p);
+      hipLaunchKernelGGL(k_grid_popc, dim3(blocks_of(words)), dim3(kMB), 0, ctx->stream, ctx->g_occ.p, words, ctx->g_occ_rank.p);
+      int rc = exclusive_scan(ctx, ctx->g_occ_rank.p, words);
+      if (rc != PCP_OK) return rc;
+    }
+    int32_t occupied = 0;
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(&occupied, ctx->g_occ_rank.p + words, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    entries = occupied;
+  }
+  PCP_HIP_TRY(ctx, ctx->g_start.ensure(static_cast<size_t>(entries) + 8));
+  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->g_start.p, 0, (static_cast<size_t>(entries) + 8) * 4, ctx->stream));
   {
     LaunchTimer t(ctx, PCP_K_MLS_GRID);
-    hipLaunchKernelGGL(k_grid_count, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, x, y, z, n, g, ctx->g_cell.p,
-                       ctx->g_rank.p, ctx->g_start.p);
-    int rc = exclusive_scan(ctx, ctx->g_start.p, ncell);
+    if (sparse)
+      hipLaunchKernelGGL(k_grid_count_sparse, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, x, y, z, n, g, ctx->g_cell.p,
+                         ctx->g_rank.p, ctx->g_start.p);
+    else
+      hipLaunchKernelGGL(k_grid_count, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, x, y, z, n, g, ctx->g_cell.p,
+                         ctx->g_rank.p, ctx->g_start.p);
+    int rc = exclusive_scan(ctx, ctx->g_start.p, entries);
     if (rc != PCP_OK) return rc;
     hipLaunchKernelGGL(k_grid_scatter, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, n, ctx->g_cell.p, ctx->g_rank.p,
                        ctx->g_start.p, ctx->g_order.p + sn + 4);

@@ -192,11 +192,15 @@ def test_mls_voxel_grid_dilation_refuses_oversized_grids(gpu_ctx_factory):
     assert e.value.code == capi.PCP_ERR_NOMEM
 
 
+@pytest.mark.parametrize("grid_form", ["dense", "sparse"])
 @pytest.mark.parametrize("upsampling", [0, 3])
-def test_cloud_smooth_chain_matches_oracle(gpu_ctx_factory, oracle, upsampling):
+def test_cloud_smooth_chain_matches_oracle(gpu_ctx_factory, oracle, upsampling, grid_form, monkeypatch):
     """CloudSmooth::process end to end: SOR -> MLS (+VGD) -> SOR on the device vs the
-    same chain composed from the oracle's stages."""
+    same chain composed from the oracle's stages; with the grids' table of cell starts in its dense form and in the
+    sparse one (occupied cells only, PCP_GRID_SPARSE=1: what boxes of more than 2^29 cells get)."""
     from pointcloudprocessor_amd import capi
+
+    monkeypatch.setenv("PCP_GRID_SPARSE", "1" if grid_form == "sparse" else "0")
 
     rng = np.random.default_rng(33)
     n = 9000

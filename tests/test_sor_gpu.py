@@ -149,3 +149,32 @@ def test_sor_large_neighbour_counts(gpu_ctx_factory, oracle, mean_k):
     ctx = gpu_ctx_factory()
     _check(ctx, oracle, pts[:, 0].copy(), pts[:, 1].copy(), pts[:, 2].copy(), mean_k, 1.0)
     assert (ctx.sor_redo_fraction() == 0.0) == (mean_k + 1 > 250)
+
+
+@pytest.mark.parametrize("form", ["0", "1"])
+def test_sor_dense_and_sparse_grid_forms(gpu_ctx_factory, oracle, monkeypatch, form):
+    """The table of cell starts as one entry per cell (dense) and as entries of the occupied cells found through a bitmap
+    with running popcounts (sparse, what a grid of more than 2^29 cells gets): same distances, bit for bit."""
+    monkeypatch.setenv("PCP_GRID_SPARSE", form)
+    rng = np.random.default_rng(12)
+    n = 50000
+    a = rng.uniform(-0.5, 0.5, (n, 2))
+    pts = np.stack([a[:, 0], a[:, 1], 0.05 * np.cos(5 * a[:, 1]) + rng.normal(0, 1e-3, n)], 1)
+    pts = np.concatenate([pts, rng.uniform(-1, 1, (200, 3))]).astype(np.float32)
+    ctx = gpu_ctx_factory()
+    _check(ctx, oracle, pts[:, 0].copy(), pts[:, 1].copy(), pts[:, 2].copy(), 60, 0.7)
+
+
+def test_sor_stray_points_far_from_the_cloud(gpu_ctx_factory, oracle):
+    """Points hundreds of metres from a 1 m sheet: the bounding box needs 10^12 cells at the wanted edge (sparse form,
+    coarser cells), and a stray point's block of cells would have to grow over millions of empty rows -- it reads every
+    point instead.  An earlier build took 45 s for this cloud."""
+    import time
+
+    rng = np.random.default_rng(3)
+    sheet = np.stack([rng.uniform(0, 1, 40000), rng.uniform(0, 1, 40000), rng.normal(0, 1e-3, 40000)], 1)
+    pts = np.concatenate([sheet, [[300.0, -200.0, 50.0]], rng.uniform(-1000, 1000, (20, 3))]).astype(np.float32)
+    ctx = gpu_ctx_factory()
+    t = time.time()
+    _check(ctx, oracle, pts[:, 0].copy(), pts[:, 1].copy(), pts[:, 2].copy(), 60, 0.7)
+    assert time.time() - t < 20.0  # oracle included
