@@ -2405,6 +2405,11 @@ int pcp_close_pairs(pcp_context *ctx, double radius, int64_t *points_with_close_
   PCP_HIP_TRY(ctx, hipMemcpyAsync(&c, ctx->s_counter.p, 8, hipMemcpyDeviceToHost, ctx->stream));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   *points_with_close_neighbour = static_cast<int64_t>(c);
+  // a micrometre radius takes the finest grid there is: do not keep gigabytes of bitmap for a one-off check
+  if (ctx->g_occ.count > (size_t(1) << 25)) {
+    ctx->g_occ.release();
+    ctx->g_occ_rank.release();
+  }
   return PCP_OK;
 }
 
