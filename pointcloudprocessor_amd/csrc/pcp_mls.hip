@@ -923,26 +923,32 @@ __global__ __launch_bounds__(kSorBlock) void k_sor_mean_distance(const float *__
   const float cell = 1.0f / g.inv_cell;
   const int32_t maxr = max(g.nx, max(g.ny, g.nz));
   int size = 0;
+  // candidates of one run of cells, four at a time (12 coordinate loads in flight)
+  auto scan = [&](int32_t b, int32_t e) {
+    for (int32_t q = b; q < e; q += 4) {
+      const int32_t q1 = min(q + 1, e - 1), q2 = min(q + 2, e - 1), q3 = min(q + 3, e - 1);
+      const float d0 = sqdist_f32(sx[q], sy[q], sz[q], qx, qy, qz);
+      const float d1 = sqdist_f32(sx[q1], sy[q1], sz[q1], qx, qy, qz);
+      const float d2 = sqdist_f32(sx[q2], sy[q2], sz[q2], qx, qy, qz);
+      const float d3 = sqdist_f32(sx[q3], sy[q3], sz[q3], qx, qy, qz);
+      heap_push(heap, size, k, d0);
+      if (q + 1 < e) heap_push(heap, size, k, d1);
+      if (q + 2 < e) heap_push(heap, size, k, d2);
+      if (q + 3 < e) heap_push(heap, size, k, d3);
+    }
+  };
   for (int32_t ring = 0; ring <= maxr; ++ring) {
     if (size == k && ring >= 1) {
       // every unvisited point is at least (ring - 1) cells away; 0.999 absorbs the fp32 cell-assignment slop
       const float reach = static_cast<float>(ring - 1) * cell * 0.999f;
       if (reach * reach > heap[0]) break;
     }
-    // candidates of one run of cells, four at a time (12 coordinate loads in flight)
-    auto scan = [&](int32_t b, int32_t e) {
-      for (int32_t q = b; q < e; q += 4) {
-        const int32_t q1 = min(q + 1, e - 1), q2 = min(q + 2, e - 1), q3 = min(q + 3, e - 1);
-        const float d0 = sqdist_f32(sx[q], sy[q], sz[q], qx, qy, qz);
-        const float d1 = sqdist_f32(sx[q1], sy[q1], sz[q1], qx, qy, qz);
-        const float d2 = sqdist_f32(sx[q2], sy[q2], sz[q2], qx, qy, qz);
-        const float d3 = sqdist_f32(sx[q3], sy[q3], sz[q3], qx, qy, qz);
-        heap_push(heap, size, k, d0);
-        if (q + 1 < e) heap_push(heap, size, k, d1);
-        if (q + 2 < e) heap_push(heap, size, k, d2);
-        if (q + 3 < e) heap_push(heap, size, k, d3);
-      }
-    };
+    if (ring > 1 && static_cast<int64_t>(2 * ring + 1) * (2 * ring + 1) > n / 32) {
+      // a stray point far from the rest of the cloud: the shells of empty rows cost more than every point once
+      size = 0;
+      scan(0, static_cast<int32_t>(n));
+      break;
+    }
     for (int32_t zz = max(cz - ring, 0); zz <= min(cz + ring, g.nz - 1); ++zz)
       for (int32_t yy = max(cy - ring, 0); yy <= min(cy + ring, g.ny - 1); ++yy) {
         const bool shell_yz = zz == cz - ring || zz == cz + ring || yy == cy - ring || yy == cy + ring;
