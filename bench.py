@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=0, help="0: 100 at N = 1, 20 at N > 1")
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--settle-ms", type=float, default=400.0,
+                    help="untimed whole steps before the warm-up until this much time has passed (clock / power state of a fresh box)")
     ap.add_argument("--points", type=int, default=0, help="points per GPU (0: 10 M at N = 1, 50 M / N at N > 1)")
     ap.add_argument("--frames", type=int, default=0, help="keyframes (0: 256 at N = 1, 1024 at N > 1)")
     ap.add_argument("--camera", default="cfg", choices=["cfg", "ref", "tiny"])
@@ -186,10 +188,12 @@ def main():
         def step():
             colorizer.run(download=False)
             engine.ctx.download_result_packed_async(landing[step_no[0] & 1].data_ptr())
+            t_enq = time.perf_counter()
             # the other landing buffer is about to be reused: its colours (the previous step's) must have arrived.
             # Waits for that copy only, never for a kernel; it also keeps the host one step ahead instead of hundreds
             engine.ctx.download_wait_previous()
             step_no[0] += 1
+            return t_enq
         return step
 
     step = make_step(col, eng, pinned)
@@ -201,12 +205,35 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # ---- settle phase (untimed, reported): a fresh box idles at a low clock and the upload phase above is too light
+    # to raise it; BENCH_r02 timed 20 steps 10 ms after the first kernel and read 2.19 ms per step where 100-step runs
+    # of the same build read 1.80-1.85.  Whole steps run until `--settle-ms` have passed; the W warm-up steps and
+    # the K timed steps of the contract follow unchanged. ----
+    fence()
+    t_settle = time.perf_counter()
+    settle_steps = 0
+    while True:
+        go = (time.perf_counter() - t_settle) * 1e3 < args.settle_ms
+        if dist is not None:  # a step holds a collective: every rank takes the number of steps rank 0 decides on
+            flag = torch.tensor([1 if go else 0], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.broadcast(flag, 0)
+            go = bool(flag.item())
+        if not go:
+            break
+        for _ in range(8):
+            step()
+        settle_steps += 8
+    fence()
+    t_settle = time.perf_counter() - t_settle
     for _ in range(args.warmup):
         step()
     fence()
+    marks = np.empty((steps, 3))  # per step: host time at entry, after the last enqueue, after the wait for the previous copy
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
+    for i in range(steps):
+        t_in = time.perf_counter()
+        t_enq = step()
+        marks[i] = (t_in, t_enq, time.perf_counter())
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -214,6 +241,16 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ms_per_step = dt / max(steps, 1) * 1e3
+    # per-step figures of the timed region (host clock): a step returns when the PREVIOUS step's colours have landed,
+    # so in steady state the interval between two returns is one device step; enqueue = host time spent queueing a step
+    d_step = np.diff(marks[:, 2]) * 1e3 if steps > 1 else np.array([ms_per_step])
+    step_stats = {"min": round(float(d_step.min()), 3), "median": round(float(np.median(d_step)), 3),
+                  "max": round(float(d_step.max()), 3),
+                  "host_enqueue_median": round(float(np.median(marks[:, 1] - marks[:, 0])) * 1e3, 3),
+                  "host_wait_median": round(float(np.median(marks[:, 2] - marks[:, 1])) * 1e3, 3),
+                  "what": "interval between the returns of consecutive timed steps (each waits for the previous step's "
+                          "colours on the host); host_enqueue = time to queue one step, host_wait = time blocked on the "
+                          "previous step's download"}
     value = world * N * F * steps / dt / 1e6  # Mpoints x frames / s, whole job
 
     result = None
@@ -572,6 +609,10 @@ def main():
             "steps": steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
+            "step_ms": step_stats,
+            "settle": {"steps": settle_steps, "ms": round(t_settle * 1e3, 1),
+                       "what": "untimed whole steps before the W warm-up steps, so that the timed region starts at the clock "
+                               "the device holds under this load"},
             "higher_is_better": True,
             "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,

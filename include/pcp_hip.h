@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define PCP_ABI_VERSION 2 /* 2: pcp_cull_params grew cull_mode / match_mode; pcp_set_image_adjust */
+#define PCP_ABI_VERSION 3 /* 2: pcp_cull_params grew cull_mode / match_mode; pcp_set_image_adjust
+                             3: PCP_CULL_HPR, pcp_cull_params.hpr_flip_radius, pcp_hpr_stats */
 
 #define PCP_OK 0
 #define PCP_ERR_INVALID (-1) /* bad argument */
@@ -60,12 +61,18 @@ typedef struct pcp_camera {
 /* Which of ViewCulling's two routines decides the candidates (pcp_cull_params.cull_mode). */
 #define PCP_CULL_ZBUFFER 0 /* ViewCulling::view_culling, view_culling.cpp:52-174 (the routine north_star names; its
                               call is commented out at :43) */
-#define PCP_CULL_HPR_CANDIDATES 1 /* the candidate filter of ViewCulling::hidden_points_removal, view_culling.cpp:
-                              276-288 (the routine the reference binary calls, :46): z > 0 and 0 <= (int)u < cull_width
-                              and 0 <= (int)v < cull_height, every candidate kept.  qhull's convex hull of the
-                              spherically flipped candidates (:291-329) is NOT run: with the hard-coded flip radius
-                              90000 (view_culling.hpp:14) it keeps every candidate on non-degenerate data and drops
-                              a handful on near-collinear ones ("HPR"). */
+#define PCP_CULL_HPR_CANDIDATES 1 /* ONLY the candidate filter of ViewCulling::hidden_points_removal, view_culling.cpp:
+                              276-288: z > 0 and 0 <= (int)u < cull_width and 0 <= (int)v < cull_height, every candidate
+                              kept -- a frustum cull, no occlusion test.  It is a SUPERSET of what the reference binary
+                              keeps: at map density the hull below drops most of these candidates (C3 scene, 10 M points:
+                              between 3 % and 90 % of a keyframe's candidates, profiles/r03_hpr_retention.json). */
+#define PCP_CULL_HPR 2 /* ViewCulling::hidden_points_removal, view_culling.cpp:266-334, the routine the reference binary
+                              calls (:46): the candidates above, flipped about a sphere of radius hpr_flip_radius
+                              (:291-292), the origin appended (:297); visible = the vertices of the convex hull of that
+                              set other than the origin (qhull, :302-329).  Computed on the device, per candidate, with
+                              checked certificates (csrc/pcp_hpr.hip); the keep set is the exact set of extreme points,
+                              from which qhull's differs by the points within its round-off (~1e-10 m) of a facet.  Kept
+                              points are reported in input order (the reference lists them in qhull's vertex order). */
 
 /* How a visible sample is credited to map points (pcp_cull_params.match_mode), PointCloudProcessor.cpp:554-592. */
 #define PCP_MATCH_IDENTITY 0 /* the sample of point i is credited to point i, scores from the transform output p_c
@@ -82,8 +89,9 @@ typedef struct pcp_cull_params {
   int32_t enable_depth_buffer_culling;
   int32_t downsample_factor;
   double depth_slack;
-  int32_t cull_mode;  /* PCP_CULL_ZBUFFER (default) / PCP_CULL_HPR_CANDIDATES */
+  int32_t cull_mode;  /* PCP_CULL_ZBUFFER (default) / PCP_CULL_HPR_CANDIDATES / PCP_CULL_HPR */
   int32_t match_mode; /* PCP_MATCH_ROUNDTRIP (default) / PCP_MATCH_IDENTITY */
+  double hpr_flip_radius; /* ViewCullingParams::hidden_points_removal_max_z = 90000 (view_culling.hpp:14) */
 } pcp_cull_params;
 
 /* MLSParameters, PCP/include/cloudSmooth.hpp:21-36; values
@@ -113,7 +121,8 @@ enum {
   PCP_K_MLS_VOXEL = 8,  /* VOXEL_GRID_DILATION upsampling */
   PCP_K_TILE_MASK = 9,  /* tile x keyframe visibility masks (conservative culling) */
   PCP_K_NID = 10,       /* NID joint histograms (value + SE(3) tangent gradient) */
-  PCP_K_COUNT = 11
+  PCP_K_HPR = 11,       /* hidden_points_removal: flip, binning, per-candidate hull membership */
+  PCP_K_COUNT = 12
 };
 
 /* ---- lifecycle ---------------------------------------------------------- */
@@ -202,6 +211,13 @@ int pcp_cull_frame(pcp_context *ctx, int32_t frame, uint8_t *out_keep, int64_t *
  * uploaded.  All outputs nullable; capacity in points; *out_count = true count. */
 int pcp_frame_visible(pcp_context *ctx, int32_t frame, int64_t capacity, int32_t *out_index, uint8_t *out_rgb,
                       uint16_t *out_mask, float *out_xyz_cam, float *out_xyz_world, int64_t *out_count);
+
+/* diagnostic: the last hidden_points_removal run on ctx (PCP_CULL_HPR; the latest keyframe of a batched call):
+ * out[0] visible, [1] hidden, [2] candidates that went to the exact path (neither floating-point certificate held),
+ * [3] trial normals, [4] batches of 64 point tests, [5] searches restarted from the wide box, [6] UNRESOLVED (no exact
+ * certificate either: exactly degenerate input such as four coplanar flipped points; classified hidden), [7] exact
+ * predicate evaluations, [8] grid cells, [9] candidates. */
+int pcp_hpr_stats(pcp_context *ctx, int64_t out[10]);
 
 /* ---- whole run (pcdColorizationAndSmooth, PointCloudProcessor.cpp:474-602) -- */
 /* z-buffer MIN pass for keyframes [frame_begin, frame_end) over the local points */

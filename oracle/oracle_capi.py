@@ -55,8 +55,8 @@ class MLSParams(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the restatement with the committed Makefile (gcc, -ffp-contract=off)."""
-    srcs = [os.path.join(_HERE, f) for f in ("pcp_oracle.c", "pcp_oracle_mls.c", "pcp_oracle_nid.c", "pcp_oracle.h",
-                                            "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("pcp_oracle.c", "pcp_oracle_mls.c", "pcp_oracle_nid.c", "pcp_oracle_hpr.c",
+                                            "pcp_oracle.h", "Makefile")]
     stale = force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
     )
@@ -85,6 +85,10 @@ def lib() -> C.CDLL:
         L.orc_colorize.restype = C.c_int
         L.orc_colorize_faithful.restype = C.c_int
         L.orc_affine_inverse_f32.restype = None
+        L.orc_convex_hull_vertices.restype = C.c_int64
+        L.orc_hpr_frame.restype = C.c_int64
+        L.orc_orient3d.restype = C.c_int
+        L.orc_hpr_flip.restype = None
         _ = fp
         _lib = L
     return _lib
@@ -168,6 +172,46 @@ def cull_frame(cam, cp, w2c, x, y, z, threads: int = 1):
     kept = lib().orc_cull_frame(C.byref(cam), C.byref(cp), _p(w2c), _p(x), _p(y), _p(z), C.c_int64(n), _p(keep),
                                 _p(dmap), C.c_int32(threads))
     return keep, dmap.reshape(mh, mw), int(kept)
+
+
+def orient3d(a, b, c, d, exact_only: bool = False) -> int:
+    """Sign of det [a-d; b-d; c-d] (> 0: d below the plane through a, b, c counter-clockwise from above), decided
+    exactly; exact_only skips the floating-point filter."""
+    a, b, c, d = (np.ascontiguousarray(v, np.float64).reshape(3) for v in (a, b, c, d))
+    return int(lib().orc_orient3d(_p(a), _p(b), _p(c), _p(d), C.c_int32(1 if exact_only else 0)))
+
+
+def hpr_flip(xc, yc, zc, flip_radius: float = 90000.0):
+    """view_culling.cpp:291-292 on fp32 camera coordinates -> (m, 3) fp64 flipped points."""
+    xc, yc, zc = _f32(xc), _f32(yc), _f32(zc)
+    out = np.empty((len(xc), 3), np.float64)
+    lib().orc_hpr_flip(_p(xc), _p(yc), _p(zc), C.c_int64(len(xc)), C.c_double(flip_radius), _p(out))
+    return out
+
+
+def convex_hull_vertices(points):
+    """Exact extreme points of an (n, 3) fp64 point set: (is_vertex uint8[n], count or -1 for flat / too few points,
+    stats dict)."""
+    pts = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    is_v = np.zeros(len(pts), np.uint8)
+    st = np.zeros(4, np.int64)
+    nv = lib().orc_convex_hull_vertices(_p(pts), C.c_int64(len(pts)), _p(is_v), _p(st))
+    return is_v, int(nv), dict(filtered=int(st[0]), exact=int(st[1]), zero=int(st[2]), duplicates=int(st[3]))
+
+
+def hpr_frame(cam, w2c, x, y, z, flip_radius: float = 90000.0):
+    """ViewCulling::hidden_points_removal (view_culling.cpp:266-334) for one keyframe: keep mask in input order, stats."""
+    x, y, z = _f32(x), _f32(y), _f32(z)
+    n = len(x)
+    keep = np.zeros(n, np.uint8)
+    st = np.zeros(5, np.int64)
+    w2c = _f32(w2c)
+    kept = lib().orc_hpr_frame(C.byref(cam), _p(w2c), _p(x), _p(y), _p(z), C.c_int64(n), C.c_double(flip_radius), _p(keep),
+                               _p(st))
+    if kept < 0:
+        raise MemoryError("orc_hpr_frame")
+    return keep, dict(candidates=int(st[0]), filtered=int(st[1]), exact=int(st[2]), zero=int(st[3]), duplicates=int(st[4]),
+                      kept=int(kept))
 
 
 def scores(xc, yc, zc, pose):

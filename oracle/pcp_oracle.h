@@ -172,6 +172,17 @@ int orc_nid(const orc_camera *cam, const uint8_t *const *images, int32_t n_frame
             const float *x, const float *y, const float *z, const float *intensity, const double T[16], int32_t bins,
             double *out_cost, double *out_grad);
 
+/* a4: ViewCulling::hidden_points_removal (view_culling.cpp:266-334), see pcp_oracle_hpr.c.
+ * orc_orient3d: sign of det [a-d; b-d; c-d], exact.  orc_convex_hull_vertices: exact extreme points of n points
+ * (xyz triples); stats (nullable, 4): filtered / exact / exactly-zero orientation tests, duplicates; returns the vertex
+ * count, -1 for fewer than 4 points or a flat set, -2 out of memory.  orc_hpr_flip: :291-292.  orc_hpr_frame: keep mask
+ * (input order) of one keyframe; stats (nullable, 5): candidates, then the four above. */
+int orc_orient3d(const double a[3], const double b[3], const double c[3], const double d[3], int32_t exact_only);
+int64_t orc_convex_hull_vertices(const double *points, int64_t n, uint8_t *is_vertex, int64_t *stats);
+void orc_hpr_flip(const float *xc, const float *yc, const float *zc, int64_t m, double flip_radius, double *out_flipped);
+int64_t orc_hpr_frame(const orc_camera *cam, const float w2c[12], const float *x, const float *y, const float *z,
+                      int64_t n, double flip_radius, uint8_t *out_keep, int64_t *stats);
+
 int32_t orc_hardware_threads(void);
 
 #ifdef __cplusplus

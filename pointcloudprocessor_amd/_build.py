@@ -16,8 +16,8 @@ LIB_DIR = os.path.join(_PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpcp_hip.so")
 INCLUDE = os.path.join(_ROOT, "include")
 
-SOURCES = ["pcp_context.hip", "pcp_colour.hip", "pcp_mls.hip", "pcp_nid.hip"]
-HEADERS = ["pcp_internal.hpp", "pcp_device.hpp", "pcp_scan.hpp", "pcp_hsv.hpp"]
+SOURCES = ["pcp_context.hip", "pcp_colour.hip", "pcp_mls.hip", "pcp_nid.hip", "pcp_hpr.hip"]
+HEADERS = ["pcp_internal.hpp", "pcp_device.hpp", "pcp_scan.hpp", "pcp_hsv.hpp", "pcp_exact.hpp"]
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",

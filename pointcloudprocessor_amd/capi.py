@@ -24,8 +24,8 @@ PCP_ERR_RANGE = -5
 
 NID_EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                           C.POINTER(C.c_int32))
-K_PROJECT, K_DEPTH, K_COLOUR, K_VISIBILITY, K_MLS_GRID, K_MLS_FIT, K_MISC, K_SOR, K_MLS_VOXEL, K_TILE_MASK, K_NID = range(11)
-K_COUNT = 11
+K_PROJECT, K_DEPTH, K_COLOUR, K_VISIBILITY, K_MLS_GRID, K_MLS_FIT, K_MISC, K_SOR, K_MLS_VOXEL, K_TILE_MASK, K_NID, K_HPR = range(12)
+K_COUNT = 12
 
 
 class PcpError(RuntimeError):
@@ -49,12 +49,13 @@ class CullParams(C.Structure):
         ("enable_depth_buffer_culling", C.c_int32),
         ("downsample_factor", C.c_int32),
         ("depth_slack", C.c_double),
-        ("cull_mode", C.c_int32),   # CULL_ZBUFFER / CULL_HPR_CANDIDATES
+        ("cull_mode", C.c_int32),   # CULL_ZBUFFER / CULL_HPR_CANDIDATES / CULL_HPR
         ("match_mode", C.c_int32),  # MATCH_IDENTITY / MATCH_ROUNDTRIP
+        ("hpr_flip_radius", C.c_double),  # hidden_points_removal_max_z, view_culling.hpp:14
     ]
 
 
-CULL_ZBUFFER, CULL_HPR_CANDIDATES = 0, 1
+CULL_ZBUFFER, CULL_HPR_CANDIDATES, CULL_HPR = 0, 1, 2
 MATCH_IDENTITY, MATCH_ROUNDTRIP = 0, 1
 
 
@@ -300,6 +301,14 @@ class Context:
         kept = C.c_int64()
         self._check(self.lib.pcp_cull_frame(self.h, C.c_int32(frame), _ptr(keep), C.byref(kept), _ptr(dmap)))
         return keep, dmap.reshape(mh, mw), kept.value
+
+    def hpr_stats(self) -> dict:
+        """Counters of the last hidden_points_removal run (pcp_hpr_stats)."""
+        out = np.zeros(10, np.int64)
+        self._check(self.lib.pcp_hpr_stats(self.h, _ptr(out)))
+        keys = ("visible", "hidden", "exact_path", "trial_normals", "test_batches", "wide_box_retries", "unresolved",
+                "exact_evaluations", "cells", "candidates")
+        return {k: int(v) for k, v in zip(keys, out)}
 
     def frame_visible(self, frame: int, capacity: int | None = None):
         cap = self.n if capacity is None else capacity

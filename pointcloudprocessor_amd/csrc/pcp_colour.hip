@@ -1030,6 +1030,47 @@ static int single_frame_depth(pcp_context *ctx, int32_t frame) {
   return PCP_OK;
 }
 
+// clears the flags of points without a colour pixel (generateColorMap's bounds, PointCloudProcessor.cpp:748-754)
+__global__ __launch_bounds__(kBlock) void k_require_pixel(const float *__restrict__ x, const float *__restrict__ y,
+                                                          const float *__restrict__ z, int64_t n, DevCamera cam, DevFrame fr,
+                                                          uint8_t *__restrict__ keep) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n || !keep[i]) return;
+  if (project_point(cam, fr.w2c, x[i], y[i], z[i]).pixel < 0) keep[i] = 0;
+}
+
+// ViewCulling::cull of one keyframe as byte flags in input order (ctx->s_keep): the z-buffer routine's pass 2 against the
+// map in ctx->s_u32 (single_frame_depth), or hidden_points_removal (candidate filter, then the hull: pcp_hpr.hip).
+// require_pixel: only points that generateColorMap can colour.
+static int frame_keep_flags(pcp_context *ctx, int32_t frame, bool require_pixel) {
+  const int64_t n = ctx->n;
+  PCP_HIP_TRY(ctx, ctx->s_keep.ensure(static_cast<size_t>(n) + 16));
+  if (n == 0) return PCP_OK;
+  const size_t plane = plane_of(ctx);
+  const bool hull = ctx->cull.cull_mode == PCP_CULL_HPR;
+  {
+    LaunchTimer t(ctx, PCP_K_VISIBILITY);
+    PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->s_keep.p, 0, static_cast<size_t>(n), ctx->stream));
+    hipLaunchKernelGGL(k_visibility, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
+                       ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, n, ctx->dcam,
+                       ctx->hframes[static_cast<size_t>(frame)], ctx->s_u32.p, ctx->perm.p, ctx->s_keep.p,
+                       (require_pixel && !hull) ? 1 : 0);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  if (!hull) return PCP_OK;
+  // the hull is taken over EVERY candidate (view_culling.cpp:276-288 knows nothing of the image's own size); the
+  // colour bounds apply to what it keeps
+  int rc = hpr_refine_flags(ctx, frame, ctx->s_keep.p);
+  if (rc != PCP_OK) return rc;
+  if (require_pixel) {
+    LaunchTimer t(ctx, PCP_K_VISIBILITY);
+    hipLaunchKernelGGL(k_require_pixel, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, ctx->xyz.p, ctx->xyz.p + plane,
+                       ctx->xyz.p + 2 * plane, n, ctx->dcam, ctx->hframes[static_cast<size_t>(frame)], ctx->s_keep.p);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  return PCP_OK;
+}
+
 // ViewCulling::cull for one keyframe, device side: ordered index list of the kept points into
 // `d_index` (capacity entries), count to *count.  Used by pcp_cull_frame-like paths and the NID stage.
 int cull_frame_indices(pcp_context *ctx, int32_t frame, int32_t *d_index, int64_t capacity, int64_t *count) {
@@ -1038,16 +1079,7 @@ int cull_frame_indices(pcp_context *ctx, int32_t frame, int32_t *d_index, int64_
   if (n == 0) return PCP_OK;
   int rc = single_frame_depth(ctx, frame);
   if (rc != PCP_OK) return rc;
-  PCP_HIP_TRY(ctx, ctx->s_keep.ensure(static_cast<size_t>(n) + 16));
-  const size_t plane = plane_of(ctx);
-  {
-    LaunchTimer t(ctx, PCP_K_VISIBILITY);
-    PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->s_keep.p, 0, static_cast<size_t>(n), ctx->stream));
-    hipLaunchKernelGGL(k_visibility, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
-                       ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, n, ctx->dcam,
-                       ctx->hframes[static_cast<size_t>(frame)], ctx->s_u32.p, ctx->perm.p, ctx->s_keep.p, 0);
-    PCP_HIP_TRY(ctx, hipGetLastError());
-  }
+  if ((rc = frame_keep_flags(ctx, frame, false)) != PCP_OK) return rc;
   return compact_flags(ctx, ctx->s_keep.p, n, d_index, capacity, count);
 }
 
@@ -1287,16 +1319,7 @@ int pcp_cull_frame(pcp_context *ctx, int32_t frame, uint8_t *out_keep, int64_t *
   if ((rc = check_frame(ctx, "pcp_cull_frame", frame)) != PCP_OK) return rc;
   const int64_t n = ctx->n;
   if ((rc = single_frame_depth(ctx, frame)) != PCP_OK) return rc;
-  PCP_HIP_TRY(ctx, ctx->s_keep.ensure(static_cast<size_t>(n) + 16));
-  if (n > 0) {
-    const size_t plane = plane_of(ctx);
-    LaunchTimer t(ctx, PCP_K_VISIBILITY);
-    PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->s_keep.p, 0, static_cast<size_t>(n), ctx->stream));
-    hipLaunchKernelGGL(k_visibility, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
-                       ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, n, ctx->dcam,
-                       ctx->hframes[static_cast<size_t>(frame)], ctx->s_u32.p, ctx->perm.p, ctx->s_keep.p, 0);
-    PCP_HIP_TRY(ctx, hipGetLastError());
-  }
+  if ((rc = frame_keep_flags(ctx, frame, false)) != PCP_OK) return rc;
   if (out_kept) {
     int64_t cnt = 0;
     if (n > 0 && (rc = compact_flags(ctx, ctx->s_keep.p, n, nullptr, 0, &cnt)) != PCP_OK) return rc;
@@ -1324,16 +1347,8 @@ int pcp_frame_visible(pcp_context *ctx, int32_t frame, int64_t capacity, int32_t
   if ((rc = wait_images(ctx, frame, frame + 1)) != PCP_OK) return rc;
   if ((rc = single_frame_depth(ctx, frame)) != PCP_OK) return rc;
   const size_t plane = plane_of(ctx);
-  PCP_HIP_TRY(ctx, ctx->s_keep.ensure(static_cast<size_t>(n) + 16));
   PCP_HIP_TRY(ctx, ctx->s_cell.ensure(plane + 4));
-  {
-    LaunchTimer t(ctx, PCP_K_VISIBILITY);
-    PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->s_keep.p, 0, static_cast<size_t>(n), ctx->stream));
-    hipLaunchKernelGGL(k_visibility, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
-                       ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, n, ctx->dcam,
-                       ctx->hframes[static_cast<size_t>(frame)], ctx->s_u32.p, ctx->perm.p, ctx->s_keep.p, 1);
-    PCP_HIP_TRY(ctx, hipGetLastError());
-  }
+  if ((rc = frame_keep_flags(ctx, frame, true)) != PCP_OK) return rc;
   int64_t m = 0;
   if ((rc = compact_flags(ctx, ctx->s_keep.p, n, ctx->s_cell.p, static_cast<int64_t>(plane), &m)) != PCP_OK) return rc;
   if (out_count) *out_count = m;

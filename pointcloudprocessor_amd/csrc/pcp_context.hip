@@ -632,6 +632,13 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->m_state.release();
   ctx->m_flag.release();
   ctx->intensity.release();
+  ctx->h_index.release();
+  ctx->h_i32.release();
+  ctx->h_cells_i.release();
+  ctx->h_f64.release();
+  ctx->h_cells_d.release();
+  ctx->h_state.release();
+  ctx->h_stats.release();
   ctx->nid_pts.release();
   ctx->nid_chunk_kf.release();
   ctx->nid_hist.release();
@@ -700,6 +707,7 @@ void pcp_default_cull_params(pcp_cull_params *p) {
   p->depth_slack = 0.05;
   p->cull_mode = PCP_CULL_ZBUFFER;
   p->match_mode = PCP_MATCH_ROUNDTRIP;  // the reference's arithmetic (PointCloudProcessor.cpp:555,571-579); +2 % of a step
+  p->hpr_flip_radius = 90000.0;         // view_culling.hpp:14
 }
 
 // PointCloudProcessor.cpp:67-86
@@ -725,8 +733,10 @@ int pcp_set_camera(pcp_context *ctx, const pcp_camera *cam, const pcp_cull_param
   if (cam->image_width <= 0 || cam->image_height <= 0 || cam->cull_width <= 0 || cam->cull_height <= 0)
     return set_error(ctx, PCP_ERR_INVALID, "pcp_set_camera: image / cull size must be positive");
   if (cp.downsample_factor <= 0) return set_error(ctx, PCP_ERR_INVALID, "pcp_set_camera: downsample_factor must be > 0");
-  if (cp.cull_mode != PCP_CULL_ZBUFFER && cp.cull_mode != PCP_CULL_HPR_CANDIDATES)
+  if (cp.cull_mode != PCP_CULL_ZBUFFER && cp.cull_mode != PCP_CULL_HPR_CANDIDATES && cp.cull_mode != PCP_CULL_HPR)
     return set_error(ctx, PCP_ERR_INVALID, "pcp_set_camera: unknown cull_mode %d", cp.cull_mode);
+  if (cp.cull_mode == PCP_CULL_HPR && !(cp.hpr_flip_radius > 0.0 && cp.hpr_flip_radius < 1e300))
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_set_camera: hpr_flip_radius must be positive and finite");
   if (cp.match_mode != PCP_MATCH_IDENTITY && cp.match_mode != PCP_MATCH_ROUNDTRIP)
     return set_error(ctx, PCP_ERR_INVALID, "pcp_set_camera: unknown match_mode %d", cp.match_mode);
   if (cam->cull_width > (1 << 24) || cam->cull_height > (1 << 24))
@@ -761,7 +771,8 @@ int pcp_set_camera(pcp_context *ctx, const pcp_camera *cam, const pcp_cull_param
   d.cull_hf = static_cast<float>(cam->cull_height);
   d.mw = cam->cull_width / cp.downsample_factor;
   d.mh = cam->cull_height / cp.downsample_factor;
-  d.cull_mode = cp.cull_mode;
+  // the kernels of the colour path only know the candidate filter; the hull is a stage of its own (pcp_hpr.hip)
+  d.cull_mode = cp.cull_mode == PCP_CULL_HPR ? PCP_CULL_HPR_CANDIDATES : cp.cull_mode;
   d.match_mode = cp.match_mode;
   d.cull_wd = static_cast<double>(cam->cull_width);
   d.cull_hd = static_cast<double>(cam->cull_height);
@@ -798,7 +809,7 @@ int pcp_set_camera(pcp_context *ctx, const pcp_camera *cam, const pcp_cull_param
     // pixel rule accepts (int)u in [0, img_w).  Box = union, +-0.5 px.
     // (hidden_points_removal's rule accepts (int)u in [0, cull_w): inside the same box with cw = cull_w)
     const float ds = static_cast<float>(cp.downsample_factor);
-    const bool hpr = cp.cull_mode == PCP_CULL_HPR_CANDIDATES;
+    const bool hpr = cp.cull_mode != PCP_CULL_ZBUFFER;
     const float cw = hpr ? static_cast<float>(d.cull_w) : ds * static_cast<float>(d.enable_zbuf ? d.mw : d.cull_w);
     const float ch = hpr ? static_cast<float>(d.cull_h) : ds * static_cast<float>(d.enable_zbuf ? d.mh : d.cull_h);
     d.u_lo = -(ds + 0.5f);
@@ -939,7 +950,7 @@ int pcp_timing_get(pcp_context *ctx, int32_t kernel_id, double *total_ms, int64_
 const char *pcp_kernel_name(int32_t kernel_id) {
   static const char *names[PCP_K_COUNT] = {"project_frame", "depth_pass", "colour_pass", "visibility", "mls_grid",
                                            "mls_fit",       "misc",       "sor",         "mls_voxel",   "tile_mask",
-                                           "nid_hist"};
+                                           "nid_hist",      "hpr"};
   return (kernel_id >= 0 && kernel_id < PCP_K_COUNT) ? names[kernel_id] : "?";
 }
 

@@ -1,0 +1,831 @@
+// pcp_hpr.hip -- ViewCulling::hidden_points_removal on the device (PCP/src/vlcal/calib/view_culling.cpp:266-334):
+// the cull the reference binary runs (:46).  Candidates (z > 0, truncated pixel inside the cull size, :276-288) are
+// flipped about a sphere of radius hidden_points_removal_max_z = 90000 (:291-292, view_culling.hpp:14), the origin is
+// appended (:297) and the visible points are the vertices of the convex hull of that set other than the origin
+// (qhull, :302-329).
+//
+// gfx950 only.  Build with -ffp-contract=off (the flip is the reference's arithmetic; the error bounds below hold with
+// or without contraction).
+//
+// What is computed.  A candidate is visible iff its flipped point p is an EXTREME POINT of S = {flipped candidates} +
+// {origin}: iff some plane through p has every other point of S strictly on one side.  That is a per-point question,
+// and it is answered per point -- no hull data structure is built:
+//
+//   visible  <=>  exists n :  n . (q - p) < 0  for every q in S \ {p}                                   (1)
+//   hidden   <=>  p lies in the simplex spanned by at most four other points of S (Caratheodory)          (2)
+//
+// One wavefront per candidate searches for a witness of (1) or (2) in floating point and then CHECKS it with a
+// forward error bound; both kinds of witness are proofs, so a point the kernel decides is decided correctly whatever
+// the search did.  The search: write n = e0 + s1 e1 + s2 e2 in a frame at p (e0 radial), so that (1) is a
+// two-dimensional linear feasibility problem in s: every q contributes the half-plane s . D_q < E_q with
+// D_q = ((q-p).e1, (q-p).e2), E_q = -(q-p).e0.  The wavefront keeps the feasible polygon of the half-planes seen so far
+// (one vertex per lane), takes its vertex mean as the trial normal, tests the other points against it -- 64 at a time,
+// one per lane -- and clips the polygon with every point the trial normal does not clear.  A trial normal that clears
+// everything is a witness of (1); a polygon clipped to nothing names three half-planes with an empty intersection, and
+// the tetrahedron (origin, q_a, q_b, q_c) of their points is the witness of (2).
+//
+// Locality.  All flipped points lie within metres of a sphere of radius ~1.8e5 m, inside the camera's cone.  A plane
+// through p that is nearly tangent to that sphere leaves it by rho sep^2 / 2 at chordal distance sep, so only points
+// within a few pixels of p can reach it.  Candidates are binned by their gnomonic coordinates (X/Z, Y/Z) into cells
+// (about 8 points each, 8 x 8 cells to a coarse cell); a cell holds its centre direction u_c, a bound r_c of the chord
+// between u_c and any direction inside, and an upper bound rho_c of the norms of its points.  For q in the cell
+//     n . q = |q| |n| cos(n, q) <= rho_c |n| (1 - max(0, |n/|n| - u_c| - r_c)^2 / 2)
+// and the cell is cleared when that is below n . p.  A wavefront tests 64 coarse cells, then the 64 cells of a coarse
+// cell it could not clear, then the points of the cells that remain.
+//
+// Points neither witness settles (a trial normal within round-off of another point's plane, a tetrahedron test whose
+// determinant the filter cannot sign: margins ~1e-12 m) go to k_hpr_exact, one wavefront each, which repeats the search
+// over all candidates and checks its certificates with the exact orientation predicate (pcp_exact.hpp).  What even that
+// cannot certify -- only exactly degenerate input (four coplanar points) can get there -- is counted (`unresolved`,
+// pcp_hpr_stats) and classified hidden, as qhull classifies points on a facet ("coplanar points" are not vertices).
+// Exact duplicates: the lowest input index of a group of identical flipped points stands for the group.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
+#include "pcp_device.hpp"
+#include "pcp_exact.hpp"
+#include "pcp_scan.hpp"
+
+namespace pcp {
+
+constexpr int kHprBlock = 256;
+constexpr int kHprCoarse = 8;           // fine cells per coarse cell edge: 64 fine cells = one wavefront of tests
+constexpr double kHprTargetPerCell = 8.0;
+constexpr int64_t kHprMaxCells = int64_t(1) << 22;
+constexpr int kHprMaxRestarts = 96;
+constexpr double kPointSlack = 1.0e-15;  // |fl(n . (q - p)) - exact| <= 4.44e-16 sum |n_i (q_i - p_i)| (see test_range)
+
+enum : int32_t { kStHidden = 0, kStVisible = 1, kStUndecided = 2 };
+enum : int { kSearchVisible = 1, kSearchEmpty = 2, kSearchFail = 3, kSearchHiddenDup = 4 };
+
+struct HprGrid {
+  double a0, b0, h, inv_h;
+  int32_t gw, gh, cgw, cgh;
+  double r_fine, r_coarse;  // chord bound between a cell's centre direction and any direction inside it
+  int32_t m;
+};
+
+struct HprArrays {
+  const double *sx, *sy, *sz;   // flipped candidates, cell order
+  const int32_t *sidx;          // input index of the candidate (duplicate rule)
+  const int32_t *scell;         // fine cell of the candidate
+  const int32_t *cstart;        // fine cells: first candidate (cells + 1 entries)
+  const double *crho;           // fine cells: upper bound of |q| (0 = empty)
+  const double *cdir;           // fine cells: centre direction, SoA x[cells] y[cells] z[cells]
+  const double *Crho, *Cdir;    // coarse cells
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// wavefront helpers
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x & 63u); }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ unsigned long long order_key(double d) {
+  const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(d));
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+inline double key_to_double(unsigned long long k) {
+  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  double d;
+  std::memcpy(&d, &b, 8);
+  return d;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// the feasible polygon of the half-planes seen so far: vertex i in lane i, eid = the constraint whose boundary line
+// carries the edge from vertex i to vertex i + 1 (ids >= 0: candidates in cell order; < 0: the initial box)
+// ------------------------------------------------------------------------------------------------------------------
+struct Polygon {
+  double vx, vy;
+  int32_t eid;
+  int nv;  // wave-uniform
+};
+
+__device__ __forceinline__ void polygon_box(Polygon &P, double B) {
+  const int l = lane_id();
+  // counter-clockwise square; edge ids -1 .. -4
+  P.vx = (l == 0 || l == 3) ? B : -B;
+  P.vy = (l == 0 || l == 1) ? B : -B;
+  P.eid = -1 - l;
+  P.nv = 4;
+}
+
+// Clip with s . D <= E.  0: nothing cut, 1: cut, 2: nothing left (cert_a / cert_b = the two constraints that meet in
+// the vertex nearest to the half-plane: with `id` their intersection is empty), 3: the inside vertices are not one
+// cyclic run (round-off), or the polygon would need a 65th vertex.
+__device__ __forceinline__ int polygon_clip(Polygon &P, double Dx, double Dy, double E, int32_t id, int32_t &cert_a,
+                                            int32_t &cert_b) {
+  const int l = lane_id();
+  const int nv = P.nv;
+  const bool valid = l < nv;
+  const double val = valid ? (Dx * P.vx + Dy * P.vy) - E : 0.0;
+  const unsigned long long m_valid = nv >= 64 ? ~0ull : ((1ull << nv) - 1ull);
+  const unsigned long long m_in = __ballot(valid && val <= 0.0) & m_valid;
+  if (m_in == m_valid) return 0;
+  if (m_in == 0ull) {
+    const double best = wave_min(valid ? val : INFINITY);
+    const unsigned long long at = __ballot(valid && val == best);
+    const int bl = static_cast<int>(__builtin_ctzll(at));
+    cert_a = __shfl(P.eid, bl, 64);
+    cert_b = __shfl(P.eid, (bl + nv - 1) % nv, 64);
+    return 2;
+  }
+  const int cnt = __popcll(m_in);
+  if (cnt + 2 > 64) return 3;
+  const unsigned long long prev = ((m_in << 1) | (m_in >> (nv - 1))) & m_valid;  // bit i = inside(i - 1)
+  const unsigned long long starts = m_in & ~prev;
+  if (__popcll(starts) != 1) return 3;
+  const int a = static_cast<int>(__builtin_ctzll(starts));
+  const int b = (a + cnt - 1) % nv, b1 = (b + 1) % nv, a0 = (a + nv - 1) % nv;
+  const double vbx = __shfl(P.vx, b, 64), vby = __shfl(P.vy, b, 64), valb = __shfl(val, b, 64);
+  const double vb1x = __shfl(P.vx, b1, 64), vb1y = __shfl(P.vy, b1, 64), valb1 = __shfl(val, b1, 64);
+  const double va0x = __shfl(P.vx, a0, 64), va0y = __shfl(P.vy, a0, 64), vala0 = __shfl(val, a0, 64);
+  const double vax = __shfl(P.vx, a, 64), vay = __shfl(P.vy, a, 64), vala = __shfl(val, a, 64);
+  const int32_t eid_a0 = __shfl(P.eid, a0, 64);
+  const double t1 = valb / (valb - valb1);  // valb <= 0 < valb1
+  const double x1x = vbx + t1 * (vb1x - vbx), x1y = vby + t1 * (vb1y - vby);
+  const double t2 = vala0 / (vala0 - vala);  // vala <= 0 < vala0
+  const double x2x = va0x + t2 * (vax - va0x), x2y = va0y + t2 * (vay - va0y);
+  const int src = (a + l) % nv;
+  double nvx = __shfl(P.vx, src, 64), nvy = __shfl(P.vy, src, 64);
+  int32_t neid = __shfl(P.eid, src, 64);
+  if (l == cnt) {
+    nvx = x1x;
+    nvy = x1y;
+    neid = id;
+  } else if (l == cnt + 1) {
+    nvx = x2x;
+    nvy = x2y;
+    neid = eid_a0;
+  }
+  P.vx = nvx;
+  P.vy = nvy;
+  P.eid = neid;
+  P.nv = cnt + 2;
+  return 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// the search of one candidate
+// ------------------------------------------------------------------------------------------------------------------
+struct Search {
+  Vec3d p;           // the candidate's flipped point
+  Vec3d e0, e1, e2;  // frame at p: e0 radial
+  int32_t self;      // its place in cell order
+  int32_t self_idx;  // its input index
+  // trial normal
+  Vec3d n, nh;
+  double nn_hi, hp_lo;
+  // outcome of a pass
+  bool changed, uncertain_left;
+  int32_t cert_a, cert_b, cert_c;
+  int status;  // 0 running, kSearchEmpty, kSearchFail, kSearchHiddenDup
+  unsigned long long tests;
+};
+
+__device__ __forceinline__ void search_frame(Search &S) {
+  const double rho = sqrt(S.p.x * S.p.x + S.p.y * S.p.y + S.p.z * S.p.z);
+  S.e0 = {S.p.x / rho, S.p.y / rho, S.p.z / rho};
+  // e1 = the x axis made orthogonal to e0 (the candidates lie in the camera's cone about +z, so e0 is never near x)
+  double ax = 1.0 - S.e0.x * S.e0.x, ay = -S.e0.x * S.e0.y, az = -S.e0.x * S.e0.z;
+  const double an = sqrt(ax * ax + ay * ay + az * az);
+  S.e1 = {ax / an, ay / an, az / an};
+  S.e2 = {S.e0.y * S.e1.z - S.e0.z * S.e1.y, S.e0.z * S.e1.x - S.e0.x * S.e1.z, S.e0.x * S.e1.y - S.e0.y * S.e1.x};
+}
+
+// trial normal from the polygon's vertex mean (a point strictly inside it)
+__device__ __forceinline__ void search_witness(Search &S, const Polygon &P) {
+  const bool valid = lane_id() < P.nv;
+  const double sx = wave_sum(valid ? P.vx : 0.0) / P.nv, sy = wave_sum(valid ? P.vy : 0.0) / P.nv;
+  S.n = {S.e0.x + (sx * S.e1.x + sy * S.e2.x), S.e0.y + (sx * S.e1.y + sy * S.e2.y), S.e0.z + (sx * S.e1.z + sy * S.e2.z)};
+  const double nn = sqrt(S.n.x * S.n.x + S.n.y * S.n.y + S.n.z * S.n.z);
+  S.nh = {S.n.x / nn, S.n.y / nn, S.n.z / nn};
+  S.nn_hi = nn * (1.0 + 1.0e-14);
+  const double hp = S.n.x * S.p.x + S.n.y * S.p.y + S.n.z * S.p.z;
+  S.hp_lo = hp * (1.0 - 1.0e-13);  // n . p > 0: the origin is on the inner side of every trial plane
+}
+
+// Candidates [k0, k1) of the cell order against the trial normal, 64 at a time.  A point is cleared when
+//   fl(n . (q - p)) < -1e-15 sum |n_i fl(q_i - p_i)|:
+// the subtraction, the product and the two additions of a term are each within 2^-53 relative, so the computed value
+// is within 4.44e-16 sum |n_i (q_i - p_i)| of the real one.  Every other point clips the polygon.
+__device__ __forceinline__ void test_range(Search &S, Polygon &P, const HprArrays &A, int32_t k0, int32_t k1) {
+  const int l = lane_id();
+  for (int32_t base = k0; base < k1 && S.status == 0; base += 64) {
+    const int32_t k = base + l;
+    const bool active = k < k1 && k != S.self;
+    double dx = 0.0, dy = 0.0, dz = 0.0;
+    if (active) {
+      dx = A.sx[k] - S.p.x;
+      dy = A.sy[k] - S.p.y;
+      dz = A.sz[k] - S.p.z;
+    }
+    S.tests += 1;
+    const bool dup = active && dx == 0.0 && dy == 0.0 && dz == 0.0;
+    if (__ballot(dup)) {
+      // identical flipped points: the lowest input index stands for the group
+      if (__ballot(dup && A.sidx[k] < S.self_idx)) {
+        S.status = kSearchHiddenDup;
+        return;
+      }
+    }
+    const double tx = S.n.x * dx, ty = S.n.y * dy, tz = S.n.z * dz;
+    const double t = (tx + ty) + tz;
+    const double T = (fabs(tx) + fabs(ty)) + fabs(tz);
+    const bool bad = active && !dup && !(t < -kPointSlack * T);
+    const bool uncertain = bad && !(t > kPointSlack * T);
+    unsigned long long todo = __ballot(bad);
+    const unsigned long long m_unc = __ballot(uncertain);
+    while (todo) {
+      const int src = static_cast<int>(__builtin_ctzll(todo));
+      todo &= todo - 1ull;
+      const double qx = __shfl(dx, src, 64), qy = __shfl(dy, src, 64), qz = __shfl(dz, src, 64);
+      const double Dx = (qx * S.e1.x + qy * S.e1.y) + qz * S.e1.z;
+      const double Dy = (qx * S.e2.x + qy * S.e2.y) + qz * S.e2.z;
+      const double E = -((qx * S.e0.x + qy * S.e0.y) + qz * S.e0.z);
+      int32_t ca = 0, cb = 0;
+      const int r = polygon_clip(P, Dx, Dy, E, base + src, ca, cb);
+      if (r == 1) {
+        S.changed = true;
+      } else if (r == 2) {
+        S.status = kSearchEmpty;
+        S.cert_a = ca;
+        S.cert_b = cb;
+        S.cert_c = base + src;
+        return;
+      } else if (r == 3) {
+        S.status = kSearchFail;
+        return;
+      } else if ((m_unc >> src) & 1ull) {
+        S.uncertain_left = true;  // within round-off of the trial plane and no cut to move the plane away
+      }
+    }
+  }
+}
+
+// is every point of the cell on the inner side of the trial plane?  (file header, "Locality")
+__device__ __forceinline__ bool cell_cleared(const Search &S, double ux, double uy, double uz, double rho, double r) {
+  const double dx = S.nh.x - ux, dy = S.nh.y - uy, dz = S.nh.z - uz;
+  const double sep = sqrt((dx * dx + dy * dy) + dz * dz);
+  const double sl = fmax(sep - r - 1.0e-12, 0.0);
+  return rho * S.nn_hi * (1.0 - 0.5 * sl * sl) < S.hp_lo;
+}
+
+// one pass over everything that could reach the trial plane; returns when the polygon changed (the caller takes a new
+// trial normal) or when the pass is complete
+__device__ __forceinline__ void pass_hierarchy(Search &S, Polygon &P, const HprArrays &A, const HprGrid &G) {
+  const int l = lane_id();
+  // the cells around the candidate's own first: that is where the binding constraints are
+  const int32_t cell = A.scell[S.self];
+  const int32_t ci = cell % G.gw, cj = cell / G.gw;
+  for (int dj = -1; dj <= 1 && S.status == 0; ++dj) {
+    const int32_t rj = cj + dj;
+    if (rj < 0 || rj >= G.gh) continue;
+    const int32_t c0 = rj * G.gw + max(ci - 1, 0), c1 = rj * G.gw + min(ci + 1, G.gw - 1);
+    test_range(S, P, A, A.cstart[c0], A.cstart[c1 + 1]);
+  }
+  if (S.changed || S.status != 0) return;
+  const int32_t n_coarse = G.cgw * G.cgh, n_fine = G.gw * G.gh;
+  for (int32_t cb = 0; cb < n_coarse && S.status == 0; cb += 64) {
+    const int32_t C = cb + l;
+    bool open = false;
+    if (C < n_coarse) {
+      const double rho = A.Crho[C];
+      open = rho > 0.0 && !cell_cleared(S, A.Cdir[C], A.Cdir[n_coarse + C], A.Cdir[2 * n_coarse + C], rho, G.r_coarse);
+    }
+    unsigned long long open_c = __ballot(open);
+    while (open_c && S.status == 0) {
+      const int32_t Cc = cb + static_cast<int32_t>(__builtin_ctzll(open_c));
+      open_c &= open_c - 1ull;
+      const int32_t fi = (Cc % G.cgw) * kHprCoarse + (l & 7), fj = (Cc / G.cgw) * kHprCoarse + (l >> 3);
+      bool fopen = false;
+      int32_t f = 0;
+      if (fi < G.gw && fj < G.gh) {
+        f = fj * G.gw + fi;
+        const double rho = A.crho[f];
+        fopen = rho > 0.0 && !cell_cleared(S, A.cdir[f], A.cdir[n_fine + f], A.cdir[2 * n_fine + f], rho, G.r_fine);
+      }
+      unsigned long long open_f = __ballot(fopen);
+      while (open_f && S.status == 0) {
+        const int src = static_cast<int>(__builtin_ctzll(open_f));
+        open_f &= open_f - 1ull;
+        const int32_t ff = __shfl(f, src, 64);
+        test_range(S, P, A, A.cstart[ff], A.cstart[ff + 1]);
+      }
+      if (S.changed) return;
+    }
+  }
+}
+
+// Runs the search from a box of half-width B.  kBrute: every pass tests all candidates (no cells).
+// Returns kSearchVisible (the last trial normal cleared every point; `uncertain_left` tells whether some only within
+// round-off), kSearchEmpty (cert_a / cert_b / cert_c), kSearchFail or kSearchHiddenDup.
+template <bool kBrute>
+__device__ __forceinline__ int run_search(Search &S, Polygon &P, const HprArrays &A, const HprGrid &G, double B,
+                                          int max_restarts, unsigned long long &restarts) {
+  polygon_box(P, B);
+  S.status = 0;
+  for (int it = 0; it < max_restarts; ++it) {
+    search_witness(S, P);
+    S.changed = false;
+    S.uncertain_left = false;
+    if (kBrute)
+      test_range(S, P, A, 0, G.m);
+    else
+      pass_hierarchy(S, P, A, G);
+    restarts += 1;
+    if (S.status != 0) return S.status;
+    if (!S.changed) return kSearchVisible;
+  }
+  return kSearchFail;
+}
+
+__device__ __forceinline__ Vec3d load_point(const HprArrays &A, int32_t k) { return {A.sx[k], A.sy[k], A.sz[k]}; }
+
+// p inside (or on) the tetrahedron (origin, a, b, c)?  Filtered signs: 1 yes, 0 cannot tell (or no).
+__device__ __forceinline__ int tetra_contains_filtered(const Vec3d &p, const Vec3d &a, const Vec3d &b, const Vec3d &c) {
+  const Vec3d o = {0.0, 0.0, 0.0};
+  const int s0 = orient3d_filtered(a, b, c, o), t0 = orient3d_filtered(a, b, c, p);
+  const int s1 = orient3d_filtered(o, b, c, a), t1 = orient3d_filtered(o, b, c, p);
+  const int s2 = orient3d_filtered(o, c, a, b), t2 = orient3d_filtered(o, c, a, p);
+  const int s3 = orient3d_filtered(o, a, b, c), t3 = orient3d_filtered(o, a, b, p);
+  return (s0 != 0 && s0 == t0 && s1 != 0 && s1 == t1 && s2 != 0 && s2 == t2 && s3 != 0 && s3 == t3) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------------------------
+
+// flipped points of the candidates (view_culling.cpp:291-292), their gnomonic coordinates, and the bounds of both
+__global__ __launch_bounds__(kHprBlock) void k_hpr_prepare(const float *__restrict__ x, const float *__restrict__ y,
+                                                           const float *__restrict__ z, DevFrame fr,
+                                                           const int32_t *__restrict__ index, int32_t m, double flip_radius,
+                                                           double *__restrict__ px, double *__restrict__ py,
+                                                           double *__restrict__ pz, double *__restrict__ ga,
+                                                           double *__restrict__ gb, double *__restrict__ rho,
+                                                           unsigned long long *__restrict__ bounds) {
+  const int32_t k = static_cast<int32_t>(blockIdx.x) * kHprBlock + static_cast<int32_t>(threadIdx.x);
+  unsigned long long amin = ~0ull, amax = 0ull, bmin = ~0ull, bmax = 0ull;
+  if (k < m) {
+    const int32_t i = index[k];
+    float xc, yc, zc;
+    xform(fr.w2c, x[i], y[i], z[i], xc, yc, zc);
+    // pt_norm = pt.head<3>().norm(); flipped = pt + 2.0 * (max_z - pt_norm) * pt / pt_norm, per coefficient
+    // x + ((2.0 * (R - norm)) * x) / norm on the promoted camera coordinates
+    const double X = xc, Y = yc, Z = zc;
+    const double norm = sqrt((X * X + Y * Y) + Z * Z);
+    const double s = 2.0 * (flip_radius - norm);
+    const double fx = X + (s * X) / norm, fy = Y + (s * Y) / norm, fz = Z + (s * Z) / norm;
+    px[k] = fx;
+    py[k] = fy;
+    pz[k] = fz;
+    const double a = fx / fz, b = fy / fz;
+    ga[k] = a;
+    gb[k] = b;
+    rho[k] = sqrt((fx * fx + fy * fy) + fz * fz) * (1.0 + 1.0e-15);  // an upper bound of the norm
+    amin = amax = order_key(a);
+    bmin = bmax = order_key(b);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    amin = min(amin, static_cast<unsigned long long>(__shfl_xor(static_cast<long long>(amin), o, 64)));
+    amax = max(amax, static_cast<unsigned long long>(__shfl_xor(static_cast<long long>(amax), o, 64)));
+    bmin = min(bmin, static_cast<unsigned long long>(__shfl_xor(static_cast<long long>(bmin), o, 64)));
+    bmax = max(bmax, static_cast<unsigned long long>(__shfl_xor(static_cast<long long>(bmax), o, 64)));
+  }
+  if (lane_id() == 0 && amax != 0ull) {
+    atomicMin(&bounds[0], amin);
+    atomicMax(&bounds[1], amax);
+    atomicMin(&bounds[2], bmin);
+    atomicMax(&bounds[3], bmax);
+  }
+}
+
+__device__ __forceinline__ int32_t hpr_cell_of(const HprGrid &G, double a, double b) {
+  const int32_t ci = min(G.gw - 1, max(0, static_cast<int32_t>((a - G.a0) * G.inv_h)));
+  const int32_t cj = min(G.gh - 1, max(0, static_cast<int32_t>((b - G.b0) * G.inv_h)));
+  return cj * G.gw + ci;
+}
+
+__global__ __launch_bounds__(kHprBlock) void k_hpr_count(const double *__restrict__ ga, const double *__restrict__ gb,
+                                                         HprGrid G, int32_t *__restrict__ cell, int32_t *__restrict__ count) {
+  const int32_t k = static_cast<int32_t>(blockIdx.x) * kHprBlock + static_cast<int32_t>(threadIdx.x);
+  if (k >= G.m) return;
+  const int32_t c = hpr_cell_of(G, ga[k], gb[k]);
+  cell[k] = c;
+  atomicAdd(&count[c], 1);
+}
+
+__global__ __launch_bounds__(kHprBlock) void k_hpr_scatter(const double *__restrict__ px, const double *__restrict__ py,
+                                                           const double *__restrict__ pz, const double *__restrict__ rho,
+                                                           const int32_t *__restrict__ index, const int32_t *__restrict__ cell,
+                                                           int32_t m, const int32_t *__restrict__ cstart,
+                                                           int32_t *__restrict__ cursor, double *__restrict__ sx,
+                                                           double *__restrict__ sy, double *__restrict__ sz,
+                                                           int32_t *__restrict__ sidx, int32_t *__restrict__ scell,
+                                                           int32_t *__restrict__ scand, unsigned long long *__restrict__ crho_bits) {
+  const int32_t k = static_cast<int32_t>(blockIdx.x) * kHprBlock + static_cast<int32_t>(threadIdx.x);
+  if (k >= m) return;
+  const int32_t c = cell[k];
+  const int32_t pos = cstart[c] + atomicAdd(&cursor[c], 1);
+  sx[pos] = px[k];
+  sy[pos] = py[k];
+  sz[pos] = pz[k];
+  sidx[pos] = index[k];
+  scell[pos] = c;
+  scand[pos] = k;
+  atomicMax(&crho_bits[c], static_cast<unsigned long long>(__double_as_longlong(rho[k])));  // positive doubles order as integers
+}
+
+// centre directions of the fine cells; coarse cells: centre direction and the largest rho of their fine cells
+__global__ __launch_bounds__(kHprBlock) void k_hpr_cells(HprGrid G, const unsigned long long *__restrict__ crho_bits,
+                                                         double *__restrict__ cdir, double *__restrict__ Crho,
+                                                         double *__restrict__ Cdir) {
+  const int32_t t = static_cast<int32_t>(blockIdx.x) * kHprBlock + static_cast<int32_t>(threadIdx.x);
+  const int32_t n_fine = G.gw * G.gh, n_coarse = G.cgw * G.cgh;
+  if (t < n_fine) {
+    const double a = G.a0 + (static_cast<double>(t % G.gw) + 0.5) * G.h, b = G.b0 + (static_cast<double>(t / G.gw) + 0.5) * G.h;
+    const double inv = 1.0 / sqrt((a * a + b * b) + 1.0);
+    cdir[t] = a * inv;
+    cdir[n_fine + t] = b * inv;
+    cdir[2 * n_fine + t] = inv;
+  }
+  if (t < n_coarse) {
+    const int32_t Ci = t % G.cgw, Cj = t / G.cgw;
+    unsigned long long best = 0ull;
+    for (int dj = 0; dj < kHprCoarse; ++dj)
+      for (int di = 0; di < kHprCoarse; ++di) {
+        const int32_t fi = Ci * kHprCoarse + di, fj = Cj * kHprCoarse + dj;
+        if (fi < G.gw && fj < G.gh) best = max(best, crho_bits[fj * G.gw + fi]);
+      }
+    Crho[t] = __longlong_as_double(static_cast<long long>(best));
+    const double a = G.a0 + (static_cast<double>(Ci) + 0.5) * (G.h * kHprCoarse);
+    const double b = G.b0 + (static_cast<double>(Cj) + 0.5) * (G.h * kHprCoarse);
+    const double inv = 1.0 / sqrt((a * a + b * b) + 1.0);
+    Cdir[t] = a * inv;
+    Cdir[n_coarse + t] = b * inv;
+    Cdir[2 * n_coarse + t] = inv;
+  }
+}
+
+// stats: [0] hidden [1] visible [2] undecided [3] trial normals [4] batches of 64 point tests [5] second-box retries
+// [6] unresolved [7] exact predicate evaluations [8] length of the list for k_hpr_exact
+__global__ __launch_bounds__(kHprBlock) void k_hpr_decide(HprArrays A, HprGrid G, uint8_t *__restrict__ state,
+                                                          int32_t *__restrict__ undecided,
+                                                          unsigned long long *__restrict__ stats, int32_t force_exact) {
+  const int32_t j = static_cast<int32_t>(blockIdx.x) * (kHprBlock / 64) + static_cast<int32_t>(threadIdx.x >> 6);
+  if (j >= G.m) return;
+  Search S;
+  S.p = load_point(A, j);
+  S.self = j;
+  S.self_idx = A.sidx[j];
+  S.tests = 0;
+  search_frame(S);
+  Polygon P;
+  unsigned long long restarts = 0;
+  int32_t out = kStUndecided;
+  int retries = 0;
+  if (!force_exact) {
+    // a box of +-1/16 rad holds the trial normals of every visible point that is not within a hundredth of a pixel of a
+    // much nearer one; the few that need more take the second box
+    int r = run_search<false>(S, P, A, G, 0.0625, kHprMaxRestarts, restarts);
+    const bool box_hit = r == kSearchEmpty && (S.cert_a < 0 || S.cert_b < 0);
+    if (box_hit || r == kSearchFail) {
+      retries = 1;
+      r = run_search<false>(S, P, A, G, 16.0, kHprMaxRestarts, restarts);
+    }
+    int why = 0;
+    if (r == kSearchHiddenDup) {
+      out = kStHidden;
+    } else if (r == kSearchVisible) {
+      if (!S.uncertain_left) out = kStVisible; else why = 10;
+    } else if (r == kSearchEmpty && S.cert_a >= 0 && S.cert_b >= 0) {
+      if (tetra_contains_filtered(S.p, load_point(A, S.cert_a), load_point(A, S.cert_b), load_point(A, S.cert_c)))
+        out = kStHidden;
+      else why = 11;
+    } else if (r == kSearchEmpty) why = 12; else why = 13;
+    if (why && lane_id() == 0) atomicAdd(&stats[why], 1ull);
+  }
+  if (lane_id() == 0) {
+    state[j] = static_cast<uint8_t>(out);
+    atomicAdd(&stats[out], 1ull);
+    if (out == kStUndecided) undecided[atomicAdd(&stats[8], 1ull)] = j;
+    atomicAdd(&stats[3], restarts);
+    atomicAdd(&stats[4], S.tests);
+    if (retries) atomicAdd(&stats[5], 1ull);
+  }
+}
+
+// ---- the exact path ----
+
+// all of S strictly on the origin's side of the plane (p, a, b)?  (then p, a, b span a facet of the hull: p is a vertex)
+__device__ inline bool plane_supports(const Search &S, const HprArrays &A, int32_t m, int32_t ia, int32_t ib, int *n_exact) {
+  const Vec3d o = {0.0, 0.0, 0.0};
+  const Vec3d a = load_point(A, ia), b = load_point(A, ib);
+  const int so = orient3d_sign(S.p, a, b, o, n_exact);
+  if (so == 0) return false;
+  const int l = lane_id();
+  for (int32_t base = 0; base < m; base += 64) {
+    const int32_t k = base + l;
+    bool ok = true;
+    if (k < m && k != S.self && k != ia && k != ib) {
+      const Vec3d q = load_point(A, k);
+      const bool same_p = q.x == S.p.x && q.y == S.p.y && q.z == S.p.z;  // a duplicate the duplicate rule lets p stand for
+      const bool same_ab = (q.x == a.x && q.y == a.y && q.z == a.z) || (q.x == b.x && q.y == b.y && q.z == b.z);
+      if (!same_p && !same_ab) ok = orient3d_sign(S.p, a, b, q, n_exact) == so;
+    }
+    if (__ballot(!ok)) return false;
+  }
+  return true;
+}
+
+// p in the closed tetrahedron (origin, a, b, c), the tetrahedron not flat
+__device__ inline bool tetra_contains_exact(const Vec3d &p, const Vec3d &a, const Vec3d &b, const Vec3d &c, int *n_exact) {
+  const Vec3d o = {0.0, 0.0, 0.0};
+  const int s0 = orient3d_sign(a, b, c, o, n_exact);
+  if (s0 == 0) return false;
+  const int t0 = orient3d_sign(a, b, c, p, n_exact);
+  if (t0 != 0 && t0 != s0) return false;
+  const int s1 = orient3d_sign(o, b, c, a, n_exact), t1 = orient3d_sign(o, b, c, p, n_exact);
+  if (s1 == 0 || (t1 != 0 && t1 != s1)) return false;
+  const int s2 = orient3d_sign(o, c, a, b, n_exact), t2 = orient3d_sign(o, c, a, p, n_exact);
+  if (s2 == 0 || (t2 != 0 && t2 != s2)) return false;
+  const int s3 = orient3d_sign(o, a, b, c, n_exact), t3 = orient3d_sign(o, a, b, p, n_exact);
+  if (s3 == 0 || (t3 != 0 && t3 != s3)) return false;
+  return true;
+}
+
+constexpr int kHprExactIds = 16;
+
+__global__ __launch_bounds__(64) void k_hpr_exact(HprArrays A, HprGrid G, const int32_t *__restrict__ undecided,
+                                                  int32_t n_undecided, uint8_t *__restrict__ state,
+                                                  unsigned long long *__restrict__ stats) {
+  const int32_t u = static_cast<int32_t>(blockIdx.x);
+  if (u >= n_undecided) return;
+  __shared__ int32_t ids[kHprExactIds];
+  const int32_t j = undecided[u];
+  const int l = lane_id();
+  Search S;
+  S.p = load_point(A, j);
+  S.self = j;
+  S.self_idx = A.sidx[j];
+  S.tests = 0;
+  search_frame(S);
+  Polygon P;
+  unsigned long long restarts = 0;
+  int n_exact = 0;
+  int32_t out = -1;
+  // the search again, over every candidate, from a box that holds any plane tilted less than 89.9 degrees
+  const int r = run_search<true>(S, P, A, G, 1024.0, 4 * kHprMaxRestarts, restarts);
+  int n_ids = 0;
+  if (r == kSearchHiddenDup) {
+    out = kStHidden;
+  } else {
+    // the constraints that bound what is left of the polygon (and, when nothing is left, the three that emptied it)
+    if (r == kSearchEmpty) {
+      if (l == 0) {
+        ids[0] = S.cert_c;
+        ids[1] = S.cert_a;
+        ids[2] = S.cert_b;
+      }
+      n_ids = 3;
+    }
+    __syncthreads();
+    for (int i = 0; i < P.nv && n_ids < kHprExactIds; ++i) {
+      const int32_t e = __shfl(P.eid, i, 64);
+      bool seen = false;
+      for (int t = 0; t < n_ids; ++t) seen = seen || ids[t] == e;
+      if (!seen) {
+        if (l == 0) ids[n_ids] = e;
+        ++n_ids;
+      }
+      __syncthreads();
+    }
+    if (r == kSearchVisible || r == kSearchFail) {
+      // a facet of the hull at p: the planes through p and two constraints that meet in a vertex of the polygon
+      for (int i = 0; i < P.nv && out < 0; ++i) {
+        const int32_t ea = __shfl(P.eid, (i + P.nv - 1) % P.nv, 64), eb = __shfl(P.eid, i, 64);
+        if (ea >= 0 && eb >= 0 && ea != eb && plane_supports(S, A, G.m, ea, eb, &n_exact)) out = kStVisible;
+      }
+    }
+    if (out < 0) {
+      // a simplex (origin, a, b, c) around p, among the binding constraints: triples dealt out over the lanes
+      int found = 0;
+      int t = 0;
+      for (int ia = 0; ia < n_ids; ++ia)
+        for (int ib = ia + 1; ib < n_ids; ++ib)
+          for (int ic = ib + 1; ic < n_ids; ++ic, ++t) {
+            if ((t & 63) != l || found) continue;
+            const int32_t a = ids[ia], b = ids[ib], c = ids[ic];
+            if (a < 0 || b < 0 || c < 0) continue;
+            if (tetra_contains_exact(S.p, load_point(A, a), load_point(A, b), load_point(A, c), &n_exact)) found = 1;
+          }
+      if (__ballot(found)) out = kStHidden;
+    }
+    if (out < 0 && r == kSearchEmpty) {
+      // the polygon emptied in floating point but no simplex holds p: any pair of binding constraints as a facet
+      for (int ia = 0; ia < n_ids && out < 0; ++ia)
+        for (int ib = ia + 1; ib < n_ids && out < 0; ++ib)
+          if (ids[ia] >= 0 && ids[ib] >= 0 && plane_supports(S, A, G.m, ids[ia], ids[ib], &n_exact)) out = kStVisible;
+    }
+  }
+  const unsigned long long exact_total = static_cast<unsigned long long>(wave_sum(static_cast<double>(n_exact)));
+  if (l == 0) {
+    if (out < 0) {
+      atomicAdd(&stats[6], 1ull);  // unresolved: classified hidden (file header)
+      out = kStHidden;
+    }
+    state[j] = static_cast<uint8_t>(out);
+    atomicAdd(&stats[out], 1ull);
+    atomicAdd(&stats[3], restarts);
+    atomicAdd(&stats[4], S.tests);
+    atomicAdd(&stats[7], exact_total);
+  }
+}
+
+// keep flags (input order): the candidate flags become the visible flags
+__global__ __launch_bounds__(kHprBlock) void k_hpr_writeback(const uint8_t *__restrict__ state, const int32_t *__restrict__ sidx,
+                                                             int32_t m, uint8_t *__restrict__ keep) {
+  const int32_t k = static_cast<int32_t>(blockIdx.x) * kHprBlock + static_cast<int32_t>(threadIdx.x);
+  if (k < m) keep[sidx[k]] = state[k] == kStVisible ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host
+// ------------------------------------------------------------------------------------------------------------------
+static inline uint32_t hpr_blocks(int64_t n) { return static_cast<uint32_t>(std::max<int64_t>(1, div_up(n, kHprBlock))); }
+
+static int hpr_scan(pcp_context *ctx, int32_t *counts, int64_t entries) {
+  const int64_t tiles = div_up(entries, kScanTile);
+  PCP_HIP_TRY(ctx, ctx->s_tiles.ensure(static_cast<size_t>(tiles) + 4));
+  hipLaunchKernelGGL(k_scan_tile_sums, dim3(static_cast<uint32_t>(tiles)), dim3(kScanBlock), 0, ctx->stream, counts, entries,
+                     ctx->s_tiles.p);
+  hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kScanBlock), 0, ctx->stream, ctx->s_tiles.p, tiles,
+                     static_cast<unsigned long long *>(nullptr));
+  hipLaunchKernelGGL(k_scan_apply, dim3(static_cast<uint32_t>(tiles)), dim3(kScanBlock), 0, ctx->stream, counts, entries,
+                     ctx->s_tiles.p, counts);
+  PCP_HIP_TRY(ctx, hipGetLastError());
+  return PCP_OK;
+}
+
+// Turns the candidate flags of one keyframe (input order, n bytes on the device: 1 = passes the filter of
+// view_culling.cpp:276-288) into the flags of hidden_points_removal's output: 1 = hull vertex.
+int hpr_refine_flags(pcp_context *ctx, int32_t frame, uint8_t *d_flags) {
+  const int64_t n = ctx->n;
+  if (n == 0) return PCP_OK;
+  const size_t plane = (static_cast<size_t>(n) + 3) & ~size_t(3);
+  PCP_HIP_TRY(ctx, ctx->h_index.ensure(static_cast<size_t>(n) + 4));
+  int64_t m64 = 0;
+  int rc = compact_flags(ctx, d_flags, n, ctx->h_index.p, n, &m64);
+  if (rc != PCP_OK) return rc;
+  std::memset(ctx->hpr_stats, 0, sizeof(ctx->hpr_stats));
+  ctx->hpr_stats[9] = m64;
+  if (m64 < 3) {
+    // qhull needs dim + 1 points (here: three candidates and the origin); with fewer it fails and the reference
+    // returns no visible point (view_culling.cpp:307-312)
+    PCP_HIP_TRY(ctx, hipMemsetAsync(d_flags, 0, static_cast<size_t>(n), ctx->stream));
+    return PCP_OK;
+  }
+  const int32_t m = static_cast<int32_t>(m64);
+  const size_t sm = static_cast<size_t>(m);
+  // doubles: px py pz ga gb rho | sx sy sz
+  PCP_HIP_TRY(ctx, ctx->h_f64.ensure(9 * sm + 16));
+  double *px = ctx->h_f64.p, *py = px + sm, *pz = py + sm, *ga = pz + sm, *gb = ga + sm, *rho = gb + sm;
+  double *sx = rho + sm, *sy = sx + sm, *sz = sy + sm;
+  // ints: cell | sidx scell scand | undecided
+  PCP_HIP_TRY(ctx, ctx->h_i32.ensure(5 * sm + 16));
+  int32_t *cell = ctx->h_i32.p, *sidx = cell + sm, *scell = sidx + sm, *scand = scell + sm, *undecided = scand + sm;
+  PCP_HIP_TRY(ctx, ctx->h_state.ensure(sm + 16));
+  PCP_HIP_TRY(ctx, ctx->h_stats.ensure(32));
+  unsigned long long *bounds = ctx->h_stats.p + 16, *stats = ctx->h_stats.p;
+  {
+    const unsigned long long init[4] = {~0ull, 0ull, ~0ull, 0ull};
+    PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->h_stats.p, 0, 32 * sizeof(unsigned long long), ctx->stream));
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(bounds, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+  }
+  const DevFrame &fr = ctx->hframes[static_cast<size_t>(frame)];
+  {
+    LaunchTimer t(ctx, PCP_K_HPR);
+    hipLaunchKernelGGL(k_hpr_prepare, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, ctx->stream, ctx->xyz.p, ctx->xyz.p + plane,
+                       ctx->xyz.p + 2 * plane, fr, ctx->h_index.p, m, ctx->cull.hpr_flip_radius, px, py, pz, ga, gb, rho,
+                       bounds);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  unsigned long long hb[4];
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(hb, bounds, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const double amin = key_to_double(hb[0]), amax = key_to_double(hb[1]), bmin = key_to_double(hb[2]), bmax = key_to_double(hb[3]);
+  if (!(std::isfinite(amin) && std::isfinite(amax) && std::isfinite(bmin) && std::isfinite(bmax)))
+    return set_error(ctx, PCP_ERR_INVALID, "hidden_points_removal: non-finite flipped coordinates (flip radius %g)",
+                     ctx->cull.hpr_flip_radius);
+  HprGrid G{};
+  G.m = m;
+  G.a0 = amin;
+  G.b0 = bmin;
+  {
+    const double wa = amax - amin, wb = bmax - bmin;
+    double h = std::sqrt(kHprTargetPerCell * std::max(wa, 1e-12) * std::max(wb, 1e-12) / static_cast<double>(m));
+    h = std::max(h, std::max(wa, wb) * 1e-6);
+    h = std::max(h, 1e-9);
+    for (;;) {
+      G.gw = static_cast<int32_t>(std::min(wa / h, 1e9)) + 1;
+      G.gh = static_cast<int32_t>(std::min(wb / h, 1e9)) + 1;
+      if (static_cast<int64_t>(G.gw) * G.gh <= kHprMaxCells) break;
+      h *= 1.5;
+    }
+    G.h = h;
+    G.inv_h = 1.0 / h;
+    G.cgw = (G.gw + kHprCoarse - 1) / kHprCoarse;
+    G.cgh = (G.gh + kHprCoarse - 1) / kHprCoarse;
+    // the gnomonic plane z = 1 projects onto the unit sphere without stretching any distance, so half a cell diagonal
+    // bounds the chord from the centre direction; the slack covers a coordinate that rounding put on a cell's edge
+    G.r_fine = 0.5 * h * std::sqrt(2.0) * (1.0 + 1e-9) + 1e-12;
+    G.r_coarse = 0.5 * h * kHprCoarse * std::sqrt(2.0) * (1.0 + 1e-9) + 1e-12;
+  }
+  const int64_t n_fine = static_cast<int64_t>(G.gw) * G.gh, n_coarse = static_cast<int64_t>(G.cgw) * G.cgh;
+  // per cell: count / start (n_fine + 1), cursor (n_fine); rho bits (n_fine), centre directions, coarse rho / directions
+  PCP_HIP_TRY(ctx, ctx->h_cells_i.ensure(static_cast<size_t>(2 * n_fine) + 16));
+  PCP_HIP_TRY(ctx, ctx->h_cells_d.ensure(static_cast<size_t>(4 * n_fine + 4 * n_coarse) + 16));
+  int32_t *cstart = ctx->h_cells_i.p, *cursor = cstart + n_fine + 2;
+  double *crho = ctx->h_cells_d.p, *cdir = crho + n_fine, *Crho = cdir + 3 * n_fine, *Cdir = Crho + n_coarse;
+  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->h_cells_i.p, 0, (static_cast<size_t>(2 * n_fine) + 16) * sizeof(int32_t), ctx->stream));
+  PCP_HIP_TRY(ctx, hipMemsetAsync(crho, 0, static_cast<size_t>(n_fine) * sizeof(double), ctx->stream));
+  HprArrays A{sx, sy, sz, sidx, scell, cstart, crho, cdir, Crho, Cdir};
+  // PCP_HPR_FORCE_EXACT=1 (tests): every candidate takes the exact path; read per call
+  const char *fe = std::getenv("PCP_HPR_FORCE_EXACT");
+  const bool force_exact = fe && fe[0] == '1';
+  {
+    LaunchTimer t(ctx, PCP_K_HPR);
+    hipLaunchKernelGGL(k_hpr_count, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, ctx->stream, ga, gb, G, cell, cstart);
+    if ((rc = hpr_scan(ctx, cstart, n_fine + 1)) != PCP_OK) return rc;
+    hipLaunchKernelGGL(k_hpr_scatter, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, ctx->stream, px, py, pz, rho, ctx->h_index.p,
+                       cell, m, cstart, cursor, sx, sy, sz, sidx, scell, scand,
+                       reinterpret_cast<unsigned long long *>(crho));
+    hipLaunchKernelGGL(k_hpr_cells, dim3(hpr_blocks(std::max(n_fine, n_coarse))), dim3(kHprBlock), 0, ctx->stream, G,
+                       reinterpret_cast<const unsigned long long *>(crho), cdir, Crho, Cdir);
+    hipLaunchKernelGGL(k_hpr_decide, dim3(static_cast<uint32_t>(div_up(m, kHprBlock / 64))), dim3(kHprBlock), 0, ctx->stream,
+                       A, G, ctx->h_state.p, undecided, stats, force_exact ? 1 : 0);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  unsigned long long hs[9];
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(hs, stats, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const int64_t n_und = static_cast<int64_t>(hs[8]);
+  if (n_und > 0) {
+    LaunchTimer t(ctx, PCP_K_HPR);
+    hipLaunchKernelGGL(k_hpr_exact, dim3(static_cast<uint32_t>(n_und)), dim3(64), 0, ctx->stream, A, G, undecided,
+                       static_cast<int32_t>(n_und), ctx->h_state.p, stats);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(hs, stats, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
+    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  {
+    LaunchTimer t(ctx, PCP_K_HPR);
+    hipLaunchKernelGGL(k_hpr_writeback, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, ctx->stream, ctx->h_state.p, sidx, m, d_flags);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  // visible / hidden as finally classified (the exact path moved its points out of "undecided")
+  ctx->hpr_stats[0] = static_cast<int64_t>(hs[1]);           // visible
+  ctx->hpr_stats[1] = static_cast<int64_t>(hs[0]);           // hidden
+  ctx->hpr_stats[2] = n_und;                                 // sent to the exact path
+  ctx->hpr_stats[3] = static_cast<int64_t>(hs[3]);
+  ctx->hpr_stats[4] = static_cast<int64_t>(hs[4]);
+  ctx->hpr_stats[5] = static_cast<int64_t>(hs[5]);
+  ctx->hpr_stats[6] = static_cast<int64_t>(hs[6]);
+  ctx->hpr_stats[7] = static_cast<int64_t>(hs[7]);
+  ctx->hpr_stats[8] = n_fine;
+  if (std::getenv("PCP_HPR_DEBUG")) {
+    unsigned long long dbg[16];
+    (void)hipMemcpy(dbg, stats, sizeof(dbg), hipMemcpyDeviceToHost);
+    fprintf(stderr, "hpr debug: uncertain_left %llu tetra_filter %llu box_cert %llu fail %llu\n", dbg[10], dbg[11], dbg[12], dbg[13]);
+  }
+  return PCP_OK;
+}
+
+}  // namespace pcp
+
+using namespace pcp;
+
+extern "C" {
+
+int pcp_hpr_stats(pcp_context *ctx, int64_t out[10]) {
+  if (!ctx || !out) return PCP_ERR_INVALID;
+  for (int i = 0; i < 10; ++i) out[i] = ctx->hpr_stats[i];
+  return PCP_OK;
+}
+
+}  // extern "C"

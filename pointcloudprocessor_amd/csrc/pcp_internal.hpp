@@ -31,7 +31,8 @@ struct DevCamera {
   int32_t cull_w, cull_h;
   int32_t mw, mh;  // cull_w/ds, cull_h/ds
   int32_t enable_zbuf;
-  int32_t cull_mode;   // PCP_CULL_ZBUFFER / PCP_CULL_HPR_CANDIDATES (enable_zbuf is 0 with the latter)
+  int32_t cull_mode;   // PCP_CULL_ZBUFFER / PCP_CULL_HPR_CANDIDATES (enable_zbuf is 0 with the latter; PCP_CULL_HPR runs
+                       // the candidate filter here and the hull in pcp_hpr.hip)
   int32_t match_mode;  // PCP_MATCH_IDENTITY / PCP_MATCH_ROUNDTRIP
   double cull_wd, cull_hd;  // cull size as fp64: bounds of hidden_points_removal's (int)u, (int)v rule
   float match_r2;      // f32(1e-5 * 1e-5): radiusSearch(epsilon) squared radius, PointCloudProcessor.cpp:482,571
@@ -185,6 +186,13 @@ struct pcp_context {
   pcp::DevBuf<unsigned long long> s_counter;
   pcp::DevBuf<int32_t> s_tiles;
 
+  // hidden_points_removal (pcp_hpr.hip): candidate list, flipped points (candidate and cell order), cells, states
+  pcp::DevBuf<int32_t> h_index, h_i32, h_cells_i;
+  pcp::DevBuf<double> h_f64, h_cells_d;
+  pcp::DevBuf<uint8_t> h_state;
+  pcp::DevBuf<unsigned long long> h_stats;
+  int64_t hpr_stats[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
   // MLS: uniform grid (cell id / in-cell rank per point, cell starts, cell-sorted
   // order + coordinates), per-input-point results, compacted outputs
   pcp::DevBuf<int32_t> g_cell, g_rank, g_start, g_order;
@@ -264,6 +272,10 @@ int compact_flags(pcp_context *ctx, const uint8_t *flags, int64_t n, int32_t *ou
 
 // ViewCulling::cull of one keyframe on the device: ordered index list of kept points (pcp_colour.hip)
 int cull_frame_indices(pcp_context *ctx, int32_t frame, int32_t *d_index, int64_t capacity, int64_t *count);
+
+// hidden_points_removal's hull over the candidate flags of one keyframe (pcp_hpr.hip): flags (input order, device)
+// in: 1 = candidate; out: 1 = hull vertex
+int hpr_refine_flags(pcp_context *ctx, int32_t frame, uint8_t *d_flags);
 
 inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
