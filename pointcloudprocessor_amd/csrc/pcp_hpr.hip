@@ -54,6 +54,7 @@ constexpr int kHprCoarse = 8;           // fine cells per coarse cell edge: 64 f
 constexpr double kHprTargetPerCell = 8.0;
 constexpr int64_t kHprMaxCells = int64_t(1) << 22;
 constexpr int kHprMaxRestarts = 96;
+constexpr double kHprBox = 1073741824.0;  // half-width of the initial box of trial normals (2^30 rad of tilt)
 constexpr double kPointSlack = 1.0e-15;  // |fl(n . (q - p)) - exact| <= 4.44e-16 sum |n_i (q_i - p_i)| (see test_range)
 
 enum : int32_t { kStHidden = 0, kStVisible = 1, kStUndecided = 2 };
@@ -93,6 +94,12 @@ __device__ __forceinline__ double wave_min(double v) {
   return v;
 }
 
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
 __device__ __forceinline__ unsigned long long order_key(double d) {
   const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(d));
   return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
@@ -111,17 +118,31 @@ inline double key_to_double(unsigned long long k) {
 // ------------------------------------------------------------------------------------------------------------------
 struct Polygon {
   double vx, vy;
+  double lx, ly, le;  // the line of the edge from this vertex to the next: s . (lx, ly) = le, inside <=
   int32_t eid;
   int nv;  // wave-uniform
 };
 
 __device__ __forceinline__ void polygon_box(Polygon &P, double B) {
   const int l = lane_id();
-  // counter-clockwise square; edge ids -1 .. -4
+  // counter-clockwise square; edge ids -1 .. -4: top, left, bottom, right
   P.vx = (l == 0 || l == 3) ? B : -B;
   P.vy = (l == 0 || l == 1) ? B : -B;
+  P.lx = l == 1 ? -1.0 : (l == 3 ? 1.0 : 0.0);
+  P.ly = l == 0 ? 1.0 : (l == 2 ? -1.0 : 0.0);
+  P.le = B;
   P.eid = -1 - l;
   P.nv = 4;
+}
+
+// where the lines s . (ax, ay) = ae and s . (bx, by) = be meet; false when they are parallel in floating point
+__device__ __forceinline__ bool line_meet(double ax, double ay, double ae, double bx, double by, double be, double &x,
+                                          double &y) {
+  const double det = ax * by - ay * bx;
+  if (det == 0.0) return false;
+  x = (ae * by - ay * be) / det;
+  y = (ax * be - ae * bx) / det;
+  return isfinite(x) && isfinite(y);
 }
 
 // Clip with s . D <= E.  0: nothing cut, 1: cut, 2: nothing left (cert_a / cert_b = the two constraints that meet in
@@ -132,9 +153,17 @@ __device__ __forceinline__ int polygon_clip(Polygon &P, double Dx, double Dy, do
   const int l = lane_id();
   const int nv = P.nv;
   const bool valid = l < nv;
-  const double val = valid ? (Dx * P.vx + Dy * P.vy) - E : 0.0;
+  const double ax = Dx * P.vx, ay = Dy * P.vy;
+  const double val = valid ? (ax + ay) - E : 0.0;
+  // a vertex within the rounding of its own evaluation counts as inside: a vertex this very half-plane created
+  // earlier must not be cut again (the clip would never settle)
+  const double tol = 4.0e-16 * ((fabs(ax) + fabs(ay)) + fabs(E));
   const unsigned long long m_valid = nv >= 64 ? ~0ull : ((1ull << nv) - 1ull);
-  const unsigned long long m_in = __ballot(valid && val <= 0.0) & m_valid;
+  // ... and so does a vertex that lies on this half-plane's own line by construction (an end of an edge it made
+  // earlier), however ill-conditioned the intersection that placed it
+  const int32_t eid_prev = __shfl(P.eid, (l + nv - 1) % nv, 64);
+  const bool own = P.eid == id || eid_prev == id;
+  const unsigned long long m_in = __ballot(valid && (val <= tol || own)) & m_valid;
   if (m_in == m_valid) return 0;
   if (m_in == 0ull) {
     const double best = wave_min(valid ? val : INFINITY);
@@ -145,7 +174,7 @@ __device__ __forceinline__ int polygon_clip(Polygon &P, double Dx, double Dy, do
     return 2;
   }
   const int cnt = __popcll(m_in);
-  if (cnt + 2 > 64) return 3;
+  if (cnt + 2 > 64) return 4;
   const unsigned long long prev = ((m_in << 1) | (m_in >> (nv - 1))) & m_valid;  // bit i = inside(i - 1)
   const unsigned long long starts = m_in & ~prev;
   if (__popcll(starts) != 1) return 3;
@@ -156,24 +185,46 @@ __device__ __forceinline__ int polygon_clip(Polygon &P, double Dx, double Dy, do
   const double va0x = __shfl(P.vx, a0, 64), va0y = __shfl(P.vy, a0, 64), vala0 = __shfl(val, a0, 64);
   const double vax = __shfl(P.vx, a, 64), vay = __shfl(P.vy, a, 64), vala = __shfl(val, a, 64);
   const int32_t eid_a0 = __shfl(P.eid, a0, 64);
-  const double t1 = valb / (valb - valb1);  // valb <= 0 < valb1
-  const double x1x = vbx + t1 * (vb1x - vbx), x1y = vby + t1 * (vb1y - vby);
-  const double t2 = vala0 / (vala0 - vala);  // vala <= 0 < vala0
-  const double x2x = va0x + t2 * (vax - va0x), x2y = va0y + t2 * (vay - va0y);
+  // The new vertices are where the half-plane's line meets the lines of the two edges it crosses -- from the LINES, not
+  // by interpolating between the edges' end points: an edge of the initial box is 2^31 long, and a point near s = 0
+  // interpolated between end points that far apart is only good to 1e-7.
+  const double lbx = __shfl(P.lx, b, 64), lby = __shfl(P.ly, b, 64), lbe = __shfl(P.le, b, 64);
+  const double l0x = __shfl(P.lx, a0, 64), l0y = __shfl(P.ly, a0, 64), l0e = __shfl(P.le, a0, 64);
+  double x1x, x1y, x2x, x2y;
+  if (!line_meet(lbx, lby, lbe, Dx, Dy, E, x1x, x1y)) {
+    const double t1 = fmin(fmax(valb / (valb - valb1), 0.0), 1.0);  // valb <= tol < valb1
+    x1x = vbx + t1 * (vb1x - vbx);
+    x1y = vby + t1 * (vb1y - vby);
+  }
+  if (!line_meet(l0x, l0y, l0e, Dx, Dy, E, x2x, x2y)) {
+    const double t2 = fmin(fmax(vala0 / (vala0 - vala), 0.0), 1.0);  // vala <= tol < vala0
+    x2x = va0x + t2 * (vax - va0x);
+    x2y = va0y + t2 * (vay - va0y);
+  }
   const int src = (a + l) % nv;
   double nvx = __shfl(P.vx, src, 64), nvy = __shfl(P.vy, src, 64);
   int32_t neid = __shfl(P.eid, src, 64);
+  double nlx = __shfl(P.lx, src, 64), nly = __shfl(P.ly, src, 64), nle = __shfl(P.le, src, 64);
   if (l == cnt) {
     nvx = x1x;
     nvy = x1y;
     neid = id;
+    nlx = Dx;
+    nly = Dy;
+    nle = E;
   } else if (l == cnt + 1) {
     nvx = x2x;
     nvy = x2y;
     neid = eid_a0;
+    nlx = l0x;
+    nly = l0y;
+    nle = l0e;
   }
   P.vx = nvx;
   P.vy = nvy;
+  P.lx = nlx;
+  P.ly = nly;
+  P.le = nle;
   P.eid = neid;
   P.nv = cnt + 2;
   return 1;
@@ -194,6 +245,7 @@ struct Search {
   bool changed, uncertain_left;
   int32_t cert_a, cert_b, cert_c;
   int status;  // 0 running, kSearchEmpty, kSearchFail, kSearchHiddenDup
+  int fail_code;
   unsigned long long tests;
 };
 
@@ -207,10 +259,39 @@ __device__ __forceinline__ void search_frame(Search &S) {
   S.e2 = {S.e0.y * S.e1.z - S.e0.z * S.e1.y, S.e0.z * S.e1.x - S.e0.x * S.e1.z, S.e0.x * S.e1.y - S.e0.y * S.e1.x};
 }
 
-// trial normal from the polygon's vertex mean (a point strictly inside it)
+// Trial normal: the point of the polygon nearest to s = 0 (the least tilted plane the constraints so far allow), moved
+// up to kNudge into the polygon so that it is strictly inside.  Least tilt keeps the trial plane nearly tangent to the
+// sphere of flipped points, which is what keeps the set of points that can reach it small (file header, "Locality"),
+// whatever the size of the initial box.
+constexpr double kNudge = 1.0e-6;
+
 __device__ __forceinline__ void search_witness(Search &S, const Polygon &P) {
-  const bool valid = lane_id() < P.nv;
-  const double sx = wave_sum(valid ? P.vx : 0.0) / P.nv, sy = wave_sum(valid ? P.vy : 0.0) / P.nv;
+  const int l = lane_id();
+  const bool valid = l < P.nv;
+  const int nxt = (l + 1 < P.nv) ? l + 1 : 0;
+  const double wx = __shfl(P.vx, nxt, 64), wy = __shfl(P.vy, nxt, 64);
+  const double ex = wx - P.vx, ey = wy - P.vy;
+  const double l2 = ex * ex + ey * ey;
+  double t = l2 > 0.0 ? -(P.vx * ex + P.vy * ey) / l2 : 0.0;
+  t = fmin(fmax(t, 0.0), 1.0);
+  const double cx = P.vx + t * ex, cy = P.vy + t * ey;
+  const double d2 = valid ? cx * cx + cy * cy : INFINITY;
+  const double dmin2 = wave_min(d2);
+  // counter-clockwise polygon: s = 0 is inside iff it is to the left of every edge
+  const bool inside = !__ballot(valid && !(P.vx * wy - P.vy * wx > 0.0));
+  double sx = 0.0, sy = 0.0;
+  if (!(inside && dmin2 > kNudge * kNudge)) {
+    // b = the boundary point nearest to s = 0.  Every vertex pulled in to within kNudge of b stays on its segment
+    // from b, hence in the polygon, and so does their mean: a point of the polygon next to b whose direction from b
+    // does not depend on how far away the far vertices (the initial box) are.
+    const int src = static_cast<int>(__builtin_ctzll(__ballot(valid && d2 == dmin2)));
+    const double bx = __shfl(cx, src, 64), by = __shfl(cy, src, 64);
+    const double gx = P.vx - bx, gy = P.vy - by;
+    const double len = sqrt(gx * gx + gy * gy);
+    const double f = len > kNudge ? kNudge / len : 1.0;
+    sx = bx + wave_sum(valid ? f * gx : 0.0) / P.nv;
+    sy = by + wave_sum(valid ? f * gy : 0.0) / P.nv;
+  }
   S.n = {S.e0.x + (sx * S.e1.x + sy * S.e2.x), S.e0.y + (sx * S.e1.y + sy * S.e2.y), S.e0.z + (sx * S.e1.z + sy * S.e2.z)};
   const double nn = sqrt(S.n.x * S.n.x + S.n.y * S.n.y + S.n.z * S.n.z);
   S.nh = {S.n.x / nn, S.n.y / nn, S.n.z / nn};
@@ -219,10 +300,13 @@ __device__ __forceinline__ void search_witness(Search &S, const Polygon &P) {
   S.hp_lo = hp * (1.0 - 1.0e-13);  // n . p > 0: the origin is on the inner side of every trial plane
 }
 
-// Candidates [k0, k1) of the cell order against the trial normal, 64 at a time.  A point is cleared when
+// Candidates [k0, k1) of the cell order against the trial normal, 64 at a time (one per lane).  A point is cleared when
 //   fl(n . (q - p)) < -1e-15 sum |n_i fl(q_i - p_i)|:
 // the subtraction, the product and the two additions of a term are each within 2^-53 relative, so the computed value
-// is within 4.44e-16 sum |n_i (q_i - p_i)| of the real one.  Every other point clips the polygon.
+// is within 4.44e-16 sum |n_i (q_i - p_i)| of the real one.  While some lane's point is not cleared, the worst of them
+// (largest n . d relative to its bound) clips the polygon and the trial normal is taken again at once -- the 64
+// differences stay in registers, so the wavefront solves the batch's own little feasibility problem without touching
+// memory.  Points cleared by an earlier trial normal of the pass are re-tested by the caller's next pass.
 __device__ __forceinline__ void test_range(Search &S, Polygon &P, const HprArrays &A, int32_t k0, int32_t k1) {
   const int l = lane_id();
   for (int32_t base = k0; base < k1 && S.status == 0; base += 64) {
@@ -243,16 +327,21 @@ __device__ __forceinline__ void test_range(Search &S, Polygon &P, const HprArray
         return;
       }
     }
-    const double tx = S.n.x * dx, ty = S.n.y * dy, tz = S.n.z * dz;
-    const double t = (tx + ty) + tz;
-    const double T = (fabs(tx) + fabs(ty)) + fabs(tz);
-    const bool bad = active && !dup && !(t < -kPointSlack * T);
-    const bool uncertain = bad && !(t > kPointSlack * T);
-    unsigned long long todo = __ballot(bad);
-    const unsigned long long m_unc = __ballot(uncertain);
-    while (todo) {
-      const int src = static_cast<int>(__builtin_ctzll(todo));
-      todo &= todo - 1ull;
+    bool open = active && !dup;  // this lane's point may still clip
+    for (int guard = 0;; ++guard) {
+      if (guard > 192) {  // every cut removes a vertex or retires a lane: 64 lanes cannot need this many
+        S.fail_code = 1;
+        S.status = kSearchFail;
+        return;
+      }
+      const double tx = S.n.x * dx, ty = S.n.y * dy, tz = S.n.z * dz;
+      const double t = (tx + ty) + tz;
+      const double T = (fabs(tx) + fabs(ty)) + fabs(tz);
+      const bool bad = open && !(t < -kPointSlack * T);
+      if (!__ballot(bad)) break;
+      const double score = bad ? t / T : -INFINITY;
+      const double worst = wave_max(score);
+      const int src = static_cast<int>(__builtin_ctzll(__ballot(bad && score == worst)));
       const double qx = __shfl(dx, src, 64), qy = __shfl(dy, src, 64), qz = __shfl(dz, src, 64);
       const double Dx = (qx * S.e1.x + qy * S.e1.y) + qz * S.e1.z;
       const double Dy = (qx * S.e2.x + qy * S.e2.y) + qz * S.e2.z;
@@ -261,17 +350,22 @@ __device__ __forceinline__ void test_range(Search &S, Polygon &P, const HprArray
       const int r = polygon_clip(P, Dx, Dy, E, base + src, ca, cb);
       if (r == 1) {
         S.changed = true;
+        search_witness(S, P);
       } else if (r == 2) {
         S.status = kSearchEmpty;
         S.cert_a = ca;
         S.cert_b = cb;
         S.cert_c = base + src;
         return;
-      } else if (r == 3) {
+      } else if (r >= 3) {
+        S.fail_code = r;
         S.status = kSearchFail;
         return;
-      } else if ((m_unc >> src) & 1ull) {
-        S.uncertain_left = true;  // within round-off of the trial plane and no cut to move the plane away
+      } else {
+        // the whole polygon satisfies this point's half-plane, yet the trial normal (a point of the polygon) does not
+        // clear it: the point is within round-off of the trial plane and there is no cut to move the plane away
+        S.uncertain_left = true;
+        if (l == src) open = false;
       }
     }
   }
@@ -285,22 +379,26 @@ __device__ __forceinline__ bool cell_cleared(const Search &S, double ux, double 
   return rho * S.nn_hi * (1.0 - 0.5 * sl * sl) < S.hp_lo;
 }
 
-// one pass over everything that could reach the trial plane; returns when the polygon changed (the caller takes a new
-// trial normal) or when the pass is complete
-__device__ __forceinline__ void pass_hierarchy(Search &S, Polygon &P, const HprArrays &A, const HprGrid &G) {
-  const int l = lane_id();
-  // the cells around the candidate's own first: that is where the binding constraints are
+// The candidates that could reach the plane (S.nh, S.nn_hi, S.hp_lo), as runs of the cell order handed to
+// range(k0, k1); range returns false to stop.  traverse_near: the 3 x 3 cells around the candidate's own -- that is
+// where the binding constraints are; traverse_all: every cell the bound cannot clear (the near cells again included).
+template <typename RangeFn>
+__device__ __forceinline__ void traverse_near(const Search &S, const HprArrays &A, const HprGrid &G, RangeFn range) {
   const int32_t cell = A.scell[S.self];
   const int32_t ci = cell % G.gw, cj = cell / G.gw;
-  for (int dj = -1; dj <= 1 && S.status == 0; ++dj) {
+  for (int dj = -1; dj <= 1; ++dj) {
     const int32_t rj = cj + dj;
     if (rj < 0 || rj >= G.gh) continue;
     const int32_t c0 = rj * G.gw + max(ci - 1, 0), c1 = rj * G.gw + min(ci + 1, G.gw - 1);
-    test_range(S, P, A, A.cstart[c0], A.cstart[c1 + 1]);
+    if (!range(A.cstart[c0], A.cstart[c1 + 1])) return;
   }
-  if (S.changed || S.status != 0) return;
+}
+
+template <typename RangeFn>
+__device__ __forceinline__ void traverse_all(const Search &S, const HprArrays &A, const HprGrid &G, RangeFn range) {
+  const int l = lane_id();
   const int32_t n_coarse = G.cgw * G.cgh, n_fine = G.gw * G.gh;
-  for (int32_t cb = 0; cb < n_coarse && S.status == 0; cb += 64) {
+  for (int32_t cb = 0; cb < n_coarse; cb += 64) {
     const int32_t C = cb + l;
     bool open = false;
     if (C < n_coarse) {
@@ -308,7 +406,7 @@ __device__ __forceinline__ void pass_hierarchy(Search &S, Polygon &P, const HprA
       open = rho > 0.0 && !cell_cleared(S, A.Cdir[C], A.Cdir[n_coarse + C], A.Cdir[2 * n_coarse + C], rho, G.r_coarse);
     }
     unsigned long long open_c = __ballot(open);
-    while (open_c && S.status == 0) {
+    while (open_c) {
       const int32_t Cc = cb + static_cast<int32_t>(__builtin_ctzll(open_c));
       open_c &= open_c - 1ull;
       const int32_t fi = (Cc % G.cgw) * kHprCoarse + (l & 7), fj = (Cc / G.cgw) * kHprCoarse + (l >> 3);
@@ -320,37 +418,42 @@ __device__ __forceinline__ void pass_hierarchy(Search &S, Polygon &P, const HprA
         fopen = rho > 0.0 && !cell_cleared(S, A.cdir[f], A.cdir[n_fine + f], A.cdir[2 * n_fine + f], rho, G.r_fine);
       }
       unsigned long long open_f = __ballot(fopen);
-      while (open_f && S.status == 0) {
+      while (open_f) {
         const int src = static_cast<int>(__builtin_ctzll(open_f));
         open_f &= open_f - 1ull;
         const int32_t ff = __shfl(f, src, 64);
-        test_range(S, P, A, A.cstart[ff], A.cstart[ff + 1]);
+        if (!range(A.cstart[ff], A.cstart[ff + 1])) return;
       }
-      if (S.changed) return;
     }
   }
 }
 
-// Runs the search from a box of half-width B.  kBrute: every pass tests all candidates (no cells).
-// Returns kSearchVisible (the last trial normal cleared every point; `uncertain_left` tells whether some only within
-// round-off), kSearchEmpty (cert_a / cert_b / cert_c), kSearchFail or kSearchHiddenDup.
-template <bool kBrute>
+// Runs the search from a box of half-width B.  Returns kSearchVisible (the last trial normal cleared every point;
+// `uncertain_left` tells whether some only within round-off), kSearchEmpty (cert_a / cert_b / cert_c), kSearchFail or
+// kSearchHiddenDup.
 __device__ __forceinline__ int run_search(Search &S, Polygon &P, const HprArrays &A, const HprGrid &G, double B,
                                           int max_restarts, unsigned long long &restarts) {
   polygon_box(P, B);
   S.status = 0;
+  search_witness(S, P);
   for (int it = 0; it < max_restarts; ++it) {
-    search_witness(S, P);
     S.changed = false;
     S.uncertain_left = false;
-    if (kBrute)
-      test_range(S, P, A, 0, G.m);
-    else
-      pass_hierarchy(S, P, A, G);
+    // the near cells first; once they have moved the trial normal, what it cleared before must be seen again
+    traverse_near(S, A, G, [&](int32_t k0, int32_t k1) {
+      test_range(S, P, A, k0, k1);
+      return S.status == 0;
+    });
+    if (S.status == 0 && !S.changed)
+      traverse_all(S, A, G, [&](int32_t k0, int32_t k1) {
+        test_range(S, P, A, k0, k1);
+        return S.status == 0 && !S.changed;
+      });
     restarts += 1;
     if (S.status != 0) return S.status;
     if (!S.changed) return kSearchVisible;
   }
+  S.fail_code = 2;
   return kSearchFail;
 }
 
@@ -486,7 +589,8 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_cells(HprGrid G, const unsign
 // [6] unresolved [7] exact predicate evaluations [8] length of the list for k_hpr_exact
 __global__ __launch_bounds__(kHprBlock) void k_hpr_decide(HprArrays A, HprGrid G, uint8_t *__restrict__ state,
                                                           int32_t *__restrict__ undecided,
-                                                          unsigned long long *__restrict__ stats, int32_t force_exact) {
+                                                          unsigned long long *__restrict__ stats, int32_t force_exact,
+                                                          double *__restrict__ dbg) {
   const int32_t j = static_cast<int32_t>(blockIdx.x) * (kHprBlock / 64) + static_cast<int32_t>(threadIdx.x >> 6);
   if (j >= G.m) return;
   Search S;
@@ -494,20 +598,15 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_decide(HprArrays A, HprGrid G
   S.self = j;
   S.self_idx = A.sidx[j];
   S.tests = 0;
+  S.fail_code = 0;
   search_frame(S);
   Polygon P;
   unsigned long long restarts = 0;
   int32_t out = kStUndecided;
-  int retries = 0;
   if (!force_exact) {
-    // a box of +-1/16 rad holds the trial normals of every visible point that is not within a hundredth of a pixel of a
-    // much nearer one; the few that need more take the second box
-    int r = run_search<false>(S, P, A, G, 0.0625, kHprMaxRestarts, restarts);
-    const bool box_hit = r == kSearchEmpty && (S.cert_a < 0 || S.cert_b < 0);
-    if (box_hit || r == kSearchFail) {
-      retries = 1;
-      r = run_search<false>(S, P, A, G, 16.0, kHprMaxRestarts, restarts);
-    }
+    // the box holds every plane that misses the ray from the origin through p by 1e-9 rad.  The trial normal is the
+    // least tilted one the constraints allow, so the size of the box costs nothing.
+    const int r = run_search(S, P, A, G, kHprBox, kHprMaxRestarts, restarts);
     int why = 0;
     if (r == kSearchHiddenDup) {
       out = kStHidden;
@@ -517,8 +616,21 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_decide(HprArrays A, HprGrid G
       if (tetra_contains_filtered(S.p, load_point(A, S.cert_a), load_point(A, S.cert_b), load_point(A, S.cert_c)))
         out = kStHidden;
       else why = 11;
-    } else if (r == kSearchEmpty) why = 12; else why = 13;
+    } else if (r == kSearchEmpty) why = 12; else why = 13 + (S.fail_code & 7);
     if (why && lane_id() == 0) atomicAdd(&stats[why], 1ull);
+    if (dbg && why >= 13) {
+      unsigned long long slot = 0;
+      if (lane_id() == 0) slot = atomicAdd(&stats[20], 1ull);
+      slot = __shfl(static_cast<long long>(slot), 0, 64);
+      if (slot < 4) {
+        double *o = dbg + slot * 256;
+        if (lane_id() == 0) {
+          o[0] = j; o[1] = S.self_idx; o[2] = P.nv; o[3] = S.fail_code; o[4] = static_cast<double>(restarts);
+          o[5] = S.p.x; o[6] = S.p.y; o[7] = S.p.z;
+        }
+        o[8 + 3 * lane_id()] = P.vx; o[9 + 3 * lane_id()] = P.vy; o[10 + 3 * lane_id()] = P.eid >= 0 ? A.sidx[P.eid] : P.eid;
+      }
+    }
   }
   if (lane_id() == 0) {
     state[j] = static_cast<uint8_t>(out);
@@ -526,31 +638,61 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_decide(HprArrays A, HprGrid G
     if (out == kStUndecided) undecided[atomicAdd(&stats[8], 1ull)] = j;
     atomicAdd(&stats[3], restarts);
     atomicAdd(&stats[4], S.tests);
-    if (retries) atomicAdd(&stats[5], 1ull);
   }
 }
 
 // ---- the exact path ----
 
-// all of S strictly on the origin's side of the plane (p, a, b)?  (then p, a, b span a facet of the hull: p is a vertex)
-__device__ inline bool plane_supports(const Search &S, const HprArrays &A, int32_t m, int32_t ia, int32_t ib, int *n_exact) {
+// All of S strictly on the origin's side of the plane (p, a, b)?  (Then p, a, b span a facet of the hull and p is a
+// vertex.)  Cells are cleared against the floating-point normal n_f = (a - p) x (b - p) with room for its distance from
+// the real normal: |n_f - n| <= 6 eps |a - p| |b - p|, so n . (q - p) < 0 follows from n_f . q < n_f . p - slack with
+// slack = 1e-15 |a - p| |b - p| reach, reach >= |q - p| for every q.  Points of the cells that remain are signed exactly.
+__device__ inline bool plane_supports(const Search &S0, const HprArrays &A, const HprGrid &G, double reach, int32_t ia,
+                                      int32_t ib, int *n_exact) {
   const Vec3d o = {0.0, 0.0, 0.0};
   const Vec3d a = load_point(A, ia), b = load_point(A, ib);
-  const int so = orient3d_sign(S.p, a, b, o, n_exact);
+  const int so = orient3d_sign(S0.p, a, b, o, n_exact);
   if (so == 0) return false;
-  const int l = lane_id();
-  for (int32_t base = 0; base < m; base += 64) {
-    const int32_t k = base + l;
-    bool ok = true;
-    if (k < m && k != S.self && k != ia && k != ib) {
-      const Vec3d q = load_point(A, k);
-      const bool same_p = q.x == S.p.x && q.y == S.p.y && q.z == S.p.z;  // a duplicate the duplicate rule lets p stand for
-      const bool same_ab = (q.x == a.x && q.y == a.y && q.z == a.z) || (q.x == b.x && q.y == b.y && q.z == b.z);
-      if (!same_p && !same_ab) ok = orient3d_sign(S.p, a, b, q, n_exact) == so;
-    }
-    if (__ballot(!ok)) return false;
+  Search S = S0;
+  const double ux = a.x - S.p.x, uy = a.y - S.p.y, uz = a.z - S.p.z;
+  const double vx = b.x - S.p.x, vy = b.y - S.p.y, vz = b.z - S.p.z;
+  Vec3d n = {uy * vz - uz * vy, uz * vx - ux * vz, ux * vy - uy * vx};
+  double hp = n.x * S.p.x + n.y * S.p.y + n.z * S.p.z;
+  if (hp < 0.0) {
+    n = {-n.x, -n.y, -n.z};
+    hp = -hp;
   }
-  return true;
+  const double nn = sqrt(n.x * n.x + n.y * n.y + n.z * n.z);
+  const double lu = sqrt(ux * ux + uy * uy + uz * uz), lv = sqrt(vx * vx + vy * vy + vz * vz);
+  const double slack = 1.0e-15 * lu * lv * reach;
+  const bool use_cells = nn > 0.0 && hp * (1.0 - 1.0e-13) - slack > 0.0;
+  S.nh = {n.x / nn, n.y / nn, n.z / nn};
+  S.nn_hi = nn * (1.0 + 1.0e-14);
+  S.hp_lo = hp * (1.0 - 1.0e-13) - slack;
+  bool ok_all = true;
+  const int l = lane_id();
+  auto range = [&](int32_t k0, int32_t k1) {
+    for (int32_t base = k0; base < k1; base += 64) {
+      const int32_t k = base + l;
+      bool ok = true;
+      if (k < k1 && k != S.self && k != ia && k != ib) {
+        const Vec3d q = load_point(A, k);
+        const bool same_p = q.x == S.p.x && q.y == S.p.y && q.z == S.p.z;  // a duplicate the duplicate rule lets p stand for
+        const bool same_ab = (q.x == a.x && q.y == a.y && q.z == a.z) || (q.x == b.x && q.y == b.y && q.z == b.z);
+        if (!same_p && !same_ab) ok = orient3d_sign(S.p, a, b, q, n_exact) == so;
+      }
+      if (__ballot(!ok)) {
+        ok_all = false;
+        return false;
+      }
+    }
+    return true;
+  };
+  if (use_cells)
+    traverse_all(S, A, G, range);
+  else
+    range(0, G.m);
+  return ok_all;
 }
 
 // p in the closed tetrahedron (origin, a, b, c), the tetrahedron not flat
@@ -571,7 +713,7 @@ __device__ inline bool tetra_contains_exact(const Vec3d &p, const Vec3d &a, cons
 
 constexpr int kHprExactIds = 16;
 
-__global__ __launch_bounds__(64) void k_hpr_exact(HprArrays A, HprGrid G, const int32_t *__restrict__ undecided,
+__global__ __launch_bounds__(64) void k_hpr_exact(HprArrays A, HprGrid G, double reach, const int32_t *__restrict__ undecided,
                                                   int32_t n_undecided, uint8_t *__restrict__ state,
                                                   unsigned long long *__restrict__ stats) {
   const int32_t u = static_cast<int32_t>(blockIdx.x);
@@ -584,13 +726,14 @@ __global__ __launch_bounds__(64) void k_hpr_exact(HprArrays A, HprGrid G, const 
   S.self = j;
   S.self_idx = A.sidx[j];
   S.tests = 0;
+  S.fail_code = 0;
   search_frame(S);
   Polygon P;
   unsigned long long restarts = 0;
   int n_exact = 0;
   int32_t out = -1;
-  // the search again, over every candidate, from a box that holds any plane tilted less than 89.9 degrees
-  const int r = run_search<true>(S, P, A, G, 1024.0, 4 * kHprMaxRestarts, restarts);
+  // the search again, with more patience
+  const int r = run_search(S, P, A, G, kHprBox, 4 * kHprMaxRestarts, restarts);
   int n_ids = 0;
   if (r == kSearchHiddenDup) {
     out = kStHidden;
@@ -619,7 +762,7 @@ __global__ __launch_bounds__(64) void k_hpr_exact(HprArrays A, HprGrid G, const 
       // a facet of the hull at p: the planes through p and two constraints that meet in a vertex of the polygon
       for (int i = 0; i < P.nv && out < 0; ++i) {
         const int32_t ea = __shfl(P.eid, (i + P.nv - 1) % P.nv, 64), eb = __shfl(P.eid, i, 64);
-        if (ea >= 0 && eb >= 0 && ea != eb && plane_supports(S, A, G.m, ea, eb, &n_exact)) out = kStVisible;
+        if (ea >= 0 && eb >= 0 && ea != eb && plane_supports(S, A, G, reach, ea, eb, &n_exact)) out = kStVisible;
       }
     }
     if (out < 0) {
@@ -640,7 +783,7 @@ __global__ __launch_bounds__(64) void k_hpr_exact(HprArrays A, HprGrid G, const 
       // the polygon emptied in floating point but no simplex holds p: any pair of binding constraints as a facet
       for (int ia = 0; ia < n_ids && out < 0; ++ia)
         for (int ib = ia + 1; ib < n_ids && out < 0; ++ib)
-          if (ids[ia] >= 0 && ids[ib] >= 0 && plane_supports(S, A, G.m, ids[ia], ids[ib], &n_exact)) out = kStVisible;
+          if (ids[ia] >= 0 && ids[ib] >= 0 && plane_supports(S, A, G, reach, ids[ia], ids[ib], &n_exact)) out = kStVisible;
     }
   }
   const unsigned long long exact_total = static_cast<unsigned long long>(wave_sum(static_cast<double>(n_exact)));
@@ -711,7 +854,7 @@ int hpr_refine_flags(pcp_context *ctx, int32_t frame, uint8_t *d_flags) {
   int32_t *cell = ctx->h_i32.p, *sidx = cell + sm, *scell = sidx + sm, *scand = scell + sm, *undecided = scand + sm;
   PCP_HIP_TRY(ctx, ctx->h_state.ensure(sm + 16));
   PCP_HIP_TRY(ctx, ctx->h_stats.ensure(32));
-  unsigned long long *bounds = ctx->h_stats.p + 16, *stats = ctx->h_stats.p;
+  unsigned long long *bounds = ctx->h_stats.p + 24, *stats = ctx->h_stats.p;
   {
     const unsigned long long init[4] = {~0ull, 0ull, ~0ull, 0ull};
     PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->h_stats.p, 0, 32 * sizeof(unsigned long long), ctx->stream));
@@ -765,6 +908,8 @@ int hpr_refine_flags(pcp_context *ctx, int32_t frame, uint8_t *d_flags) {
   PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->h_cells_i.p, 0, (static_cast<size_t>(2 * n_fine) + 16) * sizeof(int32_t), ctx->stream));
   PCP_HIP_TRY(ctx, hipMemsetAsync(crho, 0, static_cast<size_t>(n_fine) * sizeof(double), ctx->stream));
   HprArrays A{sx, sy, sz, sidx, scell, cstart, crho, cdir, Crho, Cdir};
+  double *dbg_buf = nullptr;
+  if (std::getenv("PCP_HPR_DEBUG")) (void)hipMalloc(reinterpret_cast<void **>(&dbg_buf), 1024 * sizeof(double));
   // PCP_HPR_FORCE_EXACT=1 (tests): every candidate takes the exact path; read per call
   const char *fe = std::getenv("PCP_HPR_FORCE_EXACT");
   const bool force_exact = fe && fe[0] == '1';
@@ -778,7 +923,7 @@ int hpr_refine_flags(pcp_context *ctx, int32_t frame, uint8_t *d_flags) {
     hipLaunchKernelGGL(k_hpr_cells, dim3(hpr_blocks(std::max(n_fine, n_coarse))), dim3(kHprBlock), 0, ctx->stream, G,
                        reinterpret_cast<const unsigned long long *>(crho), cdir, Crho, Cdir);
     hipLaunchKernelGGL(k_hpr_decide, dim3(static_cast<uint32_t>(div_up(m, kHprBlock / 64))), dim3(kHprBlock), 0, ctx->stream,
-                       A, G, ctx->h_state.p, undecided, stats, force_exact ? 1 : 0);
+                       A, G, ctx->h_state.p, undecided, stats, force_exact ? 1 : 0, dbg_buf);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   unsigned long long hs[9];
@@ -787,7 +932,8 @@ int hpr_refine_flags(pcp_context *ctx, int32_t frame, uint8_t *d_flags) {
   const int64_t n_und = static_cast<int64_t>(hs[8]);
   if (n_und > 0) {
     LaunchTimer t(ctx, PCP_K_HPR);
-    hipLaunchKernelGGL(k_hpr_exact, dim3(static_cast<uint32_t>(n_und)), dim3(64), 0, ctx->stream, A, G, undecided,
+    hipLaunchKernelGGL(k_hpr_exact, dim3(static_cast<uint32_t>(n_und)), dim3(64), 0, ctx->stream, A, G,
+                       4.0 * std::fabs(ctx->cull.hpr_flip_radius) + 1.0e4, undecided,
                        static_cast<int32_t>(n_und), ctx->h_state.p, stats);
     PCP_HIP_TRY(ctx, hipGetLastError());
     PCP_HIP_TRY(ctx, hipMemcpyAsync(hs, stats, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
@@ -809,9 +955,20 @@ int hpr_refine_flags(pcp_context *ctx, int32_t frame, uint8_t *d_flags) {
   ctx->hpr_stats[7] = static_cast<int64_t>(hs[7]);
   ctx->hpr_stats[8] = n_fine;
   if (std::getenv("PCP_HPR_DEBUG")) {
-    unsigned long long dbg[16];
+    unsigned long long dbg[24];
     (void)hipMemcpy(dbg, stats, sizeof(dbg), hipMemcpyDeviceToHost);
-    fprintf(stderr, "hpr debug: uncertain_left %llu tetra_filter %llu box_cert %llu fail %llu\n", dbg[10], dbg[11], dbg[12], dbg[13]);
+    if (dbg_buf) {
+      std::vector<double> h(1024);
+      (void)hipMemcpy(h.data(), dbg_buf, 1024 * sizeof(double), hipMemcpyDeviceToHost);
+      (void)hipFree(dbg_buf);
+      for (int sl = 0; sl < 4 && sl < static_cast<int>(dbg[20]); ++sl) {
+        const double *o = h.data() + sl * 256;
+        fprintf(stderr, "hpr fail: j %.0f idx %.0f nv %.0f code %.0f restarts %.0f p %.17g %.17g %.17g\n", o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
+        for (int v = 0; v < static_cast<int>(o[2]) && v < 64; ++v)
+          fprintf(stderr, "   v%d %.9g %.9g eid_idx %.0f\n", v, o[8 + 3 * v], o[9 + 3 * v], o[10 + 3 * v]);
+      }
+    }
+    fprintf(stderr, "hpr debug: uncertain_left %llu tetra_filter %llu box_cert %llu fail: guard %llu restarts %llu noncontig %llu overflow %llu\n", dbg[10], dbg[11], dbg[12], dbg[14], dbg[15], dbg[16], dbg[17]);
   }
   return PCP_OK;
 }
