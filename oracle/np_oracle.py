@@ -635,11 +635,17 @@ def hpr_frame(cam: dict, w2c, x, y, z, flip_radius: float = 90000.0):
     vi = np.where(ok, np.trunc(np.where(ok, v, 0)), -1)
     cand = ok & (ui >= 0) & (ui < cam["cull_width"]) & (vi >= 0) & (vi < cam["cull_height"])
     idx = np.nonzero(cand)[0]
-    if len(idx) < 4:
-        return idx
+    if len(idx) < 3:
+        # qhull needs dim + 1 = 4 points (three candidates and the origin): it fails on fewer and the reference then
+        # returns no visible point (view_culling.cpp:307-312)
+        return idx[:0]
     pts = np.stack([p["xc"][idx], p["yc"][idx], p["zc"][idx]], axis=1).astype(f64)
-    nrm = np.linalg.norm(pts, axis=1, keepdims=True)
-    flipped = pts + 2.0 * (flip_radius - nrm) * pts / nrm
-    hull = ConvexHull(np.concatenate([flipped, np.zeros((1, 3))], axis=0))
+    X, Y, Z = pts[:, 0], pts[:, 1], pts[:, 2]
+    nrm = np.sqrt((X * X + Y * Y) + Z * Z)[:, None]  # Eigen's norm of a 3-vector block, as the z-buffer's range
+    flipped = pts + (2.0 * (flip_radius - nrm) * pts) / nrm  # per coefficient x + ((2 (R - norm)) x) / norm
+    try:
+        hull = ConvexHull(np.concatenate([flipped, np.zeros((1, 3))], axis=0))
+    except Exception:  # QhullError: flat input -> qh_new_qhull returns non-zero -> no visible point (:307-312)
+        return idx[:0]
     vis = np.array(sorted(int(k) for k in hull.vertices if k < len(idx)), dtype=np.int64)
     return idx[vis]

@@ -31,12 +31,13 @@ class CullParams(C.Structure):
         ("enable_depth_buffer_culling", C.c_int32),
         ("downsample_factor", C.c_int32),
         ("depth_slack", C.c_double),
-        ("cull_mode", C.c_int32),   # 0 z-buffer, 1 hidden_points_removal's candidate filter
+        ("cull_mode", C.c_int32),   # 0 z-buffer, 1 hidden_points_removal's candidate filter, 2 hidden_points_removal
         ("match_mode", C.c_int32),  # 0 identity, 1 fp32 world round trip + self-match
+        ("hpr_flip_radius", C.c_double),
     ]
 
 
-CULL_ZBUFFER, CULL_HPR_CANDIDATES = 0, 1
+CULL_ZBUFFER, CULL_HPR_CANDIDATES, CULL_HPR = 0, 1, 2
 MATCH_IDENTITY, MATCH_ROUNDTRIP = 0, 1
 
 

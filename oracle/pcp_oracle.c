@@ -44,6 +44,7 @@ void orc_default_cull_params(orc_cull_params *p) {
   p->depth_slack = 0.05;
   p->cull_mode = ORC_CULL_ZBUFFER;
   p->match_mode = ORC_MATCH_ROUNDTRIP;
+  p->hpr_flip_radius = 90000.0; /* view_culling.hpp:14 */
 }
 
 /* PCP/src/PointCloudProcessor.cpp:67-86 */
@@ -250,7 +251,7 @@ static inline void project_one(const orc_camera *cam, const orc_cull_params *cp,
   orc_project_point(cam, X, Y, Z, &u, &v);
   /* A4' hidden_points_removal's candidate filter, view_culling.cpp:284-288:
    * project(p).cast<int>() against the full image_size; no map, reported as -2 */
-  if (cp->cull_mode == ORC_CULL_HPR_CANDIDATES) {
+  if (cp->cull_mode != ORC_CULL_ZBUFFER) {
     int32_t ui, vi;
     if (trunc_d(u, &ui) && trunc_d(v, &vi) && ui >= 0 && ui < cam->cull_width && vi >= 0 && vi < cam->cull_height)
       o->cell = -2;
@@ -345,13 +346,21 @@ static void depth_pass(const orc_camera *cam, const orc_cull_params *cp, const f
  * !(dist > (double)map + 0.05); without depth-buffer culling every candidate
  * (cell >= 0 or -2) is kept (:92-93, indices.emplace_back). */
 static inline int keep_rule(const orc_cull_params *cp, const projected *p, const float *map) {
-  if (!cp->enable_depth_buffer_culling || cp->cull_mode == ORC_CULL_HPR_CANDIDATES) return p->cell != -1;
+  if (!cp->enable_depth_buffer_culling || cp->cull_mode != ORC_CULL_ZBUFFER) return p->cell != -1;
   if (p->cell < 0) return 0;
   return !(p->range > (double)map[p->cell] + cp->depth_slack);
 }
 
 static inline int zbuf_on(const orc_cull_params *cp) {
   return cp->enable_depth_buffer_culling && cp->cull_mode == ORC_CULL_ZBUFFER;
+}
+
+/* ORC_CULL_HPR: the keep mask of ViewCulling::hidden_points_removal for one keyframe (pcp_oracle_hpr.c), n bytes in
+ * `hull`; keep_rule's candidate test (cell != -1) is then ANDed with it.  Other modes: hull is left untouched. */
+static inline int hull_mask(const orc_camera *cam, const orc_cull_params *cp, const float w2c[12], const float *x,
+                            const float *y, const float *z, int64_t n, uint8_t *hull) {
+  if (cp->cull_mode != ORC_CULL_HPR) return 0;
+  return orc_hpr_frame(cam, w2c, x, y, z, n, cp->hpr_flip_radius, hull, NULL) < 0 ? -1 : 0;
 }
 
 int64_t orc_cull_frame(const orc_camera *cam, const orc_cull_params *cp, const float w2c[12], const float *x,
@@ -365,16 +374,19 @@ int64_t orc_cull_frame(const orc_camera *cam, const orc_cull_params *cp, const f
   else
     depth_map_fill(map, cells);
   int64_t kept = 0;
+  uint8_t *hull = cp->cull_mode == ORC_CULL_HPR ? (uint8_t *)malloc((size_t)(n > 0 ? n : 1)) : NULL;
+  if (hull) hull_mask(cam, cp, w2c, x, y, z, n, hull);
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static) num_threads(nt) reduction(+ : kept)
 #endif
   for (int64_t i = 0; i < n; ++i) {
     projected p;
     project_one(cam, cp, w2c, x[i], y[i], z[i], &p);
-    const int k = keep_rule(cp, &p, map);
+    const int k = keep_rule(cp, &p, map) && (!hull || hull[i]);
     if (out_keep) out_keep[i] = (uint8_t)k;
     kept += k;
   }
+  free(hull);
   if (!depth_map) free(map);
   return kept;
 }
@@ -524,6 +536,7 @@ int orc_colorize(const orc_camera *cam, const orc_cull_params *cp, const float *
       state[i].frame[k] = -1;
     }
   }
+  uint8_t *hull = NULL; /* ORC_CULL_HPR: this keyframe's hull vertices */
   for (int32_t f = 0; f < n_frames; ++f) { /* PCP/src/PointCloudProcessor.cpp:488 */
     float w2c[12], c2w[12], c2w_inv[12];
     const double *T = T_opt ? T_opt + (int64_t)T_opt_stride * f : NULL;
@@ -531,6 +544,15 @@ int orc_colorize(const orc_camera *cam, const orc_cull_params *cp, const float *
     affine_inverse_f32(c2w, c2w_inv); /* transformation_c2w_optimized.inverse(), :578 */
     const float r2 = match_radius_sq();
     if (zbuf_on(cp)) depth_pass(cam, cp, w2c, x, y, z, n, map, nt);
+    if (cp->cull_mode == ORC_CULL_HPR) {
+      if (!hull) hull = (uint8_t *)malloc((size_t)(n > 0 ? n : 1));
+      if (!hull || hull_mask(cam, cp, w2c, x, y, z, n, hull) != 0) {
+        free(hull);
+        free(map);
+        free(state);
+        return -1;
+      }
+    }
     const uint8_t *img = images[f];
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static) num_threads(nt)
@@ -538,7 +560,7 @@ int orc_colorize(const orc_camera *cam, const orc_cull_params *cp, const float *
     for (int64_t i = 0; i < n; ++i) {
       projected p;
       project_one(cam, cp, w2c, x[i], y[i], z[i], &p);
-      if (!keep_rule(cp, &p, map)) continue; /* ViewCulling::cull, :527 */
+      if (!keep_rule(cp, &p, map) || (hull && !hull[i])) continue; /* ViewCulling::cull, :527 */
       if (p.pixel < 0) continue;             /* generateColorMap bounds, :748-754 */
       const uint8_t *px = img + (int64_t)p.pixel * 3; /* BGR, :760-762 */
       const uint32_t rgb = ((uint32_t)px[2] << 16) | ((uint32_t)px[1] << 8) | (uint32_t)px[0];
@@ -572,6 +594,7 @@ int orc_colorize(const orc_camera *cam, const orc_cull_params *cp, const float *
       if (out_top_frame) out_top_frame[ORC_TOPM * i + k] = state[i].frame[k];
     }
   }
+  free(hull);
   free(map);
   free(state);
   return 0;
@@ -672,6 +695,12 @@ int orc_colorize_faithful(const orc_camera *cam, const orc_cull_params *cp, cons
       project_one(cam, cp, w2c, x[i], y[i], z[i], &p);
       vis[i] = (uint8_t)(keep_rule(cp, &p, map) && p.pixel >= 0);
     }
+    if (cp->cull_mode == ORC_CULL_HPR) { /* the hull is taken over every candidate, then the colour bounds apply */
+      uint8_t *hull = (uint8_t *)malloc((size_t)(n > 0 ? n : 1));
+      if (hull && hull_mask(cam, cp, w2c, x, y, z, n, hull) == 0)
+        for (int64_t i = 0; i < n; ++i) vis[i] = (uint8_t)(vis[i] && hull[i]);
+      free(hull);
+    }
     for (int64_t i = 0; i < n; ++i) { /* the loop at :559-594, in coloredCloudInWorld order */
       if (!vis[i]) continue;
       projected p;
@@ -766,11 +795,13 @@ int64_t orc_frame_visible(const orc_camera *cam, const orc_cull_params *cp, cons
   const int64_t cells = (int64_t)(cam->cull_width / cp->downsample_factor) * (cam->cull_height / cp->downsample_factor);
   float *map = (float *)malloc((size_t)(cells > 0 ? cells : 1) * sizeof(float));
   if (zbuf_on(cp)) depth_pass(cam, cp, w2c, x, y, z, n, map, 1);
+  uint8_t *hull = cp->cull_mode == ORC_CULL_HPR ? (uint8_t *)malloc((size_t)(n > 0 ? n : 1)) : NULL;
+  if (hull) hull_mask(cam, cp, w2c, x, y, z, n, hull);
   int64_t m = 0;
   for (int64_t i = 0; i < n; ++i) {
     projected p;
     project_one(cam, cp, w2c, x[i], y[i], z[i], &p);
-    if (!keep_rule(cp, &p, map)) continue;
+    if (!keep_rule(cp, &p, map) || (hull && !hull[i])) continue;
     if (p.pixel < 0) continue;
     uint8_t r = 0, g = 0, b = 0;
     if (image) {
@@ -806,6 +837,7 @@ int64_t orc_frame_visible(const orc_camera *cam, const orc_cull_params *cp, cons
     }
     ++m;
   }
+  free(hull);
   free(map);
   return m;
 }

@@ -43,6 +43,7 @@ typedef struct orc_camera {
 /* PCP/include/vlcal/calib/view_culling.hpp:10-19, view_culling.cpp:63,157 */
 #define ORC_CULL_ZBUFFER 0        /* ViewCulling::view_culling, view_culling.cpp:52-174 */
 #define ORC_CULL_HPR_CANDIDATES 1 /* candidate filter of hidden_points_removal, view_culling.cpp:276-288, keep all */
+#define ORC_CULL_HPR 2            /* hidden_points_removal, view_culling.cpp:266-334: filter + hull (pcp_oracle_hpr.c) */
 #define ORC_MATCH_IDENTITY 0      /* Appendix B3: the sample of point i goes to point i, scores from p_c */
 #define ORC_MATCH_ROUNDTRIP 1     /* fp32 world round trip + the 10 um self-match test + scores from
                                      c2w.inverse() * p_w (PointCloudProcessor.cpp:555,571-579), no cross-credit */
@@ -52,6 +53,7 @@ typedef struct orc_cull_params {
   double depth_slack;                  /* ref: 0.05 */
   int32_t cull_mode;                   /* ORC_CULL_* */
   int32_t match_mode;                  /* ORC_MATCH_* (orc_colorize; orc_colorize_faithful ignores it) */
+  double hpr_flip_radius;              /* ref: 90000 (view_culling.hpp:14) */
 } orc_cull_params;
 
 /* PCP/include/cloudSmooth.hpp:21-36, values PCP/src/PointCloudProcessor.cpp:67-86 */

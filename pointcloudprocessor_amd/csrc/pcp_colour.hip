@@ -470,7 +470,8 @@ __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict_
                                                         const uint32_t *__restrict__ images, int64_t image_px,
                                                         TopState st, const int32_t *__restrict__ perm,
                                                         uint32_t *__restrict__ rgba, int32_t flags,
-                                                        const int32_t *__restrict__ tile_order) {
+                                                        const int32_t *__restrict__ tile_order,
+                                                        const uint32_t *__restrict__ hull_bits) {
   const int64_t j = tile_order ? static_cast<int64_t>(tile_order[blockIdx.x]) * 64 + threadIdx.x
                                : static_cast<int64_t>(xcd_chunked_block()) * kBlock + threadIdx.x;
   const bool live = j < n;
@@ -493,13 +494,16 @@ __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict_
     uint32_t todo = range_bits(w, f0, f1);
     if (tile_mask) todo &= tile_mask[tile * words + w];
     todo = __builtin_amdgcn_readfirstlane(todo);
+    // PCP_CULL_HPR: bit f of this word = the point is a hull vertex of keyframe f (pcp_hpr.hip): the cull's verdict
+    const uint32_t hull_word = (hull_bits && live) ? hull_bits[static_cast<int64_t>(w) * n + j] : 0xffffffffu;
     while (todo) {
       const int32_t f = (w << 5) + __builtin_ctz(todo);
       todo &= todo - 1u;
       const DevFrame &fr = frames[f];
       // the refined masks only keep pairs with a candidate lane: the fp32 rejection test cannot skip the wavefront
       const Projected p = project_point<false>(cam, fr.w2c, px, py, pz);
-      const bool cand = live && p.pixel >= 0 && (cam.enable_zbuf ? p.cell >= 0 : p.cell != -1);
+      const bool cand = live && p.pixel >= 0 && (cam.enable_zbuf ? p.cell >= 0 : p.cell != -1) &&
+                        ((hull_word >> (f & 31)) & 1u);
       if (cand) {
         const uint32_t dbits = cam.enable_zbuf ? depth[static_cast<int64_t>(f) * cells + p.cell] : 0u;
         // A4 keep rule (view_culling.cpp:135-171)
@@ -1039,6 +1043,15 @@ __global__ __launch_bounds__(kBlock) void k_require_pixel(const float *__restric
   if (project_point(cam, fr.w2c, x[i], y[i], z[i]).pixel < 0) keep[i] = 0;
 }
 
+// PCP_CULL_HPR, whole run: bit `bit` of word[j] = keep flag of the point at place j of the Morton order
+__global__ __launch_bounds__(kBlock) void k_hull_bits(const uint8_t *__restrict__ keep, const int32_t *__restrict__ perm,
+                                                      int64_t n, uint32_t *__restrict__ word, uint32_t bit) {
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t w = word[j];
+  word[j] = keep[perm[j]] ? (w | bit) : (w & ~bit);
+}
+
 // ViewCulling::cull of one keyframe as byte flags in input order (ctx->s_keep): the z-buffer routine's pass 2 against the
 // map in ctx->s_u32 (single_frame_depth), or hidden_points_removal (candidate filter, then the hull: pcp_hpr.hip).
 // require_pixel: only points that generateColorMap can colour.
@@ -1437,6 +1450,20 @@ int pcp_depth_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
       PCP_HIP_TRY(ctx, hipGetLastError());
     }
   }
+  if (ctx->cull.cull_mode == PCP_CULL_HPR && ctx->n > 0) {
+    // hidden_points_removal has no depth map to pass on: its verdict per (point, keyframe) is a bit (pcp_hpr.hip), taken
+    // here keyframe by keyframe; the colour pass reads the bits where the z-buffer routine reads the maps
+    const size_t words = static_cast<size_t>((ctx->n_frames + 31) / 32);
+    PCP_HIP_TRY(ctx, ctx->hull_bits.ensure(words * static_cast<size_t>(ctx->n) + 4));
+    for (int32_t f = frame_begin; f < frame_end; ++f) {
+      if ((rc = frame_keep_flags(ctx, f, false)) != PCP_OK) return rc;
+      LaunchTimer t(ctx, PCP_K_HPR);
+      hipLaunchKernelGGL(k_hull_bits, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, ctx->s_keep.p, ctx->perm.p,
+                         ctx->n, ctx->hull_bits.p + static_cast<size_t>(f >> 5) * static_cast<size_t>(ctx->n),
+                         1u << (f & 31));
+      PCP_HIP_TRY(ctx, hipGetLastError());
+    }
+  }
   for (int32_t f = frame_begin; f < frame_end; ++f) ctx->depth_valid[static_cast<size_t>(f)] = 1;
   return PCP_OK;
 }
@@ -1533,7 +1560,8 @@ static int colour_pass_impl(pcp_context *ctx, int32_t frame_begin, int32_t frame
                        static_cast<int64_t>(ctx->dcam.img_w) * ctx->dcam.img_h, st, ctx->perm.p,
                        (one_shot && unpermute_results()) ? ctx->rgba_sorted.p : result,
                        flags | ((one_shot && unpermute_results()) ? 8 : 0),
-                       ordered ? ctx->tile_order.p : static_cast<const int32_t *>(nullptr));
+                       ordered ? ctx->tile_order.p : static_cast<const int32_t *>(nullptr),
+                       ctx->cull.cull_mode == PCP_CULL_HPR ? ctx->hull_bits.p : static_cast<const uint32_t *>(nullptr));
     if (one_shot && unpermute_results())
       hipLaunchKernelGGL(k_unpermute, dim3(blocks_for(div_up(ctx->n, 4))), dim3(kBlock), 0, ctx->stream, ctx->rgba_sorted.p,
                          ctx->inv_perm.p, ctx->n, result);

@@ -639,6 +639,7 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->h_cells_d.release();
   ctx->h_state.release();
   ctx->h_stats.release();
+  ctx->hull_bits.release();
   ctx->nid_pts.release();
   ctx->nid_chunk_kf.release();
   ctx->nid_hist.release();

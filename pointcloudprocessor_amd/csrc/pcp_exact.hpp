@@ -156,6 +156,27 @@ __device__ inline int orient3d_exact(const Vec3d &a, const Vec3d &b, const Vec3d
   return 0;
 }
 
+// the sign of n . (q - p), every operation exact (six exact products of the exact differences, summed as expansions)
+__device__ inline int dot_diff_sign_exact(const Vec3d &n, const Vec3d &q, const Vec3d &p) {
+  using namespace exact;
+  double acc[12], term[2];
+  int len = 0;
+  const double nn[3] = {n.x, n.y, n.z}, qq[3] = {q.x, q.y, q.z}, pp[3] = {p.x, p.y, p.z};
+  for (int k = 0; k < 3; ++k) {
+    double hi, lo;
+    two_diff(qq[k], pp[k], hi, lo);
+    two_prod(nn[k], lo, term[1], term[0]);
+    len = len == 0 ? (acc[0] = term[0], acc[1] = term[1], 2) : expansion_sum(len, acc, 2, term, acc);
+    two_prod(nn[k], hi, term[1], term[0]);
+    len = expansion_sum(len, acc, 2, term, acc);
+  }
+  for (int i = len - 1; i >= 0; --i) {
+    if (acc[i] > 0.0) return 1;
+    if (acc[i] < 0.0) return -1;
+  }
+  return 0;
+}
+
 // filter, then the exact evaluation; *used_exact (nullable) counts the latter
 __device__ inline int orient3d_sign(const Vec3d &a, const Vec3d &b, const Vec3d &c, const Vec3d &d, int *used_exact) {
   const int s = orient3d_filtered(a, b, c, d);

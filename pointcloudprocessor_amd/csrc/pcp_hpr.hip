@@ -643,6 +643,40 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_decide(HprArrays A, HprGrid G
 
 // ---- the exact path ----
 
+// Does the trial normal S.n have every other point of S strictly on its inner side, EXACTLY?  Cells are cleared by the
+// bound of the file header (rigorous for this n); a point the floating-point evaluation cannot clear is signed in
+// expansion arithmetic.  The origin is inside because n . p > 0 (checked the same way).
+__device__ inline bool witness_supports(const Search &S, const HprArrays &A, const HprGrid &G, int *n_exact) {
+  const Vec3d o = {0.0, 0.0, 0.0};
+  if (dot_diff_sign_exact(S.n, o, S.p) >= 0) return false;
+  bool ok_all = true;
+  const int l = lane_id();
+  traverse_all(S, A, G, [&](int32_t k0, int32_t k1) {
+    for (int32_t base = k0; base < k1; base += 64) {
+      const int32_t k = base + l;
+      bool ok = true;
+      if (k < k1 && k != S.self) {
+        const Vec3d q = load_point(A, k);
+        const double dx = q.x - S.p.x, dy = q.y - S.p.y, dz = q.z - S.p.z;
+        if (!(dx == 0.0 && dy == 0.0 && dz == 0.0)) {  // a duplicate p stands for (a lower index was found by the search)
+          const double tx = S.n.x * dx, ty = S.n.y * dy, tz = S.n.z * dz;
+          const double t = (tx + ty) + tz, T = (fabs(tx) + fabs(ty)) + fabs(tz);
+          if (!(t < -kPointSlack * T)) {
+            ++*n_exact;
+            ok = dot_diff_sign_exact(S.n, q, S.p) < 0;
+          }
+        }
+      }
+      if (__ballot(!ok)) {
+        ok_all = false;
+        return false;
+      }
+    }
+    return true;
+  });
+  return ok_all;
+}
+
 // All of S strictly on the origin's side of the plane (p, a, b)?  (Then p, a, b span a facet of the hull and p is a
 // vertex.)  Cells are cleared against the floating-point normal n_f = (a - p) x (b - p) with room for its distance from
 // the real normal: |n_f - n| <= 6 eps |a - p| |b - p|, so n . (q - p) < 0 follows from n_f . q < n_f . p - slack with
@@ -758,7 +792,26 @@ __global__ __launch_bounds__(64) void k_hpr_exact(HprArrays A, HprGrid G, double
       }
       __syncthreads();
     }
-    if (r == kSearchVisible || r == kSearchFail) {
+    if (r == kSearchVisible) {
+      // the last trial normal, signed exactly where floating point could not; failing that, the polygon's vertex mean
+      // (a point deep inside what the search left)
+      if (witness_supports(S, A, G, &n_exact)) {
+        out = kStVisible;
+      } else {
+        const bool valid = l < P.nv;
+        const double mx = wave_sum(valid ? P.vx : 0.0) / P.nv, my = wave_sum(valid ? P.vy : 0.0) / P.nv;
+        if (fabs(mx) < 64.0 && fabs(my) < 64.0) {
+          S.n = {S.e0.x + (mx * S.e1.x + my * S.e2.x), S.e0.y + (mx * S.e1.y + my * S.e2.y),
+                 S.e0.z + (mx * S.e1.z + my * S.e2.z)};
+          const double nn = sqrt(S.n.x * S.n.x + S.n.y * S.n.y + S.n.z * S.n.z);
+          S.nh = {S.n.x / nn, S.n.y / nn, S.n.z / nn};
+          S.nn_hi = nn * (1.0 + 1.0e-14);
+          S.hp_lo = (S.n.x * S.p.x + S.n.y * S.p.y + S.n.z * S.p.z) * (1.0 - 1.0e-13);
+          if (S.hp_lo > 0.0 && witness_supports(S, A, G, &n_exact)) out = kStVisible;
+        }
+      }
+    }
+    if (out < 0 && (r == kSearchVisible || r == kSearchFail)) {
       // a facet of the hull at p: the planes through p and two constraints that meet in a vertex of the polygon
       for (int i = 0; i < P.nv && out < 0; ++i) {
         const int32_t ea = __shfl(P.eid, (i + P.nv - 1) % P.nv, 64), eb = __shfl(P.eid, i, 64);

@@ -84,6 +84,28 @@ def main():
     save("g3_hpr.npz", camera=cam_array(cam), pose=poses[0], x=x, y=y, z=z, visible=hpr.astype(np.int32),
          zbuffer_keep=np.nonzero(keeps[0])[0].astype(np.int32), candidates=np.nonzero(cand)[0].astype(np.int32))
 
+    # g3b: the same cull at map density -- the candidates of keyframe 1 of the 2 M-point scene at the 1920x1080 camera
+    # (61 532 of them; qhull keeps 42 %).  The fixture holds the candidates' CAMERA coordinates as a cloud of their own
+    # with the identity pose: the transform of the identity (x * 1 + (y * 0 + (z * 0 + 0))) returns every coordinate
+    # unchanged, so candidates, flipped points and hull are those of the 2 M-point scene without shipping it.
+    if not ONLY or "g3b" in ONLY:
+        camd = synth.camera_dict("cfg")
+        xs, ys, zs, _ = synth.make_cloud(2_000_000)
+        poses8, _ = synth.make_trajectory(8)
+        w2c_d, _ = npo.pose_to_matrices(poses8[1])
+        cand_d, pd = npo.hpr_candidates(camd, w2c_d, xs, ys, zs)
+        ci = np.nonzero(cand_d)[0]
+        vis_full = npo.hpr_frame(camd, w2c_d, xs, ys, zs)
+        cx, cy, cz = pd["xc"][ci], pd["yc"][ci], pd["zc"][ci]
+        ident = np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0])
+        w2c_i, _ = npo.pose_to_matrices(ident)
+        vis_i = npo.hpr_frame(camd, w2c_i, cx, cy, cz)
+        assert np.array_equal(ci[vis_i], vis_full), "the candidate-only cloud must reproduce the scene's hull"
+        vis_mask = np.zeros(len(ci), bool)
+        vis_mask[vis_i] = True
+        save("g3b_hpr_dense.npz", camera=cam_array(camd), pose=ident, x=cx, y=cy, z=cz,
+             visible_bits=np.packbits(vis_mask), n_visible=np.int64(len(vis_i)))
+
     # g4: 6-keyframe colour run, procedural images
     imgs = [synth.make_image(f, cam["image_width"], cam["image_height"], seed=5) for f in range(6)]
     col = npo.colorize(cam, x, y, z, poses, imgs)

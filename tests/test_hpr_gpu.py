@@ -1,0 +1,221 @@
+"""PCP_CULL_HPR on the device (csrc/pcp_hpr.hip) = ViewCulling::hidden_points_removal (view_culling.cpp:266-334): the
+hull vertices among the flipped candidates, through the C ABI, against the committed goldens (scipy's qhull_r) and the
+oracle's exact quickhull.  Both sides decide exactly, so the keep masks must be EQUAL, not close; `unresolved` (points
+the exact path could not certify: exactly degenerate input only) must be 0 on every scene here."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import cam_struct
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CAM_KEYS = ["fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3", "image_width", "image_height", "cull_width",
+            "cull_height"]
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name), allow_pickle=False)
+
+
+def cam_of(mod, a):
+    return cam_struct(mod, {k: (int(v) if k.endswith(("width", "height")) else float(v)) for k, v in zip(CAM_KEYS, a)})
+
+
+def hull_ctx(factory, capi, cam, x, y, z, poses):
+    cull = capi.default_cull_params()
+    cull.cull_mode = capi.CULL_HPR
+    ctx = factory()
+    ctx.set_camera(cam, cull)
+    ctx.upload_cloud(x, y, z)
+    ctx.set_frames(np.asarray(poses, np.float64).reshape(-1, 7))
+    return ctx
+
+
+def test_g3_sparse_golden(gpu_ctx_factory):
+    from pointcloudprocessor_amd import capi
+
+    g = load("g3_hpr.npz")
+    ctx = hull_ctx(gpu_ctx_factory, capi, cam_of(capi, g["camera"]), g["x"], g["y"], g["z"], g["pose"])
+    keep, _, kept = ctx.cull_frame(0)
+    st = ctx.hpr_stats()
+    assert np.array_equal(np.nonzero(keep)[0], g["visible"]) and kept == len(g["visible"])
+    assert st["candidates"] == len(g["candidates"]) and st["unresolved"] == 0
+    assert st["visible"] + st["hidden"] == st["candidates"]
+    ctx.close()
+
+
+def test_g3b_dense_golden(gpu_ctx_factory, oracle):
+    """61 532 candidates at map density: qhull keeps 26 022 (42 %) -- the hull is an occlusion cull, not a no-op."""
+    from pointcloudprocessor_amd import capi
+
+    g = load("g3b_hpr_dense.npz")
+    n = len(g["x"])
+    ctx = hull_ctx(gpu_ctx_factory, capi, cam_of(capi, g["camera"]), g["x"], g["y"], g["z"], g["pose"])
+    keep, _, kept = ctx.cull_frame(0)
+    st = ctx.hpr_stats()
+    want = np.unpackbits(g["visible_bits"])[:n]
+    assert np.array_equal(keep, want), f"{int((keep != want).sum())} points differ from qhull's vertex set"
+    assert kept == int(g["n_visible"]) == 26022 and st["candidates"] == n and st["unresolved"] == 0
+    w2c, _ = oracle.pose_to_matrices(g["pose"])
+    okeep, _ = oracle.hpr_frame(cam_of(oracle, g["camera"]), w2c, g["x"], g["y"], g["z"])
+    assert np.array_equal(keep, okeep)
+    ctx.close()
+
+
+@pytest.mark.parametrize("camname", ["cfg", "ref"])
+def test_scene_equals_oracle(gpu_ctx_factory, oracle, camname):
+    """300 k points, 6 keyframes, both cameras: every keep mask equals the exact hull of the oracle."""
+    from pointcloudprocessor_amd import capi, synth
+
+    cd = synth.camera_dict(camname)
+    x, y, z, _ = synth.make_cloud(300_000)
+    poses, _ = synth.make_trajectory(6)
+    ctx = hull_ctx(gpu_ctx_factory, capi, cam_struct(capi, cd), x, y, z, poses)
+    ocam = cam_struct(oracle, cd)
+    dropped = 0
+    for f in range(6):
+        keep, _, kept = ctx.cull_frame(f)
+        st = ctx.hpr_stats()
+        w2c, _ = oracle.pose_to_matrices(poses[f])
+        okeep, ost = oracle.hpr_frame(ocam, w2c, x, y, z)
+        assert np.array_equal(keep, okeep), (camname, f, int((keep != okeep).sum()))
+        assert st["unresolved"] == 0 and st["candidates"] == ost["candidates"] and kept == ost["kept"]
+        dropped += ost["candidates"] - ost["kept"]
+    assert dropped > 0
+    ctx.close()
+
+
+def test_exact_path_alone_decides_the_same(gpu_ctx_factory, oracle, monkeypatch):
+    """PCP_HPR_FORCE_EXACT=1 sends every candidate to k_hpr_exact (certificates checked with the exact predicate):
+    same keep masks."""
+    from pointcloudprocessor_amd import capi, synth
+
+    cd = synth.camera_dict("cfg")
+    x, y, z, _ = synth.make_cloud(120_000)
+    poses, _ = synth.make_trajectory(3)
+    ctx = hull_ctx(gpu_ctx_factory, capi, cam_struct(capi, cd), x, y, z, poses)
+    ocam = cam_struct(oracle, cd)
+    for f in range(3):
+        monkeypatch.setenv("PCP_HPR_FORCE_EXACT", "1")
+        keep, _, _ = ctx.cull_frame(f)
+        st = ctx.hpr_stats()
+        monkeypatch.delenv("PCP_HPR_FORCE_EXACT")
+        w2c, _ = oracle.pose_to_matrices(poses[f])
+        okeep, ost = oracle.hpr_frame(ocam, w2c, x, y, z)
+        assert st["exact_path"] == st["candidates"] == ost["candidates"] and st["unresolved"] == 0
+        assert np.array_equal(keep, okeep)
+    ctx.close()
+
+
+def test_near_degenerate_points(gpu_ctx_factory, oracle):
+    """Points placed within 1e-12 .. 1e-7 m of facets of the hull of the flipped set (on either side): the
+    floating-point certificates cannot settle the closest ones, the exact path must, and the result is the oracle's."""
+    from pointcloudprocessor_amd import capi, synth
+
+    cd = synth.camera_dict("cfg")
+    rng = np.random.default_rng(9)
+    x, y, z, _ = synth.make_cloud(40_000)
+    poses, _ = synth.make_trajectory(3)
+    ocam = cam_struct(oracle, cd)
+    w2c, _ = oracle.pose_to_matrices(poses[1])
+    p = oracle.project_frame(ocam, _hpr_candidates_params(oracle), w2c, x, y, z)
+    cand = np.nonzero(p["cell"] != -1)[0]
+    cx, cy, cz = p["xc"][cand], p["yc"][cand], p["zc"][cand]
+    # camera-frame cloud with the identity pose (the transform of the identity returns the coordinates unchanged);
+    # add points interpolated between neighbouring candidates: their flipped images land next to hull facets / edges
+    k = len(cand)
+    a, b = rng.integers(0, k, 4000), rng.integers(0, k, 4000)
+    t = rng.random(4000).astype(np.float32)
+    near = np.abs(cx[a] / cz[a] - cx[b] / cz[b]) + np.abs(cy[a] / cz[a] - cy[b] / cz[b]) < 0.02
+    a, b, t = a[near], b[near], t[near]
+    ex = np.concatenate([cx, cx[a] * (1 - t) + cx[b] * t])
+    ey = np.concatenate([cy, cy[a] * (1 - t) + cy[b] * t])
+    ez = np.concatenate([cz, cz[a] * (1 - t) + cz[b] * t])
+    ident = np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0])
+    ctx = hull_ctx(gpu_ctx_factory, capi, cam_struct(capi, cd), ex, ey, ez, ident)
+    keep, _, _ = ctx.cull_frame(0)
+    st = ctx.hpr_stats()
+    w2i, _ = oracle.pose_to_matrices(ident)
+    okeep, ost = oracle.hpr_frame(ocam, w2i, ex, ey, ez)
+    assert np.array_equal(keep, okeep), int((keep != okeep).sum())
+    assert st["unresolved"] == 0 and ost["zero"] == 0
+    ctx.close()
+
+
+def _hpr_candidates_params(oracle):
+    cp = oracle.default_cull_params()
+    cp.cull_mode = oracle.CULL_HPR_CANDIDATES
+    return cp
+
+
+def test_duplicates_and_tiny_candidate_sets(gpu_ctx_factory, oracle):
+    from pointcloudprocessor_amd import capi, synth
+
+    cd = synth.camera_dict("cfg")
+    x, y, z, _ = synth.make_cloud(30_000)
+    poses, _ = synth.make_trajectory(2)
+    # exact duplicates of 500 points, appended: the lowest index of a group stands for it
+    dup = np.random.default_rng(5).choice(len(x), 500, replace=False)
+    xd, yd, zd = np.concatenate([x, x[dup]]), np.concatenate([y, y[dup]]), np.concatenate([z, z[dup]])
+    ctx = hull_ctx(gpu_ctx_factory, capi, cam_struct(capi, cd), xd, yd, zd, poses)
+    ocam = cam_struct(oracle, cd)
+    for f in range(2):
+        keep, _, _ = ctx.cull_frame(f)
+        w2c, _ = oracle.pose_to_matrices(poses[f])
+        okeep, ost = oracle.hpr_frame(ocam, w2c, xd, yd, zd)
+        assert np.array_equal(keep, okeep) and not keep[len(x):].any()
+        assert ctx.hpr_stats()["unresolved"] == 0
+    ctx.close()
+    # fewer than three candidates: qhull fails, the reference returns nothing (view_culling.cpp:307-312); three: all
+    ident = np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0])
+    pts = np.array([[0.1, 0.0, 2.0], [-0.1, 0.05, 2.5], [0.0, -0.1, 3.0], [0.0, 0.0, -1.0]], np.float32)
+    for m, want in ((2, 0), (3, 3)):
+        sel = np.concatenate([pts[:m], pts[3:]])  # the last point is behind the camera: never a candidate
+        c2 = hull_ctx(gpu_ctx_factory, capi, cam_struct(capi, cd), sel[:, 0], sel[:, 1], sel[:, 2], ident)
+        keep, _, kept = c2.cull_frame(0)
+        w2i, _ = oracle.pose_to_matrices(ident)
+        okeep, _ = oracle.hpr_frame(ocam, w2i, sel[:, 0], sel[:, 1], sel[:, 2])
+        assert kept == want and np.array_equal(keep, okeep)
+        c2.close()
+
+
+def test_frame_visible_and_whole_run_in_hull_mode(gpu_ctx_factory, oracle, small_scene):
+    """The single-keyframe record call and the whole colourisation with cull_mode = PCP_CULL_HPR against the oracle's
+    ORC_CULL_HPR: visible lists, colours, masks, top-5 lists."""
+    from pointcloudprocessor_amd import capi
+
+    s = small_scene
+    cull = capi.default_cull_params()
+    cull.cull_mode = capi.CULL_HPR
+    ctx = gpu_ctx_factory()
+    ctx.set_camera(cam_struct(capi, s["cam"]), cull)
+    ctx.upload_cloud(s["x"], s["y"], s["z"])
+    ctx.set_frames(s["poses"])
+    for f, (im, mk) in enumerate(zip(s["images"], s["masks"])):
+        ctx.upload_image(f, im)
+        ctx.upload_mask(f, mk)
+    ocam = cam_struct(oracle, s["cam"])
+    ocp = oracle.default_cull_params()
+    ocp.cull_mode = oracle.CULL_HPR
+    for f in range(len(s["poses"])):
+        got = ctx.frame_visible(f)
+        ref = oracle.frame_visible(ocam, ocp, s["poses"][f], s["x"], s["y"], s["z"], s["images"][f], s["masks"][f])
+        assert np.array_equal(got["index"], ref["index"]) and np.array_equal(got["rgb"], ref["rgb"])
+        assert np.array_equal(got["mask"], ref["mask"]) and np.array_equal(got["xyz_cam"], ref["xyz_cam"])
+    ref = oracle.colorize(ocam, ocp, s["x"], s["y"], s["z"], s["poses"], s["images"])
+    col = ctx.colorize()
+    assert np.array_equal(col["has"], ref["has"]) and np.array_equal(col["rgb"], ref["rgb"])
+    ctx.depth_pass()
+    ctx.colour_reset()
+    ctx.colour_pass(0, 2)
+    ctx.colour_pass(2, len(s["poses"]))
+    r = ctx.colour_finalise(want_top=True)
+    for k in ("rgb", "has", "count", "top_score", "top_rgb", "top_frame"):
+        assert np.array_equal(r[k], ref[k]), k
+    # not the z-buffer's answer: the two culls keep different view lists
+    zref = oracle.colorize(ocam, oracle.default_cull_params(), s["x"], s["y"], s["z"], s["poses"], s["images"])
+    assert not np.array_equal(zref["count"], ref["count"])
+    ctx.close()
