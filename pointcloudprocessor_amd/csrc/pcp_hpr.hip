@@ -54,6 +54,7 @@ constexpr int kHprCoarse = 8;           // fine cells per coarse cell edge: 64 f
 constexpr double kHprTargetPerCell = 8.0;
 constexpr int64_t kHprMaxCells = int64_t(1) << 22;
 constexpr int kHprMaxRestarts = 96;
+constexpr int kStatStride = 32, kStatCopies = 64;  // counters: block 0 + kStatCopies copies of 32 words
 constexpr double kHprBox = 1073741824.0;  // half-width of the initial box of trial normals (2^30 rad of tilt)
 constexpr double kPointSlack = 1.0e-15;  // |fl(n . (q - p)) - exact| <= 4.44e-16 sum |n_i (q_i - p_i)| (see test_range)
 
@@ -64,6 +65,8 @@ struct HprGrid {
   double a0, b0, h, inv_h;
   int32_t gw, gh, cgw, cgh;
   double r_fine, r_coarse;  // chord bound between a cell's centre direction and any direction inside it
+  double a_reach;           // sqrt(1 + max |A|^2) over the grid: bounds 1 / u_z of every candidate direction
+  const double *rho_max;    // device: upper bound of |q| over all candidates (k_hpr_cells)
   int32_t m;
 };
 
@@ -394,20 +397,55 @@ __device__ __forceinline__ void traverse_near(const Search &S, const HprArrays &
   }
 }
 
+// Which coarse cells can hold a point that reaches the plane at all?  With rho_max >= |q| for every candidate, a point
+// can only fail n . q < n . p when the chord between its direction u and n / |n| is at most
+//     sep = sqrt(2 (1 - hp_lo / (rho_max |n|)))                                   (0 when p itself tops the plane).
+// Gnomonic coordinates A = (u_x, u_y) / u_z of two directions differ by at most |u - u'| (1 + |A'|) / u_z, and
+// 1 / u_z <= a_reach for every candidate, so such a point lies within R = sep (1 + |A_n|) a_reach of A_n, the gnomonic
+// image of n.  The window is the coarse cells that disc touches; a plane tilted beyond the grid's reach (n_z <= 0) gets
+// the whole grid.
+struct Window {
+  int32_t i0, i1, j0, j1;  // coarse cells, inclusive; i0 > i1: empty
+};
+
+__device__ __forceinline__ Window reach_window(const Search &S, const HprGrid &G) {
+  Window W = {0, G.cgw - 1, 0, G.cgh - 1};
+  const double ratio = S.hp_lo / (*G.rho_max * S.nn_hi);
+  if (ratio >= 1.0) return {1, 0, 1, 0};
+  if (!(S.nh.z > 1.0e-3)) return W;
+  const double sep = sqrt(2.0 * (1.0 - ratio)) * (1.0 + 1.0e-9) + 1.0e-12;
+  const double ax = S.nh.x / S.nh.z, ay = S.nh.y / S.nh.z;
+  const double R = sep * (1.0 + sqrt(ax * ax + ay * ay)) * G.a_reach * (1.0 + 1.0e-9);
+  const double H = G.h * kHprCoarse;
+  const double fi0 = floor((ax - R - G.a0) / H), fi1 = floor((ax + R - G.a0) / H);
+  const double fj0 = floor((ay - R - G.b0) / H), fj1 = floor((ay + R - G.b0) / H);
+  if (!(fi0 == fi0 && fi1 == fi1 && fj0 == fj0 && fj1 == fj1)) return W;  // NaN: no window
+  W.i0 = static_cast<int32_t>(fmax(fi0, 0.0));
+  W.j0 = static_cast<int32_t>(fmax(fj0, 0.0));
+  W.i1 = static_cast<int32_t>(fmin(fi1, static_cast<double>(G.cgw - 1)));
+  W.j1 = static_cast<int32_t>(fmin(fj1, static_cast<double>(G.cgh - 1)));
+  if (fi1 < 0.0 || fj1 < 0.0 || fi0 > G.cgw - 1 || fj0 > G.cgh - 1) return {1, 0, 1, 0};
+  return W;
+}
+
 template <typename RangeFn>
 __device__ __forceinline__ void traverse_all(const Search &S, const HprArrays &A, const HprGrid &G, RangeFn range) {
   const int l = lane_id();
   const int32_t n_coarse = G.cgw * G.cgh, n_fine = G.gw * G.gh;
-  for (int32_t cb = 0; cb < n_coarse; cb += 64) {
-    const int32_t C = cb + l;
+  const Window W = reach_window(S, G);
+  if (W.i0 > W.i1 || W.j0 > W.j1) return;
+  const int32_t ww = W.i1 - W.i0 + 1, wn = ww * (W.j1 - W.j0 + 1);
+  for (int32_t cb = 0; cb < wn; cb += 64) {
+    const int32_t t = cb + l;
+    const int32_t C = t < wn ? (W.j0 + t / ww) * G.cgw + W.i0 + t % ww : -1;
     bool open = false;
-    if (C < n_coarse) {
+    if (C >= 0) {
       const double rho = A.Crho[C];
       open = rho > 0.0 && !cell_cleared(S, A.Cdir[C], A.Cdir[n_coarse + C], A.Cdir[2 * n_coarse + C], rho, G.r_coarse);
     }
     unsigned long long open_c = __ballot(open);
     while (open_c) {
-      const int32_t Cc = cb + static_cast<int32_t>(__builtin_ctzll(open_c));
+      const int32_t Cc = __shfl(C, static_cast<int>(__builtin_ctzll(open_c)), 64);
       open_c &= open_c - 1ull;
       const int32_t fi = (Cc % G.cgw) * kHprCoarse + (l & 7), fj = (Cc / G.cgw) * kHprCoarse + (l >> 3);
       bool fopen = false;
@@ -557,7 +595,7 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_scatter(const double *__restr
 // centre directions of the fine cells; coarse cells: centre direction and the largest rho of their fine cells
 __global__ __launch_bounds__(kHprBlock) void k_hpr_cells(HprGrid G, const unsigned long long *__restrict__ crho_bits,
                                                          double *__restrict__ cdir, double *__restrict__ Crho,
-                                                         double *__restrict__ Cdir) {
+                                                         double *__restrict__ Cdir, unsigned long long *__restrict__ rho_max_bits) {
   const int32_t t = static_cast<int32_t>(blockIdx.x) * kHprBlock + static_cast<int32_t>(threadIdx.x);
   const int32_t n_fine = G.gw * G.gh, n_coarse = G.cgw * G.cgh;
   if (t < n_fine) {
@@ -576,6 +614,7 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_cells(HprGrid G, const unsign
         if (fi < G.gw && fj < G.gh) best = max(best, crho_bits[fj * G.gw + fi]);
       }
     Crho[t] = __longlong_as_double(static_cast<long long>(best));
+    if (best) atomicMax(rho_max_bits, best);
     const double a = G.a0 + (static_cast<double>(Ci) + 0.5) * (G.h * kHprCoarse);
     const double b = G.b0 + (static_cast<double>(Cj) + 0.5) * (G.h * kHprCoarse);
     const double inv = 1.0 / sqrt((a * a + b * b) + 1.0);
@@ -617,7 +656,7 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_decide(HprArrays A, HprGrid G
         out = kStHidden;
       else why = 11;
     } else if (r == kSearchEmpty) why = 12; else why = 13 + (S.fail_code & 7);
-    if (why && lane_id() == 0) atomicAdd(&stats[why], 1ull);
+    if (why && lane_id() == 0) atomicAdd(&stats[why], 1ull);  // rare
     if (dbg && why >= 13) {
       unsigned long long slot = 0;
       if (lane_id() == 0) slot = atomicAdd(&stats[20], 1ull);
@@ -634,10 +673,13 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_decide(HprArrays A, HprGrid G
   }
   if (lane_id() == 0) {
     state[j] = static_cast<uint8_t>(out);
-    atomicAdd(&stats[out], 1ull);
+    // the tallies of all wavefronts on one cache line would queue up behind each other in the L2 (measured: 38 ns per
+    // candidate whatever its work): kStatCopies copies, each on lines of its own, summed by the host
+    unsigned long long *mine = stats + kStatStride * (1 + (blockIdx.x % kStatCopies));
+    atomicAdd(&mine[out], 1ull);
+    atomicAdd(&mine[3], restarts);
+    atomicAdd(&mine[4], S.tests);
     if (out == kStUndecided) undecided[atomicAdd(&stats[8], 1ull)] = j;
-    atomicAdd(&stats[3], restarts);
-    atomicAdd(&stats[4], S.tests);
   }
 }
 
@@ -906,11 +948,11 @@ int hpr_refine_flags(pcp_context *ctx, int32_t frame, uint8_t *d_flags) {
   PCP_HIP_TRY(ctx, ctx->h_i32.ensure(5 * sm + 16));
   int32_t *cell = ctx->h_i32.p, *sidx = cell + sm, *scell = sidx + sm, *scand = scell + sm, *undecided = scand + sm;
   PCP_HIP_TRY(ctx, ctx->h_state.ensure(sm + 16));
-  PCP_HIP_TRY(ctx, ctx->h_stats.ensure(32));
+  PCP_HIP_TRY(ctx, ctx->h_stats.ensure(kStatStride * (1 + kStatCopies)));
   unsigned long long *bounds = ctx->h_stats.p + 24, *stats = ctx->h_stats.p;
   {
     const unsigned long long init[4] = {~0ull, 0ull, ~0ull, 0ull};
-    PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->h_stats.p, 0, 32 * sizeof(unsigned long long), ctx->stream));
+    PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->h_stats.p, 0, kStatStride * (1 + kStatCopies) * sizeof(unsigned long long), ctx->stream));
     PCP_HIP_TRY(ctx, hipMemcpyAsync(bounds, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
   }
   const DevFrame &fr = ctx->hframes[static_cast<size_t>(frame)];
@@ -951,6 +993,9 @@ int hpr_refine_flags(pcp_context *ctx, int32_t frame, uint8_t *d_flags) {
     // bounds the chord from the centre direction; the slack covers a coordinate that rounding put on a cell's edge
     G.r_fine = 0.5 * h * std::sqrt(2.0) * (1.0 + 1e-9) + 1e-12;
     G.r_coarse = 0.5 * h * kHprCoarse * std::sqrt(2.0) * (1.0 + 1e-9) + 1e-12;
+    const double ax = std::max(std::fabs(amin), std::fabs(amin + G.gw * h)), ay = std::max(std::fabs(bmin), std::fabs(bmin + G.gh * h));
+    G.a_reach = std::sqrt(1.0 + ax * ax + ay * ay) * (1.0 + 1e-9);
+    G.rho_max = reinterpret_cast<const double *>(ctx->h_stats.p + 28);
   }
   const int64_t n_fine = static_cast<int64_t>(G.gw) * G.gh, n_coarse = static_cast<int64_t>(G.cgw) * G.cgh;
   // per cell: count / start (n_fine + 1), cursor (n_fine); rho bits (n_fine), centre directions, coarse rho / directions
@@ -974,14 +1019,24 @@ int hpr_refine_flags(pcp_context *ctx, int32_t frame, uint8_t *d_flags) {
                        cell, m, cstart, cursor, sx, sy, sz, sidx, scell, scand,
                        reinterpret_cast<unsigned long long *>(crho));
     hipLaunchKernelGGL(k_hpr_cells, dim3(hpr_blocks(std::max(n_fine, n_coarse))), dim3(kHprBlock), 0, ctx->stream, G,
-                       reinterpret_cast<const unsigned long long *>(crho), cdir, Crho, Cdir);
+                       reinterpret_cast<const unsigned long long *>(crho), cdir, Crho, Cdir, stats + 28);
     hipLaunchKernelGGL(k_hpr_decide, dim3(static_cast<uint32_t>(div_up(m, kHprBlock / 64))), dim3(kHprBlock), 0, ctx->stream,
                        A, G, ctx->h_state.p, undecided, stats, force_exact ? 1 : 0, dbg_buf);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
+  std::vector<unsigned long long> hall(kStatStride * (1 + kStatCopies));
   unsigned long long hs[9];
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(hs, stats, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
-  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  auto fetch_stats = [&]() -> int {
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(hall.data(), stats, hall.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 9; ++k) {
+      hs[k] = hall[static_cast<size_t>(k)];
+      if (k != 8)
+        for (int c = 1; c <= kStatCopies; ++c) hs[k] += hall[static_cast<size_t>(c * kStatStride + k)];
+    }
+    return PCP_OK;
+  };
+  if ((rc = fetch_stats()) != PCP_OK) return rc;
   const int64_t n_und = static_cast<int64_t>(hs[8]);
   if (n_und > 0) {
     LaunchTimer t(ctx, PCP_K_HPR);
@@ -989,8 +1044,7 @@ int hpr_refine_flags(pcp_context *ctx, int32_t frame, uint8_t *d_flags) {
                        4.0 * std::fabs(ctx->cull.hpr_flip_radius) + 1.0e4, undecided,
                        static_cast<int32_t>(n_und), ctx->h_state.p, stats);
     PCP_HIP_TRY(ctx, hipGetLastError());
-    PCP_HIP_TRY(ctx, hipMemcpyAsync(hs, stats, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
-    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = fetch_stats()) != PCP_OK) return rc;
   }
   {
     LaunchTimer t(ctx, PCP_K_HPR);

@@ -19,6 +19,10 @@
 //     ceres::Solve (same cost, gradient, domain limits and outer loop; not Ceres' line search).
 //   * --enableInitialGuessManual is accepted and rejected with an exception (exit -2): the
 //     interactive GUI is out of scope.
+//   * --cull zbuffer|hpr|hpr_candidates (new, default zbuffer): which of ViewCulling's two routines decides visibility.
+//     zbuffer = view_culling (view_culling.cpp:52-174, the routine north_star names; its call is commented out at :43);
+//     hpr = hidden_points_removal (:266-334), the routine the reference binary actually calls (:46), flip + convex
+//     hull on the GPU; hpr_candidates = only its candidate filter (:276-288), a frustum cull.
 //   * --gpus N (new, default 1): the map is sharded by point index over N GPUs of this node (pcp_multi.hpp: one
 //     process, N contexts, RCCL all-reduce(MIN) of the depth maps over xGMI, images broadcast over xGMI); every
 //     output file is identical to the one-GPU run.  The NID refinement sums its joint histograms over the shards
@@ -57,6 +61,7 @@ struct Options {
   bool help = false;
   bool skip_filtered_dumps = false;
   int gpus = 1;
+  int cull_mode = PCP_CULL_ZBUFFER;
 };
 
 static bool parse_bool(const std::string &v) {  // boost::program_options bool semantics
@@ -94,6 +99,13 @@ static Options parse(int argc, char **argv) {
     else if (a == "--enableInitialGuessManual") o.enableInitialGuessManual = parse_bool(next());
     else if (a == "--skip_filtered_dumps") o.skip_filtered_dumps = parse_bool(next());
     else if (a == "--gpus") o.gpus = std::stoi(next());
+    else if (a == "--cull") {
+      const std::string v = next();
+      if (v == "zbuffer") o.cull_mode = PCP_CULL_ZBUFFER;
+      else if (v == "hpr") o.cull_mode = PCP_CULL_HPR;
+      else if (v == "hpr_candidates") o.cull_mode = PCP_CULL_HPR_CANDIDATES;
+      else throw std::runtime_error("the argument ('" + v + "') for option '--cull' is invalid (zbuffer, hpr, hpr_candidates)");
+    }
     else throw std::runtime_error("unrecognised option '" + a + "'");
   }
   return o;
@@ -265,7 +277,13 @@ class Processor {
       cam.image_width = img_w;
       cam.image_height = img_h;
     }
-    gpu->setCamera(cam);
+    pcp_cull_params cull;
+    pcp_default_cull_params(&cull);
+    cull.cull_mode = opt.cull_mode;
+    if (opt.cull_mode == PCP_CULL_HPR && gpu->size() > 1)
+      throw std::runtime_error("--cull hpr needs the whole map on one GPU (the hull of a keyframe is taken over every "
+                               "candidate): use --gpus 1");
+    gpu->setCamera(cam, &cull);
     std::vector<pcp_pose> poses;
     for (const auto &k : keyframes) poses.push_back(k.pose);
     gpu->setKeyframes(poses);
