@@ -1,0 +1,153 @@
+"""BASELINE.json configs[3] and configs[4] WHOLE, on the one GPU of the test box:
+
+  configs[3]  50 M points x 1024 keyframes, sharded by point index over 8 GPUs with an all-reduce(MIN) of the depth maps
+  configs[4]  100 M points x 2048 keyframes + segmentation masks + NID pose refine, 8 GPUs
+
+Both maps fit one MI355X, so the real partition is rehearsed here: the unsharded run on one context, then the 8 index
+shards as 8 contexts (each with every keyframe and image, as every rank holds them), their depth maps MIN-merged -- what
+ncclAllReduce(ncclMin) computes -- and PCP_DEPTH_BATCHED for the per-keyframe calls.  Asserted: the shards' colours,
+three depth maps and two frame_visible / cull_frame dumps equal the unsharded run exactly; for configs[4] the joint
+histograms of the NID cost accumulated per shard and summed -- the all-reduce(SUM) -- give the unsharded cost to 1e-12
+on 64 keyframes.  What stays unmeasured is the 8-GPU TIMING (no multi-GPU lease)."""
+import numpy as np
+import pytest
+
+from conftest import cam_struct
+
+pytestmark = pytest.mark.gpu
+
+SHARDS = 8
+
+
+def _engine(cd, x, y, z, poses, images, masks=None, batched_depth=False, intensity=None):
+    from pointcloudprocessor_amd import pipeline
+
+    eng = pipeline.HipEngine(0)
+    eng.configure(cd)
+    eng.upload_cloud(x, y, z)
+    if intensity is not None:
+        eng.ctx.upload_intensity(intensity)
+    eng.ctx.set_frames(poses)
+    for f in range(len(poses)):
+        eng.ctx.upload_image(f, images[f % len(images)])
+        if masks is not None:
+            eng.ctx.upload_mask(f, masks[f % len(masks)])
+    if batched_depth:
+        eng.ctx.set_depth_source(True)
+    return eng
+
+
+def _min_merge(maps):
+    import torch
+
+    merged = maps[0].clone()
+    for t in maps[1:]:
+        merged = torch.minimum(merged, t)
+    for t in maps:
+        t.copy_(merged)
+    torch.cuda.synchronize()
+    return merged
+
+
+def _whole_config(cd, x, y, z, poses, images, masks, probe_frames, dump_capacity):
+    from pointcloudprocessor_amd import pipeline
+
+    n = len(x)
+    full = _engine(cd, x, y, z, poses, images, masks)
+    a = full.ctx.colorize()
+    assert 0.2 * n < int(a["has"].sum()) < n
+    depth_full = {f: full.ctx.download_depth_map(f) for f in probe_frames}
+    vis_full = {f: full.ctx.frame_visible(f, capacity=dump_capacity) for f in probe_frames[:2]}
+    keep_full = {f: full.ctx.cull_frame(f)[0] for f in probe_frames[:2]}
+    for f in probe_frames[:2]:
+        assert vis_full[f]["count"] <= dump_capacity
+    full.close()
+    bounds = [pipeline.shard_bounds(n, r, SHARDS) for r in range(SHARDS)]
+    engs, maps = [], []
+    for lo, hi in bounds:
+        e = _engine(cd, x[lo:hi], y[lo:hi], z[lo:hi], poses, images, masks, batched_depth=True)
+        e.depth_pass()
+        engs.append(e)
+        maps.append(e.depth_maps_tensor())
+    merged = _min_merge(maps)  # all-reduce(MIN)
+    for f, ref in depth_full.items():
+        cells = ref.size
+        got = merged[f * cells:(f + 1) * cells].cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, ref.reshape(-1).view(np.uint32)), f
+    parts = [e.colour_from_depth() for e in engs]
+    assert np.array_equal(np.concatenate([q["rgb"] for q in parts]), a["rgb"])
+    assert np.array_equal(np.concatenate([q["has"] for q in parts]), a["has"])
+    del parts
+    for f in probe_frames[:2]:
+        v = [e.ctx.frame_visible(f, capacity=dump_capacity) for e in engs]
+        assert np.array_equal(np.concatenate([q["index"] + lo for q, (lo, _) in zip(v, bounds)]), vis_full[f]["index"]), f
+        for k in ("rgb", "mask", "xyz_cam", "xyz_world"):
+            assert np.array_equal(np.concatenate([q[k] for q in v]), vis_full[f][k]), (f, k)
+        keep = np.concatenate([e.ctx.cull_frame(f)[0] for e in engs])
+        assert np.array_equal(keep, keep_full[f]), f
+    for e in engs:
+        e.close()
+    return a
+
+
+def test_config3_whole_50M_x_1024_in_8_shards():
+    from pointcloudprocessor_amd import synth
+
+    cd = synth.camera_dict("cfg")
+    N, F = 50_000_000, 1024
+    x, y, z, _ = synth.make_cloud(N)
+    poses, _ = synth.make_trajectory(F)
+    images = [synth.make_image(f, cd["image_width"], cd["image_height"]) for f in range(8)]
+    _whole_config(cd, x, y, z, poses, images, None, [0, 517, 1023], dump_capacity=8_000_000)
+
+
+def test_config4_whole_100M_x_2048_masks_nid_in_8_shards():
+    import torch
+
+    from pointcloudprocessor_amd import pipeline, synth
+
+    cd = synth.camera_dict("cfg")
+    N, F = 100_000_000, 2048
+    W, H = cd["image_width"], cd["image_height"]
+    x, y, z, inten = synth.make_cloud(N)
+    poses, _ = synth.make_trajectory(F)
+    images = [synth.make_image(f, W, H) for f in range(8)]
+    masks = [synth.make_mask(f, W, H) for f in range(8)]
+    a = _whole_config(cd, x, y, z, poses, images, masks, [5, 1030, 2047], dump_capacity=16_000_000)
+    assert int(a["has"].sum()) > 0.5 * N
+    del a
+    # ---- NID pose refine at this map size: 64 keyframes spread over the trajectory ----
+    kf = poses[:: F // 64][:64]
+    full = _engine(cd, x, y, z, kf, images, intensity=inten)
+    total = full.ctx.nid_prepare()
+    T = np.eye(4)
+    T[:3, 3] = [0.01, -0.02, 0.015]
+    c0, g0, ok0 = full.ctx.nid_evaluate(T)
+    full.close()
+    bounds = [pipeline.shard_bounds(N, r, SHARDS) for r in range(SHARDS)]
+    shards = []
+    for lo, hi in bounds:
+        e = _engine(cd, x[lo:hi], y[lo:hi], z[lo:hi], kf, images, batched_depth=True, intensity=inten[lo:hi])
+        e.depth_pass()
+        shards.append(e)
+    _min_merge([e.depth_maps_tensor() for e in shards])
+    assert sum(e.ctx.nid_prepare() for e in shards) == total  # the shards cull against the whole map's depth maps
+    for e in shards:
+        e.ctx.nid_accumulate(T, 16)
+        e.ctx.synchronize()
+    hists = [torch.as_tensor(pipeline._DeviceArray(*e.ctx.nid_histograms_device(), "<f8"), device="cuda:0") for e in shards]
+    s = hists[0].clone()
+    for h in hists[1:]:
+        s += h  # all-reduce(SUM)
+    for h in hists:
+        h.copy_(s)
+    torch.cuda.synchronize()
+    results = [e.ctx.nid_finish(16) for e in shards]
+    c1, g1, ok1 = results[0]
+    for c, g, ok in results[1:]:  # the same numbers on every shard: the ranks' optimisers walk in lockstep
+        assert c == c1 and np.array_equal(g, g1) and ok == ok1
+    assert ok0 and ok1 and total > 50_000_000
+    assert abs(c1 - c0) <= 1e-12 * abs(c0)
+    np.testing.assert_allclose(g1, g0, rtol=1e-9, atol=1e-12)
+    for e in shards:
+        e.close()
