@@ -509,8 +509,10 @@ def main():
                                                          for k in (capi.K_SOR, capi.K_MLS_GRID, capi.K_MLS_FIT, capi.K_MISC)}}
                 except capi.PcpError as e:
                     mls["sor_mls_sor"] = {"error": str(e)}
-                # VOXEL_GRID_DILATION (the reference's configuration: 1 mm voxels, 4 iterations) on a thin slab of
-                # the same cloud -- at full C3 size the reference's own settings produce > 2^31 voxels
+                # VOXEL_GRID_DILATION with the reference's own configuration (1 mm voxels, 4 dilations,
+                # PointCloudProcessor.cpp:78-81): (a) a thin slab in one result (5.8 G outputs / s class), (b) the whole
+                # enableMLS chain on a 1 M-point sub-sample of the map, (c) the whole C3 map through the chunked form --
+                # ~3.8e9 output points, more than one result can hold (2^31) or the device could keep (78 B each)
                 try:
                     vs = (x[:nm] > 0.0) & (x[:nm] < 0.12)
                     eng.upload_cloud(x[:nm][vs], y[:nm][vs], z[:nm][vs])
@@ -539,6 +541,45 @@ def main():
                                       f"{t_c:.1f} s per pass, oracle/pcp_oracle_mls.c"}
                 except capi.PcpError as e:
                     mls["voxel_grid_dilation"] = {"error": str(e)}
+                try:
+                    sub = 10  # every 10th point of the map: 1 M points at the C3 size
+                    eng.upload_cloud(x[:nm:sub], y[:nm:sub], z[:nm:sub])
+                    vp = capi.default_mls_params()
+                    t1 = time.perf_counter()
+                    mc = eng.ctx.cloud_smooth(vp)
+                    eng.ctx.synchronize()
+                    t_c1 = time.perf_counter() - t1
+                    mls["reference_config_chain"] = {
+                        "points": int(len(x[:nm:sub])), "outputs": int(mc), "ms": round(t_c1 * 1e3, 1),
+                        "what": "SOR -> MLS + VOXEL_GRID_DILATION (1 mm x 4) -> SOR, PointCloudProcessor.cpp:67-86, in one "
+                                "pcp_cloud_smooth call (first call: includes allocations)"}
+                except capi.PcpError as e:
+                    mls["reference_config_chain"] = {"error": str(e)}
+                try:
+                    eng.upload_cloud(x[:nm], y[:nm], z[:nm])
+                    vp = capi.default_mls_params()
+                    cap = 1 << 28
+                    t1 = time.perf_counter()
+                    total_v, chunks_v = eng.ctx.mls_stream_begin(vp, cap)
+                    eng.ctx.synchronize()
+                    t_b = time.perf_counter() - t1
+                    emitted = 0
+                    t1 = time.perf_counter()
+                    while True:
+                        mchunk = eng.ctx.mls_stream_next()
+                        if mchunk == 0:
+                            break
+                        emitted += mchunk
+                    eng.ctx.synchronize()
+                    t_e = time.perf_counter() - t1
+                    mls["reference_config_stream"] = {
+                        "points": nm, "voxels": int(total_v), "outputs": int(emitted), "chunks": int(chunks_v),
+                        "chunk_capacity": cap, "fit_and_count_ms": round(t_b * 1e3, 1), "emit_ms": round(t_e * 1e3, 1),
+                        "Moutputs_per_s": round(emitted / max(t_e, 1e-9) / 1e6, 1),
+                        "what": "MLS + VOXEL_GRID_DILATION (1 mm x 4) of the whole map, emitted on the device in chunks "
+                                "(pcp_mls_stream_begin / _next); each chunk is overwritten by the next, nothing is copied to the host"}
+                except capi.PcpError as e:
+                    mls["reference_config_stream"] = {"error": str(e)}
                 eng.upload_cloud(x[:nm], y[:nm], z[:nm])
                 if not args.no_cpu:
                     # CPU baseline of the MLS leg: the oracle (OpenMP) on a full-density slab of the same cloud

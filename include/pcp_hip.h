@@ -272,6 +272,16 @@ int pcp_mls_process(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_coun
  * only the queries index_begin <= i < index_end (upsampling NONE).  Outputs as pcp_mls_process. */
 int pcp_mls_process_shard(pcp_context *ctx, const pcp_mls_params *p, int64_t index_begin, int64_t index_end,
                           int64_t *out_count);
+/* VOXEL_GRID_DILATION in chunks.  One result holds fewer than 2^31 points and must fit the device (78 B per point); the
+ * reference's own configuration (1 mm voxels, 4 dilations, PointCloudProcessor.cpp:78-81) turns every input point into up
+ * to 729 output points -- ~3.8e9 for a 10 M-point map -- and pcp_mls_process then fails with PCP_ERR_NOMEM.  The
+ * streamed form fits the surfaces once, counts the dilated voxel set in 64 bits (*out_total) and cuts its ascending key
+ * order into *out_chunks chunks of at most chunk_capacity voxels; every pcp_mls_stream_next emits the next chunk into
+ * the result buffers (read with pcp_mls_fetch; *out_count = its points, 0 after the last chunk).  The chunks in order
+ * are exactly what one pcp_mls_process would return.  No other call on ctx may come between begin and the last next. */
+int pcp_mls_stream_begin(pcp_context *ctx, const pcp_mls_params *p, int64_t chunk_capacity, int64_t *out_total,
+                         int32_t *out_chunks);
+int pcp_mls_stream_next(pcp_context *ctx, int64_t *out_count);
 /* xyz / normal 3*m floats AoS, curvature m, source index m (input order for
  * NONE; ascending voxel key for VOXEL_GRID_DILATION). */
 int pcp_mls_fetch(pcp_context *ctx, int64_t capacity, float *out_xyz, float *out_normal, float *out_curvature,

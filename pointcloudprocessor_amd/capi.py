@@ -403,6 +403,19 @@ class Context:
         self._check(self.lib.pcp_mls_process(self.h, C.byref(params), C.byref(cnt)))
         return cnt.value
 
+    def mls_stream_begin(self, params: "MLSParams", chunk_capacity: int):
+        """(total voxels, chunks) of a chunked VOXEL_GRID_DILATION emission (pcp_mls_stream_begin)."""
+        total = C.c_int64()
+        chunks = C.c_int32()
+        self._check(self.lib.pcp_mls_stream_begin(self.h, C.byref(params), C.c_int64(chunk_capacity), C.byref(total),
+                                                  C.byref(chunks)))
+        return total.value, chunks.value
+
+    def mls_stream_next(self) -> int:
+        m = C.c_int64()
+        self._check(self.lib.pcp_mls_stream_next(self.h, C.byref(m)))
+        return m.value
+
     def mls_process_shard(self, params: MLSParams, index_begin: int, index_end: int) -> int:
         cnt = C.c_int64()
         self._check(self.lib.pcp_mls_process_shard(self.h, C.byref(params), C.c_int64(index_begin), C.c_int64(index_end),

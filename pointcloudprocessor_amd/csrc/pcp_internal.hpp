@@ -220,6 +220,10 @@ struct pcp_context {
   pcp::DevBuf<float> mls_alt_xyz, mls_alt_normal, mls_alt_curv;
   pcp::DevBuf<int32_t> mls_alt_index;
   int64_t mls_count = 0;
+  // pcp_mls_stream_*: the plan of a chunked VOXEL_GRID_DILATION emission (pcp_mls.hip VgdStream; word0, word1, count per chunk)
+  std::vector<uint8_t> vgd_blob;
+  std::vector<int64_t> vgd_chunks;
+  int64_t vgd_next = -1;
   double sor_redo_fraction = 0.0;  // diagnostic: share of points the SOR selection kernel handed to the heap kernel
 
   // NID stage (section 8 f1): per-point intensity, per-keyframe culled clouds in camera

@@ -719,10 +719,11 @@ __global__ __launch_bounds__(kMB) void k_voxel_stamp(const float *__restrict__ x
     }
 }
 
+// (grid-stride: a bitmap of more than 2^32 words does not fit one launch's 32-bit work-item count)
 __global__ __launch_bounds__(kMB) void k_voxel_popcount(const uint32_t *__restrict__ bitmap, int64_t words,
                                                         int32_t *__restrict__ counts) {
-  const int64_t w = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
-  if (w < words) counts[w] = __popc(bitmap[w]);
+  for (int64_t w = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x; w < words; w += static_cast<int64_t>(gridDim.x) * kMB)
+    counts[w] = __popc(bitmap[w]);
 }
 
 struct VoxelEmitArgs {
@@ -748,14 +749,14 @@ struct VoxelEmitArgs {
 // bitmap word; stores only (the bitmap is ~1 % full: the search below must not run at this granularity).
 __global__ __launch_bounds__(kMB) void k_voxel_expand(const uint32_t *__restrict__ bitmap,
                                                       const int32_t *__restrict__ offsets, int64_t words,
-                                                      int64_t *__restrict__ vox) {
-  const int64_t w = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
-  if (w >= words) return;
-  uint32_t bits = bitmap[w];
-  int64_t out = offsets[w];
-  while (bits) {
-    vox[out++] = (w << 5) + __builtin_ctz(bits);
-    bits &= bits - 1u;
+                                                      int64_t word_base, int64_t *__restrict__ vox) {
+  for (int64_t w = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x; w < words; w += static_cast<int64_t>(gridDim.x) * kMB) {
+    uint32_t bits = bitmap[w];
+    int64_t out = offsets[w];
+    while (bits) {
+      vox[out++] = ((w + word_base) << 5) + __builtin_ctz(bits);
+      bits &= bits - 1u;
+    }
   }
 }
 
@@ -1845,12 +1846,23 @@ static int compact_results(pcp_context *ctx, const int32_t *keep_index, int64_t 
   return PCP_OK;
 }
 
-// performUpsampling(VOXEL_GRID_DILATION) on the fitted surfaces in ctx->m_state
-static int voxel_grid_dilation(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *p, const GridDesc &g,
-                               int64_t *out_count) {
+// performUpsampling(VOXEL_GRID_DILATION) on the fitted surfaces in ctx->m_state.  Two steps: vgd_prepare stamps the
+// dilated voxel set into the bitmap and counts it (per bitmap word on the device, per tile of 1024 words on the host,
+// in 64 bits); vgd_emit turns a range of bitmap words -- a slab of the key order -- into output points.  The one-shot
+// form emits the whole range; pcp_mls_stream_* emit it in chunks, which is how a voxel set above 2^31 points, or above
+// what the device can hold as output (78 B per point), is produced at all: the reference's own configuration (1 mm
+// voxels, 4 dilations, PointCloudProcessor.cpp:78-81) makes ~3.8e9 points of the 10 M-point C3 map.
+struct VgdStream {  // plain data: kept in ctx->vgd_blob between pcp_mls_stream_begin and _next
+  VoxelDesc v;
+  GridDesc g;
+  const int32_t *remap;
+  size_t plane;
+  int32_t order_poly;
+};
+
+static int vgd_prepare(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *p, VoxelDesc *out_v,
+                       std::vector<int64_t> *tile_prefix, unsigned long long *out_total) {
   const int64_t n = cv.n;
-  const size_t sn = static_cast<size_t>(n);
-  const size_t plane = (sn + 3) & ~size_t(3);
   VoxelDesc v{};
   v.bminx = cv.mn[0];
   v.bminy = cv.mn[1];
@@ -1864,8 +1876,9 @@ static int voxel_grid_dilation(pcp_context *ctx, const CloudView &cv, const pcp_
   const double bits = static_cast<double>(mx) * static_cast<double>(my) * static_cast<double>(mz);
   size_t free_b = 0, total_b = 0;
   PCP_HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
-  // bitmap (bits / 8) + popcount offsets (bits / 8): both must fit with room for the outputs
-  if (mx >= (int64_t(1) << 31) || my >= (int64_t(1) << 31) || mz >= (int64_t(1) << 31) || bits / 4.0 > 0.5 * static_cast<double>(free_b))
+  // bitmap (bits / 8) + per-word counts (bits / 8): both must fit with room for the outputs
+  const double have = static_cast<double>(free_b) + static_cast<double>(ctx->v_bitmap.count + ctx->v_offsets.count) * 4.0;
+  if (mx >= (int64_t(1) << 31) || my >= (int64_t(1) << 31) || mz >= (int64_t(1) << 31) || bits / 4.0 > 0.6 * have)
     return set_error(ctx, PCP_ERR_NOMEM,
                      "pcp_mls_process: the %lld x %lld x %lld voxel grid (%.3g voxels at %.4g m) does not fit the device; "
                      "use a larger vgd_voxel_size or crop the cloud",
@@ -1877,87 +1890,125 @@ static int voxel_grid_dilation(pcp_context *ctx, const CloudView &cv, const pcp_
   const size_t sw = static_cast<size_t>(v.words);
   PCP_HIP_TRY(ctx, ctx->v_bitmap.ensure(sw + 8));
   PCP_HIP_TRY(ctx, ctx->v_offsets.ensure(sw + 8));
-  PCP_HIP_TRY(ctx, ctx->s_counter.ensure(4));
   PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->v_bitmap.p, 0, (sw + 8) * 4, ctx->stream));
   PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->v_offsets.p, 0, (sw + 8) * 4, ctx->stream));
-  const float *x = cv.x, *y = cv.y, *z = cv.z;
-  unsigned long long total = 0;
+  const int64_t tiles = std::max<int64_t>(1, div_up(v.words, kScanTile));
+  PCP_HIP_TRY(ctx, ctx->s_tiles.ensure(static_cast<size_t>(tiles) + 4));
   {
     LaunchTimer t(ctx, PCP_K_MLS_VOXEL);
-    hipLaunchKernelGGL(k_voxel_stamp, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, x, y, z, n, v, ctx->v_bitmap.p);
-    hipLaunchKernelGGL(k_voxel_popcount, dim3(blocks_of(v.words)), dim3(kMB), 0, ctx->stream, ctx->v_bitmap.p, v.words,
-                       ctx->v_offsets.p);
-    // exclusive scan of words + 1 counts; 64-bit grand total through the tile-offset kernel
-    const int64_t tiles = std::max<int64_t>(1, div_up(v.words + 1, kScanTile));
-    PCP_HIP_TRY(ctx, ctx->s_tiles.ensure(static_cast<size_t>(tiles) + 4));
-    hipLaunchKernelGGL(k_scan_tile_sums, dim3(static_cast<uint32_t>(tiles)), dim3(kScanBlock), 0, ctx->stream,
-                       ctx->v_offsets.p, v.words + 1, ctx->s_tiles.p);
-    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kScanBlock), 0, ctx->stream, ctx->s_tiles.p, tiles,
-                       ctx->s_counter.p);
-    hipLaunchKernelGGL(k_scan_apply, dim3(static_cast<uint32_t>(tiles)), dim3(kScanBlock), 0, ctx->stream,
-                       ctx->v_offsets.p, v.words + 1, ctx->s_tiles.p, ctx->v_offsets.p);
+    hipLaunchKernelGGL(k_voxel_stamp, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, cv.x, cv.y, cv.z, n, v, ctx->v_bitmap.p);
+    hipLaunchKernelGGL(k_voxel_popcount, dim3(scan_grid(div_up(v.words, kMB))), dim3(kMB), 0, ctx->stream, ctx->v_bitmap.p,
+                       v.words, ctx->v_offsets.p);
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(scan_grid(tiles)), dim3(kScanBlock), 0, ctx->stream,
+                       ctx->v_offsets.p, v.words, ctx->s_tiles.p);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->s_counter.p, sizeof(total), hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<int32_t> sums(static_cast<size_t>(tiles));
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(sums.data(), ctx->s_tiles.p, sums.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (total >= (1ull << 31))
-    return set_error(ctx, PCP_ERR_NOMEM, "pcp_mls_process: %llu dilated voxels exceed the 2^31 output limit", total);
-  const size_t st = static_cast<size_t>(total);
+  tile_prefix->assign(static_cast<size_t>(tiles) + 1, 0);
+  for (int64_t t = 0; t < tiles; ++t) (*tile_prefix)[static_cast<size_t>(t) + 1] = (*tile_prefix)[static_cast<size_t>(t)] + sums[static_cast<size_t>(t)];
+  *out_total = static_cast<unsigned long long>(tile_prefix->back());
+  *out_v = v;
+  return PCP_OK;
+}
+
+// the voxels of bitmap words [word0, word1) (word0 a multiple of kScanTile), `count` of them: results in ctx->mls_*
+static int vgd_emit(pcp_context *ctx, const VgdStream &S, int64_t word0, int64_t word1, int64_t count, int64_t *out_m) {
+  const size_t st = static_cast<size_t>(count);
+  size_t free_b = 0, total_b = 0;
   PCP_HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
   if (static_cast<double>(st) * 78.0 > static_cast<double>(free_b) + static_cast<double>(ctx->mls_xyz.count) * 4.0 * 2.4)
-    return set_error(ctx, PCP_ERR_NOMEM, "pcp_mls_process: %llu upsampled points do not fit the device memory", total);
+    return set_error(ctx, PCP_ERR_NOMEM, "pcp_mls_process: %lld upsampled points do not fit the device memory "
+                     "(pcp_mls_stream_begin / _next emit them in chunks)", (long long)count);
   PCP_HIP_TRY(ctx, ctx->mls_xyz.ensure(3 * st + 4));
   PCP_HIP_TRY(ctx, ctx->mls_normal.ensure(3 * st + 4));
   PCP_HIP_TRY(ctx, ctx->mls_curv.ensure(st + 4));
   PCP_HIP_TRY(ctx, ctx->mls_index.ensure(st + 4));
   PCP_HIP_TRY(ctx, ctx->m_flag.ensure(st + 16));
-  VoxelEmitArgs e{};
-  e.bitmap = ctx->v_bitmap.p;
-  e.offsets = ctx->v_offsets.p;
-  e.v = v;
-  e.sx = ctx->g_xyz.p;
-  e.sy = ctx->g_xyz.p + plane;
-  e.sz = ctx->g_xyz.p + 2 * plane;
-  e.order = ctx->g_order.p;
-  e.remap = cv.remap;
-  e.start = ctx->g_start.p;
-  e.g = g;
-  // a dilated voxel's corner lies within sqrt(3) * (it + 1) voxels of the point that stamped it (1 % + 1 um of
-  // slack for the fp32 roundings of getCellIndex / getPosition)
-  e.dmax = static_cast<float>(1.7321 * (v.it + 1) * static_cast<double>(v.vs) * 1.01 + 1e-6);
   PCP_HIP_TRY(ctx, ctx->v_vox.ensure(st + 4));
-  e.vox = ctx->v_vox.p;
-  e.total = static_cast<int64_t>(total);
-  e.state = ctx->m_state.p;
-  e.order_poly = p->polynomial_order;
-  const int32_t nr_coeff = (p->polynomial_order + 1) * (p->polynomial_order + 2) / 2;
-  e.required_neighbors = 5 * nr_coeff;
-  e.xyz = ctx->mls_xyz.p;
-  e.normal = ctx->mls_normal.p;
-  e.curv = ctx->mls_curv.p;
-  e.index = ctx->mls_index.p;
-  e.valid = ctx->m_flag.p;
-  int64_t m = static_cast<int64_t>(total);
-  if (total > 0) {
+  int64_t m = count;
+  if (count > 0) {
+    const int64_t words = word1 - word0;
+    const int64_t tiles = std::max<int64_t>(1, div_up(words, kScanTile));
+    PCP_HIP_TRY(ctx, ctx->s_tiles.ensure(static_cast<size_t>(tiles) + 4));
+    int32_t *counts = ctx->v_offsets.p + word0;  // per-word counts -> exclusive prefix inside the chunk, in place
+    VoxelEmitArgs e{};
+    e.bitmap = ctx->v_bitmap.p;
+    e.offsets = ctx->v_offsets.p;
+    e.v = S.v;
+    e.sx = ctx->g_xyz.p;
+    e.sy = ctx->g_xyz.p + S.plane;
+    e.sz = ctx->g_xyz.p + 2 * S.plane;
+    e.order = ctx->g_order.p;
+    e.remap = S.remap;
+    e.start = ctx->g_start.p;
+    e.g = S.g;
+    // a dilated voxel's corner lies within sqrt(3) * (it + 1) voxels of the point that stamped it (1 % + 1 um of
+    // slack for the fp32 roundings of getCellIndex / getPosition)
+    e.dmax = static_cast<float>(1.7321 * (S.v.it + 1) * static_cast<double>(S.v.vs) * 1.01 + 1e-6);
+    e.vox = ctx->v_vox.p;
+    e.total = count;
+    e.state = ctx->m_state.p;
+    e.order_poly = S.order_poly;
+    const int32_t nr_coeff = (S.order_poly + 1) * (S.order_poly + 2) / 2;
+    e.required_neighbors = 5 * nr_coeff;
+    e.xyz = ctx->mls_xyz.p;
+    e.normal = ctx->mls_normal.p;
+    e.curv = ctx->mls_curv.p;
+    e.index = ctx->mls_index.p;
+    e.valid = ctx->m_flag.p;
     {
       LaunchTimer t(ctx, PCP_K_MLS_VOXEL);
-      hipLaunchKernelGGL(k_voxel_expand, dim3(blocks_of(v.words)), dim3(kMB), 0, ctx->stream, ctx->v_bitmap.p,
-                         ctx->v_offsets.p, v.words, ctx->v_vox.p);
-      hipLaunchKernelGGL(k_voxel_emit, dim3(blocks_of(static_cast<int64_t>(total))), dim3(kMB), 0, ctx->stream, e);
+      hipLaunchKernelGGL(k_scan_tile_sums, dim3(scan_grid(tiles)), dim3(kScanBlock), 0, ctx->stream, counts, words,
+                         ctx->s_tiles.p);
+      hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kScanBlock), 0, ctx->stream, ctx->s_tiles.p, tiles,
+                         static_cast<unsigned long long *>(nullptr));
+      hipLaunchKernelGGL(k_scan_apply, dim3(scan_grid(tiles)), dim3(kScanBlock), 0, ctx->stream, counts, words,
+                         ctx->s_tiles.p, counts);
+      hipLaunchKernelGGL(k_voxel_expand, dim3(scan_grid(div_up(words, kMB))), dim3(kMB), 0, ctx->stream,
+                         ctx->v_bitmap.p + word0, counts, words, word0, ctx->v_vox.p);
+      hipLaunchKernelGGL(k_voxel_emit, dim3(blocks_of(count)), dim3(kMB), 0, ctx->stream, e);
       PCP_HIP_TRY(ctx, hipGetLastError());
     }
     // voxels whose nearest point has no valid fit are skipped by PCL: compact if any
     PCP_HIP_TRY(ctx, ctx->s_cell.ensure(st + 4));
     int64_t kept = 0;
-    int rc = compact_flags(ctx, ctx->m_flag.p, static_cast<int64_t>(total), ctx->s_cell.p, static_cast<int64_t>(total), &kept);
+    int rc = compact_flags(ctx, ctx->m_flag.p, count, ctx->s_cell.p, count, &kept);
     if (rc != PCP_OK) return rc;
-    if (kept != static_cast<int64_t>(total)) {
+    if (kept != count) {
       LaunchTimer t(ctx, PCP_K_MLS_VOXEL);
-      if ((rc = compact_results(ctx, ctx->s_cell.p, static_cast<int64_t>(total), kept)) != PCP_OK) return rc;
+      if ((rc = compact_results(ctx, ctx->s_cell.p, count, kept)) != PCP_OK) return rc;
       m = kept;
     }
   }
   ctx->mls_count = m;
+  if (out_m) *out_m = m;
+  return PCP_OK;
+}
+
+static VgdStream vgd_stream_of(const CloudView &cv, const pcp_mls_params *p, const GridDesc &g, const VoxelDesc &v) {
+  VgdStream S{};
+  S.v = v;
+  S.g = g;
+  S.remap = cv.remap;
+  S.plane = (static_cast<size_t>(cv.n) + 3) & ~size_t(3);
+  S.order_poly = p->polynomial_order;
+  return S;
+}
+
+static int voxel_grid_dilation(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *p, const GridDesc &g,
+                               int64_t *out_count) {
+  VoxelDesc v{};
+  std::vector<int64_t> prefix;
+  unsigned long long total = 0;
+  int rc = vgd_prepare(ctx, cv, p, &v, &prefix, &total);
+  if (rc != PCP_OK) return rc;
+  if (total >= (1ull << 31))
+    return set_error(ctx, PCP_ERR_NOMEM, "pcp_mls_process: %llu dilated voxels exceed the 2^31 points one result holds "
+                     "(pcp_mls_stream_begin / _next emit them in chunks)", total);
+  int64_t m = 0;
+  if ((rc = vgd_emit(ctx, vgd_stream_of(cv, p, g, v), 0, v.words, static_cast<int64_t>(total), &m)) != PCP_OK) return rc;
   if (out_count) *out_count = m;
   return PCP_OK;
 }
@@ -2006,7 +2057,7 @@ static int check_mls_params(pcp_context *ctx, const pcp_mls_params *p) {
 // keep_rows: leave the fitted rows in ctx->m_tmp (7 floats at the view index mls_index names) instead of gathering them
 // into the result arrays -- pcp_cloud_smooth picks the survivors of its last filter straight from there
 static int mls_run(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *p, int64_t *out_count,
-                   int64_t q_begin = 0, int64_t q_end = -1, bool keep_rows = false) {
+                   int64_t q_begin = 0, int64_t q_end = -1, bool keep_rows = false, int64_t stream_capacity = 0) {
   const int64_t n = cv.n;
   ctx->mls_count = 0;
   if (out_count) *out_count = 0;
@@ -2050,6 +2101,32 @@ static int mls_run(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *
     else
       hipLaunchKernelGGL(k_mls_fit<false>, dim3(static_cast<uint32_t>(div_up(n, kFitBlock))), dim3(kFitBlock), 0, ctx->stream, a);
     PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  if (p->upsampling == 3 && stream_capacity > 0) {
+    // pcp_mls_stream_begin: count the voxel set and cut its key range into chunks of whole tiles
+    VoxelDesc v{};
+    std::vector<int64_t> prefix;
+    unsigned long long total = 0;
+    if ((rc = vgd_prepare(ctx, cv, p, &v, &prefix, &total)) != PCP_OK) return rc;
+    const VgdStream S = vgd_stream_of(cv, p, g, v);
+    ctx->vgd_blob.assign(reinterpret_cast<const uint8_t *>(&S), reinterpret_cast<const uint8_t *>(&S) + sizeof(S));
+    ctx->vgd_chunks.clear();
+    const int64_t tiles = static_cast<int64_t>(prefix.size()) - 1;
+    int64_t t0 = 0;
+    while (t0 < tiles) {
+      int64_t t1 = t0 + 1;
+      while (t1 < tiles && prefix[static_cast<size_t>(t1) + 1] - prefix[static_cast<size_t>(t0)] <= stream_capacity) ++t1;
+      const int64_t cnt = prefix[static_cast<size_t>(t1)] - prefix[static_cast<size_t>(t0)];
+      if (cnt > 0) {
+        ctx->vgd_chunks.push_back(t0 * kScanTile);
+        ctx->vgd_chunks.push_back(std::min<int64_t>(t1 * kScanTile, v.words));
+        ctx->vgd_chunks.push_back(cnt);
+      }
+      t0 = t1;
+    }
+    ctx->vgd_next = 0;
+    if (out_count) *out_count = static_cast<int64_t>(total);
+    return PCP_OK;
   }
   if (p->upsampling == 3) return voxel_grid_dilation(ctx, cv, p, g, out_count);
   // points with < 3 neighbours are dropped; output keeps the input order
@@ -2228,6 +2305,46 @@ int pcp_mls_process(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_coun
   return mls_run(ctx, uploaded_view(ctx), p, out_count);
 }
 
+int pcp_mls_stream_begin(pcp_context *ctx, const pcp_mls_params *p, int64_t chunk_capacity, int64_t *out_total,
+                         int32_t *out_chunks) {
+  if (!ctx) return PCP_ERR_INVALID;
+  int rc = check_mls_params(ctx, p);
+  if (rc != PCP_OK) return rc;
+  if (p->upsampling != 3) return set_error(ctx, PCP_ERR_INVALID, "pcp_mls_stream_begin: upsampling must be VOXEL_GRID_DILATION (3)");
+  if (chunk_capacity < 32768 || chunk_capacity >= (int64_t(1) << 31))
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_mls_stream_begin: chunk_capacity must be in [32768, 2^31)");
+  if (!ctx->xyz.p) return set_error(ctx, PCP_ERR_STATE, "pcp_mls_stream_begin: no cloud uploaded");
+  if (int rcf = require_finite_cloud(ctx, "pcp_mls_stream_begin")) return rcf;
+  PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ctx->vgd_next = -1;
+  int64_t total = 0;
+  if ((rc = mls_run(ctx, uploaded_view(ctx), p, &total, 0, -1, false, chunk_capacity)) != PCP_OK) return rc;
+  if (out_total) *out_total = total;
+  if (out_chunks) *out_chunks = static_cast<int32_t>(ctx->vgd_chunks.size() / 3);
+  return PCP_OK;
+}
+
+int pcp_mls_stream_next(pcp_context *ctx, int64_t *out_count) {
+  if (!ctx || !out_count) return PCP_ERR_INVALID;
+  *out_count = 0;
+  if (ctx->vgd_next < 0 || ctx->vgd_blob.size() != sizeof(VgdStream))
+    return set_error(ctx, PCP_ERR_STATE, "pcp_mls_stream_next: no stream (call pcp_mls_stream_begin)");
+  PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t k = static_cast<size_t>(ctx->vgd_next) * 3;
+  if (k >= ctx->vgd_chunks.size()) {  // past the last chunk
+    ctx->mls_count = 0;
+    return PCP_OK;
+  }
+  VgdStream S;
+  std::memcpy(&S, ctx->vgd_blob.data(), sizeof(S));
+  int64_t m = 0;
+  const int rc = vgd_emit(ctx, S, ctx->vgd_chunks[k], ctx->vgd_chunks[k + 1], ctx->vgd_chunks[k + 2], &m);
+  if (rc != PCP_OK) return rc;
+  ctx->vgd_next += 1;
+  *out_count = m;
+  return PCP_OK;
+}
+
 int pcp_mls_process_shard(pcp_context *ctx, const pcp_mls_params *p, int64_t index_begin, int64_t index_end,
                           int64_t *out_count) {
   if (!ctx) return PCP_ERR_INVALID;
@@ -2398,8 +2515,16 @@ int pcp_close_pairs(pcp_context *ctx, double radius, int64_t *points_with_close_
   const CloudView cv = uploaded_view(ctx);
   if (cv.n < 2) return PCP_OK;
   GridDesc g;
-  // the grid builder grows the cell until the table fits; reach = ceil(radius / cell) stays 1 for micrometre radii
-  int rc = build_grid(ctx, cv, static_cast<float>(radius) * 1.001f, static_cast<float>(radius), &g);
+  // Cell edge: the radius, but never finer than ~8 cells per point.  A micrometre radius on a map tens of metres across
+  // would otherwise take the finest grid there is (2^35 cells: 6 GiB of bitmap and running popcounts, a 4 GiB memset
+  // and a scan over 2^29 words, all for one count -- ADVICE r2); with the coarser cell the search is as exact (reach =
+  // ceil(radius / cell) = 1, every pair closer than the radius lies in adjacent cells) and the table stays a few
+  // entries per point.
+  const double vol = std::max<double>(cv.mx[0] - cv.mn[0], 1e-3) * std::max<double>(cv.mx[1] - cv.mn[1], 1e-3) *
+                     std::max<double>(cv.mx[2] - cv.mn[2], 1e-3);
+  const float by_density = static_cast<float>(std::cbrt(vol / (8.0 * static_cast<double>(cv.n))));
+  const float cell = std::max(static_cast<float>(radius) * 1.001f, by_density);
+  int rc = build_grid(ctx, cv, cell, static_cast<float>(radius), &g);
   if (rc != PCP_OK) return rc;
   const size_t plane = (static_cast<size_t>(cv.n) + 3) & ~size_t(3);
   PCP_HIP_TRY(ctx, ctx->s_counter.ensure(4));

@@ -33,17 +33,28 @@ __device__ __forceinline__ int32_t scan_block_exclusive(int32_t v, int32_t *tota
   return base + incl - v;
 }
 
+// A launch holds fewer than 2^32 work-items (the dispatch packet counts them in 32 bits), i.e. fewer than 2^24
+// workgroups of 256: the per-tile kernels walk the tiles with the grid's stride and their launches are capped
+// (scan_grid), so that arrays of more than 2^34 entries -- the voxel bitmap of a map at 1 mm -- are covered.
+constexpr int64_t kScanMaxGrid = int64_t(1) << 22;
+static inline uint32_t scan_grid(int64_t tiles) {
+  return static_cast<uint32_t>(tiles < 1 ? 1 : (tiles > kScanMaxGrid ? kScanMaxGrid : tiles));
+}
+
 static __global__ __launch_bounds__(kScanBlock) void k_scan_tile_sums(const int32_t *__restrict__ in, int64_t n,
                                                                       int32_t *__restrict__ tile_sum) {
   __shared__ int32_t ws[kScanBlock / 64];
-  const int64_t base = static_cast<int64_t>(blockIdx.x) * kScanTile + threadIdx.x * 4;
-  int32_t c = 0;
+  const int64_t tiles = (n + kScanTile - 1) / kScanTile;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t base = tile * kScanTile + threadIdx.x * 4;
+    int32_t c = 0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (base + k < n) c += in[base + k];
-  int32_t total;
-  (void)scan_block_exclusive(c, &total, ws);
-  if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
+    for (int k = 0; k < 4; ++k)
+      if (base + k < n) c += in[base + k];
+    int32_t total;
+    (void)scan_block_exclusive(c, &total, ws);
+    if (threadIdx.x == 0) tile_sum[tile] = total;
+  }
 }
 
 // single block: exclusive scan of tile sums in place; grand total to *total
@@ -72,20 +83,23 @@ static __global__ __launch_bounds__(kScanBlock) void k_scan_apply(const int32_t 
                                                                   const int32_t *__restrict__ tile_offset,
                                                                   int32_t *out) {
   __shared__ int32_t ws[kScanBlock / 64];
-  const int64_t base = static_cast<int64_t>(blockIdx.x) * kScanTile + threadIdx.x * 4;
-  int32_t v[4];
-  int32_t c = 0;
+  const int64_t tiles = (n + kScanTile - 1) / kScanTile;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t base = tile * kScanTile + threadIdx.x * 4;
+    int32_t v[4];
+    int32_t c = 0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    v[k] = base + k < n ? in[base + k] : 0;
-    c += v[k];
-  }
-  int32_t total;
-  int32_t run = tile_offset[blockIdx.x] + scan_block_exclusive(c, &total, ws);
+    for (int k = 0; k < 4; ++k) {
+      v[k] = base + k < n ? in[base + k] : 0;
+      c += v[k];
+    }
+    int32_t total;
+    int32_t run = tile_offset[tile] + scan_block_exclusive(c, &total, ws);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (base + k < n) out[base + k] = run;
-    run += v[k];
+    for (int k = 0; k < 4; ++k) {
+      if (base + k < n) out[base + k] = run;
+      run += v[k];
+    }
   }
 }
 

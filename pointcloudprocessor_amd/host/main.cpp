@@ -23,6 +23,9 @@
 //     zbuffer = view_culling (view_culling.cpp:52-174, the routine north_star names; its call is commented out at :43);
 //     hpr = hidden_points_removal (:266-334), the routine the reference binary actually calls (:46), flip + convex
 //     hull on the GPU; hpr_candidates = only its candidate filter (:276-288), a frustum cull.
+//   * --mlsVoxelSize v, --mlsDilationIterations k, --mlsUpsampling none|vgd (new): the three MLSParameters the reference
+//     hard-codes (upsampling VOXEL_GRID_DILATION, 0.001 m, 4 iterations, PointCloudProcessor.cpp:78-81; the defaults here);
+//     at 1 mm x 4 every input point becomes up to 729 output points.
 //   * --gpus N (new, default 1): the map is sharded by point index over N GPUs of this node (pcp_multi.hpp: one
 //     process, N contexts, RCCL all-reduce(MIN) of the depth maps over xGMI, images broadcast over xGMI); every
 //     output file is identical to the one-GPU run.  The NID refinement sums its joint histograms over the shards
@@ -62,6 +65,9 @@ struct Options {
   bool skip_filtered_dumps = false;
   int gpus = 1;
   int cull_mode = PCP_CULL_ZBUFFER;
+  float mls_voxel_size = -1.0f;  // < 0: the reference's constants (PointCloudProcessor.cpp:67-86)
+  int mls_dilation_iterations = -1;
+  int mls_upsampling = -1;
 };
 
 static bool parse_bool(const std::string &v) {  // boost::program_options bool semantics
@@ -99,6 +105,14 @@ static Options parse(int argc, char **argv) {
     else if (a == "--enableInitialGuessManual") o.enableInitialGuessManual = parse_bool(next());
     else if (a == "--skip_filtered_dumps") o.skip_filtered_dumps = parse_bool(next());
     else if (a == "--gpus") o.gpus = std::stoi(next());
+    else if (a == "--mlsVoxelSize") o.mls_voxel_size = std::stof(next());
+    else if (a == "--mlsDilationIterations") o.mls_dilation_iterations = std::stoi(next());
+    else if (a == "--mlsUpsampling") {
+      const std::string v = next();
+      if (v == "none") o.mls_upsampling = 0;
+      else if (v == "vgd") o.mls_upsampling = 3;
+      else throw std::runtime_error("the argument ('" + v + "') for option '--mlsUpsampling' is invalid (none, vgd)");
+    }
     else if (a == "--cull") {
       const std::string v = next();
       if (v == "zbuffer") o.cull_mode = PCP_CULL_ZBUFFER;
@@ -220,6 +234,9 @@ class Processor {
       CloudSmooth smooth(mls_gpu);
       pcp_mls_params mp;
       pcp_default_mls_params(&mp);  // PointCloudProcessor.cpp:67-86
+      if (opt.mls_voxel_size > 0.0f) mp.vgd_voxel_size = opt.mls_voxel_size;
+      if (opt.mls_dilation_iterations >= 0) mp.vgd_iterations = opt.mls_dilation_iterations;
+      if (opt.mls_upsampling >= 0) mp.upsampling = opt.mls_upsampling;
       smooth.initialize(mp);
       SmoothedCloud s = smooth.processWithOutlierRemoval();
       const std::string mlsPath = fs::path(cropPath).stem().string() + "_mls.pcd";  // CWD-relative, sic (B14)
@@ -230,6 +247,12 @@ class Processor {
         cloud.y[i] = s.xyz[3 * i + 1];
         cloud.z[i] = s.xyz[3 * i + 2];
         cloud.intensity[i] = 0.0f;  // PointNormal carries no intensity (copyPointCloud, :144)
+      }
+      if (const char *dump = std::getenv("PCP_CLI_DUMP_SMOOTHED")) {
+        // test hook: the smoothed cloud as the colour stage receives it (raw fp32 xyz triples; the ASCII file above
+        // carries 8 significant digits, one short of a float's round trip)
+        std::ofstream df(dump, std::ios::binary);
+        df.write(reinterpret_cast<const char *>(s.xyz.data()), static_cast<std::streamsize>(s.xyz.size() * sizeof(float)));
       }
     } else {
       cloud = std::move(original);  // the reference reloads the same file (:148)

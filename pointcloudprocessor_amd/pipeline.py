@@ -223,7 +223,25 @@ class VisualLiDARCalibration:
                 import torch
 
                 torch.cuda.synchronize()
-        return ctx.nid_finish(bins)
+        cost, grad, ok = ctx.nid_finish(bins)
+        if self.world > 1:
+            # every rank derives (cost, gradient) from the same summed histograms, so every rank's optimiser takes the
+            # same steps without a broadcast -- IF the all-reduce hands every rank the same bits.  Checked instead of
+            # assumed: a rank that saw different numbers would walk a different line search and the ranks would wait
+            # for each other in different collectives for ever.
+            import torch
+            import torch.distributed as dist
+
+            mine = torch.tensor([cost, *[float(g) for g in grad], float(ok)], dtype=torch.float64).view(torch.int64)  # bit patterns: NaN == NaN
+            lo, hi = mine.clone(), mine.clone()
+            if dist.get_backend(self.group) == "nccl":
+                lo, hi = lo.cuda(), hi.cuda()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+            if not torch.equal(lo.cpu(), hi.cpu()):
+                raise RuntimeError("NID cost / gradient differ between the ranks after the all-reduce of the histograms: "
+                                   f"min {lo.tolist()} max {hi.tolist()}")
+        return cost, grad, ok
 
     def calibrate(self, T_init=None, bins: int = 16, max_outer_iterations: int = 10):
         """T_camera_lidar_optimized (4x4), final cost, evaluations -- identity initial guess as calibrate.cpp:45-51"""

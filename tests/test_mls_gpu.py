@@ -257,3 +257,37 @@ def test_mls_query_shards_concatenate_to_the_full_result(gpu_ctx_factory):
         assert np.array_equal(np.concatenate([p[k] for p in parts]), full[k]), k
     with pytest.raises(capi.PcpError):
         ctx.mls_process_shard(mp, 10, 5)
+
+
+def test_voxel_dilation_stream_equals_one_shot(gpu_ctx_factory):
+    """pcp_mls_stream_begin / _next: the dilated voxel set counted in 64 bits and emitted in ascending key order chunk by
+    chunk -- the concatenation is the one-shot result, bit for bit, whatever the chunk size."""
+    from pointcloudprocessor_amd import capi
+
+    x, y, z = _patches(seed=23, n=6000)
+    ctx = gpu_ctx_factory()
+    ctx.upload_cloud(x, y, z)
+    mp = capi.default_mls_params()
+    mp.vgd_voxel_size = 0.002
+    mp.vgd_iterations = 2
+    full = ctx.mls_fetch(ctx.mls_process(mp))
+    assert len(full["index"]) > 300_000
+    for cap in (32768, 100_000, 1 << 22):
+        total, chunks = ctx.mls_stream_begin(mp, cap)
+        parts = []
+        while True:
+            m = ctx.mls_stream_next()
+            if m == 0:
+                break
+            assert m <= cap
+            parts.append(ctx.mls_fetch(m))
+        assert len(parts) == chunks and (chunks > 3 or cap > 100_000)
+        assert total >= len(full["index"])  # voxels whose nearest point has no valid fit are counted but not emitted
+        for k in ("index", "xyz", "normal", "curvature"):
+            assert np.array_equal(np.concatenate([q[k] for q in parts]), full[k]), (cap, k)
+    assert ctx.mls_stream_next() == 0  # past the end: nothing, no error
+    with pytest.raises(capi.PcpError):
+        ctx.mls_stream_begin(mp, 1000)  # below one tile's worst case
+    mp.upsampling = 0
+    with pytest.raises(capi.PcpError):
+        ctx.mls_stream_begin(mp, 1 << 20)
