@@ -71,6 +71,9 @@ def parse():
                     help="gloo: rehearsal of the N > 1 path on fewer GPUs than ranks (ranks share devices); not a measurement")
     ap.add_argument("--dist-chunks", type=int, default=0,
                     help="keyframe groups whose all-reduce overlaps the next depth pass (0 = by the size of the depth maps)")
+    ap.add_argument("--verify", action="store_true",
+                    help="N > 1: the ranks' shares are slices of ONE seeded map, and after the timed region the gathered "
+                         "colours are compared with a one-GPU run of the whole map on rank 0 (first multi-GPU lease)")
     ap.add_argument("--match-mode", default="roundtrip", choices=["roundtrip", "identity"],
                     help="pcp_cull_params.match_mode (default: the reference's fp32 round-trip arithmetic)")
     return ap.parse_args()
@@ -166,8 +169,16 @@ def main():
     t_setup = time.time()
     eng = pipeline.HipEngine(local_rank)
     eng.configure(cam, cull)
-    # every rank samples its own share of the map (the seeds differ: together the shares are one N x world-point map)
-    x, y, z, _ = synth.make_cloud(N, seed=synth.SEED + 1000 * rank)
+    if args.verify and sharded:
+        # one seeded map, every rank takes its index slice: the sharded result can be compared with a one-GPU run
+        fx, fy, fz, _ = synth.make_cloud(N * world, seed=synth.SEED)
+        lo, hi = pipeline.shard_bounds(N * world, rank, world)
+        x, y, z = fx[lo:hi].copy(), fy[lo:hi].copy(), fz[lo:hi].copy()
+        if rank != 0:
+            del fx, fy, fz
+    else:
+        # every rank samples its own share of the map (the seeds differ: together the shares are one N x world-point map)
+        x, y, z, _ = synth.make_cloud(N, seed=synth.SEED + 1000 * rank)
     eng.upload_cloud(x, y, z)
     poses, _ = synth.make_trajectory(F)
     eng.ctx.set_frames(poses)
@@ -255,6 +266,24 @@ def main():
 
     result = None
     coloured = int(((pinned[(step_no[0] - 1) & 1].numpy().view(np.uint32) >> 24) & 1).sum())
+    verify = None
+    if args.verify and sharded:
+        # the shards' colours, all-gathered, against the whole map coloured by ONE context on rank 0
+        local = col.run(download=True)
+        full = col.gather(local, N * world)
+        if rank == 0:
+            one = pipeline.HipEngine(local_rank)
+            one.configure(cam, cull)
+            one.upload_cloud(fx, fy, fz)
+            one.ctx.set_frames(poses)
+            for f in range(F):
+                one.ctx.upload_image(f, synth.make_image(f, W, H))
+            ref = one.ctx.colorize()
+            one.close()
+            same = bool(np.array_equal(ref["rgb"], full["rgb"]) and np.array_equal(ref["has"], full["has"]))
+            verify = {"equal_to_one_gpu_run": same, "points": int(N * world), "keyframes": int(F),
+                      "coloured": int(full["has"].sum()), "differing_points": int((ref["rgb"] != full["rgb"]).any(axis=1).sum())}
+            del fx, fy, fz
     # ---- per-kernel times of one more step (hipEvents on the launch stream).  Every rank takes the step:
     # with N > 1 it contains the all-reduce, a collective ----
     eng.ctx.timing_enable(True)
@@ -601,7 +630,7 @@ def main():
                 mls = {"error": str(e)}
         # ---- CPU baseline: the oracle on a bounded sample, all host cores (rank 0, N = 1 only) ----
         cpu = None
-        if not args.no_cpu and world == 1:
+        if not args.no_cpu:  # rank 0 only (this whole block); at N > 1 the other ranks wait at the closing barrier
             from oracle import oracle_capi as oc
 
             ocam = oc.Camera()
@@ -680,6 +709,8 @@ def main():
             "nid": nid,
             "mls": mls,
         }
+        if verify is not None:
+            result["verify"] = verify
         if args.backend != "nccl":
             result["rehearsal"] = f"backend {args.backend}: ranks share GPUs, not a measurement"
         # the two boundaries side by side: `value` is the contract's -- inputs resident in HBM when the

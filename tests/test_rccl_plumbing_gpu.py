@@ -65,7 +65,8 @@ def test_bench_two_rank_path_runs_to_completion():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--points", "200000",
-           "--frames", "8", "--steps", "1", "--warmup", "1", "--roofline-points", "2000000"]
+           "--frames", "8", "--steps", "1", "--warmup", "1", "--roofline-points", "2000000", "--settle-ms", "0", "--verify",
+           "--cpu-points", "100000", "--cpu-frames", "2"]
     proc = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=root)
     assert proc.returncode == 0, proc.stderr[-2000:]
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
@@ -75,3 +76,6 @@ def test_bench_two_rank_path_runs_to_completion():
     assert line["config"]["points_total"] == 400000 and "configs[3]" in line["config"]["workload"]
     assert line["roofline"]["frac"] > 0  # the roofline leg stays on rank 0 at N > 1
     assert "rehearsal" in line
+    # --verify: the two shards' colours, all-gathered, equal a one-GPU run of the whole 400 k-point map on rank 0
+    assert line["verify"]["equal_to_one_gpu_run"] is True and line["verify"]["coloured"] > 0
+    assert line["cpu_baseline"]["value"] > 0  # reported at N > 1 as well (rank 0)
