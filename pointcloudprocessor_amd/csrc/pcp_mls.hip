@@ -478,6 +478,10 @@ __global__ __launch_bounds__(kFitBlock) void k_mls_fit(MlsArgs a) {
     }
   };
 
+  // From here on the arithmetic is the fit's own fp64 work on fp32 data, compared with the oracle within tolerances (3 um,
+  // 1e-4), not bit for bit -- PCL's Eigen code is itself free to fuse -- so the multiply-adds of the two sweeps are written
+  // as fma (the compiler had fused them already: the object code did not change).  The neighbour SELECTION above (fp32,
+  // FLANN's exact form) decides index sets and keeps its individually rounded operations.
   // sweep 1: moments of (p - q)
   double s1x = 0, s1y = 0, s1z = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
   if (K >= 3)
@@ -486,8 +490,8 @@ __global__ __launch_bounds__(kFitBlock) void k_mls_fit(MlsArgs a) {
       const double dy = static_cast<double>(py) - static_cast<double>(qy);
       const double dz = static_cast<double>(pz) - static_cast<double>(qz);
       s1x += dx; s1y += dy; s1z += dz;
-      sxx += dx * dx; sxy += dx * dy; sxz += dx * dz;
-      syy += dy * dy; syz += dy * dz; szz += dz * dz;
+      sxx = fma(dx, dx, sxx); sxy = fma(dx, dy, sxy); sxz = fma(dx, dz, sxz);
+      syy = fma(dy, dy, syy); syz = fma(dy, dz, syz); szz = fma(dz, dz, szz);
     });
   if (K < 3) {  // MovingLeastSquares::performProcessing skips the point
     a.flag[i] = 0;
@@ -548,20 +552,22 @@ __global__ __launch_bounds__(kFitBlock) void k_mls_fit(MlsArgs a) {
       // ~2e-7 relative error moves the fitted surface by ~1e-7 of its millimetre-scale offset -- five orders below
       // the 3 um parity bar -- while ocml's fp64 exp costs ~40 of this loop's ~100 VALU instructions per neighbour
       // (k_mls_fit 10 M points: 5.99 -> 5.5 ms).
-      const double w = static_cast<double>(__expf(static_cast<float>(-((dx * dx + dy * dy) + dz * dz) * a.inv_sq_radius)));
-      const double uc = (dx * ux + dy * uy) + dz * uz;
-      const double vc = (dx * vx + dy * vy) + dz * vz;
-      const double f = (dx * nrm[0] + dy * nrm[1]) + dz * nrm[2];
+      const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+      const double w = static_cast<double>(__expf(static_cast<float>(-d2 * a.inv_sq_radius)));
+      const double uc = fma(dz, uz, fma(dy, uy, dx * ux));
+      const double vc = fma(dz, vz, fma(dy, vy, dx * vx));
+      const double f = fma(dz, nrm[2], fma(dy, nrm[1], dx * nrm[0]));
       const double p1 = vc, p2 = vc * vc, p3 = uc, p4 = uc * vc, p5 = uc * uc;
       const double w1 = w * p1, w2 = w * p2, w3 = w * p3, w4 = w * p4, w5 = w * p5;
       // the 21 entries of P W P^T are sums of w u^a v^b with a + b <= 4: only 15 distinct monomials
       A00 += w; A01 += w1; A02 += w2; A03 += w3; A04 += w4; A05 += w5;
-      A12 += w1 * p2; A14 += w1 * p4; A15 += w1 * p5;
-      A22 += w2 * p2; A24 += w2 * p4; A25 += w2 * p5;
-      A35 += w3 * p5;
-      A45 += w4 * p5;
-      A55 += w5 * p5;
-      b0 += w * f; b1 += w1 * f; b2 += w2 * f; b3 += w3 * f; b4 += w4 * f; b5 += w5 * f;
+      A12 = fma(w1, p2, A12); A14 = fma(w1, p4, A14); A15 = fma(w1, p5, A15);
+      A22 = fma(w2, p2, A22); A24 = fma(w2, p4, A24); A25 = fma(w2, p5, A25);
+      A35 = fma(w3, p5, A35);
+      A45 = fma(w4, p5, A45);
+      A55 = fma(w5, p5, A55);
+      b0 = fma(w, f, b0); b1 = fma(w1, f, b1); b2 = fma(w2, f, b2); b3 = fma(w3, f, b3); b4 = fma(w4, f, b4);
+      b5 = fma(w5, f, b5);
     });
     A11 = A02;  // w v^2
     A13 = A04;  // w u v

@@ -525,3 +525,54 @@ def test_cli_enable_mls_end_to_end(tmp_path, oracle):
     packed = (0xFF000000 | (ref["rgb"][sel, 0].astype(np.uint64) << 16) | (ref["rgb"][sel, 1].astype(np.uint64) << 8)
               | ref["rgb"][sel, 2].astype(np.uint64))
     assert np.array_equal(got_rgb, packed)
+
+
+@pytest.mark.gpu
+def test_cli_cull_hpr_end_to_end(tmp_path, oracle):
+    """--cull hpr: the cull the reference binary actually runs (hidden_points_removal, view_culling.cpp:46,266-334) through
+    the command line -- per-keyframe dumps and final colours against the oracle's ORC_CULL_HPR."""
+    from pointcloudprocessor_amd import synth
+
+    W, H = 1024, 750
+    x, y, z, inten = synth.make_cloud(200_000, seed=13)
+    _write_pcd_binary(tmp_path / "scans.pcd", x, y, z, inten)
+    poses, ts = synth.make_trajectory(4)
+    imgs = []
+    with open(tmp_path / "odo.txt", "w") as f:
+        for k, (t, p) in enumerate(zip(ts, poses)):
+            f.write(synth.odometry_line(t, p))
+            img = synth.make_image(k, W, H)
+            imgs.append(img)
+            with open(tmp_path / ("%f.ppm" % t), "wb") as g:
+                g.write(b"P6\n%d %d\n255\n" % (W, H) + img[:, :, ::-1].tobytes())
+    out = str(tmp_path) + "/"
+    p = subprocess.run([_exe(), "-p", str(tmp_path / "scans.pcd"), "-o", str(tmp_path / "odo.txt"), "-i", out, "-t", out,
+                        "--cull", "hpr"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    cam = oracle.default_camera()
+    cam.image_width, cam.image_height = W, H  # cull size stays 4096x3000
+    cp = oracle.default_cull_params()
+    cp.cull_mode = oracle.CULL_HPR
+    dropped = 0
+    for k in range(len(poses)):
+        w2c, _ = oracle.pose_to_matrices(poses[k])
+        keep, st = oracle.hpr_frame(cam, w2c, x, y, z)
+        _, rows = _read_pcd_ascii(tmp_path / "filtered_pcd" / ("%f_beforeNID.pcd" % ts[k]))
+        assert len(rows) == st["kept"] > 0
+        dropped += st["candidates"] - st["kept"]
+    assert dropped > 100  # the hull really removed points on this scene
+    imgs = [oracle.hsv_round_trip(im) for im in imgs]
+    ref = oracle.colorize(cam, cp, x, y, z, poses, imgs, threads=8, want_top=False)
+    _, rows = _read_pcd_ascii(tmp_path / "cloudInWorldWithRGB.pcd")
+    sel = np.nonzero(ref["has"])[0]
+    assert len(rows) == len(sel) > 100
+    got_rgb = np.array([int(r[3]) for r in rows], dtype=np.uint64)
+    packed = (0xFF000000 | (ref["rgb"][sel, 0].astype(np.uint64) << 16) | (ref["rgb"][sel, 1].astype(np.uint64) << 8)
+              | ref["rgb"][sel, 2].astype(np.uint64))
+    assert np.array_equal(got_rgb, packed)
+    # the hull needs the whole map on one GPU
+    p = subprocess.run([_exe(), "-p", str(tmp_path / "scans.pcd"), "-o", str(tmp_path / "odo.txt"), "-i", out, "-t", out,
+                        "--cull", "hpr", "--gpus", "2"], capture_output=True, text=True, env=dict(os.environ, PCP_MULTI_REHEARSAL="1"))
+    assert p.returncode == 254 and "--cull hpr" in p.stderr
+    p = subprocess.run([_exe(), "-p", "a", "-o", "b", "-i", "c", "--cull", "qhull"], capture_output=True, text=True)
+    assert p.returncode == 254
