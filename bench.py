@@ -43,6 +43,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PROJ_BYTES_PER_POINT = 20  # 12 B xyz read + 4 B cell + 4 B range written
 PMC_SUMMARY = "r03_pmc.json"  # profiles/: summary of the rocprofv3 --pmc passes of this command (profiles/summarise_pmc.py)
+MLS_PMC_SUMMARY = "r03_mls_pmc.json"  # profiles/: PMC summary of MLS alone (profiles/collect_mls.sh)
 SIMDS, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md max clock
 C3_POINTS, C3_FRAMES = 50_000_000, 1024  # BASELINE.json configs[3]
 
@@ -520,6 +521,27 @@ def main():
                        "radius": 0.03, "order": 2, "upsampling": "NONE", "ms": round(t_mls * 1e3, 2),
                        "kernels_ms": {eng.ctx.kernel_name(k): round(eng.ctx.timing_get(k)[0], 3)
                                       for k in (capi.K_MLS_GRID, capi.K_MLS_FIT)}}
+                # "MLS is gather / LDS-bound with an FP64 tail; report HBM GB/s for it but no fraction target".
+                # HBM traffic and issue counters of k_mls_fit from the recorded rocprofv3 PMC passes of this workload
+                # (profiles/collect_mls.sh: SQ counters, FETCH_SIZE, WRITE_SIZE in separate passes), against the kernel's
+                # duration in THIS run
+                try:
+                    with open(os.path.join(ROOT, "profiles", MLS_PMC_SUMMARY)) as fh:
+                        mp_pmc = json.load(fh).get("k_mls_fit", {})
+                    fit_ms = eng.ctx.timing_get(capi.K_MLS_FIT)[0]
+                    if nm == 10_000_000 and "FETCH_SIZE" in mp_pmc and fit_ms > 0:
+                        hbm = (2 * mp_pmc["FETCH_SIZE"] + mp_pmc["WRITE_SIZE"]) * 1024  # gfx950: FETCH_SIZE counts 64 B as 32
+                        issue_ms = mp_pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (SIMDS * CLOCK_GHZ * 1e9) * 1e3
+                        mls["k_mls_fit"] = {
+                            "source": f"profiles/{MLS_PMC_SUMMARY} (recorded PMC passes of profiles/mls_probe.py, same workload)",
+                            "hbm_bytes": round(hbm), "hbm_GBps": round(hbm / (fit_ms * 1e-3) / 1e9, 1),
+                            "hbm_frac_of_peak": round(hbm / (fit_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 3),
+                            "algorithmic_bytes": 40 * nm, "valu_issue_ms": round(issue_ms, 3),
+                            "valu_issue_share": round(issue_ms / fit_ms, 3),
+                            "lane_utilisation": round(mp_pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * mp_pmc["SQ_ACTIVE_INST_VALU"]), 3),
+                            "bound": "vector issue + neighbour gathers through L1 / L2 (not HBM)"}
+                except (OSError, ValueError, KeyError):
+                    pass
                 # the whole CloudSmooth::process of enableMLS=1 (cloudSmooth.cpp:109-164): SOR -> MLS -> SOR on the device
                 try:
                     eng.ctx.cloud_smooth(mp)  # warm-up
