@@ -722,6 +722,12 @@ def main():
             "coloured_points_rank0": coloured,
             "kernels_ms": {k: round(v[0], 3) for k, v in kt.items()},
             "tile_pairs_kept": pairs_kept,
+            "value_note": "rate of the pruned algorithm: conservative interval tests prove (tile of 64 points, keyframe) pairs certainly "
+                          "rejected by the reference's rule and the passes skip them (tile_pairs_kept = the share that is walked; "
+                          "results equal the unpruned run and the oracle bit for bit); points x keyframes x 20 B / ms_per_step exceeds the "
+                          "HBM peak for that reason.  The bound of the step is vector issue (roofline_step); the HBM roofline claim is "
+                          "made on the unbatched single-keyframe projection kernel (roofline).  speedup_vs_cpu_baseline compares with "
+                          "the CPU restatement's unpruned loop, which is what the reference runs.",
             "setup_s": round(t_setup, 1),
             "roofline": roofline,
             "roofline_step": roofline_step,

@@ -282,6 +282,9 @@ int pcp_mls_process_shard(pcp_context *ctx, const pcp_mls_params *p, int64_t ind
 int pcp_mls_stream_begin(pcp_context *ctx, const pcp_mls_params *p, int64_t chunk_capacity, int64_t *out_total,
                          int32_t *out_chunks);
 int pcp_mls_stream_next(pcp_context *ctx, int64_t *out_count);
+/* The chunk the next pcp_mls_stream_next emits (0 .. chunks; a chunk may be emitted more than once): several GPUs that
+ * hold the same cloud and began the same stream deal the chunks out among themselves (chunk c to GPU c mod N). */
+int pcp_mls_stream_seek(pcp_context *ctx, int32_t chunk);
 /* xyz / normal 3*m floats AoS, curvature m, source index m (input order for
  * NONE; ascending voxel key for VOXEL_GRID_DILATION). */
 int pcp_mls_fetch(pcp_context *ctx, int64_t capacity, float *out_xyz, float *out_normal, float *out_curvature,

@@ -416,6 +416,9 @@ class Context:
         self._check(self.lib.pcp_mls_stream_next(self.h, C.byref(m)))
         return m.value
 
+    def mls_stream_seek(self, chunk: int):
+        self._check(self.lib.pcp_mls_stream_seek(self.h, C.c_int32(chunk)))
+
     def mls_process_shard(self, params: MLSParams, index_begin: int, index_end: int) -> int:
         cnt = C.c_int64()
         self._check(self.lib.pcp_mls_process_shard(self.h, C.byref(params), C.c_int64(index_begin), C.c_int64(index_end),

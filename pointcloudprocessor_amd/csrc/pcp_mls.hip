@@ -2351,6 +2351,17 @@ int pcp_mls_stream_next(pcp_context *ctx, int64_t *out_count) {
   return PCP_OK;
 }
 
+int pcp_mls_stream_seek(pcp_context *ctx, int32_t chunk) {
+  if (!ctx) return PCP_ERR_INVALID;
+  if (ctx->vgd_next < 0 || ctx->vgd_blob.empty())
+    return set_error(ctx, PCP_ERR_STATE, "pcp_mls_stream_seek: no stream (call pcp_mls_stream_begin)");
+  const int64_t chunks = static_cast<int64_t>(ctx->vgd_chunks.size() / 3);
+  if (chunk < 0 || chunk > chunks)
+    return set_error(ctx, PCP_ERR_RANGE, "pcp_mls_stream_seek: chunk %d outside 0..%lld", chunk, (long long)chunks);
+  ctx->vgd_next = chunk;
+  return PCP_OK;
+}
+
 int pcp_mls_process_shard(pcp_context *ctx, const pcp_mls_params *p, int64_t index_begin, int64_t index_end,
                           int64_t *out_count) {
   if (!ctx) return PCP_ERR_INVALID;

@@ -29,7 +29,8 @@
 //   * --gpus N (new, default 1): the map is sharded by point index over N GPUs of this node (pcp_multi.hpp: one
 //     process, N contexts, RCCL all-reduce(MIN) of the depth maps over xGMI, images broadcast over xGMI); every
 //     output file is identical to the one-GPU run.  The NID refinement sums its joint histograms over the shards
-//     (same optimum, last-digit differences in the printed cost); MLS runs on GPU 0.
+//     (same optimum, last-digit differences in the printed cost); --enableMLS deals the MLS queries / the dilated voxel
+//     chunks out over the GPUs (MultiCloudSmooth), the two outlier-removal brackets run on GPU 0.
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -229,16 +230,15 @@ class Processor {
         std::cerr << "Couldn't read file " << cropPath << std::endl;
         return;
       }
-      Device mls_gpu(0);
-      mls_gpu.uploadCloud(crop8.x.data(), crop8.y.data(), crop8.z.data(), static_cast<int64_t>(crop8.size()));
-      CloudSmooth smooth(mls_gpu);
+      MultiCloudSmooth smooth(opt.gpus);  // --gpus N: MLS queries / voxel chunks dealt out over the GPUs (pcp_multi.hpp)
       pcp_mls_params mp;
       pcp_default_mls_params(&mp);  // PointCloudProcessor.cpp:67-86
       if (opt.mls_voxel_size > 0.0f) mp.vgd_voxel_size = opt.mls_voxel_size;
       if (opt.mls_dilation_iterations >= 0) mp.vgd_iterations = opt.mls_dilation_iterations;
       if (opt.mls_upsampling >= 0) mp.upsampling = opt.mls_upsampling;
       smooth.initialize(mp);
-      SmoothedCloud s = smooth.processWithOutlierRemoval();
+      SmoothedCloud s = smooth.processWithOutlierRemoval(crop8.x.data(), crop8.y.data(), crop8.z.data(),
+                                                         static_cast<int64_t>(crop8.size()));
       const std::string mlsPath = fs::path(cropPath).stem().string() + "_mls.pcd";  // CWD-relative, sic (B14)
       writeASCII_PointNormal(mlsPath, s.xyz.data(), s.normal.data(), s.curvature.data(), s.curvature.size());
       cloud.resize(s.curvature.size());

@@ -347,4 +347,114 @@ class MultiDevice {
   std::string nid_error_;
 };
 
+// CloudSmooth::process (cloudSmooth.cpp:77-185) over the GPUs of a node, SURVEY.md 8(e): the cloud on EVERY GPU, the work
+// dealt out -- MLS queries by index range (pcp_mls_process_shard), the dilated voxel set by chunks of its key order
+// (pcp_mls_stream_*, chunk c to GPU c mod N) -- and the pieces put together in order on the host, which needs them anyway to
+// write <stem>_mls.pcd.  The two StatisticalOutlierRemoval brackets run on GPU 0: each is milliseconds of work whose
+// sharding would cost an exchange of the intermediate cloud.  One GPU: pcp_cloud_smooth.
+class MultiCloudSmooth {
+ public:
+  explicit MultiCloudSmooth(int n_gpus) {
+    const char *rehearsal = std::getenv("PCP_MULTI_REHEARSAL");
+    const bool one_gpu = rehearsal && rehearsal[0] == '1';
+    for (int r = 0; r < std::max(n_gpus, 1); ++r) dev_.emplace_back(new Device(one_gpu ? 0 : r));
+    pcp_default_mls_params(&params_);
+  }
+  void initialize(const pcp_mls_params &p) { params_ = p; }
+  int size() const { return static_cast<int>(dev_.size()); }
+
+  SmoothedCloud processWithOutlierRemoval(const float *x, const float *y, const float *z, int64_t n) {
+    if (size() == 1) {
+      dev_[0]->uploadCloud(x, y, z, n);
+      return CloudSmooth(*dev_[0], params_).processWithOutlierRemoval();
+    }
+    // SOR 1 (cloudSmooth.cpp:109-116)
+    std::vector<int32_t> idx1 = outlierRemoval(x, y, z, n);
+    std::vector<float> cx(idx1.size()), cy(idx1.size()), cz(idx1.size());
+    for (size_t k = 0; k < idx1.size(); ++k) {
+      cx[k] = x[idx1[k]];
+      cy[k] = y[idx1[k]];
+      cz[k] = z[idx1[k]];
+    }
+    // MLS (+ upsampling) on the survivors, on every GPU (:124-154)
+    const int64_t m1 = static_cast<int64_t>(idx1.size());
+    for (auto &d : dev_) d->uploadCloud(cx.data(), cy.data(), cz.data(), m1);
+    SmoothedCloud s;
+    auto append = [&](Device &d, int64_t count) {
+      const size_t at = s.curvature.size(), c = static_cast<size_t>(count);
+      s.xyz.resize(3 * (at + c));
+      s.normal.resize(3 * (at + c));
+      s.curvature.resize(at + c);
+      s.index.resize(at + c);
+      d.check(pcp_mls_fetch(d.get(), count, s.xyz.data() + 3 * at, s.normal.data() + 3 * at, s.curvature.data() + at,
+                            s.index.data() + at));
+    };
+    if (params_.upsampling == 0) {
+      std::vector<int64_t> counts(static_cast<size_t>(size()));
+      for (int r = 0; r < size(); ++r)  // queued on every GPU before the first fetch waits
+        dev_[static_cast<size_t>(r)]->check(pcp_mls_process_shard(dev_[static_cast<size_t>(r)]->get(), &params_, m1 * r / size(),
+                                                                  m1 * (r + 1) / size(), &counts[static_cast<size_t>(r)]));
+      for (int r = 0; r < size(); ++r) append(*dev_[static_cast<size_t>(r)], counts[static_cast<size_t>(r)]);
+    } else {
+      int32_t chunks = 0;
+      for (auto &d : dev_) {  // the same plan on every GPU (same cloud, same capacity)
+        int64_t total = 0;
+        int32_t c = 0;
+        d->check(pcp_mls_stream_begin(d->get(), &params_, int64_t(1) << 26, &total, &c));
+        if (&d != &dev_[0] && c != chunks) throw std::runtime_error("pcp_multi: the GPUs disagree about the voxel chunks");
+        chunks = c;
+      }
+      for (int32_t c = 0; c < chunks; ++c) {
+        Device &d = *dev_[static_cast<size_t>(c % size())];
+        int64_t count = 0;
+        d.check(pcp_mls_stream_seek(d.get(), c));
+        d.check(pcp_mls_stream_next(d.get(), &count));
+        append(d, count);
+      }
+    }
+    // SOR 2 on the smoothed cloud (:158-164)
+    const size_t m2 = s.curvature.size();
+    std::vector<float> sx(m2), sy(m2), sz(m2);
+    for (size_t k = 0; k < m2; ++k) {
+      sx[k] = s.xyz[3 * k];
+      sy[k] = s.xyz[3 * k + 1];
+      sz[k] = s.xyz[3 * k + 2];
+    }
+    const std::vector<int32_t> idx2 = outlierRemoval(sx.data(), sy.data(), sz.data(), static_cast<int64_t>(m2));
+    SmoothedCloud out;
+    out.xyz.resize(3 * idx2.size());
+    out.normal.resize(3 * idx2.size());
+    out.curvature.resize(idx2.size());
+    out.index.resize(idx2.size());
+    for (size_t k = 0; k < idx2.size(); ++k) {
+      const size_t j = static_cast<size_t>(idx2[k]);
+      for (int c = 0; c < 3; ++c) {
+        out.xyz[3 * k + static_cast<size_t>(c)] = s.xyz[3 * j + static_cast<size_t>(c)];
+        out.normal[3 * k + static_cast<size_t>(c)] = s.normal[3 * j + static_cast<size_t>(c)];
+      }
+      out.curvature[k] = s.curvature[j];
+      out.index[k] = idx1[static_cast<size_t>(s.index[j])];  // index into the caller's cloud
+    }
+    return out;
+  }
+
+ private:
+  // pcl::StatisticalOutlierRemoval on GPU 0: indices kept, ascending
+  std::vector<int32_t> outlierRemoval(const float *x, const float *y, const float *z, int64_t n) {
+    Device &d = *dev_[0];
+    d.uploadCloud(x, y, z, n);
+    std::vector<uint8_t> keep(static_cast<size_t>(n));
+    int64_t kept = 0;
+    d.check(pcp_sor(d.get(), params_.sor_mean_k, params_.sor_std_mul, keep.data(), &kept));
+    std::vector<int32_t> idx;
+    idx.reserve(static_cast<size_t>(kept));
+    for (int64_t i = 0; i < n; ++i)
+      if (keep[static_cast<size_t>(i)]) idx.push_back(static_cast<int32_t>(i));
+    return idx;
+  }
+
+  std::vector<std::unique_ptr<Device>> dev_;
+  pcp_mls_params params_;
+};
+
 }  // namespace pcp_amd

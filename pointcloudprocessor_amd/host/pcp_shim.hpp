@@ -171,6 +171,7 @@ struct SmoothedCloud {  // pcl::PointCloud<pcl::PointNormal> mls_points + corres
 class CloudSmooth {
  public:
   explicit CloudSmooth(Device &dev) : dev_(dev) { pcp_default_mls_params(&params_); }
+  CloudSmooth(Device &dev, const pcp_mls_params &p) : dev_(dev), params_(p) {}
   void initialize(const pcp_mls_params &p) { params_ = p; }  // CloudSmooth::initialize(MLSParameters)
   // the whole CloudSmooth::process: SOR -> MLS (+ upsampling) -> SOR (cloudSmooth.cpp:109-164)
   SmoothedCloud processWithOutlierRemoval() const { return run(true); }

@@ -576,3 +576,49 @@ def test_cli_cull_hpr_end_to_end(tmp_path, oracle):
     assert p.returncode == 254 and "--cull hpr" in p.stderr
     p = subprocess.run([_exe(), "-p", "a", "-o", "b", "-i", "c", "--cull", "qhull"], capture_output=True, text=True)
     assert p.returncode == 254
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("upsampling", ["vgd", "none"])
+def test_cli_enable_mls_over_three_gpus_rehearsal(tmp_path, upsampling):
+    """--enableMLS 1 --gpus 3 (MultiCloudSmooth: the MLS queries, or the dilated voxel chunks, dealt out over the GPUs;
+    here three contexts on the one GPU, PCP_MULTI_REHEARSAL=1) against --gpus 1 (pcp_cloud_smooth): the same rows.
+    Not byte-equal by construction: the intermediate clouds are re-uploaded, hence re-sorted, so fp64 sums run in another
+    order and a coordinate may differ in its last fp32 bit; compared at 2e-6."""
+    from pointcloudprocessor_amd import synth
+    from oracle import np_oracle as npo
+
+    W, H = 640, 480
+    rng = np.random.default_rng(31)
+    poses, ts = synth.make_trajectory(3, spacing=0.12)
+    n = 30_000
+    p0 = poses[0, :3]
+    R0 = npo.quat_to_rot(*poses[0, 3:7])
+    a, b = rng.uniform(-0.8, 0.8, n), rng.uniform(-0.8, 0.8, n)
+    depth = 1.7 + 0.04 * np.cos(4.0 * b) + rng.normal(0, 1e-3, n)
+    wall = p0 + a[:, None] * R0[:, 0] + b[:, None] * R0[:, 1] + depth[:, None] * R0[:, 2]
+    stray = rng.uniform(-1.0, 1.0, (200, 3)) + p0 + 0.5 * R0[:, 2]
+    pts = np.concatenate([wall, stray]).astype(np.float32)
+    _write_pcd_binary(tmp_path / "scans.pcd", pts[:, 0], pts[:, 1], pts[:, 2], rng.random(len(pts), dtype=np.float32))
+    with open(tmp_path / "odo.txt", "w") as f:
+        for k, (t, p) in enumerate(zip(ts, poses)):
+            f.write(synth.odometry_line(t, p))
+            img = synth.make_image(k, W, H)
+            with open(tmp_path / ("%f.ppm" % t), "wb") as g:
+                g.write(b"P6\n%d %d\n255\n" % (W, H) + img[:, :, ::-1].tobytes())
+    rows = {}
+    for gpus in (1, 3):
+        out = tmp_path / f"g{gpus}"
+        out.mkdir()
+        p = subprocess.run([_exe(), "-p", str(tmp_path / "scans.pcd"), "-o", str(tmp_path / "odo.txt"), "-i", str(tmp_path) + "/",
+                            "-t", str(out) + "/", "--enableMLS", "1", "--mlsVoxelSize", "0.004", "--mlsDilationIterations", "1",
+                            "--mlsUpsampling", upsampling, "--gpus", str(gpus), "--skip_filtered_dumps", "1"],
+                           capture_output=True, text=True, cwd=out, env=dict(os.environ, PCP_MULTI_REHEARSAL="1"))
+        assert p.returncode == 0, p.stderr[-2000:]
+        _, r = _read_pcd_ascii(out / "scans-crop_mls.pcd")
+        rows[gpus] = np.array([[float(v) for v in row] for row in r])
+    assert rows[1].shape == rows[3].shape and len(rows[1]) > (100_000 if upsampling == "vgd" else 20_000)
+    assert np.abs(rows[1][:, :3] - rows[3][:, :3]).max() <= 2e-6
+    sgn = np.sign((rows[1][:, 3:6] * rows[3][:, 3:6]).sum(axis=1))
+    assert np.abs(rows[1][:, 3:6] * sgn[:, None] - rows[3][:, 3:6]).max() <= 2e-4
+    np.testing.assert_allclose(rows[1][:, 6], rows[3][:, 6], rtol=2e-4, atol=1e-8)
