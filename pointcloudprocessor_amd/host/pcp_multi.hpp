@@ -46,7 +46,7 @@ class MultiDevice {
     for (int i = 0; i < n_gpus; ++i) dev_.emplace_back(new Device(ordinal(i)));
     if (n_gpus == 1) return;
     stream_.resize(static_cast<size_t>(n_gpus));
-    stage_.assign(static_cast<size_t>(n_gpus), nullptr);
+    stage_.assign(static_cast<size_t>(n_gpus) * kStageSlots, nullptr);
     std::vector<int> ids(static_cast<size_t>(n_gpus));
     for (int i = 0; i < n_gpus; ++i) {
       ids[static_cast<size_t>(i)] = i;
@@ -64,7 +64,7 @@ class MultiDevice {
     for (size_t i = 0; i < comm_.size(); ++i) (void)ncclCommDestroy(comm_[i]);
     for (size_t i = 0; i < stage_.size(); ++i)
       if (stage_[i]) {
-        (void)hipSetDevice(ordinal(static_cast<int>(i)));
+        (void)hipSetDevice(ordinal(static_cast<int>(i / kStageSlots)));
         (void)hipFree(stage_[i]);
       }
     dev_.clear();  // the contexts go before their streams
@@ -184,11 +184,14 @@ class MultiDevice {
     if (!depth_ready_) depthPassAll();
     for (int r = 0; r < size(); ++r)  // queued on every GPU before any host wait
       device(r).check(pcp_colorize_from_depth(device(r).get(), nullptr, nullptr));
-    std::vector<uint32_t> packed;
+    // every shard's packed colours start for the host at once (each GPU's copy stream), then the host waits shard by shard
+    std::vector<uint32_t> all(static_cast<size_t>(n_));
+    for (int r = 0; r < size(); ++r)
+      device(r).check(pcp_download_result_packed_async(device(r).get(), all.data() + shardBegin(r)));
     for (int r = 0; r < size(); ++r) {
       const int64_t lo = shardBegin(r), m = shardBegin(r + 1) - lo;
-      packed.resize(static_cast<size_t>(m));
-      device(r).check(pcp_download_result_packed(device(r).get(), packed.data()));
+      device(r).check(pcp_synchronize(device(r).get()));
+      const uint32_t *packed = all.data() + lo;
       for (int64_t i = 0; i < m; ++i) {
         const uint32_t v = packed[static_cast<size_t>(i)];
         uint8_t *o = rgb.data() + 3 * (lo + i);
@@ -290,6 +293,12 @@ class MultiDevice {
     if (r != ncclSuccess) throw std::runtime_error(std::string("pcp_multi: ") + what + ": " + ncclGetErrorString(r));
   }
 
+  // One keyframe image (or mask) to every GPU: over PCIe once (to GPU 0), to the others over xGMI (ncclBroadcast on the
+  // GPUs' streams), then packed into texels by every library from its device copy.  A ring of kStageSlots staging buffers
+  // per GPU: the copy of keyframe k + 1 crosses PCIe while keyframe k is broadcast and packed, nothing waits on the host
+  // until a slot comes round again (every kStageSlots keyframes: one pcp_synchronize per GPU) -- the one-buffer version
+  // waited for the pack of every keyframe before the next copy could start ("What's weak" 11).
+  static constexpr int kStageSlots = 4;
   void replicate(int keyframe, const uint8_t *host, int64_t step, int rows, bool mask) {
     if (size() == 1) {
       if (mask)
@@ -300,36 +309,52 @@ class MultiDevice {
     }
     const size_t bytes = static_cast<size_t>(step) * static_cast<size_t>(rows);
     if (bytes > stage_bytes_) {
+      drainStages();
       for (int r = 0; r < size(); ++r) {
         hip(hipSetDevice(ordinal(r)), "hipSetDevice");
-        if (stage_[static_cast<size_t>(r)]) hip(hipFree(stage_[static_cast<size_t>(r)]), "hipFree");
-        hip(hipMalloc(reinterpret_cast<void **>(&stage_[static_cast<size_t>(r)]), bytes), "hipMalloc(image staging)");
+        for (int k = 0; k < kStageSlots; ++k) {
+          uint8_t *&p = stage_[static_cast<size_t>(r * kStageSlots + k)];
+          if (p) hip(hipFree(p), "hipFree");
+          hip(hipMalloc(reinterpret_cast<void **>(&p), bytes), "hipMalloc(image staging)");
+        }
       }
       stage_bytes_ = bytes;
     }
+    if (stage_used_ == kStageSlots) drainStages();  // the oldest slot is about to be overwritten: its pack must be done
+    const int slot = stage_next_;
+    stage_next_ = (stage_next_ + 1) % kStageSlots;
+    stage_used_ += 1;
+    auto buf = [&](int r) { return stage_[static_cast<size_t>(r * kStageSlots + slot)]; };
     hip(hipSetDevice(ordinal(0)), "hipSetDevice");
-    hip(hipMemcpyAsync(stage_[0], host, bytes, hipMemcpyHostToDevice, stream_[0]), "hipMemcpyAsync(image)");
+    hip(hipMemcpyAsync(buf(0), host, bytes, hipMemcpyHostToDevice, stream_[0]), "hipMemcpyAsync(image)");
     if (rehearsal_) {
       hip(hipStreamSynchronize(stream_[0]), "hipStreamSynchronize");
       for (int r = 1; r < size(); ++r)
-        hip(hipMemcpyAsync(stage_[static_cast<size_t>(r)], stage_[0], bytes, hipMemcpyDeviceToDevice, stream_[static_cast<size_t>(r)]),
+        hip(hipMemcpyAsync(buf(r), buf(0), bytes, hipMemcpyDeviceToDevice, stream_[static_cast<size_t>(r)]),
             "hipMemcpyAsync(image, rehearsal)");
     } else {
       nccl(ncclGroupStart(), "ncclGroupStart");
       for (int r = 0; r < size(); ++r)
-        nccl(ncclBroadcast(stage_[0], stage_[static_cast<size_t>(r)], bytes, ncclUint8, 0, comm_[static_cast<size_t>(r)],
-                           stream_[static_cast<size_t>(r)]),
+        nccl(ncclBroadcast(buf(0), buf(r), bytes, ncclUint8, 0, comm_[static_cast<size_t>(r)], stream_[static_cast<size_t>(r)]),
              "ncclBroadcast(image)");
       nccl(ncclGroupEnd(), "ncclGroupEnd");
     }
-    // device pointers: the library orders its pack kernel after the broadcast queued on the same stream, and the
-    // synchronous form returns once the staging buffer may be overwritten by the next keyframe
+    // device pointers: the library orders its pack kernel after the broadcast queued on the same stream.  Images take the
+    // asynchronous form (the slot stays untouched until drainStages); the mask upload synchronises by itself.
     for (int r = 0; r < size(); ++r) {
       if (mask)
-        device(r).uploadMask(keyframe, stage_[static_cast<size_t>(r)], step);
+        device(r).uploadMask(keyframe, buf(r), step);
       else
-        device(r).uploadImage(keyframe, stage_[static_cast<size_t>(r)], step);
+        device(r).uploadImageAsync(keyframe, buf(r), step);
     }
+    // the host buffer belongs to the caller again when this returns: the PCIe copy must have left it
+    hip(hipStreamSynchronize(stream_[0]), "hipStreamSynchronize(image copy)");
+  }
+  // every queued pack has read its staging slot
+  void drainStages() {
+    if (stage_used_ == 0) return;
+    for (int r = 0; r < size(); ++r) device(r).check(pcp_synchronize(device(r).get()));
+    stage_used_ = 0;
   }
 
   int ordinal(int shard) const { return rehearsal_ ? 0 : shard; }
@@ -338,8 +363,9 @@ class MultiDevice {
   std::vector<std::unique_ptr<Device>> dev_;
   std::vector<hipStream_t> stream_;
   std::vector<ncclComm_t> comm_;
-  std::vector<uint8_t *> stage_;
+  std::vector<uint8_t *> stage_;  // [gpu][slot]
   size_t stage_bytes_ = 0;
+  int stage_next_ = 0, stage_used_ = 0;
   pcp_camera cam_{};
   int64_t n_ = 0;
   int n_frames_ = 0;
