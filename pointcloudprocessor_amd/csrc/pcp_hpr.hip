@@ -85,22 +85,50 @@ struct HprArrays {
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x & 63u); }
 
+// Reductions over the wavefront in DPP steps (row_shr 1, 2, 4, 8 inside the rows of 16 lanes, then row_bcast:15 and
+// row_bcast:31 across them -- the sequence of LLVM's own wave reductions on gfx9): the total lands in lane 63 and is read
+// from there.  Six steps of two register moves and one operation, no LDS round trip (the butterfly through
+// ds_bpermute took ~700 cycles of latency per reduction, four reductions per cut of the polygon).
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ double dpp_move(double identity, double v) {
+  const long long iv = __double_as_longlong(v), id = __double_as_longlong(identity);
+  const int lo = __builtin_amdgcn_update_dpp(static_cast<int>(id), static_cast<int>(iv), kCtrl, kRowMask, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(static_cast<int>(id >> 32), static_cast<int>(iv >> 32), kCtrl, kRowMask, 0xf, false);
+  return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+
+template <typename Op>
+__device__ __forceinline__ double wave_reduce(double v, double identity, Op op) {
+  v = op(v, dpp_move<0x111, 0xf>(identity, v));  // row_shr:1
+  v = op(v, dpp_move<0x112, 0xf>(identity, v));  // row_shr:2
+  v = op(v, dpp_move<0x114, 0xf>(identity, v));  // row_shr:4
+  v = op(v, dpp_move<0x118, 0xf>(identity, v));  // row_shr:8
+  v = op(v, dpp_move<0x142, 0xa>(identity, v));  // row_bcast:15 into rows 1 and 3
+  v = op(v, dpp_move<0x143, 0xc>(identity, v));  // row_bcast:31 into rows 2 and 3
+  const long long t = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane(static_cast<int>(t), 63), hi = __builtin_amdgcn_readlane(static_cast<int>(t >> 32), 63);
+  return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  return wave_reduce(v, 0.0, [](double a, double b) { return a + b; });
 }
-
 __device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
-  return v;
+  return wave_reduce(v, INFINITY, [](double a, double b) { return fmin(a, b); });
+}
+__device__ __forceinline__ double wave_max(double v) {
+  return wave_reduce(v, -INFINITY, [](double a, double b) { return fmax(a, b); });
 }
 
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-  return v;
+// the value a lane holds, for a lane index every lane agrees on (a scalar register: v_readlane, no LDS permute)
+__device__ __forceinline__ double lane_value(double v, int lane) {
+  const int l = __builtin_amdgcn_readfirstlane(lane);
+  const long long t = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane(static_cast<int>(t), l), hi = __builtin_amdgcn_readlane(static_cast<int>(t >> 32), l);
+  return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+__device__ __forceinline__ int32_t lane_value(int32_t v, int lane) {
+  return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(lane));
 }
 
 __device__ __forceinline__ unsigned long long order_key(double d) {
@@ -172,8 +200,8 @@ __device__ __forceinline__ int polygon_clip(Polygon &P, double Dx, double Dy, do
     const double best = wave_min(valid ? val : INFINITY);
     const unsigned long long at = __ballot(valid && val == best);
     const int bl = static_cast<int>(__builtin_ctzll(at));
-    cert_a = __shfl(P.eid, bl, 64);
-    cert_b = __shfl(P.eid, (bl + nv - 1) % nv, 64);
+    cert_a = lane_value(P.eid, bl);
+    cert_b = lane_value(P.eid, (bl + nv - 1) % nv);
     return 2;
   }
   const int cnt = __popcll(m_in);
@@ -183,16 +211,16 @@ __device__ __forceinline__ int polygon_clip(Polygon &P, double Dx, double Dy, do
   if (__popcll(starts) != 1) return 3;
   const int a = static_cast<int>(__builtin_ctzll(starts));
   const int b = (a + cnt - 1) % nv, b1 = (b + 1) % nv, a0 = (a + nv - 1) % nv;
-  const double vbx = __shfl(P.vx, b, 64), vby = __shfl(P.vy, b, 64), valb = __shfl(val, b, 64);
-  const double vb1x = __shfl(P.vx, b1, 64), vb1y = __shfl(P.vy, b1, 64), valb1 = __shfl(val, b1, 64);
-  const double va0x = __shfl(P.vx, a0, 64), va0y = __shfl(P.vy, a0, 64), vala0 = __shfl(val, a0, 64);
-  const double vax = __shfl(P.vx, a, 64), vay = __shfl(P.vy, a, 64), vala = __shfl(val, a, 64);
-  const int32_t eid_a0 = __shfl(P.eid, a0, 64);
+  const double vbx = lane_value(P.vx, b), vby = lane_value(P.vy, b), valb = lane_value(val, b);
+  const double vb1x = lane_value(P.vx, b1), vb1y = lane_value(P.vy, b1), valb1 = lane_value(val, b1);
+  const double va0x = lane_value(P.vx, a0), va0y = lane_value(P.vy, a0), vala0 = lane_value(val, a0);
+  const double vax = lane_value(P.vx, a), vay = lane_value(P.vy, a), vala = lane_value(val, a);
+  const int32_t eid_a0 = lane_value(P.eid, a0);
   // The new vertices are where the half-plane's line meets the lines of the two edges it crosses -- from the LINES, not
   // by interpolating between the edges' end points: an edge of the initial box is 2^31 long, and a point near s = 0
   // interpolated between end points that far apart is only good to 1e-7.
-  const double lbx = __shfl(P.lx, b, 64), lby = __shfl(P.ly, b, 64), lbe = __shfl(P.le, b, 64);
-  const double l0x = __shfl(P.lx, a0, 64), l0y = __shfl(P.ly, a0, 64), l0e = __shfl(P.le, a0, 64);
+  const double lbx = lane_value(P.lx, b), lby = lane_value(P.ly, b), lbe = lane_value(P.le, b);
+  const double l0x = lane_value(P.lx, a0), l0y = lane_value(P.ly, a0), l0e = lane_value(P.le, a0);
   double x1x, x1y, x2x, x2y;
   if (!line_meet(lbx, lby, lbe, Dx, Dy, E, x1x, x1y)) {
     const double t1 = fmin(fmax(valb / (valb - valb1), 0.0), 1.0);  // valb <= tol < valb1
@@ -288,7 +316,7 @@ __device__ __forceinline__ void search_witness(Search &S, const Polygon &P) {
     // from b, hence in the polygon, and so does their mean: a point of the polygon next to b whose direction from b
     // does not depend on how far away the far vertices (the initial box) are.
     const int src = static_cast<int>(__builtin_ctzll(__ballot(valid && d2 == dmin2)));
-    const double bx = __shfl(cx, src, 64), by = __shfl(cy, src, 64);
+    const double bx = lane_value(cx, src), by = lane_value(cy, src);
     const double gx = P.vx - bx, gy = P.vy - by;
     const double len = sqrt(gx * gx + gy * gy);
     const double f = len > kNudge ? kNudge / len : 1.0;
@@ -345,7 +373,7 @@ __device__ __forceinline__ void test_range(Search &S, Polygon &P, const HprArray
       const double score = bad ? t / T : -INFINITY;
       const double worst = wave_max(score);
       const int src = static_cast<int>(__builtin_ctzll(__ballot(bad && score == worst)));
-      const double qx = __shfl(dx, src, 64), qy = __shfl(dy, src, 64), qz = __shfl(dz, src, 64);
+      const double qx = lane_value(dx, src), qy = lane_value(dy, src), qz = lane_value(dz, src);
       const double Dx = (qx * S.e1.x + qy * S.e1.y) + qz * S.e1.z;
       const double Dy = (qx * S.e2.x + qy * S.e2.y) + qz * S.e2.z;
       const double E = -((qx * S.e0.x + qy * S.e0.y) + qz * S.e0.z);
@@ -445,7 +473,7 @@ __device__ __forceinline__ void traverse_all(const Search &S, const HprArrays &A
     }
     unsigned long long open_c = __ballot(open);
     while (open_c) {
-      const int32_t Cc = __shfl(C, static_cast<int>(__builtin_ctzll(open_c)), 64);
+      const int32_t Cc = lane_value(C, static_cast<int>(__builtin_ctzll(open_c)));
       open_c &= open_c - 1ull;
       const int32_t fi = (Cc % G.cgw) * kHprCoarse + (l & 7), fj = (Cc / G.cgw) * kHprCoarse + (l >> 3);
       bool fopen = false;
@@ -459,7 +487,7 @@ __device__ __forceinline__ void traverse_all(const Search &S, const HprArrays &A
       while (open_f) {
         const int src = static_cast<int>(__builtin_ctzll(open_f));
         open_f &= open_f - 1ull;
-        const int32_t ff = __shfl(f, src, 64);
+        const int32_t ff = lane_value(f, src);
         if (!range(A.cstart[ff], A.cstart[ff + 1])) return;
       }
     }
