@@ -40,3 +40,12 @@ def test_bench_line_carries_the_contract():
     assert line["value_host_images"] == line["host_images"]["value"] > 0
     assert line["host_images"]["pcie_floor_ms"] > 0 and line["camera_ref"]["value"] > 0
     assert line["mls"]["value"] > 0 and line["mls"]["sor_mls_sor"]["outputs"] > 0 and line["nid"]["valid"] is True
+    # the timed region: an untimed settle phase in front of it, per-step statistics inside it
+    assert line["settle"]["steps"] > 0 and line["settle"]["ms"] >= 400.0
+    st = line["step_ms"]
+    assert 0 < st["min"] <= st["median"] <= st["max"] and st["host_enqueue_median"] > 0
+    assert "pruned" in line["value_note"]
+    # the reference's own upsampling configuration (1 mm x 4): whole chain on a sub-sample, whole map in chunks
+    assert line["mls"]["reference_config_chain"]["outputs"] > 0
+    rs = line["mls"]["reference_config_stream"]
+    assert rs["voxels"] >= rs["outputs"] > 0 and rs["chunks"] >= 1
