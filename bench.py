@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--no-mls", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-side-legs", action="store_true", help="only the timed step and the roofline leg")
+    ap.add_argument("--no-ic-leg", action="store_true",
+                    help="skip the cache-resident projection launches (roofline.ic_resident): under rocprofv3 --kernel-trace "
+                         "--stats the k_project_frame row then holds the HBM launches only")
     ap.add_argument("--cpu-points", type=int, default=1_000_000)
     ap.add_argument("--cpu-frames", type=int, default=16)
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even at world size 1")
@@ -316,7 +319,7 @@ def main():
 
         # (a) on the workload's own cloud: the same buffers every launch -- at 10 M points the 191 MiB working set
         # fits the 256 MiB Infinity Cache, so this figure is NOT an HBM rate
-        avg_ic, launches_ic, achieved_ic = project_leg(eng.ctx, N, range(min(F, 256)))
+        avg_ic, launches_ic, achieved_ic = (0.0, 0, 0.0) if args.no_ic_leg else project_leg(eng.ctx, N, range(min(F, 256)))
         # (b) the HBM figure: a cloud large enough that more than 256 MiB pass between two uses of any line
         # (MI355X_MICROARCH.md, Infinity Cache residency rule): 12 B x Nr read + 8 B x Nr written per launch
         Nr = max(args.roofline_points, N)

@@ -576,11 +576,29 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_prepare(const float *__restri
     bmin = min(bmin, static_cast<unsigned long long>(__shfl_xor(static_cast<long long>(bmin), o, 64)));
     bmax = max(bmax, static_cast<unsigned long long>(__shfl_xor(static_cast<long long>(bmax), o, 64)));
   }
-  if (lane_id() == 0 && amax != 0ull) {
-    atomicMin(&bounds[0], amin);
-    atomicMax(&bounds[1], amax);
-    atomicMin(&bounds[2], bmin);
-    atomicMax(&bounds[3], bmax);
+  // one set of atomics per workgroup: the four bounds share a cache line, and atomics on one line queue up in the L2
+  __shared__ unsigned long long part[kHprBlock / 64][4];
+  const int w = static_cast<int>(threadIdx.x >> 6);
+  if (lane_id() == 0) {
+    part[w][0] = amin;
+    part[w][1] = amax;
+    part[w][2] = bmin;
+    part[w][3] = bmax;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < kHprBlock / 64; ++k) {
+      amin = min(amin, part[k][0]);
+      amax = max(amax, part[k][1]);
+      bmin = min(bmin, part[k][2]);
+      bmax = max(bmax, part[k][3]);
+    }
+    if (amax != 0ull) {
+      atomicMin(&bounds[0], amin);
+      atomicMax(&bounds[1], amax);
+      atomicMin(&bounds[2], bmin);
+      atomicMax(&bounds[3], bmax);
+    }
   }
 }
 
