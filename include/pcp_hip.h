@@ -214,7 +214,7 @@ int pcp_frame_visible(pcp_context *ctx, int32_t frame, int64_t capacity, int32_t
 
 /* diagnostic: the last hidden_points_removal run on ctx (PCP_CULL_HPR; the latest keyframe of a batched call):
  * out[0] visible, [1] hidden, [2] candidates that went to the exact path (neither floating-point certificate held),
- * [3] trial normals, [4] batches of 64 point tests, [5] searches restarted from the wide box, [6] UNRESOLVED (no exact
+ * [3] trial normals, [4] batches of 64 point tests, [5] reserved (0), [6] UNRESOLVED (no exact
  * certificate either: exactly degenerate input such as four coplanar flipped points; classified hidden), [7] exact
  * predicate evaluations, [8] grid cells, [9] candidates. */
 int pcp_hpr_stats(pcp_context *ctx, int64_t out[10]);

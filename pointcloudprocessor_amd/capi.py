@@ -306,7 +306,7 @@ class Context:
         """Counters of the last hidden_points_removal run (pcp_hpr_stats)."""
         out = np.zeros(10, np.int64)
         self._check(self.lib.pcp_hpr_stats(self.h, _ptr(out)))
-        keys = ("visible", "hidden", "exact_path", "trial_normals", "test_batches", "wide_box_retries", "unresolved",
+        keys = ("visible", "hidden", "exact_path", "trial_normals", "test_batches", "reserved", "unresolved",
                 "exact_evaluations", "cells", "candidates")
         return {k: int(v) for k, v in zip(keys, out)}
 

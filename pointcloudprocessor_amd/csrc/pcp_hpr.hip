@@ -674,8 +674,7 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_cells(HprGrid G, const unsign
 // [6] unresolved [7] exact predicate evaluations [8] length of the list for k_hpr_exact
 __global__ __launch_bounds__(kHprBlock) void k_hpr_decide(HprArrays A, HprGrid G, uint8_t *__restrict__ state,
                                                           int32_t *__restrict__ undecided,
-                                                          unsigned long long *__restrict__ stats, int32_t force_exact,
-                                                          double *__restrict__ dbg) {
+                                                          unsigned long long *__restrict__ stats, int32_t force_exact) {
   const int32_t j = static_cast<int32_t>(blockIdx.x) * (kHprBlock / 64) + static_cast<int32_t>(threadIdx.x >> 6);
   if (j >= G.m) return;
   Search S;
@@ -703,19 +702,6 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_decide(HprArrays A, HprGrid G
       else why = 11;
     } else if (r == kSearchEmpty) why = 12; else why = 13 + (S.fail_code & 7);
     if (why && lane_id() == 0) atomicAdd(&stats[why], 1ull);  // rare
-    if (dbg && why >= 13) {
-      unsigned long long slot = 0;
-      if (lane_id() == 0) slot = atomicAdd(&stats[20], 1ull);
-      slot = __shfl(static_cast<long long>(slot), 0, 64);
-      if (slot < 4) {
-        double *o = dbg + slot * 256;
-        if (lane_id() == 0) {
-          o[0] = j; o[1] = S.self_idx; o[2] = P.nv; o[3] = S.fail_code; o[4] = static_cast<double>(restarts);
-          o[5] = S.p.x; o[6] = S.p.y; o[7] = S.p.z;
-        }
-        o[8 + 3 * lane_id()] = P.vx; o[9 + 3 * lane_id()] = P.vy; o[10 + 3 * lane_id()] = P.eid >= 0 ? A.sidx[P.eid] : P.eid;
-      }
-    }
   }
   if (lane_id() == 0) {
     state[j] = static_cast<uint8_t>(out);
@@ -1052,8 +1038,6 @@ int hpr_refine_flags(pcp_context *ctx, int32_t frame, uint8_t *d_flags) {
   PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->h_cells_i.p, 0, (static_cast<size_t>(2 * n_fine) + 16) * sizeof(int32_t), ctx->stream));
   PCP_HIP_TRY(ctx, hipMemsetAsync(crho, 0, static_cast<size_t>(n_fine) * sizeof(double), ctx->stream));
   HprArrays A{sx, sy, sz, sidx, scell, cstart, crho, cdir, Crho, Cdir};
-  double *dbg_buf = nullptr;
-  if (std::getenv("PCP_HPR_DEBUG")) (void)hipMalloc(reinterpret_cast<void **>(&dbg_buf), 1024 * sizeof(double));
   // PCP_HPR_FORCE_EXACT=1 (tests): every candidate takes the exact path; read per call
   const char *fe = std::getenv("PCP_HPR_FORCE_EXACT");
   const bool force_exact = fe && fe[0] == '1';
@@ -1067,7 +1051,7 @@ int hpr_refine_flags(pcp_context *ctx, int32_t frame, uint8_t *d_flags) {
     hipLaunchKernelGGL(k_hpr_cells, dim3(hpr_blocks(std::max(n_fine, n_coarse))), dim3(kHprBlock), 0, ctx->stream, G,
                        reinterpret_cast<const unsigned long long *>(crho), cdir, Crho, Cdir, stats + 28);
     hipLaunchKernelGGL(k_hpr_decide, dim3(static_cast<uint32_t>(div_up(m, kHprBlock / 64))), dim3(kHprBlock), 0, ctx->stream,
-                       A, G, ctx->h_state.p, undecided, stats, force_exact ? 1 : 0, dbg_buf);
+                       A, G, ctx->h_state.p, undecided, stats, force_exact ? 1 : 0);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   std::vector<unsigned long long> hall(kStatStride * (1 + kStatCopies));
@@ -1110,18 +1094,10 @@ int hpr_refine_flags(pcp_context *ctx, int32_t frame, uint8_t *d_flags) {
   if (std::getenv("PCP_HPR_DEBUG")) {
     unsigned long long dbg[24];
     (void)hipMemcpy(dbg, stats, sizeof(dbg), hipMemcpyDeviceToHost);
-    if (dbg_buf) {
-      std::vector<double> h(1024);
-      (void)hipMemcpy(h.data(), dbg_buf, 1024 * sizeof(double), hipMemcpyDeviceToHost);
-      (void)hipFree(dbg_buf);
-      for (int sl = 0; sl < 4 && sl < static_cast<int>(dbg[20]); ++sl) {
-        const double *o = h.data() + sl * 256;
-        fprintf(stderr, "hpr fail: j %.0f idx %.0f nv %.0f code %.0f restarts %.0f p %.17g %.17g %.17g\n", o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]);
-        for (int v = 0; v < static_cast<int>(o[2]) && v < 64; ++v)
-          fprintf(stderr, "   v%d %.9g %.9g eid_idx %.0f\n", v, o[8 + 3 * v], o[9 + 3 * v], o[10 + 3 * v]);
-      }
-    }
-    fprintf(stderr, "hpr debug: uncertain_left %llu tetra_filter %llu box_cert %llu fail: guard %llu restarts %llu noncontig %llu overflow %llu\n", dbg[10], dbg[11], dbg[12], dbg[14], dbg[15], dbg[16], dbg[17]);
+    // why candidates left the floating-point path: a point within round-off of the last trial plane / a simplex the
+    // filter could not sign / an emptied polygon that still had an edge of the initial box / searches that gave up
+    // (inner-loop guard, restart cap, non-contiguous clip, more than 64 polygon vertices)
+    fprintf(stderr, "hpr: to the exact path: uncertain_left %llu tetra_filter %llu box_cert %llu fail: guard %llu restarts %llu noncontig %llu overflow %llu\n", dbg[10], dbg[11], dbg[12], dbg[14], dbg[15], dbg[16], dbg[17]);
   }
   return PCP_OK;
 }
