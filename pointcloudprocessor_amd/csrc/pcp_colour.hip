@@ -1471,6 +1471,9 @@ int pcp_depth_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
 int pcp_depth_maps_device(pcp_context *ctx, void **device_ptr, int64_t *n_floats) {
   int rc = check_ready(ctx, "pcp_depth_maps_device", true);
   if (rc != PCP_OK) return rc;
+  if (ctx->cull.cull_mode == PCP_CULL_HPR)
+    return set_error(ctx, PCP_ERR_STATE, "pcp_depth_maps_device: PCP_CULL_HPR has no depth maps to merge across point shards "
+                     "(the hull needs the whole map on one GPU)");
   if ((rc = ensure_depth(ctx)) != PCP_OK) return rc;
   if (device_ptr) *device_ptr = ctx->depth.p;
   if (n_floats) *n_floats = cells_of(ctx) * ctx->n_frames;
@@ -1481,6 +1484,9 @@ int pcp_set_depth_source(pcp_context *ctx, int32_t source) {
   if (!ctx) return PCP_ERR_INVALID;
   if (source != PCP_DEPTH_OWN && source != PCP_DEPTH_BATCHED)
     return set_error(ctx, PCP_ERR_INVALID, "pcp_set_depth_source: unknown source %d", source);
+  if (source == PCP_DEPTH_BATCHED && ctx->have_camera && ctx->cull.cull_mode == PCP_CULL_HPR)
+    return set_error(ctx, PCP_ERR_STATE, "pcp_set_depth_source: PCP_CULL_HPR takes a keyframe's hull over every candidate of "
+                     "the map; a context that holds one index shard cannot decide its points (one GPU only)");
   ctx->depth_from_batch = source == PCP_DEPTH_BATCHED;
   return PCP_OK;
 }

@@ -744,6 +744,9 @@ int pcp_set_camera(pcp_context *ctx, const pcp_camera *cam, const pcp_cull_param
     return set_error(ctx, PCP_ERR_INVALID, "pcp_set_camera: cull size above 2^24 is not supported");
   if (static_cast<int64_t>(cam->image_width) * cam->image_height >= (int64_t(1) << 31))
     return set_error(ctx, PCP_ERR_INVALID, "pcp_set_camera: image too large for int32 pixel indices");
+  if (cp.cull_mode == PCP_CULL_HPR && ctx->depth_from_batch)
+    return set_error(ctx, PCP_ERR_STATE, "pcp_set_camera: PCP_CULL_HPR on a context set to PCP_DEPTH_BATCHED (an index shard): "
+                     "the hull needs the whole map on one GPU");
   ctx->camera = *cam;
   ctx->cull = cp;
   DevCamera &d = ctx->dcam;

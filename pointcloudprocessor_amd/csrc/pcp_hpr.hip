@@ -325,7 +325,8 @@ __device__ __forceinline__ void search_witness(Search &S, const Polygon &P) {
   }
   S.n = {S.e0.x + (sx * S.e1.x + sy * S.e2.x), S.e0.y + (sx * S.e1.y + sy * S.e2.y), S.e0.z + (sx * S.e1.z + sy * S.e2.z)};
   const double nn = sqrt(S.n.x * S.n.x + S.n.y * S.n.y + S.n.z * S.n.z);
-  S.nh = {S.n.x / nn, S.n.y / nn, S.n.z / nn};
+  const double inv = 1.0 / nn;  // n / |n| to a few ulp: the cell bound carries 1e-12 of slack for it
+  S.nh = {S.n.x * inv, S.n.y * inv, S.n.z * inv};
   S.nn_hi = nn * (1.0 + 1.0e-14);
   const double hp = S.n.x * S.p.x + S.n.y * S.p.y + S.n.z * S.p.z;
   S.hp_lo = hp * (1.0 - 1.0e-13);  // n . p > 0: the origin is on the inner side of every trial plane
@@ -485,10 +486,14 @@ __device__ __forceinline__ void traverse_all(const Search &S, const HprArrays &A
       }
       unsigned long long open_f = __ballot(fopen);
       while (open_f) {
+        // a run of open cells side by side in one row of the coarse cell is one run of the cell order: one range, full
+        // batches, instead of a batch of ~8 points per cell
         const int src = static_cast<int>(__builtin_ctzll(open_f));
-        open_f &= open_f - 1ull;
+        const int room = 8 - (src & 7);
+        const int run = min(room, static_cast<int>(__builtin_ctzll(~(open_f >> src))));
+        open_f &= ~(((1ull << run) - 1ull) << src);
         const int32_t ff = lane_value(f, src);
-        if (!range(A.cstart[ff], A.cstart[ff + 1])) return;
+        if (!range(A.cstart[ff], A.cstart[ff + run])) return;
       }
     }
   }

@@ -219,3 +219,26 @@ def test_frame_visible_and_whole_run_in_hull_mode(gpu_ctx_factory, oracle, small
     zref = oracle.colorize(ocam, oracle.default_cull_params(), s["x"], s["y"], s["z"], s["poses"], s["images"])
     assert not np.array_equal(zref["count"], ref["count"])
     ctx.close()
+
+
+def test_hull_mode_refuses_index_shards(gpu_ctx_factory):
+    """A keyframe's hull is taken over every candidate of the map: the calls that make a context one shard of a larger
+    map fail loudly in PCP_CULL_HPR instead of deciding from a part of the candidates."""
+    from pointcloudprocessor_amd import capi, synth
+
+    cd = synth.camera_dict("tiny")
+    x, y, z, _ = synth.make_cloud(5000)
+    poses, _ = synth.make_trajectory(2)
+    ctx = hull_ctx(gpu_ctx_factory, capi, cam_struct(capi, cd), x, y, z, poses)
+    with pytest.raises(capi.PcpError):
+        ctx.set_depth_source(True)
+    with pytest.raises(capi.PcpError):
+        ctx.depth_maps_device()
+    ctx.close()
+    c2 = gpu_ctx_factory()
+    c2.set_depth_source(True)
+    cull = capi.default_cull_params()
+    cull.cull_mode = capi.CULL_HPR
+    with pytest.raises(capi.PcpError):
+        c2.set_camera(cam_struct(capi, cd), cull)
+    c2.close()
