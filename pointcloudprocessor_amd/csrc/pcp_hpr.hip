@@ -120,6 +120,16 @@ __device__ __forceinline__ double wave_max(double v) {
   return wave_reduce(v, -INFINITY, [](double a, double b) { return fmax(a, b); });
 }
 
+// 1 / b to ~1 ulp without the IEEE division's scaling and fix-up steps (v_rcp_f64 and two Newton steps; b is a moderate,
+// non-zero number everywhere it is used).  For the SEARCH only -- frames, trial normals, polygon vertices: what the search
+// finds is checked by the certificates, whose own arithmetic (differences, products, sums) has no division in it.
+__device__ __forceinline__ double quick_rcp(double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+  return r;
+}
+
 // the value a lane holds, for a lane index every lane agrees on (a scalar register: v_readlane, no LDS permute)
 __device__ __forceinline__ double lane_value(double v, int lane) {
   const int l = __builtin_amdgcn_readfirstlane(lane);
@@ -171,8 +181,9 @@ __device__ __forceinline__ bool line_meet(double ax, double ay, double ae, doubl
                                           double &y) {
   const double det = ax * by - ay * bx;
   if (det == 0.0) return false;
-  x = (ae * by - ay * be) / det;
-  y = (ax * be - ae * bx) / det;
+  const double inv = quick_rcp(det);
+  x = (ae * by - ay * be) * inv;
+  y = (ax * be - ae * bx) * inv;
   return isfinite(x) && isfinite(y);
 }
 
@@ -281,12 +292,12 @@ struct Search {
 };
 
 __device__ __forceinline__ void search_frame(Search &S) {
-  const double rho = sqrt(S.p.x * S.p.x + S.p.y * S.p.y + S.p.z * S.p.z);
-  S.e0 = {S.p.x / rho, S.p.y / rho, S.p.z / rho};
+  const double irho = quick_rcp(sqrt(S.p.x * S.p.x + S.p.y * S.p.y + S.p.z * S.p.z));
+  S.e0 = {S.p.x * irho, S.p.y * irho, S.p.z * irho};
   // e1 = the x axis made orthogonal to e0 (the candidates lie in the camera's cone about +z, so e0 is never near x)
   double ax = 1.0 - S.e0.x * S.e0.x, ay = -S.e0.x * S.e0.y, az = -S.e0.x * S.e0.z;
-  const double an = sqrt(ax * ax + ay * ay + az * az);
-  S.e1 = {ax / an, ay / an, az / an};
+  const double ian = quick_rcp(sqrt(ax * ax + ay * ay + az * az));
+  S.e1 = {ax * ian, ay * ian, az * ian};
   S.e2 = {S.e0.y * S.e1.z - S.e0.z * S.e1.y, S.e0.z * S.e1.x - S.e0.x * S.e1.z, S.e0.x * S.e1.y - S.e0.y * S.e1.x};
 }
 
@@ -303,7 +314,7 @@ __device__ __forceinline__ void search_witness(Search &S, const Polygon &P) {
   const double wx = __shfl(P.vx, nxt, 64), wy = __shfl(P.vy, nxt, 64);
   const double ex = wx - P.vx, ey = wy - P.vy;
   const double l2 = ex * ex + ey * ey;
-  double t = l2 > 0.0 ? -(P.vx * ex + P.vy * ey) / l2 : 0.0;
+  double t = l2 > 0.0 ? -(P.vx * ex + P.vy * ey) * quick_rcp(l2) : 0.0;
   t = fmin(fmax(t, 0.0), 1.0);
   const double cx = P.vx + t * ex, cy = P.vy + t * ey;
   const double d2 = valid ? cx * cx + cy * cy : INFINITY;
@@ -319,13 +330,13 @@ __device__ __forceinline__ void search_witness(Search &S, const Polygon &P) {
     const double bx = lane_value(cx, src), by = lane_value(cy, src);
     const double gx = P.vx - bx, gy = P.vy - by;
     const double len = sqrt(gx * gx + gy * gy);
-    const double f = len > kNudge ? kNudge / len : 1.0;
+    const double f = len > kNudge ? kNudge * quick_rcp(len) : 1.0;
     sx = bx + wave_sum(valid ? f * gx : 0.0) / P.nv;
     sy = by + wave_sum(valid ? f * gy : 0.0) / P.nv;
   }
   S.n = {S.e0.x + (sx * S.e1.x + sy * S.e2.x), S.e0.y + (sx * S.e1.y + sy * S.e2.y), S.e0.z + (sx * S.e1.z + sy * S.e2.z)};
   const double nn = sqrt(S.n.x * S.n.x + S.n.y * S.n.y + S.n.z * S.n.z);
-  const double inv = 1.0 / nn;  // n / |n| to a few ulp: the cell bound carries 1e-12 of slack for it
+  const double inv = quick_rcp(nn);  // n / |n| to a few ulp: the cell bound carries 1e-12 of slack for it
   S.nh = {S.n.x * inv, S.n.y * inv, S.n.z * inv};
   S.nn_hi = nn * (1.0 + 1.0e-14);
   const double hp = S.n.x * S.p.x + S.n.y * S.p.y + S.n.z * S.p.z;
@@ -371,7 +382,8 @@ __device__ __forceinline__ void test_range(Search &S, Polygon &P, const HprArray
       const double T = (fabs(tx) + fabs(ty)) + fabs(tz);
       const bool bad = open && !(t < -kPointSlack * T);
       if (!__ballot(bad)) break;
-      const double score = bad ? t / T : -INFINITY;
+      // which one is "worst" only steers the search: the ratio in fp32
+      const double score = bad ? static_cast<double>(static_cast<float>(t) * __builtin_amdgcn_rcpf(static_cast<float>(T))) : -INFINITY;
       const double worst = wave_max(score);
       const int src = static_cast<int>(__builtin_ctzll(__ballot(bad && score == worst)));
       const double qx = lane_value(dx, src), qy = lane_value(dy, src), qz = lane_value(dz, src);
@@ -443,7 +455,8 @@ __device__ __forceinline__ Window reach_window(const Search &S, const HprGrid &G
   if (ratio >= 1.0) return {1, 0, 1, 0};
   if (!(S.nh.z > 1.0e-3)) return W;
   const double sep = sqrt(2.0 * (1.0 - ratio)) * (1.0 + 1.0e-9) + 1.0e-12;
-  const double ax = S.nh.x / S.nh.z, ay = S.nh.y / S.nh.z;
+  const double inz = quick_rcp(S.nh.z);
+  const double ax = S.nh.x * inz, ay = S.nh.y * inz;  // to ~1 ulp; R below carries 1e-9 of slack
   const double R = sep * (1.0 + sqrt(ax * ax + ay * ay)) * G.a_reach * (1.0 + 1.0e-9);
   const double H = G.h * kHprCoarse;
   const double fi0 = floor((ax - R - G.a0) / H), fi1 = floor((ax + R - G.a0) / H);
