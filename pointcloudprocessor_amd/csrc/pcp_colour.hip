@@ -33,6 +33,21 @@ constexpr uint32_t kFltMaxBits = 0x7f7fffffu;  // FLT_MAX, view_culling.cpp:64
 // 4 B range written per point (optionally pixel and camera coordinates).
 // 4 points per lane: dwordx4 loads / stores, 1 KiB per wave-instruction.
 // ---------------------------------------------------------------------------
+template <bool kCommon>
+__device__ __forceinline__ DevCamera common_camera(const DevCamera &in) {
+  DevCamera c = in;
+  if constexpr (kCommon) {
+    c.cull_mode = PCP_CULL_ZBUFFER;
+    c.enable_zbuf = 1;
+    c.pretest = 1;
+    c.ds_fast = 1;
+  }
+  return c;
+}
+inline bool is_common_camera(const DevCamera &c) {
+  return c.cull_mode == PCP_CULL_ZBUFFER && c.enable_zbuf == 1 && c.pretest == 1 && c.ds_fast == 1;
+}
+
 struct ProjectOut {
   int32_t *cell;
   int32_t *pixel;
@@ -52,9 +67,11 @@ __device__ __forceinline__ void project_store_one(const DevCamera &cam, const De
   zc = p.zc;
 }
 
+template <bool kCommon>
 __global__ __launch_bounds__(kBlock) void k_project_frame(const float *__restrict__ x, const float *__restrict__ y,
-                                                          const float *__restrict__ z, int64_t n, DevCamera cam,
+                                                          const float *__restrict__ z, int64_t n, DevCamera cam_in,
                                                           DevFrame fr, ProjectOut out) {
+  const DevCamera cam = common_camera<kCommon>(cam_in);
   const int64_t q = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;  // quad index
   const int64_t i0 = q * 4;
   if (i0 >= n) return;
@@ -366,13 +383,18 @@ __device__ __forceinline__ uint32_t range_bits(int32_t w, int32_t f0, int32_t f1
   return nb <= 0 ? 0u : (((nb >= 32) ? 0xffffffffu : ((1u << nb) - 1u)) << (fb & 31));
 }
 
+// kCommon: the configuration every batched run of the CLI and the bench uses (z-buffer cull with its depth buffer on, fp32
+// rejection test and exact short divisions enabled) is compiled with those switches as constants -- the mode fields, the
+// hidden_points_removal bounds and the branches on them leave the scalar register file (see common_camera).
+template <bool kCommon>
 __global__ __launch_bounds__(kBlock) void k_depth_pass(const float *__restrict__ x, const float *__restrict__ y,
-                                                       const float *__restrict__ z, int64_t n, DevCamera cam,
+                                                       const float *__restrict__ z, int64_t n, DevCamera cam_in,
                                                        const DevFrame *__restrict__ frames, int32_t f0, int32_t f1,
                                                        uint32_t *__restrict__ depth, int64_t cells,
                                                        int32_t depth_first_frame, uint32_t *__restrict__ tile_mask,
                                                        const uint32_t *__restrict__ tile_inside, int32_t words,
                                                        const int32_t *__restrict__ tile_order) {
+  const DevCamera cam = common_camera<kCommon>(cam_in);
   // per-wavefront combining table: slot = cell & 63 holds min over (cell << 32 | range bits)
   __shared__ unsigned long long combine[kBlock];
   const int lane = threadIdx.x & 63;
@@ -462,16 +484,26 @@ struct TopState {
   int32_t *count;
 };
 
+// kMatch: 0 = match mode read from the camera block, else the mode itself (PCP_MATCH_IDENTITY 1 ... see match_constant)
+// kOneShot: flags == 4 (no top-5 state loaded or stored, packed result written in input order): the usual whole-run call
+template <bool kCommon, int kMatch, bool kOneShot>
 __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict__ x, const float *__restrict__ y,
-                                                        const float *__restrict__ z, int64_t n, DevCamera cam,
+                                                        const float *__restrict__ z, int64_t n, DevCamera cam_in,
                                                         const DevFrame *__restrict__ frames, int32_t f0, int32_t f1,
                                                         const uint32_t *__restrict__ depth, int64_t cells,
                                                         const uint32_t *__restrict__ tile_mask, int32_t words,
                                                         const uint32_t *__restrict__ images, int64_t image_px,
                                                         TopState st, const int32_t *__restrict__ perm,
-                                                        uint32_t *__restrict__ rgba, int32_t flags,
-                                                        const int32_t *__restrict__ tile_order,
-                                                        const uint32_t *__restrict__ hull_bits) {
+                                                        uint32_t *__restrict__ rgba, int32_t flags_in,
+                                                        const int32_t *__restrict__ tile_order_in,
+                                                        const uint32_t *__restrict__ hull_bits_in) {
+  DevCamera cam = common_camera<kCommon>(cam_in);
+  if constexpr (kMatch == 1) cam.match_mode = PCP_MATCH_IDENTITY;
+  if constexpr (kMatch == 2) cam.match_mode = PCP_MATCH_ROUNDTRIP;
+  // the common configuration walks the cloud order and has no hull bits (both are null then: the host checks)
+  const int32_t *__restrict__ tile_order = kCommon ? nullptr : tile_order_in;
+  const uint32_t *__restrict__ hull_bits = kCommon ? nullptr : hull_bits_in;
+  const int32_t flags = kOneShot ? 4 : flags_in;
   const int64_t j = tile_order ? static_cast<int64_t>(tile_order[blockIdx.x]) * 64 + threadIdx.x
                                : static_cast<int64_t>(xcd_chunked_block()) * kBlock + threadIdx.x;
   const bool live = j < n;
@@ -1025,7 +1057,7 @@ static int single_frame_depth(pcp_context *ctx, int32_t frame) {
   if (ctx->n > 0 && ctx->dcam.enable_zbuf) {
     const size_t plane = plane_of(ctx);
     LaunchTimer t(ctx, PCP_K_DEPTH);
-    hipLaunchKernelGGL(k_depth_pass, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
+    hipLaunchKernelGGL(k_depth_pass<false>, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
                        ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, ctx->n, ctx->dcam, ctx->frames.p, frame, frame + 1,
                        ctx->s_u32.p, cells, frame, static_cast<uint32_t *>(nullptr),
                        static_cast<const uint32_t *>(nullptr), 0, static_cast<const int32_t *>(nullptr));
@@ -1296,7 +1328,7 @@ int pcp_project_frame(pcp_context *ctx, int32_t frame, int32_t *out_cell, int32_
   o.zc = out_xyz_cam ? ctx->s_cam.p + 2 * plane : nullptr;
   {
     LaunchTimer t(ctx, PCP_K_PROJECT);
-    hipLaunchKernelGGL(k_project_frame, dim3(blocks_for(div_up(n, 4))), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
+    hipLaunchKernelGGL(is_common_camera(ctx->dcam) ? k_project_frame<true> : k_project_frame<false>, dim3(blocks_for(div_up(n, 4))), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
                        ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, n, ctx->dcam,
                        ctx->hframes[static_cast<size_t>(frame)], o);
     PCP_HIP_TRY(ctx, hipGetLastError());
@@ -1443,7 +1475,8 @@ int pcp_depth_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
     }
     {
       LaunchTimer t(ctx, PCP_K_DEPTH);
-      hipLaunchKernelGGL(k_depth_pass, dim3(static_cast<uint32_t>(ctx->n_tiles)), dim3(64), 0, ctx->stream, ctx->sxyz.p,
+      hipLaunchKernelGGL(is_common_camera(ctx->dcam) ? k_depth_pass<true> : k_depth_pass<false>,
+                         dim3(static_cast<uint32_t>(ctx->n_tiles)), dim3(64), 0, ctx->stream, ctx->sxyz.p,
                          ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, ctx->n, ctx->dcam, ctx->frames.p, frame_begin,
                          frame_end, ctx->depth.p, cells, 0, ctx->tile_mask.p, ctx->tile_inside.p, ctx->mask_words,
                          ctx->tile_order.p);
@@ -1559,14 +1592,20 @@ static int colour_pass_impl(pcp_context *ctx, int32_t frame_begin, int32_t frame
     // tiles (longest-first order: no gain at 1920x1080), and its texel gathers want neighbouring tiles on the same L2
     // (longest-first order at 4096x3000: 1.96 -> 2.18 ms)
     const bool ordered = false;
-    hipLaunchKernelGGL(k_colour_pass, dim3(ordered ? static_cast<uint32_t>(ctx->n_tiles) : blocks_for(ctx->n)),
+    const bool common = is_common_camera(ctx->dcam) && !ordered && ctx->cull.cull_mode != PCP_CULL_HPR;
+    const int32_t launch_flags = flags | ((one_shot && unpermute_results()) ? 8 : 0);
+    auto kernel = k_colour_pass<false, 0, false>;
+    if (common && ctx->dcam.match_mode == PCP_MATCH_IDENTITY)
+      kernel = launch_flags == 4 ? k_colour_pass<true, 1, true> : k_colour_pass<true, 1, false>;
+    if (common && ctx->dcam.match_mode == PCP_MATCH_ROUNDTRIP)
+      kernel = launch_flags == 4 ? k_colour_pass<true, 2, true> : k_colour_pass<true, 2, false>;
+    hipLaunchKernelGGL(kernel, dim3(ordered ? static_cast<uint32_t>(ctx->n_tiles) : blocks_for(ctx->n)),
                        dim3(ordered ? 64 : kBlock), 0, ctx->stream, ctx->sxyz.p, ctx->sxyz.p + plane,
                        ctx->sxyz.p + 2 * plane, ctx->n, ctx->dcam, ctx->frames.p, frame_begin, frame_end, ctx->depth.p,
                        cells_of(ctx), ctx->tile_mask.p, ctx->mask_words, ctx->images.p,
                        static_cast<int64_t>(ctx->dcam.img_w) * ctx->dcam.img_h, st, ctx->perm.p,
                        (one_shot && unpermute_results()) ? ctx->rgba_sorted.p : result,
-                       flags | ((one_shot && unpermute_results()) ? 8 : 0),
-                       ordered ? ctx->tile_order.p : static_cast<const int32_t *>(nullptr),
+                       launch_flags, ordered ? ctx->tile_order.p : static_cast<const int32_t *>(nullptr),
                        ctx->cull.cull_mode == PCP_CULL_HPR ? ctx->hull_bits.p : static_cast<const uint32_t *>(nullptr));
     if (one_shot && unpermute_results())
       hipLaunchKernelGGL(k_unpermute, dim3(blocks_for(div_up(ctx->n, 4))), dim3(kBlock), 0, ctx->stream, ctx->rgba_sorted.p,

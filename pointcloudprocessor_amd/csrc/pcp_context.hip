@@ -799,15 +799,6 @@ int pcp_set_camera(pcp_context *ctx, const pcp_camera *cam, const pcp_cull_param
   d.qk3 = static_cast<float>(cam->k3);
   d.qp1 = static_cast<float>(cam->p1);
   d.qp2 = static_cast<float>(cam->p2);
-  d.ak1 = std::fabs(d.qk1);
-  d.ak2 = std::fabs(d.qk2);
-  d.ak3 = std::fabs(d.qk3);
-  d.ap1 = std::fabs(d.qp1);
-  d.ap2 = std::fabs(d.qp2);
-  d.afx = std::fabs(d.qfx);
-  d.afy = std::fabs(d.qfy);
-  d.acx = std::fabs(d.qcx);
-  d.acy = std::fabs(d.qcy);
   {
     // cell rule accepts trunc(f32(u)/ds) in [0, mw) (depth buffer on) or [0, cull_w) (off);
     // pixel rule accepts (int)u in [0, img_w).  Box = union, +-0.5 px.

@@ -150,18 +150,19 @@ __device__ __forceinline__ bool surely_rejected(const DevCamera &c, float xc, fl
   const float x2 = xn * xn, y2 = yn * yn;
   const float r2 = x2 + y2, r4 = r2 * r2, r6 = r2 * r4;
   const float rc = __builtin_fmaf(c.qk3, r6, __builtin_fmaf(c.qk2, r4, __builtin_fmaf(c.qk1, r2, 1.0f)));
-  const float ra = __builtin_fmaf(c.ak3, r6, __builtin_fmaf(c.ak2, r4, __builtin_fmaf(c.ak1, r2, 1.0f)));
+  // the absolute-valued coefficients are |q..| as source modifiers of the same scalar registers (no copies held)
+  const float ra = __builtin_fmaf(fabsf(c.qk3), r6, __builtin_fmaf(fabsf(c.qk2), r4, __builtin_fmaf(fabsf(c.qk1), r2, 1.0f)));
   const float t1 = 2.0f * xn * yn;
   const float t2 = __builtin_fmaf(2.0f, x2, r2), t3 = __builtin_fmaf(2.0f, y2, r2);
   const float at1 = fabsf(t1);
   const float xd = __builtin_fmaf(c.qp2, t2, __builtin_fmaf(c.qp1, t1, rc * xn));
   const float yd = __builtin_fmaf(c.qp2, t1, __builtin_fmaf(c.qp1, t3, rc * yn));
-  const float sx = __builtin_fmaf(c.ap2, t2, __builtin_fmaf(c.ap1, at1, ra * fabsf(xn)));
-  const float sy = __builtin_fmaf(c.ap2, at1, __builtin_fmaf(c.ap1, t3, ra * fabsf(yn)));
+  const float sx = __builtin_fmaf(fabsf(c.qp2), t2, __builtin_fmaf(fabsf(c.qp1), at1, ra * fabsf(xn)));
+  const float sy = __builtin_fmaf(fabsf(c.qp2), at1, __builtin_fmaf(fabsf(c.qp1), t3, ra * fabsf(yn)));
   const float u = __builtin_fmaf(c.qfx, xd, c.qcx), v = __builtin_fmaf(c.qfy, yd, c.qcy);
   constexpr float kErr = 1.52587890625e-05f;  // 2^-16
-  const float eu = kErr * __builtin_fmaf(c.afx, sx, c.acx);
-  const float ev = kErr * __builtin_fmaf(c.afy, sy, c.acy);
+  const float eu = kErr * __builtin_fmaf(fabsf(c.qfx), sx, fabsf(c.qcx));
+  const float ev = kErr * __builtin_fmaf(fabsf(c.qfy), sy, fabsf(c.qcy));
   return (u + eu < c.u_lo) | (u - eu > c.u_hi) | (v + ev < c.v_lo) | (v - ev > c.v_hi);
 }
 

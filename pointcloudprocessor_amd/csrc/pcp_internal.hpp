@@ -37,13 +37,11 @@ struct DevCamera {
   double cull_wd, cull_hd;  // cull size as fp64: bounds of hidden_points_removal's (int)u, (int)v rule
   float match_r2;      // f32(1e-5 * 1e-5): radiusSearch(epsilon) squared radius, PointCloudProcessor.cpp:482,571
   int32_t pretest;  // 1: run the conservative fp32 rejection test before the fp64 projection
-  // fp32 copies for the rejection test (pcp_device.hpp surely_rejected): signed and
-  // absolute coefficients, and the (u, v) box outside of which BOTH the cell rule and
-  // the pixel rule reject, widened by 0.5 px
+  // fp32 copies for the rejection test (pcp_device.hpp surely_rejected): the coefficients (their absolute
+  // values are source modifiers of the same registers) and the (u, v) box outside of which BOTH the cell rule
+  // and the pixel rule reject, widened by 0.5 px
   float qfx, qfy, qcx, qcy;
   float qk1, qk2, qk3, qp1, qp2;
-  float ak1, ak2, ak3, ap1, ap2;
-  float afx, afy, acx, acy;
   float u_lo, u_hi, v_lo, v_hi;
 };
 
