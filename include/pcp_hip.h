@@ -299,6 +299,20 @@ int pcp_cloud_smooth(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_cou
  * coordinates: a cloud with NaN or infinite points is refused with PCP_ERR_INVALID (PCL's filters skip such points one
  * by one; the projection / colour entry points accept them and reject the points, Appendix B6). */
 int pcp_sor(pcp_context *ctx, int32_t mean_k, double std_mul, uint8_t *out_keep, int64_t *out_kept);
+/* Multi-GPU form of pcp_sor (the cloud on every GPU, the queries dealt out by index).  The filter's threshold
+ * is mean + std_mul * stddev of ALL mean distances (cloudSmooth.cpp:113-115 -> statistical_outlier_removal.hpp [upstream]),
+ * so a shard cannot classify alone; its statistics are kept as one (sum, sum of squares) pair per chunk of
+ * pcp_sor_chunk_points() consecutive indices, each chunk summed in a fixed order by whichever GPU owns it:
+ *   pcp_sor_partial  mean distances of the queries index_begin <= i < index_end (bounds on chunk boundaries, index_end
+ *                    may be the point count) and their chunk sums: 2 doubles per chunk of the range into out_chunk_sums;
+ *   (the caller concatenates the shards' arrays in index order: ceil(n / chunk) pairs -- the array one GPU computes)
+ *   pcp_sor_finish   threshold from all chunk sums, keep flags of the range (out_keep[i - index_begin]).
+ * pcp_sor itself is partial + finish over [0, n): the sharded keep mask equals it bit for bit. */
+int64_t pcp_sor_chunk_points(void);
+int pcp_sor_partial(pcp_context *ctx, int32_t mean_k, int64_t index_begin, int64_t index_end, int64_t capacity,
+                    double *out_chunk_sums);
+int pcp_sor_finish(pcp_context *ctx, double std_mul, const double *all_chunk_sums, int64_t n_chunks, int64_t index_begin,
+                   int64_t index_end, uint8_t *out_keep, int64_t *out_kept);
 
 /* ---- NID extrinsic refinement (VisualLiDARCalibration::calibrate, PCP/src/calibrate.cpp:42-126) -- */
 /* per-point intensity of the uploaded cloud (pcl::PointXYZI::intensity), needed by the NID stage */

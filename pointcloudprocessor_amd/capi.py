@@ -110,6 +110,8 @@ def load(build_if_needed: bool = True) -> C.CDLL:
     L.pcp_last_error.argtypes = [C.c_void_p]
     L.pcp_kernel_name.restype = C.c_char_p
     L.pcp_cloud_size.restype = C.c_int64
+    L.pcp_sor_chunk_points.restype = C.c_int64
+    L.pcp_sor_chunk_points.argtypes = []
     L.pcp_cloud_size.argtypes = [C.c_void_p]
     L.pcp_frame_count.restype = C.c_int32
     L.pcp_frame_count.argtypes = [C.c_void_p]
@@ -442,6 +444,26 @@ class Context:
         keep = np.empty(self.n, np.uint8)
         kept = C.c_int64()
         self._check(self.lib.pcp_sor(self.h, C.c_int32(mean_k), C.c_double(std_mul), _ptr(keep), C.byref(kept)))
+        return keep, kept.value
+
+    def sor_chunk_points(self) -> int:
+        return int(self.lib.pcp_sor_chunk_points())
+
+    def sor_partial(self, mean_k: int, index_begin: int, index_end: int) -> np.ndarray:
+        """Index shard of sor(): (sum, sum of squares) of the mean distances per chunk of the range."""
+        c = self.sor_chunk_points()
+        chunks = (index_end + c - 1) // c - index_begin // c
+        out = np.zeros((max(chunks, 0), 2), np.float64)
+        self._check(self.lib.pcp_sor_partial(self.h, C.c_int32(mean_k), C.c_int64(index_begin), C.c_int64(index_end),
+                                             C.c_int64(len(out)), _ptr(out)))
+        return out
+
+    def sor_finish(self, std_mul: float, all_chunk_sums: np.ndarray, index_begin: int, index_end: int):
+        sums = np.ascontiguousarray(all_chunk_sums, np.float64)
+        keep = np.empty(max(index_end - index_begin, 0), np.uint8)
+        kept = C.c_int64()
+        self._check(self.lib.pcp_sor_finish(self.h, C.c_double(std_mul), _ptr(sums), C.c_int64(len(sums)),
+                                            C.c_int64(index_begin), C.c_int64(index_end), _ptr(keep), C.byref(kept)))
         return keep, kept.value
 
     def close_pairs(self, radius: float = 2.5e-5) -> int:

@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(6, 8))
                                                          const int32_t *__restrict__ remap,
                                                          const int32_t *__restrict__ start, int64_t n, GridDesc g,
                                                          int32_t mean_k, float *__restrict__ distances,
-                                                         uint8_t *__restrict__ redo) {
+                                                         uint8_t *__restrict__ redo, int64_t q_begin, int64_t q_end) {
 #pragma clang fp contract(off)
   __shared__ uint32_t sel_lds[kSelLdsWords];
   float *list = reinterpret_cast<float *>(sel_lds);            // [kSelDrain][64]
@@ -1120,8 +1120,15 @@ __global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(6, 8))
     const uint32_t v = sel_lds[b * 32 + (lane & 31)];
     return static_cast<int>(lane < 32 ? (v & 0xffffu) : (v >> 16));
   };
-  bool bad = false, sparse = false;
-  {
+  // index shards (pcp_sor_partial): a point whose index (as `distances` is indexed) lies outside [q_begin, q_end) belongs
+  // to another GPU -- its lane sits out and writes nothing
+  bool skip = false;
+  if (q_begin > 0 || q_end < n) {
+    const int64_t i = remap ? remap[order[j]] : order[j];
+    skip = i < q_begin || i >= q_end;
+  }
+  bool bad = skip, sparse = false;
+  if (!skip) {
     // a counter cannot wrap (and carry into the lane it shares a dword with): the 27 cells hold fewer candidates than
     // it can count, else the heap kernel takes the lane
     uint32_t total = 0;
@@ -1297,7 +1304,7 @@ __global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(6, 8))
     if (live && !tiny) distances[remap ? remap[order[j]] : order[j]] = static_cast<float>(sum / static_cast<double>(mean_k));
   }
   // 1: the ball of one cell holds too few points (k_sor_wave starts with two cells); 3: any other reason
-  if (live) redo[j] = sparse ? 1 : ((bad || tiny) ? 3 : 0);
+  if (live) redo[j] = skip ? 0 : (sparse ? 1 : ((bad || tiny) ? 3 : 0));
 }
 
 // The lanes k_sor_select flags (sparse spots and borders of a surface: fewer than k + 1 points within one cell; dense
@@ -1512,14 +1519,19 @@ __global__ __launch_bounds__(kSelWave) void k_sor_wave(const float *__restrict__
   }
 }
 
-// sum and sum of squares (fp32 squares, as the reference) of the distances, fp64 accumulation: one pair of partial sums
-// per workgroup, added up in a fixed order by k_sor_threshold (no atomics: the threshold is the same on every run)
-constexpr int kStatsBlocks = 1024;
-__global__ __launch_bounds__(kMB) void k_sor_stats(const float *__restrict__ distances, int64_t n,
-                                                   double *__restrict__ partial /* [kStatsBlocks][2] */) {
+// sum and sum of squares (fp32 squares, as the reference) of the distances, fp64 accumulation.  One pair of partial sums
+// per CHUNK of kSorChunk consecutive points (a workgroup per chunk, every lane a fixed sub-sequence, a fixed reduction
+// tree), added up over the chunks in a fixed order by k_sor_threshold: no atomics, so the threshold is the same on every
+// run -- and the same however the chunks are dealt out to GPUs (pcp_sor_partial: index shards aligned to chunks compute
+// their own chunks' pairs; the concatenation is the array one GPU computes).
+constexpr int64_t kSorChunk = 16384;
+__global__ __launch_bounds__(kMB) void k_sor_stats(const float *__restrict__ distances, int64_t n, int64_t first_chunk,
+                                                   double *__restrict__ partial /* [chunks of the cloud][2] */) {
   __shared__ double sh[2][kMB / 64];
+  const int64_t chunk = first_chunk + blockIdx.x;
+  const int64_t lo = chunk * kSorChunk, hi = min(lo + kSorChunk, n);
   double s = 0.0, q = 0.0;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kMB) {
+  for (int64_t i = lo + threadIdx.x; i < hi; i += kMB) {
     const float d = distances[i];
     s += static_cast<double>(d);
     q += static_cast<double>(__fmul_rn(d, d));
@@ -1539,19 +1551,19 @@ __global__ __launch_bounds__(kMB) void k_sor_stats(const float *__restrict__ dis
       ts += sh[0][k];
       tq += sh[1][k];
     }
-    partial[2 * blockIdx.x] = ts;
-    partial[2 * blockIdx.x + 1] = tq;
+    partial[2 * chunk] = ts;
+    partial[2 * chunk + 1] = tq;
   }
 }
 
 // mean + std_mul * stddev of the distances from the workgroups' partial sums (statistical_outlier_removal.hpp [upstream]), on the device:
 // the host does not have to wait for the sums between the two kernels.  Individually rounded IEEE operations, as the
 // host form compiles.
-__global__ __launch_bounds__(64) void k_sor_threshold(const double *__restrict__ partial, int blocks, int64_t n, double std_mul,
+__global__ __launch_bounds__(64) void k_sor_threshold(const double *__restrict__ partial, int64_t blocks, int64_t n, double std_mul,
                                                       double *__restrict__ threshold) {
 #pragma clang fp contract(off)
   double s = 0.0, q = 0.0;
-  for (int b = threadIdx.x; b < blocks; b += 64) {
+  for (int64_t b = threadIdx.x; b < blocks; b += 64) {
     s += partial[2 * b];
     q += partial[2 * b + 1];
   }
@@ -1567,10 +1579,10 @@ __global__ __launch_bounds__(64) void k_sor_threshold(const double *__restrict__
   }
 }
 
-__global__ __launch_bounds__(kMB) void k_sor_classify(const float *__restrict__ distances, int64_t n,
+__global__ __launch_bounds__(kMB) void k_sor_classify(const float *__restrict__ distances, int64_t begin, int64_t end,
                                                       const double *__restrict__ threshold, uint8_t *__restrict__ keep) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
-  if (i < n) keep[i] = !(static_cast<double>(distances[i]) > *threshold) ? 1 : 0;
+  const int64_t i = begin + static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  if (i < end) keep[i] = !(static_cast<double>(distances[i]) > *threshold) ? 1 : 0;
 }
 
 // a cloud on the device the smoothing stages operate on (the uploaded map, or an
@@ -2155,10 +2167,16 @@ static int mls_run(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *
 
 // StatisticalOutlierRemoval on a cloud view: keep flags in ctx->m_flag (view order)
 // view_order: distances and keep flags under the view's own indices (ctx->m_flag[view index]) instead of the caller's
-static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double std_mul, bool view_order = false) {
+// Index shards (pcp_sor_partial / pcp_sor_finish): q_begin <= index < q_end are this GPU's queries (bounds on chunk
+// boundaries, see k_sor_stats); `classify` false stops after the chunk sums (they sit in ctx->m_sums from double 4 on).
+static int sor_classify(pcp_context *ctx, int64_t n, double std_mul, int64_t q_begin, int64_t q_end);
+static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double std_mul, bool view_order = false,
+                   int64_t q_begin = 0, int64_t q_end = -1, bool classify = true) {
   const int32_t *remap = view_order ? nullptr : cv.remap;
   const int64_t n = cv.n;
   if (n == 0) return PCP_OK;
+  if (q_end < 0) q_end = n;
+  const bool whole = q_begin == 0 && q_end == n;
   const size_t sn = static_cast<size_t>(n);
   const size_t plane = (sn + 3) & ~size_t(3);
   // cell edge: first a volume-based guess, then refined from the number of occupied cells so that
@@ -2207,12 +2225,15 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
   }
   PCP_HIP_TRY(ctx, ctx->s_dist.ensure(sn + 8));
   PCP_HIP_TRY(ctx, ctx->m_flag.ensure(sn + 16));
-  PCP_HIP_TRY(ctx, ctx->m_sums.ensure(4 + 2 * kStatsBlocks));
+  const int64_t chunks = div_up(n, kSorChunk);
+  PCP_HIP_TRY(ctx, ctx->m_sums.ensure(4 + 2 * static_cast<size_t>(chunks)));
   float *dist = ctx->s_dist.p;
   const size_t heap_lds = static_cast<size_t>(mean_k + 1) * kSorBlock * sizeof(float);
   const char *heap_only = std::getenv("PCP_SOR_HEAP_ONLY");
   // the selection kernel addresses the coordinate planes through buffer descriptors (32-bit byte offsets)
-  const bool use_select = !(heap_only && heap_only[0] == '1') && n < (int64_t(1) << 30);
+  const bool use_select = (!(heap_only && heap_only[0] == '1') || !whole) && n < (int64_t(1) << 30);
+  if (!whole && !(use_select && mean_k + 1 <= 250))
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_sor_partial: index shards need mean_k <= 249 and fewer than 2^30 points");
   if (use_select && mean_k + 1 <= 250) {
     // selection kernel for every point, heap kernel for the few it flags (sparse spots, borders of a surface)
     PCP_HIP_TRY(ctx, ctx->s_cell.ensure(sn + 8));
@@ -2220,7 +2241,7 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
       LaunchTimer t(ctx, PCP_K_SOR);
       hipLaunchKernelGGL(k_sor_select, dim3(static_cast<uint32_t>(div_up(n, kSelWave))), dim3(kSelWave), 0, ctx->stream,
                          ctx->g_xyz.p, ctx->g_xyz.p + plane, ctx->g_xyz.p + 2 * plane, ctx->g_order.p, remap,
-                         ctx->g_start.p, n, g, mean_k, dist, ctx->m_flag.p);
+                         ctx->g_start.p, n, g, mean_k, dist, ctx->m_flag.p, q_begin, q_end);
       PCP_HIP_TRY(ctx, hipGetLastError());
     }
     int64_t redo = 0;
@@ -2252,14 +2273,26 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   {
+    // the chunks of this GPU's index range
     LaunchTimer t(ctx, PCP_K_SOR);
-    const int blocks = static_cast<int>(std::min<int64_t>(div_up(n, kMB), kStatsBlocks));
-    double *partial = ctx->m_sums.p + 4, *threshold = ctx->m_sums.p;
-    hipLaunchKernelGGL(k_sor_stats, dim3(static_cast<uint32_t>(blocks)), dim3(kMB), 0, ctx->stream, dist, n, partial);
-    hipLaunchKernelGGL(k_sor_threshold, dim3(1), dim3(64), 0, ctx->stream, partial, blocks, n, std_mul, threshold);
-    hipLaunchKernelGGL(k_sor_classify, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, dist, n, threshold, ctx->m_flag.p);
+    const int64_t c0 = q_begin / kSorChunk, c1 = div_up(q_end, kSorChunk);
+    if (c1 > c0)
+      hipLaunchKernelGGL(k_sor_stats, dim3(static_cast<uint32_t>(c1 - c0)), dim3(kMB), 0, ctx->stream, dist, n, c0,
+                         ctx->m_sums.p + 4);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
+  return classify ? sor_classify(ctx, n, std_mul, q_begin, q_end) : PCP_OK;
+}
+
+// threshold from the chunk sums of the WHOLE cloud (ctx->m_sums), keep flags of the indices [q_begin, q_end)
+static int sor_classify(pcp_context *ctx, int64_t n, double std_mul, int64_t q_begin, int64_t q_end) {
+  LaunchTimer t(ctx, PCP_K_SOR);
+  double *partial = ctx->m_sums.p + 4, *threshold = ctx->m_sums.p;
+  hipLaunchKernelGGL(k_sor_threshold, dim3(1), dim3(64), 0, ctx->stream, partial, div_up(n, kSorChunk), n, std_mul, threshold);
+  if (q_end > q_begin)
+    hipLaunchKernelGGL(k_sor_classify, dim3(blocks_of(q_end - q_begin)), dim3(kMB), 0, ctx->stream, ctx->s_dist.p, q_begin, q_end,
+                       threshold, ctx->m_flag.p);
+  PCP_HIP_TRY(ctx, hipGetLastError());
   return PCP_OK;
 }
 
@@ -2416,6 +2449,67 @@ int pcp_sor(pcp_context *ctx, int32_t mean_k, double std_mul, uint8_t *out_keep,
   }
   if (out_keep)
     PCP_HIP_TRY(ctx, hipMemcpyAsync(out_keep, ctx->m_flag.p, static_cast<size_t>(n), hipMemcpyDeviceToHost, ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PCP_OK;
+}
+
+int64_t pcp_sor_chunk_points(void) { return kSorChunk; }
+
+static int check_sor_shard(pcp_context *ctx, const char *who, int64_t index_begin, int64_t index_end) {
+  if (!ctx->xyz.p) return set_error(ctx, PCP_ERR_STATE, "%s: no cloud uploaded", who);
+  const int64_t n = ctx->n;
+  if (index_begin < 0 || index_end < index_begin || index_end > n)
+    return set_error(ctx, PCP_ERR_RANGE, "%s: index range [%lld, %lld) outside the %lld uploaded points", who, (long long)index_begin, (long long)index_end, (long long)n);
+  if (index_begin % kSorChunk != 0 || (index_end % kSorChunk != 0 && index_end != n))
+    return set_error(ctx, PCP_ERR_INVALID, "%s: shard bounds must be multiples of pcp_sor_chunk_points() = %lld (or the point count)", who, (long long)kSorChunk);
+  return PCP_OK;
+}
+
+int pcp_sor_partial(pcp_context *ctx, int32_t mean_k, int64_t index_begin, int64_t index_end, int64_t capacity,
+                    double *out_chunk_sums) {
+  if (!ctx) return PCP_ERR_INVALID;
+  int rc = check_sor_shard(ctx, "pcp_sor_partial", index_begin, index_end);
+  if (rc != PCP_OK) return rc;
+  if (int rcf = require_finite_cloud(ctx, "pcp_sor_partial")) return rcf;
+  if (mean_k < 1 || mean_k > 249) return set_error(ctx, PCP_ERR_INVALID, "pcp_sor_partial: mean_k %d out of range (1..249)", mean_k);
+  const int64_t c0 = index_begin / kSorChunk, c1 = div_up(index_end, kSorChunk);
+  if (capacity < c1 - c0 || (c1 > c0 && !out_chunk_sums))
+    return set_error(ctx, PCP_ERR_RANGE, "pcp_sor_partial: room for %lld chunks, the range has %lld", (long long)capacity, (long long)(c1 - c0));
+  PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ctx->sor_distances_live = false;
+  if (index_end == index_begin) return PCP_OK;
+  if ((rc = sor_run(ctx, uploaded_view(ctx), mean_k, 0.0, false, index_begin, index_end, /*classify=*/false)) != PCP_OK) return rc;
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(out_chunk_sums, ctx->m_sums.p + 4 + 2 * c0, static_cast<size_t>(c1 - c0) * 2 * sizeof(double),
+                                  hipMemcpyDeviceToHost, ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PCP_OK;
+}
+
+int pcp_sor_finish(pcp_context *ctx, double std_mul, const double *all_chunk_sums, int64_t n_chunks, int64_t index_begin,
+                   int64_t index_end, uint8_t *out_keep, int64_t *out_kept) {
+  if (!ctx) return PCP_ERR_INVALID;
+  int rc = check_sor_shard(ctx, "pcp_sor_finish", index_begin, index_end);
+  if (rc != PCP_OK) return rc;
+  const int64_t n = ctx->n;
+  if (out_kept) *out_kept = 0;
+  if (n == 0) return PCP_OK;
+  if (n_chunks != div_up(n, kSorChunk) || !all_chunk_sums)
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_sor_finish: %lld chunk sums given, the cloud has %lld chunks", (long long)n_chunks, (long long)div_up(n, kSorChunk));
+  if (index_end == index_begin) return PCP_OK;  // a GPU without queries (fewer chunks than GPUs)
+  if (!ctx->s_dist.p || !ctx->m_sums.p || ctx->m_sums.count < 4 + 2 * static_cast<size_t>(n_chunks))
+    return set_error(ctx, PCP_ERR_STATE, "pcp_sor_finish: no pcp_sor_partial on this context");
+  PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->m_sums.p + 4, all_chunk_sums, static_cast<size_t>(n_chunks) * 2 * sizeof(double),
+                                  hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = sor_classify(ctx, n, std_mul, index_begin, index_end)) != PCP_OK) return rc;
+  const int64_t m = index_end - index_begin;
+  if (out_kept && m > 0) {
+    int64_t kept = 0;
+    if ((rc = compact_flags(ctx, ctx->m_flag.p + index_begin, m, nullptr, 0, &kept)) != PCP_OK) return rc;
+    *out_kept = kept;
+  }
+  if (out_keep && m > 0)
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(out_keep, ctx->m_flag.p + index_begin, static_cast<size_t>(m), hipMemcpyDeviceToHost, ctx->stream));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return PCP_OK;
 }

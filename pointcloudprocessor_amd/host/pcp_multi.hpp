@@ -28,6 +28,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pcp_shim.hpp"
@@ -465,15 +466,41 @@ class MultiCloudSmooth {
   }
 
  private:
-  // pcl::StatisticalOutlierRemoval on GPU 0: indices kept, ascending
+  // pcl::StatisticalOutlierRemoval over all GPUs (cloudSmooth.cpp:109-116,160-164): the cloud on every GPU, the queries
+  // dealt out by index on chunk boundaries (pcp_sor_partial), the chunk sums of the shards put together in index order --
+  // the array one GPU computes, so the threshold is the one-GPU threshold bit for bit -- and every GPU classifies its own
+  // range (pcp_sor_finish).  The exchange is ceil(n / 16384) pairs of doubles through the host (10 KB at 10 M points); the
+  // calls synchronise with the host, hence one host thread per GPU.  Returns the indices kept, ascending.
   std::vector<int32_t> outlierRemoval(const float *x, const float *y, const float *z, int64_t n) {
-    Device &d = *dev_[0];
-    d.uploadCloud(x, y, z, n);
+    const int N = size();
+    const int64_t chunk = pcp_sor_chunk_points(), chunks = (n + chunk - 1) / chunk;
+    std::vector<int64_t> bound(static_cast<size_t>(N) + 1, n);
+    for (int r = 0; r < N; ++r) bound[static_cast<size_t>(r)] = std::min<int64_t>(n, (chunks * r / N) * chunk);
+    std::vector<double> sums(static_cast<size_t>(2 * chunks));
     std::vector<uint8_t> keep(static_cast<size_t>(n));
-    int64_t kept = 0;
-    d.check(pcp_sor(d.get(), params_.sor_mean_k, params_.sor_std_mul, keep.data(), &kept));
+    std::vector<std::string> failure(static_cast<size_t>(N));
+    auto on_every_gpu = [&](auto &&body) {
+      std::vector<std::thread> th;
+      for (int r = 0; r < N; ++r)
+        th.emplace_back([&, r] {
+          try {
+            body(r, *dev_[static_cast<size_t>(r)], bound[static_cast<size_t>(r)], bound[static_cast<size_t>(r) + 1]);
+          } catch (const std::exception &e) {
+            failure[static_cast<size_t>(r)] = e.what();
+          }
+        });
+      for (auto &t : th) t.join();
+      for (const auto &f : failure)
+        if (!f.empty()) throw std::runtime_error(f);
+    };
+    on_every_gpu([&](int, Device &d, int64_t b, int64_t e) {
+      d.uploadCloud(x, y, z, n);
+      d.check(pcp_sor_partial(d.get(), params_.sor_mean_k, b, e, (e + chunk - 1) / chunk - b / chunk, sums.data() + 2 * (b / chunk)));
+    });
+    on_every_gpu([&](int, Device &d, int64_t b, int64_t e) {
+      d.check(pcp_sor_finish(d.get(), params_.sor_std_mul, sums.data(), chunks, b, e, keep.data() + b, nullptr));
+    });
     std::vector<int32_t> idx;
-    idx.reserve(static_cast<size_t>(kept));
     for (int64_t i = 0; i < n; ++i)
       if (keep[static_cast<size_t>(i)]) idx.push_back(static_cast<int32_t>(i));
     return idx;

@@ -290,6 +290,35 @@ class CloudSmooth:
         return dict(xyz=np.ascontiguousarray(allp[:, 0:3]), normal=np.ascontiguousarray(allp[:, 3:6]),
                     curvature=np.ascontiguousarray(allp[:, 6]), index=np.ascontiguousarray(allp[:, 7]).view(np.int32))
 
+    def outlier_removal_sharded(self, n_total: int, rank: int, world: int, group=None):
+        """StatisticalOutlierRemoval (cloudSmooth.cpp:109-116) with the queries dealt out by index on chunk boundaries:
+        every rank holds the whole cloud, computes the mean distances and per-chunk (sum, sum of squares) of its own
+        range, the chunk sums are all-gathered (ceil(n / 16384) pairs of doubles), every rank classifies its range and
+        the keep flags are all-gathered.  Equal to ctx.sor() on one GPU bit for bit.  Returns the full keep mask."""
+        ctx = self.engine.ctx
+        c = ctx.sor_chunk_points()
+        chunks = (n_total + c - 1) // c
+        bounds = [min(n_total, (chunks * r // world) * c) for r in range(world)] + [n_total]
+        lo, hi = bounds[rank], bounds[rank + 1]
+        sums = np.zeros((chunks, 2), np.float64)
+        sums[lo // c:(hi + c - 1) // c] = ctx.sor_partial(self.params.sor_mean_k, lo, hi)
+        keep = np.zeros(n_total, np.uint8)
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+
+            dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+            # every chunk is owned by exactly one rank and zero elsewhere: x + 0.0 is exact, the sum IS the concatenation
+            t = torch.from_numpy(sums).to(dev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            sums = t.cpu().numpy()
+        keep[lo:hi] = ctx.sor_finish(self.params.sor_std_mul, sums, lo, hi)[0]
+        if world > 1:
+            t = torch.from_numpy(keep).to(dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            keep = t.cpu().numpy()
+        return keep
+
     def process(self, with_outlier_removal: bool = True):
         """SOR -> MLS (+ upsampling) -> SOR as cloudSmooth.cpp:109-164; MLS alone when asked."""
         ctx = self.engine.ctx

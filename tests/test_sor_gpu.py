@@ -178,3 +178,53 @@ def test_sor_stray_points_far_from_the_cloud(gpu_ctx_factory, oracle):
     t = time.time()
     _check(ctx, oracle, pts[:, 0].copy(), pts[:, 1].copy(), pts[:, 2].copy(), 60, 0.7)
     assert time.time() - t < 20.0  # oracle included
+
+
+@pytest.mark.parametrize("shards", [2, 3, 5])
+def test_sor_index_shards_equal_the_one_gpu_filter(gpu_ctx_factory, shards):
+    """pcp_sor_partial / pcp_sor_finish (queries dealt out by index, cloudSmooth.cpp:109-116): shards on
+    chunk boundaries, chunk sums concatenated, every shard classifies its own range == pcp_sor bit for bit."""
+    from pointcloudprocessor_amd import synth
+
+    x, y, z, _ = synth.make_cloud(150_000, seed=11)
+    n = len(x)
+    ref = gpu_ctx_factory()
+    ref.upload_cloud(x, y, z)
+    keep_ref, kept_ref = ref.sor(60, 0.7)
+    c = ref.sor_chunk_points()
+    chunks = (n + c - 1) // c
+    bounds = [min(n, (chunks * r // shards) * c) for r in range(shards)] + [n]
+    ctxs = []
+    sums = []
+    for r in range(shards):
+        ctx = gpu_ctx_factory()
+        ctx.upload_cloud(x, y, z)
+        sums.append(ctx.sor_partial(60, bounds[r], bounds[r + 1]))
+        ctxs.append(ctx)
+    all_sums = np.concatenate(sums)
+    assert len(all_sums) == chunks
+    keep = np.concatenate([ctxs[r].sor_finish(0.7, all_sums, bounds[r], bounds[r + 1])[0] for r in range(shards)])
+    assert np.array_equal(keep, keep_ref)
+    assert int(keep.sum()) == kept_ref
+    # misaligned bounds are refused
+    with pytest.raises(Exception):
+        ctxs[0].sor_partial(60, 100, n)
+
+
+def test_sor_sharded_python_host_single_rank(gpu_ctx_factory):
+    """pipeline.CloudSmooth.outlier_removal_sharded at world 1 (the collective-free path) == ctx.sor()."""
+    from pointcloudprocessor_amd import pipeline, synth
+
+    x, y, z, _ = synth.make_cloud(60_000, seed=5)
+    ctx = gpu_ctx_factory()
+    ctx.upload_cloud(x, y, z)
+    keep_ref, _ = ctx.sor(60, 0.7)
+
+    class _Engine:
+        pass
+
+    eng = _Engine()
+    eng.ctx = ctx
+    cs = pipeline.CloudSmooth(eng)
+    keep = cs.outlier_removal_sharded(len(x), 0, 1)
+    assert np.array_equal(keep, keep_ref)
