@@ -371,10 +371,31 @@ __device__ __forceinline__ uint32_t xcd_chunked_block() {
 // point per pass) and the wavefront only visits keyframes its tile mask keeps.
 // tile_mask == nullptr: visit every keyframe of the range.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void depth_min(uint32_t *__restrict__ map, int32_t cell, float range) {
-  const uint32_t bits = __float_as_uint(range);
+// The z-buffer holds, per cell, min over the points of f32(sqrt(s)), s = (X X + Y Y) + Z Z in fp64 (view_culling.cpp:102).
+// s -> f32(RN(sqrt(s))) is monotone, so that minimum is f32(sqrt(min s)): the pass takes the minimum of s itself (the bit
+// pattern of a non-negative double orders as an unsigned integer) and k_depth_finish takes ONE square root per cell -- the
+// correctly rounded fp64 sqrt (a 16-cycle v_rsq_f64 and ~20 more instructions) leaves the per-visit path.
+constexpr unsigned long long kDepthEmpty = 0x7f7f7f7f7f7f7f7full;  // hipMemset pattern; above every finite s, below NaN
+__device__ __forceinline__ void depth_min(unsigned long long *__restrict__ map, int32_t cell, unsigned long long bits) {
   // a plain (possibly stale, hence >= current) read filters most atomics
   if (bits < map[cell]) atomicMin(map + cell, bits);
+}
+__device__ __forceinline__ double sumsq64(float xc, float yc, float zc) {
+  const double X = xc, Y = yc, Z = zc;
+  return (X * X + Y * Y) + Z * Z;
+}
+// range map of the reference from the squared-range map: f32(sqrt(min s)); an empty cell keeps FLT_MAX, and so does a cell
+// whose nearest point is farther than FLT_MAX (the reference's `dist < map` is false for an infinite fp32 range)
+__global__ __launch_bounds__(kBlock) void k_depth_finish(const unsigned long long *__restrict__ sq, int64_t count,
+                                                         uint32_t *__restrict__ range) {
+  int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (; i < count; i += stride) {
+    const unsigned long long b = sq[i];
+    float r = FLT_MAX;
+    if (b != kDepthEmpty) r = fminf(static_cast<float>(sqrt(__longlong_as_double(static_cast<long long>(b)))), FLT_MAX);
+    range[i] = __float_as_uint(r);
+  }
 }
 
 __device__ __forceinline__ uint32_t range_bits(int32_t w, int32_t f0, int32_t f1) {
@@ -390,7 +411,7 @@ template <bool kCommon>
 __global__ __launch_bounds__(kBlock) void k_depth_pass(const float *__restrict__ x, const float *__restrict__ y,
                                                        const float *__restrict__ z, int64_t n, DevCamera cam_in,
                                                        const DevFrame *__restrict__ frames, int32_t f0, int32_t f1,
-                                                       uint32_t *__restrict__ depth, int64_t cells,
+                                                       unsigned long long *__restrict__ depth, int64_t cells,
                                                        int32_t depth_first_frame, uint32_t *__restrict__ tile_mask,
                                                        const uint32_t *__restrict__ tile_inside, int32_t words,
                                                        const int32_t *__restrict__ tile_order) {
@@ -429,11 +450,14 @@ __global__ __launch_bounds__(kBlock) void k_depth_pass(const float *__restrict__
         // cell's current value first and skipping the square root, the combine and the atomic for points that cannot
         // lower it -- s >= m * m -- was slower, 0.79 -> 0.82 ms: some lane of the wavefront nearly always stays, so the
         // wavefront pays for the whole path anyway, plus the extra gather.)
-        uint32_t *map = depth + static_cast<int64_t>(f - depth_first_frame) * cells;
-        unsigned long long key = ~0ull;
-        if (in_map)
-          key = (static_cast<unsigned long long>(static_cast<uint32_t>(p.cell)) << 32) |
-                __float_as_uint(static_cast<float>(range64(p.xc, p.yc, p.zc)));
+        unsigned long long *map = depth + static_cast<int64_t>(f - depth_first_frame) * cells;
+        // the table elects by the upper half of s's bit pattern (monotone in s): lanes of a cell that tie there (ranges
+        // within 1e-6 of each other) all go to the map, which settles them in full precision
+        unsigned long long key = ~0ull, sbits = 0ull;
+        if (in_map) {
+          sbits = static_cast<unsigned long long>(__double_as_longlong(sumsq64(p.xc, p.yc, p.zc)));
+          key = (static_cast<unsigned long long>(static_cast<uint32_t>(p.cell)) << 32) | (sbits >> 32);
+        }
         tbl[lane] = ~0ull;
         __builtin_amdgcn_wave_barrier();
         if (in_map) atomicMin(&tbl[p.cell & 63], key);
@@ -441,8 +465,7 @@ __global__ __launch_bounds__(kBlock) void k_depth_pass(const float *__restrict__
         if (in_map) {
           const unsigned long long got = tbl[p.cell & 63];
           // winner of its cell, or a cell that lost its slot to a smaller cell id
-          if (got == key || static_cast<uint32_t>(got >> 32) != static_cast<uint32_t>(p.cell))
-            depth_min(map, p.cell, __uint_as_float(static_cast<uint32_t>(key)));
+          if (got == key || static_cast<uint32_t>(got >> 32) != static_cast<uint32_t>(p.cell)) depth_min(map, p.cell, sbits);
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -477,6 +500,20 @@ __global__ __launch_bounds__(kBlock) void k_visibility(const float *__restrict__
 // K4: visibility + colour + scores + top-5 over keyframes [f0, f1), same tile
 // mask walk as K2.  flags: bit0 load state, bit1 store state, bit2 write packed result.
 // ---------------------------------------------------------------------------
+// !(r > lim), r = RN(sqrt(s)) the reference's fp64 range (view_culling.cpp:144,157), decided from s where that is certain:
+// with L = fl(lim lim) = lim^2 (1 + d), |d| <= 2^-53, and lim > 0,
+//   s > L (1 + 2^-40)  =>  sqrt(s) > lim (1 + 2^-42) > lim + ulp(lim) / 2  =>  r >= next(lim) > lim;
+//   s < L (1 - 2^-40)  =>  sqrt(s) < lim                                   =>  r <= lim (rounding is monotone);
+// in between (2^-39 of the candidates), for lim <= 0 and for non-finite values the square root is taken as before.
+__device__ __forceinline__ bool keep_by_depth(float xc, float yc, float zc, double lim) {
+  const double s = sumsq64(xc, yc, zc);
+  const double L = lim * lim;
+  bool keep = s < L * (1.0 - 0x1p-40);
+  const bool sure = lim > 0.0 && (keep || s > L * (1.0 + 0x1p-40));
+  if (!sure) keep = !(sqrt(s) > lim);
+  return keep;
+}
+
 struct TopState {
   float *score;
   uint32_t *rgb;
@@ -540,8 +577,7 @@ __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict_
         const uint32_t dbits = cam.enable_zbuf ? depth[static_cast<int64_t>(f) * cells + p.cell] : 0u;
         // A4 keep rule (view_culling.cpp:135-171)
         bool keep = true;
-        if (cam.enable_zbuf)
-          keep = !(range64(p.xc, p.yc, p.zc) > static_cast<double>(__uint_as_float(dbits)) + cam.slack);
+        if (cam.enable_zbuf) keep = keep_by_depth(p.xc, p.yc, p.zc, static_cast<double>(__uint_as_float(dbits)) + cam.slack);
         float sx = p.xc, sy = p.yc, sz = p.zc;
         if (cam.match_mode == PCP_MATCH_ROUNDTRIP && keep) keep = roundtrip_sample(cam, fr, px, py, pz, sx, sy, sz);
         // only samples that pass the keep rule fetch their texel: nearly every fetch is a 64-B sector of its own
@@ -1052,18 +1088,21 @@ static int single_frame_depth(pcp_context *ctx, int32_t frame) {
                                     static_cast<size_t>(cells) * 4, hipMemcpyDeviceToDevice, ctx->stream));
     return PCP_OK;
   }
-  int rc = fill_u32(ctx, ctx->s_u32.p, cells, kFltMaxBits);
-  if (rc != PCP_OK) return rc;
   if (ctx->n > 0 && ctx->dcam.enable_zbuf) {
     const size_t plane = plane_of(ctx);
+    PCP_HIP_TRY(ctx, ctx->depth_sq.ensure(static_cast<size_t>(cells) + 4));
+    PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->depth_sq.p, 0x7f, static_cast<size_t>(cells) * 8, ctx->stream));
     LaunchTimer t(ctx, PCP_K_DEPTH);
     hipLaunchKernelGGL(k_depth_pass<false>, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
                        ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, ctx->n, ctx->dcam, ctx->frames.p, frame, frame + 1,
-                       ctx->s_u32.p, cells, frame, static_cast<uint32_t *>(nullptr),
+                       ctx->depth_sq.p, cells, frame, static_cast<uint32_t *>(nullptr),
                        static_cast<const uint32_t *>(nullptr), 0, static_cast<const int32_t *>(nullptr));
+    hipLaunchKernelGGL(k_depth_finish, dim3(blocks_for(cells)), dim3(kBlock), 0, ctx->stream, ctx->depth_sq.p, cells,
+                       ctx->s_u32.p);
     PCP_HIP_TRY(ctx, hipGetLastError());
+    return PCP_OK;
   }
-  return PCP_OK;
+  return fill_u32(ctx, ctx->s_u32.p, cells, kFltMaxBits);
 }
 
 // clears the flags of points without a colour pixel (generateColorMap's bounds, PointCloudProcessor.cpp:748-754)
@@ -1445,9 +1484,15 @@ int pcp_depth_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
   if (frame_begin == frame_end) return PCP_OK;
   if ((rc = ensure_depth(ctx)) != PCP_OK) return rc;
   const int64_t cells = cells_of(ctx);
-  if ((rc = fill_u32(ctx, ctx->depth.p + static_cast<int64_t>(frame_begin) * cells,
-                     static_cast<int64_t>(frame_end - frame_begin) * cells, kFltMaxBits)) != PCP_OK)
+  // the pass takes the minimum of the SQUARED ranges (k_depth_finish turns them into the reference's fp32 range maps)
+  const int64_t map_cells = static_cast<int64_t>(frame_end - frame_begin) * cells;
+  const bool z_maps = ctx->n > 0 && ctx->dcam.enable_zbuf;
+  if (z_maps) {
+    PCP_HIP_TRY(ctx, ctx->depth_sq.ensure(static_cast<size_t>(map_cells) + 4));
+    PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->depth_sq.p, 0x7f, static_cast<size_t>(map_cells) * 8, ctx->stream));
+  } else if ((rc = fill_u32(ctx, ctx->depth.p + static_cast<int64_t>(frame_begin) * cells, map_cells, kFltMaxBits)) != PCP_OK) {
     return rc;
+  }
   if (ctx->n > 0) {
     const size_t plane = plane_of(ctx);
     // tile x keyframe masks for the words this range touches
@@ -1478,8 +1523,12 @@ int pcp_depth_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
       hipLaunchKernelGGL(is_common_camera(ctx->dcam) ? k_depth_pass<true> : k_depth_pass<false>,
                          dim3(static_cast<uint32_t>(ctx->n_tiles)), dim3(64), 0, ctx->stream, ctx->sxyz.p,
                          ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, ctx->n, ctx->dcam, ctx->frames.p, frame_begin,
-                         frame_end, ctx->depth.p, cells, 0, ctx->tile_mask.p, ctx->tile_inside.p, ctx->mask_words,
-                         ctx->tile_order.p);
+                         frame_end, ctx->depth_sq.p, cells, frame_begin, ctx->tile_mask.p, ctx->tile_inside.p,
+                         ctx->mask_words, ctx->tile_order.p);
+      if (z_maps)
+        hipLaunchKernelGGL(k_depth_finish, dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(map_cells, kBlock), 4096))),
+                           dim3(kBlock), 0, ctx->stream, ctx->depth_sq.p, map_cells,
+                           ctx->depth.p + static_cast<int64_t>(frame_begin) * cells);
       PCP_HIP_TRY(ctx, hipGetLastError());
     }
   }

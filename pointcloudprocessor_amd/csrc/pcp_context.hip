@@ -594,6 +594,7 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->images.release();
   ctx->hsv_tables.release();
   ctx->depth.release();
+  ctx->depth_sq.release();
   ctx->tile_sphere.release();
   ctx->tile_mask.release();
   ctx->tile_inside.release();

@@ -147,6 +147,7 @@ struct pcp_context {
 
   // depth maps [n_frames][mh*mw] as uint view of positive floats
   pcp::DevBuf<uint32_t> depth;
+  pcp::DevBuf<unsigned long long> depth_sq;  // per cell, min of the squared fp64 range (bit pattern) during a depth pass
   std::vector<uint8_t> depth_valid;
   bool depth_from_batch = false;  // pcp_set_depth_source: single-keyframe calls use the batched (merged) maps
 
