@@ -234,6 +234,12 @@ int pcp_download_depth_map(pcp_context *ctx, int32_t frame, float *out_depth_map
 #define PCP_DEPTH_OWN 0
 #define PCP_DEPTH_BATCHED 1
 int pcp_set_depth_source(pcp_context *ctx, int32_t source);
+/* PCP_CULL_HPR over index shards: a keyframe's hull is taken over EVERY candidate of the map (view_culling.cpp:291-329), so
+ * a context that holds one shard (PCP_DEPTH_BATCHED) cannot decide its points.  The verdicts come from a context that holds
+ * the whole map (pcp_cull_frame there returns them, input order) and are handed to the shard here: keep[i] != 0 = point i
+ * of THIS context is a hull vertex of `frame` (n flags, host or device memory).  pcp_colour_pass and the single-keyframe
+ * calls of the shard then read them where the z-buffer routine reads the merged depth maps. */
+int pcp_hull_flags_import(pcp_context *ctx, int32_t frame, const uint8_t *keep);
 int pcp_colour_reset(pcp_context *ctx);
 /* visibility + colour lookup + scores + per-point top-5 for [frame_begin, frame_end) */
 int pcp_colour_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end);

@@ -339,6 +339,12 @@ class Context:
         """PCP_DEPTH_BATCHED: the single-keyframe calls use the maps pcp_depth_pass left (MIN-merged across shards)."""
         self._check(self.lib.pcp_set_depth_source(self.h, C.c_int32(1 if batched else 0)))
 
+    def hull_flags_import(self, frame: int, keep):
+        """PCP_CULL_HPR on an index shard: the verdicts of keyframe `frame` for this context's points, from a whole-map context."""
+        a = np.ascontiguousarray(keep, np.uint8)
+        assert len(a) == self.n
+        self._check(self.lib.pcp_hull_flags_import(self.h, C.c_int32(frame), _ptr(a)))
+
     def download_depth_map(self, frame: int):
         mh, mw = self.map_shape
         d = np.empty(mh * mw, np.float32)

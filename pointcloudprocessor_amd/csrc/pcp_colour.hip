@@ -1014,6 +1014,16 @@ static int sort_tiles_by_work(pcp_context *ctx, int32_t *order) {
   return PCP_OK;
 }
 
+static int ensure_hull_bits(pcp_context *ctx) {
+  const size_t words = static_cast<size_t>((ctx->n_frames + 31) / 32);
+  const size_t need = words * static_cast<size_t>(ctx->n) + 4;
+  if (ctx->hull_bits.count < need || ctx->hull_valid.size() != static_cast<size_t>(ctx->n_frames)) {
+    PCP_HIP_TRY(ctx, ctx->hull_bits.ensure(need));
+    ctx->hull_valid.assign(static_cast<size_t>(ctx->n_frames), 0);
+  }
+  return PCP_OK;
+}
+
 static int ensure_depth(pcp_context *ctx) {
   const size_t need = static_cast<size_t>(cells_of(ctx)) * ctx->n_frames + 4;
   if (ctx->depth.count < need) {
@@ -1123,6 +1133,14 @@ __global__ __launch_bounds__(kBlock) void k_hull_bits(const uint8_t *__restrict_
   word[j] = keep[perm[j]] ? (w | bit) : (w & ~bit);
 }
 
+// the inverse: keep flags (input order) of one keyframe from the hull bits (pcp_hull_flags_import on an index shard)
+__global__ __launch_bounds__(kBlock) void k_flags_from_hull_bits(const uint32_t *__restrict__ word, uint32_t bit,
+                                                                 const int32_t *__restrict__ perm, int64_t n,
+                                                                 uint8_t *__restrict__ keep) {
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (j < n) keep[perm[j]] = (word[j] & bit) ? 1 : 0;
+}
+
 // ViewCulling::cull of one keyframe as byte flags in input order (ctx->s_keep): the z-buffer routine's pass 2 against the
 // map in ctx->s_u32 (single_frame_depth), or hidden_points_removal (candidate filter, then the hull: pcp_hpr.hip).
 // require_pixel: only points that generateColorMap can colour.
@@ -1132,6 +1150,20 @@ static int frame_keep_flags(pcp_context *ctx, int32_t frame, bool require_pixel)
   if (n == 0) return PCP_OK;
   const size_t plane = plane_of(ctx);
   const bool hull = ctx->cull.cull_mode == PCP_CULL_HPR;
+  if (hull && ctx->depth_from_batch) {
+    // one index shard of a larger map: the hull was taken over the WHOLE map elsewhere and its verdicts were imported
+    if (!ctx->hull_bits.p || static_cast<size_t>(frame) >= ctx->hull_valid.size() || !ctx->hull_valid[static_cast<size_t>(frame)])
+      return set_error(ctx, PCP_ERR_STATE, "PCP_CULL_HPR on an index shard: pcp_hull_flags_import has not covered keyframe %d", frame);
+    LaunchTimer t(ctx, PCP_K_VISIBILITY);
+    hipLaunchKernelGGL(k_flags_from_hull_bits, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream,
+                       ctx->hull_bits.p + static_cast<size_t>(frame >> 5) * static_cast<size_t>(n), 1u << (frame & 31), ctx->perm.p,
+                       n, ctx->s_keep.p);
+    if (require_pixel)
+      hipLaunchKernelGGL(k_require_pixel, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, ctx->xyz.p, ctx->xyz.p + plane,
+                         ctx->xyz.p + 2 * plane, n, ctx->dcam, ctx->hframes[static_cast<size_t>(frame)], ctx->s_keep.p);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+    return PCP_OK;
+  }
   {
     LaunchTimer t(ctx, PCP_K_VISIBILITY);
     PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->s_keep.p, 0, static_cast<size_t>(n), ctx->stream));
@@ -1535,9 +1567,10 @@ int pcp_depth_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
   if (ctx->cull.cull_mode == PCP_CULL_HPR && ctx->n > 0) {
     // hidden_points_removal has no depth map to pass on: its verdict per (point, keyframe) is a bit (pcp_hpr.hip), taken
     // here keyframe by keyframe; the colour pass reads the bits where the z-buffer routine reads the maps
-    const size_t words = static_cast<size_t>((ctx->n_frames + 31) / 32);
-    PCP_HIP_TRY(ctx, ctx->hull_bits.ensure(words * static_cast<size_t>(ctx->n) + 4));
-    for (int32_t f = frame_begin; f < frame_end; ++f) {
+    int rch = ensure_hull_bits(ctx);
+    if (rch != PCP_OK) return rch;
+    // an index shard (PCP_DEPTH_BATCHED) cannot take a hull: its bits come through pcp_hull_flags_import
+    for (int32_t f = frame_begin; f < frame_end && !ctx->depth_from_batch; ++f) {
       if ((rc = frame_keep_flags(ctx, f, false)) != PCP_OK) return rc;
       LaunchTimer t(ctx, PCP_K_HPR);
       hipLaunchKernelGGL(k_hull_bits, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, ctx->s_keep.p, ctx->perm.p,
@@ -1566,10 +1599,28 @@ int pcp_set_depth_source(pcp_context *ctx, int32_t source) {
   if (!ctx) return PCP_ERR_INVALID;
   if (source != PCP_DEPTH_OWN && source != PCP_DEPTH_BATCHED)
     return set_error(ctx, PCP_ERR_INVALID, "pcp_set_depth_source: unknown source %d", source);
-  if (source == PCP_DEPTH_BATCHED && ctx->have_camera && ctx->cull.cull_mode == PCP_CULL_HPR)
-    return set_error(ctx, PCP_ERR_STATE, "pcp_set_depth_source: PCP_CULL_HPR takes a keyframe's hull over every candidate of "
-                     "the map; a context that holds one index shard cannot decide its points (one GPU only)");
   ctx->depth_from_batch = source == PCP_DEPTH_BATCHED;
+  return PCP_OK;
+}
+
+int pcp_hull_flags_import(pcp_context *ctx, int32_t frame, const uint8_t *keep) {
+  int rc = check_ready(ctx, "pcp_hull_flags_import", true);
+  if (rc != PCP_OK) return rc;
+  if ((rc = check_frame(ctx, "pcp_hull_flags_import", frame)) != PCP_OK) return rc;
+  if (ctx->cull.cull_mode != PCP_CULL_HPR || !ctx->depth_from_batch)
+    return set_error(ctx, PCP_ERR_STATE, "pcp_hull_flags_import: needs cull_mode PCP_CULL_HPR and pcp_set_depth_source(PCP_DEPTH_BATCHED)");
+  if (!keep && ctx->n > 0) return set_error(ctx, PCP_ERR_INVALID, "pcp_hull_flags_import: NULL flags");
+  if ((rc = ensure_hull_bits(ctx)) != PCP_OK) return rc;
+  if (ctx->n > 0) {
+    PCP_HIP_TRY(ctx, ctx->s_keep.ensure(static_cast<size_t>(ctx->n) + 16));
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->s_keep.p, keep, static_cast<size_t>(ctx->n), hipMemcpyDefault, ctx->stream));
+    LaunchTimer t(ctx, PCP_K_HPR);
+    hipLaunchKernelGGL(k_hull_bits, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, ctx->s_keep.p, ctx->perm.p, ctx->n,
+                       ctx->hull_bits.p + static_cast<size_t>(frame >> 5) * static_cast<size_t>(ctx->n), 1u << (frame & 31));
+    PCP_HIP_TRY(ctx, hipGetLastError());
+    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the caller's buffer is free again
+  }
+  ctx->hull_valid[static_cast<size_t>(frame)] = 1;
   return PCP_OK;
 }
 
@@ -1619,6 +1670,9 @@ static int colour_pass_impl(pcp_context *ctx, int32_t frame_begin, int32_t frame
       return set_error(ctx, PCP_ERR_STATE, "pcp_colour_pass: pcp_depth_pass has not covered keyframe %d", f);
     if (!ctx->images.p || !ctx->image_set[static_cast<size_t>(f)])
       return set_error(ctx, PCP_ERR_STATE, "pcp_colour_pass: no image uploaded for keyframe %d", f);
+    if (ctx->cull.cull_mode == PCP_CULL_HPR && ctx->depth_from_batch &&
+        (static_cast<size_t>(f) >= ctx->hull_valid.size() || !ctx->hull_valid[static_cast<size_t>(f)]))
+      return set_error(ctx, PCP_ERR_STATE, "pcp_colour_pass: PCP_CULL_HPR on an index shard, pcp_hull_flags_import has not covered keyframe %d", f);
   }
   if ((rc = ensure_state(ctx)) != PCP_OK) return rc;
   if ((rc = wait_images(ctx, frame_begin, frame_end)) != PCP_OK) return rc;

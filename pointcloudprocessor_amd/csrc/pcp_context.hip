@@ -406,6 +406,7 @@ static int store_cloud(pcp_context *ctx, const float *x, const float *y, const f
   ctx->colour_result_live = false;
   ctx->mls_count = 0;
   std::fill(ctx->depth_valid.begin(), ctx->depth_valid.end(), uint8_t(0));
+  ctx->hull_valid.clear();
   for (int a = 0; a < 3; ++a) ctx->host_min[a] = ctx->host_max[a] = 0.0f;
   if (n == 0) return PCP_OK;
   hipStream_t st = ctx->stream;
@@ -745,9 +746,6 @@ int pcp_set_camera(pcp_context *ctx, const pcp_camera *cam, const pcp_cull_param
     return set_error(ctx, PCP_ERR_INVALID, "pcp_set_camera: cull size above 2^24 is not supported");
   if (static_cast<int64_t>(cam->image_width) * cam->image_height >= (int64_t(1) << 31))
     return set_error(ctx, PCP_ERR_INVALID, "pcp_set_camera: image too large for int32 pixel indices");
-  if (cp.cull_mode == PCP_CULL_HPR && ctx->depth_from_batch)
-    return set_error(ctx, PCP_ERR_STATE, "pcp_set_camera: PCP_CULL_HPR on a context set to PCP_DEPTH_BATCHED (an index shard): "
-                     "the hull needs the whole map on one GPU");
   ctx->camera = *cam;
   ctx->cull = cp;
   DevCamera &d = ctx->dcam;
@@ -823,6 +821,7 @@ int pcp_set_camera(pcp_context *ctx, const pcp_camera *cam, const pcp_cull_param
   ctx->image_set.assign(ctx->image_set.size(), 0);
   ctx->mask_set.assign(ctx->mask_set.size(), 0);
   std::fill(ctx->depth_valid.begin(), ctx->depth_valid.end(), uint8_t(0));
+  ctx->hull_valid.clear();
   ctx->colour_state_live = false;
   ctx->colour_result_live = false;
   return PCP_OK;
@@ -910,6 +909,7 @@ int pcp_set_frames(pcp_context *ctx, const pcp_pose *poses, int32_t n_frames, co
   ctx->image_set.assign(static_cast<size_t>(n_frames), 0);
   ctx->mask_set.assign(static_cast<size_t>(n_frames), 0);
   ctx->depth_valid.assign(static_cast<size_t>(n_frames), 0);
+  ctx->hull_valid.clear();
   ctx->colour_state_live = false;
   ctx->colour_result_live = false;
   return PCP_OK;

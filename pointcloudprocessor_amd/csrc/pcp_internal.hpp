@@ -192,6 +192,7 @@ struct pcp_context {
   pcp::DevBuf<unsigned long long> h_stats;
   pcp::DevBuf<uint32_t> hull_bits;  // whole run: uint32[(F + 31) / 32][n], bit f & 31 of word (f >> 5, j) = point j (Morton
                                     // order) is a hull vertex of keyframe f
+  std::vector<uint8_t> hull_valid;  // per keyframe: hull bits imported (index shards)
   int64_t hpr_stats[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
   // MLS: uniform grid (cell id / in-cell rank per point, cell starts, cell-sorted

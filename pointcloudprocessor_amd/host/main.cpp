@@ -303,9 +303,6 @@ class Processor {
     pcp_cull_params cull;
     pcp_default_cull_params(&cull);
     cull.cull_mode = opt.cull_mode;
-    if (opt.cull_mode == PCP_CULL_HPR && gpu->size() > 1)
-      throw std::runtime_error("--cull hpr needs the whole map on one GPU (the hull of a keyframe is taken over every "
-                               "candidate): use --gpus 1");
     gpu->setCamera(cam, &cull);
     std::vector<pcp_pose> poses;
     for (const auto &k : keyframes) poses.push_back(k.pose);

@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -86,22 +87,46 @@ class MultiDevice {
     return r * base + std::min<int64_t>(r, rem);
   }
 
+  // The arrays must stay valid until the next uploadCloud (hidden_points_removal over several GPUs uploads the WHOLE map
+  // to every GPU once the cull mode is known, see setCamera).
   void uploadCloud(const float *x, const float *y, const float *z, int64_t n) {
     n_ = n;
+    hx_ = x;
+    hy_ = y;
+    hz_ = z;
     for (int r = 0; r < size(); ++r) {
       const int64_t lo = shardBegin(r), hi = shardBegin(r + 1);
       device(r).uploadCloud(x + lo, y + lo, z + lo, hi - lo);
     }
+    for (auto &h : hull_) h->uploadCloud(x, y, z, n);
     depth_ready_ = false;
   }
+  // PCP_CULL_HPR with N > 1: a keyframe's hull is taken over EVERY candidate of the map (view_culling.cpp:291-329), so an
+  // index shard cannot decide its own points.  Every GPU gets a second context that holds the whole map (no images);
+  // keyframe f's hull is taken by GPU f mod N there, and its verdicts (one flag per map point, through the host) are
+  // handed to the shards (pcp_hull_flags_import), which colour / dump their points from them exactly as they do from the
+  // merged depth maps of the z-buffer routine.
   void setCamera(const pcp_camera &cam, const pcp_cull_params *cull = nullptr) {
     cam_ = cam;
     for (auto &d : dev_) d->setCamera(cam, cull);
+    hpr_ = cull && cull->cull_mode == PCP_CULL_HPR && size() > 1;
+    if (hpr_) {
+      if (hull_.empty()) {
+        for (int r = 0; r < size(); ++r) {
+          hull_.emplace_back(new Device(ordinal(r)));
+          if (hx_) hull_.back()->uploadCloud(hx_, hy_, hz_, n_);
+        }
+      }
+      for (auto &h : hull_) h->setCamera(cam, cull);
+    } else {
+      hull_.clear();
+    }
     depth_ready_ = false;
   }
   void setKeyframes(const std::vector<pcp_pose> &poses, const double *T_opt = nullptr, int T_opt_stride = 0) {
     n_frames_ = static_cast<int>(poses.size());
     for (auto &d : dev_) d->setKeyframes(poses, T_opt, T_opt_stride);
+    for (auto &h : hull_) h->setKeyframes(poses, T_opt, T_opt_stride);
     depth_ready_ = false;
   }
   void setImageAdjust(bool enable, float saturation_scale = 1.0f, float brightness_scale = 1.0f) {
@@ -115,6 +140,11 @@ class MultiDevice {
   void depthPassAll() {
     if (size() == 1) return;  // pcp_colorize / pcp_cull_frame build their own maps
     for (int r = 0; r < size(); ++r) device(r).check(pcp_depth_pass(device(r).get(), 0, n_frames_));
+    if (hpr_) {  // no depth maps in this mode: the hulls of the whole map, keyframes dealt out round-robin
+      hullPassAll();
+      depth_ready_ = true;
+      return;
+    }
     if (rehearsal_) {
       std::vector<uint32_t> merged, part;
       std::vector<void *> ptr(static_cast<size_t>(size()));
@@ -287,6 +317,35 @@ class MultiDevice {
     }
   }
 
+  // hidden_points_removal of every keyframe on the whole-map contexts (GPU f mod N takes keyframe f, one host thread per
+  // GPU), verdicts sliced by index range into the shards
+  void hullPassAll() {
+    const int N = size();
+    std::vector<std::mutex> shard_mu(static_cast<size_t>(N));
+    std::vector<std::string> failure(static_cast<size_t>(N));
+    std::vector<std::thread> th;
+    for (int r = 0; r < N; ++r)
+      th.emplace_back([&, r] {
+        try {
+          Device &h = *hull_[static_cast<size_t>(r)];
+          std::vector<uint8_t> keep(static_cast<size_t>(n_));
+          for (int f = r; f < n_frames_; f += N) {
+            int64_t kept = 0;
+            h.check(pcp_cull_frame(h.get(), f, keep.data(), &kept, nullptr));
+            for (int s = 0; s < N; ++s) {
+              std::lock_guard<std::mutex> lk(shard_mu[static_cast<size_t>(s)]);
+              device(s).check(pcp_hull_flags_import(device(s).get(), f, keep.data() + shardBegin(s)));
+            }
+          }
+        } catch (const std::exception &e) {
+          failure[static_cast<size_t>(r)] = e.what();
+        }
+      });
+    for (auto &t : th) t.join();
+    for (const auto &f : failure)
+      if (!f.empty()) throw std::runtime_error(f);
+  }
+
   static void hip(hipError_t e, const char *what) {
     if (e != hipSuccess) throw std::runtime_error(std::string("pcp_multi: ") + what + ": " + hipGetErrorString(e));
   }
@@ -361,6 +420,9 @@ class MultiDevice {
   int ordinal(int shard) const { return rehearsal_ ? 0 : shard; }
 
   bool rehearsal_ = false;
+  bool hpr_ = false;
+  const float *hx_ = nullptr, *hy_ = nullptr, *hz_ = nullptr;
+  std::vector<std::unique_ptr<Device>> hull_;  // PCP_CULL_HPR, N > 1: the whole map on every GPU
   std::vector<std::unique_ptr<Device>> dev_;
   std::vector<hipStream_t> stream_;
   std::vector<ncclComm_t> comm_;

@@ -570,10 +570,18 @@ def test_cli_cull_hpr_end_to_end(tmp_path, oracle):
     packed = (0xFF000000 | (ref["rgb"][sel, 0].astype(np.uint64) << 16) | (ref["rgb"][sel, 1].astype(np.uint64) << 8)
               | ref["rgb"][sel, 2].astype(np.uint64))
     assert np.array_equal(got_rgb, packed)
-    # the hull needs the whole map on one GPU
-    p = subprocess.run([_exe(), "-p", str(tmp_path / "scans.pcd"), "-o", str(tmp_path / "odo.txt"), "-i", out, "-t", out,
-                        "--cull", "hpr", "--gpus", "2"], capture_output=True, text=True, env=dict(os.environ, PCP_MULTI_REHEARSAL="1"))
-    assert p.returncode == 254 and "--cull hpr" in p.stderr
+    # over several GPUs (here three contexts on the one GPU): the hulls are taken on whole-map contexts, keyframe f by GPU
+    # f mod N, and handed to the index shards (pcp_hull_flags_import) -- every output file equals the one-GPU run
+    one = {}
+    for name in ["cloudInWorldWithRGB.pcd"] + ["filtered_pcd/%f_beforeNID.pcd" % t for t in ts]:
+        one[name] = open(tmp_path / name, "rb").read()
+    out3 = tmp_path / "g3"
+    out3.mkdir()
+    p = subprocess.run([_exe(), "-p", str(tmp_path / "scans.pcd"), "-o", str(tmp_path / "odo.txt"), "-i", out, "-t", str(out3) + "/",
+                        "--cull", "hpr", "--gpus", "3"], capture_output=True, text=True, env=dict(os.environ, PCP_MULTI_REHEARSAL="1"))
+    assert p.returncode == 0, p.stderr[-2000:]
+    for name, data in one.items():
+        assert open(out3 / name, "rb").read() == data, name
     p = subprocess.run([_exe(), "-p", "a", "-o", "b", "-i", "c", "--cull", "qhull"], capture_output=True, text=True)
     assert p.returncode == 254
 

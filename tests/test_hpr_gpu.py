@@ -221,24 +221,60 @@ def test_frame_visible_and_whole_run_in_hull_mode(gpu_ctx_factory, oracle, small
     ctx.close()
 
 
-def test_hull_mode_refuses_index_shards(gpu_ctx_factory):
-    """A keyframe's hull is taken over every candidate of the map: the calls that make a context one shard of a larger
-    map fail loudly in PCP_CULL_HPR instead of deciding from a part of the candidates."""
-    from pointcloudprocessor_amd import capi, synth
+def test_hull_mode_over_index_shards(gpu_ctx_factory, small_scene):
+    """A keyframe's hull is taken over every candidate of the map, so an index shard cannot decide its own points: in
+    PCP_CULL_HPR a shard (PCP_DEPTH_BATCHED) fails loudly until the verdicts of a whole-map context have been handed to
+    it (pcp_hull_flags_import); with them its colours and per-keyframe records equal the whole-map run's, slice by slice."""
+    from pointcloudprocessor_amd import capi
 
-    cd = synth.camera_dict("tiny")
-    x, y, z, _ = synth.make_cloud(5000)
-    poses, _ = synth.make_trajectory(2)
-    ctx = hull_ctx(gpu_ctx_factory, capi, cam_struct(capi, cd), x, y, z, poses)
-    with pytest.raises(capi.PcpError):
-        ctx.set_depth_source(True)
-    with pytest.raises(capi.PcpError):
-        ctx.depth_maps_device()
-    ctx.close()
-    c2 = gpu_ctx_factory()
-    c2.set_depth_source(True)
+    s = small_scene
+    F, n = len(s["poses"]), len(s["x"])
     cull = capi.default_cull_params()
     cull.cull_mode = capi.CULL_HPR
-    with pytest.raises(capi.PcpError):
-        c2.set_camera(cam_struct(capi, cd), cull)
-    c2.close()
+
+    def make(lo, hi, shard):
+        ctx = gpu_ctx_factory()
+        if shard:
+            ctx.set_depth_source(True)
+        ctx.set_camera(cam_struct(capi, s["cam"]), cull)
+        ctx.upload_cloud(s["x"][lo:hi], s["y"][lo:hi], s["z"][lo:hi])
+        ctx.set_frames(s["poses"])
+        for f, (im, mk) in enumerate(zip(s["images"], s["masks"])):
+            ctx.upload_image(f, im)
+            ctx.upload_mask(f, mk)
+        return ctx
+
+    full = make(0, n, False)
+    ref = full.colorize()
+    flags = [full.cull_frame(f)[0] for f in range(F)]
+    vis = [full.frame_visible(f) for f in range(F)]
+    bounds = [0, n // 3, n // 3 + n // 4, n]
+    rgb, has = [], []
+    idx = [[] for _ in range(F)]
+    vrgb = [[] for _ in range(F)]
+    for r in range(3):
+        lo, hi = bounds[r], bounds[r + 1]
+        sh = make(lo, hi, True)
+        sh.depth_pass()
+        with pytest.raises(capi.PcpError):
+            sh.colorize_from_depth()
+        with pytest.raises(capi.PcpError):
+            sh.cull_frame(0)
+        for f in range(F):
+            sh.hull_flags_import(f, flags[f][lo:hi])
+        col = sh.colorize_from_depth()
+        rgb.append(col["rgb"])
+        has.append(col["has"])
+        for f in range(F):
+            keep, _, kept = sh.cull_frame(f)
+            assert np.array_equal(keep, flags[f][lo:hi]) and kept == int(flags[f][lo:hi].sum())
+            v = sh.frame_visible(f)
+            idx[f].append(v["index"] + lo)
+            vrgb[f].append(v["rgb"])
+        sh.close()
+    assert np.array_equal(np.concatenate(rgb), ref["rgb"]) and np.array_equal(np.concatenate(has), ref["has"])
+    assert ref["has"].sum() > 100
+    for f in range(F):
+        assert np.array_equal(np.concatenate(idx[f]), vis[f]["index"])
+        assert np.array_equal(np.concatenate(vrgb[f]), vis[f]["rgb"])
+    full.close()
