@@ -690,7 +690,7 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_cells(HprGrid G, const unsign
 
 // stats: [0] hidden [1] visible [2] undecided [3] trial normals [4] batches of 64 point tests [5] second-box retries
 // [6] unresolved [7] exact predicate evaluations [8] length of the list for k_hpr_exact
-__global__ __launch_bounds__(kHprBlock) void k_hpr_decide(HprArrays A, HprGrid G, uint8_t *__restrict__ state,
+__global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_hpr_decide(HprArrays A, HprGrid G, uint8_t *__restrict__ state,
                                                           int32_t *__restrict__ undecided,
                                                           unsigned long long *__restrict__ stats, int32_t force_exact) {
   const int32_t j = static_cast<int32_t>(blockIdx.x) * (kHprBlock / 64) + static_cast<int32_t>(threadIdx.x >> 6);

@@ -1,0 +1,22 @@
+import os, sys, time, json
+sys.path.insert(0, "/root/repo")
+import numpy as np
+from pointcloudprocessor_amd import capi, synth
+cam = synth.camera_dict("cfg")
+x, y, z, _ = synth.make_cloud(10_000_000)
+poses, _ = synth.make_trajectory(256)
+cull = capi.default_cull_params()
+cull.cull_mode = capi.CULL_HPR
+with capi.Context(0) as ctx:
+    ctx.set_camera(capi.camera_from_dict(cam), cull)
+    ctx.upload_cloud(x, y, z)
+    ctx.set_frames(poses)
+    ctx.cull_frame(0)
+    ctx.timing_enable(True)
+    for f in (0, 64, 100, 144, 192, 200, 224):
+        ctx.timing_reset()
+        t0 = time.perf_counter()
+        keep, _, kept = ctx.cull_frame(f)
+        ms = (time.perf_counter() - t0) * 1e3
+        st = ctx.hpr_stats()
+        print(f, round(ms, 2), {k: st[k] for k in ("candidates", "visible", "hidden", "exact_path", "trial_normals", "test_batches", "cells")}, flush=True)

@@ -16,6 +16,7 @@ import collections
 import csv
 import glob
 import json
+import re
 import sys
 
 
@@ -32,7 +33,9 @@ def main():
     for d in sys.argv[6:]:
         for fn in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(fn)):
-                k = r["Kernel_Name"].split("(")[0]
+                # "void pcp::k_depth_pass<true>(float const*, ...)" -> "pcp::k_depth_pass" (the batched kernels are templates
+                # since round 3: the specialisations of one kernel are one row)
+                k = re.sub(r"<.*>$", "", re.sub(r"^void ", "", r["Kernel_Name"].split("(")[0]))
                 if k == "pcp::k_project_frame":
                     g = int(r["Grid_Size"])
                     k += "@hbm" if g == grid_of(roof_points) else ("@ic" if g == grid_of(step_points) else f"@grid{g}")
