@@ -31,8 +31,10 @@
 extern "C" {
 #endif
 
-#define PCP_ABI_VERSION 3 /* 2: pcp_cull_params grew cull_mode / match_mode; pcp_set_image_adjust
-                             3: PCP_CULL_HPR, pcp_cull_params.hpr_flip_radius, pcp_hpr_stats */
+#define PCP_ABI_VERSION 4 /* 2: pcp_cull_params grew cull_mode / match_mode; pcp_set_image_adjust
+                             3: PCP_CULL_HPR, pcp_cull_params.hpr_flip_radius, pcp_hpr_stats
+                             4: entry points added, no layout changed: pcp_sor_partial / pcp_sor_finish /
+                                pcp_sor_chunk_points, pcp_hull_flags_import; PCP_DEPTH_BATCHED accepts PCP_CULL_HPR */
 
 #define PCP_OK 0
 #define PCP_ERR_INVALID (-1) /* bad argument */
