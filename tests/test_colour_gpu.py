@@ -479,3 +479,44 @@ def test_async_uploads_from_pinned_memory_are_ordered_against_the_passes(gpu_ctx
     got = ctx.colorize()
     assert np.array_equal(got["rgb"], refs[0]["rgb"])
     ctx.synchronize()
+
+
+@pytest.mark.parametrize("z1,z2", [(1.25, 1.3125), (1.0, 1.09375), (1.7109375, 1.84375)])
+def test_keep_rule_within_rounding_of_the_depth_limit(gpu_ctx_factory, oracle, z1, z2):
+    """The colour pass decides `!(r > depth + slack)` from the squared range and takes the square root only when
+    s is within 2^-40 of the squared limit (keep_by_depth).  Two points on the optical axis (ranges z1 < z2, exact in
+    fp32) and slacks that put the limit z1 + slack exactly on z2, one and 256 ulps of fp64 to either side of it, and
+    clearly off: every outcome must be the reference's (view_culling.cpp:144,157)."""
+    from pointcloudprocessor_amd import capi, synth
+
+    cd = synth.camera_dict("tiny")
+    img = synth.make_image(0, cd["image_width"], cd["image_height"])
+    pose = np.array([[0, 0, 0, 0, 0, 0, 1]], np.float64)  # identity: camera frame == world frame
+    x = np.array([0.0, 0.0, 0.3], np.float32)  # the third point keeps the bounding box from degenerating
+    y = np.array([0.0, 0.0, 0.2], np.float32)
+    z = np.array([z1, z2, 1.5], np.float32)
+    assert float(z[0]) == z1 and float(z[1]) == z2
+    gap, ulp = z2 - z1, 2.0 ** -52
+    outcomes = []
+    for slack in (gap - 256 * ulp, gap - ulp, gap, gap + ulp, gap + 256 * ulp, 0.5 * gap, 2.0 * gap):
+        cp_g, cp_o = capi.default_cull_params(), oracle.default_cull_params()
+        cp_g.depth_slack = cp_o.depth_slack = slack
+        ctx = gpu_ctx_factory()
+        ctx.set_camera(cam_struct(capi, cd), cp_g)
+        ctx.upload_cloud(x, y, z)
+        ctx.set_frames(pose)
+        ctx.upload_image(0, img)
+        ctx.colour_reset()
+        ctx.depth_pass()
+        ctx.colour_pass()
+        got = ctx.colour_finalise(want_top=True)
+        ref = oracle.colorize(cam_struct(oracle, cd), cp_o, x, y, z, pose, [img])
+        assert np.array_equal(got["count"], ref["count"]), (slack, got["count"], ref["count"])
+        assert np.array_equal(got["rgb"], ref["rgb"]) and np.array_equal(got["has"], ref["has"])
+        keep, dmap, _ = ctx.cull_frame(0)
+        keep_r, dmap_r, _ = oracle.cull_frame(cam_struct(oracle, cd), cp_o, oracle.pose_to_matrices(pose[0])[0], x, y, z)
+        assert np.array_equal(keep, keep_r) and np.array_equal(dmap.view(np.uint32), dmap_r.view(np.uint32))
+        assert ref["count"][0] == 1
+        outcomes.append(int(ref["count"][1]))
+        ctx.close()
+    assert outcomes == [0, 0, 1, 1, 1, 0, 1]  # dropped below the limit, kept on it and above
