@@ -9,6 +9,8 @@
 #  2. the C++ host: PointCloudProcessor --gpus N against --gpus 1 on a generated scene, every output file byte for byte
 #     (ncclCommInitAll, grouped ncclAllReduce(ncclMin), ncclBroadcast of the images, ncclAllReduce(ncclSum) of the NID
 #     histograms with --enableNIDOptimize 1).
+#     Also --cull hpr (the hulls taken on whole-map contexts, keyframe f on GPU f mod N, verdicts handed to the shards) and
+#     --enableMLS 1 (both outlier-removal brackets, MLS queries and voxel chunks dealt out): --gpus N against --gpus 1.
 #  3. the RCCL plumbing tests of the suite (device-pointer all-reduce on the library's stream).
 set -u -o pipefail
 N=${1:-2}
@@ -63,13 +65,26 @@ diff -rq -x stdout.log -x stderr.log -x T_camera_lidar_optimized.txt "$OUT/cli_g
 # the NID refinement sums fp64 histograms in a different order on N GPUs: the optimum agrees to ~1e-5, the files may not
 diff -rq -x stdout.log -x stderr.log -x T_camera_lidar_optimized.txt "$OUT/cli_g1_nid1" "$OUT/cli_g${N}_nid1" > "$OUT/cli_diff_nid1.txt" 2>&1; D1=$?
 
+# hidden_points_removal and the smoothing stage over the GPUs
+for G in 1 "$N"; do
+  D=$OUT/cli_g${G}_hpr; rm -rf "$D"; mkdir -p "$D"
+  (cd "$D" && "$EXE" -p "$OUT/scene/scans.pcd" -o "$OUT/scene/odo.txt" -i "$OUT/scene/" -t "$D/" --gpus "$G" --cull hpr \
+      > "$D/stdout.log" 2> "$D/stderr.log") || RC_CLI=1
+  D=$OUT/cli_g${G}_mls; rm -rf "$D"; mkdir -p "$D"
+  (cd "$D" && "$EXE" -p "$OUT/scene/scans.pcd" -o "$OUT/scene/odo.txt" -i "$OUT/scene/" -t "$D/" --gpus "$G" --enableMLS 1 \
+      --mlsUpsampling none --skip_filtered_dumps 1 > "$D/stdout.log" 2> "$D/stderr.log") || RC_CLI=1
+done
+diff -rq -x stdout.log -x stderr.log "$OUT/cli_g1_hpr" "$OUT/cli_g${N}_hpr" > "$OUT/cli_diff_hpr.txt" 2>&1; DH=$?
+# the smoothed coordinates may differ in their last fp32 bit (re-uploaded intermediate clouds: another summation order)
+diff -rq -x stdout.log -x stderr.log "$OUT/cli_g1_mls" "$OUT/cli_g${N}_mls" > "$OUT/cli_diff_mls.txt" 2>&1; DM=$?
+
 # 3 -- the RCCL plumbing tests
 python3 -m pytest tests/test_rccl_plumbing_gpu.py -x -q -m gpu > "$OUT/pytest.log" 2>&1
 RC_TEST=$?
 
-python3 - "$OUT" "$N" "$RC_BENCH" "$RC_CLI" "$D0" "$D1" "$RC_TEST" <<'PY'
+python3 - "$OUT" "$N" "$RC_BENCH" "$RC_CLI" "$D0" "$D1" "$RC_TEST" "$DH" "$DM" <<'PY'
 import json, os, sys
-out, n, rc_bench, rc_cli, d0, d1, rc_test = sys.argv[1], int(sys.argv[2]), *map(int, sys.argv[3:8])
+out, n, rc_bench, rc_cli, d0, d1, rc_test, dh, dm = sys.argv[1], int(sys.argv[2]), *map(int, sys.argv[3:10])
 def line(p):
     try:
         return json.loads([l for l in open(p).read().splitlines() if l.startswith("{")][-1])
@@ -78,8 +93,9 @@ def line(p):
 bn, b1 = line(os.path.join(out, f"bench_n{n}.json")), line(os.path.join(out, "bench_n1.json"))
 v = {"n_gpus": n, "bench_rc": rc_bench, "bench_value": bn.get("value"), "bench_ms_per_step": bn.get("ms_per_step"),
      "bench_verify": bn.get("verify"), "bench_n1_value": b1.get("value"), "cli_rc": rc_cli,
-     "cli_outputs_identical_to_one_gpu": d0 == 0, "cli_nid_outputs_identical_to_one_gpu": d1 == 0, "pytest_rc": rc_test}
-v["ok"] = bool(rc_bench == 0 and (bn.get("verify") or {}).get("equal_to_one_gpu_run") and rc_cli == 0 and d0 == 0)
+     "cli_outputs_identical_to_one_gpu": d0 == 0, "cli_nid_outputs_identical_to_one_gpu": d1 == 0,
+     "cli_hpr_outputs_identical_to_one_gpu": dh == 0, "cli_mls_outputs_identical_to_one_gpu": dm == 0, "pytest_rc": rc_test}
+v["ok"] = bool(rc_bench == 0 and (bn.get("verify") or {}).get("equal_to_one_gpu_run") and rc_cli == 0 and d0 == 0 and dh == 0)
 json.dump(v, open(os.path.join(out, "verdict.json"), "w"), indent=1)
 print(json.dumps(v))
 PY
