@@ -482,6 +482,50 @@ def main():
                 reng.close()
             except (RuntimeError, capi.PcpError) as e:
                 camera_ref = {"error": str(e)}
+        # ---- hidden_points_removal leg: the cull the reference binary runs (view_culling.cpp:46,266-334), PCP_CULL_HPR ----
+        hpr = None
+        if side and args.camera == "cfg" and not args.no_mls:
+            try:
+                hcull = capi.default_cull_params()
+                hcull.cull_mode = capi.CULL_HPR
+                heng = pipeline.HipEngine(local_rank)
+                heng.configure(cam, hcull)
+                heng.upload_cloud(x, y, z)
+                heng.ctx.set_frames(poses)
+                heng.ctx.cull_frame(0)  # allocations
+                heng.ctx.synchronize()
+                t1 = time.perf_counter()
+                heng.ctx.depth_pass()  # the hull of every keyframe -> one bit per (point, keyframe) for the colour pass
+                heng.ctx.synchronize()
+                t_hull = time.perf_counter() - t1
+                per_kf = {}
+                kept_gpu = None
+                for f in (0, F // 2):
+                    t1 = time.perf_counter()
+                    keep_h, _, kept_h = heng.ctx.cull_frame(f)
+                    per_kf[str(f)] = {"ms": round((time.perf_counter() - t1) * 1e3, 2), "candidates": heng.ctx.hpr_stats()["candidates"],
+                                      "kept": int(kept_h)}
+                    if f == 0:
+                        kept_gpu = keep_h.copy()
+                hpr = {"keyframes": F, "points": N, "hull_pass_s": round(t_hull, 3), "ms_per_keyframe": round(t_hull / F * 1e3, 2),
+                       "Mpoints_frames_per_s": round(N * F / t_hull / 1e6, 1), "cull_frame": per_kf,
+                       "what": "spherical flip + convex-hull vertex test of every keyframe's candidates on the GPU "
+                               "(csrc/pcp_hpr.hip), per-keyframe calls with their host synchronisations included"}
+                if not args.no_cpu:
+                    from oracle import oracle_capi as oc
+                    ocam_h = oc.Camera()
+                    for k_, _t in oc.Camera._fields_:
+                        setattr(ocam_h, k_, cam[k_])
+                    w2c_h, _ = oc.pose_to_matrices(poses[0])
+                    t1 = time.perf_counter()
+                    okeep, ost = oc.hpr_frame(ocam_h, w2c_h, x, y, z)
+                    t_o = time.perf_counter() - t1
+                    hpr["cpu_baseline"] = {"value": round(t_o * 1e3, 1), "unit": "ms per keyframe", "cores": 1, "kind": "port",
+                                           "sample": "keyframe 0 of the same scene, exact quickhull of oracle/pcp_oracle_hpr.c",
+                                           "equal_to_gpu": bool(np.array_equal(okeep, kept_gpu))}
+                heng.close()
+            except (RuntimeError, capi.PcpError, AttributeError) as e:
+                hpr = {"error": str(e)}
         # ---- NID leg (config 5's pose refine): one cost + SE(3)-gradient evaluation over every keyframe's culled cloud ----
         nid = None
         if side and not args.no_mls:
@@ -738,6 +782,7 @@ def main():
             "host_images": host_images,
             "camera_ref": camera_ref,
             "nid": nid,
+            "hpr": hpr,
             "mls": mls,
         }
         if verify is not None:

@@ -40,6 +40,8 @@ def test_bench_line_carries_the_contract():
     assert line["value_host_images"] == line["host_images"]["value"] > 0
     assert line["host_images"]["pcie_floor_ms"] > 0 and line["camera_ref"]["value"] > 0
     assert line["mls"]["value"] > 0 and line["mls"]["sor_mls_sor"]["outputs"] > 0 and line["nid"]["valid"] is True
+    # hidden_points_removal, the cull the reference binary runs: whole hull pass, and keyframe 0 against the oracle's quickhull
+    assert line["hpr"]["hull_pass_s"] > 0 and line["hpr"]["cpu_baseline"]["equal_to_gpu"] is True
     # the timed region: an untimed settle phase in front of it, per-step statistics inside it
     assert line["settle"]["steps"] > 0 and line["settle"]["ms"] >= 400.0
     st = line["step_ms"]
