@@ -111,6 +111,71 @@ class OracleMlsEngine:
         self.ctx = OracleMlsCtx(x, y, z)
 
 
+class OracleSorCtx:
+    """sor_chunk_points / sor_partial / sor_finish of capi.Context on the C oracle's mean distances: the protocol of
+    pcp_sor_partial / pcp_sor_finish (per-chunk sums in a fixed order, threshold from the concatenated array), with a small
+    chunk so that two ranks own several chunks each."""
+
+    CHUNK = 256
+
+    def __init__(self, x, y, z, mean_k):
+        from oracle import oracle_capi as oc
+
+        _, _, self.dist, _ = oc.sor(x, y, z, mean_k, 1.0, threads=2, details=True)
+        self.dist = self.dist.astype(np.float32)
+        self.n = len(x)
+
+    def sor_chunk_points(self):
+        return self.CHUNK
+
+    @staticmethod
+    def chunk_sums(d):
+        d32 = d.astype(np.float32)
+        sq = (d32 * d32).astype(np.float64)  # fp32 squares, as the reference
+        return np.array([np.sum(d32.astype(np.float64)), np.sum(sq)])
+
+    def sor_partial(self, mean_k, lo, hi):
+        c = self.CHUNK
+        assert lo % c == 0 and (hi % c == 0 or hi == self.n)
+        return np.array([self.chunk_sums(self.dist[b:min(b + c, hi)]) for b in range(lo, hi, c)]).reshape(-1, 2)
+
+    def sor_finish(self, std_mul, sums, lo, hi):
+        assert len(sums) == (self.n + self.CHUNK - 1) // self.CHUNK
+        s, q = 0.0, 0.0
+        for a, b in np.asarray(sums, np.float64):  # fixed order
+            s, q = s + a, q + b
+        n = float(self.n)
+        thr = s / n + std_mul * np.sqrt((q - s * s / n) / (n - 1.0))
+        keep = (~(self.dist[lo:hi].astype(np.float64) > thr)).astype(np.uint8)
+        return keep, int(keep.sum())
+
+
+def _sor_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+
+    from pointcloudprocessor_amd import pipeline
+    from test_sharding_gloo import OracleMlsEngine, OracleSorCtx, _mls_points
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x, y, z = _mls_points()
+
+    class P:
+        sor_mean_k, sor_std_mul = 12, 0.7
+
+    smooth = pipeline.CloudSmooth.__new__(pipeline.CloudSmooth)
+    smooth.engine = OracleMlsEngine(x, y, z)
+    smooth.engine.ctx = OracleSorCtx(x, y, z, P.sor_mean_k)
+    smooth.params = P
+    keep = smooth.outlier_removal_sharded(len(x), rank, world)
+    np.save(os.path.join(out_dir, f"sor{rank}.npy"), keep)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _mls_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -215,6 +280,25 @@ def test_two_rank_gloo_equals_single_process(tmp_path, oracle):
     for r in (r0, r1):
         assert np.array_equal(r["rgb"], ref["rgb"]) and np.array_equal(r["has"], ref["has"])
     assert ref["has"].sum() > 100
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_outlier_removal_sharding(tmp_path, oracle):
+    """StatisticalOutlierRemoval with the queries dealt out by index on chunk boundaries over 2 gloo ranks
+    (pipeline.CloudSmooth.outlier_removal_sharded: all-reduce of the chunk sums, every rank classifies its range, all-reduce of
+    the flags): the keep mask equals the one-process filter on every rank."""
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_sor_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    x, y, z = _mls_points()
+    ctx = OracleSorCtx(x, y, z, 12)
+    sums = ctx.sor_partial(12, 0, len(x))
+    ref, kept = ctx.sor_finish(0.7, sums, 0, len(x))
+    keep_o, kept_o = oracle.sor(x, y, z, 12, 0.7, threads=2)[:2]
+    assert 0 < kept < len(x) and abs(kept - kept_o) <= 2  # the chunked sums against PCL's running sums: a borderline point at most
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"sor{r}.npy"), ref), r
 
 
 @pytest.mark.timeout(300)
