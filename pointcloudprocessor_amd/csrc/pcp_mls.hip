@@ -317,9 +317,10 @@ __device__ __forceinline__ float sqdist_f32(float ax, float ay, float az, float 
 // every lane busy (in the plain double loop only the ~35 % of lanes whose current candidate is
 // inside the radius do fp64 work).  Lanes whose neighbourhood does not fit (K > kMaxNbr, a run
 // longer than 4096 points, or a grid with reach > 1) take the plain loops.
-constexpr int kMaxNbr = 96;
+constexpr int kMaxNbr = 88;  // 13.3 KB of LDS per wavefront: 12 wavefronts per CU, what the 140 VGPRs allow (96: 11 wavefronts, fit +3 %;
+                             // 72: the 4.6 % of lanes with more neighbours take the plain loops, fit +38 %)
 constexpr int kMaxRun = 9;
-constexpr int kFitBlock = 64;  // 14.3 KB of LDS per wavefront: 11 wavefronts per CU (the 140 VGPRs would allow 12)
+constexpr int kFitBlock = 64;
 
 // kBuf: the cell-sorted coordinate planes are read through buffer descriptors (uniform base, 32-bit byte offset per
 // lane: one shift per candidate instead of three 64-bit addresses); needs n < 2^30 points.
