@@ -2440,6 +2440,7 @@ int pcp_sor(pcp_context *ctx, int32_t mean_k, double std_mul, uint8_t *out_keep,
   if (out_kept) *out_kept = 0;
   if (n == 0) return PCP_OK;
   ctx->sor_distances_live = false;
+  ctx->sor_partial_begin = ctx->sor_partial_end = -1;
   int rc = sor_run(ctx, uploaded_view(ctx), mean_k, std_mul);
   if (rc != PCP_OK) return rc;
   ctx->sor_distances_live = true;
@@ -2478,8 +2479,11 @@ int pcp_sor_partial(pcp_context *ctx, int32_t mean_k, int64_t index_begin, int64
     return set_error(ctx, PCP_ERR_RANGE, "pcp_sor_partial: room for %lld chunks, the range has %lld", (long long)capacity, (long long)(c1 - c0));
   PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
   ctx->sor_distances_live = false;
+  ctx->sor_partial_begin = ctx->sor_partial_end = -1;
   if (index_end == index_begin) return PCP_OK;
   if ((rc = sor_run(ctx, uploaded_view(ctx), mean_k, 0.0, false, index_begin, index_end, /*classify=*/false)) != PCP_OK) return rc;
+  ctx->sor_partial_begin = index_begin;
+  ctx->sor_partial_end = index_end;
   PCP_HIP_TRY(ctx, hipMemcpyAsync(out_chunk_sums, ctx->m_sums.p + 4 + 2 * c0, static_cast<size_t>(c1 - c0) * 2 * sizeof(double),
                                   hipMemcpyDeviceToHost, ctx->stream));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -2497,8 +2501,10 @@ int pcp_sor_finish(pcp_context *ctx, double std_mul, const double *all_chunk_sum
   if (n_chunks != div_up(n, kSorChunk) || !all_chunk_sums)
     return set_error(ctx, PCP_ERR_INVALID, "pcp_sor_finish: %lld chunk sums given, the cloud has %lld chunks", (long long)n_chunks, (long long)div_up(n, kSorChunk));
   if (index_end == index_begin) return PCP_OK;  // a GPU without queries (fewer chunks than GPUs)
-  if (!ctx->s_dist.p || !ctx->m_sums.p || ctx->m_sums.count < 4 + 2 * static_cast<size_t>(n_chunks))
-    return set_error(ctx, PCP_ERR_STATE, "pcp_sor_finish: no pcp_sor_partial on this context");
+  if (!ctx->s_dist.p || !ctx->m_sums.p || ctx->m_sums.count < 4 + 2 * static_cast<size_t>(n_chunks) ||
+      index_begin < ctx->sor_partial_begin || index_end > ctx->sor_partial_end)
+    return set_error(ctx, PCP_ERR_STATE, "pcp_sor_finish: the range [%lld, %lld) was not covered by the last pcp_sor_partial of this context",
+                     (long long)index_begin, (long long)index_end);
   PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
   PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->m_sums.p + 4, all_chunk_sums, static_cast<size_t>(n_chunks) * 2 * sizeof(double),
                                   hipMemcpyHostToDevice, ctx->stream));
@@ -2529,6 +2535,7 @@ int pcp_cloud_smooth(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_cou
   PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
   ctx->mls_count = 0;
   ctx->sor_distances_live = false;
+  ctx->sor_partial_begin = ctx->sor_partial_end = -1;
   if (out_count) *out_count = 0;
   const CloudView cv0 = uploaded_view(ctx);
   if (cv0.n == 0) return PCP_OK;

@@ -228,3 +228,19 @@ def test_sor_sharded_python_host_single_rank(gpu_ctx_factory):
     cs = pipeline.CloudSmooth(eng)
     keep = cs.outlier_removal_sharded(len(x), 0, 1)
     assert np.array_equal(keep, keep_ref)
+
+
+def test_sor_finish_needs_its_range_from_the_last_partial(gpu_ctx_factory):
+    from pointcloudprocessor_amd import capi, synth
+
+    x, y, z, _ = synth.make_cloud(40_000, seed=2)
+    ctx = gpu_ctx_factory()
+    ctx.upload_cloud(x, y, z)
+    c = ctx.sor_chunk_points()
+    sums = ctx.sor_partial(60, 0, len(x))
+    ctx.sor_partial(60, 0, c)  # only the first chunk's distances are current now
+    with pytest.raises(capi.PcpError):
+        ctx.sor_finish(0.7, sums, c, len(x))
+    keep, kept = ctx.sor_finish(0.7, sums, 0, c)
+    ref, _ = ctx.sor(60, 0.7)
+    assert np.array_equal(keep, ref[:c]) and kept == int(ref[:c].sum())
