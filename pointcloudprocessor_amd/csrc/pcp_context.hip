@@ -211,19 +211,50 @@ __global__ __launch_bounds__(kUpBlock) void k_up_bbox(const float *__restrict__ 
   }
 }
 
+// 30-bit index of the cell (ix, iy, iz), 10 bits each, along the 3-D Hilbert curve (Skilling, "Programming the Hilbert
+// curve", AIP Conf. Proc. 707, 2004: axes to transpose, then the bits interleaved, x most significant).  Consecutive
+// indices are always face-adjacent cells: a run of 64 sorted points never straddles one of the Z-order curve's jumps.
+__device__ __forceinline__ uint32_t hilbert30(uint32_t x, uint32_t y, uint32_t z) {
+  uint32_t X[3] = {x, y, z};
+  for (uint32_t Q = 512u; Q > 1u; Q >>= 1) {
+    const uint32_t P = Q - 1u;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (X[i] & Q) {
+        X[0] ^= P;
+      } else {
+        const uint32_t t = (X[0] ^ X[i]) & P;
+        X[0] ^= t;
+        X[i] ^= t;
+      }
+    }
+  }
+  X[1] ^= X[0];
+  X[2] ^= X[1];
+  uint32_t t = 0u;
+  for (uint32_t Q = 512u; Q > 1u; Q >>= 1)
+    if (X[2] & Q) t ^= Q - 1u;
+  X[0] ^= t;
+  X[1] ^= t;
+  X[2] ^= t;
+  return (spread10(X[0]) << 2) | (spread10(X[1]) << 1) | spread10(X[2]);
+}
+
 // Spatial order for the batched run: 64 consecutive points (one wavefront) then fall in few z-buffer cells
-// and mostly share their keyframe visibility.
+// and mostly share their keyframe visibility.  Hilbert order by default (PCP_CLOUD_ORDER=morton: Z order, as rounds 1-3
+// shipped it): on the C3 scene the bounding spheres of the 64-point tiles shrink from 8.4 to 6.0 cm on average, and the
+// few tiles that straddle a jump of the Z curve (radius up to metres) disappear.
 __global__ __launch_bounds__(kUpBlock) void k_up_keys(const float *__restrict__ x, const float *__restrict__ y,
                                                      const float *__restrict__ z, int64_t n, float mnx, float mny,
                                                      float mnz, float scx, float scy, float scz,
-                                                     uint32_t *__restrict__ key, int32_t *__restrict__ val) {
+                                                     uint32_t *__restrict__ key, int32_t *__restrict__ val, int32_t hilbert) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * kUpBlock + threadIdx.x;
   if (i >= n) return;
   // non-finite coordinates convert to 0 / saturate: any key is fine, the order only affects speed
   const uint32_t ix = static_cast<uint32_t>(fminf(fmaxf((x[i] - mnx) * scx, 0.0f), 1023.0f));
   const uint32_t iy = static_cast<uint32_t>(fminf(fmaxf((y[i] - mny) * scy, 0.0f), 1023.0f));
   const uint32_t iz = static_cast<uint32_t>(fminf(fmaxf((z[i] - mnz) * scz, 0.0f), 1023.0f));
-  key[i] = spread10(ix) | (spread10(iy) << 1) | (spread10(iz) << 2);
+  key[i] = hilbert ? hilbert30(ix, iy, iz) : (spread10(ix) | (spread10(iy) << 1) | (spread10(iz) << 2));
   val[i] = static_cast<int32_t>(i);
 }
 
@@ -464,8 +495,10 @@ static int store_cloud(pcp_context *ctx, const float *x, const float *y, const f
   PCP_HIP_TRY(ctx, hist.ensure(static_cast<size_t>(hm) + 8));
   const int64_t scan_tiles = std::max<int64_t>(1, (hm + 1 + kScanTile - 1) / kScanTile);
   PCP_HIP_TRY(ctx, ctx->s_tiles.ensure(static_cast<size_t>(scan_tiles) + 4));
+  const char *order_env = std::getenv("PCP_CLOUD_ORDER");
+  const int32_t hilbert = !(order_env && order_env[0] == 'm');
   hipLaunchKernelGGL(k_up_keys, dim3(up_blocks(n)), dim3(kUpBlock), 0, st, dx, dy, dz, n, mn[0], mn[1], mn[2], sc[0], sc[1],
-                     sc[2], key_a.p, ctx->perm.p);
+                     sc[2], key_a.p, ctx->perm.p, hilbert);
   uint32_t *kin = key_a.p, *kout = key_b.p;
   int32_t *vin = ctx->perm.p, *vout = val_b.p;
   for (int pass = 0; pass < 4; ++pass) {  // 30 key bits: 4 passes of 8 (an even count: the result lands in perm)
