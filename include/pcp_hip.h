@@ -170,6 +170,13 @@ int pcp_upload_image(pcp_context *ctx, int32_t frame, const uint8_t *bgr, int64_
  * host buffer must stay valid and unchanged until pcp_synchronize (or any synchronising call) returns; from
  * pinned memory a sequence of keyframes streams at the PCIe rate with the packing kernels in between. */
 int pcp_upload_image_async(pcp_context *ctx, int32_t frame, const uint8_t *bgr, int64_t row_stride_bytes);
+/* `count` keyframes first_frame ... that sit one after the other in PINNED host memory, frame_stride_bytes apart (a pinned
+ * arena the decoder fills, cv::Mat headers over it): the copy engine moves them in blocks of <= 128 MB (one DMA per block:
+ * the PCIe rate, which neither one copy per keyframe nor kernels reading pinned memory in place reach), each block's
+ * keyframes are packed from the device copy, consecutive blocks alternate between two streams.  Asynchronous like
+ * pcp_upload_image_async.  Pageable or device memory is accepted and handled keyframe by keyframe. */
+int pcp_upload_images_block(pcp_context *ctx, int32_t first_frame, int32_t count, const uint8_t *bgr, int64_t row_stride_bytes,
+                            int64_t frame_stride_bytes);
 /* Both upload calls also take a DEVICE pointer for `bgr` (e.g. frames broadcast or all-gathered over xGMI by a
  * multi-GPU host): the transfer is then ordered after everything already queued on the context's stream
  * (pcp_set_stream), so a collective that produced the bytes on that stream needs no host synchronisation.  Pinned

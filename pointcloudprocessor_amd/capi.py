@@ -256,6 +256,13 @@ class Context:
         assert bgr.shape == (self.camera.image_height, self.camera.image_width, 3), bgr.shape
         self._check(self.lib.pcp_upload_image_async(self.h, C.c_int32(frame), _ptr(bgr), C.c_int64(bgr.strides[0])))
 
+    def upload_images_block(self, first_frame: int, block: np.ndarray):
+        """Keyframes first_frame ... from one (count, H, W, 3) array (ideally pinned): DMA in blocks, packed on the device."""
+        assert block.dtype == np.uint8 and block.flags.c_contiguous and block.ndim == 4
+        assert block.shape[1:] == (self.camera.image_height, self.camera.image_width, 3), block.shape
+        self._check(self.lib.pcp_upload_images_block(self.h, C.c_int32(first_frame), C.c_int32(block.shape[0]), _ptr(block),
+                                                     C.c_int64(block.strides[1]), C.c_int64(block.strides[0])))
+
     def upload_image_async_ptr(self, frame: int, ptr: int, row_stride_bytes: int):
         """The same from a raw address: pinned host memory or DEVICE memory (e.g. frames all-gathered over xGMI)."""
         self._check(self.lib.pcp_upload_image_async(self.h, C.c_int32(frame), C.c_void_p(ptr), C.c_int64(row_stride_bytes)))

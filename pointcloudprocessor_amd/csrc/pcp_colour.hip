@@ -1208,8 +1208,10 @@ extern "C" {
 // Both forms run on the upload stream: copy into the staging buffer, pack kernel (with the HSV round trip when
 // pcp_set_image_adjust enabled it), event.  `bgr` may be a host pointer (pinned for a real overlap) or a device
 // pointer (hipMemcpyDefault: e.g. frames all-gathered over xGMI by the multi-GPU driver).
+// block_bytes > 0: `bgr` is the first of block_frames keyframes (block_stride bytes apart) in pinned host memory; the whole
+// block is copied into the lane's staging buffer by one DMA and every keyframe of it is packed from there.
 static int upload_image_impl(pcp_context *ctx, const char *who, int32_t frame, const uint8_t *bgr, int64_t row_stride_bytes,
-                             bool wait) {
+                             bool wait, size_t block_bytes = 0, int64_t block_stride = 0, int32_t block_frames = 1) {
   int rc = check_ready(ctx, who, true);
   if (rc != PCP_OK) return rc;
   if ((rc = check_frame(ctx, who, frame)) != PCP_OK) return rc;
@@ -1237,7 +1239,12 @@ static int upload_image_impl(pcp_context *ctx, const char *who, int32_t frame, c
   const size_t sf = static_cast<size_t>(frame);
   // a keyframe uploaded again goes to the lane of its previous upload while that one may still be in flight (two
   // lanes writing the same texels would race); otherwise the lanes take turns
-  const int lane = ctx->image_pending[sf] ? ctx->image_lane[sf] : static_cast<int>(ctx->upload_seq % pcp_context::kUploadLanes);
+  const int lane = (ctx->image_pending[sf] && block_bytes == 0) ? ctx->image_lane[sf]
+                                                                : static_cast<int>(ctx->upload_turn % pcp_context::kUploadLanes);
+  if (block_bytes > 0)  // a block takes one lane: uploads of its keyframes still in flight on the other lane come first
+    for (int32_t k = 0; k < block_frames; ++k)
+      if (ctx->image_pending[sf + static_cast<size_t>(k)] && ctx->image_lane[sf + static_cast<size_t>(k)] != lane)
+        PCP_HIP_TRY(ctx, hipStreamWaitEvent(ctx->upload_stream[lane], ctx->image_event[sf + static_cast<size_t>(k)], 0));
   // kernels of the compute stream that read or write texels (a colour pass still sampling the previous image of this
   // keyframe, a mask pack, the clearing of a fresh buffer) come first, on every lane
   if (fresh || ctx->texels_touched) {
@@ -1255,7 +1262,11 @@ static int upload_image_impl(pcp_context *ctx, const char *who, int32_t frame, c
   // Where do the pack kernel's loads go?  Device memory and pinned (device-mapped) host memory are read in place;
   // pageable host memory goes through the lane's staging buffer.
   const uint8_t *src = nullptr;
-  {
+  if (block_bytes > 0) {
+    PCP_HIP_TRY(ctx, ctx->upload_stage[lane].ensure(block_bytes + 16));
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->upload_stage[lane].p, bgr, block_bytes, hipMemcpyHostToDevice, us));
+    src = ctx->upload_stage[lane].p;
+  } else {
     static const bool direct = [] {
       const char *e = std::getenv("PCP_UPLOAD_DIRECT");
       return !(e && e[0] == '0');
@@ -1279,25 +1290,30 @@ static int upload_image_impl(pcp_context *ctx, const char *who, int32_t frame, c
     src = ctx->upload_stage[lane].p;
   }
   const int32_t *tables = ctx->adjust_images ? ctx->hsv_tables.p : static_cast<const int32_t *>(nullptr);
-  uint32_t *dst = ctx->images.p + static_cast<int64_t>(frame) * px;
-  const int32_t clear_mask = ctx->mask_set[frame] ? 0 : 1;
-  if ((w & 15) == 0 && (row_stride_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0)
-    hipLaunchKernelGGL(k_pack_bgr16, dim3(blocks_for(px / 16)), dim3(kBlock), 0, us, src, row_stride_bytes, w, h, dst,
-                       clear_mask, tables, ctx->saturation_scale, ctx->brightness_scale);
-  else
-    hipLaunchKernelGGL(k_pack_bgr, dim3(blocks_for(px)), dim3(kBlock), 0, us, src, row_stride_bytes, w, h, dst, clear_mask,
-                       tables, ctx->saturation_scale, ctx->brightness_scale);
-  PCP_HIP_TRY(ctx, hipGetLastError());
-  PCP_HIP_TRY(ctx, hipEventRecord(ctx->image_event[sf], us));
-  ctx->image_pending[sf] = 1;
-  ctx->image_lane[sf] = static_cast<uint8_t>(lane);
-  ctx->image_seq[sf] = ++ctx->upload_seq;
+  ++ctx->upload_turn;  // one turn of the lanes per call (a block is one call)
+  for (int32_t k = 0; k < block_frames; ++k) {
+    const int32_t fk = frame + k;
+    const uint8_t *sk = src + static_cast<int64_t>(k) * block_stride;
+    uint32_t *dst = ctx->images.p + static_cast<int64_t>(fk) * px;
+    const int32_t clear_mask = ctx->mask_set[fk] ? 0 : 1;
+    if ((w & 15) == 0 && (row_stride_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(sk) & 15u) == 0)
+      hipLaunchKernelGGL(k_pack_bgr16, dim3(blocks_for(px / 16)), dim3(kBlock), 0, us, sk, row_stride_bytes, w, h, dst,
+                         clear_mask, tables, ctx->saturation_scale, ctx->brightness_scale);
+    else
+      hipLaunchKernelGGL(k_pack_bgr, dim3(blocks_for(px)), dim3(kBlock), 0, us, sk, row_stride_bytes, w, h, dst, clear_mask,
+                         tables, ctx->saturation_scale, ctx->brightness_scale);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+    PCP_HIP_TRY(ctx, hipEventRecord(ctx->image_event[static_cast<size_t>(fk)], us));
+    ctx->image_pending[static_cast<size_t>(fk)] = 1;
+    ctx->image_lane[static_cast<size_t>(fk)] = static_cast<uint8_t>(lane);
+    ctx->image_seq[static_cast<size_t>(fk)] = ++ctx->upload_seq;  // queue position: a lane is in order
+    ctx->image_set[static_cast<size_t>(fk)] = 1;
+  }
   if (wait) {  // the host buffer may be reused by the caller
     PCP_HIP_TRY(ctx, hipStreamSynchronize(us));
     for (size_t f = 0; f < nf; ++f)
       if (ctx->image_lane[f] == lane) ctx->image_pending[f] = 0;
   }
-  ctx->image_set[static_cast<size_t>(frame)] = 1;
   return PCP_OK;
 }
 
@@ -1307,6 +1323,49 @@ int pcp_upload_image(pcp_context *ctx, int32_t frame, const uint8_t *bgr, int64_
 
 int pcp_upload_image_async(pcp_context *ctx, int32_t frame, const uint8_t *bgr, int64_t row_stride_bytes) {
   return upload_image_impl(ctx, "pcp_upload_image_async", frame, bgr, row_stride_bytes, false);
+}
+
+// `count` keyframes that sit one after the other in pinned host memory (frame_stride_bytes apart): the copy engine moves
+// them in blocks of up to kBlockUploadBytes into a staging buffer of the lane (one hipMemcpyAsync per block: 57.6 GB/s
+// measured, against 52 GB/s for the pack kernels reading pinned memory in place and 43-46 GB/s for one copy per
+// keyframe), the pack kernels of the block's keyframes follow on the same stream, the next block goes to the other lane.
+// SURVEY 8(d)(i)'s boundary at C3: 29.8 ms instead of 32.5 (PCIe floor 27.7 ms).  Asynchronous like
+// pcp_upload_image_async: the host memory must stay valid and unchanged until a synchronising call returns.
+constexpr size_t kBlockUploadBytes = size_t(128) << 20;
+
+int pcp_upload_images_block(pcp_context *ctx, int32_t first_frame, int32_t count, const uint8_t *bgr, int64_t row_stride_bytes,
+                            int64_t frame_stride_bytes) {
+  int rc = check_ready(ctx, "pcp_upload_images_block", true);
+  if (rc != PCP_OK) return rc;
+  if (count < 0 || first_frame < 0 || first_frame + count > ctx->n_frames)
+    return set_error(ctx, PCP_ERR_RANGE, "pcp_upload_images_block: keyframes [%d, %d) outside 0..%d", first_frame, first_frame + count,
+                     ctx->n_frames);
+  if (count == 0) return PCP_OK;
+  const int32_t w = ctx->dcam.img_w, h = ctx->dcam.img_h;
+  if (!bgr || row_stride_bytes < 3 * static_cast<int64_t>(w) || frame_stride_bytes < row_stride_bytes * h)
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_upload_images_block: NULL block, row stride < 3*width or frame stride < rows");
+  hipPointerAttribute_t attr{};
+  const bool host_pinned = hipPointerGetAttributes(&attr, bgr) == hipSuccess && attr.type == hipMemoryTypeHost;
+  if (!host_pinned) {
+    // device memory is read in place and pageable memory is staged per keyframe: the single-keyframe path serves both
+    (void)hipGetLastError();
+    for (int32_t k = 0; k < count; ++k)
+      if ((rc = upload_image_impl(ctx, "pcp_upload_images_block", first_frame + k, bgr + static_cast<int64_t>(k) * frame_stride_bytes,
+                                  row_stride_bytes, false)) != PCP_OK)
+        return rc;
+    return PCP_OK;
+  }
+  const int32_t per_block = static_cast<int32_t>(std::max<int64_t>(1, static_cast<int64_t>(kBlockUploadBytes) / frame_stride_bytes));
+  for (int32_t b0 = 0; b0 < count; b0 += per_block) {
+    const int32_t b1 = std::min(count, b0 + per_block);
+    // the first keyframe goes through the single-keyframe path's bookkeeping (streams, events, lane choice, ordering against
+    // the compute stream) with the block's staging buffer as its source; the others of the block follow on its lane
+    const size_t bytes = static_cast<size_t>(b1 - b0 - 1) * static_cast<size_t>(frame_stride_bytes) + static_cast<size_t>(row_stride_bytes) * h;
+    if ((rc = upload_image_impl(ctx, "pcp_upload_images_block", first_frame + b0, bgr + static_cast<int64_t>(b0) * frame_stride_bytes,
+                                row_stride_bytes, false, bytes, frame_stride_bytes, b1 - b0)) != PCP_OK)
+      return rc;
+  }
+  return PCP_OK;
 }
 
 int pcp_set_image_adjust(pcp_context *ctx, int32_t enable, float saturation_scale, float brightness_scale) {

@@ -137,7 +137,8 @@ struct pcp_context {
   std::vector<uint8_t> image_lane;       // lane of the keyframe's latest upload
   std::vector<uint64_t> image_seq;       // queue position of the keyframe's latest upload
   bool lane_must_wait[kUploadLanes] = {false, false};  // texels_idle not yet waited for on this lane
-  uint64_t upload_seq = 0;
+  uint64_t upload_seq = 0;   // queue position of the latest packed keyframe
+  uint64_t upload_turn = 0;  // upload calls so far: the lanes take turns per call (a block of keyframes is one call)
   hipEvent_t texels_idle = nullptr;      // recorded on the compute stream
   bool texels_touched = false;           // compute-stream work on the texel buffer since the last wait
   // generateColorMap's 8-bit BGR -> HSV -> BGR round trip, fused into the pack kernel (pcp_set_image_adjust)

@@ -520,3 +520,48 @@ def test_keep_rule_within_rounding_of_the_depth_limit(gpu_ctx_factory, oracle, z
         outcomes.append(int(ref["count"][1]))
         ctx.close()
     assert outcomes == [0, 0, 1, 1, 1, 0, 1]  # dropped below the limit, kept on it and above
+
+
+def test_block_uploads_from_a_pinned_arena(gpu_ctx_factory, oracle, small_scene, monkeypatch):
+    """pcp_upload_images_block: runs of keyframes copied by one DMA per block and packed from the device copy, mixed with
+    single-keyframe uploads of the same keyframes on the other lane, blocks smaller than a run (several DMAs), pageable
+    and device memory as the source -- colours equal the oracle's for whichever image set was uploaded last."""
+    import torch
+
+    from pointcloudprocessor_amd import capi
+
+    s = small_scene
+    cd = s["cam"]
+    F = len(s["poses"])
+    H, W = cd["image_height"], cd["image_width"]
+    ctx = gpu_ctx_factory()
+    ctx.set_camera(cam_struct(capi, cd))
+    ctx.upload_cloud(s["x"], s["y"], s["z"])
+    ctx.set_frames(s["poses"])
+    stage = torch.empty((2 * F, H, W, 3), dtype=torch.uint8).pin_memory()
+    snp = stage.numpy()
+    for f in range(F):
+        snp[f] = s["images"][f]
+        snp[F + f] = s["images"][(f + 1) % F][::-1, ::-1]
+    ocam, ocp = cam_struct(oracle, cd), oracle.default_cull_params()
+    refs = [oracle.colorize(ocam, ocp, s["x"], s["y"], s["z"], s["poses"], [snp[k * F + f] for f in range(F)], want_top=False)
+            for k in range(2)]
+    for rep in range(3):
+        for k in range(2):
+            ctx.colour_reset()
+            if rep == 1:  # some keyframes singly first: the block's lane must wait for uploads in flight on the other lane
+                for f in (1, 4):
+                    ctx.upload_image_async(f, snp[(1 - k) * F + f])
+            ctx.upload_images_block(0, snp[k * F:k * F + 2])
+            ctx.upload_images_block(2, snp[k * F + 2:(k + 1) * F])
+            ctx.depth_pass()
+            for f0 in range(0, F, 2):
+                ctx.colour_pass(f0, min(F, f0 + 2))
+            got = ctx.colour_finalise()
+            assert np.array_equal(got["rgb"], refs[k]["rgb"]) and np.array_equal(got["has"], refs[k]["has"]), (rep, k)
+    # pageable memory and device memory take the keyframe-by-keyframe path
+    ctx.upload_images_block(0, np.ascontiguousarray(snp[F:2 * F]).copy())
+    assert np.array_equal(ctx.colorize()["rgb"], refs[1]["rgb"])
+    ctx.synchronize()
+    with pytest.raises(capi.PcpError):
+        ctx.upload_images_block(F - 1, snp[:2])
