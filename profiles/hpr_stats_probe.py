@@ -1,5 +1,5 @@
 import os, sys, time, json
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pointcloudprocessor_amd import capi, synth
 cam = synth.camera_dict("cfg")

@@ -2,8 +2,8 @@
 grid sized as sor_run sizes it), and the lane utilisation that the raggedness of those runs ALONE would give: one lane per
 query (64 consecutive cell-sorted queries per wavefront: the shipped kernel), 4 or 8 lanes per query.  CPU only.
 python profiles/sim_lane_util.py [points]"""
-import numpy as np, sys, time
-sys.path.insert(0, "/root/repo")
+import os, numpy as np, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pointcloudprocessor_amd import synth
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
 x, y, z, _ = synth.make_cloud(N)
