@@ -287,6 +287,11 @@ int pcp_mls_process(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_coun
  * only the queries index_begin <= i < index_end (upsampling NONE).  Outputs as pcp_mls_process. */
 int pcp_mls_process_shard(pcp_context *ctx, const pcp_mls_params *p, int64_t index_begin, int64_t index_end,
                           int64_t *out_count);
+/* The same deal by SLABS of the stage's own spatial order (consecutive places of its cell-sorted cloud, whole wavefronts):
+ * slab `slab` of `n_slabs` is 1 / n_slabs of the work whatever order the caller's points come in (an index range only
+ * divides the work when the caller's order is spatially coherent).  Outputs as pcp_mls_process: the slab's rows in input
+ * order; the slabs' results merged by source index are the unsharded result. */
+int pcp_mls_process_slab(pcp_context *ctx, const pcp_mls_params *p, int32_t slab, int32_t n_slabs, int64_t *out_count);
 /* VOXEL_GRID_DILATION in chunks.  One result holds fewer than 2^31 points and must fit the device (78 B per point); the
  * reference's own configuration (1 mm voxels, 4 dilations, PointCloudProcessor.cpp:78-81) turns every input point into up
  * to 729 output points -- ~3.8e9 for a 10 M-point map -- and pcp_mls_process then fails with PCP_ERR_NOMEM.  The
@@ -314,20 +319,24 @@ int pcp_cloud_smooth(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_cou
  * coordinates: a cloud with NaN or infinite points is refused with PCP_ERR_INVALID (PCL's filters skip such points one
  * by one; the projection / colour entry points accept them and reject the points, Appendix B6). */
 int pcp_sor(pcp_context *ctx, int32_t mean_k, double std_mul, uint8_t *out_keep, int64_t *out_kept);
-/* Multi-GPU form of pcp_sor (the cloud on every GPU, the queries dealt out by index).  The filter's threshold
- * is mean + std_mul * stddev of ALL mean distances (cloudSmooth.cpp:113-115 -> statistical_outlier_removal.hpp [upstream]),
- * so a shard cannot classify alone; its statistics are kept as one (sum, sum of squares) pair per chunk of
- * pcp_sor_chunk_points() consecutive indices, each chunk summed in a fixed order by whichever GPU owns it:
- *   pcp_sor_partial  mean distances of the queries index_begin <= i < index_end (bounds on chunk boundaries, index_end
- *                    may be the point count) and their chunk sums: 2 doubles per chunk of the range into out_chunk_sums;
- *   (the caller concatenates the shards' arrays in index order: ceil(n / chunk) pairs -- the array one GPU computes)
- *   pcp_sor_finish   threshold from all chunk sums, keep flags of the range (out_keep[i - index_begin]).
- * pcp_sor itself is partial + finish over [0, n): the sharded keep mask equals it bit for bit. */
+/* Multi-GPU form of pcp_sor (the cloud on every GPU, the queries dealt out).  The queries are dealt out by
+ * SLABS of the filter's own spatial order (consecutive places of its cell-sorted cloud), not by the caller's indices: a
+ * wavefront holds 64 consecutive places, so a slab is whole wavefronts and 1 / n_slabs of the work whatever order the
+ * caller's points come in.  The filter's threshold is mean + std_mul * stddev of ALL mean distances (cloudSmooth.cpp:113-115 ->
+ * statistical_outlier_removal.hpp [upstream]), so a slab cannot classify alone; the statistics are kept as one (sum, sum of
+ * squares) pair per chunk of pcp_sor_chunk_points() consecutive places, each chunk summed in a fixed order by the GPU whose
+ * slab holds it (slabs are whole chunks):
+ *   pcp_sor_partial  mean distances of slab `slab` of `n_slabs` and its chunk sums: 2 doubles per chunk into out_chunk_sums,
+ *                    *out_first_chunk / *out_chunks = where they belong among the ceil(n / chunk) pairs of the cloud;
+ *   (the caller puts the slabs' arrays together: the array one GPU computes)
+ *   pcp_sor_finish   threshold from all chunk sums, keep flags of the slab's points: out_keep[i] (n bytes, the caller's
+ *                    indices, 0 for every point of another slab -- the OR of the slabs' arrays is the filter's mask).
+ * pcp_sor itself is partial + finish with one slab: the sharded keep mask equals it bit for bit. */
 int64_t pcp_sor_chunk_points(void);
-int pcp_sor_partial(pcp_context *ctx, int32_t mean_k, int64_t index_begin, int64_t index_end, int64_t capacity,
-                    double *out_chunk_sums);
-int pcp_sor_finish(pcp_context *ctx, double std_mul, const double *all_chunk_sums, int64_t n_chunks, int64_t index_begin,
-                   int64_t index_end, uint8_t *out_keep, int64_t *out_kept);
+int pcp_sor_partial(pcp_context *ctx, int32_t mean_k, int32_t slab, int32_t n_slabs, int64_t capacity, double *out_chunk_sums,
+                    int64_t *out_first_chunk, int64_t *out_chunks);
+int pcp_sor_finish(pcp_context *ctx, double std_mul, const double *all_chunk_sums, int64_t n_chunks, int32_t slab, int32_t n_slabs,
+                   uint8_t *out_keep, int64_t *out_kept);
 
 /* ---- NID extrinsic refinement (VisualLiDARCalibration::calibrate, PCP/src/calibrate.cpp:42-126) -- */
 /* per-point intensity of the uploaded cloud (pcl::PointXYZI::intensity), needed by the NID stage */

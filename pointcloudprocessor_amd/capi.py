@@ -440,6 +440,12 @@ class Context:
                                                    C.byref(cnt)))
         return cnt.value
 
+    def mls_process_slab(self, params: MLSParams, slab: int, n_slabs: int) -> int:
+        """Queries of one slab of the stage's own spatial order (1 / n_slabs of the work whatever the caller's point order)."""
+        cnt = C.c_int64()
+        self._check(self.lib.pcp_mls_process_slab(self.h, C.byref(params), C.c_int32(slab), C.c_int32(n_slabs), C.byref(cnt)))
+        return cnt.value
+
     def cloud_smooth(self, params: MLSParams) -> int:
         cnt = C.c_int64()
         self._check(self.lib.pcp_cloud_smooth(self.h, C.byref(params), C.byref(cnt)))
@@ -462,21 +468,23 @@ class Context:
     def sor_chunk_points(self) -> int:
         return int(self.lib.pcp_sor_chunk_points())
 
-    def sor_partial(self, mean_k: int, index_begin: int, index_end: int) -> np.ndarray:
-        """Index shard of sor(): (sum, sum of squares) of the mean distances per chunk of the range."""
+    def sor_partial(self, mean_k: int, slab: int, n_slabs: int):
+        """Slab `slab` of `n_slabs` of sor(): (first chunk, (sum, sum of squares) per chunk of the slab)."""
         c = self.sor_chunk_points()
-        chunks = (index_end + c - 1) // c - index_begin // c
-        out = np.zeros((max(chunks, 0), 2), np.float64)
-        self._check(self.lib.pcp_sor_partial(self.h, C.c_int32(mean_k), C.c_int64(index_begin), C.c_int64(index_end),
-                                             C.c_int64(len(out)), _ptr(out)))
-        return out
+        chunks = (self.n + c - 1) // c
+        out = np.zeros((max(chunks, 1), 2), np.float64)
+        first, cnt = C.c_int64(), C.c_int64()
+        self._check(self.lib.pcp_sor_partial(self.h, C.c_int32(mean_k), C.c_int32(slab), C.c_int32(n_slabs), C.c_int64(len(out)),
+                                             _ptr(out), C.byref(first), C.byref(cnt)))
+        return first.value, out[:cnt.value].copy()
 
-    def sor_finish(self, std_mul: float, all_chunk_sums: np.ndarray, index_begin: int, index_end: int):
+    def sor_finish(self, std_mul: float, all_chunk_sums: np.ndarray, slab: int, n_slabs: int):
+        """Keep flags of the slab's points (n bytes under the caller's indices, 0 for the other slabs' points)."""
         sums = np.ascontiguousarray(all_chunk_sums, np.float64)
-        keep = np.empty(max(index_end - index_begin, 0), np.uint8)
+        keep = np.empty(self.n, np.uint8)
         kept = C.c_int64()
-        self._check(self.lib.pcp_sor_finish(self.h, C.c_double(std_mul), _ptr(sums), C.c_int64(len(sums)),
-                                            C.c_int64(index_begin), C.c_int64(index_end), _ptr(keep), C.byref(kept)))
+        self._check(self.lib.pcp_sor_finish(self.h, C.c_double(std_mul), _ptr(sums), C.c_int64(len(sums)), C.c_int32(slab),
+                                            C.c_int32(n_slabs), _ptr(keep), C.byref(kept)))
         return keep, kept.value
 
     def close_pairs(self, radius: float = 2.5e-5) -> int:

@@ -429,7 +429,7 @@ static int store_cloud(pcp_context *ctx, const float *x, const float *y, const f
   ctx->n = n;
   ctx->nonfinite_points = 0;
   ctx->sor_distances_live = false;
-  ctx->sor_partial_begin = ctx->sor_partial_end = -1;
+  ctx->sor_partial_slab = ctx->sor_partial_slabs = -1;
   ctx->n_tiles = 0;
   ctx->tile_order_live = false;
   ctx->have_intensity = false;

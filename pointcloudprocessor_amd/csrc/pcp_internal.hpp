@@ -208,7 +208,7 @@ struct pcp_context {
   pcp::DevBuf<uint8_t> m_flag;   // n
   pcp::DevBuf<double> m_sums;    // SOR statistics
   pcp::DevBuf<int32_t> c_index;  // pcp_cloud_smooth: survivors of the 1st SOR (indices into the uploaded cloud)
-  int64_t sor_partial_begin = -1, sor_partial_end = -1;  // index range whose mean distances the last pcp_sor_partial left in s_dist
+  int32_t sor_partial_slab = -1, sor_partial_slabs = -1;  // the slab of the cell order whose mean distances the last pcp_sor_partial left in s_dist
   bool sor_distances_live = false;  // s_dist holds the mean distances of the last pcp_sor (caller's order)
   pcp::DevBuf<uint8_t> c_mark;    // pcp_cloud_smooth: per uploaded point, survives the whole chain
   pcp::DevBuf<int32_t> c_where;   // ... and the result row that holds it

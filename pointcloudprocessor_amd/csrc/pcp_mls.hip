@@ -304,7 +304,8 @@ struct MlsArgs {
   float *tmp;                    // 7 floats per input point
   uint8_t *flag;                 // per input point
   double *state;                 // kMlsState doubles per input point (nullable)
-  int32_t q_begin, q_end;        // only queries with q_begin <= input index < q_end are fitted (query sharding)
+  int32_t q_begin, q_end;        // only queries with q_begin <= input index < q_end are fitted (query sharding by index)
+  int64_t j_begin, j_end;        // the places of the cell order this launch covers (query sharding by slabs)
 };
 
 __device__ __forceinline__ float sqdist_f32(float ax, float ay, float az, float bx, float by, float bz) {
@@ -345,8 +346,8 @@ __global__ __launch_bounds__(kFitBlock) void k_mls_fit(MlsArgs a) {
     }
   };
   const int tid = threadIdx.x;
-  const int64_t j = static_cast<int64_t>(blockIdx.x) * kFitBlock + threadIdx.x;
-  if (j >= a.n) return;
+  const int64_t j = a.j_begin + static_cast<int64_t>(blockIdx.x) * kFitBlock + threadIdx.x;
+  if (j >= a.j_end) return;
   const int32_t i = a.remap ? a.remap[a.order[j]] : a.order[j];
   if (i < a.q_begin || i >= a.q_end) {  // another shard's query
     a.flag[i] = 0;
@@ -1018,15 +1019,16 @@ __global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(6, 8))
                                                          const int32_t *__restrict__ remap,
                                                          const int32_t *__restrict__ start, int64_t n, GridDesc g,
                                                          int32_t mean_k, float *__restrict__ distances,
-                                                         uint8_t *__restrict__ redo, int64_t q_begin, int64_t q_end) {
+                                                         uint8_t *__restrict__ redo, int64_t j_begin, int64_t j_end) {
+  // [j_begin, j_end): the slab of the cell order this launch covers (the whole cloud, or one GPU's share: pcp_sor_partial)
 #pragma clang fp contract(off)
   __shared__ uint32_t sel_lds[kSelLdsWords];
   float *list = reinterpret_cast<float *>(sel_lds);            // [kSelDrain][64]
   float *members = list + kSelDrain * kSelWave;                // [kSelList][64]
   const int lane = threadIdx.x;
-  const int64_t t = static_cast<int64_t>(blockIdx.x) * kSelWave + lane;
-  const bool live = t < n;
-  const int64_t j = min(t, n - 1);  // lanes past the end shadow the last point and write nothing
+  const int64_t t = j_begin + static_cast<int64_t>(blockIdx.x) * kSelWave + lane;
+  const bool live = t < j_end;
+  const int64_t j = min(t, j_end - 1);  // lanes past the end shadow the last point and write nothing
   const int k = mean_k + 1;
   const float qx = sx[j], qy = sy[j], qz = sz[j];
   int32_t cx, cy, cz;
@@ -1121,15 +1123,8 @@ __global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(6, 8))
     const uint32_t v = sel_lds[b * 32 + (lane & 31)];
     return static_cast<int>(lane < 32 ? (v & 0xffffu) : (v >> 16));
   };
-  // index shards (pcp_sor_partial): a point whose index (as `distances` is indexed) lies outside [q_begin, q_end) belongs
-  // to another GPU -- its lane sits out and writes nothing
-  bool skip = false;
-  if (q_begin > 0 || q_end < n) {
-    const int64_t i = remap ? remap[order[j]] : order[j];
-    skip = i < q_begin || i >= q_end;
-  }
-  bool bad = skip, sparse = false;
-  if (!skip) {
+  bool bad = false, sparse = false;
+  {
     // a counter cannot wrap (and carry into the lane it shares a dword with): the 27 cells hold fewer candidates than
     // it can count, else the heap kernel takes the lane
     uint32_t total = 0;
@@ -1305,7 +1300,7 @@ __global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(6, 8))
     if (live && !tiny) distances[remap ? remap[order[j]] : order[j]] = static_cast<float>(sum / static_cast<double>(mean_k));
   }
   // 1: the ball of one cell holds too few points (k_sor_wave starts with two cells); 3: any other reason
-  if (live) redo[j] = skip ? 0 : (sparse ? 1 : ((bad || tiny) ? 3 : 0));
+  if (live) redo[j] = sparse ? 1 : ((bad || tiny) ? 3 : 0);
 }
 
 // The lanes k_sor_select flags (sparse spots and borders of a surface: fewer than k + 1 points within one cell; dense
@@ -1521,19 +1516,20 @@ __global__ __launch_bounds__(kSelWave) void k_sor_wave(const float *__restrict__
 }
 
 // sum and sum of squares (fp32 squares, as the reference) of the distances, fp64 accumulation.  One pair of partial sums
-// per CHUNK of kSorChunk consecutive points (a workgroup per chunk, every lane a fixed sub-sequence, a fixed reduction
-// tree), added up over the chunks in a fixed order by k_sor_threshold: no atomics, so the threshold is the same on every
-// run -- and the same however the chunks are dealt out to GPUs (pcp_sor_partial: index shards aligned to chunks compute
-// their own chunks' pairs; the concatenation is the array one GPU computes).
+// per CHUNK of kSorChunk consecutive places of the cell order (a workgroup per chunk, every lane a fixed sub-sequence, a
+// fixed reduction tree), added up over the chunks in a fixed order by k_sor_threshold: no atomics, so the threshold is the
+// same on every run -- and the same however the chunks are dealt out to GPUs (pcp_sor_partial: a GPU's slab of the cell
+// order is whole chunks; the concatenation of the slabs' pairs is the array one GPU computes).
 constexpr int64_t kSorChunk = 16384;
-__global__ __launch_bounds__(kMB) void k_sor_stats(const float *__restrict__ distances, int64_t n, int64_t first_chunk,
+__global__ __launch_bounds__(kMB) void k_sor_stats(const float *__restrict__ distances, const int32_t *__restrict__ order,
+                                                   const int32_t *__restrict__ remap, int64_t n, int64_t first_chunk,
                                                    double *__restrict__ partial /* [chunks of the cloud][2] */) {
   __shared__ double sh[2][kMB / 64];
   const int64_t chunk = first_chunk + blockIdx.x;
   const int64_t lo = chunk * kSorChunk, hi = min(lo + kSorChunk, n);
   double s = 0.0, q = 0.0;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += kMB) {
-    const float d = distances[i];
+  for (int64_t j = lo + threadIdx.x; j < hi; j += kMB) {
+    const float d = distances[remap ? remap[order[j]] : order[j]];
     s += static_cast<double>(d);
     q += static_cast<double>(__fmul_rn(d, d));
   }
@@ -1580,10 +1576,14 @@ __global__ __launch_bounds__(64) void k_sor_threshold(const double *__restrict__
   }
 }
 
-__global__ __launch_bounds__(kMB) void k_sor_classify(const float *__restrict__ distances, int64_t begin, int64_t end,
+// keep flags (under the indices `distances` uses) of the points at places [begin, end) of the cell order
+__global__ __launch_bounds__(kMB) void k_sor_classify(const float *__restrict__ distances, const int32_t *__restrict__ order,
+                                                      const int32_t *__restrict__ remap, int64_t begin, int64_t end,
                                                       const double *__restrict__ threshold, uint8_t *__restrict__ keep) {
-  const int64_t i = begin + static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
-  if (i < end) keep[i] = !(static_cast<double>(distances[i]) > *threshold) ? 1 : 0;
+  const int64_t j = begin + static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  if (j >= end) return;
+  const int64_t i = remap ? remap[order[j]] : order[j];
+  keep[i] = !(static_cast<double>(distances[i]) > *threshold) ? 1 : 0;
 }
 
 // a cloud on the device the smoothing stages operate on (the uploaded map, or an
@@ -2076,7 +2076,8 @@ static int check_mls_params(pcp_context *ctx, const pcp_mls_params *p) {
 // keep_rows: leave the fitted rows in ctx->m_tmp (7 floats at the view index mls_index names) instead of gathering them
 // into the result arrays -- pcp_cloud_smooth picks the survivors of its last filter straight from there
 static int mls_run(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *p, int64_t *out_count,
-                   int64_t q_begin = 0, int64_t q_end = -1, bool keep_rows = false, int64_t stream_capacity = 0) {
+                   int64_t q_begin = 0, int64_t q_end = -1, bool keep_rows = false, int64_t stream_capacity = 0,
+                   int32_t slab = 0, int32_t n_slabs = 1) {
   const int64_t n = cv.n;
   ctx->mls_count = 0;
   if (out_count) *out_count = 0;
@@ -2107,6 +2108,10 @@ static int mls_run(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *
   a.state = nullptr;
   a.q_begin = static_cast<int32_t>(q_begin);
   a.q_end = static_cast<int32_t>(q_end < 0 ? n : q_end);
+  // a slab of the cell order (whole wavefronts: the deal divides the work whatever the caller's point order is)
+  a.j_begin = n_slabs > 1 ? (n * slab / n_slabs) / kFitBlock * kFitBlock : 0;
+  a.j_end = (n_slabs > 1 && slab + 1 < n_slabs) ? (n * (slab + 1) / n_slabs) / kFitBlock * kFitBlock : n;
+  if (n_slabs > 1) PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->m_flag.p, 0, sn, ctx->stream));  // the other slabs' points: no output
   if (p->upsampling == 3) {
     PCP_HIP_TRY(ctx, ctx->m_state.ensure(static_cast<size_t>(kMlsState) * sn + 8));
     // points skipped by the fit (< 3 neighbours) must read as "invalid" later
@@ -2115,10 +2120,11 @@ static int mls_run(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *
   }
   {
     LaunchTimer t(ctx, PCP_K_MLS_FIT);
-    if (n < (int64_t(1) << 30))
-      hipLaunchKernelGGL(k_mls_fit<true>, dim3(static_cast<uint32_t>(div_up(n, kFitBlock))), dim3(kFitBlock), 0, ctx->stream, a);
-    else
-      hipLaunchKernelGGL(k_mls_fit<false>, dim3(static_cast<uint32_t>(div_up(n, kFitBlock))), dim3(kFitBlock), 0, ctx->stream, a);
+    const uint32_t fit_blocks = static_cast<uint32_t>(div_up(a.j_end - a.j_begin, kFitBlock));
+    if (fit_blocks > 0 && n < (int64_t(1) << 30))
+      hipLaunchKernelGGL(k_mls_fit<true>, dim3(fit_blocks), dim3(kFitBlock), 0, ctx->stream, a);
+    else if (fit_blocks > 0)
+      hipLaunchKernelGGL(k_mls_fit<false>, dim3(fit_blocks), dim3(kFitBlock), 0, ctx->stream, a);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   if (p->upsampling == 3 && stream_capacity > 0) {
@@ -2168,16 +2174,18 @@ static int mls_run(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *
 
 // StatisticalOutlierRemoval on a cloud view: keep flags in ctx->m_flag (view order)
 // view_order: distances and keep flags under the view's own indices (ctx->m_flag[view index]) instead of the caller's
-// Index shards (pcp_sor_partial / pcp_sor_finish): q_begin <= index < q_end are this GPU's queries (bounds on chunk
-// boundaries, see k_sor_stats); `classify` false stops after the chunk sums (they sit in ctx->m_sums from double 4 on).
-static int sor_classify(pcp_context *ctx, int64_t n, double std_mul, int64_t q_begin, int64_t q_end);
+// Slabs (pcp_sor_partial / pcp_sor_finish): the places [chunk c0, chunk c1) of the cell order are this GPU's queries (see
+// k_sor_stats); `classify` false stops after the chunk sums (they sit in ctx->m_sums from double 4 on).
+static int sor_classify(pcp_context *ctx, int64_t n, const int32_t *remap, double std_mul, int64_t j_begin, int64_t j_end);
 static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double std_mul, bool view_order = false,
-                   int64_t q_begin = 0, int64_t q_end = -1, bool classify = true) {
+                   int32_t slab = 0, int32_t n_slabs = 1, bool classify = true) {
   const int32_t *remap = view_order ? nullptr : cv.remap;
   const int64_t n = cv.n;
   if (n == 0) return PCP_OK;
-  if (q_end < 0) q_end = n;
-  const bool whole = q_begin == 0 && q_end == n;
+  const int64_t n_chunks = div_up(n, kSorChunk);
+  const int64_t c0 = n_chunks * slab / n_slabs, c1 = n_chunks * (slab + 1) / n_slabs;
+  const int64_t q_begin = c0 * kSorChunk, q_end = std::min<int64_t>(c1 * kSorChunk, n);  // places of the cell order
+  const bool whole = n_slabs == 1;
   const size_t sn = static_cast<size_t>(n);
   const size_t plane = (sn + 3) & ~size_t(3);
   // cell edge: first a volume-based guess, then refined from the number of occupied cells so that
@@ -2234,13 +2242,14 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
   // the selection kernel addresses the coordinate planes through buffer descriptors (32-bit byte offsets)
   const bool use_select = (!(heap_only && heap_only[0] == '1') || !whole) && n < (int64_t(1) << 30);
   if (!whole && !(use_select && mean_k + 1 <= 250))
-    return set_error(ctx, PCP_ERR_INVALID, "pcp_sor_partial: index shards need mean_k <= 249 and fewer than 2^30 points");
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_sor_partial: slabs need mean_k <= 249 and fewer than 2^30 points");
   if (use_select && mean_k + 1 <= 250) {
     // selection kernel for every point, heap kernel for the few it flags (sparse spots, borders of a surface)
     PCP_HIP_TRY(ctx, ctx->s_cell.ensure(sn + 8));
-    {
+    if (!whole) PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->m_flag.p, 0, sn, ctx->stream));  // nothing to redo outside the slab
+    if (q_end > q_begin) {
       LaunchTimer t(ctx, PCP_K_SOR);
-      hipLaunchKernelGGL(k_sor_select, dim3(static_cast<uint32_t>(div_up(n, kSelWave))), dim3(kSelWave), 0, ctx->stream,
+      hipLaunchKernelGGL(k_sor_select, dim3(static_cast<uint32_t>(div_up(q_end - q_begin, kSelWave))), dim3(kSelWave), 0, ctx->stream,
                          ctx->g_xyz.p, ctx->g_xyz.p + plane, ctx->g_xyz.p + 2 * plane, ctx->g_order.p, remap,
                          ctx->g_start.p, n, g, mean_k, dist, ctx->m_flag.p, q_begin, q_end);
       PCP_HIP_TRY(ctx, hipGetLastError());
@@ -2274,25 +2283,26 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   {
-    // the chunks of this GPU's index range
+    // the chunks of this GPU's slab
     LaunchTimer t(ctx, PCP_K_SOR);
-    const int64_t c0 = q_begin / kSorChunk, c1 = div_up(q_end, kSorChunk);
     if (c1 > c0)
-      hipLaunchKernelGGL(k_sor_stats, dim3(static_cast<uint32_t>(c1 - c0)), dim3(kMB), 0, ctx->stream, dist, n, c0,
-                         ctx->m_sums.p + 4);
+      hipLaunchKernelGGL(k_sor_stats, dim3(static_cast<uint32_t>(c1 - c0)), dim3(kMB), 0, ctx->stream, dist, ctx->g_order.p,
+                         remap, n, c0, ctx->m_sums.p + 4);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
-  return classify ? sor_classify(ctx, n, std_mul, q_begin, q_end) : PCP_OK;
+  return classify ? sor_classify(ctx, n, remap, std_mul, q_begin, q_end) : PCP_OK;
 }
 
-// threshold from the chunk sums of the WHOLE cloud (ctx->m_sums), keep flags of the indices [q_begin, q_end)
-static int sor_classify(pcp_context *ctx, int64_t n, double std_mul, int64_t q_begin, int64_t q_end) {
+// threshold from the chunk sums of the WHOLE cloud (ctx->m_sums), keep flags (ctx->m_flag, zero elsewhere) of the points
+// at places [j_begin, j_end) of the cell order (ctx->g_order: the grid of the sor_run that left the distances)
+static int sor_classify(pcp_context *ctx, int64_t n, const int32_t *remap, double std_mul, int64_t j_begin, int64_t j_end) {
   LaunchTimer t(ctx, PCP_K_SOR);
   double *partial = ctx->m_sums.p + 4, *threshold = ctx->m_sums.p;
   hipLaunchKernelGGL(k_sor_threshold, dim3(1), dim3(64), 0, ctx->stream, partial, div_up(n, kSorChunk), n, std_mul, threshold);
-  if (q_end > q_begin)
-    hipLaunchKernelGGL(k_sor_classify, dim3(blocks_of(q_end - q_begin)), dim3(kMB), 0, ctx->stream, ctx->s_dist.p, q_begin, q_end,
-                       threshold, ctx->m_flag.p);
+  if (j_begin > 0 || j_end < n) PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->m_flag.p, 0, static_cast<size_t>(n), ctx->stream));
+  if (j_end > j_begin)
+    hipLaunchKernelGGL(k_sor_classify, dim3(blocks_of(j_end - j_begin)), dim3(kMB), 0, ctx->stream, ctx->s_dist.p, ctx->g_order.p,
+                       remap, j_begin, j_end, threshold, ctx->m_flag.p);
   PCP_HIP_TRY(ctx, hipGetLastError());
   return PCP_OK;
 }
@@ -2412,6 +2422,19 @@ int pcp_mls_process_shard(pcp_context *ctx, const pcp_mls_params *p, int64_t ind
   return mls_run(ctx, uploaded_view(ctx), p, out_count, index_begin, index_end);
 }
 
+int pcp_mls_process_slab(pcp_context *ctx, const pcp_mls_params *p, int32_t slab, int32_t n_slabs, int64_t *out_count) {
+  if (!ctx) return PCP_ERR_INVALID;
+  int rc = check_mls_params(ctx, p);
+  if (rc != PCP_OK) return rc;
+  if (!ctx->xyz.p) return set_error(ctx, PCP_ERR_STATE, "pcp_mls_process_slab: no cloud uploaded");
+  if (int rcf = require_finite_cloud(ctx, "pcp_mls_process_slab")) return rcf;
+  if (p->upsampling != 0)
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_mls_process_slab: query sharding supports upsampling NONE only");
+  if (n_slabs < 1 || slab < 0 || slab >= n_slabs) return set_error(ctx, PCP_ERR_RANGE, "pcp_mls_process_slab: slab %d of %d", slab, n_slabs);
+  PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return mls_run(ctx, uploaded_view(ctx), p, out_count, 0, -1, false, 0, slab, n_slabs);
+}
+
 int pcp_mls_fetch(pcp_context *ctx, int64_t capacity, float *out_xyz, float *out_normal, float *out_curvature,
                   int32_t *out_index) {
   if (!ctx) return PCP_ERR_INVALID;
@@ -2440,7 +2463,7 @@ int pcp_sor(pcp_context *ctx, int32_t mean_k, double std_mul, uint8_t *out_keep,
   if (out_kept) *out_kept = 0;
   if (n == 0) return PCP_OK;
   ctx->sor_distances_live = false;
-  ctx->sor_partial_begin = ctx->sor_partial_end = -1;
+  ctx->sor_partial_slab = ctx->sor_partial_slabs = -1;
   int rc = sor_run(ctx, uploaded_view(ctx), mean_k, std_mul);
   if (rc != PCP_OK) return rc;
   ctx->sor_distances_live = true;
@@ -2457,66 +2480,67 @@ int pcp_sor(pcp_context *ctx, int32_t mean_k, double std_mul, uint8_t *out_keep,
 
 int64_t pcp_sor_chunk_points(void) { return kSorChunk; }
 
-static int check_sor_shard(pcp_context *ctx, const char *who, int64_t index_begin, int64_t index_end) {
+static int check_sor_slab(pcp_context *ctx, const char *who, int32_t slab, int32_t n_slabs) {
   if (!ctx->xyz.p) return set_error(ctx, PCP_ERR_STATE, "%s: no cloud uploaded", who);
-  const int64_t n = ctx->n;
-  if (index_begin < 0 || index_end < index_begin || index_end > n)
-    return set_error(ctx, PCP_ERR_RANGE, "%s: index range [%lld, %lld) outside the %lld uploaded points", who, (long long)index_begin, (long long)index_end, (long long)n);
-  if (index_begin % kSorChunk != 0 || (index_end % kSorChunk != 0 && index_end != n))
-    return set_error(ctx, PCP_ERR_INVALID, "%s: shard bounds must be multiples of pcp_sor_chunk_points() = %lld (or the point count)", who, (long long)kSorChunk);
+  if (n_slabs < 1 || slab < 0 || slab >= n_slabs)
+    return set_error(ctx, PCP_ERR_RANGE, "%s: slab %d of %d", who, slab, n_slabs);
   return PCP_OK;
 }
 
-int pcp_sor_partial(pcp_context *ctx, int32_t mean_k, int64_t index_begin, int64_t index_end, int64_t capacity,
-                    double *out_chunk_sums) {
+int pcp_sor_partial(pcp_context *ctx, int32_t mean_k, int32_t slab, int32_t n_slabs, int64_t capacity, double *out_chunk_sums,
+                    int64_t *out_first_chunk, int64_t *out_chunks) {
   if (!ctx) return PCP_ERR_INVALID;
-  int rc = check_sor_shard(ctx, "pcp_sor_partial", index_begin, index_end);
+  int rc = check_sor_slab(ctx, "pcp_sor_partial", slab, n_slabs);
   if (rc != PCP_OK) return rc;
   if (int rcf = require_finite_cloud(ctx, "pcp_sor_partial")) return rcf;
   if (mean_k < 1 || mean_k > 249) return set_error(ctx, PCP_ERR_INVALID, "pcp_sor_partial: mean_k %d out of range (1..249)", mean_k);
-  const int64_t c0 = index_begin / kSorChunk, c1 = div_up(index_end, kSorChunk);
+  const int64_t n = ctx->n, n_chunks = div_up(n, kSorChunk);
+  const int64_t c0 = n_chunks * slab / n_slabs, c1 = n_chunks * (slab + 1) / n_slabs;
+  if (out_first_chunk) *out_first_chunk = c0;
+  if (out_chunks) *out_chunks = c1 - c0;
   if (capacity < c1 - c0 || (c1 > c0 && !out_chunk_sums))
-    return set_error(ctx, PCP_ERR_RANGE, "pcp_sor_partial: room for %lld chunks, the range has %lld", (long long)capacity, (long long)(c1 - c0));
+    return set_error(ctx, PCP_ERR_RANGE, "pcp_sor_partial: room for %lld chunks, the slab has %lld", (long long)capacity, (long long)(c1 - c0));
   PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
   ctx->sor_distances_live = false;
-  ctx->sor_partial_begin = ctx->sor_partial_end = -1;
-  if (index_end == index_begin) return PCP_OK;
-  if ((rc = sor_run(ctx, uploaded_view(ctx), mean_k, 0.0, false, index_begin, index_end, /*classify=*/false)) != PCP_OK) return rc;
-  ctx->sor_partial_begin = index_begin;
-  ctx->sor_partial_end = index_end;
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(out_chunk_sums, ctx->m_sums.p + 4 + 2 * c0, static_cast<size_t>(c1 - c0) * 2 * sizeof(double),
-                                  hipMemcpyDeviceToHost, ctx->stream));
+  ctx->sor_partial_slab = ctx->sor_partial_slabs = -1;
+  if (n == 0) return PCP_OK;
+  // (a slab without chunks still builds the grid: pcp_sor_finish reads the cell order from it)
+  if ((rc = sor_run(ctx, uploaded_view(ctx), mean_k, 0.0, false, slab, n_slabs, /*classify=*/false)) != PCP_OK) return rc;
+  if (c1 > c0)
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(out_chunk_sums, ctx->m_sums.p + 4 + 2 * c0, static_cast<size_t>(c1 - c0) * 2 * sizeof(double),
+                                    hipMemcpyDeviceToHost, ctx->stream));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->sor_partial_slab = slab;
+  ctx->sor_partial_slabs = n_slabs;
   return PCP_OK;
 }
 
-int pcp_sor_finish(pcp_context *ctx, double std_mul, const double *all_chunk_sums, int64_t n_chunks, int64_t index_begin,
-                   int64_t index_end, uint8_t *out_keep, int64_t *out_kept) {
+int pcp_sor_finish(pcp_context *ctx, double std_mul, const double *all_chunk_sums, int64_t n_chunks, int32_t slab, int32_t n_slabs,
+                   uint8_t *out_keep, int64_t *out_kept) {
   if (!ctx) return PCP_ERR_INVALID;
-  int rc = check_sor_shard(ctx, "pcp_sor_finish", index_begin, index_end);
+  int rc = check_sor_slab(ctx, "pcp_sor_finish", slab, n_slabs);
   if (rc != PCP_OK) return rc;
   const int64_t n = ctx->n;
   if (out_kept) *out_kept = 0;
   if (n == 0) return PCP_OK;
   if (n_chunks != div_up(n, kSorChunk) || !all_chunk_sums)
     return set_error(ctx, PCP_ERR_INVALID, "pcp_sor_finish: %lld chunk sums given, the cloud has %lld chunks", (long long)n_chunks, (long long)div_up(n, kSorChunk));
-  if (index_end == index_begin) return PCP_OK;  // a GPU without queries (fewer chunks than GPUs)
-  if (!ctx->s_dist.p || !ctx->m_sums.p || ctx->m_sums.count < 4 + 2 * static_cast<size_t>(n_chunks) ||
-      index_begin < ctx->sor_partial_begin || index_end > ctx->sor_partial_end)
-    return set_error(ctx, PCP_ERR_STATE, "pcp_sor_finish: the range [%lld, %lld) was not covered by the last pcp_sor_partial of this context",
-                     (long long)index_begin, (long long)index_end);
+  if (!ctx->s_dist.p || !ctx->m_sums.p || ctx->m_sums.count < 4 + 2 * static_cast<size_t>(n_chunks) || slab != ctx->sor_partial_slab ||
+      n_slabs != ctx->sor_partial_slabs)
+    return set_error(ctx, PCP_ERR_STATE, "pcp_sor_finish: slab %d of %d is not the slab of the last pcp_sor_partial of this context", slab, n_slabs);
   PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
   PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->m_sums.p + 4, all_chunk_sums, static_cast<size_t>(n_chunks) * 2 * sizeof(double),
                                   hipMemcpyHostToDevice, ctx->stream));
-  if ((rc = sor_classify(ctx, n, std_mul, index_begin, index_end)) != PCP_OK) return rc;
-  const int64_t m = index_end - index_begin;
-  if (out_kept && m > 0) {
+  const int64_t c0 = n_chunks * slab / n_slabs, c1 = n_chunks * (slab + 1) / n_slabs;
+  const int64_t j0 = c0 * kSorChunk, j1 = std::min<int64_t>(c1 * kSorChunk, n);
+  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->m_flag.p, 0, static_cast<size_t>(n), ctx->stream));
+  if ((rc = sor_classify(ctx, n, uploaded_view(ctx).remap, std_mul, j0, j1)) != PCP_OK) return rc;
+  if (out_kept) {
     int64_t kept = 0;
-    if ((rc = compact_flags(ctx, ctx->m_flag.p + index_begin, m, nullptr, 0, &kept)) != PCP_OK) return rc;
+    if ((rc = compact_flags(ctx, ctx->m_flag.p, n, nullptr, 0, &kept)) != PCP_OK) return rc;
     *out_kept = kept;
   }
-  if (out_keep && m > 0)
-    PCP_HIP_TRY(ctx, hipMemcpyAsync(out_keep, ctx->m_flag.p + index_begin, static_cast<size_t>(m), hipMemcpyDeviceToHost, ctx->stream));
+  if (out_keep) PCP_HIP_TRY(ctx, hipMemcpyAsync(out_keep, ctx->m_flag.p, static_cast<size_t>(n), hipMemcpyDeviceToHost, ctx->stream));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return PCP_OK;
 }
@@ -2535,7 +2559,7 @@ int pcp_cloud_smooth(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_cou
   PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
   ctx->mls_count = 0;
   ctx->sor_distances_live = false;
-  ctx->sor_partial_begin = ctx->sor_partial_end = -1;
+  ctx->sor_partial_slab = ctx->sor_partial_slabs = -1;
   if (out_count) *out_count = 0;
   const CloudView cv0 = uploaded_view(ctx);
   if (cv0.n == 0) return PCP_OK;

@@ -479,11 +479,46 @@ class MultiCloudSmooth {
                             s.index.data() + at));
     };
     if (params_.upsampling == 0) {
+      // queries by slabs of the stage's own spatial order (1 / N of the work whatever order the points come in); every
+      // slab's rows arrive in input order, a point is fitted by exactly one slab: an N-way merge by source index
       std::vector<int64_t> counts(static_cast<size_t>(size()));
       for (int r = 0; r < size(); ++r)  // queued on every GPU before the first fetch waits
-        dev_[static_cast<size_t>(r)]->check(pcp_mls_process_shard(dev_[static_cast<size_t>(r)]->get(), &params_, m1 * r / size(),
-                                                                  m1 * (r + 1) / size(), &counts[static_cast<size_t>(r)]));
-      for (int r = 0; r < size(); ++r) append(*dev_[static_cast<size_t>(r)], counts[static_cast<size_t>(r)]);
+        dev_[static_cast<size_t>(r)]->check(pcp_mls_process_slab(dev_[static_cast<size_t>(r)]->get(), &params_, r, size(), &counts[static_cast<size_t>(r)]));
+      std::vector<SmoothedCloud> part(static_cast<size_t>(size()));
+      size_t total = 0;
+      for (int r = 0; r < size(); ++r) {
+        SmoothedCloud &q = part[static_cast<size_t>(r)];
+        const size_t c = static_cast<size_t>(counts[static_cast<size_t>(r)]);
+        q.xyz.resize(3 * c);
+        q.normal.resize(3 * c);
+        q.curvature.resize(c);
+        q.index.resize(c);
+        dev_[static_cast<size_t>(r)]->check(pcp_mls_fetch(dev_[static_cast<size_t>(r)]->get(), counts[static_cast<size_t>(r)], q.xyz.data(),
+                                                          q.normal.data(), q.curvature.data(), q.index.data()));
+        total += c;
+      }
+      s.xyz.resize(3 * total);
+      s.normal.resize(3 * total);
+      s.curvature.resize(total);
+      s.index.resize(total);
+      std::vector<size_t> head(static_cast<size_t>(size()), 0);
+      for (size_t k = 0; k < total; ++k) {
+        int best = -1;
+        for (int r = 0; r < size(); ++r) {
+          const SmoothedCloud &q = part[static_cast<size_t>(r)];
+          if (head[static_cast<size_t>(r)] < q.index.size() &&
+              (best < 0 || q.index[head[static_cast<size_t>(r)]] < part[static_cast<size_t>(best)].index[head[static_cast<size_t>(best)]]))
+            best = r;
+        }
+        const SmoothedCloud &q = part[static_cast<size_t>(best)];
+        const size_t h = head[static_cast<size_t>(best)]++;
+        for (int c = 0; c < 3; ++c) {
+          s.xyz[3 * k + static_cast<size_t>(c)] = q.xyz[3 * h + static_cast<size_t>(c)];
+          s.normal[3 * k + static_cast<size_t>(c)] = q.normal[3 * h + static_cast<size_t>(c)];
+        }
+        s.curvature[k] = q.curvature[h];
+        s.index[k] = q.index[h];
+      }
     } else {
       int32_t chunks = 0;
       for (auto &d : dev_) {  // the same plan on every GPU (same cloud, same capacity)
@@ -529,24 +564,23 @@ class MultiCloudSmooth {
 
  private:
   // pcl::StatisticalOutlierRemoval over all GPUs (cloudSmooth.cpp:109-116,160-164): the cloud on every GPU, the queries
-  // dealt out by index on chunk boundaries (pcp_sor_partial), the chunk sums of the shards put together in index order --
-  // the array one GPU computes, so the threshold is the one-GPU threshold bit for bit -- and every GPU classifies its own
-  // range (pcp_sor_finish).  The exchange is ceil(n / 16384) pairs of doubles through the host (10 KB at 10 M points); the
-  // calls synchronise with the host, hence one host thread per GPU.  Returns the indices kept, ascending.
+  // dealt out by slabs of the filter's own spatial order (pcp_sor_partial: whole wavefronts, whole statistic chunks), the
+  // chunk sums of the slabs put together -- the array one GPU computes, so the threshold is the one-GPU threshold bit for
+  // bit -- and every GPU classifies its own slab (pcp_sor_finish: flags under the caller's indices, zero for the other
+  // slabs' points).  The exchange is ceil(n / 16384) pairs of doubles and the flags, through the host; the calls
+  // synchronise with the host, hence one host thread per GPU.  Returns the indices kept, ascending.
   std::vector<int32_t> outlierRemoval(const float *x, const float *y, const float *z, int64_t n) {
     const int N = size();
     const int64_t chunk = pcp_sor_chunk_points(), chunks = (n + chunk - 1) / chunk;
-    std::vector<int64_t> bound(static_cast<size_t>(N) + 1, n);
-    for (int r = 0; r < N; ++r) bound[static_cast<size_t>(r)] = std::min<int64_t>(n, (chunks * r / N) * chunk);
-    std::vector<double> sums(static_cast<size_t>(2 * chunks));
-    std::vector<uint8_t> keep(static_cast<size_t>(n));
+    std::vector<double> sums(static_cast<size_t>(2 * std::max<int64_t>(chunks, 1)));
+    std::vector<std::vector<uint8_t>> keep(static_cast<size_t>(N), std::vector<uint8_t>(static_cast<size_t>(n)));
     std::vector<std::string> failure(static_cast<size_t>(N));
     auto on_every_gpu = [&](auto &&body) {
       std::vector<std::thread> th;
       for (int r = 0; r < N; ++r)
         th.emplace_back([&, r] {
           try {
-            body(r, *dev_[static_cast<size_t>(r)], bound[static_cast<size_t>(r)], bound[static_cast<size_t>(r) + 1]);
+            body(r, *dev_[static_cast<size_t>(r)]);
           } catch (const std::exception &e) {
             failure[static_cast<size_t>(r)] = e.what();
           }
@@ -555,16 +589,22 @@ class MultiCloudSmooth {
       for (const auto &f : failure)
         if (!f.empty()) throw std::runtime_error(f);
     };
-    on_every_gpu([&](int, Device &d, int64_t b, int64_t e) {
+    on_every_gpu([&](int r, Device &d) {
       d.uploadCloud(x, y, z, n);
-      d.check(pcp_sor_partial(d.get(), params_.sor_mean_k, b, e, (e + chunk - 1) / chunk - b / chunk, sums.data() + 2 * (b / chunk)));
+      std::vector<double> mine(static_cast<size_t>(2 * std::max<int64_t>(chunks, 1)));
+      int64_t first = 0, cnt = 0;
+      d.check(pcp_sor_partial(d.get(), params_.sor_mean_k, r, N, chunks, mine.data(), &first, &cnt));
+      std::copy(mine.begin(), mine.begin() + 2 * cnt, sums.begin() + 2 * first);  // disjoint ranges: no lock
     });
-    on_every_gpu([&](int, Device &d, int64_t b, int64_t e) {
-      d.check(pcp_sor_finish(d.get(), params_.sor_std_mul, sums.data(), chunks, b, e, keep.data() + b, nullptr));
+    on_every_gpu([&](int r, Device &d) {
+      d.check(pcp_sor_finish(d.get(), params_.sor_std_mul, sums.data(), chunks, r, N, keep[static_cast<size_t>(r)].data(), nullptr));
     });
     std::vector<int32_t> idx;
-    for (int64_t i = 0; i < n; ++i)
-      if (keep[static_cast<size_t>(i)]) idx.push_back(static_cast<int32_t>(i));
+    for (int64_t i = 0; i < n; ++i) {
+      uint8_t k = 0;
+      for (int r = 0; r < N; ++r) k |= keep[static_cast<size_t>(r)][static_cast<size_t>(i)];
+      if (k) idx.push_back(static_cast<int32_t>(i));
+    }
     return idx;
   }
 

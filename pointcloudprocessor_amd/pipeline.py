@@ -259,12 +259,12 @@ class CloudSmooth:
         self.params = params if params is not None else capi.default_mls_params()
 
     def process_sharded(self, n_total: int, rank: int, world: int, group=None):
-        """MLS (upsampling NONE) with the queries sharded by index over `world` ranks: every rank
-        holds the whole cloud, fits its own index range, and the variable-length results are
-        all-gathered.  Returns the full result on every rank."""
-        lo, hi = shard_bounds(n_total, rank, world)
+        """MLS (upsampling NONE) with the queries dealt out over `world` ranks by slabs of the stage's own spatial order
+        (whole wavefronts: 1 / world of the work whatever order the caller's points come in): every rank holds the whole
+        cloud, fits its slab, the variable-length results are all-gathered and merged by source index.
+        Returns the full result, in input order, on every rank."""
         ctx = self.engine.ctx
-        local = ctx.mls_fetch(ctx.mls_process_shard(self.params, lo, hi))
+        local = ctx.mls_fetch(ctx.mls_process_slab(self.params, rank, world))
         if world == 1:
             return local
         import torch
@@ -287,22 +287,22 @@ class CloudSmooth:
         dist.all_gather(outs, mine, group=group)
         parts = [outs[r].cpu().numpy()[: counts[r]] for r in range(world)]
         allp = np.concatenate(parts, axis=0) if parts else np.zeros((0, 8), np.float32)
+        idx = np.ascontiguousarray(allp[:, 7]).view(np.int32)
+        allp = allp[np.argsort(idx, kind="stable")]  # a point is fitted by exactly one slab: the merge restores input order
         return dict(xyz=np.ascontiguousarray(allp[:, 0:3]), normal=np.ascontiguousarray(allp[:, 3:6]),
                     curvature=np.ascontiguousarray(allp[:, 6]), index=np.ascontiguousarray(allp[:, 7]).view(np.int32))
 
     def outlier_removal_sharded(self, n_total: int, rank: int, world: int, group=None):
-        """StatisticalOutlierRemoval (cloudSmooth.cpp:109-116) with the queries dealt out by index on chunk boundaries:
-        every rank holds the whole cloud, computes the mean distances and per-chunk (sum, sum of squares) of its own
-        range, the chunk sums are all-gathered (ceil(n / 16384) pairs of doubles), every rank classifies its range and
-        the keep flags are all-gathered.  Equal to ctx.sor() on one GPU bit for bit.  Returns the full keep mask."""
+        """StatisticalOutlierRemoval (cloudSmooth.cpp:109-116) with the queries dealt out by slabs of the filter's own spatial
+        order: every rank holds the whole cloud, computes the mean distances and per-chunk (sum, sum of squares) of its
+        slab, the chunk sums are put together (ceil(n / 16384) pairs of doubles), every rank classifies its slab and the
+        keep flags are combined.  Equal to ctx.sor() on one GPU bit for bit.  Returns the full keep mask."""
         ctx = self.engine.ctx
         c = ctx.sor_chunk_points()
         chunks = (n_total + c - 1) // c
-        bounds = [min(n_total, (chunks * r // world) * c) for r in range(world)] + [n_total]
-        lo, hi = bounds[rank], bounds[rank + 1]
         sums = np.zeros((chunks, 2), np.float64)
-        sums[lo // c:(hi + c - 1) // c] = ctx.sor_partial(self.params.sor_mean_k, lo, hi)
-        keep = np.zeros(n_total, np.uint8)
+        first, mine = ctx.sor_partial(self.params.sor_mean_k, rank, world)
+        sums[first:first + len(mine)] = mine
         if world > 1:
             import torch
             import torch.distributed as dist
@@ -312,7 +312,7 @@ class CloudSmooth:
             t = torch.from_numpy(sums).to(dev)
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
             sums = t.cpu().numpy()
-        keep[lo:hi] = ctx.sor_finish(self.params.sor_std_mul, sums, lo, hi)[0]
+        keep = ctx.sor_finish(self.params.sor_std_mul, sums, rank, world)[0]
         if world > 1:
             t = torch.from_numpy(keep).to(dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)

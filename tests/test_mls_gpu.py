@@ -259,6 +259,32 @@ def test_mls_query_shards_concatenate_to_the_full_result(gpu_ctx_factory):
         ctx.mls_process_shard(mp, 10, 5)
 
 
+@pytest.mark.parametrize("slabs", [2, 3, 7])
+def test_mls_query_slabs_merge_to_the_full_result(gpu_ctx_factory, slabs):
+    """Multi-GPU form by slabs of the stage's own spatial order (pcp_mls_process_slab): every point is fitted by exactly one
+    slab, the slabs' rows merged by source index are the unsharded result, bit for bit -- on a shuffled cloud too."""
+    from pointcloudprocessor_amd import capi
+
+    x, y, z = _patches(seed=11, n=3000)
+    perm = np.random.default_rng(2).permutation(len(x))
+    x, y, z = x[perm].copy(), y[perm].copy(), z[perm].copy()
+    ctx = gpu_ctx_factory()
+    ctx.upload_cloud(x, y, z)
+    mp = capi.default_mls_params()
+    mp.upsampling = 0
+    full = ctx.mls_fetch(ctx.mls_process(mp))
+    parts = [ctx.mls_fetch(ctx.mls_process_slab(mp, r, slabs)) for r in range(slabs)]
+    for q in parts:
+        assert np.all(np.diff(q["index"]) > 0)  # each slab's rows in input order
+    idx = np.concatenate([q["index"] for q in parts])
+    assert len(np.unique(idx)) == len(idx) == len(full["index"])
+    order = np.argsort(idx, kind="stable")
+    for k in ("index", "xyz", "normal", "curvature"):
+        assert np.array_equal(np.concatenate([q[k] for q in parts])[order], full[k]), k
+    with pytest.raises(capi.PcpError):
+        ctx.mls_process_slab(mp, 3, 3)
+
+
 def test_voxel_dilation_stream_equals_one_shot(gpu_ctx_factory):
     """pcp_mls_stream_begin / _next: the dilated voxel set counted in 64 bits and emitted in ascending key order chunk by
     chunk -- the concatenation is the one-shot result, bit for bit, whatever the chunk size."""

@@ -85,20 +85,25 @@ class OracleEngine:
 
 
 class OracleMlsCtx:
-    """mls_process_shard / mls_fetch of capi.Context, computed with the C oracle."""
+    """mls_process_slab / mls_fetch of capi.Context, computed with the C oracle."""
 
     def __init__(self, x, y, z):
         self.xyz = (x, y, z)
         self.last = None
 
-    def mls_process_shard(self, params, lo, hi):
+    def mls_process_slab(self, params, slab, n_slabs):
+        """a slab of a spatial order of the queries (here: sorted by x): every point belongs to exactly one slab"""
         from oracle import oracle_capi as oc
 
         op = oc.default_mls_params()
         op.upsampling = 0
         op.threads = 2
         r = oc.mls(*self.xyz, op)
-        sel = (r["index"] >= lo) & (r["index"] < hi)
+        n = len(self.xyz[0])
+        place = np.empty(n, np.int64)
+        place[np.argsort(self.xyz[0], kind="stable")] = np.arange(n)
+        lo, hi = n * slab // n_slabs, n * (slab + 1) // n_slabs
+        sel = (place[r["index"]] >= lo) & (place[r["index"]] < hi)
         self.last = {k: v[sel] for k, v in r.items()}
         return int(sel.sum())
 
@@ -113,8 +118,8 @@ class OracleMlsEngine:
 
 class OracleSorCtx:
     """sor_chunk_points / sor_partial / sor_finish of capi.Context on the C oracle's mean distances: the protocol of
-    pcp_sor_partial / pcp_sor_finish (per-chunk sums in a fixed order, threshold from the concatenated array), with a small
-    chunk so that two ranks own several chunks each."""
+    pcp_sor_partial / pcp_sor_finish (slabs of a spatial order -- here: sorted by x --, per-chunk sums in a fixed order,
+    threshold from the array put together), with a small chunk so that two ranks own several chunks each."""
 
     CHUNK = 256
 
@@ -124,6 +129,7 @@ class OracleSorCtx:
         _, _, self.dist, _ = oc.sor(x, y, z, mean_k, 1.0, threads=2, details=True)
         self.dist = self.dist.astype(np.float32)
         self.n = len(x)
+        self.order = np.argsort(x, kind="stable")  # place -> index
 
     def sor_chunk_points(self):
         return self.CHUNK
@@ -134,19 +140,28 @@ class OracleSorCtx:
         sq = (d32 * d32).astype(np.float64)  # fp32 squares, as the reference
         return np.array([np.sum(d32.astype(np.float64)), np.sum(sq)])
 
-    def sor_partial(self, mean_k, lo, hi):
-        c = self.CHUNK
-        assert lo % c == 0 and (hi % c == 0 or hi == self.n)
-        return np.array([self.chunk_sums(self.dist[b:min(b + c, hi)]) for b in range(lo, hi, c)]).reshape(-1, 2)
+    def _slab(self, slab, n_slabs):
+        chunks = (self.n + self.CHUNK - 1) // self.CHUNK
+        c0, c1 = chunks * slab // n_slabs, chunks * (slab + 1) // n_slabs
+        return c0, c1
 
-    def sor_finish(self, std_mul, sums, lo, hi):
+    def sor_partial(self, mean_k, slab, n_slabs):
+        c0, c1 = self._slab(slab, n_slabs)
+        c = self.CHUNK
+        sums = [self.chunk_sums(self.dist[self.order[k * c:min((k + 1) * c, self.n)]]) for k in range(c0, c1)]
+        return c0, np.array(sums).reshape(-1, 2)
+
+    def sor_finish(self, std_mul, sums, slab, n_slabs):
         assert len(sums) == (self.n + self.CHUNK - 1) // self.CHUNK
         s, q = 0.0, 0.0
         for a, b in np.asarray(sums, np.float64):  # fixed order
             s, q = s + a, q + b
         n = float(self.n)
         thr = s / n + std_mul * np.sqrt((q - s * s / n) / (n - 1.0))
-        keep = (~(self.dist[lo:hi].astype(np.float64) > thr)).astype(np.uint8)
+        c0, c1 = self._slab(slab, n_slabs)
+        mine = self.order[c0 * self.CHUNK:min(c1 * self.CHUNK, self.n)]
+        keep = np.zeros(self.n, np.uint8)
+        keep[mine] = ~(self.dist[mine].astype(np.float64) > thr)
         return keep, int(keep.sum())
 
 
@@ -284,7 +299,7 @@ def test_two_rank_gloo_equals_single_process(tmp_path, oracle):
 
 @pytest.mark.timeout(300)
 def test_two_rank_outlier_removal_sharding(tmp_path, oracle):
-    """StatisticalOutlierRemoval with the queries dealt out by index on chunk boundaries over 2 gloo ranks
+    """StatisticalOutlierRemoval with the queries dealt out by slabs of a spatial order over 2 gloo ranks
     (pipeline.CloudSmooth.outlier_removal_sharded: all-reduce of the chunk sums, every rank classifies its range, all-reduce of
     the flags): the keep mask equals the one-process filter on every rank."""
     import torch.multiprocessing as mp
@@ -293,8 +308,8 @@ def test_two_rank_outlier_removal_sharding(tmp_path, oracle):
     mp.spawn(_sor_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     x, y, z = _mls_points()
     ctx = OracleSorCtx(x, y, z, 12)
-    sums = ctx.sor_partial(12, 0, len(x))
-    ref, kept = ctx.sor_finish(0.7, sums, 0, len(x))
+    _, sums = ctx.sor_partial(12, 0, 1)
+    ref, kept = ctx.sor_finish(0.7, sums, 0, 1)
     keep_o, kept_o = oracle.sor(x, y, z, 12, 0.7, threads=2)[:2]
     assert 0 < kept < len(x) and abs(kept - kept_o) <= 2  # the chunked sums against PCL's running sums: a borderline point at most
     for r in range(2):
@@ -303,8 +318,8 @@ def test_two_rank_outlier_removal_sharding(tmp_path, oracle):
 
 @pytest.mark.timeout(300)
 def test_two_rank_mls_query_sharding(tmp_path, oracle):
-    """MLS with queries sharded by index over 2 gloo ranks: the all-gathered result equals
-    the single-process result on every rank."""
+    """MLS with queries dealt out by slabs of a spatial order over 2 gloo ranks: the all-gathered result, merged by source
+    index, equals the single-process result on every rank."""
     import torch.multiprocessing as mp
 
     port = _free_port()

@@ -181,34 +181,70 @@ def test_sor_stray_points_far_from_the_cloud(gpu_ctx_factory, oracle):
 
 
 @pytest.mark.parametrize("shards", [2, 3, 5])
-def test_sor_index_shards_equal_the_one_gpu_filter(gpu_ctx_factory, shards):
-    """pcp_sor_partial / pcp_sor_finish (queries dealt out by index, cloudSmooth.cpp:109-116): shards on
-    chunk boundaries, chunk sums concatenated, every shard classifies its own range == pcp_sor bit for bit."""
+@pytest.mark.parametrize("shuffled", [False, True])
+def test_sor_slabs_equal_the_one_gpu_filter(gpu_ctx_factory, shards, shuffled):
+    """pcp_sor_partial / pcp_sor_finish (the queries dealt out, cloudSmooth.cpp:109-116) by slabs of the filter's
+    own spatial order: chunk sums put together, every slab classifies its own points, the OR of the masks == pcp_sor bit for
+    bit -- whether the caller's point order is spatially coherent or shuffled."""
     from pointcloudprocessor_amd import synth
 
     x, y, z, _ = synth.make_cloud(150_000, seed=11)
+    if shuffled:
+        perm = np.random.default_rng(3).permutation(len(x))
+        x, y, z = x[perm].copy(), y[perm].copy(), z[perm].copy()
     n = len(x)
     ref = gpu_ctx_factory()
     ref.upload_cloud(x, y, z)
     keep_ref, kept_ref = ref.sor(60, 0.7)
     c = ref.sor_chunk_points()
     chunks = (n + c - 1) // c
-    bounds = [min(n, (chunks * r // shards) * c) for r in range(shards)] + [n]
-    ctxs = []
-    sums = []
+    ctxs, all_sums, covered = [], np.zeros((chunks, 2)), np.zeros(chunks, bool)
     for r in range(shards):
         ctx = gpu_ctx_factory()
         ctx.upload_cloud(x, y, z)
-        sums.append(ctx.sor_partial(60, bounds[r], bounds[r + 1]))
+        first, sums = ctx.sor_partial(60, r, shards)
+        assert not covered[first:first + len(sums)].any()
+        covered[first:first + len(sums)] = True
+        all_sums[first:first + len(sums)] = sums
         ctxs.append(ctx)
-    all_sums = np.concatenate(sums)
-    assert len(all_sums) == chunks
-    keep = np.concatenate([ctxs[r].sor_finish(0.7, all_sums, bounds[r], bounds[r + 1])[0] for r in range(shards)])
-    assert np.array_equal(keep, keep_ref)
-    assert int(keep.sum()) == kept_ref
-    # misaligned bounds are refused
+    assert covered.all()
+    keep = np.zeros(n, np.uint8)
+    total = 0
+    for r in range(shards):
+        k, kept = ctxs[r].sor_finish(0.7, all_sums, r, shards)
+        assert not (keep & k).any() and kept == int(k.sum())
+        keep |= k
+        total += kept
+    assert np.array_equal(keep, keep_ref) and total == kept_ref
     with pytest.raises(Exception):
-        ctxs[0].sor_partial(60, 100, n)
+        ctxs[0].sor_finish(0.7, all_sums, 1, shards)  # not the slab of this context's last partial
+
+
+def test_sor_slab_is_its_share_of_the_work(gpu_ctx_factory):
+    """A slab of a SHUFFLED cloud costs about its share of the filter (whole wavefronts of the cell order); this is what
+    dealing the queries out by the caller's index ranges could not give."""
+    import time
+
+    from pointcloudprocessor_amd import synth
+
+    x, y, z, _ = synth.make_cloud(8_000_000, seed=4)
+    perm = np.random.default_rng(5).permutation(len(x))
+    x, y, z = x[perm].copy(), y[perm].copy(), z[perm].copy()
+    ctx = gpu_ctx_factory()
+    ctx.upload_cloud(x, y, z)
+    ctx.timing_enable(True)
+
+    def sor_ms(slab, slabs):
+        ctx.sor_partial(60, slab, slabs)
+        ctx.timing_reset()
+        ctx.sor_partial(60, slab, slabs)
+        from pointcloudprocessor_amd import capi
+        return ctx.timing_get(capi.K_SOR)[0]
+
+    whole = sor_ms(0, 1)
+    quarters = [sor_ms(r, 4) for r in range(4)]
+    # equal numbers of points, not equal work (denser places cost more), plus a per-call fixed part
+    assert max(quarters) < 0.45 * whole and sum(quarters) < 1.4 * whole, (whole, quarters)
 
 
 def test_sor_sharded_python_host_single_rank(gpu_ctx_factory):
@@ -228,19 +264,3 @@ def test_sor_sharded_python_host_single_rank(gpu_ctx_factory):
     cs = pipeline.CloudSmooth(eng)
     keep = cs.outlier_removal_sharded(len(x), 0, 1)
     assert np.array_equal(keep, keep_ref)
-
-
-def test_sor_finish_needs_its_range_from_the_last_partial(gpu_ctx_factory):
-    from pointcloudprocessor_amd import capi, synth
-
-    x, y, z, _ = synth.make_cloud(40_000, seed=2)
-    ctx = gpu_ctx_factory()
-    ctx.upload_cloud(x, y, z)
-    c = ctx.sor_chunk_points()
-    sums = ctx.sor_partial(60, 0, len(x))
-    ctx.sor_partial(60, 0, c)  # only the first chunk's distances are current now
-    with pytest.raises(capi.PcpError):
-        ctx.sor_finish(0.7, sums, c, len(x))
-    keep, kept = ctx.sor_finish(0.7, sums, 0, c)
-    ref, _ = ctx.sor(60, 0.7)
-    assert np.array_equal(keep, ref[:c]) and kept == int(ref[:c].sum())
