@@ -582,6 +582,14 @@ def test_cli_cull_hpr_end_to_end(tmp_path, oracle):
     assert p.returncode == 0, p.stderr[-2000:]
     for name, data in one.items():
         assert open(out3 / name, "rb").read() == data, name
+    # ... and with the NID refinement in front (the shards' culls read the imported hull verdicts): runs to completion
+    out4 = tmp_path / "g3nid"
+    out4.mkdir()
+    p = subprocess.run([_exe(), "-p", str(tmp_path / "scans.pcd"), "-o", str(tmp_path / "odo.txt"), "-i", out, "-t", str(out4) + "/",
+                        "--cull", "hpr", "--gpus", "3", "--enableNIDOptimize", "1"], capture_output=True, text=True,
+                       env=dict(os.environ, PCP_MULTI_REHEARSAL="1"))
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert (out4 / "cloudInWorldWithRGB.pcd").read_bytes().count(b"\n") > 20  # header + rows: some points got a colour
     p = subprocess.run([_exe(), "-p", "a", "-o", "b", "-i", "c", "--cull", "qhull"], capture_output=True, text=True)
     assert p.returncode == 254
 
