@@ -2127,6 +2127,20 @@ static int mls_run(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *
       hipLaunchKernelGGL(k_mls_fit<false>, dim3(fit_blocks), dim3(kFitBlock), 0, ctx->stream, a);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
+  if (p->upsampling == 3) {
+    // The emission looks for every dilated voxel's nearest input point inside the box p +- dmax (dmax = the reach of the
+    // dilation, < 9 mm for the reference's 1 mm x 4): the fit's own grid (3 cm cells) makes that ~85 candidates per voxel,
+    // a grid with cells of 2 dmax ~25 -- the fit is done (its results sit under the input indices), so the cell tables are
+    // rebuilt for the emission.  PCP_VGD_GRID=fit keeps the fit's grid (results identical).
+    const char *ge = std::getenv("PCP_VGD_GRID");
+    if (!(ge && ge[0] == 'f')) {
+      const float dmax = static_cast<float>(1.7321 * (p->vgd_iterations + 1) * static_cast<double>(p->vgd_voxel_size) * 1.01 + 1e-6);
+      const float cell_emit = 2.0f * dmax;  // measured at C3: 439 ms of emission (1.5 dmax: 449, 3: 474, 1: 604; the fit's grid: 543)
+      if (cell_emit < static_cast<float>(p->search_radius)) {
+        if ((rc = build_grid(ctx, cv, cell_emit, cell_emit, &g)) != PCP_OK) return rc;
+      }
+    }
+  }
   if (p->upsampling == 3 && stream_capacity > 0) {
     // pcp_mls_stream_begin: count the voxel set and cut its key range into chunks of whole tiles
     VoxelDesc v{};
