@@ -657,7 +657,7 @@ def main():
                     vp = capi.default_mls_params()
                     cap = 1 << 28
                     first_call = None
-                    for rep_v in range(2):  # the first call allocates (and first touches) 120 GB of bitmap and counts
+                    for rep_v in range(2):  # the first call allocates (and first touches) the 60 GB voxel bitmap
                         t1 = time.perf_counter()
                         total_v, chunks_v = eng.ctx.mls_stream_begin(vp, cap)
                         eng.ctx.synchronize()

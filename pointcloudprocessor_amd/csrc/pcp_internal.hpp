@@ -214,7 +214,7 @@ struct pcp_context {
   pcp::DevBuf<int32_t> c_where;   // ... and the result row that holds it
   pcp::DevBuf<float> c_xyz, c_xyz2;  // pcp_cloud_smooth: intermediate clouds (SoA)
   pcp::DevBuf<uint32_t> v_bitmap;  // dilated voxel set, dense bitmap over the bounding box
-  pcp::DevBuf<int32_t> v_offsets;  // exclusive popcount prefix per bitmap word
+  pcp::DevBuf<int32_t> v_offsets;  // set bits per tile of 1024 bitmap words (k_voxel_tile_counts)
   pcp::DevBuf<int64_t> v_vox;      // occupied voxels (linear index) in key order
   pcp::DevBuf<float> mls_xyz, mls_normal, mls_curv;
   pcp::DevBuf<int32_t> mls_index;

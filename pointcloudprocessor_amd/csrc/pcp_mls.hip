@@ -727,16 +727,28 @@ __global__ __launch_bounds__(kMB) void k_voxel_stamp(const float *__restrict__ x
     }
 }
 
-// (grid-stride: a bitmap of more than 2^32 words does not fit one launch's 32-bit work-item count)
-__global__ __launch_bounds__(kMB) void k_voxel_popcount(const uint32_t *__restrict__ bitmap, int64_t words,
-                                                        int32_t *__restrict__ counts) {
-  for (int64_t w = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x; w < words; w += static_cast<int64_t>(gridDim.x) * kMB)
-    counts[w] = __popc(bitmap[w]);
+// set bits per tile of kScanTile bitmap words (a workgroup per tile, four words per lane; grid-stride: a bitmap of more than
+// 2^32 words does not fit one launch's 32-bit work-item count).  The per-WORD counts and their prefix used to be an array
+// of their own, as large as the bitmap (60 GB for the room at 1 mm) and 99 % zeros; the prefix inside a tile is now taken
+// where it is needed (k_voxel_expand).
+__global__ __launch_bounds__(kScanBlock) void k_voxel_tile_counts(const uint32_t *__restrict__ bitmap, int64_t words,
+                                                                int32_t *__restrict__ tile_count) {
+  __shared__ int32_t ws[kScanBlock / 64];
+  const int64_t tiles = (words + kScanTile - 1) / kScanTile;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t base = tile * kScanTile + threadIdx.x * 4;
+    int32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (base + k < words) c += __popc(bitmap[base + k]);
+    int32_t total;
+    (void)scan_block_exclusive(c, &total, ws);
+    if (threadIdx.x == 0) tile_count[tile] = total;
+  }
 }
 
 struct VoxelEmitArgs {
   const uint32_t *bitmap;
-  const int32_t *offsets;  // exclusive prefix of the popcounts
   VoxelDesc v;
   // neighbour grid of the MLS stage (cell-sorted coordinates)
   const float *sx, *sy, *sz;
@@ -753,17 +765,32 @@ struct VoxelEmitArgs {
   uint8_t *valid;
 };
 
-// the occupied voxels in key order: vox[offsets[w] + rank of bit b in word w] = (w << 5) + b.  One lane per
-// bitmap word; stores only (the bitmap is ~1 % full: the search below must not run at this granularity).
-__global__ __launch_bounds__(kMB) void k_voxel_expand(const uint32_t *__restrict__ bitmap,
-                                                      const int32_t *__restrict__ offsets, int64_t words,
-                                                      int64_t word_base, int64_t *__restrict__ vox) {
-  for (int64_t w = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x; w < words; w += static_cast<int64_t>(gridDim.x) * kMB) {
-    uint32_t bits = bitmap[w];
-    int64_t out = offsets[w];
-    while (bits) {
-      vox[out++] = ((w + word_base) << 5) + __builtin_ctz(bits);
-      bits &= bits - 1u;
+// the occupied voxels of bitmap words [word_base, word_base + words) in key order: a workgroup per tile of kScanTile words,
+// four consecutive words per lane, the prefix of the set bits inside the tile by a block scan, the tile's first place from
+// the exclusive prefix of the tile counts (tile_first).  Stores only (the bitmap is ~1 % full: the search of k_voxel_emit
+// must not run at this granularity).
+__global__ __launch_bounds__(kScanBlock) void k_voxel_expand(const uint32_t *__restrict__ bitmap, const int32_t *__restrict__ tile_first,
+                                                           int64_t words, int64_t word_base, int64_t *__restrict__ vox) {
+  __shared__ int32_t ws[kScanBlock / 64];
+  const int64_t tiles = (words + kScanTile - 1) / kScanTile;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t base = tile * kScanTile + threadIdx.x * 4;
+    uint32_t bits[4];
+    int32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      bits[k] = base + k < words ? bitmap[base + k] : 0u;
+      c += __popc(bits[k]);
+    }
+    int32_t total;
+    int64_t out = static_cast<int64_t>(tile_first[tile]) + scan_block_exclusive(c, &total, ws);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint32_t b = bits[k];
+      while (b) {
+        vox[out++] = ((base + k + word_base) << 5) + __builtin_ctz(b);
+        b &= b - 1u;
+      }
     }
   }
 }
@@ -1895,9 +1922,9 @@ static int vgd_prepare(pcp_context *ctx, const CloudView &cv, const pcp_mls_para
   const double bits = static_cast<double>(mx) * static_cast<double>(my) * static_cast<double>(mz);
   size_t free_b = 0, total_b = 0;
   PCP_HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
-  // bitmap (bits / 8) + per-word counts (bits / 8): both must fit with room for the outputs
-  const double have = static_cast<double>(free_b) + static_cast<double>(ctx->v_bitmap.count + ctx->v_offsets.count) * 4.0;
-  if (mx >= (int64_t(1) << 31) || my >= (int64_t(1) << 31) || mz >= (int64_t(1) << 31) || bits / 4.0 > 0.6 * have)
+  // the bitmap (bits / 8; the per-tile counts are 1 / 8192 of that) must fit with room for the outputs
+  const double have = static_cast<double>(free_b) + static_cast<double>(ctx->v_bitmap.count) * 4.0;
+  if (mx >= (int64_t(1) << 31) || my >= (int64_t(1) << 31) || mz >= (int64_t(1) << 31) || bits / 8.0 > 0.6 * have)
     return set_error(ctx, PCP_ERR_NOMEM,
                      "pcp_mls_process: the %lld x %lld x %lld voxel grid (%.3g voxels at %.4g m) does not fit the device; "
                      "use a larger vgd_voxel_size or crop the cloud",
@@ -1908,22 +1935,18 @@ static int vgd_prepare(pcp_context *ctx, const CloudView &cv, const pcp_mls_para
   v.words = (static_cast<int64_t>(v.NX) * v.NY * v.NZ + 31) / 32;
   const size_t sw = static_cast<size_t>(v.words);
   PCP_HIP_TRY(ctx, ctx->v_bitmap.ensure(sw + 8));
-  PCP_HIP_TRY(ctx, ctx->v_offsets.ensure(sw + 8));
   PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->v_bitmap.p, 0, (sw + 8) * 4, ctx->stream));
-  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->v_offsets.p, 0, (sw + 8) * 4, ctx->stream));
   const int64_t tiles = std::max<int64_t>(1, div_up(v.words, kScanTile));
-  PCP_HIP_TRY(ctx, ctx->s_tiles.ensure(static_cast<size_t>(tiles) + 4));
+  PCP_HIP_TRY(ctx, ctx->v_offsets.ensure(static_cast<size_t>(tiles) + 8));  // set bits per tile of the whole bitmap
   {
     LaunchTimer t(ctx, PCP_K_MLS_VOXEL);
     hipLaunchKernelGGL(k_voxel_stamp, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, cv.x, cv.y, cv.z, n, v, ctx->v_bitmap.p);
-    hipLaunchKernelGGL(k_voxel_popcount, dim3(scan_grid(div_up(v.words, kMB))), dim3(kMB), 0, ctx->stream, ctx->v_bitmap.p,
-                       v.words, ctx->v_offsets.p);
-    hipLaunchKernelGGL(k_scan_tile_sums, dim3(scan_grid(tiles)), dim3(kScanBlock), 0, ctx->stream,
-                       ctx->v_offsets.p, v.words, ctx->s_tiles.p);
+    hipLaunchKernelGGL(k_voxel_tile_counts, dim3(scan_grid(tiles)), dim3(kScanBlock), 0, ctx->stream, ctx->v_bitmap.p, v.words,
+                       ctx->v_offsets.p);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   std::vector<int32_t> sums(static_cast<size_t>(tiles));
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(sums.data(), ctx->s_tiles.p, sums.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(sums.data(), ctx->v_offsets.p, sums.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   tile_prefix->assign(static_cast<size_t>(tiles) + 1, 0);
   for (int64_t t = 0; t < tiles; ++t) (*tile_prefix)[static_cast<size_t>(t) + 1] = (*tile_prefix)[static_cast<size_t>(t)] + sums[static_cast<size_t>(t)];
@@ -1950,11 +1973,15 @@ static int vgd_emit(pcp_context *ctx, const VgdStream &S, int64_t word0, int64_t
   if (count > 0) {
     const int64_t words = word1 - word0;
     const int64_t tiles = std::max<int64_t>(1, div_up(words, kScanTile));
-    PCP_HIP_TRY(ctx, ctx->s_tiles.ensure(static_cast<size_t>(tiles) + 4));
-    int32_t *counts = ctx->v_offsets.p + word0;  // per-word counts -> exclusive prefix inside the chunk, in place
+    // the chunk's tile counts -> the first place of every tile inside the chunk (exclusive prefix, on a copy: the counts
+    // of the whole bitmap stay for the other chunks)
+    const int64_t tiles2 = std::max<int64_t>(1, div_up(tiles, kScanTile));
+    PCP_HIP_TRY(ctx, ctx->s_tiles.ensure(static_cast<size_t>(tiles + tiles2) + 8));
+    int32_t *tile_first = ctx->s_tiles.p, *level2 = ctx->s_tiles.p + tiles + 4;
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(tile_first, ctx->v_offsets.p + word0 / kScanTile, static_cast<size_t>(tiles) * 4, hipMemcpyDeviceToDevice,
+                                    ctx->stream));
     VoxelEmitArgs e{};
     e.bitmap = ctx->v_bitmap.p;
-    e.offsets = ctx->v_offsets.p;
     e.v = S.v;
     e.sx = ctx->g_xyz.p;
     e.sy = ctx->g_xyz.p + S.plane;
@@ -1979,14 +2006,12 @@ static int vgd_emit(pcp_context *ctx, const VgdStream &S, int64_t word0, int64_t
     e.valid = ctx->m_flag.p;
     {
       LaunchTimer t(ctx, PCP_K_MLS_VOXEL);
-      hipLaunchKernelGGL(k_scan_tile_sums, dim3(scan_grid(tiles)), dim3(kScanBlock), 0, ctx->stream, counts, words,
-                         ctx->s_tiles.p);
-      hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kScanBlock), 0, ctx->stream, ctx->s_tiles.p, tiles,
+      hipLaunchKernelGGL(k_scan_tile_sums, dim3(scan_grid(tiles2)), dim3(kScanBlock), 0, ctx->stream, tile_first, tiles, level2);
+      hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kScanBlock), 0, ctx->stream, level2, tiles2,
                          static_cast<unsigned long long *>(nullptr));
-      hipLaunchKernelGGL(k_scan_apply, dim3(scan_grid(tiles)), dim3(kScanBlock), 0, ctx->stream, counts, words,
-                         ctx->s_tiles.p, counts);
-      hipLaunchKernelGGL(k_voxel_expand, dim3(scan_grid(div_up(words, kMB))), dim3(kMB), 0, ctx->stream,
-                         ctx->v_bitmap.p + word0, counts, words, word0, ctx->v_vox.p);
+      hipLaunchKernelGGL(k_scan_apply, dim3(scan_grid(tiles2)), dim3(kScanBlock), 0, ctx->stream, tile_first, tiles, level2, tile_first);
+      hipLaunchKernelGGL(k_voxel_expand, dim3(scan_grid(tiles)), dim3(kScanBlock), 0, ctx->stream, ctx->v_bitmap.p + word0, tile_first,
+                         words, word0, ctx->v_vox.p);
       hipLaunchKernelGGL(k_voxel_emit, dim3(blocks_of(count)), dim3(kMB), 0, ctx->stream, e);
       PCP_HIP_TRY(ctx, hipGetLastError());
     }
