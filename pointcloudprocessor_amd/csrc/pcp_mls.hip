@@ -1907,7 +1907,7 @@ struct VgdStream {  // plain data: kept in ctx->vgd_blob between pcp_mls_stream_
 };
 
 static int vgd_prepare(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *p, VoxelDesc *out_v,
-                       std::vector<int64_t> *tile_prefix, unsigned long long *out_total) {
+                       std::vector<int32_t> *tile_counts, unsigned long long *out_total) {
   const int64_t n = cv.n;
   VoxelDesc v{};
   v.bminx = cv.mn[0];
@@ -1945,12 +1945,14 @@ static int vgd_prepare(pcp_context *ctx, const CloudView &cv, const pcp_mls_para
                        ctx->v_offsets.p);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
-  std::vector<int32_t> sums(static_cast<size_t>(tiles));
+  // the tile counts to the host (the caller cuts the key range into chunks from them); one pass for the total
+  std::vector<int32_t> &sums = *tile_counts;
+  sums.resize(static_cast<size_t>(tiles));
   PCP_HIP_TRY(ctx, hipMemcpyAsync(sums.data(), ctx->v_offsets.p, sums.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  tile_prefix->assign(static_cast<size_t>(tiles) + 1, 0);
-  for (int64_t t = 0; t < tiles; ++t) (*tile_prefix)[static_cast<size_t>(t) + 1] = (*tile_prefix)[static_cast<size_t>(t)] + sums[static_cast<size_t>(t)];
-  *out_total = static_cast<unsigned long long>(tile_prefix->back());
+  unsigned long long total = 0;
+  for (int32_t c : sums) total += static_cast<unsigned long long>(c);
+  *out_total = total;
   *out_v = v;
   return PCP_OK;
 }
@@ -2044,9 +2046,9 @@ static VgdStream vgd_stream_of(const CloudView &cv, const pcp_mls_params *p, con
 static int voxel_grid_dilation(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *p, const GridDesc &g,
                                int64_t *out_count) {
   VoxelDesc v{};
-  std::vector<int64_t> prefix;
+  std::vector<int32_t> tile_counts;
   unsigned long long total = 0;
-  int rc = vgd_prepare(ctx, cv, p, &v, &prefix, &total);
+  int rc = vgd_prepare(ctx, cv, p, &v, &tile_counts, &total);
   if (rc != PCP_OK) return rc;
   if (total >= (1ull << 31))
     return set_error(ctx, PCP_ERR_NOMEM, "pcp_mls_process: %llu dilated voxels exceed the 2^31 points one result holds "
@@ -2169,24 +2171,27 @@ static int mls_run(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *
   if (p->upsampling == 3 && stream_capacity > 0) {
     // pcp_mls_stream_begin: count the voxel set and cut its key range into chunks of whole tiles
     VoxelDesc v{};
-    std::vector<int64_t> prefix;
+    std::vector<int32_t> tile_counts;
     unsigned long long total = 0;
-    if ((rc = vgd_prepare(ctx, cv, p, &v, &prefix, &total)) != PCP_OK) return rc;
+    if ((rc = vgd_prepare(ctx, cv, p, &v, &tile_counts, &total)) != PCP_OK) return rc;
     const VgdStream S = vgd_stream_of(cv, p, g, v);
     ctx->vgd_blob.assign(reinterpret_cast<const uint8_t *>(&S), reinterpret_cast<const uint8_t *>(&S) + sizeof(S));
     ctx->vgd_chunks.clear();
-    const int64_t tiles = static_cast<int64_t>(prefix.size()) - 1;
-    int64_t t0 = 0;
-    while (t0 < tiles) {
-      int64_t t1 = t0 + 1;
-      while (t1 < tiles && prefix[static_cast<size_t>(t1) + 1] - prefix[static_cast<size_t>(t0)] <= stream_capacity) ++t1;
-      const int64_t cnt = prefix[static_cast<size_t>(t1)] - prefix[static_cast<size_t>(t0)];
-      if (cnt > 0) {
-        ctx->vgd_chunks.push_back(t0 * kScanTile);
-        ctx->vgd_chunks.push_back(std::min<int64_t>(t1 * kScanTile, v.words));
-        ctx->vgd_chunks.push_back(cnt);
+    // chunks = maximal runs of whole tiles that hold at most stream_capacity voxels (a tile alone holds <= 32 768)
+    const int64_t tiles = static_cast<int64_t>(tile_counts.size());
+    int64_t t0 = 0, cnt = 0;
+    for (int64_t t = 0; t <= tiles; ++t) {
+      const int64_t c = t < tiles ? tile_counts[static_cast<size_t>(t)] : 0;
+      if (t == tiles || (cnt + c > stream_capacity && t > t0)) {
+        if (cnt > 0) {
+          ctx->vgd_chunks.push_back(t0 * kScanTile);
+          ctx->vgd_chunks.push_back(std::min<int64_t>(t * kScanTile, v.words));
+          ctx->vgd_chunks.push_back(cnt);
+        }
+        t0 = t;
+        cnt = 0;
       }
-      t0 = t1;
+      cnt += c;
     }
     ctx->vgd_next = 0;
     if (out_count) *out_count = static_cast<int64_t>(total);
