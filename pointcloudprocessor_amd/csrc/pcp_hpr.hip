@@ -470,9 +470,13 @@ __device__ __forceinline__ Window reach_window(const Search &S, const HprGrid &G
   return W;
 }
 
-template <typename RangeFn>
+// skip_near: leave out the 3 x 3 cells traverse_near covers (run_search only calls this after a near pass that changed
+// nothing: those cells are cleared for the current trial normal already; the exact path enumerates everything)
+template <bool kSkipNear = false, typename RangeFn>
 __device__ __forceinline__ void traverse_all(const Search &S, const HprArrays &A, const HprGrid &G, RangeFn range) {
   const int l = lane_id();
+  const int32_t own = kSkipNear ? A.scell[S.self] : 0;
+  const int32_t oi = own % G.gw, oj = own / G.gw;
   const int32_t n_coarse = G.cgw * G.cgh, n_fine = G.gw * G.gh;
   const Window W = reach_window(S, G);
   if (W.i0 > W.i1 || W.j0 > W.j1) return;
@@ -492,7 +496,7 @@ __device__ __forceinline__ void traverse_all(const Search &S, const HprArrays &A
       const int32_t fi = (Cc % G.cgw) * kHprCoarse + (l & 7), fj = (Cc / G.cgw) * kHprCoarse + (l >> 3);
       bool fopen = false;
       int32_t f = 0;
-      if (fi < G.gw && fj < G.gh) {
+      if (fi < G.gw && fj < G.gh && !(kSkipNear && abs(fi - oi) <= 1 && abs(fj - oj) <= 1)) {
         f = fj * G.gw + fi;
         const double rho = A.crho[f];
         fopen = rho > 0.0 && !cell_cleared(S, A.cdir[f], A.cdir[n_fine + f], A.cdir[2 * n_fine + f], rho, G.r_fine);
@@ -529,7 +533,7 @@ __device__ __forceinline__ int run_search(Search &S, Polygon &P, const HprArrays
       return S.status == 0;
     });
     if (S.status == 0 && !S.changed)
-      traverse_all(S, A, G, [&](int32_t k0, int32_t k1) {
+      traverse_all<true>(S, A, G, [&](int32_t k0, int32_t k1) {
         test_range(S, P, A, k0, k1);
         return S.status == 0 && !S.changed;
       });
