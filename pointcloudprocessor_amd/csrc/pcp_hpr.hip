@@ -692,6 +692,123 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_cells(HprGrid G, const unsign
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The easy majority first: a candidate whose RADIAL plane (n = p / |p|, the first trial normal of every search) already
+// has every other point strictly on its inner side is a hull vertex, and nearly every visible candidate is of that kind
+// (the tangent plane of the flipped sphere leaves its neighbours by |q| delta^2 / 2).  That needs no polygon and no cuts --
+// only the traversal -- so four candidates share a wavefront here, 16 lanes each: the wave-uniform arithmetic of a search
+// (frame, window, bounds) is paid once per four candidates, the cell and point tests run 16 at a time.  Same certificate as
+// k_hpr_decide's (same plane, same rounding-proof point test, same cell bound); whatever this pass cannot certify -- an
+// uncleared point, a duplicate -- stays kStUndecided and k_hpr_decide searches it as before.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kHprBlock) void k_hpr_radial(HprArrays A, HprGrid G, uint8_t *__restrict__ state,
+                                                          unsigned long long *__restrict__ stats) {
+  const int lane = lane_id();
+  const int rl = lane & 15, row_base = lane & 48;
+  const int32_t j = static_cast<int32_t>(blockIdx.x) * (kHprBlock / 16) + static_cast<int32_t>(threadIdx.x >> 4);
+  const bool have = j < G.m;
+  auto row_mask = [&](bool b) -> uint32_t { return static_cast<uint32_t>((__ballot(b) >> row_base) & 0xffffull); };
+  Search S;
+  S.self = have ? j : 0;
+  S.p = load_point(A, S.self);
+  S.self_idx = A.sidx[S.self];
+  search_frame(S);
+  S.n = S.e0;
+  {
+    const double nn = sqrt((S.n.x * S.n.x + S.n.y * S.n.y) + S.n.z * S.n.z);
+    const double inv = quick_rcp(nn);
+    S.nh = {S.n.x * inv, S.n.y * inv, S.n.z * inv};
+    S.nn_hi = nn * (1.0 + 1.0e-14);
+    S.hp_lo = ((S.n.x * S.p.x + S.n.y * S.p.y) + S.n.z * S.p.z) * (1.0 - 1.0e-13);
+  }
+  bool open = have;       // the row may still certify its candidate
+  bool hidden_dup = false;
+  unsigned long long batches = 0;
+  // points [k0, k1) of the cell order against the plane, 16 at a time; `go`: this row takes part
+  auto test_points = [&](bool go, int32_t k0, int32_t k1) {
+    for (int32_t base = k0; __ballot(go && open && base < k1); base += 16) {
+      const int32_t k = base + rl;
+      const bool active = go && open && k < k1 && k != S.self;
+      bool bad = false, dup_lower = false;
+      if (active) {
+        const double dx = A.sx[k] - S.p.x, dy = A.sy[k] - S.p.y, dz = A.sz[k] - S.p.z;
+        if (dx == 0.0 && dy == 0.0 && dz == 0.0) {
+          dup_lower = A.sidx[k] < S.self_idx;  // identical flipped points: the lowest input index stands for the group
+        } else {
+          const double tx = S.n.x * dx, ty = S.n.y * dy, tz = S.n.z * dz;
+          const double t = (tx + ty) + tz, T = (fabs(tx) + fabs(ty)) + fabs(tz);
+          bad = !(t < -kPointSlack * T);
+        }
+      }
+      if (go && open && base < k1 && rl == 0) batches += 1;
+      if (row_mask(dup_lower)) {
+        hidden_dup = true;
+        open = false;
+      }
+      if (row_mask(bad)) open = false;
+    }
+  };
+  const int32_t cell = A.scell[S.self];
+  const int32_t ci = cell % G.gw, cj = cell / G.gw;
+  // the 3 x 3 cells around the candidate's own
+  for (int dj = -1; dj <= 1; ++dj) {
+    const int32_t rj = cj + dj;
+    const bool in = rj >= 0 && rj < G.gh;
+    const int32_t c0 = (in ? rj : cj) * G.gw + max(ci - 1, 0), c1 = (in ? rj : cj) * G.gw + min(ci + 1, G.gw - 1);
+    test_points(in, A.cstart[c0], A.cstart[c1 + 1]);
+  }
+  // every other cell the bound cannot clear
+  const int32_t n_coarse = G.cgw * G.cgh, n_fine = G.gw * G.gh;
+  const Window W = reach_window(S, G);
+  const bool has_window = open && W.i0 <= W.i1 && W.j0 <= W.j1;
+  const int32_t ww = has_window ? W.i1 - W.i0 + 1 : 1, wn = has_window ? ww * (W.j1 - W.j0 + 1) : 0;
+  for (int32_t cb = 0; __ballot(open && cb < wn); cb += 16) {
+    const int32_t t = cb + rl;
+    const int32_t C = (open && t < wn) ? (W.j0 + t / ww) * G.cgw + W.i0 + t % ww : -1;
+    bool copen = false;
+    if (C >= 0) {
+      const double rho = A.Crho[C];
+      copen = rho > 0.0 && !cell_cleared(S, A.Cdir[C], A.Cdir[n_coarse + C], A.Cdir[2 * n_coarse + C], rho, G.r_coarse);
+    }
+    uint32_t open_c = row_mask(copen);
+    while (__ballot(open && open_c != 0u)) {
+      const bool go_c = open && open_c != 0u;
+      const int bc = go_c ? __builtin_ctz(open_c) : 0;
+      open_c &= open_c - 1u;
+      const int32_t Cc = __shfl(C, row_base + bc, 64);
+      for (int q4 = 0; q4 < 4; ++q4) {  // the 64 fine cells of the coarse cell, 16 at a time
+        const int fidx = q4 * 16 + rl;
+        const int32_t fi = (go_c ? Cc % G.cgw : 0) * kHprCoarse + (fidx & 7), fj = (go_c ? Cc / G.cgw : 0) * kHprCoarse + (fidx >> 3);
+        bool fopen = false;
+        int32_t f = 0;
+        if (go_c && fi < G.gw && fj < G.gh && !(abs(fi - ci) <= 1 && abs(fj - cj) <= 1)) {
+          f = fj * G.gw + fi;
+          const double rho = A.crho[f];
+          fopen = rho > 0.0 && !cell_cleared(S, A.cdir[f], A.cdir[n_fine + f], A.cdir[2 * n_fine + f], rho, G.r_fine);
+        }
+        uint32_t open_f = row_mask(fopen);
+        while (__ballot(open && open_f != 0u)) {
+          const bool go_f = open && open_f != 0u;
+          const int bf = go_f ? __builtin_ctz(open_f) : 0;
+          open_f &= open_f - 1u;
+          const int32_t ff = __shfl(f, row_base + bf, 64);
+          test_points(go_f, go_f ? A.cstart[ff] : 0, go_f ? A.cstart[ff + 1] : 0);
+        }
+      }
+    }
+  }
+  if (have && rl == 0) {
+    const int32_t out = hidden_dup ? kStHidden : (open ? kStVisible : kStUndecided);
+    state[j] = static_cast<uint8_t>(out);
+    unsigned long long *mine = stats + kStatStride * (1 + (blockIdx.x % kStatCopies));
+    if (out != kStUndecided) {
+      atomicAdd(&mine[out], 1ull);
+      atomicAdd(&mine[3], 1ull);
+    }
+    atomicAdd(&mine[4], batches);
+  }
+}
+
 // stats: [0] hidden [1] visible [2] undecided [3] trial normals [4] batches of 64 point tests [5] second-box retries
 // [6] unresolved [7] exact predicate evaluations [8] length of the list for k_hpr_exact
 __global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_hpr_decide(HprArrays A, HprGrid G, uint8_t *__restrict__ state,
@@ -699,6 +816,7 @@ __global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(3, 3)
                                                           unsigned long long *__restrict__ stats, int32_t force_exact) {
   const int32_t j = static_cast<int32_t>(blockIdx.x) * (kHprBlock / 64) + static_cast<int32_t>(threadIdx.x >> 6);
   if (j >= G.m) return;
+  if (state[j] != kStUndecided) return;  // k_hpr_radial certified it
   Search S;
   S.p = load_point(A, j);
   S.self = j;
@@ -1072,6 +1190,13 @@ int hpr_refine_flags(pcp_context *ctx, int32_t frame, uint8_t *d_flags) {
                        reinterpret_cast<unsigned long long *>(crho));
     hipLaunchKernelGGL(k_hpr_cells, dim3(hpr_blocks(std::max(n_fine, n_coarse))), dim3(kHprBlock), 0, ctx->stream, G,
                        reinterpret_cast<const unsigned long long *>(crho), cdir, Crho, Cdir, stats + 28);
+    // PCP_HPR_RADIAL=0: every candidate through k_hpr_decide (results identical)
+    const char *re = std::getenv("PCP_HPR_RADIAL");
+    if (force_exact || (re && re[0] == '0'))
+      PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->h_state.p, kStUndecided, sm, ctx->stream));
+    else
+      hipLaunchKernelGGL(k_hpr_radial, dim3(static_cast<uint32_t>(div_up(m, kHprBlock / 16))), dim3(kHprBlock), 0, ctx->stream, A, G,
+                         ctx->h_state.p, stats);
     hipLaunchKernelGGL(k_hpr_decide, dim3(static_cast<uint32_t>(div_up(m, kHprBlock / 64))), dim3(kHprBlock), 0, ctx->stream,
                        A, G, ctx->h_state.p, undecided, stats, force_exact ? 1 : 0);
     PCP_HIP_TRY(ctx, hipGetLastError());
