@@ -675,6 +675,7 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->h_cells_d.release();
   ctx->h_state.release();
   ctx->h_stats.release();
+  ctx->h_rep.release();
   ctx->hull_bits.release();
   ctx->nid_pts.release();
   ctx->nid_chunk_kf.release();
