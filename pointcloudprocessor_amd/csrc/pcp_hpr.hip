@@ -717,10 +717,12 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_quick(HprArrays A, HprGrid G,
       const unsigned long long v = A.crep[jj * G.gw + i];
       return v ? static_cast<int32_t>(v & 0x3ffffffull) : -1;
     };
-    for (int t = 0; t < 2 && !hit; ++t) {
-      const int32_t ia = t == 0 ? rep_of(-1, -1) : rep_of(-1, 1);
-      const int32_t ib = t == 0 ? rep_of(1, -1) : rep_of(1, 1);
-      const int32_t ic = t == 0 ? rep_of(0, 1) : rep_of(0, -1);
+    // four triangles of neighbouring cells that enclose the candidate's own cell
+    const int8_t tri[4][6] = {{-1, -1, 1, -1, 0, 1}, {-1, 1, 1, 1, 0, -1}, {-1, -1, -1, 1, 1, 0}, {1, -1, 1, 1, -1, 0}};
+    for (int t = 0; t < 4 && !hit; ++t) {
+      const int32_t ia = rep_of(tri[t][0], tri[t][1]);
+      const int32_t ib = rep_of(tri[t][2], tri[t][3]);
+      const int32_t ic = rep_of(tri[t][4], tri[t][5]);
       if (ia < 0 || ib < 0 || ic < 0 || ia == j || ib == j || ic == j) continue;
       hit = tetra_contains_filtered(p, load_point(A, ia), load_point(A, ib), load_point(A, ic)) != 0;
     }
