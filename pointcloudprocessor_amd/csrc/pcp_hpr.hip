@@ -1003,11 +1003,14 @@ __device__ inline bool tetra_contains_exact(const Vec3d &p, const Vec3d &a, cons
 
 constexpr int kHprExactIds = 16;
 
+// (launched with a fixed grid; the length of the list is read where k_hpr_decide counted it -- stats[8] -- so that the host
+// does not have to wait for it; kHprExactGrid entries are taken per launch, the host adds launches in the rare case of more)
+constexpr int32_t kHprExactGrid = 4096;
 __global__ __launch_bounds__(64) void k_hpr_exact(HprArrays A, HprGrid G, double reach, const int32_t *__restrict__ undecided,
-                                                  int32_t n_undecided, uint8_t *__restrict__ state,
+                                                  int32_t first, uint8_t *__restrict__ state,
                                                   unsigned long long *__restrict__ stats) {
-  const int32_t u = static_cast<int32_t>(blockIdx.x);
-  if (u >= n_undecided) return;
+  const int32_t u = first + static_cast<int32_t>(blockIdx.x);
+  if (static_cast<unsigned long long>(u) >= stats[8]) return;
   __shared__ int32_t ids[kHprExactIds];
   const int32_t j = undecided[u];
   const int l = lane_id();
@@ -1145,6 +1148,7 @@ int hpr_refine_flags(pcp_context *ctx, int32_t frame, uint8_t *d_flags) {
   int rc = compact_flags(ctx, d_flags, n, ctx->h_index.p, n, &m64);
   if (rc != PCP_OK) return rc;
   std::memset(ctx->hpr_stats, 0, sizeof(ctx->hpr_stats));
+  ctx->hpr_stats_pending = false;
   ctx->hpr_stats[9] = m64;
   if (m64 < 3) {
     // qhull needs dim + 1 points (here: three candidates and the origin); with fewer it fails and the reference
@@ -1255,43 +1259,33 @@ int hpr_refine_flags(pcp_context *ctx, int32_t frame, uint8_t *d_flags) {
                        A, G, ctx->h_state.p, undecided, stats, force_exact ? 1 : 0);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
-  std::vector<unsigned long long> hall(kStatStride * (1 + kStatCopies));
-  unsigned long long hs[9];
-  auto fetch_stats = [&]() -> int {
-    PCP_HIP_TRY(ctx, hipMemcpyAsync(hall.data(), stats, hall.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (int k = 0; k < 9; ++k) {
-      hs[k] = hall[static_cast<size_t>(k)];
-      if (k != 8)
-        for (int c = 1; c <= kStatCopies; ++c) hs[k] += hall[static_cast<size_t>(c * kStatStride + k)];
-    }
-    return PCP_OK;
-  };
-  if ((rc = fetch_stats()) != PCP_OK) return rc;
-  const int64_t n_und = static_cast<int64_t>(hs[8]);
-  if (n_und > 0) {
+  {
+    // the exact path for what the searches left undecided (a handful per keyframe): a fixed grid that reads the count on
+    // the device; the tallies stay on the device until pcp_hpr_stats asks for them -- no host round trip in here
     LaunchTimer t(ctx, PCP_K_HPR);
-    hipLaunchKernelGGL(k_hpr_exact, dim3(static_cast<uint32_t>(n_und)), dim3(64), 0, ctx->stream, A, G,
-                       4.0 * std::fabs(ctx->cull.hpr_flip_radius) + 1.0e4, undecided,
-                       static_cast<int32_t>(n_und), ctx->h_state.p, stats);
+    hipLaunchKernelGGL(k_hpr_exact, dim3(static_cast<uint32_t>(std::min<int32_t>(m, kHprExactGrid))), dim3(64), 0, ctx->stream, A, G,
+                       4.0 * std::fabs(ctx->cull.hpr_flip_radius) + 1.0e4, undecided, 0, ctx->h_state.p, stats);
     PCP_HIP_TRY(ctx, hipGetLastError());
-    if ((rc = fetch_stats()) != PCP_OK) return rc;
+  }
+  if (m > kHprExactGrid) {
+    // more undecided candidates than one launch takes?  (never seen: forced exact mode, pathological input)  Then the
+    // host does look at the count.
+    unsigned long long n_und = 0;
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(&n_und, stats + 8, sizeof(n_und), hipMemcpyDeviceToHost, ctx->stream));
+    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t first = kHprExactGrid; first < static_cast<int64_t>(n_und); first += kHprExactGrid) {
+      hipLaunchKernelGGL(k_hpr_exact, dim3(static_cast<uint32_t>(kHprExactGrid)), dim3(64), 0, ctx->stream, A, G,
+                         4.0 * std::fabs(ctx->cull.hpr_flip_radius) + 1.0e4, undecided, static_cast<int32_t>(first), ctx->h_state.p, stats);
+      PCP_HIP_TRY(ctx, hipGetLastError());
+    }
   }
   {
     LaunchTimer t(ctx, PCP_K_HPR);
     hipLaunchKernelGGL(k_hpr_writeback, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, ctx->stream, ctx->h_state.p, sidx, m, d_flags);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
-  // visible / hidden as finally classified (the exact path moved its points out of "undecided")
-  ctx->hpr_stats[0] = static_cast<int64_t>(hs[1]);           // visible
-  ctx->hpr_stats[1] = static_cast<int64_t>(hs[0]);           // hidden
-  ctx->hpr_stats[2] = n_und;                                 // sent to the exact path
-  ctx->hpr_stats[3] = static_cast<int64_t>(hs[3]);
-  ctx->hpr_stats[4] = static_cast<int64_t>(hs[4]);
-  ctx->hpr_stats[5] = static_cast<int64_t>(hs[5]);
-  ctx->hpr_stats[6] = static_cast<int64_t>(hs[6]);
-  ctx->hpr_stats[7] = static_cast<int64_t>(hs[7]);
   ctx->hpr_stats[8] = n_fine;
+  ctx->hpr_stats_pending = true;  // [0..7] are summed from the device tallies when pcp_hpr_stats is called
   if (std::getenv("PCP_HPR_DEBUG")) {
     unsigned long long dbg[24];
     (void)hipMemcpy(dbg, stats, sizeof(dbg), hipMemcpyDeviceToHost);
@@ -1311,6 +1305,24 @@ extern "C" {
 
 int pcp_hpr_stats(pcp_context *ctx, int64_t out[10]) {
   if (!ctx || !out) return PCP_ERR_INVALID;
+  if (ctx->hpr_stats_pending && ctx->h_stats.p) {
+    // the tallies of the last run: block 0 + kStatCopies per-workgroup copies (k_hpr_decide), summed here
+    PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<unsigned long long> hall(kStatStride * (1 + kStatCopies));
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(hall.data(), ctx->h_stats.p, hall.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long hs[9];
+    for (int k = 0; k < 9; ++k) {
+      hs[k] = hall[static_cast<size_t>(k)];
+      if (k != 8)
+        for (int c = 1; c <= kStatCopies; ++c) hs[k] += hall[static_cast<size_t>(c * kStatStride + k)];
+    }
+    ctx->hpr_stats[0] = static_cast<int64_t>(hs[1]);  // visible, as finally classified (the exact path moved its points out of "undecided")
+    ctx->hpr_stats[1] = static_cast<int64_t>(hs[0]);  // hidden
+    ctx->hpr_stats[2] = static_cast<int64_t>(hs[8]);  // sent to the exact path
+    for (int k = 3; k <= 7; ++k) ctx->hpr_stats[k] = static_cast<int64_t>(hs[k]);
+    ctx->hpr_stats_pending = false;
+  }
   for (int i = 0; i < 10; ++i) out[i] = ctx->hpr_stats[i];
   return PCP_OK;
 }

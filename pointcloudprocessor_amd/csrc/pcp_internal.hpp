@@ -195,6 +195,7 @@ struct pcp_context {
                                     // order) is a hull vertex of keyframe f
   std::vector<uint8_t> hull_valid;  // per keyframe: hull bits imported (index shards)
   int64_t hpr_stats[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  bool hpr_stats_pending = false;  // the tallies of the last hull still sit on the device (h_stats)
 
   // MLS: uniform grid (cell id / in-cell rank per point, cell starts, cell-sorted
   // order + coordinates), per-input-point results, compacted outputs
