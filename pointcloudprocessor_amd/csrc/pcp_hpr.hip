@@ -1003,16 +1003,9 @@ __device__ inline bool tetra_contains_exact(const Vec3d &p, const Vec3d &a, cons
 
 constexpr int kHprExactIds = 16;
 
-// (launched with a fixed grid; the length of the list is read where k_hpr_decide counted it -- stats[8] -- so that the host
-// does not have to wait for it; kHprExactGrid entries are taken per launch, the host adds launches in the rare case of more)
-constexpr int32_t kHprExactGrid = 4096;
-__global__ __launch_bounds__(64) void k_hpr_exact(HprArrays A, HprGrid G, double reach, const int32_t *__restrict__ undecided,
-                                                  int32_t first, uint8_t *__restrict__ state,
-                                                  unsigned long long *__restrict__ stats) {
-  const int32_t u = first + static_cast<int32_t>(blockIdx.x);
-  if (static_cast<unsigned long long>(u) >= stats[8]) return;
-  __shared__ int32_t ids[kHprExactIds];
-  const int32_t j = undecided[u];
+// one undecided candidate (place j of the cell order), one wavefront
+__device__ void hpr_exact_one(const HprArrays &A, const HprGrid &G, double reach, int32_t j, uint8_t *__restrict__ state,
+                              unsigned long long *__restrict__ stats, int32_t *ids) {
   const int l = lane_id();
   Search S;
   S.p = load_point(A, j);
@@ -1109,6 +1102,19 @@ __global__ __launch_bounds__(64) void k_hpr_exact(HprArrays A, HprGrid G, double
     atomicAdd(&stats[3], restarts);
     atomicAdd(&stats[4], S.tests);
     atomicAdd(&stats[7], exact_total);
+  }
+}
+
+// (a fixed grid whose wavefronts stride over the list; its length is read where k_hpr_decide counted it -- stats[8] -- so the
+// host neither waits for the count nor adds launches, however long the list)
+constexpr int32_t kHprExactGrid = 1024;
+__global__ __launch_bounds__(64) void k_hpr_exact(HprArrays A, HprGrid G, double reach, const int32_t *__restrict__ undecided,
+                                                  uint8_t *__restrict__ state, unsigned long long *__restrict__ stats) {
+  __shared__ int32_t ids[kHprExactIds];
+  const unsigned long long count = stats[8];
+  for (unsigned long long u = blockIdx.x; u < count; u += gridDim.x) {
+    hpr_exact_one(A, G, reach, undecided[u], state, stats, ids);
+    __syncthreads();
   }
 }
 
@@ -1261,23 +1267,12 @@ int hpr_refine_flags(pcp_context *ctx, int32_t frame, uint8_t *d_flags) {
   }
   {
     // the exact path for what the searches left undecided (a handful per keyframe): a fixed grid that reads the count on
-    // the device; the tallies stay on the device until pcp_hpr_stats asks for them -- no host round trip in here
+    // the device and strides over the list; the tallies stay on the device until pcp_hpr_stats asks for them -- no host
+    // round trip in here
     LaunchTimer t(ctx, PCP_K_HPR);
     hipLaunchKernelGGL(k_hpr_exact, dim3(static_cast<uint32_t>(std::min<int32_t>(m, kHprExactGrid))), dim3(64), 0, ctx->stream, A, G,
-                       4.0 * std::fabs(ctx->cull.hpr_flip_radius) + 1.0e4, undecided, 0, ctx->h_state.p, stats);
+                       4.0 * std::fabs(ctx->cull.hpr_flip_radius) + 1.0e4, undecided, ctx->h_state.p, stats);
     PCP_HIP_TRY(ctx, hipGetLastError());
-  }
-  if (m > kHprExactGrid) {
-    // more undecided candidates than one launch takes?  (never seen: forced exact mode, pathological input)  Then the
-    // host does look at the count.
-    unsigned long long n_und = 0;
-    PCP_HIP_TRY(ctx, hipMemcpyAsync(&n_und, stats + 8, sizeof(n_und), hipMemcpyDeviceToHost, ctx->stream));
-    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (int64_t first = kHprExactGrid; first < static_cast<int64_t>(n_und); first += kHprExactGrid) {
-      hipLaunchKernelGGL(k_hpr_exact, dim3(static_cast<uint32_t>(kHprExactGrid)), dim3(64), 0, ctx->stream, A, G,
-                         4.0 * std::fabs(ctx->cull.hpr_flip_radius) + 1.0e4, undecided, static_cast<int32_t>(first), ctx->h_state.p, stats);
-      PCP_HIP_TRY(ctx, hipGetLastError());
-    }
   }
   {
     LaunchTimer t(ctx, PCP_K_HPR);

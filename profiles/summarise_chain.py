@@ -14,6 +14,8 @@ KEEP = ("k_sor_select", "k_sor_mean_distance", "k_mls_fit", "k_grid_count", "k_g
 
 
 def short(name):
+    if "k_mls_fit" in name and "<false, true>" in name:  # the tile form, apart from the gather form that takes its leftovers
+        return "k_mls_fit_tile"
     for k in KEEP:
         if k in name:
             return k
