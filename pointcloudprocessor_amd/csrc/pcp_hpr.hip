@@ -702,7 +702,8 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_cells(HprGrid G, const unsign
 // checked with the same filtered determinants, found without a search.  (A point ON the surface is not in it: the
 // triangle's plane passes below the sphere by the sagitta of the cells' spacing.)  One LANE per candidate: the test is a few
 // hundred scalar operations, which a wavefront per candidate would spend 64 times over.  On hidden-heavy keyframes of C3 it
-// settles 70-85 % of the hidden candidates; the rest stay kStUndecided for k_hpr_radial / k_hpr_decide.
+// settles 88-94 % of the hidden candidates (75-89 % with the first four triangles alone; profiles/hpr_quick_sim.py); the rest
+// stay kStUndecided for k_hpr_radial / k_hpr_decide.
 __global__ __launch_bounds__(kHprBlock) void k_hpr_quick(HprArrays A, HprGrid G, uint8_t *__restrict__ state,
                                                          unsigned long long *__restrict__ stats) {
   const int32_t j = static_cast<int32_t>(blockIdx.x) * kHprBlock + static_cast<int32_t>(threadIdx.x);
@@ -725,6 +726,23 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_quick(HprArrays A, HprGrid G,
       const int32_t ic = rep_of(tri[t][4], tri[t][5]);
       if (ia < 0 || ib < 0 || ic < 0 || ia == j || ib == j || ic == j) continue;
       hit = tetra_contains_filtered(p, load_point(A, ia), load_point(A, ib), load_point(A, ic)) != 0;
+    }
+    // then the fan around the outermost candidate of the candidate's OWN cell: with two consecutive cells of the ring it
+    // spans the small triangles that lie right above a candidate just behind the surface (on C3 the four triangles leave
+    // 11-25 % of a keyframe's hidden candidates to the searches, the fan half of that)
+    const int32_t io = hit ? -1 : rep_of(0, 0);
+    if (io >= 0 && io != j) {
+      const Vec3d o = load_point(A, io);
+      const int8_t ring[9][2] = {{-1, -1}, {0, -1}, {1, -1}, {1, 0}, {1, 1}, {0, 1}, {-1, 1}, {-1, 0}, {-1, -1}};
+      int32_t ia = rep_of(ring[0][0], ring[0][1]);
+      Vec3d a = load_point(A, max(ia, 0));
+      for (int t = 1; t < 9 && !hit; ++t) {
+        const int32_t ib = rep_of(ring[t][0], ring[t][1]);
+        const Vec3d b = load_point(A, max(ib, 0));
+        if (ia >= 0 && ib >= 0 && ia != j && ib != j) hit = tetra_contains_filtered(p, o, a, b) != 0;
+        ia = ib;
+        a = b;
+      }
     }
     state[j] = static_cast<uint8_t>(hit ? kStHidden : kStUndecided);
   }
@@ -1261,8 +1279,28 @@ int hpr_refine_flags(pcp_context *ctx, int32_t frame, uint8_t *d_flags) {
     if (!(force_exact || (re && re[0] == '0')))
       hipLaunchKernelGGL(k_hpr_radial, dim3(static_cast<uint32_t>(div_up(m, kHprBlock / 16))), dim3(kHprBlock), 0, ctx->stream, A, G,
                          ctx->h_state.p, stats);
+    std::vector<uint8_t> dbg_before;
+    if (std::getenv("PCP_HPR_DEBUG")) {  // what the two passes in front left to the searches
+      dbg_before.resize(sm);
+      (void)hipMemcpyAsync(dbg_before.data(), ctx->h_state.p, sm, hipMemcpyDeviceToHost, ctx->stream);
+      (void)hipStreamSynchronize(ctx->stream);
+    }
     hipLaunchKernelGGL(k_hpr_decide, dim3(static_cast<uint32_t>(div_up(m, kHprBlock / 64))), dim3(kHprBlock), 0, ctx->stream,
                        A, G, ctx->h_state.p, undecided, stats, force_exact ? 1 : 0);
+    if (!dbg_before.empty()) {
+      std::vector<uint8_t> after(sm);
+      (void)hipMemcpyAsync(after.data(), ctx->h_state.p, sm, hipMemcpyDeviceToHost, ctx->stream);
+      (void)hipStreamSynchronize(ctx->stream);
+      size_t und = 0, to_vis = 0, to_hid = 0, left = 0;
+      for (size_t k = 0; k < sm; ++k)
+        if (dbg_before[k] == kStUndecided) {
+          ++und;
+          if (after[k] == kStVisible) ++to_vis;
+          else if (after[k] == kStHidden) ++to_hid;
+          else ++left;
+        }
+      fprintf(stderr, "hpr: %d candidates, %zu searched: %zu visible, %zu hidden, %zu to the exact path\n", m, und, to_vis, to_hid, left);
+    }
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   {

@@ -1,0 +1,70 @@
+import sys, time
+sys.path.insert(0, '/root/repo')
+import numpy as np
+from scipy.spatial import ConvexHull
+from oracle import np_oracle as no
+from pointcloudprocessor_amd import synth
+N = int(sys.argv[1]); kf = int(sys.argv[2])
+cam = synth.camera_dict("cfg")
+x, y, z, _ = synth.make_cloud(N)
+poses, _ = synth.make_trajectory(256)
+w2c, _ = no.pose_to_matrices(poses[kf])
+p = no.project_frame(cam, w2c, x, y, z)
+u, v = p["u"], p["v"]
+ok = (p["zc"] > 0) & no._trunc_ok(u) & no._trunc_ok(v)
+ui = np.where(ok, np.trunc(np.where(ok, u, 0)), -1); vi = np.where(ok, np.trunc(np.where(ok, v, 0)), -1)
+cand = ok & (ui >= 0) & (ui < cam["cull_width"]) & (vi >= 0) & (vi < cam["cull_height"])
+idx = np.nonzero(cand)[0]
+pts = np.stack([p["xc"][idx], p["yc"][idx], p["zc"][idx]], axis=1).astype(np.float64)
+nrm = np.linalg.norm(pts, axis=1)[:, None]
+F = pts + (2.0 * (90000.0 - nrm) * pts) / nrm
+m = len(F)
+hull = ConvexHull(np.concatenate([F, np.zeros((1, 3))]))
+vis = np.zeros(m, bool); vis[[k for k in hull.vertices if k < m]] = True
+V = np.nonzero(vis)[0]
+print("candidates", m, "visible", len(V), flush=True)
+def supports(nv, ids):
+    """for candidates ids with normals nv: is max_q n.(q - p) <= 0 with only p itself at 0 (strict for others)?"""
+    out = np.zeros(len(ids), bool)
+    B = 2000
+    for s in range(0, len(ids), B):
+        n = nv[s:s + B]; P = F[ids[s:s + B]]
+        d = F @ n.T - np.einsum('ij,ij->i', P, n)[None, :]     # m x B
+        d[ids[s:s + B], np.arange(len(n))] = -np.inf
+        out[s:s + B] = d.max(axis=0) < 0
+    return out
+t0 = time.time()
+rad = F[V] / np.linalg.norm(F[V], axis=1)[:, None]
+okr = supports(rad, V)
+print("radial certifies", okr.mean(), "left", (~okr).sum(), round(time.time() - t0), "s", flush=True)
+L = V[~okr]
+# grid + reps
+a, b = F[:, 0] / F[:, 2], F[:, 1] / F[:, 2]
+rho = np.linalg.norm(F, axis=1)
+wa, wb = a.max() - a.min(), b.max() - b.min()
+h = np.sqrt(8.0 * wa * wb / m)
+gw, gh = int(wa / h) + 1, int(wb / h) + 1
+ci = np.minimum(gw - 1, ((a - a.min()) / h).astype(int)); cj = np.minimum(gh - 1, ((b - b.min()) / h).astype(int))
+cell = cj * gw + ci
+order = np.lexsort((rho, cell))
+rep = np.full(gw * gh, -1); rep[cell[order]] = order
+ring = [(-1,-1),(0,-1),(1,-1),(1,0),(1,1),(0,1),(-1,1),(-1,0)]
+def reps(ids, di, dj):
+    i, j = ci[ids] + di, cj[ids] + dj
+    okk = (i >= 0) & (j >= 0) & (i < gw) & (j < gh)
+    r = np.where(okk, rep[np.where(okk, j * gw + i, 0)], -1)
+    return np.where(r == ids, -1, r)
+for dist in (1, 2):
+    R = [reps(L, di * dist, dj * dist) for di, dj in ring]
+    nsum = np.zeros((len(L), 3))
+    for k in range(8):
+        ra, rb = R[k], R[(k + 1) % 8]
+        okk = (ra >= 0) & (rb >= 0)
+        A = F[np.maximum(ra, 0)] - F[L]; B_ = F[np.maximum(rb, 0)] - F[L]
+        c = np.cross(A, B_)
+        c *= np.sign(np.einsum('ij,ij->i', c, F[L]))[:, None]     # outward
+        nsum += np.where(okk[:, None], c / np.maximum(np.linalg.norm(c, axis=1), 1e-300)[:, None], 0)
+    good = np.linalg.norm(nsum, axis=1) > 0
+    nv = np.where(good[:, None], nsum / np.maximum(np.linalg.norm(nsum, axis=1), 1e-300)[:, None], F[L] / np.linalg.norm(F[L], axis=1)[:, None])
+    ok2 = supports(nv, L)
+    print(f"fan normal (ring distance {dist}, unit-normal mean) certifies {ok2.mean():.3f} of the {len(L)} left", flush=True)
