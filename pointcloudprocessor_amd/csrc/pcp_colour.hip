@@ -22,6 +22,7 @@
 
 #include "pcp_device.hpp"
 #include "pcp_hsv.hpp"
+#include "pcp_scan.hpp"
 
 namespace pcp {
 
@@ -851,24 +852,11 @@ __global__ __launch_bounds__(kBlock) void k_tile_count(const uint8_t *__restrict
   if (threadIdx.x == 0) tile_count[blockIdx.x] = total;
 }
 
-// single block: exclusive scan of tile counts in place, grand total to *total
-__global__ __launch_bounds__(kBlock) void k_scan_tiles(int32_t *__restrict__ tile_count, int64_t tiles,
-                                                       unsigned long long *__restrict__ total) {
-  __shared__ int64_t carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int64_t base = 0; base < tiles; base += kBlock) {
-    const int64_t i = base + threadIdx.x;
-    const int32_t v = i < tiles ? tile_count[i] : 0;
-    int32_t tot;
-    const int32_t ex = block_exclusive_scan(v, &tot);
-    const int64_t c = carry;
-    if (i < tiles) tile_count[i] = static_cast<int32_t>(c + ex);
-    __syncthreads();
-    if (threadIdx.x == 0) carry = c + tot;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *total = static_cast<unsigned long long>(carry);
+// single block: exclusive scan of tile counts in place, grand total to *total (scan_single_block, pcp_scan.hpp)
+constexpr int kScanTilesBlock = kScanSingle;
+__global__ __launch_bounds__(kScanTilesBlock) void k_scan_tiles(int32_t *__restrict__ tile_count, int64_t tiles,
+                                                                unsigned long long *__restrict__ total) {
+  scan_single_block(tile_count, tiles, total);
 }
 
 __global__ __launch_bounds__(kBlock) void k_tile_scatter(const uint8_t *__restrict__ flags, int64_t n,
@@ -1072,7 +1060,7 @@ int compact_flags(pcp_context *ctx, const uint8_t *flags, int64_t n, int32_t *ou
     LaunchTimer t(ctx, PCP_K_MISC);
     hipLaunchKernelGGL(k_tile_count, dim3(static_cast<uint32_t>(tiles)), dim3(kBlock), 0, ctx->stream, flags, n,
                        ctx->s_tiles.p);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->s_tiles.p, tiles, ctx->s_counter.p);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(kScanTilesBlock), 0, ctx->stream, ctx->s_tiles.p, tiles, ctx->s_counter.p);
     if (out_index)
       hipLaunchKernelGGL(k_tile_scatter, dim3(static_cast<uint32_t>(tiles)), dim3(kBlock), 0, ctx->stream, flags, n,
                          ctx->s_tiles.p, out_index, capacity);

@@ -507,7 +507,7 @@ static int store_cloud(pcp_context *ctx, const float *x, const float *y, const f
     PCP_HIP_TRY(ctx, hipMemsetAsync(hist.p + hm, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(k_scan_tile_sums, dim3(static_cast<uint32_t>(scan_tiles)), dim3(kScanBlock), 0, st, hist.p, hm + 1,
                        ctx->s_tiles.p);
-    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kScanBlock), 0, st, ctx->s_tiles.p, scan_tiles,
+    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kScanSingle), 0, st, ctx->s_tiles.p, scan_tiles,
                        static_cast<unsigned long long *>(nullptr));
     hipLaunchKernelGGL(k_scan_apply, dim3(static_cast<uint32_t>(scan_tiles)), dim3(kScanBlock), 0, st, hist.p, hm + 1,
                        ctx->s_tiles.p, hist.p);

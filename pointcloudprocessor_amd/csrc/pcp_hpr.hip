@@ -1153,7 +1153,7 @@ static int hpr_scan(pcp_context *ctx, int32_t *counts, int64_t entries) {
   PCP_HIP_TRY(ctx, ctx->s_tiles.ensure(static_cast<size_t>(tiles) + 4));
   hipLaunchKernelGGL(k_scan_tile_sums, dim3(static_cast<uint32_t>(tiles)), dim3(kScanBlock), 0, ctx->stream, counts, entries,
                      ctx->s_tiles.p);
-  hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kScanBlock), 0, ctx->stream, ctx->s_tiles.p, tiles,
+  hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kScanSingle), 0, ctx->stream, ctx->s_tiles.p, tiles,
                      static_cast<unsigned long long *>(nullptr));
   hipLaunchKernelGGL(k_scan_apply, dim3(static_cast<uint32_t>(tiles)), dim3(kScanBlock), 0, ctx->stream, counts, entries,
                      ctx->s_tiles.p, counts);

@@ -1768,7 +1768,7 @@ static int exclusive_scan(pcp_context *ctx, int32_t *counts, int64_t m) {
   PCP_HIP_TRY(ctx, ctx->s_tiles.ensure(static_cast<size_t>(tiles) + 4));
   hipLaunchKernelGGL(k_scan_tile_sums, dim3(static_cast<uint32_t>(tiles)), dim3(kScanBlock), 0, ctx->stream, counts,
                      m + 1, ctx->s_tiles.p);
-  hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kScanBlock), 0, ctx->stream, ctx->s_tiles.p, tiles,
+  hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kScanSingle), 0, ctx->stream, ctx->s_tiles.p, tiles,
                      static_cast<unsigned long long *>(nullptr));
   hipLaunchKernelGGL(k_scan_apply, dim3(static_cast<uint32_t>(tiles)), dim3(kScanBlock), 0, ctx->stream, counts, m + 1,
                      ctx->s_tiles.p, counts);
@@ -2009,7 +2009,7 @@ static int vgd_emit(pcp_context *ctx, const VgdStream &S, int64_t word0, int64_t
     {
       LaunchTimer t(ctx, PCP_K_MLS_VOXEL);
       hipLaunchKernelGGL(k_scan_tile_sums, dim3(scan_grid(tiles2)), dim3(kScanBlock), 0, ctx->stream, tile_first, tiles, level2);
-      hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kScanBlock), 0, ctx->stream, level2, tiles2,
+      hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kScanSingle), 0, ctx->stream, level2, tiles2,
                          static_cast<unsigned long long *>(nullptr));
       hipLaunchKernelGGL(k_scan_apply, dim3(scan_grid(tiles2)), dim3(kScanBlock), 0, ctx->stream, tile_first, tiles, level2, tile_first);
       hipLaunchKernelGGL(k_voxel_expand, dim3(scan_grid(tiles)), dim3(kScanBlock), 0, ctx->stream, ctx->v_bitmap.p + word0, tile_first,
