@@ -1112,13 +1112,42 @@ __global__ __launch_bounds__(kBlock) void k_require_pixel(const float *__restric
   if (project_point(cam, fr.w2c, x[i], y[i], z[i]).pixel < 0) keep[i] = 0;
 }
 
-// PCP_CULL_HPR, whole run: bit `bit` of word[j] = keep flag of the point at place j of the Morton order
-__global__ __launch_bounds__(kBlock) void k_hull_bits(const uint8_t *__restrict__ keep, const int32_t *__restrict__ perm,
-                                                      int64_t n, uint32_t *__restrict__ word, uint32_t bit) {
+// PCP_CULL_HPR, whole run: bit `bit` of word[j] = keep flag of the point at place j of the sorted order.  The keep flags
+// are in input order and few of them are set (the hull vertices among the candidates of one keyframe: 1-4 % of the map), so
+// the plane's bit is cleared with a streaming pass (or the whole plane with a memset when its 32 keyframes are all being
+// produced) and the set flags are scattered through inv_perm -- the first form read keep[perm[j]] for every place: a random
+// byte gather over the whole map, 117 us per keyframe at 10 M points.
+__global__ __launch_bounds__(kBlock) void k_hull_clear(uint32_t *__restrict__ word, int64_t n, uint32_t bit) {
   const int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (j >= n) return;
-  const uint32_t w = word[j];
-  word[j] = keep[perm[j]] ? (w | bit) : (w & ~bit);
+  if (j < n) word[j] &= ~bit;
+}
+
+__global__ __launch_bounds__(kBlock) void k_hull_set(const uint8_t *__restrict__ keep, const int32_t *__restrict__ inv_perm,
+                                                     int64_t n, uint32_t *__restrict__ word, uint32_t bit) {
+  const int64_t i0 = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * 4;
+  if (i0 >= n) return;
+  uint32_t four = 0;
+  if (i0 + 4 <= n) {
+    four = *reinterpret_cast<const uint32_t *>(keep + i0);
+  } else {
+    for (int k = 0; k < 4 && i0 + k < n; ++k) four |= static_cast<uint32_t>(keep[i0 + k]) << (8 * k);
+  }
+  if (four == 0) return;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if ((four >> (8 * k)) & 0xffu) atomicOr(word + inv_perm[i0 + k], bit);
+}
+
+// ctx->s_keep (input order) -> bit f of the hull bits; plane_clear: the plane of f has just been zeroed
+static int store_hull_bits(pcp_context *ctx, int32_t f, bool plane_clear) {
+  uint32_t *plane = ctx->hull_bits.p + static_cast<size_t>(f >> 5) * static_cast<size_t>(ctx->n);
+  const uint32_t bit = 1u << (f & 31);
+  LaunchTimer t(ctx, PCP_K_HPR);
+  if (!plane_clear) hipLaunchKernelGGL(k_hull_clear, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, plane, ctx->n, bit);
+  hipLaunchKernelGGL(k_hull_set, dim3(blocks_for((ctx->n + 3) / 4)), dim3(kBlock), 0, ctx->stream, ctx->s_keep.p, ctx->inv_perm.p,
+                     ctx->n, plane, bit);
+  PCP_HIP_TRY(ctx, hipGetLastError());
+  return PCP_OK;
 }
 
 // the inverse: keep flags (input order) of one keyframe from the hull bits (pcp_hull_flags_import on an index shard)
@@ -1617,13 +1646,15 @@ int pcp_depth_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
     int rch = ensure_hull_bits(ctx);
     if (rch != PCP_OK) return rch;
     // an index shard (PCP_DEPTH_BATCHED) cannot take a hull: its bits come through pcp_hull_flags_import
+    int32_t clear_until = frame_begin;  // keyframes below this one have their plane zeroed already
     for (int32_t f = frame_begin; f < frame_end && !ctx->depth_from_batch; ++f) {
+      if ((f & 31) == 0 && std::min(f + 32, ctx->n_frames) <= frame_end) {  // all keyframes of this plane are coming
+        PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->hull_bits.p + static_cast<size_t>(f >> 5) * static_cast<size_t>(ctx->n), 0,
+                                        static_cast<size_t>(ctx->n) * 4, ctx->stream));
+        clear_until = std::min(f + 32, ctx->n_frames);
+      }
       if ((rc = frame_keep_flags(ctx, f, false)) != PCP_OK) return rc;
-      LaunchTimer t(ctx, PCP_K_HPR);
-      hipLaunchKernelGGL(k_hull_bits, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, ctx->s_keep.p, ctx->perm.p,
-                         ctx->n, ctx->hull_bits.p + static_cast<size_t>(f >> 5) * static_cast<size_t>(ctx->n),
-                         1u << (f & 31));
-      PCP_HIP_TRY(ctx, hipGetLastError());
+      if ((rc = store_hull_bits(ctx, f, f < clear_until)) != PCP_OK) return rc;
     }
   }
   for (int32_t f = frame_begin; f < frame_end; ++f) ctx->depth_valid[static_cast<size_t>(f)] = 1;
@@ -1661,10 +1692,7 @@ int pcp_hull_flags_import(pcp_context *ctx, int32_t frame, const uint8_t *keep) 
   if (ctx->n > 0) {
     PCP_HIP_TRY(ctx, ctx->s_keep.ensure(static_cast<size_t>(ctx->n) + 16));
     PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->s_keep.p, keep, static_cast<size_t>(ctx->n), hipMemcpyDefault, ctx->stream));
-    LaunchTimer t(ctx, PCP_K_HPR);
-    hipLaunchKernelGGL(k_hull_bits, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, ctx->s_keep.p, ctx->perm.p, ctx->n,
-                       ctx->hull_bits.p + static_cast<size_t>(frame >> 5) * static_cast<size_t>(ctx->n), 1u << (frame & 31));
-    PCP_HIP_TRY(ctx, hipGetLastError());
+    if ((rc = store_hull_bits(ctx, frame, false)) != PCP_OK) return rc;
     PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the caller's buffer is free again
   }
   ctx->hull_valid[static_cast<size_t>(frame)] = 1;
