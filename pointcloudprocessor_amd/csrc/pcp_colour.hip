@@ -1181,19 +1181,19 @@ static int frame_keep_flags(pcp_context *ctx, int32_t frame, bool require_pixel)
     PCP_HIP_TRY(ctx, hipGetLastError());
     return PCP_OK;
   }
-  {
+  if (!hull) {
     LaunchTimer t(ctx, PCP_K_VISIBILITY);
     PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->s_keep.p, 0, static_cast<size_t>(n), ctx->stream));
     hipLaunchKernelGGL(k_visibility, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, ctx->sxyz.p,
                        ctx->sxyz.p + plane, ctx->sxyz.p + 2 * plane, n, ctx->dcam,
                        ctx->hframes[static_cast<size_t>(frame)], ctx->s_u32.p, ctx->perm.p, ctx->s_keep.p,
-                       (require_pixel && !hull) ? 1 : 0);
+                       require_pixel ? 1 : 0);
     PCP_HIP_TRY(ctx, hipGetLastError());
+    return PCP_OK;
   }
-  if (!hull) return PCP_OK;
-  // the hull is taken over EVERY candidate (view_culling.cpp:276-288 knows nothing of the image's own size); the
-  // colour bounds apply to what it keeps
-  int rc = hpr_refine_flags(ctx, frame, ctx->s_keep.p);
+  // the hull is taken over EVERY candidate (view_culling.cpp:276-288 knows nothing of the image's own size; pcp_hpr.hip
+  // finds them itself); the colour bounds apply to what it keeps
+  int rc = hpr_run(ctx, frame, ctx->s_keep.p, nullptr, 0u);
   if (rc != PCP_OK) return rc;
   if (require_pixel) {
     LaunchTimer t(ctx, PCP_K_VISIBILITY);
@@ -1653,8 +1653,13 @@ int pcp_depth_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
                                         static_cast<size_t>(ctx->n) * 4, ctx->stream));
         clear_until = std::min(f + 32, ctx->n_frames);
       }
-      if ((rc = frame_keep_flags(ctx, f, false)) != PCP_OK) return rc;
-      if ((rc = store_hull_bits(ctx, f, f < clear_until)) != PCP_OK) return rc;
+      // (no flags of the whole map in between: the hull routine sets the bit at the sorted place of every hull vertex)
+      uint32_t *hull_plane = ctx->hull_bits.p + static_cast<size_t>(f >> 5) * static_cast<size_t>(ctx->n);
+      if (f >= clear_until) {
+        LaunchTimer t(ctx, PCP_K_HPR);
+        hipLaunchKernelGGL(k_hull_clear, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, hull_plane, ctx->n, 1u << (f & 31));
+      }
+      if ((rc = hpr_run(ctx, f, nullptr, hull_plane, 1u << (f & 31))) != PCP_OK) return rc;
     }
   }
   for (int32_t f = frame_begin; f < frame_end; ++f) ctx->depth_valid[static_cast<size_t>(f)] = 1;

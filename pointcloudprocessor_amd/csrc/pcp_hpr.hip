@@ -562,36 +562,58 @@ __device__ __forceinline__ int tetra_contains_filtered(const Vec3d &p, const Vec
 // kernels
 // ------------------------------------------------------------------------------------------------------------------
 
-// flipped points of the candidates (view_culling.cpp:291-292), their gnomonic coordinates, and the bounds of both
-__global__ __launch_bounds__(kHprBlock) void k_hpr_prepare(const float *__restrict__ x, const float *__restrict__ y,
-                                                           const float *__restrict__ z, DevFrame fr,
-                                                           const int32_t *__restrict__ index, int32_t m, double flip_radius,
-                                                           double *__restrict__ px, double *__restrict__ py,
-                                                           double *__restrict__ pz, double *__restrict__ ga,
-                                                           double *__restrict__ gb, double *__restrict__ rho,
-                                                           unsigned long long *__restrict__ bounds) {
-  const int32_t k = static_cast<int32_t>(blockIdx.x) * kHprBlock + static_cast<int32_t>(threadIdx.x);
-  unsigned long long amin = ~0ull, amax = 0ull, bmin = ~0ull, bmax = 0ull;
-  if (k < m) {
-    const int32_t i = index[k];
-    float xc, yc, zc;
-    xform(fr.w2c, x[i], y[i], z[i], xc, yc, zc);
-    // pt_norm = pt.head<3>().norm(); flipped = pt + 2.0 * (max_z - pt_norm) * pt / pt_norm, per coefficient
-    // x + ((2.0 * (R - norm)) * x) / norm on the promoted camera coordinates
-    const double X = xc, Y = yc, Z = zc;
-    const double norm = sqrt((X * X + Y * Y) + Z * Z);
-    const double s = 2.0 * (flip_radius - norm);
-    const double fx = X + (s * X) / norm, fy = Y + (s * Y) / norm, fz = Z + (s * Z) / norm;
-    px[k] = fx;
-    py[k] = fy;
-    pz[k] = fz;
-    const double a = fx / fz, b = fy / fz;
-    ga[k] = a;
-    gb[k] = b;
-    rho[k] = sqrt((fx * fx + fy * fy) + fz * fz) * (1.0 + 1.0e-15);  // an upper bound of the norm
-    amin = amax = order_key(a);
-    bmin = bmax = order_key(b);
+// The candidates of one keyframe straight from the SORTED copy of the cloud (the order the batched passes walk): the filter
+// of view_culling.cpp:276-288 (project_point's cull cell), the flip, the gnomonic coordinates and their bounds in one kernel,
+// appended wavefront by wavefront to the candidate arrays -- no flag array of the whole map, no compaction, no second
+// gather of the coordinates by index, and the host learns the count and the bounds in ONE wait.  place[] keeps the point's
+// place in the sorted order (the whole-run bits are addressed by it), index[] its input index (the duplicate rule and the
+// flags of pcp_cull_frame).  The order of the candidates is whatever the appends make it; no result depends on it.
+constexpr int kStatCandidates = 20;  // block 0 of the tallies: number of candidates (a cache line away from the bounds)
+__global__ __launch_bounds__(kHprBlock) void k_hpr_candidates(const float *__restrict__ x, const float *__restrict__ y,
+                                                              const float *__restrict__ z, int64_t n, DevCamera cam, DevFrame fr,
+                                                              const int32_t *__restrict__ perm, double flip_radius,
+                                                              int64_t stride, int32_t *__restrict__ index,
+                                                              int32_t *__restrict__ place, double *__restrict__ f64,
+                                                              unsigned long long *__restrict__ stats) {
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * kHprBlock + threadIdx.x;
+  bool cand = false;
+  float xc = 0.0f, yc = 0.0f, zc = 0.0f;
+  if (j < n) {
+    const Projected p = project_point(cam, fr.w2c, x[j], y[j], z[j]);
+    cand = p.cell != -1;
+    xc = p.xc;
+    yc = p.yc;
+    zc = p.zc;
   }
+  const unsigned long long m = __ballot(cand);
+  unsigned long long amin = ~0ull, amax = 0ull, bmin = ~0ull, bmax = 0ull;
+  if (m) {
+    unsigned long long base = 0;
+    if (lane_id() == 0) base = atomicAdd(&stats[kStatCandidates], static_cast<unsigned long long>(__popcll(m)));
+    base = static_cast<unsigned long long>(__shfl(static_cast<long long>(base), 0, 64));
+    if (cand) {
+      const int64_t k = static_cast<int64_t>(base) + __popcll(m & ((1ull << lane_id()) - 1ull));
+      // pt_norm = pt.head<3>().norm(); flipped = pt + 2.0 * (max_z - pt_norm) * pt / pt_norm, per coefficient
+      // x + ((2.0 * (R - norm)) * x) / norm on the promoted camera coordinates (view_culling.cpp:291-292)
+      const double X = xc, Y = yc, Z = zc;
+      const double norm = sqrt((X * X + Y * Y) + Z * Z);
+      const double s = 2.0 * (flip_radius - norm);
+      const double fx = X + (s * X) / norm, fy = Y + (s * Y) / norm, fz = Z + (s * Z) / norm;
+      const double a = fx / fz, b = fy / fz;
+      f64[k] = fx;
+      f64[stride + k] = fy;
+      f64[2 * stride + k] = fz;
+      f64[3 * stride + k] = a;
+      f64[4 * stride + k] = b;
+      f64[5 * stride + k] = sqrt((fx * fx + fy * fy) + fz * fz) * (1.0 + 1.0e-15);  // an upper bound of the norm
+      index[k] = perm ? perm[j] : static_cast<int32_t>(j);
+      place[k] = static_cast<int32_t>(j);
+      amin = amax = order_key(a);
+      bmin = bmax = order_key(b);
+    }
+  }
+  // bounds: per wavefront, then one set of atomics per workgroup that holds a candidate
+  __shared__ unsigned long long part[kHprBlock / 64][4];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     amin = min(amin, static_cast<unsigned long long>(__shfl_xor(static_cast<long long>(amin), o, 64)));
@@ -599,8 +621,6 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_prepare(const float *__restri
     bmin = min(bmin, static_cast<unsigned long long>(__shfl_xor(static_cast<long long>(bmin), o, 64)));
     bmax = max(bmax, static_cast<unsigned long long>(__shfl_xor(static_cast<long long>(bmax), o, 64)));
   }
-  // one set of atomics per workgroup: the four bounds share a cache line, and atomics on one line queue up in the L2
-  __shared__ unsigned long long part[kHprBlock / 64][4];
   const int w = static_cast<int>(threadIdx.x >> 6);
   if (lane_id() == 0) {
     part[w][0] = amin;
@@ -617,10 +637,10 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_prepare(const float *__restri
       bmax = max(bmax, part[k][3]);
     }
     if (amax != 0ull) {
-      atomicMin(&bounds[0], amin);
-      atomicMax(&bounds[1], amax);
-      atomicMin(&bounds[2], bmin);
-      atomicMax(&bounds[3], bmax);
+      atomicMin(&stats[24], amin);
+      atomicMax(&stats[25], amax);
+      atomicMin(&stats[26], bmin);
+      atomicMax(&stats[27], bmax);
     }
   }
 }
@@ -642,11 +662,13 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_count(const double *__restric
 
 __global__ __launch_bounds__(kHprBlock) void k_hpr_scatter(const double *__restrict__ px, const double *__restrict__ py,
                                                            const double *__restrict__ pz, const double *__restrict__ rho,
-                                                           const int32_t *__restrict__ index, const int32_t *__restrict__ cell,
+                                                           const int32_t *__restrict__ index, const int32_t *__restrict__ place,
+                                                           const int32_t *__restrict__ cell,
                                                            int32_t m, const int32_t *__restrict__ cstart,
                                                            int32_t *__restrict__ cursor, double *__restrict__ sx,
                                                            double *__restrict__ sy, double *__restrict__ sz,
-                                                           int32_t *__restrict__ sidx, int32_t *__restrict__ scell,
+                                                           int32_t *__restrict__ sidx, int32_t *__restrict__ splace,
+                                                           int32_t *__restrict__ scell,
                                                            int32_t *__restrict__ scand, unsigned long long *__restrict__ crho_bits,
                                                            unsigned long long *__restrict__ crep) {
   const int32_t k = static_cast<int32_t>(blockIdx.x) * kHprBlock + static_cast<int32_t>(threadIdx.x);
@@ -657,6 +679,7 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_scatter(const double *__restr
   sy[pos] = py[k];
   sz[pos] = pz[k];
   sidx[pos] = index[k];
+  splace[pos] = place[k];
   scell[pos] = c;
   scand[pos] = k;
   const unsigned long long rb = static_cast<unsigned long long>(__double_as_longlong(rho[k]));
@@ -1136,6 +1159,13 @@ __global__ __launch_bounds__(64) void k_hpr_exact(HprArrays A, HprGrid G, double
   }
 }
 
+// whole-run bits (pcp_colour.hip, hull_bits): bit of the keyframe at the sorted place of every hull vertex (plane cleared)
+__global__ __launch_bounds__(kHprBlock) void k_hpr_set_bits(const uint8_t *__restrict__ state, const int32_t *__restrict__ splace,
+                                                            int32_t m, uint32_t *__restrict__ word, uint32_t bit) {
+  const int32_t k = static_cast<int32_t>(blockIdx.x) * kHprBlock + static_cast<int32_t>(threadIdx.x);
+  if (k < m && state[k] == kStVisible) atomicOr(word + splace[k], bit);
+}
+
 // keep flags (input order): the candidate flags become the visible flags
 __global__ __launch_bounds__(kHprBlock) void k_hpr_writeback(const uint8_t *__restrict__ state, const int32_t *__restrict__ sidx,
                                                              int32_t m, uint8_t *__restrict__ keep) {
@@ -1161,36 +1191,23 @@ static int hpr_scan(pcp_context *ctx, int32_t *counts, int64_t entries) {
   return PCP_OK;
 }
 
-// Turns the candidate flags of one keyframe (input order, n bytes on the device: 1 = passes the filter of
-// view_culling.cpp:276-288) into the flags of hidden_points_removal's output: 1 = hull vertex.
-int hpr_refine_flags(pcp_context *ctx, int32_t frame, uint8_t *d_flags) {
+// hidden_points_removal of one keyframe: the candidates (the filter of view_culling.cpp:276-288) from the sorted copy of the
+// cloud, then the hull.  Two outputs, each optional: d_flags (n bytes on the device, input order: 1 = hull vertex), and the
+// keyframe's bit in a CLEARED plane of the whole-run bits (hull_plane[place in the sorted order] |= bit).
+int hpr_run(pcp_context *ctx, int32_t frame, uint8_t *d_flags, uint32_t *hull_plane, uint32_t bit) {
   const int64_t n = ctx->n;
   if (n == 0) return PCP_OK;
+  if (n >= (int64_t(1) << 31)) return set_error(ctx, PCP_ERR_RANGE, "hidden_points_removal: %lld points (fewer than 2^31 are handled)", (long long)n);
+  const size_t cap = static_cast<size_t>(n);  // every point may be a candidate
   const size_t plane = (static_cast<size_t>(n) + 3) & ~size_t(3);
-  PCP_HIP_TRY(ctx, ctx->h_index.ensure(static_cast<size_t>(n) + 4));
-  int64_t m64 = 0;
-  int rc = compact_flags(ctx, d_flags, n, ctx->h_index.p, n, &m64);
-  if (rc != PCP_OK) return rc;
-  std::memset(ctx->hpr_stats, 0, sizeof(ctx->hpr_stats));
-  ctx->hpr_stats_pending = false;
-  ctx->hpr_stats[9] = m64;
-  if (m64 < 3) {
-    // qhull needs dim + 1 points (here: three candidates and the origin); with fewer it fails and the reference
-    // returns no visible point (view_culling.cpp:307-312)
-    PCP_HIP_TRY(ctx, hipMemsetAsync(d_flags, 0, static_cast<size_t>(n), ctx->stream));
-    return PCP_OK;
-  }
-  const int32_t m = static_cast<int32_t>(m64);
-  const size_t sm = static_cast<size_t>(m);
-  // doubles: px py pz ga gb rho | sx sy sz
-  PCP_HIP_TRY(ctx, ctx->h_f64.ensure(9 * sm + 16));
-  double *px = ctx->h_f64.p, *py = px + sm, *pz = py + sm, *ga = pz + sm, *gb = ga + sm, *rho = gb + sm;
-  double *sx = rho + sm, *sy = sx + sm, *sz = sy + sm;
-  // ints: cell | sidx scell scand | undecided
-  PCP_HIP_TRY(ctx, ctx->h_i32.ensure(5 * sm + 16));
-  int32_t *cell = ctx->h_i32.p, *sidx = cell + sm, *scell = sidx + sm, *scand = scell + sm, *undecided = scand + sm;
-  PCP_HIP_TRY(ctx, ctx->h_state.ensure(sm + 16));
+  int rc = PCP_OK;
+  // doubles: px py pz ga gb rho | sx sy sz, `cap` apart; ints: candidate's input index | its place in the sorted order
+  PCP_HIP_TRY(ctx, ctx->h_f64.ensure(9 * cap + 16));
+  PCP_HIP_TRY(ctx, ctx->h_index.ensure(2 * cap + 16));
   PCP_HIP_TRY(ctx, ctx->h_stats.ensure(kStatStride * (1 + kStatCopies)));
+  double *px = ctx->h_f64.p, *py = px + cap, *pz = py + cap, *ga = pz + cap, *gb = ga + cap, *rho = gb + cap;
+  double *sx = rho + cap, *sy = sx + cap, *sz = sy + cap;
+  int32_t *cidx = ctx->h_index.p, *cplace = cidx + cap;
   unsigned long long *bounds = ctx->h_stats.p + 24, *stats = ctx->h_stats.p;
   {
     const unsigned long long init[4] = {~0ull, 0ull, ~0ull, 0ull};
@@ -1200,14 +1217,31 @@ int hpr_refine_flags(pcp_context *ctx, int32_t frame, uint8_t *d_flags) {
   const DevFrame &fr = ctx->hframes[static_cast<size_t>(frame)];
   {
     LaunchTimer t(ctx, PCP_K_HPR);
-    hipLaunchKernelGGL(k_hpr_prepare, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, ctx->stream, ctx->xyz.p, ctx->xyz.p + plane,
-                       ctx->xyz.p + 2 * plane, fr, ctx->h_index.p, m, ctx->cull.hpr_flip_radius, px, py, pz, ga, gb, rho,
-                       bounds);
+    hipLaunchKernelGGL(k_hpr_candidates, dim3(hpr_blocks(n)), dim3(kHprBlock), 0, ctx->stream, ctx->sxyz.p, ctx->sxyz.p + plane,
+                       ctx->sxyz.p + 2 * plane, n, ctx->dcam, fr, ctx->perm.p, ctx->cull.hpr_flip_radius, static_cast<int64_t>(cap),
+                       cidx, cplace, px, stats);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
-  unsigned long long hb[4];
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(hb, bounds, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
+  unsigned long long hb8[8];  // block 0 of the tallies, words 20..27: [0] = candidates, [4..7] = the bounds
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(hb8, stats + kStatCandidates, sizeof(hb8), hipMemcpyDeviceToHost, ctx->stream));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const int64_t m64 = static_cast<int64_t>(hb8[0]);
+  const unsigned long long *hb = hb8 + 4;
+  std::memset(ctx->hpr_stats, 0, sizeof(ctx->hpr_stats));
+  ctx->hpr_stats_pending = false;
+  ctx->hpr_stats[9] = m64;
+  if (d_flags) PCP_HIP_TRY(ctx, hipMemsetAsync(d_flags, 0, static_cast<size_t>(n), ctx->stream));  // the hull vertices are set below
+  if (m64 < 3) {
+    // qhull needs dim + 1 points (here: three candidates and the origin); with fewer it fails and the reference
+    // returns no visible point (view_culling.cpp:307-312)
+    return PCP_OK;
+  }
+  const int32_t m = static_cast<int32_t>(m64);
+  const size_t sm = static_cast<size_t>(m);
+  // ints: cell | sidx splace scell scand | undecided
+  PCP_HIP_TRY(ctx, ctx->h_i32.ensure(6 * sm + 16));
+  int32_t *cell = ctx->h_i32.p, *sidx = cell + sm, *splace = sidx + sm, *scell = splace + sm, *scand = scell + sm, *undecided = scand + sm;
+  PCP_HIP_TRY(ctx, ctx->h_state.ensure(sm + 16));
   const double amin = key_to_double(hb[0]), amax = key_to_double(hb[1]), bmin = key_to_double(hb[2]), bmax = key_to_double(hb[3]);
   if (!(std::isfinite(amin) && std::isfinite(amax) && std::isfinite(bmin) && std::isfinite(bmax)))
     return set_error(ctx, PCP_ERR_INVALID, "hidden_points_removal: non-finite flipped coordinates (flip radius %g)",
@@ -1265,8 +1299,8 @@ int hpr_refine_flags(pcp_context *ctx, int32_t frame, uint8_t *d_flags) {
     LaunchTimer t(ctx, PCP_K_HPR);
     hipLaunchKernelGGL(k_hpr_count, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, ctx->stream, ga, gb, G, cell, cstart);
     if ((rc = hpr_scan(ctx, cstart, n_fine + 1)) != PCP_OK) return rc;
-    hipLaunchKernelGGL(k_hpr_scatter, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, ctx->stream, px, py, pz, rho, ctx->h_index.p,
-                       cell, m, cstart, cursor, sx, sy, sz, sidx, scell, scand,
+    hipLaunchKernelGGL(k_hpr_scatter, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, ctx->stream, px, py, pz, rho, cidx, cplace,
+                       cell, m, cstart, cursor, sx, sy, sz, sidx, splace, scell, scand,
                        reinterpret_cast<unsigned long long *>(crho), crep);
     hipLaunchKernelGGL(k_hpr_cells, dim3(hpr_blocks(std::max(n_fine, n_coarse))), dim3(kHprBlock), 0, ctx->stream, G,
                        reinterpret_cast<const unsigned long long *>(crho), cdir, Crho, Cdir, stats + 28);
@@ -1314,7 +1348,10 @@ int hpr_refine_flags(pcp_context *ctx, int32_t frame, uint8_t *d_flags) {
   }
   {
     LaunchTimer t(ctx, PCP_K_HPR);
-    hipLaunchKernelGGL(k_hpr_writeback, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, ctx->stream, ctx->h_state.p, sidx, m, d_flags);
+    if (d_flags)
+      hipLaunchKernelGGL(k_hpr_writeback, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, ctx->stream, ctx->h_state.p, sidx, m, d_flags);
+    if (hull_plane)
+      hipLaunchKernelGGL(k_hpr_set_bits, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, ctx->stream, ctx->h_state.p, splace, m, hull_plane, bit);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   ctx->hpr_stats[8] = n_fine;

@@ -284,7 +284,7 @@ int cull_frame_indices(pcp_context *ctx, int32_t frame, int32_t *d_index, int64_
 
 // hidden_points_removal's hull over the candidate flags of one keyframe (pcp_hpr.hip): flags (input order, device)
 // in: 1 = candidate; out: 1 = hull vertex
-int hpr_refine_flags(pcp_context *ctx, int32_t frame, uint8_t *d_flags);
+int hpr_run(pcp_context *ctx, int32_t frame, uint8_t *d_flags, uint32_t *hull_plane, uint32_t bit);
 
 inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
