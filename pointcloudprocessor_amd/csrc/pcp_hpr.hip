@@ -587,10 +587,24 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_candidates(const float *__res
   }
   const unsigned long long m = __ballot(cand);
   unsigned long long amin = ~0ull, amax = 0ull, bmin = ~0ull, bmax = 0ull;
+  // places in the candidate arrays: ONE atomic per workgroup that holds candidates (an atomic per wavefront on the one
+  // counter queues up in its L2 channel: ~15 k of them per keyframe cost more than the projection).  Most workgroups hold
+  // none -- the cloud is in spatial order, a keyframe sees a few per cent of it -- and leave at the first barrier.
+  __shared__ uint32_t wave_count[kHprBlock / 64];
+  __shared__ unsigned long long block_base;
+  __shared__ unsigned long long part[kHprBlock / 64][4];
+  const int w = static_cast<int>(threadIdx.x >> 6);
+  if (lane_id() == 0) wave_count[w] = static_cast<uint32_t>(__popcll(m));
+  if (!__syncthreads_or(m != 0ull ? 1 : 0)) return;
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+    for (int k = 0; k < kHprBlock / 64; ++k) total += wave_count[k];
+    block_base = atomicAdd(&stats[kStatCandidates], static_cast<unsigned long long>(total));
+  }
+  __syncthreads();
   if (m) {
-    unsigned long long base = 0;
-    if (lane_id() == 0) base = atomicAdd(&stats[kStatCandidates], static_cast<unsigned long long>(__popcll(m)));
-    base = static_cast<unsigned long long>(__shfl(static_cast<long long>(base), 0, 64));
+    unsigned long long base = block_base;
+    for (int k = 0; k < w; ++k) base += wave_count[k];
     if (cand) {
       const int64_t k = static_cast<int64_t>(base) + __popcll(m & ((1ull << lane_id()) - 1ull));
       // pt_norm = pt.head<3>().norm(); flipped = pt + 2.0 * (max_z - pt_norm) * pt / pt_norm, per coefficient
@@ -612,16 +626,17 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_candidates(const float *__res
       bmin = bmax = order_key(b);
     }
   }
-  // bounds: per wavefront, then one set of atomics per workgroup that holds a candidate
-  __shared__ unsigned long long part[kHprBlock / 64][4];
+  // bounds: per wavefront (a wavefront without a candidate skips the 24 64-bit shuffles), then one set of atomics per
+  // workgroup
+  if (m) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    amin = min(amin, static_cast<unsigned long long>(__shfl_xor(static_cast<long long>(amin), o, 64)));
-    amax = max(amax, static_cast<unsigned long long>(__shfl_xor(static_cast<long long>(amax), o, 64)));
-    bmin = min(bmin, static_cast<unsigned long long>(__shfl_xor(static_cast<long long>(bmin), o, 64)));
-    bmax = max(bmax, static_cast<unsigned long long>(__shfl_xor(static_cast<long long>(bmax), o, 64)));
+    for (int o = 32; o > 0; o >>= 1) {
+      amin = min(amin, static_cast<unsigned long long>(__shfl_xor(static_cast<long long>(amin), o, 64)));
+      amax = max(amax, static_cast<unsigned long long>(__shfl_xor(static_cast<long long>(amax), o, 64)));
+      bmin = min(bmin, static_cast<unsigned long long>(__shfl_xor(static_cast<long long>(bmin), o, 64)));
+      bmax = max(bmax, static_cast<unsigned long long>(__shfl_xor(static_cast<long long>(bmax), o, 64)));
+    }
   }
-  const int w = static_cast<int>(threadIdx.x >> 6);
   if (lane_id() == 0) {
     part[w][0] = amin;
     part[w][1] = amax;
@@ -636,11 +651,15 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_candidates(const float *__res
       bmin = min(bmin, part[k][2]);
       bmax = max(bmax, part[k][3]);
     }
+    // kStatCopies copies of the bounds, each on a line of its own (thousands of atomics on ONE line queue up in its L2
+    // channel: ~7 ns each, 60-120 us per keyframe); the minima as maxima of the inverted keys, so that zeroed memory is
+    // the identity of all four; the host folds the copies
+    unsigned long long *mine = stats + kStatStride * (1 + (blockIdx.x % kStatCopies)) + 24;
     if (amax != 0ull) {
-      atomicMin(&stats[24], amin);
-      atomicMax(&stats[25], amax);
-      atomicMin(&stats[26], bmin);
-      atomicMax(&stats[27], bmax);
+      atomicMax(&mine[0], ~amin);
+      atomicMax(&mine[1], amax);
+      atomicMax(&mine[2], ~bmin);
+      atomicMax(&mine[3], bmax);
     }
   }
 }
@@ -1208,12 +1227,8 @@ int hpr_run(pcp_context *ctx, int32_t frame, uint8_t *d_flags, uint32_t *hull_pl
   double *px = ctx->h_f64.p, *py = px + cap, *pz = py + cap, *ga = pz + cap, *gb = ga + cap, *rho = gb + cap;
   double *sx = rho + cap, *sy = sx + cap, *sz = sy + cap;
   int32_t *cidx = ctx->h_index.p, *cplace = cidx + cap;
-  unsigned long long *bounds = ctx->h_stats.p + 24, *stats = ctx->h_stats.p;
-  {
-    const unsigned long long init[4] = {~0ull, 0ull, ~0ull, 0ull};
-    PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->h_stats.p, 0, kStatStride * (1 + kStatCopies) * sizeof(unsigned long long), ctx->stream));
-    PCP_HIP_TRY(ctx, hipMemcpyAsync(bounds, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-  }
+  unsigned long long *stats = ctx->h_stats.p;
+  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->h_stats.p, 0, kStatStride * (1 + kStatCopies) * sizeof(unsigned long long), ctx->stream));
   const DevFrame &fr = ctx->hframes[static_cast<size_t>(frame)];
   {
     LaunchTimer t(ctx, PCP_K_HPR);
@@ -1222,11 +1237,16 @@ int hpr_run(pcp_context *ctx, int32_t frame, uint8_t *d_flags, uint32_t *hull_pl
                        cidx, cplace, px, stats);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
-  unsigned long long hb8[8];  // block 0 of the tallies, words 20..27: [0] = candidates, [4..7] = the bounds
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(hb8, stats + kStatCandidates, sizeof(hb8), hipMemcpyDeviceToHost, ctx->stream));
+  // the number of candidates (block 0) and the copies of the bounds (words 24..27 of the other blocks), one download
+  std::vector<unsigned long long> hall(kStatStride * (1 + kStatCopies));
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(hall.data(), stats, hall.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  const int64_t m64 = static_cast<int64_t>(hb8[0]);
-  const unsigned long long *hb = hb8 + 4;
+  const int64_t m64 = static_cast<int64_t>(hall[kStatCandidates]);
+  unsigned long long hb[4] = {0ull, 0ull, 0ull, 0ull};
+  for (int c = 1; c <= kStatCopies; ++c)
+    for (int k = 0; k < 4; ++k) hb[k] = std::max(hb[k], hall[static_cast<size_t>(kStatStride * c + 24 + k)]);
+  hb[0] = ~hb[0];  // the minima were kept as maxima of the inverted keys
+  hb[2] = ~hb[2];
   std::memset(ctx->hpr_stats, 0, sizeof(ctx->hpr_stats));
   ctx->hpr_stats_pending = false;
   ctx->hpr_stats[9] = m64;
