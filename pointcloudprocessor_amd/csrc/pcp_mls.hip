@@ -327,7 +327,7 @@ __device__ __forceinline__ float sqdist_f32(float ax, float ay, float az, float 
 // every lane busy (in the plain double loop only the ~35 % of lanes whose current candidate is
 // inside the radius do fp64 work).  Lanes whose neighbourhood does not fit (K > kMaxNbr, a run
 // longer than 4096 points, or a grid with reach > 1) take the plain loops.
-constexpr int kMaxNbr = 88;  // 13.3 KB of LDS per wavefront: 12 wavefronts per CU, what the 140 VGPRs allow (96: 11 wavefronts, fit +3 %;
+constexpr int kMaxNbr = 87;  // 13.3 KB of LDS per wavefront: 12 wavefronts per CU, what the 140 VGPRs allow (96: 11 wavefronts, fit +3 %;
                              // 72: the 4.6 % of lanes with more neighbours take the plain loops, fit +38 %)
 constexpr int kMaxRun = 9;
 constexpr int kFitBlock = 64;
@@ -336,7 +336,7 @@ constexpr int kFitBlock = 64;
 // lane: one shift per candidate instead of three 64-bit addresses); needs n < 2^30 points.
 template <bool kBuf>
 __global__ __launch_bounds__(kFitBlock) void k_mls_fit(MlsArgs a) {
-  __shared__ uint16_t nbr_code[kMaxNbr][kFitBlock];
+  __shared__ uint16_t nbr_code[kMaxNbr + 1][kFitBlock];  // + the row that takes the writes once the list is full
   __shared__ int32_t run_base[kMaxRun][kFitBlock];
   const uint32_t plane_bytes = kBuf ? static_cast<uint32_t>(a.n) * 4u : 0u;
   const auto rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.sx), 0, plane_bytes, 0x00020000);
@@ -388,11 +388,11 @@ __global__ __launch_bounds__(kFitBlock) void k_mls_fit(MlsArgs a) {
       const int32_t b = rb[r], e = re[r];
       run_base[r][tid] = b;
       if (e - b > 4096) fast = false;
+      // branch-free: every candidate is written to the list's next free row (a hit keeps it by moving on, a miss is
+      // overwritten by the next candidate); row kMaxNbr takes what comes after the list is full
       auto append = [&](bool hit, int32_t k) {
-        if (hit) {
-          if (K < kMaxNbr) nbr_code[K][tid] = static_cast<uint16_t>((r << 12) | ((k - b) & 4095));
-          ++K;
-        }
+        nbr_code[min(K, kMaxNbr)][tid] = static_cast<uint16_t>((r << 12) | ((k - b) & 4095));
+        K += hit ? 1 : 0;
       };
       if constexpr (kBuf) {
         // four candidates per trip: one 16-byte load per coordinate plane (dword alignment suffices for buffer loads),
