@@ -913,12 +913,38 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_radial(HprArrays A, HprGrid G
 
 // stats: [0] hidden [1] visible [2] undecided [3] trial normals [4] batches of 64 point tests [5] second-box retries
 // [6] unresolved [7] exact predicate evaluations [8] length of the list for k_hpr_exact
-__global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_hpr_decide(HprArrays A, HprGrid G, uint8_t *__restrict__ state,
-                                                          int32_t *__restrict__ undecided,
-                                                          unsigned long long *__restrict__ stats, int32_t force_exact) {
-  const int32_t j = static_cast<int32_t>(blockIdx.x) * (kHprBlock / 64) + static_cast<int32_t>(threadIdx.x >> 6);
-  if (j >= G.m) return;
-  if (state[j] != kStUndecided) return;  // k_hpr_radial certified it
+// The candidates the passes in front left undecided, as a list (any order): the searches then run on wavefronts that all have
+// work.  Launched over every candidate, nine wavefronts in ten found theirs decided and left after one load -- and the
+// dispatcher could not refill the slots as fast as they emptied: 1.15 resident wavefronts per SIMD of the 3 the registers
+// allow, vector ALU busy 28 % (profiles/r03m_hpr_pmc.json).  One atomic per 1024 candidates.
+constexpr int kStatSearch = 21;  // block 0 of the tallies: length of the list
+constexpr int kHprListPer = 4;   // candidates per lane
+__global__ __launch_bounds__(kHprBlock) void k_hpr_list(const uint8_t *__restrict__ state, int32_t m, int32_t *__restrict__ list,
+                                                        unsigned long long *__restrict__ stats) {
+  __shared__ int32_t ws[kHprBlock / 64];
+  __shared__ unsigned long long block_base;
+  const int32_t base = (static_cast<int32_t>(blockIdx.x) * kHprBlock + static_cast<int32_t>(threadIdx.x)) * kHprListPer;
+  bool und[kHprListPer];
+  int32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < kHprListPer; ++k) {
+    und[k] = base + k < m && state[base + k] == kStUndecided;
+    c += und[k] ? 1 : 0;
+  }
+  int32_t total;
+  const int32_t ex = scan_block_exclusive(c, &total, ws);
+  if (total == 0) return;  // uniform
+  if (threadIdx.x == 0) block_base = atomicAdd(&stats[kStatSearch], static_cast<unsigned long long>(total));
+  __syncthreads();
+  int32_t at = static_cast<int32_t>(block_base) + ex;
+#pragma unroll
+  for (int k = 0; k < kHprListPer; ++k)
+    if (und[k]) list[at++] = base + k;
+}
+
+__device__ __forceinline__ void hpr_decide_one(const HprArrays &A, const HprGrid &G, int32_t j, uint8_t *__restrict__ state,
+                                               int32_t *__restrict__ undecided, unsigned long long *__restrict__ stats,
+                                               int32_t force_exact) {
   Search S;
   S.p = load_point(A, j);
   S.self = j;
@@ -955,6 +981,17 @@ __global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(3, 3)
     atomicAdd(&mine[4], S.tests);
     if (out == kStUndecided) undecided[atomicAdd(&stats[8], 1ull)] = j;
   }
+}
+
+// one wavefront per entry of the list, the wavefronts of a capped grid striding over it (its length is read on the device)
+constexpr int32_t kHprDecideGrid = 16384;
+__global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_hpr_decide(HprArrays A, HprGrid G, uint8_t *__restrict__ state,
+                                                          const int32_t *__restrict__ todo, int32_t *__restrict__ undecided,
+                                                          unsigned long long *__restrict__ stats, int32_t force_exact) {
+  const int32_t count = static_cast<int32_t>(stats[kStatSearch]);
+  const int32_t n_waves = static_cast<int32_t>(gridDim.x) * (kHprBlock / 64);
+  for (int32_t u = static_cast<int32_t>(blockIdx.x) * (kHprBlock / 64) + static_cast<int32_t>(threadIdx.x >> 6); u < count; u += n_waves)
+    hpr_decide_one(A, G, todo[u], state, undecided, stats, force_exact);
 }
 
 // ---- the exact path ----
@@ -1258,9 +1295,10 @@ int hpr_run(pcp_context *ctx, int32_t frame, uint8_t *d_flags, uint32_t *hull_pl
   }
   const int32_t m = static_cast<int32_t>(m64);
   const size_t sm = static_cast<size_t>(m);
-  // ints: cell | sidx splace scell scand | undecided
-  PCP_HIP_TRY(ctx, ctx->h_i32.ensure(6 * sm + 16));
+  // ints: cell | sidx splace scell scand | undecided | todo (the list of the searches)
+  PCP_HIP_TRY(ctx, ctx->h_i32.ensure(7 * sm + 16));
   int32_t *cell = ctx->h_i32.p, *sidx = cell + sm, *splace = sidx + sm, *scell = splace + sm, *scand = scell + sm, *undecided = scand + sm;
+  int32_t *todo = undecided + sm;
   PCP_HIP_TRY(ctx, ctx->h_state.ensure(sm + 16));
   const double amin = key_to_double(hb[0]), amax = key_to_double(hb[1]), bmin = key_to_double(hb[2]), bmax = key_to_double(hb[3]);
   if (!(std::isfinite(amin) && std::isfinite(amax) && std::isfinite(bmin) && std::isfinite(bmax)))
@@ -1339,8 +1377,10 @@ int hpr_run(pcp_context *ctx, int32_t frame, uint8_t *d_flags, uint32_t *hull_pl
       (void)hipMemcpyAsync(dbg_before.data(), ctx->h_state.p, sm, hipMemcpyDeviceToHost, ctx->stream);
       (void)hipStreamSynchronize(ctx->stream);
     }
-    hipLaunchKernelGGL(k_hpr_decide, dim3(static_cast<uint32_t>(div_up(m, kHprBlock / 64))), dim3(kHprBlock), 0, ctx->stream,
-                       A, G, ctx->h_state.p, undecided, stats, force_exact ? 1 : 0);
+    hipLaunchKernelGGL(k_hpr_list, dim3(static_cast<uint32_t>(div_up(m, kHprBlock * kHprListPer))), dim3(kHprBlock), 0, ctx->stream,
+                       ctx->h_state.p, m, todo, stats);
+    hipLaunchKernelGGL(k_hpr_decide, dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(m, kHprBlock / 64), kHprDecideGrid))), dim3(kHprBlock),
+                       0, ctx->stream, A, G, ctx->h_state.p, todo, undecided, stats, force_exact ? 1 : 0);
     if (!dbg_before.empty()) {
       std::vector<uint8_t> after(sm);
       (void)hipMemcpyAsync(after.data(), ctx->h_state.p, sm, hipMemcpyDeviceToHost, ctx->stream);
