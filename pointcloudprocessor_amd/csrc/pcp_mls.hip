@@ -1070,11 +1070,13 @@ __global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(6, 8))
   int32_t cx, cy, cz;
   grid_coords(g, qx, qy, qz, cx, cy, cz);
   const float cell = 1.0f / g.inv_cell;
-  // every point closer than one cell lies in the 27 cells; 0.999: fp32 slop of the cell assignment
-  const float limit = cell * 0.999f, limit2 = limit * limit;
-  const int32_t x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
-  const int32_t y0 = max(cy - 1, 0), y1 = min(cy + 1, g.ny - 1);
-  const int32_t z0 = max(cz - 1, 0), z1 = min(cz + 1, g.nz - 1);
+  // every point closer than g.reach cells lies in the (2 reach + 1)^3 cells; 0.999: fp32 slop of the cell assignment.
+  // (reach = 1 unless PCP_SOR_REACH says otherwise: see sor_run)
+  const int32_t sr = g.reach;
+  const float limit = static_cast<float>(sr) * cell * 0.999f, limit2 = limit * limit;
+  const int32_t x0 = max(cx - sr, 0), x1 = min(cx + sr, g.nx - 1);
+  const int32_t y0 = max(cy - sr, 0), y1 = min(cy + sr, g.ny - 1);
+  const int32_t z0 = max(cz - sr, 0), z1 = min(cz + sr, g.nz - 1);
   // level l splits [lo[l], lo[l] + 32 / sc[l]) into 32 bins; bnd[l] = its boundary bin (levels > `level` unused)
   float lo[kSelLevels] = {0.0f, 0.0f, 0.0f}, sc[kSelLevels] = {static_cast<float>(kSelBins) / limit2, 0.0f, 0.0f};
   int bnd[kSelLevels] = {0, 0, 0};
@@ -1386,7 +1388,8 @@ __global__ __launch_bounds__(kSelWave) void k_sor_wave(const float *__restrict__
     M += static_cast<int32_t>(__popcll(m));
   };
   // (a point k_sor_select found too few neighbours for within one cell starts with two)
-  for (int32_t R = redo[j] == 1 ? 2 : 1;; R = R < 4 ? R + 1 : R + R / 2) {
+  // (in units of the selection's own ball, g.reach cells: a sparse spot starts with two of them)
+  for (int32_t R = redo[j] == 1 ? 2 * g.reach : g.reach;; R = R < 4 * g.reach ? R + g.reach : R + R / 2) {
     const bool whole = R >= maxr;  // the block is the grid: every point is a candidate
     const float lim = static_cast<float>(R) * cell * 0.999f;  // 0.999: fp32 slop of the cell assignment
     T0 = whole ? INFINITY : lim * lim;
@@ -2283,7 +2286,13 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
       const double want = std::sqrt(ball * (mean_k + 1) / (3.14159265358979 * per_area));
       if (want > 0.0 && want < 1e30) final_cell = want;
     }
-    rc = build_grid(ctx, cv, static_cast<float>(final_cell), static_cast<float>(final_cell), &g);
+    // final_cell is the radius of the selection's ball; the cells are 1 / PCP_SOR_REACH of it.  Measured at C3: reach 1
+    // (27 cells, 9 runs per lane) sor 7.33 ms / grids 0.99 ms; reach 2 (125 half-size cells, 25 runs, 31 % fewer candidates
+    // on a surface) 7.64 / 1.65 ms; reach 3 9.88 / 3.01 ms -- the runs' fixed costs and ragged ends outweigh the candidates saved
+    int sel_reach = 1;
+    if (const char *e = std::getenv("PCP_SOR_REACH")) sel_reach = std::max(1, std::min(4, atoi(e)));
+    // (0.9999: reach = ceil(radius / cell) must not round up to sel_reach + 1)
+    rc = build_grid(ctx, cv, static_cast<float>(final_cell / sel_reach), static_cast<float>(final_cell * 0.9999), &g);
     if (rc != PCP_OK) return rc;
   }
   PCP_HIP_TRY(ctx, ctx->s_dist.ensure(sn + 8));
