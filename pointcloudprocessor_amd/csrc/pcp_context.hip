@@ -670,12 +670,10 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->intensity.release();
   ctx->h_index.release();
   ctx->h_i32.release();
-  ctx->h_cells_i.release();
   ctx->h_f64.release();
   ctx->h_cells_d.release();
   ctx->h_state.release();
   ctx->h_stats.release();
-  ctx->h_rep.release();
   ctx->hull_bits.release();
   ctx->nid_pts.release();
   ctx->nid_chunk_kf.release();

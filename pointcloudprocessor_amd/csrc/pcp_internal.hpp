@@ -187,10 +187,10 @@ struct pcp_context {
   pcp::DevBuf<int32_t> s_tiles;
 
   // hidden_points_removal (pcp_hpr.hip): candidate list, flipped points (candidate and cell order), cells, states
-  pcp::DevBuf<int32_t> h_index, h_i32, h_cells_i;
+  pcp::DevBuf<int32_t> h_index, h_i32;
   pcp::DevBuf<double> h_f64, h_cells_d;
   pcp::DevBuf<uint8_t> h_state;
-  pcp::DevBuf<unsigned long long> h_stats, h_rep;
+  pcp::DevBuf<unsigned long long> h_stats;
   pcp::DevBuf<uint32_t> hull_bits;  // whole run: uint32[(F + 31) / 32][n], bit f & 31 of word (f >> 5, j) = point j (Morton
                                     // order) is a hull vertex of keyframe f
   std::vector<uint8_t> hull_valid;  // per keyframe: hull bits imported (index shards)
