@@ -327,7 +327,10 @@ __device__ __forceinline__ float sqdist_f32(float ax, float ay, float az, float 
 // every lane busy (in the plain double loop only the ~35 % of lanes whose current candidate is
 // inside the radius do fp64 work).  Lanes whose neighbourhood does not fit (K > kMaxNbr, a run
 // longer than 4096 points, or a grid with reach > 1) take the plain loops.
-constexpr int kMaxNbr = 87;  // 13.3 KB of LDS per wavefront: 12 wavefronts per CU, what the 140 VGPRs allow (96: 11 wavefronts, fit +3 %;
+#ifndef PCP_MLS_MAXNBR
+#define PCP_MLS_MAXNBR 87
+#endif
+constexpr int kMaxNbr = PCP_MLS_MAXNBR;  // 13.3 KB of LDS per wavefront: 12 wavefronts per CU, what the 140 VGPRs allow (96: 11 wavefronts, fit +3 %;
                              // 72: the 4.6 % of lanes with more neighbours take the plain loops, fit +38 %)
 constexpr int kMaxRun = 9;
 constexpr int kFitBlock = 64;
@@ -391,7 +394,8 @@ __global__ __launch_bounds__(kFitBlock) void k_mls_fit(MlsArgs a) {
       // branch-free: every candidate is written to the list's next free row (a hit keeps it by moving on, a miss is
       // overwritten by the next candidate); row kMaxNbr takes what comes after the list is full
       auto append = [&](bool hit, int32_t k) {
-        nbr_code[min(K, kMaxNbr)][tid] = static_cast<uint16_t>((r << 12) | ((k - b) & 4095));
+        // (k - b < 4096 whenever the list is used: a longer run clears `fast`; unmasked, the code is one scalar add)
+        nbr_code[min(K, kMaxNbr)][tid] = static_cast<uint16_t>((r << 12) + (k - b));
         K += hit ? 1 : 0;
       };
       if constexpr (kBuf) {
