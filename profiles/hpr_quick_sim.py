@@ -1,5 +1,5 @@
 import sys, time, itertools
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from scipy.spatial import ConvexHull
 from oracle import np_oracle as no
