@@ -1,3 +1,6 @@
+"""CPU simulation (numpy, scipy's hull as the truth) of what the quick hidden certificate of pcp_hpr.hip can settle on a real
+candidate set of C3: the four triangles of neighbouring cells, all 56 triangles of the ring, with the own cell's outermost
+candidate, the fan around it, triangles two cells away.  python profiles/hpr_quick_sim.py [points] [keyframe]"""
 import sys, time, itertools
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,3 +1,6 @@
+"""CPU simulation of the radial certificate of pcp_hpr.hip on a real candidate set of C3: the share of the visible candidates
+whose radial plane supports the hull (brute force, fp64), and what a second trial normal from the fan of the ring's
+representatives would add.  python profiles/hpr_radial_sim.py <points> <keyframe>"""
 import sys, time
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
