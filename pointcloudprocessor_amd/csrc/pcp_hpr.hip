@@ -802,12 +802,18 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_quick(HprArrays A, HprGrid G,
 // k_hpr_decide's (same plane, same rounding-proof point test, same cell bound); whatever this pass cannot certify -- an
 // uncleared point, a duplicate -- stays kStUndecided and k_hpr_decide searches it as before.
 // ------------------------------------------------------------------------------------------------------------------
+// `todo` (nullable): the candidates k_hpr_quick left undecided, as a list (k_hpr_list; its length in the tallies): the four rows
+// of a wavefront then all have work on keyframes where most candidates are hidden and certified already.
+constexpr int kStatRadial = 22;  // block 0 of the tallies: length of that list
 __global__ __launch_bounds__(kHprBlock) void k_hpr_radial(HprArrays A, HprGrid G, uint8_t *__restrict__ state,
-                                                          unsigned long long *__restrict__ stats) {
+                                                          const int32_t *__restrict__ todo, unsigned long long *__restrict__ stats) {
   const int lane = lane_id();
   const int rl = lane & 15, row_base = lane & 48;
-  const int32_t j = static_cast<int32_t>(blockIdx.x) * (kHprBlock / 16) + static_cast<int32_t>(threadIdx.x >> 4);
-  const bool have = j < G.m;
+  const int32_t u = static_cast<int32_t>(blockIdx.x) * (kHprBlock / 16) + static_cast<int32_t>(threadIdx.x >> 4);
+  const int32_t count = todo ? static_cast<int32_t>(stats[kStatRadial]) : G.m;
+  if (static_cast<int32_t>(blockIdx.x) * (kHprBlock / 16) >= count) return;  // (the grid covers every candidate)
+  const bool have = u < count;
+  const int32_t j = have ? (todo ? todo[u] : u) : 0;
   auto row_mask = [&](bool b) -> uint32_t { return static_cast<uint32_t>((__ballot(b) >> row_base) & 0xffffull); };
   Search S;
   S.self = have ? j : 0;
@@ -920,7 +926,7 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_radial(HprArrays A, HprGrid G
 constexpr int kStatSearch = 21;  // block 0 of the tallies: length of the list
 constexpr int kHprListPer = 4;   // candidates per lane
 __global__ __launch_bounds__(kHprBlock) void k_hpr_list(const uint8_t *__restrict__ state, int32_t m, int32_t *__restrict__ list,
-                                                        unsigned long long *__restrict__ stats) {
+                                                        unsigned long long *__restrict__ length) {
   __shared__ int32_t ws[kHprBlock / 64];
   __shared__ unsigned long long block_base;
   const int32_t base = (static_cast<int32_t>(blockIdx.x) * kHprBlock + static_cast<int32_t>(threadIdx.x)) * kHprListPer;
@@ -934,7 +940,7 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_list(const uint8_t *__restric
   int32_t total;
   const int32_t ex = scan_block_exclusive(c, &total, ws);
   if (total == 0) return;  // uniform
-  if (threadIdx.x == 0) block_base = atomicAdd(&stats[kStatSearch], static_cast<unsigned long long>(total));
+  if (threadIdx.x == 0) block_base = atomicAdd(length, static_cast<unsigned long long>(total));
   __syncthreads();
   int32_t at = static_cast<int32_t>(block_base) + ex;
 #pragma unroll
@@ -1367,9 +1373,16 @@ int hpr_run(pcp_context *ctx, int32_t frame, uint8_t *d_flags, uint32_t *hull_pl
       hipLaunchKernelGGL(k_hpr_quick, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, ctx->stream, A, G, ctx->h_state.p, stats);
     else
       PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->h_state.p, kStUndecided, sm, ctx->stream));
-    if (!(force_exact || (re && re[0] == '0')))
+    if (!(force_exact || (re && re[0] == '0'))) {
+      const int32_t *radial_todo = nullptr;
+      if (quick) {  // rows for the candidates the quick certificate left, and only for them
+        hipLaunchKernelGGL(k_hpr_list, dim3(static_cast<uint32_t>(div_up(m, kHprBlock * kHprListPer))), dim3(kHprBlock), 0, ctx->stream,
+                           ctx->h_state.p, m, undecided, stats + kStatRadial);  // (`undecided` is free until the searches)
+        radial_todo = undecided;
+      }
       hipLaunchKernelGGL(k_hpr_radial, dim3(static_cast<uint32_t>(div_up(m, kHprBlock / 16))), dim3(kHprBlock), 0, ctx->stream, A, G,
-                         ctx->h_state.p, stats);
+                         ctx->h_state.p, radial_todo, stats);
+    }
     std::vector<uint8_t> dbg_before;
     if (std::getenv("PCP_HPR_DEBUG")) {  // what the two passes in front left to the searches
       dbg_before.resize(sm);
@@ -1377,7 +1390,7 @@ int hpr_run(pcp_context *ctx, int32_t frame, uint8_t *d_flags, uint32_t *hull_pl
       (void)hipStreamSynchronize(ctx->stream);
     }
     hipLaunchKernelGGL(k_hpr_list, dim3(static_cast<uint32_t>(div_up(m, kHprBlock * kHprListPer))), dim3(kHprBlock), 0, ctx->stream,
-                       ctx->h_state.p, m, todo, stats);
+                       ctx->h_state.p, m, todo, stats + kStatSearch);
     hipLaunchKernelGGL(k_hpr_decide, dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(m, kHprBlock / 64), kHprDecideGrid))), dim3(kHprBlock),
                        0, ctx->stream, A, G, ctx->h_state.p, todo, undecided, stats, force_exact ? 1 : 0);
     if (!dbg_before.empty()) {
