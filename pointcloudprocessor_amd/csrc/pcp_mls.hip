@@ -1509,7 +1509,7 @@ __global__ __launch_bounds__(kSelWave) void k_sor_wave(const float *__restrict__
     decided |= 1u << bit;
   };
   if (M > k && M <= 4 * kSelWave) {
-    // the usual case: at most four entries per lane, kept in registers (finite values never match all-ones)
+    // at most four entries per lane, kept in registers (finite values never match all-ones)
     uint32_t u[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) u[i] = i * kSelWave + lane < M ? __float_as_uint(cache[i * kSelWave + lane]) : 0xffffffffu;
@@ -1518,6 +1518,19 @@ __global__ __launch_bounds__(kSelWave) void k_sor_wave(const float *__restrict__
       int32_t zeros = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) zeros += static_cast<int32_t>(__popcll(__ballot((u[i] & probe) == prefix)));
+      decide(bit, zeros);
+    }
+  } else if (M > k && M <= 8 * kSelWave) {
+    // a sparse spot's ball of two cells holds 250-400 values: eight per lane, still in registers (the loop over the
+    // cache below re-reads every value for every bit)
+    uint32_t u[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = i * kSelWave + lane < M ? __float_as_uint(cache[i * kSelWave + lane]) : 0xffffffffu;
+    for (int bit = 30; bit >= 0 && in_play != need; --bit) {
+      const uint32_t probe = decided | (1u << bit);
+      int32_t zeros = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) zeros += static_cast<int32_t>(__popcll(__ballot((u[i] & probe) == prefix)));
       decide(bit, zeros);
     }
   } else if (M > k) {
