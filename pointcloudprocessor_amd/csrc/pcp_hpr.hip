@@ -991,7 +991,10 @@ __device__ __forceinline__ void hpr_decide_one(const HprArrays &A, const HprGrid
 
 // one wavefront per entry of the list, the wavefronts of a capped grid striding over it (its length is read on the device)
 constexpr int32_t kHprDecideGrid = 16384;
-__global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_hpr_decide(HprArrays A, HprGrid G, uint8_t *__restrict__ state,
+#ifndef PCP_DECIDE_WPE
+#define PCP_DECIDE_WPE 2  // 214 VGPRs, nothing spilled; at 3 wavefronts per SIMD (168 VGPRs) 63 registers went to scratch: hull pass 0.312 -> 0.285 s once the searches ran from a list
+#endif
+__global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_DECIDE_WPE, PCP_DECIDE_WPE))) void k_hpr_decide(HprArrays A, HprGrid G, uint8_t *__restrict__ state,
                                                           const int32_t *__restrict__ todo, int32_t *__restrict__ undecided,
                                                           unsigned long long *__restrict__ stats, int32_t force_exact) {
   const int32_t count = static_cast<int32_t>(stats[kStatSearch]);

@@ -1054,7 +1054,10 @@ typedef float sel_v2f __attribute__((ext_vector_type(2)));
 typedef float sel_v4f __attribute__((ext_vector_type(4)));
 typedef uint32_t sel_v4u __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_sor_select(const float *__restrict__ sx, const float *__restrict__ sy,
+#ifndef PCP_SEL_WPE
+#define PCP_SEL_WPE 6
+#endif
+__global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(PCP_SEL_WPE, 8))) void k_sor_select(const float *__restrict__ sx, const float *__restrict__ sy,
                                                          const float *__restrict__ sz,
                                                          const int32_t *__restrict__ order,
                                                          const int32_t *__restrict__ remap,
