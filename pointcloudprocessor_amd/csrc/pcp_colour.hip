@@ -1067,9 +1067,10 @@ int compact_flags(pcp_context *ctx, const uint8_t *flags, int64_t n, int32_t *ou
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   unsigned long long total = 0;
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->s_counter.p, sizeof(total), hipMemcpyDeviceToHost, ctx->stream));
+  unsigned long long *dst = ctx->readback ? static_cast<unsigned long long *>(ctx->readback) : &total;  // pinned: no staging
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(dst, ctx->s_counter.p, sizeof(total), hipMemcpyDeviceToHost, ctx->stream));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  *count = static_cast<int64_t>(total);
+  *count = static_cast<int64_t>(*dst);
   return PCP_OK;
 }
 

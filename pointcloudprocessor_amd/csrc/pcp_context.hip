@@ -598,6 +598,10 @@ int pcp_create(int32_t device, pcp_context **out) {
     pcp_destroy(ctx);
     return PCP_ERR_DEVICE;
   }
+  if (hipHostMalloc(&ctx->readback, pcp_context::kReadbackBytes, hipHostMallocDefault) != hipSuccess) {
+    ctx->readback = nullptr;  // the readbacks then go through pageable memory
+    (void)hipGetLastError();
+  }
   pcp_default_camera(&ctx->camera);
   pcp_default_cull_params(&ctx->cull);
   *out = ctx;
@@ -695,6 +699,7 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->mls_alt_normal.release();
   ctx->mls_alt_curv.release();
   ctx->mls_alt_index.release();
+  if (ctx->readback) (void)hipHostFree(ctx->readback);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }

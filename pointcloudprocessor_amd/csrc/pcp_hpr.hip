@@ -1284,8 +1284,15 @@ int hpr_run(pcp_context *ctx, int32_t frame, uint8_t *d_flags, uint32_t *hull_pl
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   // the number of candidates (block 0) and the copies of the bounds (words 24..27 of the other blocks), one download
-  std::vector<unsigned long long> hall(kStatStride * (1 + kStatCopies));
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(hall.data(), stats, hall.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<unsigned long long> pageable;
+  constexpr size_t kStatWords = kStatStride * (1 + kStatCopies);
+  static_assert(kStatWords * sizeof(unsigned long long) <= pcp_context::kReadbackBytes, "readback scratch");
+  unsigned long long *hall = static_cast<unsigned long long *>(ctx->readback);
+  if (!hall) {
+    pageable.resize(kStatWords);
+    hall = pageable.data();
+  }
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(hall, stats, kStatWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   const int64_t m64 = static_cast<int64_t>(hall[kStatCandidates]);
   unsigned long long hb[4] = {0ull, 0ull, 0ull, 0ull};
