@@ -2293,8 +2293,12 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
       PCP_HIP_TRY(ctx, hipGetLastError());
     }
     unsigned long long occ = 0;
-    PCP_HIP_TRY(ctx, hipMemcpyAsync(&occ, ctx->s_counter.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    {
+      unsigned long long *dst = ctx->readback ? static_cast<unsigned long long *>(ctx->readback) : &occ;  // pinned: no staging
+      PCP_HIP_TRY(ctx, hipMemcpyAsync(dst, ctx->s_counter.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+      PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      occ = *dst;
+    }
     const double c0 = 1.0 / g.inv_cell;
     double final_cell = static_cast<double>(cell);
     if (occ > 0) {
@@ -2408,8 +2412,13 @@ static int view_of(pcp_context *ctx, const float *x, const float *y, const float
   hipLaunchKernelGGL(k_bbox, dim3(static_cast<uint32_t>(std::max<int64_t>(1, std::min<int64_t>(div_up(n, 8 * kMB), 2048)))),
                      dim3(kMB), 0, ctx->stream, x, y, z, n, ctx->s_u32.p);
   PCP_HIP_TRY(ctx, hipGetLastError());
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(box, ctx->s_u32.p, sizeof(box), hipMemcpyDeviceToHost, ctx->stream));
-  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  {
+    static_assert(sizeof(box) <= pcp_context::kReadbackBytes, "readback scratch");
+    uint32_t *dst = ctx->readback ? static_cast<uint32_t *>(ctx->readback) : box;  // pinned: no staging
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(dst, ctx->s_u32.p, sizeof(box), hipMemcpyDeviceToHost, ctx->stream));
+    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (dst != box) std::memcpy(box, dst, sizeof(box));
+  }
   auto decode = [](uint32_t k) {
     const uint32_t b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
     float f;
