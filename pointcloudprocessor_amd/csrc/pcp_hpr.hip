@@ -989,17 +989,18 @@ __device__ __forceinline__ void hpr_decide_one(const HprArrays &A, const HprGrid
   }
 }
 
-// one wavefront per entry of the list, the wavefronts of a capped grid striding over it (its length is read on the device)
-constexpr int32_t kHprDecideGrid = 16384;
+// one wavefront per entry of the list, the wavefronts of a capped grid striding over it (its length is read on the device);
+// workgroups of ONE wavefront: with four, a workgroup's slots were refilled only as fast as whole workgroups could be placed
+// (1.38 resident wavefronts per SIMD of 2, profiles/r03q_hpr_pmc.json)
+constexpr int32_t kHprDecideGrid = 65536;
 #ifndef PCP_DECIDE_WPE
 #define PCP_DECIDE_WPE 2  // 214 VGPRs, nothing spilled; at 3 wavefronts per SIMD (168 VGPRs) 63 registers went to scratch: hull pass 0.312 -> 0.285 s once the searches ran from a list
 #endif
-__global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_DECIDE_WPE, PCP_DECIDE_WPE))) void k_hpr_decide(HprArrays A, HprGrid G, uint8_t *__restrict__ state,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PCP_DECIDE_WPE, PCP_DECIDE_WPE))) void k_hpr_decide(HprArrays A, HprGrid G, uint8_t *__restrict__ state,
                                                           const int32_t *__restrict__ todo, int32_t *__restrict__ undecided,
                                                           unsigned long long *__restrict__ stats, int32_t force_exact) {
   const int32_t count = static_cast<int32_t>(stats[kStatSearch]);
-  const int32_t n_waves = static_cast<int32_t>(gridDim.x) * (kHprBlock / 64);
-  for (int32_t u = static_cast<int32_t>(blockIdx.x) * (kHprBlock / 64) + static_cast<int32_t>(threadIdx.x >> 6); u < count; u += n_waves)
+  for (int32_t u = static_cast<int32_t>(blockIdx.x); u < count; u += static_cast<int32_t>(gridDim.x))
     hpr_decide_one(A, G, todo[u], state, undecided, stats, force_exact);
 }
 
@@ -1401,7 +1402,7 @@ int hpr_run(pcp_context *ctx, int32_t frame, uint8_t *d_flags, uint32_t *hull_pl
     }
     hipLaunchKernelGGL(k_hpr_list, dim3(static_cast<uint32_t>(div_up(m, kHprBlock * kHprListPer))), dim3(kHprBlock), 0, ctx->stream,
                        ctx->h_state.p, m, todo, stats + kStatSearch);
-    hipLaunchKernelGGL(k_hpr_decide, dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(m, kHprBlock / 64), kHprDecideGrid))), dim3(kHprBlock),
+    hipLaunchKernelGGL(k_hpr_decide, dim3(static_cast<uint32_t>(std::min<int64_t>(m, kHprDecideGrid))), dim3(64),
                        0, ctx->stream, A, G, ctx->h_state.p, todo, undecided, stats, force_exact ? 1 : 0);
     if (!dbg_before.empty()) {
       std::vector<uint8_t> after(sm);
