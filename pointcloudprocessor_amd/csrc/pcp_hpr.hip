@@ -688,7 +688,7 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_scatter(const double *__restr
                                                            double *__restrict__ sy, double *__restrict__ sz,
                                                            int32_t *__restrict__ sidx, int32_t *__restrict__ splace,
                                                            int32_t *__restrict__ scell,
-                                                           int32_t *__restrict__ scand, unsigned long long *__restrict__ crho_bits,
+                                                           unsigned long long *__restrict__ crho_bits,
                                                            unsigned long long *__restrict__ crep) {
   const int32_t k = static_cast<int32_t>(blockIdx.x) * kHprBlock + static_cast<int32_t>(threadIdx.x);
   if (k >= m) return;
@@ -700,7 +700,6 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_scatter(const double *__restr
   sidx[pos] = index[k];
   splace[pos] = place[k];
   scell[pos] = c;
-  scand[pos] = k;
   const unsigned long long rb = static_cast<unsigned long long>(__double_as_longlong(rho[k]));
   atomicMax(&crho_bits[c], rb);  // positive doubles order as integers
   // a representative of the cell for k_hpr_quick: (one of) its outermost candidates, by place in the cell order
@@ -1312,9 +1311,9 @@ int hpr_run(pcp_context *ctx, int32_t frame, uint8_t *d_flags, uint32_t *hull_pl
   }
   const int32_t m = static_cast<int32_t>(m64);
   const size_t sm = static_cast<size_t>(m);
-  // ints: cell | sidx splace scell scand | undecided | todo (the list of the searches)
-  PCP_HIP_TRY(ctx, ctx->h_i32.ensure(7 * sm + 16));
-  int32_t *cell = ctx->h_i32.p, *sidx = cell + sm, *splace = sidx + sm, *scell = splace + sm, *scand = scell + sm, *undecided = scand + sm;
+  // ints: cell | sidx splace scell | undecided | todo (the list of the searches)
+  PCP_HIP_TRY(ctx, ctx->h_i32.ensure(6 * sm + 16));
+  int32_t *cell = ctx->h_i32.p, *sidx = cell + sm, *splace = sidx + sm, *scell = splace + sm, *undecided = scell + sm;
   int32_t *todo = undecided + sm;
   PCP_HIP_TRY(ctx, ctx->h_state.ensure(sm + 16));
   const double amin = key_to_double(hb[0]), amax = key_to_double(hb[1]), bmin = key_to_double(hb[2]), bmax = key_to_double(hb[3]);
@@ -1374,7 +1373,7 @@ int hpr_run(pcp_context *ctx, int32_t frame, uint8_t *d_flags, uint32_t *hull_pl
     hipLaunchKernelGGL(k_hpr_count, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, ctx->stream, ga, gb, G, cell, cstart);
     if ((rc = hpr_scan(ctx, cstart, n_fine + 1)) != PCP_OK) return rc;
     hipLaunchKernelGGL(k_hpr_scatter, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, ctx->stream, px, py, pz, rho, cidx, cplace,
-                       cell, m, cstart, cursor, sx, sy, sz, sidx, splace, scell, scand,
+                       cell, m, cstart, cursor, sx, sy, sz, sidx, splace, scell,
                        reinterpret_cast<unsigned long long *>(crho), crep);
     hipLaunchKernelGGL(k_hpr_cells, dim3(hpr_blocks(std::max(n_fine, n_coarse))), dim3(kHprBlock), 0, ctx->stream, G,
                        reinterpret_cast<const unsigned long long *>(crho), cdir, Crho, Cdir, stats + 28);
