@@ -278,3 +278,43 @@ def test_hull_mode_over_index_shards(gpu_ctx_factory, small_scene):
         assert np.array_equal(np.concatenate(idx[f]), vis[f]["index"])
         assert np.array_equal(np.concatenate(vrgb[f]), vis[f]["rgb"])
     full.close()
+
+
+def test_whole_run_bits_in_chunks_of_keyframes(gpu_ctx_factory, oracle):
+    """The whole-run hull bits over more than one 32-keyframe plane: one pcp_depth_pass over every keyframe (whole planes are
+    zeroed by a memset) against the same pass in ranges that cut planes in two (single bits cleared by a kernel), and both
+    against the oracle's colours."""
+    from pointcloudprocessor_amd import capi, synth
+
+    cd = synth.camera_dict("tiny")
+    F = 40
+    x, y, z, _ = synth.make_cloud(30000)
+    poses, _ = synth.make_trajectory(F)
+    imgs = [synth.make_image(f, cd["image_width"], cd["image_height"]) for f in range(F)]
+    cull = capi.default_cull_params()
+    cull.cull_mode = capi.CULL_HPR
+    ctx = gpu_ctx_factory()
+    ctx.set_camera(cam_struct(capi, cd), cull)
+    ctx.upload_cloud(x, y, z)
+    ctx.set_frames(poses)
+    for f, im in enumerate(imgs):
+        ctx.upload_image(f, im)
+    whole = ctx.colorize()
+    results = []
+    for cuts in ((0, F), (0, 20, F), (0, 7, 33, 39, F)):
+        # (the bits of the round before are still there: every round must clear what it does not set)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            ctx.depth_pass(a, b)
+        ctx.colour_reset()
+        ctx.colour_pass(0, F)
+        results.append(ctx.colour_finalise(want_top=True))
+    for r in results:
+        assert np.array_equal(r["rgb"], whole["rgb"]) and np.array_equal(r["has"], whole["has"])
+        for k in ("count", "top_score", "top_frame"):
+            assert np.array_equal(r[k], results[0][k]), k
+    ocam = cam_struct(oracle, cd)
+    ocp = oracle.default_cull_params()
+    ocp.cull_mode = oracle.CULL_HPR
+    ref = oracle.colorize(ocam, ocp, x, y, z, poses, imgs)
+    assert np.array_equal(whole["rgb"], ref["rgb"]) and np.array_equal(whole["has"], ref["has"])
+    ctx.close()
