@@ -70,6 +70,9 @@ def parse():
                          "--stats the k_project_frame row then holds the HBM launches only")
     ap.add_argument("--cpu-points", type=int, default=1_000_000)
     ap.add_argument("--cpu-frames", type=int, default=16)
+    ap.add_argument("--cpu-whole-budget-s", type=float, default=60.0,
+                    help="cpu_baseline runs the WHOLE workload (and gates the timed step's colours on it) when the calibration "
+                         "run says the oracle needs at most this long; otherwise a ~15 s sample")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even at world size 1")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 path on fewer GPUs than ranks (ranks share devices); not a measurement")
@@ -269,7 +272,11 @@ def main():
     value = world * N * F * steps / dt / 1e6  # Mpoints x frames / s, whole job
 
     result = None
-    coloured = int(((pinned[(step_no[0] - 1) & 1].numpy().view(np.uint32) >> 24) & 1).sum())
+    parity_fail = False
+    # the colours the LAST TIMED STEP left on the host (the side legs below reuse the landing buffers): the parity gate
+    # of the cpu_baseline leg compares exactly these with the oracle's
+    step_colours = pinned[(step_no[0] - 1) & 1].numpy().view(np.uint32).copy()
+    coloured = int(((step_colours >> 24) & 1).sum())
     verify = None
     if args.verify and sharded:
         # the shards' colours, all-gathered, against the whole map coloured by ONE context on rank 0
@@ -498,30 +505,49 @@ def main():
                 heng.ctx.synchronize()
                 t_hull = time.perf_counter() - t1
                 per_kf = {}
-                kept_gpu = None
-                for f in (0, F // 2):
+                gate_kf = sorted({(k * F) // 8 for k in range(8)})  # 8 keyframes spread over the trajectory
+                kept_gpu = {}
+                for f in gate_kf:
                     t1 = time.perf_counter()
                     keep_h, _, kept_h = heng.ctx.cull_frame(f)
-                    per_kf[str(f)] = {"ms": round((time.perf_counter() - t1) * 1e3, 2), "candidates": heng.ctx.hpr_stats()["candidates"],
-                                      "kept": int(kept_h)}
-                    if f == 0:
-                        kept_gpu = keep_h.copy()
+                    if f in (0, F // 2):
+                        per_kf[str(f)] = {"ms": round((time.perf_counter() - t1) * 1e3, 2),
+                                          "candidates": heng.ctx.hpr_stats()["candidates"], "kept": int(kept_h)}
+                    kept_gpu[f] = keep_h.copy()
                 hpr = {"keyframes": F, "points": N, "hull_pass_s": round(t_hull, 3), "ms_per_keyframe": round(t_hull / F * 1e3, 2),
                        "Mpoints_frames_per_s": round(N * F / t_hull / 1e6, 1), "cull_frame": per_kf,
                        "what": "spherical flip + convex-hull vertex test of every keyframe's candidates on the GPU "
-                               "(csrc/pcp_hpr.hip), per-keyframe calls with their host synchronisations included"}
+                               "(csrc/pcp_hpr.hip), the whole run's hull pass (pcp_depth_pass in PCP_CULL_HPR mode)"}
                 if not args.no_cpu:
+                    from concurrent.futures import ThreadPoolExecutor
+
                     from oracle import oracle_capi as oc
                     ocam_h = oc.Camera()
                     for k_, _t in oc.Camera._fields_:
                         setattr(ocam_h, k_, cam[k_])
-                    w2c_h, _ = oc.pose_to_matrices(poses[0])
-                    t1 = time.perf_counter()
-                    okeep, ost = oc.hpr_frame(ocam_h, w2c_h, x, y, z)
-                    t_o = time.perf_counter() - t1
+
+                    def hull_on_cpu(f):
+                        w2c_h, _ = oc.pose_to_matrices(poses[f])
+                        t1_ = time.perf_counter()
+                        okeep, _st = oc.hpr_frame(ocam_h, w2c_h, x, y, z)
+                        return f, time.perf_counter() - t1_, okeep
+
+                    # one keyframe per host thread (the C oracle releases the GIL); the timing quoted is keyframe 0 alone
+                    _, t_o, okeep0 = hull_on_cpu(gate_kf[0])
+                    with ThreadPoolExecutor(max_workers=min(len(gate_kf), oc.hardware_threads())) as pool:
+                        rest = list(pool.map(hull_on_cpu, gate_kf[1:]))
+                    verdicts = {gate_kf[0]: bool(np.array_equal(okeep0, kept_gpu[gate_kf[0]]))}
+                    differing = int((okeep0 != kept_gpu[gate_kf[0]]).sum())
+                    for f, _t, okeep in rest:
+                        verdicts[f] = bool(np.array_equal(okeep, kept_gpu[f]))
+                        differing += int((okeep != kept_gpu[f]).sum())
                     hpr["cpu_baseline"] = {"value": round(t_o * 1e3, 1), "unit": "ms per keyframe", "cores": 1, "kind": "port",
-                                           "sample": "keyframe 0 of the same scene, exact quickhull of oracle/pcp_oracle_hpr.c",
-                                           "equal_to_gpu": bool(np.array_equal(okeep, kept_gpu))}
+                                           "sample": f"keyframe {gate_kf[0]} of the same scene, exact quickhull of oracle/pcp_oracle_hpr.c",
+                                           "equal_to_gpu": all(verdicts.values()), "keyframes_compared": gate_kf,
+                                           "differing_points": differing,
+                                           "compared": "keep mask of pcp_cull_frame (PCP_CULL_HPR) vs the oracle's hull vertices, "
+                                                       "every map point of each compared keyframe"}
+                    parity_fail = parity_fail or not all(verdicts.values())
                 heng.close()
             except (RuntimeError, capi.PcpError, AttributeError) as e:
                 hpr = {"error": str(e)}
@@ -563,6 +589,7 @@ def main():
                 eng.ctx.synchronize()
                 t_mls = time.perf_counter() - t1
                 eng.ctx.timing_enable(False)
+                mls_rows = eng.ctx.mls_fetch(m) if not args.no_cpu else None  # the timed run's rows, for the parity gate below
                 mls = {"value": round(nm / t_mls / 1e6, 2), "unit": "Mpoints/s", "points": nm, "outputs": int(m),
                        "radius": 0.03, "order": 2, "upsampling": "NONE", "ms": round(t_mls * 1e3, 2),
                        "kernels_ms": {eng.ctx.kernel_name(k): round(eng.ctx.timing_get(k)[0], 3)
@@ -699,6 +726,30 @@ def main():
                                            "cores": op.threads, "kind": "port",
                                            "sample": f"slab 0 < x < 3 of the same cloud, {len(sx_)} points, "
                                                      f"{t_cpu_mls:.1f} s, oracle/pcp_oracle_mls.c"}
+                    # parity gate of the MLS leg: the rows of the TIMED run against the oracle's, matched by source index,
+                    # for the slab's points whose whole r = 0.03 ball lies inside the slab (xyz <= 3 um,
+                    # normals up to sign <= 1e-4)
+                    slab_idx = np.nonzero(slab)[0]
+                    ref_idx = slab_idx[r["index"]]
+                    inner = (x[ref_idx] > 0.04) & (x[ref_idx] < 2.96)
+                    pos = np.searchsorted(mls_rows["index"], ref_idx[inner])
+                    pos = np.minimum(pos, len(mls_rows["index"]) - 1)
+                    fitted_same = bool(np.array_equal(mls_rows["index"][pos], ref_idx[inner]))
+                    # and no interior point fitted by the GPU alone
+                    g_in = mls_rows["index"][(x[mls_rows["index"]] > 0.04) & (x[mls_rows["index"]] < 2.96)]
+                    fitted_same = fitted_same and len(g_in) == int(inner.sum())
+                    if fitted_same:
+                        dxyz = float(np.abs(mls_rows["xyz"][pos].astype(np.float64) - r["xyz"][inner]).max())
+                        sgn = np.sign((mls_rows["normal"][pos] * r["normal"][inner]).sum(axis=1))
+                        dnrm = float(np.abs(mls_rows["normal"][pos] * sgn[:, None] - r["normal"][inner]).max())
+                    else:
+                        dxyz = dnrm = float("nan")
+                    mls_ok = bool(fitted_same and dxyz <= 3e-6 and dnrm <= 1e-4)
+                    mls["cpu_baseline"].update({"equal_to_gpu": mls_ok, "points_compared": int(inner.sum()),
+                                                "fitted_sets_equal": fitted_same, "max_xyz_diff_m": dxyz,
+                                                "max_normal_diff": dnrm, "tolerance": "xyz 3e-6 m, normal 1e-4 (SURVEY A9)"})
+                    parity_fail = parity_fail or not mls_ok
+                    del mls_rows
             except capi.PcpError as e:  # reported, never hidden
                 mls = {"error": str(e)}
         # ---- CPU baseline: the oracle on a bounded sample, all host cores (rank 0, N = 1 only) ----
@@ -718,23 +769,52 @@ def main():
             def cpu_run(cn, cf, threads):
                 imgs = [synth.make_image(f, W, H) for f in range(cf)]
                 t1 = time.perf_counter()
-                oc.colorize(ocam, ocp, x[:cn], y[:cn], z[:cn], poses[:cf], imgs, threads=threads, want_top=False)
-                return time.perf_counter() - t1
+                r = oc.colorize(ocam, ocp, x[:cn], y[:cn], z[:cn], poses[:cf], imgs, threads=threads, want_top=False)
+                return time.perf_counter() - t1, r
 
-            # calibrate, then size the sample for ~15 s of CPU work
+            # calibrate; the WHOLE workload when the host can do it in about a minute (16 cores: ~7 s), otherwise a
+            # sample sized for ~15 s of CPU work
             cn, cf = min(args.cpu_points, N), min(args.cpu_frames, F)
-            t_cal = cpu_run(cn, cf, cores)
+            t_cal, r_cpu = cpu_run(cn, cf, cores)
+            whole_est = t_cal * (N * F) / max(cn * cf, 1)
             scale = 15.0 / max(t_cal, 1e-3)
-            if scale > 2.0:
+            if whole_est <= args.cpu_whole_budget_s:
+                cn, cf = N, F
+                t_cpu, r_cpu = cpu_run(cn, cf, cores)
+            elif scale > 2.0:
                 cn2 = int(min(N, cn * min(scale, 10.0)))
                 cf2 = int(min(F, max(cf, cf * scale * cn / cn2)))
                 cn, cf = cn2, max(cf2, 1)
-                t_cpu = cpu_run(cn, cf, cores)
+                t_cpu, r_cpu = cpu_run(cn, cf, cores)
             else:
                 t_cpu = t_cal
             cf1 = max(min(cf, 4), 1)
             cn1 = min(cn, 1_000_000)
-            t_cpu1 = cpu_run(cn1, cf1, 1)
+            t_cpu1, _ = cpu_run(cn1, cf1, 1)
+            # ---- the parity gate that runs with every timing: the oracle's colours of this very sample
+            # against the GPU's.  Whole workload: against the colours the last TIMED step left on the host; a sample:
+            # against a run of the HIP path on the same sample (the z-buffer of a sample is not the whole map's) ----
+            if cn == N and cf == F and not sharded:
+                packed, gate_what = step_colours, "colours of the last timed step"
+            else:
+                gctx = capi.Context(local_rank)
+                gctx.set_camera(capi.camera_from_dict(cam), cull)
+                gctx.upload_cloud(x[:cn], y[:cn], z[:cn])
+                gctx.set_frames(poses[:cf])
+                for f in range(cf):
+                    gctx.upload_image(f, synth.make_image(f, W, H))
+                g = gctx.colorize()
+                gctx.close()
+                packed = (g["rgb"][:, 0].astype(np.uint32) | (g["rgb"][:, 1].astype(np.uint32) << 8)
+                          | (g["rgb"][:, 2].astype(np.uint32) << 16) | ((g["has"] > 0).astype(np.uint32) << 24))
+                gate_what = "a run of the HIP path on the same sample"
+            g_rgb = np.stack([(packed >> s_) & 255 for s_ in (0, 8, 16)], axis=1).astype(np.int16)
+            g_has = ((packed >> 24) & 1).astype(bool)
+            o_has = r_cpu["has"] > 0
+            d_rgb = np.abs(g_rgb - r_cpu["rgb"].astype(np.int16))
+            diff_pts = int((d_rgb.max(axis=1) > 0).sum())
+            has_equal = bool(np.array_equal(g_has, o_has))
+            max_diff = int(d_rgb.max()) if len(d_rgb) else 0
             cpu = {
                 "value": round(cn * cf / t_cpu / 1e6, 3),
                 "unit": "Mpoints*frames/s",
@@ -743,7 +823,21 @@ def main():
                 "sample": f"{cn} points x {cf} keyframes of the same scene ({t_cpu:.1f} s), oracle/pcp_oracle.c, "
                           f"OpenMP {cores} threads",
                 "single_thread_value": round(cn1 * cf1 / t_cpu1 / 1e6, 3),
+                "whole_workload": bool(cn == N and cf == F),
+                "equal_to_gpu": bool(has_equal and diff_pts == 0),
+                "has_equal": has_equal,
+                "differing_points": diff_pts,
+                "max_channel_diff": max_diff,
+                "coloured_points": int(o_has.sum()),
+                "compared": f"rgb and has of {cn} points after {cf} keyframes: oracle vs {gate_what} (match_mode "
+                            f"{args.match_mode}); SURVEY A9 allows one level where R/S is within 1e-4 x 255 of an integer",
             }
+            # `has` exact; uint8 equal except one level at an integer boundary of R/S.  In round-trip mode the
+            # oracle and the kernels run the same arithmetic and the gate is equality (measured: 0 of 10 M points differ)
+            if args.match_mode == "roundtrip":
+                parity_fail = parity_fail or not has_equal or diff_pts > 0
+            else:
+                parity_fail = parity_fail or not has_equal or max_diff > 1 or diff_pts > max(10, cn // 10_000)
         result = {
             "metric": "Mpoints×frames/sec colorized",
             "value": round(value, 1),
@@ -791,6 +885,14 @@ def main():
         }
         if verify is not None:
             result["verify"] = verify
+            parity_fail = parity_fail or not verify.get("equal_to_one_gpu_run", True)
+        result["parity_gate"] = {
+            "ok": not parity_fail,
+            "legs": {"colour": None if cpu is None else cpu.get("equal_to_gpu"),
+                     "hpr": None if not hpr or "cpu_baseline" not in hpr else hpr["cpu_baseline"].get("equal_to_gpu"),
+                     "mls": None if not mls or "cpu_baseline" not in mls else mls["cpu_baseline"].get("equal_to_gpu")},
+            "what": "every timed leg's output compared with the oracle's in the same run (colours of the last timed step; "
+                    "hull keep masks of 8 keyframes; MLS rows of a slab's interior); a failing leg makes bench.py exit 1"}
         if args.backend != "nccl":
             result["rehearsal"] = f"backend {args.backend}: ranks share GPUs, not a measurement"
         # the two boundaries side by side: `value` is the contract's -- inputs resident in HBM when the
@@ -810,6 +912,9 @@ def main():
         os.write(json_fd, (json.dumps(result) + "\n").encode())
     os.close(json_fd)
     eng.close()
+    if parity_fail:
+        print("bench.py: PARITY GATE FAILED (see parity_gate / cpu_baseline in the line)", file=sys.stderr)
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -1647,20 +1647,27 @@ int pcp_depth_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
     int rch = ensure_hull_bits(ctx);
     if (rch != PCP_OK) return rch;
     // an index shard (PCP_DEPTH_BATCHED) cannot take a hull: its bits come through pcp_hull_flags_import
-    int32_t clear_until = frame_begin;  // keyframes below this one have their plane zeroed already
-    for (int32_t f = frame_begin; f < frame_end && !ctx->depth_from_batch; ++f) {
-      if ((f & 31) == 0 && std::min(f + 32, ctx->n_frames) <= frame_end) {  // all keyframes of this plane are coming
-        PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->hull_bits.p + static_cast<size_t>(f >> 5) * static_cast<size_t>(ctx->n), 0,
-                                        static_cast<size_t>(ctx->n) * 4, ctx->stream));
-        clear_until = std::min(f + 32, ctx->n_frames);
+    if (!ctx->depth_from_batch) {
+      // first every bit this range is about to write is cleared (whole planes by one memset where all 32 keyframes of the
+      // plane are coming, single bits otherwise), then the hulls -- several keyframes in flight on lanes of their own
+      // (pcp_hpr.hip hpr_run_range; PCP_HPR_LANES, default 4: the keyframes are independent and one keyframe's kernels
+      // leave most of the chip idle), each setting its bit at the sorted place of every hull vertex
+      int32_t clear_until = frame_begin;  // keyframes below this one have their plane zeroed already
+      for (int32_t f = frame_begin; f < frame_end; ++f) {
+        uint32_t *hull_plane = ctx->hull_bits.p + static_cast<size_t>(f >> 5) * static_cast<size_t>(ctx->n);
+        if ((f & 31) == 0 && std::min(f + 32, ctx->n_frames) <= frame_end) {  // all keyframes of this plane are coming
+          PCP_HIP_TRY(ctx, hipMemsetAsync(hull_plane, 0, static_cast<size_t>(ctx->n) * 4, ctx->stream));
+          clear_until = std::min(f + 32, ctx->n_frames);
+        }
+        if (f >= clear_until) {
+          LaunchTimer t(ctx, PCP_K_HPR);
+          hipLaunchKernelGGL(k_hull_clear, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, hull_plane, ctx->n, 1u << (f & 31));
+        }
       }
-      // (no flags of the whole map in between: the hull routine sets the bit at the sorted place of every hull vertex)
-      uint32_t *hull_plane = ctx->hull_bits.p + static_cast<size_t>(f >> 5) * static_cast<size_t>(ctx->n);
-      if (f >= clear_until) {
-        LaunchTimer t(ctx, PCP_K_HPR);
-        hipLaunchKernelGGL(k_hull_clear, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, hull_plane, ctx->n, 1u << (f & 31));
-      }
-      if ((rc = hpr_run(ctx, f, nullptr, hull_plane, 1u << (f & 31))) != PCP_OK) return rc;
+      PCP_HIP_TRY(ctx, hipGetLastError());
+      const char *le = std::getenv("PCP_HPR_LANES");
+      const int32_t lanes = le && le[0] >= '1' && le[0] <= '8' ? le[0] - '0' : 4;
+      if ((rc = hpr_run_range(ctx, frame_begin, frame_end, lanes)) != PCP_OK) return rc;
     }
   }
   for (int32_t f = frame_begin; f < frame_end; ++f) ctx->depth_valid[static_cast<size_t>(f)] = 1;

@@ -37,7 +37,7 @@ void set_global_error(const char *fmt, ...) {
 }
 
 LaunchTimer::LaunchTimer(pcp_context *c, int32_t kernel) : ctx(c) {
-  if (!ctx->timing) return;
+  if (!ctx || !ctx->timing) return;  // (nullptr: an untimed launch, e.g. on a lane's stream)
   auto grab = [&](hipEvent_t &e) {
     if (!ctx->event_pool.empty()) {
       e = ctx->event_pool.back();
@@ -672,12 +672,10 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->m_state.release();
   ctx->m_flag.release();
   ctx->intensity.release();
-  ctx->h_index.release();
-  ctx->h_i32.release();
-  ctx->h_f64.release();
-  ctx->h_cells_d.release();
-  ctx->h_state.release();
-  ctx->h_stats.release();
+  for (auto &lane : ctx->hpr_lane) lane.release();
+  if (ctx->hpr_fork) (void)hipEventDestroy(ctx->hpr_fork);
+  for (auto &e : ctx->hpr_join)
+    if (e) (void)hipEventDestroy(e);
   ctx->hull_bits.release();
   ctx->nid_pts.release();
   ctx->nid_chunk_kf.release();

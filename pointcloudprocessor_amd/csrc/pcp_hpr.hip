@@ -1243,57 +1243,89 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_writeback(const uint8_t *__re
 // ------------------------------------------------------------------------------------------------------------------
 static inline uint32_t hpr_blocks(int64_t n) { return static_cast<uint32_t>(std::max<int64_t>(1, div_up(n, kHprBlock))); }
 
-static int hpr_scan(pcp_context *ctx, int32_t *counts, int64_t entries) {
+static int hpr_scan(pcp_context *ctx, HprLane &L, int32_t *counts, int64_t entries) {
   const int64_t tiles = div_up(entries, kScanTile);
-  PCP_HIP_TRY(ctx, ctx->s_tiles.ensure(static_cast<size_t>(tiles) + 4));
-  hipLaunchKernelGGL(k_scan_tile_sums, dim3(static_cast<uint32_t>(tiles)), dim3(kScanBlock), 0, ctx->stream, counts, entries,
-                     ctx->s_tiles.p);
-  hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kScanSingle), 0, ctx->stream, ctx->s_tiles.p, tiles,
+  PCP_HIP_TRY(ctx, L.tiles.ensure(static_cast<size_t>(tiles) + 4));
+  hipLaunchKernelGGL(k_scan_tile_sums, dim3(static_cast<uint32_t>(tiles)), dim3(kScanBlock), 0, L.stream, counts, entries,
+                     L.tiles.p);
+  hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kScanSingle), 0, L.stream, L.tiles.p, tiles,
                      static_cast<unsigned long long *>(nullptr));
-  hipLaunchKernelGGL(k_scan_apply, dim3(static_cast<uint32_t>(tiles)), dim3(kScanBlock), 0, ctx->stream, counts, entries,
-                     ctx->s_tiles.p, counts);
+  hipLaunchKernelGGL(k_scan_apply, dim3(static_cast<uint32_t>(tiles)), dim3(kScanBlock), 0, L.stream, counts, entries,
+                     L.tiles.p, counts);
   PCP_HIP_TRY(ctx, hipGetLastError());
   return PCP_OK;
 }
 
-// hidden_points_removal of one keyframe: the candidates (the filter of view_culling.cpp:276-288) from the sorted copy of the
-// cloud, then the hull.  Two outputs, each optional: d_flags (n bytes on the device, input order: 1 = hull vertex), and the
+constexpr size_t kStatWords = kStatStride * (1 + kStatCopies);
+static_assert(kStatWords * sizeof(unsigned long long) <= pcp_context::kReadbackBytes, "readback scratch");
+
+// hidden_points_removal of one keyframe, first half: the candidates (the filter of view_culling.cpp:276-288) and their
+// flipped points from the sorted copy of the cloud, queued on `stream` with the lane's buffers; the count and the bounds
+// start their way to the lane's pinned readback, an event behind them.  Nothing waits here.
+// Two outputs of the keyframe, each optional: d_flags (n bytes on the device, input order: 1 = hull vertex), and the
 // keyframe's bit in a CLEARED plane of the whole-run bits (hull_plane[place in the sorted order] |= bit).
-int hpr_run(pcp_context *ctx, int32_t frame, uint8_t *d_flags, uint32_t *hull_plane, uint32_t bit) {
+int hpr_begin(pcp_context *ctx, HprLane &L, hipStream_t stream, bool timed, int32_t frame, uint8_t *d_flags,
+              uint32_t *hull_plane, uint32_t bit) {
   const int64_t n = ctx->n;
+  L.busy = false;
   if (n == 0) return PCP_OK;
   if (n >= (int64_t(1) << 31)) return set_error(ctx, PCP_ERR_RANGE, "hidden_points_removal: %lld points (fewer than 2^31 are handled)", (long long)n);
   const size_t cap = static_cast<size_t>(n);  // every point may be a candidate
   const size_t plane = (static_cast<size_t>(n) + 3) & ~size_t(3);
-  int rc = PCP_OK;
+  L.stream = stream;
+  L.frame = frame;
+  L.d_flags = d_flags;
+  L.hull_plane = hull_plane;
+  L.bit = bit;
+  if (!L.counted) PCP_HIP_TRY(ctx, hipEventCreateWithFlags(&L.counted, hipEventDisableTiming));
+  if (!L.readback && hipHostMalloc(&L.readback, pcp_context::kReadbackBytes, hipHostMallocDefault) != hipSuccess) {
+    L.readback = nullptr;
+    return set_error(ctx, PCP_ERR_NOMEM, "hidden_points_removal: no pinned readback for a lane");
+  }
   // doubles: px py pz ga gb rho | sx sy sz, `cap` apart; ints: candidate's input index | its place in the sorted order
-  PCP_HIP_TRY(ctx, ctx->h_f64.ensure(9 * cap + 16));
-  PCP_HIP_TRY(ctx, ctx->h_index.ensure(2 * cap + 16));
-  PCP_HIP_TRY(ctx, ctx->h_stats.ensure(kStatStride * (1 + kStatCopies)));
-  double *px = ctx->h_f64.p, *py = px + cap, *pz = py + cap, *ga = pz + cap, *gb = ga + cap, *rho = gb + cap;
-  double *sx = rho + cap, *sy = sx + cap, *sz = sy + cap;
-  int32_t *cidx = ctx->h_index.p, *cplace = cidx + cap;
-  unsigned long long *stats = ctx->h_stats.p;
-  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->h_stats.p, 0, kStatStride * (1 + kStatCopies) * sizeof(unsigned long long), ctx->stream));
+  PCP_HIP_TRY(ctx, L.f64.ensure(9 * cap + 16));
+  PCP_HIP_TRY(ctx, L.index.ensure(2 * cap + 16));
+  PCP_HIP_TRY(ctx, L.stats.ensure(kStatWords));
+  double *px = L.f64.p;
+  int32_t *cidx = L.index.p, *cplace = cidx + cap;
+  unsigned long long *stats = L.stats.p;
+  PCP_HIP_TRY(ctx, hipMemsetAsync(L.stats.p, 0, kStatWords * sizeof(unsigned long long), stream));
   const DevFrame &fr = ctx->hframes[static_cast<size_t>(frame)];
   {
-    LaunchTimer t(ctx, PCP_K_HPR);
-    hipLaunchKernelGGL(k_hpr_candidates, dim3(hpr_blocks(n)), dim3(kHprBlock), 0, ctx->stream, ctx->sxyz.p, ctx->sxyz.p + plane,
+    LaunchTimer t(timed ? ctx : nullptr, PCP_K_HPR);
+    hipLaunchKernelGGL(k_hpr_candidates, dim3(hpr_blocks(n)), dim3(kHprBlock), 0, stream, ctx->sxyz.p, ctx->sxyz.p + plane,
                        ctx->sxyz.p + 2 * plane, n, ctx->dcam, fr, ctx->perm.p, ctx->cull.hpr_flip_radius, static_cast<int64_t>(cap),
                        cidx, cplace, px, stats);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   // the number of candidates (block 0) and the copies of the bounds (words 24..27 of the other blocks), one download
-  std::vector<unsigned long long> pageable;
-  constexpr size_t kStatWords = kStatStride * (1 + kStatCopies);
-  static_assert(kStatWords * sizeof(unsigned long long) <= pcp_context::kReadbackBytes, "readback scratch");
-  unsigned long long *hall = static_cast<unsigned long long *>(ctx->readback);
-  if (!hall) {
-    pageable.resize(kStatWords);
-    hall = pageable.data();
-  }
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(hall, stats, kStatWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(L.readback, stats, kStatWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+  PCP_HIP_TRY(ctx, hipEventRecord(L.counted, stream));
+  L.busy = true;
+  return PCP_OK;
+}
+
+// second half: waits for the lane's count and bounds (the one host wait of a keyframe), sizes the gnomonic grid and queues
+// binning, the certificate passes, the searches, the exact path and the outputs behind the first half.
+int hpr_finish(pcp_context *ctx, HprLane &L, bool timed) {
+  if (!L.busy) return PCP_OK;
+  L.busy = false;
+  const int64_t n = ctx->n;
+  const size_t cap = static_cast<size_t>(n);
+  int rc = PCP_OK;
+  hipStream_t stream = L.stream;
+  pcp_context *tctx = timed ? ctx : nullptr;
+  const int32_t frame = L.frame;
+  (void)frame;
+  uint8_t *d_flags = L.d_flags;
+  uint32_t *hull_plane = L.hull_plane;
+  const uint32_t bit = L.bit;
+  double *px = L.f64.p, *py = px + cap, *pz = py + cap, *ga = pz + cap, *gb = ga + cap, *rho = gb + cap;
+  double *sx = rho + cap, *sy = sx + cap, *sz = sy + cap;
+  int32_t *cidx = L.index.p, *cplace = cidx + cap;
+  unsigned long long *stats = L.stats.p;
+  PCP_HIP_TRY(ctx, hipEventSynchronize(L.counted));
+  const unsigned long long *hall = static_cast<const unsigned long long *>(L.readback);
   const int64_t m64 = static_cast<int64_t>(hall[kStatCandidates]);
   unsigned long long hb[4] = {0ull, 0ull, 0ull, 0ull};
   for (int c = 1; c <= kStatCopies; ++c)
@@ -1303,7 +1335,8 @@ int hpr_run(pcp_context *ctx, int32_t frame, uint8_t *d_flags, uint32_t *hull_pl
   std::memset(ctx->hpr_stats, 0, sizeof(ctx->hpr_stats));
   ctx->hpr_stats_pending = false;
   ctx->hpr_stats[9] = m64;
-  if (d_flags) PCP_HIP_TRY(ctx, hipMemsetAsync(d_flags, 0, static_cast<size_t>(n), ctx->stream));  // the hull vertices are set below
+  ctx->hpr_last_lane = static_cast<int32_t>(&L - ctx->hpr_lane);
+  if (d_flags) PCP_HIP_TRY(ctx, hipMemsetAsync(d_flags, 0, static_cast<size_t>(n), stream));  // the hull vertices are set below
   if (m64 < 3) {
     // qhull needs dim + 1 points (here: three candidates and the origin); with fewer it fails and the reference
     // returns no visible point (view_culling.cpp:307-312)
@@ -1312,10 +1345,10 @@ int hpr_run(pcp_context *ctx, int32_t frame, uint8_t *d_flags, uint32_t *hull_pl
   const int32_t m = static_cast<int32_t>(m64);
   const size_t sm = static_cast<size_t>(m);
   // ints: cell | sidx splace scell | undecided | todo (the list of the searches)
-  PCP_HIP_TRY(ctx, ctx->h_i32.ensure(6 * sm + 16));
-  int32_t *cell = ctx->h_i32.p, *sidx = cell + sm, *splace = sidx + sm, *scell = splace + sm, *undecided = scell + sm;
+  PCP_HIP_TRY(ctx, L.i32.ensure(6 * sm + 16));
+  int32_t *cell = L.i32.p, *sidx = cell + sm, *splace = sidx + sm, *scell = splace + sm, *undecided = scell + sm;
   int32_t *todo = undecided + sm;
-  PCP_HIP_TRY(ctx, ctx->h_state.ensure(sm + 16));
+  PCP_HIP_TRY(ctx, L.state.ensure(sm + 16));
   const double amin = key_to_double(hb[0]), amax = key_to_double(hb[1]), bmin = key_to_double(hb[2]), bmax = key_to_double(hb[3]);
   if (!(std::isfinite(amin) && std::isfinite(amax) && std::isfinite(bmin) && std::isfinite(bmax)))
     return set_error(ctx, PCP_ERR_INVALID, "hidden_points_removal: non-finite flipped coordinates (flip radius %g)",
@@ -1345,7 +1378,7 @@ int hpr_run(pcp_context *ctx, int32_t frame, uint8_t *d_flags, uint32_t *hull_pl
     G.r_coarse = 0.5 * h * kHprCoarse * std::sqrt(2.0) * (1.0 + 1e-9) + 1e-12;
     const double ax = std::max(std::fabs(amin), std::fabs(amin + G.gw * h)), ay = std::max(std::fabs(bmin), std::fabs(bmin + G.gh * h));
     G.a_reach = std::sqrt(1.0 + ax * ax + ay * ay) * (1.0 + 1e-9);
-    G.rho_max = reinterpret_cast<const double *>(ctx->h_stats.p + 28);
+    G.rho_max = reinterpret_cast<const double *>(L.stats.p + 28);
   }
   const int64_t n_fine = static_cast<int64_t>(G.gw) * G.gh, n_coarse = static_cast<int64_t>(G.cgw) * G.cgh;
   // per cell, in ONE allocation whose zeroed part comes first (one memset instead of three: each small launch costs its
@@ -1353,12 +1386,12 @@ int hpr_run(pcp_context *ctx, int32_t frame, uint8_t *d_flags, uint32_t *hull_pl
   // and cursor (n_fine) as int32 | centre directions (3 n_fine), coarse rho / directions (4 n_coarse)
   const size_t nf = static_cast<size_t>(n_fine), nc = static_cast<size_t>(n_coarse);
   const size_t int_words = (2 * nf + 16 + 1) / 2;  // the int32 part, in 8-byte words
-  PCP_HIP_TRY(ctx, ctx->h_cells_d.ensure(2 * nf + int_words + 3 * nf + 4 * nc + 16));
-  double *crho = ctx->h_cells_d.p;
+  PCP_HIP_TRY(ctx, L.cells_d.ensure(2 * nf + int_words + 3 * nf + 4 * nc + 16));
+  double *crho = L.cells_d.p;
   unsigned long long *crep_all = reinterpret_cast<unsigned long long *>(crho + nf);
   int32_t *cstart = reinterpret_cast<int32_t *>(crho + 2 * nf), *cursor = cstart + n_fine + 2;
   double *cdir = crho + 2 * nf + int_words, *Crho = cdir + 3 * nf, *Cdir = Crho + nc;
-  PCP_HIP_TRY(ctx, hipMemsetAsync(crho, 0, (2 * nf + int_words) * sizeof(double), ctx->stream));
+  PCP_HIP_TRY(ctx, hipMemsetAsync(crho, 0, (2 * nf + int_words) * sizeof(double), stream));
   // PCP_HPR_QUICK=0 / PCP_HPR_RADIAL=0: without the two passes in front of the search (results identical; the place of a
   // representative needs 26 bits)
   const char *qe = std::getenv("PCP_HPR_QUICK");
@@ -1369,44 +1402,44 @@ int hpr_run(pcp_context *ctx, int32_t frame, uint8_t *d_flags, uint32_t *hull_pl
   const char *fe = std::getenv("PCP_HPR_FORCE_EXACT");
   const bool force_exact = fe && fe[0] == '1';
   {
-    LaunchTimer t(ctx, PCP_K_HPR);
-    hipLaunchKernelGGL(k_hpr_count, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, ctx->stream, ga, gb, G, cell, cstart);
-    if ((rc = hpr_scan(ctx, cstart, n_fine + 1)) != PCP_OK) return rc;
-    hipLaunchKernelGGL(k_hpr_scatter, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, ctx->stream, px, py, pz, rho, cidx, cplace,
+    LaunchTimer t(tctx, PCP_K_HPR);
+    hipLaunchKernelGGL(k_hpr_count, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, stream, ga, gb, G, cell, cstart);
+    if ((rc = hpr_scan(ctx, L, cstart, n_fine + 1)) != PCP_OK) return rc;
+    hipLaunchKernelGGL(k_hpr_scatter, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, stream, px, py, pz, rho, cidx, cplace,
                        cell, m, cstart, cursor, sx, sy, sz, sidx, splace, scell,
                        reinterpret_cast<unsigned long long *>(crho), crep);
-    hipLaunchKernelGGL(k_hpr_cells, dim3(hpr_blocks(std::max(n_fine, n_coarse))), dim3(kHprBlock), 0, ctx->stream, G,
+    hipLaunchKernelGGL(k_hpr_cells, dim3(hpr_blocks(std::max(n_fine, n_coarse))), dim3(kHprBlock), 0, stream, G,
                        reinterpret_cast<const unsigned long long *>(crho), cdir, Crho, Cdir, stats + 28);
     // PCP_HPR_RADIAL=0: every candidate through k_hpr_decide (results identical)
     const char *re = std::getenv("PCP_HPR_RADIAL");
     if (quick && !force_exact)
-      hipLaunchKernelGGL(k_hpr_quick, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, ctx->stream, A, G, ctx->h_state.p, stats);
+      hipLaunchKernelGGL(k_hpr_quick, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, stream, A, G, L.state.p, stats);
     else
-      PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->h_state.p, kStUndecided, sm, ctx->stream));
+      PCP_HIP_TRY(ctx, hipMemsetAsync(L.state.p, kStUndecided, sm, stream));
     if (!(force_exact || (re && re[0] == '0'))) {
       const int32_t *radial_todo = nullptr;
       if (quick) {  // rows for the candidates the quick certificate left, and only for them
-        hipLaunchKernelGGL(k_hpr_list, dim3(static_cast<uint32_t>(div_up(m, kHprBlock * kHprListPer))), dim3(kHprBlock), 0, ctx->stream,
-                           ctx->h_state.p, m, undecided, stats + kStatRadial);  // (`undecided` is free until the searches)
+        hipLaunchKernelGGL(k_hpr_list, dim3(static_cast<uint32_t>(div_up(m, kHprBlock * kHprListPer))), dim3(kHprBlock), 0, stream,
+                           L.state.p, m, undecided, stats + kStatRadial);  // (`undecided` is free until the searches)
         radial_todo = undecided;
       }
-      hipLaunchKernelGGL(k_hpr_radial, dim3(static_cast<uint32_t>(div_up(m, kHprBlock / 16))), dim3(kHprBlock), 0, ctx->stream, A, G,
-                         ctx->h_state.p, radial_todo, stats);
+      hipLaunchKernelGGL(k_hpr_radial, dim3(static_cast<uint32_t>(div_up(m, kHprBlock / 16))), dim3(kHprBlock), 0, stream, A, G,
+                         L.state.p, radial_todo, stats);
     }
     std::vector<uint8_t> dbg_before;
     if (std::getenv("PCP_HPR_DEBUG")) {  // what the two passes in front left to the searches
       dbg_before.resize(sm);
-      (void)hipMemcpyAsync(dbg_before.data(), ctx->h_state.p, sm, hipMemcpyDeviceToHost, ctx->stream);
-      (void)hipStreamSynchronize(ctx->stream);
+      (void)hipMemcpyAsync(dbg_before.data(), L.state.p, sm, hipMemcpyDeviceToHost, stream);
+      (void)hipStreamSynchronize(stream);
     }
-    hipLaunchKernelGGL(k_hpr_list, dim3(static_cast<uint32_t>(div_up(m, kHprBlock * kHprListPer))), dim3(kHprBlock), 0, ctx->stream,
-                       ctx->h_state.p, m, todo, stats + kStatSearch);
+    hipLaunchKernelGGL(k_hpr_list, dim3(static_cast<uint32_t>(div_up(m, kHprBlock * kHprListPer))), dim3(kHprBlock), 0, stream,
+                       L.state.p, m, todo, stats + kStatSearch);
     hipLaunchKernelGGL(k_hpr_decide, dim3(static_cast<uint32_t>(std::min<int64_t>(m, kHprDecideGrid))), dim3(64),
-                       0, ctx->stream, A, G, ctx->h_state.p, todo, undecided, stats, force_exact ? 1 : 0);
+                       0, stream, A, G, L.state.p, todo, undecided, stats, force_exact ? 1 : 0);
     if (!dbg_before.empty()) {
       std::vector<uint8_t> after(sm);
-      (void)hipMemcpyAsync(after.data(), ctx->h_state.p, sm, hipMemcpyDeviceToHost, ctx->stream);
-      (void)hipStreamSynchronize(ctx->stream);
+      (void)hipMemcpyAsync(after.data(), L.state.p, sm, hipMemcpyDeviceToHost, stream);
+      (void)hipStreamSynchronize(stream);
       size_t und = 0, to_vis = 0, to_hid = 0, left = 0;
       for (size_t k = 0; k < sm; ++k)
         if (dbg_before[k] == kStUndecided) {
@@ -1423,17 +1456,17 @@ int hpr_run(pcp_context *ctx, int32_t frame, uint8_t *d_flags, uint32_t *hull_pl
     // the exact path for what the searches left undecided (a handful per keyframe): a fixed grid that reads the count on
     // the device and strides over the list; the tallies stay on the device until pcp_hpr_stats asks for them -- no host
     // round trip in here
-    LaunchTimer t(ctx, PCP_K_HPR);
-    hipLaunchKernelGGL(k_hpr_exact, dim3(static_cast<uint32_t>(std::min<int32_t>(m, kHprExactGrid))), dim3(64), 0, ctx->stream, A, G,
-                       4.0 * std::fabs(ctx->cull.hpr_flip_radius) + 1.0e4, undecided, ctx->h_state.p, stats);
+    LaunchTimer t(tctx, PCP_K_HPR);
+    hipLaunchKernelGGL(k_hpr_exact, dim3(static_cast<uint32_t>(std::min<int32_t>(m, kHprExactGrid))), dim3(64), 0, stream, A, G,
+                       4.0 * std::fabs(ctx->cull.hpr_flip_radius) + 1.0e4, undecided, L.state.p, stats);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   {
-    LaunchTimer t(ctx, PCP_K_HPR);
+    LaunchTimer t(tctx, PCP_K_HPR);
     if (d_flags)
-      hipLaunchKernelGGL(k_hpr_writeback, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, ctx->stream, ctx->h_state.p, sidx, m, d_flags);
+      hipLaunchKernelGGL(k_hpr_writeback, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, stream, L.state.p, sidx, m, d_flags);
     if (hull_plane)
-      hipLaunchKernelGGL(k_hpr_set_bits, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, ctx->stream, ctx->h_state.p, splace, m, hull_plane, bit);
+      hipLaunchKernelGGL(k_hpr_set_bits, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, stream, L.state.p, splace, m, hull_plane, bit);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   ctx->hpr_stats[8] = n_fine;
@@ -1449,6 +1482,53 @@ int hpr_run(pcp_context *ctx, int32_t frame, uint8_t *d_flags, uint32_t *hull_pl
   return PCP_OK;
 }
 
+// one keyframe, both halves on the context's stream with lane 0 (the single-keyframe calls: pcp_cull_frame, pcp_frame_visible, NID)
+int hpr_run(pcp_context *ctx, int32_t frame, uint8_t *d_flags, uint32_t *hull_plane, uint32_t bit) {
+  HprLane &L = ctx->hpr_lane[0];
+  int rc = hpr_begin(ctx, L, ctx->stream, true, frame, d_flags, hull_plane, bit);
+  if (rc != PCP_OK) return rc;
+  return hpr_finish(ctx, L, true);
+}
+
+// The hulls of keyframes [f0, f1) into the whole-run bits, `lanes` keyframes in flight: lane k takes keyframes f0 + k,
+// f0 + k + lanes, ... on a stream of its own; the host walks the keyframes in order, finishing the lane's previous
+// keyframe (its count and bounds arrived long ago: the other lanes' work was queued in between) before it begins the next
+// one there.  The lanes start behind everything queued on the context's stream so far (the cleared planes) and the
+// context's stream continues behind the last kernel of every lane.
+int hpr_run_range(pcp_context *ctx, int32_t f0, int32_t f1, int32_t lanes) {
+  if (f1 <= f0 || ctx->n == 0) return PCP_OK;
+  lanes = std::max(1, std::min<int32_t>(std::min<int32_t>(lanes, pcp_context::kHprMaxLanes), f1 - f0));
+  int rc = PCP_OK;
+  if (!ctx->hpr_fork) PCP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->hpr_fork, hipEventDisableTiming));
+  LaunchTimer t(ctx, PCP_K_HPR);  // the whole pass as one bracket on the context's stream
+  PCP_HIP_TRY(ctx, hipEventRecord(ctx->hpr_fork, ctx->stream));
+  for (int32_t k = 0; k < lanes; ++k) {
+    HprLane &L = ctx->hpr_lane[k];
+    if (!L.own_stream) PCP_HIP_TRY(ctx, hipStreamCreateWithFlags(&L.own_stream, hipStreamNonBlocking));
+    if (!ctx->hpr_join[k]) PCP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->hpr_join[k], hipEventDisableTiming));
+    PCP_HIP_TRY(ctx, hipStreamWaitEvent(L.own_stream, ctx->hpr_fork, 0));
+  }
+  for (int32_t f = f0; f < f1 && rc == PCP_OK; ++f) {
+    HprLane &L = ctx->hpr_lane[(f - f0) % lanes];
+    if ((rc = hpr_finish(ctx, L, false)) != PCP_OK) break;
+    uint32_t *plane = ctx->hull_bits.p + static_cast<size_t>(f >> 5) * static_cast<size_t>(ctx->n);
+    rc = hpr_begin(ctx, L, L.own_stream, false, f, nullptr, plane, 1u << (f & 31));
+  }
+  // the keyframes still in flight, oldest first; then the join (also after an error: nothing may stay queued on a lane
+  // whose buffers the next call reuses on another stream)
+  const int32_t count = f1 - f0;
+  for (int32_t k = 0; k < lanes; ++k) {
+    HprLane &L = ctx->hpr_lane[(count + k) % lanes];
+    const int rcl = hpr_finish(ctx, L, false);
+    if (rc == PCP_OK) rc = rcl;
+  }
+  for (int32_t k = 0; k < lanes; ++k) {
+    PCP_HIP_TRY(ctx, hipEventRecord(ctx->hpr_join[k], ctx->hpr_lane[k].own_stream));
+    PCP_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->hpr_join[k], 0));
+  }
+  return rc;
+}
+
 }  // namespace pcp
 
 using namespace pcp;
@@ -1457,11 +1537,12 @@ extern "C" {
 
 int pcp_hpr_stats(pcp_context *ctx, int64_t out[10]) {
   if (!ctx || !out) return PCP_ERR_INVALID;
-  if (ctx->hpr_stats_pending && ctx->h_stats.p) {
+  const HprLane &last = ctx->hpr_lane[ctx->hpr_last_lane];
+  if (ctx->hpr_stats_pending && last.stats.p) {
     // the tallies of the last run: block 0 + kStatCopies per-workgroup copies (k_hpr_decide), summed here
     PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
     std::vector<unsigned long long> hall(kStatStride * (1 + kStatCopies));
-    PCP_HIP_TRY(ctx, hipMemcpyAsync(hall.data(), ctx->h_stats.p, hall.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(hall.data(), last.stats.p, hall.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     unsigned long long hs[9];
     for (int k = 0; k < 9; ++k) {

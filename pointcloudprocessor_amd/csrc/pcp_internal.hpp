@@ -93,6 +93,42 @@ struct DevBuf {
   }
 };
 
+// hidden_points_removal: the scratch of ONE keyframe's hull (pcp_hpr.hip).  The keyframes of a run are independent, so the
+// whole-run pass keeps several of them in flight, each on a lane of its own: a stream, the buffers, a pinned readback and
+// the event recorded behind the download of the candidates' count and bounds (the one host wait of a keyframe).  Lane 0
+// also serves the single-keyframe calls, on the context's stream.
+struct HprLane {
+  hipStream_t own_stream = nullptr;  // created on first use by the whole-run pass
+  hipStream_t stream = nullptr;      // the stream the keyframe in flight was queued on
+  hipEvent_t counted = nullptr;
+  DevBuf<int32_t> index, i32, tiles;
+  DevBuf<double> f64, cells_d;
+  DevBuf<uint8_t> state;
+  DevBuf<unsigned long long> stats;
+  void *readback = nullptr;  // pinned, kReadbackBytes
+  // the keyframe between hpr_begin and hpr_finish
+  bool busy = false;
+  int32_t frame = -1;
+  uint8_t *d_flags = nullptr;
+  uint32_t *hull_plane = nullptr;
+  uint32_t bit = 0;
+  void release() {
+    index.release();
+    i32.release();
+    tiles.release();
+    f64.release();
+    cells_d.release();
+    state.release();
+    stats.release();
+    if (readback) (void)hipHostFree(readback);
+    readback = nullptr;
+    if (counted) (void)hipEventDestroy(counted);
+    counted = nullptr;
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+    own_stream = nullptr;
+  }
+};
+
 }  // namespace pcp
 
 struct pcp_context {
@@ -191,10 +227,10 @@ struct pcp_context {
   pcp::DevBuf<int32_t> s_tiles;
 
   // hidden_points_removal (pcp_hpr.hip): candidate list, flipped points (candidate and cell order), cells, states
-  pcp::DevBuf<int32_t> h_index, h_i32;
-  pcp::DevBuf<double> h_f64, h_cells_d;
-  pcp::DevBuf<uint8_t> h_state;
-  pcp::DevBuf<unsigned long long> h_stats;
+  static constexpr int kHprMaxLanes = 8;
+  pcp::HprLane hpr_lane[kHprMaxLanes];
+  int32_t hpr_last_lane = 0;  // whose tallies pcp_hpr_stats reads
+  hipEvent_t hpr_fork = nullptr, hpr_join[kHprMaxLanes] = {};
   pcp::DevBuf<uint32_t> hull_bits;  // whole run: uint32[(F + 31) / 32][n], bit f & 31 of word (f >> 5, j) = point j (Morton
                                     // order) is a hull vertex of keyframe f
   std::vector<uint8_t> hull_valid;  // per keyframe: hull bits imported (index shards)
@@ -289,6 +325,8 @@ int cull_frame_indices(pcp_context *ctx, int32_t frame, int32_t *d_index, int64_
 // hidden_points_removal's hull over the candidate flags of one keyframe (pcp_hpr.hip): flags (input order, device)
 // in: 1 = candidate; out: 1 = hull vertex
 int hpr_run(pcp_context *ctx, int32_t frame, uint8_t *d_flags, uint32_t *hull_plane, uint32_t bit);
+// the hulls of keyframes [f0, f1) into the (cleared) whole-run bits, `lanes` keyframes in flight on streams of their own
+int hpr_run_range(pcp_context *ctx, int32_t f0, int32_t f1, int32_t lanes);
 
 inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -6,7 +6,7 @@ pytest).  For `--frames` keyframes of the C3 scene (10 M points, 256 keyframes) 
 ViewCulling::hidden_points_removal (view_culling.cpp:276-288), the hull vertices among the spherically flipped
 candidates (:291-329, flip radius 90000), and what the z-buffer routine (:52-174) keeps of the same cloud.
 
-    python tests/hpr_retention_probe.py --points 10000000 --frames 16 > profiles/r03_hpr_retention.json
+    python scripts/hpr_retention_probe.py --points 10000000 --frames 16 > profiles/r03_hpr_retention.json
 """
 import argparse
 import json

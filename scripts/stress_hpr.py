@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised stress of PCP_CULL_HPR (not collected by pytest): seeds x cloud sizes x cameras x keyframes x flip radii, the
 GPU hull (quick certificate, radial pre-pass, search, exact path) against the oracle's exact quickhull; also with the two
-passes switched off.  Prints one line per case; exit 1 on the first mismatch.   python tests/stress_hpr.py [cases]"""
+passes switched off.  Prints one line per case; exit 1 on the first mismatch.   python scripts/stress_hpr.py [cases]"""
 import os
 import sys
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity stress (not collected by pytest): many seeds x distortion models x camera sets, the HIP path
 against the oracle -- colours, top-5 lists, depth maps of a few keyframes.  Prints one line per case; exit 1 on the
-first mismatch.     python tests/stress_parity.py [cases] [points] [keyframes]"""
+first mismatch.     python scripts/stress_parity.py [cases] [points] [keyframes]"""
 import os
 import sys
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity stress of the smoothing stages (not collected by pytest): crops of the bench scene at random
 places and densities -> MLS (NONE), SOR and, on a thinned crop, VOXEL_GRID_DILATION, the HIP path against the oracle.
-    python tests/stress_smooth.py [cases]"""
+    python scripts/stress_smooth.py [cases]"""
 import os
 import sys
 

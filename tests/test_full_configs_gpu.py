@@ -8,7 +8,9 @@ shards as 8 contexts (each with every keyframe and image, as every rank holds th
 ncclAllReduce(ncclMin) computes -- and PCP_DEPTH_BATCHED for the per-keyframe calls.  Asserted: the shards' colours,
 three depth maps and two frame_visible / cull_frame dumps equal the unsharded run exactly; for configs[4] the joint
 histograms of the NID cost accumulated per shard and summed -- the all-reduce(SUM) -- give the unsharded cost to 1e-12
-on 64 keyframes.  What stays unmeasured is the 8-GPU TIMING (no multi-GPU lease)."""
+over ALL 2048 keyframes (4.3e9 culled points; the reference refines on every selected keyframe,
+PointCloudProcessor.cpp:156-161,1021), and on 64 keyframes with the 8 shard contexts alive together every shard
+finishes with the same numbers (lockstep).  What stays unmeasured is the 8-GPU TIMING (no multi-GPU lease)."""
 import numpy as np
 import pytest
 
@@ -151,3 +153,47 @@ def test_config4_whole_100M_x_2048_masks_nid_in_8_shards():
     np.testing.assert_allclose(g1, g0, rtol=1e-9, atol=1e-12)
     for e in shards:
         e.close()
+    del shards, hists, s
+    torch.cuda.empty_cache()
+    # ---- the same over EVERY keyframe of configs[4] (the reference refines on all of them,
+    # PointCloudProcessor.cpp:156-161, visual_camera_calibration.cpp:86-129): ~4.3e9 culled points, 70-90 GB of
+    # (x, y, z, intensity) on the unsharded context.  The shards run one after another here (8 x 17 GB of texels
+    # beside 90 GB of culled points would crowd the one GPU): phase 1 their depth maps, MIN-merged; phase 2 each
+    # shard culls against the merged maps, accumulates its histograms, and the sums are added -- all-reduce(SUM) ----
+    full = _engine(cd, x, y, z, poses, images, intensity=inten)
+    total_all = full.ctx.nid_prepare()
+    c0a, g0a, ok0a = full.ctx.nid_evaluate(T)
+    full.close()
+    del full
+    merged = None
+    for lo, hi in bounds:
+        e = pipeline.HipEngine(0)
+        e.configure(cd)
+        e.upload_cloud(x[lo:hi], y[lo:hi], z[lo:hi])
+        e.ctx.set_frames(poses)
+        e.depth_pass()  # needs no image
+        m = e.depth_maps_tensor().clone()
+        merged = m if merged is None else torch.minimum(merged, m)
+        e.close()
+    hsum, got_total = None, 0
+    for r, (lo, hi) in enumerate(bounds):
+        e = _engine(cd, x[lo:hi], y[lo:hi], z[lo:hi], poses, images, batched_depth=True, intensity=inten[lo:hi])
+        e.depth_pass()
+        e.depth_maps_tensor().copy_(merged)
+        torch.cuda.synchronize()
+        got_total += e.ctx.nid_prepare()
+        e.ctx.nid_accumulate(T, 16)
+        e.ctx.synchronize()
+        h = torch.as_tensor(pipeline._DeviceArray(*e.ctx.nid_histograms_device(), "<f8"), device="cuda:0")
+        if r < SHARDS - 1:
+            hsum = h.clone() if hsum is None else hsum + h
+            e.close()
+        else:
+            h += hsum  # the last shard receives the others' sums: what every rank holds after the all-reduce
+            torch.cuda.synchronize()
+            c1a, g1a, ok1a = e.ctx.nid_finish(16)
+            e.close()
+    assert got_total == total_all and total_all > 2_000_000_000
+    assert ok0a and ok1a
+    assert abs(c1a - c0a) <= 1e-12 * abs(c0a)
+    np.testing.assert_allclose(g1a, g0a, rtol=1e-9, atol=1e-12)
