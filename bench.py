@@ -36,6 +36,10 @@ import time
 
 import numpy as np
 
+# the hull pass of the `hpr` leg keeps keyframes in flight on several streams; the HIP runtime reads this when it initialises
+# (before `import torch` touches the device): 8 hardware queues instead of 4 (pcp_create sets the same default for C++ hosts)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -43,6 +47,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PROJ_BYTES_PER_POINT = 20  # 12 B xyz read + 4 B cell + 4 B range written
 PMC_SUMMARY = "r03_pmc.json"  # profiles/: summary of the rocprofv3 --pmc passes of this command (profiles/summarise_pmc.py)
+HPR_PMC_SUMMARY = "r04_hpr_pmc.json"  # profiles/: trace + SQ counters of the hull kernels (profiles/collect_hpr_pmc.sh)
 MLS_PMC_SUMMARY = "r03_mls_pmc.json"  # profiles/: PMC summary of MLS alone (profiles/collect_mls.sh)
 SIMDS, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md max clock
 C3_POINTS, C3_FRAMES = 50_000_000, 1024  # BASELINE.json configs[3]
@@ -514,10 +519,38 @@ def main():
                         per_kf[str(f)] = {"ms": round((time.perf_counter() - t1) * 1e3, 2),
                                           "candidates": heng.ctx.hpr_stats()["candidates"], "kept": int(kept_h)}
                     kept_gpu[f] = keep_h.copy()
+                # the whole --cull hpr colourisation of the workload (what the reference binary runs, view_culling.cpp:46):
+                # hull pass -> colour pass reading the hull bits -> packed colours on the host
+                distinct = [synth.make_image(f, W, H) for f in range(8)]
+                for f in range(F):
+                    heng.ctx.upload_image(f, distinct[f % len(distinct)])
+                del distinct
+                heng.ctx.colorize()  # warm-up
+                runs_h = []
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    hres = heng.ctx.colorize()
+                    runs_h.append(time.perf_counter() - t1)
+                t_hcol = sorted(runs_h)[1]
                 hpr = {"keyframes": F, "points": N, "hull_pass_s": round(t_hull, 3), "ms_per_keyframe": round(t_hull / F * 1e3, 2),
                        "Mpoints_frames_per_s": round(N * F / t_hull / 1e6, 1), "cull_frame": per_kf,
+                       "keyframes_in_flight": int(os.environ.get("PCP_HPR_LANES", "4")),
+                       "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                       "value_hpr": round(N * F / t_hcol / 1e6, 1), "value_hpr_unit": "Mpoints*frames/s",
+                       "colourise_s": round(t_hcol, 3), "coloured_points": int(hres["has"].sum()),
                        "what": "spherical flip + convex-hull vertex test of every keyframe's candidates on the GPU "
-                               "(csrc/pcp_hpr.hip), the whole run's hull pass (pcp_depth_pass in PCP_CULL_HPR mode)"}
+                               "(csrc/pcp_hpr.hip), the whole run's hull pass (pcp_depth_pass in PCP_CULL_HPR mode); value_hpr = "
+                               "the whole --cull hpr colourisation (hull pass + colour pass + colours on the host, 8 distinct "
+                               "images cycled over the keyframe slots)"}
+                try:
+                    with open(os.path.join(ROOT, "profiles", HPR_PMC_SUMMARY)) as fh:
+                        hp = json.load(fh)
+                    hpr["kernels"] = {k: {c: v[c] for c in ("duration_us", "valu_busy", "waves_per_simd", "lane_utilisation") if c in v}
+                                      for k, v in hp.items() if v.get("duration_us", 0) >= 10.0}
+                    hpr["kernels_source"] = (f"profiles/{HPR_PMC_SUMMARY}: rocprofv3 kernel trace + SQ counter passes of 8 keyframes "
+                                             "(profiles/collect_hpr_pmc.sh), per launch; valu_busy = SQ_ACTIVE_INST_VALU x 4 / SIMDs / cycles")
+                except (OSError, ValueError):
+                    pass
                 if not args.no_cpu:
                     from concurrent.futures import ThreadPoolExecutor
 

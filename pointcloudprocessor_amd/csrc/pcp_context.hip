@@ -552,6 +552,12 @@ int pcp_create(int32_t device, pcp_context **out) {
     return PCP_ERR_INVALID;
   }
   *out = nullptr;
+  // The hull pass of hidden_points_removal keeps several keyframes in flight on streams of their own (pcp_hpr.hip
+  // hpr_run_range); the HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and
+  // two streams on one queue run one after the other (C3: hull pass 0.17 s on 4 queues, 0.15 s on 8).  The variable is read
+  // when the runtime initialises, so this only takes effect when pcp_create is the process's first HIP call (the C++ host);
+  // a host that initialises HIP earlier sets it itself (bench.py does).  Never overrides a value the caller chose.
+  (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0) {
@@ -687,6 +693,9 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->c_where.release();
   ctx->c_xyz2.release();
   ctx->v_bitmap.release();
+  ctx->v_occ.release();
+  ctx->v_rank.release();
+  ctx->v_plane.release();
   ctx->v_vox.release();
   ctx->v_offsets.release();
   ctx->mls_xyz.release();

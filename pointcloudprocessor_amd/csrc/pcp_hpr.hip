@@ -79,7 +79,12 @@ struct HprArrays {
   const double *cdir;           // fine cells: centre direction, SoA x[cells] y[cells] z[cells]
   const double *Crho, *Cdir;    // coarse cells
   const unsigned long long *crep;  // fine cells: (upper bits of the largest |q| | place of that candidate), 0 = empty; nullable
+  // the same bounds as ONE 16-byte record per cell, for the 16-lane passes (k_hpr_radial, k_hpr_tilt), whose time is the
+  // round trips of their cell tests: centre direction rounded to fp32 (off by <= 1.1e-7 in chord: kCell4Slack is added to
+  // the cell's radius) and the norm bound rounded UP to fp32 (0 = empty)
+  const float4 *cell4, *Cell4;
 };
+constexpr double kCell4Slack = 2.5e-7;
 
 // ------------------------------------------------------------------------------------------------------------------
 // wavefront helpers
@@ -424,6 +429,17 @@ __device__ __forceinline__ bool cell_cleared(const Search &S, double ux, double 
   return rho * S.nn_hi * (1.0 - 0.5 * sl * sl) < S.hp_lo;
 }
 
+// The same bound with the chord taken in fp32: sep only enters through max(sep - r, 0), which must not be OVER-estimated, so
+// the fp32 square root (1 ulp) is scaled down by 1 - 3e-7 and the square under it is the fp64 one rounded down.  An fp64
+// square root is ~25 instructions, and k_hpr_radial -- 78 % vector-ALU busy -- takes one per cell it looks at.
+__device__ __forceinline__ bool cell_cleared_f32sep(double nhx, double nhy, double nhz, double nn_hi, double hp_lo, double ux,
+                                                    double uy, double uz, double rho, double r) {
+  const double dx = nhx - ux, dy = nhy - uy, dz = nhz - uz;
+  const float sep_lo = __builtin_sqrtf(__double2float_rd((dx * dx + dy * dy) + dz * dz)) * (1.0f - 3.0e-7f);
+  const double sl = fmax(static_cast<double>(sep_lo) - r - 1.0e-12, 0.0);
+  return rho * nn_hi * (1.0 - 0.5 * sl * sl) < hp_lo;
+}
+
 // The candidates that could reach the plane (S.nh, S.nn_hi, S.hp_lo), as runs of the cell order handed to
 // range(k0, k1); range returns false to stop.  traverse_near: the 3 x 3 cells around the candidate's own -- that is
 // where the binding constraints are; traverse_all: every cell the bound cannot clear (the near cells again included).
@@ -709,7 +725,8 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_scatter(const double *__restr
 // centre directions of the fine cells; coarse cells: centre direction and the largest rho of their fine cells
 __global__ __launch_bounds__(kHprBlock) void k_hpr_cells(HprGrid G, const unsigned long long *__restrict__ crho_bits,
                                                          double *__restrict__ cdir, double *__restrict__ Crho,
-                                                         double *__restrict__ Cdir, unsigned long long *__restrict__ rho_max_bits) {
+                                                         double *__restrict__ Cdir, unsigned long long *__restrict__ rho_max_bits,
+                                                         float4 *__restrict__ cell4, float4 *__restrict__ Cell4) {
   const int32_t t = static_cast<int32_t>(blockIdx.x) * kHprBlock + static_cast<int32_t>(threadIdx.x);
   const int32_t n_fine = G.gw * G.gh, n_coarse = G.cgw * G.cgh;
   if (t < n_fine) {
@@ -718,6 +735,9 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_cells(HprGrid G, const unsign
     cdir[t] = a * inv;
     cdir[n_fine + t] = b * inv;
     cdir[2 * n_fine + t] = inv;
+    const unsigned long long rb = crho_bits[t];
+    cell4[t] = make_float4(static_cast<float>(a * inv), static_cast<float>(b * inv), static_cast<float>(inv),
+                           rb ? __double2float_ru(__longlong_as_double(static_cast<long long>(rb))) : 0.0f);
   }
   if (t < n_coarse) {
     const int32_t Ci = t % G.cgw, Cj = t / G.cgw;
@@ -735,6 +755,8 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_cells(HprGrid G, const unsign
     Cdir[t] = a * inv;
     Cdir[n_coarse + t] = b * inv;
     Cdir[2 * n_coarse + t] = inv;
+    Cell4[t] = make_float4(static_cast<float>(a * inv), static_cast<float>(b * inv), static_cast<float>(inv),
+                           best ? __double2float_ru(__longlong_as_double(static_cast<long long>(best))) : 0.0f);
   }
 }
 
@@ -874,8 +896,8 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_radial(HprArrays A, HprGrid G
     const int32_t C = (open && t < wn) ? (W.j0 + t / ww) * G.cgw + W.i0 + t % ww : -1;
     bool copen = false;
     if (C >= 0) {
-      const double rho = A.Crho[C];
-      copen = rho > 0.0 && !cell_cleared(S, A.Cdir[C], A.Cdir[n_coarse + C], A.Cdir[2 * n_coarse + C], rho, G.r_coarse);
+      const float4 c4 = A.Cell4[C];
+      copen = c4.w > 0.0f && !cell_cleared_f32sep(S.nh.x, S.nh.y, S.nh.z, S.nn_hi, S.hp_lo, c4.x, c4.y, c4.z, c4.w, G.r_coarse + kCell4Slack);
     }
     uint32_t open_c = row_mask(copen);
     while (__ballot(open && open_c != 0u)) {
@@ -890,8 +912,8 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_radial(HprArrays A, HprGrid G
         int32_t f = 0;
         if (go_c && fi < G.gw && fj < G.gh && !(abs(fi - ci) <= 1 && abs(fj - cj) <= 1)) {
           f = fj * G.gw + fi;
-          const double rho = A.crho[f];
-          fopen = rho > 0.0 && !cell_cleared(S, A.cdir[f], A.cdir[n_fine + f], A.cdir[2 * n_fine + f], rho, G.r_fine);
+          const float4 c4 = A.cell4[f];
+          fopen = c4.w > 0.0f && !cell_cleared_f32sep(S.nh.x, S.nh.y, S.nh.z, S.nn_hi, S.hp_lo, c4.x, c4.y, c4.z, c4.w, G.r_fine + kCell4Slack);
         }
         uint32_t open_f = row_mask(fopen);
         while (__ballot(open && open_f != 0u)) {
@@ -915,6 +937,413 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_radial(HprArrays A, HprGrid G
     atomicAdd(&mine[4], batches);
   }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The search itself, 16 lanes per candidate (round 4).  What the radial pass leaves are candidates whose least-tilted
+// supporting plane is not the radial one (or that have none).  Their feasibility problem -- find s with s . D_q < E_q for
+// every q -- is solved here as the LEAST-NORM problem  min |s|^2  s.t.  s . D_q <= E_q - margin |D_q|  by the dual
+// active-set method: the trial tilt s is the least-norm point of at most two "active" half-planes (s = 0: none, the radial
+// plane); a point the trial plane does not clear adds its half-plane, the least-norm point of (active + new) is taken from
+// the three places where the new line can be tight (alone, or meeting one of the active lines), and the half-planes that
+// are tight there become the active set.  |s| grows strictly with every step, so no active set comes back; three
+// half-planes with nothing in common end the search with the same witness the polygon search ends with -- p inside the
+// tetrahedron (origin, q_a, q_b, q_c) -- CHECKED by the same filtered determinants, and a trial plane is a witness of
+// visibility only after one whole traversal in which it did not move: the same rounding-proof point test and cell bound
+// as k_hpr_radial / k_hpr_decide.  So the state of a search is two doubles and two lines -- no polygon, no cross-lane
+// bookkeeping --, four searches share a wavefront, and the arithmetic every lane of a 64-lane search repeated for one
+// candidate (frame, trial normal, window) now serves four.  Whatever ends otherwise (round-off, a parallel pair, a cap)
+// stays kStUndecided for k_hpr_decide, whose polygon remembers every half-plane it has seen.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr double kTiltMargin = 1.0e-9;  // the trial tilt stays this far (rad) inside every half-plane it knows: n . d <= -1e-9 |D| against a rounding bound of ~1e-13
+constexpr int kTiltMaxSteps = 200;      // half-planes added per search (a dense cluster next to the candidate: 41 seen on C3)
+constexpr int kTiltMaxPasses = 8;       // traversals per search
+
+// the maximum over the 16 lanes of a row, in every lane of the row (four rotations inside the row)
+__device__ __forceinline__ float row_max16(float v) {
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false)));  // row_ror:1
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false)));  // row_ror:2
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false)));  // row_ror:4
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false)));  // row_ror:8
+  return v;
+}
+
+struct TiltLine {
+  double x, y, f;  // unit normal and offset: inside is s . (x, y) <= f (the margin is in f)
+  int32_t id;      // the point whose half-plane it is (place in cell order)
+};
+
+struct Tilt {
+  double sx, sy;
+  int na;
+  TiltLine a, b;
+};
+
+__device__ __forceinline__ bool tilt_inside(const TiltLine &c, double sx, double sy) {
+  const double u = c.x * sx, v = c.y * sy;
+  return (u + v) <= c.f + 1.0e-12 * ((fabs(u) + fabs(v)) + fabs(c.f));
+}
+
+// 1: s moved (active set replaced); 2: (a, b, c) have nothing in common; 3: no conclusion
+__device__ __forceinline__ int tilt_add(Tilt &T, double Dx, double Dy, double E, int32_t id) {
+  const double len = sqrt(Dx * Dx + Dy * Dy);
+  if (!(len > 0.0) || !isfinite(len)) return 3;
+  const double inv = quick_rcp(len);
+  TiltLine c = {Dx * inv, Dy * inv, E * inv - kTiltMargin, id};
+  // the three places where c can be tight; the least-norm one that the other lines allow
+  double bx = 0.0, by = 0.0, bn = INFINITY;
+  int pick = -1;
+  {
+    const double x = c.f * c.x, y = c.f * c.y;
+    if ((T.na < 1 || tilt_inside(T.a, x, y)) && (T.na < 2 || tilt_inside(T.b, x, y))) {
+      bx = x;
+      by = y;
+      bn = x * x + y * y;
+      pick = 0;
+    }
+  }
+  if (T.na >= 1) {
+    double x, y;
+    if (line_meet(c.x, c.y, c.f, T.a.x, T.a.y, T.a.f, x, y) && (T.na < 2 || tilt_inside(T.b, x, y))) {
+      const double n2 = x * x + y * y;
+      if (n2 < bn) {
+        bx = x;
+        by = y;
+        bn = n2;
+        pick = 1;
+      }
+    }
+  }
+  if (T.na >= 2) {
+    double x, y;
+    if (line_meet(c.x, c.y, c.f, T.b.x, T.b.y, T.b.f, x, y) && tilt_inside(T.a, x, y)) {
+      const double n2 = x * x + y * y;
+      if (n2 < bn) {
+        bx = x;
+        by = y;
+        bn = n2;
+        pick = 2;
+      }
+    }
+  }
+  if (pick < 0) return T.na == 2 ? 2 : 3;
+  if (!(bn < kHprBox * kHprBox)) return 3;
+  if (pick == 0) {
+    T.a = c;
+    T.na = 1;
+  } else if (pick == 1) {
+    T.b = c;
+    T.na = 2;
+  } else {
+    T.a = c;
+    T.na = 2;
+  }
+  T.sx = bx;
+  T.sy = by;
+  return 1;
+}
+
+__device__ __forceinline__ void tilt_normal(Search &S, const Tilt &T) {
+  S.n = {S.e0.x + (T.sx * S.e1.x + T.sy * S.e2.x), S.e0.y + (T.sx * S.e1.y + T.sy * S.e2.y), S.e0.z + (T.sx * S.e1.z + T.sy * S.e2.z)};
+  const double nn = sqrt((S.n.x * S.n.x + S.n.y * S.n.y) + S.n.z * S.n.z);
+  const double inv = quick_rcp(nn);
+  S.nh = {S.n.x * inv, S.n.y * inv, S.n.z * inv};
+  S.nn_hi = nn * (1.0 + 1.0e-14);
+  S.hp_lo = ((S.n.x * S.p.x + S.n.y * S.p.y) + S.n.z * S.p.z) * (1.0 - 1.0e-13);
+}
+
+constexpr int kStatTilt = 23;  // block 0 of the tallies: length of k_hpr_tilt's list
+// The state of a search lives in LDS, one record per row (every lane of the row writes the same values, so each thread
+// reads what it wrote itself): carried in registers through the eight loop levels below it cost a copy per level -- the
+// first build of this kernel took 263 VGPRs (one wavefront per SIMD) for ~100 registers of state.
+struct TiltRow {
+  double n[3], nh[3], nn_hi, hp_lo;  // trial normal (tilt_normal)
+  double e0[3], e1[3], e2[3];        // frame at p
+  double sx, sy;                     // trial tilt
+  double ax, ay, af, bx, by, bf;     // active lines
+  int32_t aid, bid, na, last_id;
+};
+
+#define TILT_STORE_NORMAL(R, S) \
+  do {                         \
+    R.n[0] = S.n.x;            \
+    R.n[1] = S.n.y;            \
+    R.n[2] = S.n.z;            \
+    R.nh[0] = S.nh.x;          \
+    R.nh[1] = S.nh.y;          \
+    R.nh[2] = S.nh.z;          \
+    R.nn_hi = S.nn_hi;         \
+    R.hp_lo = S.hp_lo;         \
+  } while (0)
+
+#ifndef PCP_TILT_WPE
+#define PCP_TILT_WPE 3
+#endif
+template <bool kDebug>
+__global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_TILT_WPE, PCP_TILT_WPE))) void k_hpr_tilt(
+    HprArrays A, HprGrid G, uint8_t *__restrict__ state, const int32_t *__restrict__ todo, unsigned long long *__restrict__ stats) {
+  // Really in LDS: a compiler barrier in front of every group of reads keeps the compiler from forwarding the stores to them
+  // (and so from carrying the record in registers after all); not `volatile`, which turns the accesses into flat ones with an
+  // address pair per field (60 VGPRs).
+  __shared__ TiltRow rows[kHprBlock / 16];
+#define R rows[threadIdx.x >> 4]
+#define TILT_FENCE() asm volatile("" ::: "memory")
+  const int lane = lane_id();
+  const int rl = lane & 15, row_base = lane & 48;
+  const int32_t count = static_cast<int32_t>(stats[kStatTilt]);
+  const int32_t rows_total = static_cast<int32_t>(gridDim.x) * (kHprBlock / 16);
+  auto row_mask = [&](bool b) -> uint32_t { return static_cast<uint32_t>((__ballot(b) >> row_base) & 0xffffull); };
+  const int32_t n_coarse = G.cgw * G.cgh, n_fine = G.gw * G.gh;
+  for (int32_t u0 = static_cast<int32_t>(blockIdx.x) * (kHprBlock / 16) + static_cast<int32_t>(threadIdx.x >> 6) * 4; u0 < count;
+       u0 += rows_total) {  // (u0: the first row of this wavefront; uniform over the wavefront)
+    const int32_t u = u0 + (lane >> 4);
+    const bool have = u < count;
+    const int32_t j = have ? todo[u] : 0;
+    const int32_t self = j, self_idx = A.sidx[j];
+    const Vec3d p = load_point(A, j);
+    {
+      Search S;
+      S.p = p;
+      search_frame(S);
+      Tilt T;
+      T.sx = T.sy = 0.0;
+      T.na = 0;
+      tilt_normal(S, T);
+      TILT_STORE_NORMAL(R, S);
+      R.e0[0] = S.e0.x; R.e0[1] = S.e0.y; R.e0[2] = S.e0.z;
+      R.e1[0] = S.e1.x; R.e1[1] = S.e1.y; R.e1[2] = S.e1.z;
+      R.e2[0] = S.e2.x; R.e2[1] = S.e2.y; R.e2[2] = S.e2.z;
+      R.sx = R.sy = 0.0;
+      R.ax = R.ay = R.af = R.bx = R.by = R.bf = 0.0;
+      R.aid = R.bid = -1;
+      R.na = 0;
+      R.last_id = -1;
+      TILT_FENCE();
+    }
+    bool run = have;        // the row is still searching
+    bool changed = false;   // the trial plane moved during this pass
+    int outcome = 0;        // 0 none, 1 visible, 2 hidden duplicate, 3 empty (a, b, c below), 4 gave up
+    int32_t ca = -1, cb = -1, cc = -1;
+    int steps = 0, passes = 0, why4 = 0, wide = 0, last_wn = 0;
+    unsigned long long batches = 0;
+    auto stop = [&](int why) {
+      outcome = why;
+      run = false;
+    };
+    // one more half-plane: the difference vector (qx, qy, qz) of point qid.  The record in LDS is read, advanced and written back.
+    auto add_half_plane = [&](double qx, double qy, double qz, int32_t qid) {
+      TILT_FENCE();
+      Search S;
+      S.p = p;
+      S.e0 = {R.e0[0], R.e0[1], R.e0[2]};
+      S.e1 = {R.e1[0], R.e1[1], R.e1[2]};
+      S.e2 = {R.e2[0], R.e2[1], R.e2[2]};
+      const double Dx = (qx * S.e1.x + qy * S.e1.y) + qz * S.e1.z;
+      const double Dy = (qx * S.e2.x + qy * S.e2.y) + qz * S.e2.z;
+      const double E = -((qx * S.e0.x + qy * S.e0.y) + qz * S.e0.z);
+      Tilt T;
+      T.sx = R.sx;
+      T.sy = R.sy;
+      T.na = R.na;
+      T.a = {R.ax, R.ay, R.af, R.aid};
+      T.b = {R.bx, R.by, R.bf, R.bid};
+      const int32_t pa = T.a.id, pb = T.b.id;
+      const int r = tilt_add(T, Dx, Dy, E, qid);
+      if (r == 1) {
+        changed = true;
+        tilt_normal(S, T);
+        TILT_STORE_NORMAL(R, S);
+        R.sx = T.sx;
+        R.sy = T.sy;
+        R.na = T.na;
+        R.ax = T.a.x; R.ay = T.a.y; R.af = T.a.f; R.aid = T.a.id;
+        R.bx = T.b.x; R.by = T.b.y; R.bf = T.b.f; R.bid = T.b.id;
+        TILT_FENCE();
+      } else if (r == 2) {
+        ca = pa;
+        cb = pb;
+        cc = qid;
+        stop(3);
+      } else {
+        why4 = 2;
+        stop(4);
+      }
+    };
+    // points [k0, k1) of the cell order against the trial plane, 16 at a time; `go`: this row takes part
+    auto test_points = [&](bool go, int32_t k0, int32_t k1) {
+      for (int32_t base = k0; __ballot(go && run && base < k1); base += 16) {
+        const bool on = go && run && base < k1;
+        const int32_t k = base + rl;
+        const bool active = on && k < k1 && k != self;
+        double dx = 0.0, dy = 0.0, dz = 0.0;
+        bool dup = false, dup_lower = false;
+        if (active) {
+          dx = A.sx[k] - p.x;
+          dy = A.sy[k] - p.y;
+          dz = A.sz[k] - p.z;
+          dup = dx == 0.0 && dy == 0.0 && dz == 0.0;
+          if (dup) dup_lower = A.sidx[k] < self_idx;  // identical flipped points: the lowest input index stands for the group
+        }
+        if (on && rl == 0) batches += 1;
+        if (row_mask(dup_lower) && on) stop(2);
+        const bool mine = active && !dup;
+        for (int guard = 0;; ++guard) {
+          TILT_FENCE();
+          const double tx = R.n[0] * dx, ty = R.n[1] * dy, tz = R.n[2] * dz;
+          const double t = (tx + ty) + tz, Tt = (fabs(tx) + fabs(ty)) + fabs(tz);
+          const bool bad = run && mine && !(t < -kPointSlack * Tt);
+          if (!__ballot(bad)) break;
+          const uint32_t rm = row_mask(bad);
+          if (rm) {
+            // the worst of the row's points (largest n . d relative to its bound; the choice only steers)
+            const float score = bad ? static_cast<float>(t) * __builtin_amdgcn_rcpf(static_cast<float>(Tt)) : -INFINITY;
+            const float worst = row_max16(score);
+            const uint32_t at = row_mask(bad && score == worst);
+            const int src = row_base + __builtin_ctz(at ? at : rm);
+            const double qx = __shfl(dx, src, 64), qy = __shfl(dy, src, 64), qz = __shfl(dz, src, 64);
+            const int32_t qid = base + (src - row_base);
+            // a point that is not cleared right after its own half-plane was added lies within round-off of every plane the
+            // margin allows: not for this pass
+            TILT_FENCE();
+            const int32_t last_id = R.last_id;
+            if (qid == last_id || ++steps > kTiltMaxSteps || guard > 24) {
+              why4 = qid == last_id ? 0 : 1;
+              stop(4);
+            } else {
+              R.last_id = qid;
+              add_half_plane(qx, qy, qz, qid);
+            }
+          }
+        }
+      }
+    };
+    auto cleared = [&](double ux, double uy, double uz, double rho, double r) -> bool {
+      TILT_FENCE();
+      return cell_cleared_f32sep(R.nh[0], R.nh[1], R.nh[2], R.nn_hi, R.hp_lo, ux, uy, uz, rho, r);  // on the row's record
+    };
+    const int32_t cell = A.scell[self];
+    const int32_t ci = cell % G.gw, cj = cell / G.gw;
+    for (int pass = 0; __ballot(run); ++pass) {
+      if (run && pass >= kTiltMaxPasses) {
+        why4 = 3;
+        stop(4);
+      }
+      if (run) ++passes;
+      // the 3 x 3 cells around the candidate's own -- that is where the binding half-planes are -- until the plane rests there
+      bool again = run;
+      for (int nit = 0; __ballot(again); ++nit) {
+        changed = false;
+#pragma unroll 1
+        for (int dj = -1; dj <= 1; ++dj) {
+          const int32_t rj = cj + dj;
+          const bool in = rj >= 0 && rj < G.gh;
+          const int32_t c0 = (in ? rj : cj) * G.gw + max(ci - 1, 0), c1 = (in ? rj : cj) * G.gw + min(ci + 1, G.gw - 1);
+          test_points(in && again, A.cstart[c0], A.cstart[c1 + 1]);
+        }
+        if (run && again && changed && nit >= 12) {
+          why4 = 3;
+          stop(4);
+        }
+        again = again && run && changed;
+      }
+      // (rows still running: the near cells accept the plane, changed == false)
+      // every other cell the bound cannot clear.  A point in there that moves the plane does not end the sweep: the rest of
+      // the window is taken with the new plane (its half-planes are collected in this sweep instead of one per pass) and
+      // the next pass starts over -- a plane is only a witness after a whole pass in which it did not move.
+      Window W;
+      {
+        TILT_FENCE();
+        Search S;
+        S.nh = {R.nh[0], R.nh[1], R.nh[2]};
+        S.nn_hi = R.nn_hi;
+        S.hp_lo = R.hp_lo;
+        W = reach_window(S, G);
+      }
+      const bool has_window = run && W.i0 <= W.i1 && W.j0 <= W.j1;
+      const int32_t ww = has_window ? W.i1 - W.i0 + 1 : 1, wn = has_window ? ww * (W.j1 - W.j0 + 1) : 0;
+      if (kDebug) {
+        if (wn > 256) ++wide;
+        if (run) last_wn = wn;
+      }
+      for (int32_t cbk = 0; __ballot(run && cbk < wn); cbk += 16) {
+        const int32_t t = cbk + rl;
+        const int32_t C = (run && t < wn) ? (W.j0 + t / ww) * G.cgw + W.i0 + t % ww : -1;
+        bool copen = false;
+        if (C >= 0) {
+          const float4 c4 = A.Cell4[C];
+          copen = c4.w > 0.0f && !cleared(c4.x, c4.y, c4.z, c4.w, G.r_coarse + kCell4Slack);
+        }
+        uint32_t open_c = row_mask(copen);
+        while (__ballot(run && open_c != 0u)) {
+          const bool go_c = run && open_c != 0u;
+          const int bc = go_c ? __builtin_ctz(open_c) : 0;
+          open_c &= open_c - 1u;
+          const int32_t Cc = __shfl(C, row_base + bc, 64);
+#pragma unroll 1
+          for (int q4 = 0; q4 < 4; ++q4) {  // the 64 fine cells of the coarse cell, 16 at a time
+            const int fidx = q4 * 16 + rl;
+            const int32_t fi = (go_c ? Cc % G.cgw : 0) * kHprCoarse + (fidx & 7), fj = (go_c ? Cc / G.cgw : 0) * kHprCoarse + (fidx >> 3);
+            bool fopen = false;
+            int32_t f = 0;
+            if (go_c && run && fi < G.gw && fj < G.gh && !(abs(fi - ci) <= 1 && abs(fj - cj) <= 1)) {
+              f = fj * G.gw + fi;
+              const float4 c4 = A.cell4[f];
+              fopen = c4.w > 0.0f && !cleared(c4.x, c4.y, c4.z, c4.w, G.r_fine + kCell4Slack);
+            }
+            uint32_t open_f = row_mask(fopen);
+            while (__ballot(run && open_f != 0u)) {
+              const bool go_f = run && open_f != 0u;
+              const int bf = go_f ? __builtin_ctz(open_f) : 0;
+              open_f &= open_f - 1u;
+              const int32_t ff = __shfl(f, row_base + bf, 64);
+              test_points(go_f, go_f ? A.cstart[ff] : 0, go_f ? A.cstart[ff + 1] : 0);
+            }
+          }
+        }
+      }
+      if (run && !changed) stop(1);  // one whole pass with a plane that did not move: every other point is strictly inside
+    }
+    // the witness of "hidden": p in the tetrahedron (origin, a, b, c) of the three half-planes with nothing in common
+    int32_t out = kStUndecided;
+    if (outcome == 1) out = kStVisible;
+    else if (outcome == 2) out = kStHidden;
+    if (__ballot(outcome == 3)) {
+      if (outcome == 3 && ca >= 0 && cb >= 0 && cc >= 0 &&
+          tetra_contains_filtered(p, load_point(A, ca), load_point(A, cb), load_point(A, cc)))
+        out = kStHidden;
+    }
+    if (have && rl == 0) {
+      unsigned long long *mine = stats + kStatStride * (1 + (blockIdx.x % kStatCopies));
+      if (out != kStUndecided) {
+        state[j] = static_cast<uint8_t>(out);
+        atomicAdd(&mine[out], 1ull);
+      }
+      atomicAdd(&mine[3], static_cast<unsigned long long>(steps + 1));
+      atomicAdd(&mine[4], (batches + 3ull) / 4ull);
+      if (kDebug) {  // PCP_HPR_DEBUG: what became of the searches (words 9.. of the copies; nothing else uses them)
+        if (outcome == 4)
+          printf("hpr: tilt gave up on %d: why %d passes %d steps %d batches %llu |s| %.3g na %d window %d coarse cells of %d, p = (%.17g, %.17g, %.17g)\n",
+                 j, why4, passes, steps, batches, sqrt(R.sx * R.sx + R.sy * R.sy), R.na, last_wn, n_coarse, p.x, p.y, p.z);
+        atomicAdd(&mine[9], 1ull);
+        atomicAdd(&mine[10 + min(outcome, 4)], 1ull);  // 10 none 11 visible 12 duplicate 13 empty 14 gave up
+        if (outcome == 3 && out == kStHidden) atomicAdd(&mine[15], 1ull);
+        if (outcome == 4) atomicAdd(&mine[16 + min(why4, 3)], 1ull);  // 16 same point again 17 step cap 18 no conclusion 19 pass cap
+        atomicAdd(&mine[20], static_cast<unsigned long long>(passes));
+        atomicAdd(&mine[21], static_cast<unsigned long long>(steps));
+        atomicAdd(&mine[22], batches);
+        atomicMax(&mine[28], batches);
+        if (batches > 2000ull) {
+          atomicAdd(&mine[29], 1ull);
+          atomicAdd(&mine[31], batches);
+        }
+        atomicAdd(&mine[30], static_cast<unsigned long long>(wide));
+      }
+    }
+  }
+}
+
+#undef R
+#undef TILT_STORE_NORMAL
+#undef TILT_FENCE
 
 // stats: [0] hidden [1] visible [2] undecided [3] trial normals [4] batches of 64 point tests [5] second-box retries
 // [6] unresolved [7] exact predicate evaluations [8] length of the list for k_hpr_exact
@@ -992,6 +1421,7 @@ __device__ __forceinline__ void hpr_decide_one(const HprArrays &A, const HprGrid
 // workgroups of ONE wavefront: with four, a workgroup's slots were refilled only as fast as whole workgroups could be placed
 // (1.38 resident wavefronts per SIMD of 2, profiles/r03q_hpr_pmc.json)
 constexpr int32_t kHprDecideGrid = 65536;
+constexpr int32_t kHprTiltGrid = 4096;  // workgroups of k_hpr_tilt (16 rows each) striding over its list
 #ifndef PCP_DECIDE_WPE
 #define PCP_DECIDE_WPE 2  // 214 VGPRs, nothing spilled; at 3 wavefronts per SIMD (168 VGPRs) 63 registers went to scratch: hull pass 0.312 -> 0.285 s once the searches ran from a list
 #endif
@@ -1386,18 +1816,21 @@ int hpr_finish(pcp_context *ctx, HprLane &L, bool timed) {
   // and cursor (n_fine) as int32 | centre directions (3 n_fine), coarse rho / directions (4 n_coarse)
   const size_t nf = static_cast<size_t>(n_fine), nc = static_cast<size_t>(n_coarse);
   const size_t int_words = (2 * nf + 16 + 1) / 2;  // the int32 part, in 8-byte words
-  PCP_HIP_TRY(ctx, L.cells_d.ensure(2 * nf + int_words + 3 * nf + 4 * nc + 16));
+  PCP_HIP_TRY(ctx, L.cells_d.ensure(2 * nf + int_words + 3 * nf + 4 * nc + 2 * nf + 2 * nc + 18));
   double *crho = L.cells_d.p;
   unsigned long long *crep_all = reinterpret_cast<unsigned long long *>(crho + nf);
   int32_t *cstart = reinterpret_cast<int32_t *>(crho + 2 * nf), *cursor = cstart + n_fine + 2;
   double *cdir = crho + 2 * nf + int_words, *Crho = cdir + 3 * nf, *Cdir = Crho + nc;
+  size_t off4 = 5 * nf + int_words + 4 * nc;
+  off4 += off4 & 1;  // 16-byte aligned
+  float4 *cell4 = reinterpret_cast<float4 *>(crho + off4), *Cell4 = cell4 + nf;
   PCP_HIP_TRY(ctx, hipMemsetAsync(crho, 0, (2 * nf + int_words) * sizeof(double), stream));
   // PCP_HPR_QUICK=0 / PCP_HPR_RADIAL=0: without the two passes in front of the search (results identical; the place of a
   // representative needs 26 bits)
   const char *qe = std::getenv("PCP_HPR_QUICK");
   const bool quick = !(qe && qe[0] == '0') && m < (1 << 26);
   unsigned long long *crep = quick ? crep_all : nullptr;
-  HprArrays A{sx, sy, sz, sidx, scell, cstart, crho, cdir, Crho, Cdir, crep};
+  HprArrays A{sx, sy, sz, sidx, scell, cstart, crho, cdir, Crho, Cdir, crep, cell4, Cell4};
   // PCP_HPR_FORCE_EXACT=1 (tests): every candidate takes the exact path; read per call
   const char *fe = std::getenv("PCP_HPR_FORCE_EXACT");
   const bool force_exact = fe && fe[0] == '1';
@@ -1409,7 +1842,7 @@ int hpr_finish(pcp_context *ctx, HprLane &L, bool timed) {
                        cell, m, cstart, cursor, sx, sy, sz, sidx, splace, scell,
                        reinterpret_cast<unsigned long long *>(crho), crep);
     hipLaunchKernelGGL(k_hpr_cells, dim3(hpr_blocks(std::max(n_fine, n_coarse))), dim3(kHprBlock), 0, stream, G,
-                       reinterpret_cast<const unsigned long long *>(crho), cdir, Crho, Cdir, stats + 28);
+                       reinterpret_cast<const unsigned long long *>(crho), cdir, Crho, Cdir, stats + 28, cell4, Cell4);
     // PCP_HPR_RADIAL=0: every candidate through k_hpr_decide (results identical)
     const char *re = std::getenv("PCP_HPR_RADIAL");
     if (quick && !force_exact)
@@ -1432,9 +1865,20 @@ int hpr_finish(pcp_context *ctx, HprLane &L, bool timed) {
       (void)hipMemcpyAsync(dbg_before.data(), L.state.p, sm, hipMemcpyDeviceToHost, stream);
       (void)hipStreamSynchronize(stream);
     }
+    // PCP_HPR_TILT=0: without the 16-lane search in front of the 64-lane one (results identical)
+    const char *te = std::getenv("PCP_HPR_TILT");
+    if (!force_exact && !(te && te[0] == '0')) {
+      hipLaunchKernelGGL(k_hpr_list, dim3(static_cast<uint32_t>(div_up(m, kHprBlock * kHprListPer))), dim3(kHprBlock), 0, stream,
+                         L.state.p, m, todo, stats + kStatTilt);
+      hipLaunchKernelGGL(std::getenv("PCP_HPR_DEBUG") ? k_hpr_tilt<true> : k_hpr_tilt<false>,
+                         dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(m, kHprBlock / 16), kHprTiltGrid))),
+                         dim3(kHprBlock), 0, stream, A, G, L.state.p, todo, stats);
+    }
     hipLaunchKernelGGL(k_hpr_list, dim3(static_cast<uint32_t>(div_up(m, kHprBlock * kHprListPer))), dim3(kHprBlock), 0, stream,
                        L.state.p, m, todo, stats + kStatSearch);
-    hipLaunchKernelGGL(k_hpr_decide, dim3(static_cast<uint32_t>(std::min<int64_t>(m, kHprDecideGrid))), dim3(64),
+    // (after k_hpr_tilt a few dozen candidates are left: a grid of 64 K one-wavefront workgroups that find nothing costs 15 us)
+    const bool tilted = !force_exact && !(te && te[0] == '0');
+    hipLaunchKernelGGL(k_hpr_decide, dim3(static_cast<uint32_t>(std::min<int64_t>(m, tilted ? 2048 : kHprDecideGrid))), dim3(64),
                        0, stream, A, G, L.state.p, todo, undecided, stats, force_exact ? 1 : 0);
     if (!dbg_before.empty()) {
       std::vector<uint8_t> after(sm);
@@ -1477,6 +1921,23 @@ int hpr_finish(pcp_context *ctx, HprLane &L, bool timed) {
     // why candidates left the floating-point path: a point within round-off of the last trial plane / a simplex the
     // filter could not sign / an emptied polygon that still had an edge of the initial box / searches that gave up
     // (inner-loop guard, restart cap, non-contiguous clip, more than 64 polygon vertices)
+    {
+      std::vector<unsigned long long> all(kStatWords);
+      (void)hipMemcpy(all.data(), stats, kStatWords * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      unsigned long long w[14] = {0}, bmax = 0, big = 0, wide = 0, bigsum = 0;
+      for (int c = 1; c <= kStatCopies; ++c) {
+        for (int k = 0; k < 14; ++k) w[k] += all[static_cast<size_t>(c * kStatStride + 9 + k)];
+        bmax = std::max(bmax, all[static_cast<size_t>(c * kStatStride + 28)]);
+        big += all[static_cast<size_t>(c * kStatStride + 29)];
+        wide += all[static_cast<size_t>(c * kStatStride + 30)];
+        bigsum += all[static_cast<size_t>(c * kStatStride + 31)];
+      }
+      fprintf(stderr, "hpr: tilt: longest search %llu batches; %llu searches of > 2000 batches (%llu batches together); %llu passes with a window of > 256 coarse cells\n",
+              bmax, big, bigsum, wide);
+      fprintf(stderr, "hpr: tilt: %llu searches: visible %llu duplicate %llu empty %llu (certified %llu) gave up %llu (same point %llu, step cap %llu, "
+              "no conclusion %llu, pass cap %llu); passes %llu steps %llu batches %llu\n", w[0], w[2], w[3], w[4], w[6], w[5], w[7], w[8], w[9],
+              w[10], w[11], w[12], w[13]);
+    }
     fprintf(stderr, "hpr: to the exact path: uncertain_left %llu tetra_filter %llu box_cert %llu fail: guard %llu restarts %llu noncontig %llu overflow %llu\n", dbg[10], dbg[11], dbg[12], dbg[14], dbg[15], dbg[16], dbg[17]);
   }
   return PCP_OK;

@@ -254,8 +254,11 @@ struct pcp_context {
   pcp::DevBuf<uint8_t> c_mark;    // pcp_cloud_smooth: per uploaded point, survives the whole chain
   pcp::DevBuf<int32_t> c_where;   // ... and the result row that holds it
   pcp::DevBuf<float> c_xyz, c_xyz2;  // pcp_cloud_smooth: intermediate clouds (SoA)
-  pcp::DevBuf<uint32_t> v_bitmap;  // dilated voxel set, dense bitmap over the bounding box
-  pcp::DevBuf<int32_t> v_offsets;  // set bits per tile of 1024 bitmap words (k_voxel_tile_counts)
+  pcp::DevBuf<uint32_t> v_bitmap;  // dilated voxel set: the bits of the occupied bricks (or the dense bitmap over the bounding box, PCP_VGD_DENSE=1)
+  pcp::DevBuf<int32_t> v_offsets;  // set bits per strip of the brick form (per tile of 1024 words of the dense bitmap)
+  pcp::DevBuf<uint32_t> v_occ;     // brick form: one bit per brick place
+  pcp::DevBuf<int32_t> v_rank;     // brick form: occupied places before each word of v_occ
+  pcp::DevBuf<unsigned long long> v_plane;  // brick form: voxels per plane ix
   pcp::DevBuf<int64_t> v_vox;      // occupied voxels (linear index) in key order
   pcp::DevBuf<float> mls_xyz, mls_normal, mls_curv;
   pcp::DevBuf<int32_t> mls_index;

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <limits>
 
 #include "pcp_internal.hpp"
 #include "pcp_scan.hpp"
@@ -758,6 +759,216 @@ __global__ __launch_bounds__(kScanBlock) void k_voxel_tile_counts(const uint32_t
     int32_t total;
     (void)scan_block_exclusive(c, &total, ws);
     if (threadIdx.x == 0) tile_count[tile] = total;
+  }
+}
+
+
+// ---------------------------------------------------------------------------
+// The voxel set as BRICKS (round 4): memory that follows the surface.  The dense bitmap above costs one bit per voxel of the
+// bounding box -- 60 GB for a 12 x 10 x 4 m room at 1 mm, and a 40 x 40 x 5 m map does not fit at all, where PCL's std::map
+// only grows with the occupied voxels.  Here the box is cut into bricks of 16 x 16 x 16 voxels (512 B of bits each) and only
+// the bricks a stamped cube reaches exist: one occupancy bit per brick place, linear index (bx NBY + by) NBZ + bz, with the
+// running popcount per 32-bit word, so that a brick's storage slot is its RANK among the occupied places (two loads and a
+// popcount; no allocation atomics, and slots are numbered in the same order on every run).
+//
+// Inside a brick bit ((lx 16 + ly) 16 + lz): a row of 16 z-neighbours is half a word.  PCL's key order ix, iy, iz has iz
+// fastest, so for a fixed ix the 16 columns iy = 16 by .. 16 by + 15 are ONE contiguous key range: the "strip" (ix, by), whose
+// bits are the rows lx = ix & 15 of the bricks (ix >> 4, by, 0 .. NBZ - 1) -- consecutive storage slots.  Strips in the order
+// ix NBY + by are the key order; they play the part the tiles of 1024 bitmap words play in the dense form: counted
+// (k_brick_strip_counts), cut into chunks by the host, expanded into the list of occupied voxels (k_brick_expand) in
+// ascending key order, and k_voxel_emit takes it from there unchanged.
+// ---------------------------------------------------------------------------
+constexpr int kBrick = 16;
+constexpr int kBrickWords = kBrick * kBrick * kBrick / 32;  // 128
+constexpr int kBrickColumnMax = 4096;  // bricks along z (k_brick_expand keeps a column's list in LDS): 65 m at 1 mm
+
+__device__ __forceinline__ int lane_of() { return static_cast<int>(threadIdx.x & 63u); }
+
+struct BrickDesc {
+  VoxelDesc v;
+  int32_t NBX, NBY, NBZ;
+  const uint32_t *occ;   // one bit per brick place
+  const int32_t *rank;   // occupied places in the words before this one
+  uint32_t *bits;        // kBrickWords words per occupied brick, in rank order
+};
+
+__device__ __forceinline__ int64_t brick_place(const BrickDesc &B, int32_t bx, int32_t by, int32_t bz) {
+  return (static_cast<int64_t>(bx) * B.NBY + by) * B.NBZ + bz;
+}
+
+__device__ __forceinline__ int32_t brick_slot(const BrickDesc &B, int64_t place) {
+  const int64_t w = place >> 5;
+  return B.rank[w] + __popc(B.occ[w] & ((1u << (place & 31)) - 1u));
+}
+
+// every point marks the bricks its dilated cube reaches (at most 2 x 2 x 2 for cubes of up to 17 voxels)
+__global__ __launch_bounds__(kMB) void k_brick_mark(const float *__restrict__ x, const float *__restrict__ y,
+                                                    const float *__restrict__ z, int64_t n, BrickDesc B, uint32_t *__restrict__ occ) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  if (i >= n) return;
+  const float px = x[i];
+  if (!isfinite(px)) return;  // MLSVoxelGrid ctor skips non-finite points
+  int32_t ix, iy, iz;
+  voxel_of(B.v, px, y[i], z[i], ix, iy, iz);
+  const int32_t bx0 = max(ix - B.v.it, 0) >> 4, bx1 = min(ix + B.v.it, B.v.NX - 1) >> 4;
+  const int32_t by0 = max(iy - B.v.it, 0) >> 4, by1 = min(iy + B.v.it, B.v.NY - 1) >> 4;
+  const int32_t bz0 = max(iz - B.v.it, 0) >> 4, bz1 = min(iz + B.v.it, B.v.NZ - 1) >> 4;
+  for (int32_t bx = bx0; bx <= bx1; ++bx)
+    for (int32_t by = by0; by <= by1; ++by)
+      for (int32_t bz = bz0; bz <= bz1; ++bz) {
+        const int64_t place = brick_place(B, bx, by, bz);
+        const uint32_t m = 1u << (place & 31);
+        if (!(occ[place >> 5] & m)) atomicOr(occ + (place >> 5), m);  // (neighbouring points reach the same bricks: read first)
+      }
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_brick_popc(const uint32_t *__restrict__ occ, int64_t words, int32_t *__restrict__ cnt) {
+  for (int64_t w = static_cast<int64_t>(blockIdx.x) * kScanBlock + threadIdx.x; w < words; w += static_cast<int64_t>(gridDim.x) * kScanBlock)
+    cnt[w] = __popc(occ[w]);
+}
+
+// the dilated cube of every point, stamped into its bricks (k_voxel_stamp on the brick storage)
+__global__ __launch_bounds__(kMB) void k_brick_stamp(const float *__restrict__ x, const float *__restrict__ y,
+                                                     const float *__restrict__ z, int64_t n, BrickDesc B) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  if (i >= n) return;
+  const float px = x[i];
+  if (!isfinite(px)) return;
+  int32_t ix, iy, iz;
+  voxel_of(B.v, px, y[i], z[i], ix, iy, iz);
+  const int32_t x0 = max(ix - B.v.it, 0), x1 = min(ix + B.v.it, B.v.NX - 1);
+  const int32_t y0 = max(iy - B.v.it, 0), y1 = min(iy + B.v.it, B.v.NY - 1);
+  const int32_t z0 = max(iz - B.v.it, 0), z1 = min(iz + B.v.it, B.v.NZ - 1);
+  for (int32_t bz = z0 >> 4; bz <= (z1 >> 4); ++bz) {
+    // the cube's z-run inside this layer of bricks: bits [l0, l1] of a 16-bit row
+    const int32_t l0 = max(z0, bz << 4) - (bz << 4), l1 = min(z1, (bz << 4) + 15) - (bz << 4);
+    const uint32_t row = ((1u << (l1 - l0 + 1)) - 1u) << l0;
+    for (int32_t bx = x0 >> 4; bx <= (x1 >> 4); ++bx)
+      for (int32_t by = y0 >> 4; by <= (y1 >> 4); ++by) {
+        uint32_t *bits = B.bits + static_cast<int64_t>(brick_slot(B, brick_place(B, bx, by, bz))) * kBrickWords;
+        const int32_t cx0 = max(x0, bx << 4), cx1 = min(x1, (bx << 4) + 15);
+        const int32_t cy0 = max(y0, by << 4), cy1 = min(y1, (by << 4) + 15);
+        for (int32_t cx = cx0; cx <= cx1; ++cx)
+          for (int32_t cy = cy0; cy <= cy1; ++cy) {
+            const int32_t r = ((cx & 15) << 4) | (cy & 15);
+            const uint32_t m = row << ((r & 1) << 4);
+            uint32_t *wd = bits + (r >> 1);
+            if ((*wd & m) != m) atomicOr(wd, m);
+          }
+      }
+  }
+}
+
+// the occupied bricks of brick column (bx, by): their number and the storage slot of the first (the column's places are NBZ
+// consecutive bits of the occupancy bitmap, its bricks consecutive slots).  All lanes of the wavefront call it.
+__device__ __forceinline__ int32_t brick_column(const BrickDesc &B, int64_t col, int32_t *slot0) {
+  const int64_t b0 = col * B.NBZ, b1 = b0 + B.NBZ;  // bits [b0, b1)
+  const int64_t w0 = b0 >> 5, w1 = (b1 + 31) >> 5;
+  int32_t nb = 0;
+  for (int64_t w = w0 + lane_of(); w < w1; w += 64) {
+    uint32_t bits = B.occ[w];
+    if (w == w0) bits &= ~((1u << (b0 & 31)) - 1u);
+    if (w == w1 - 1 && (b1 & 31)) bits &= (1u << (b1 & 31)) - 1u;
+    nb += __popc(bits);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) nb += __shfl_xor(nb, o, 64);
+  *slot0 = nb ? brick_slot(B, b0) : 0;
+  return nb;
+}
+
+// set bits per strip (ix, by), and per plane ix in 64 bits: one wavefront per brick column, lane = (lx, quarter of the 16 rows)
+__global__ __launch_bounds__(64) void k_brick_strip_counts(BrickDesc B, int32_t *__restrict__ strip_count,
+                                                           unsigned long long *__restrict__ plane_count) {
+  const int64_t cols = static_cast<int64_t>(B.NBX) * B.NBY;
+  const int lane = lane_of();
+  for (int64_t col = blockIdx.x; col < cols; col += gridDim.x) {
+    int32_t slot0;
+    const int32_t nb = brick_column(B, col, &slot0);
+    if (nb == 0) continue;  // (the counts were zeroed)
+    int32_t c = 0;
+    for (int32_t k = 0; k < nb; ++k) {
+      const uint2 wv = *reinterpret_cast<const uint2 *>(B.bits + static_cast<int64_t>(slot0 + k) * kBrickWords + lane * 2);
+      c += __popc(wv.x) + __popc(wv.y);
+    }
+    c += __shfl_xor(c, 1, 64);
+    c += __shfl_xor(c, 2, 64);  // words [lx 8, lx 8 + 8) = the 16 rows of lx: four lanes
+    const int32_t bx = static_cast<int32_t>(col / B.NBY), by = static_cast<int32_t>(col % B.NBY);
+    const int32_t ix = (bx << 4) + (lane >> 2);
+    if ((lane & 3) == 0 && ix < B.v.NX && c > 0) {
+      strip_count[static_cast<int64_t>(ix) * B.NBY + by] = c;
+      atomicAdd(plane_count + ix, static_cast<unsigned long long>(c));
+    }
+  }
+}
+
+// the occupied voxels of strips [s0, s0 + strips) in key order: one wavefront per strip, lane = (column ly, k-th brick of the
+// column), 16 z-neighbours each; strip_first = exclusive prefix of the strips' counts inside the chunk
+__global__ __launch_bounds__(64) void k_brick_expand(BrickDesc B, const int32_t *__restrict__ strip_count,
+                                                     const int32_t *__restrict__ strip_first, int64_t s0, int64_t strips,
+                                                     int64_t *__restrict__ vox) {
+  __shared__ int16_t bz_of[kBrickColumnMax];
+  const int lane = lane_of();
+  for (int64_t t = blockIdx.x; t < strips; t += gridDim.x) {
+    const int64_t s = s0 + t;
+    if (strip_count[s] == 0) continue;
+    const int32_t ix = static_cast<int32_t>(s / B.NBY), by = static_cast<int32_t>(s % B.NBY);
+    const int64_t col = static_cast<int64_t>(ix >> 4) * B.NBY + by;
+    // the column's bricks: bz of the k-th one, in LDS
+    const int64_t b0 = col * B.NBZ, b1 = b0 + B.NBZ, w0 = b0 >> 5, w1 = (b1 + 31) >> 5;
+    int32_t nb = 0;
+    __syncthreads();  // (one wavefront: orders the reuse of bz_of)
+    for (int64_t wb = w0; wb < w1; wb += 64) {
+      const int64_t w = wb + lane;
+      uint32_t bits = w < w1 ? B.occ[w] : 0u;
+      if (w == w0) bits &= ~((1u << (b0 & 31)) - 1u);
+      if (w == w1 - 1 && (b1 & 31)) bits &= (1u << (b1 & 31)) - 1u;
+      const int32_t c = __popc(bits);
+      int32_t incl = c;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int32_t u = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += u;
+      }
+      int32_t at = nb + incl - c;
+      while (bits) {
+        const int32_t bit = __builtin_ctz(bits);
+        bits &= bits - 1u;
+        if (at < kBrickColumnMax) bz_of[at] = static_cast<int16_t>((w << 5) + bit - b0);
+        ++at;
+      }
+      nb += __shfl(incl, 63, 64);
+    }
+    __syncthreads();
+    const int32_t slot0 = brick_slot(B, b0);
+    const int32_t lx = ix & 15;
+    int64_t out = strip_first[t];
+    const int32_t rows = 16 * nb;
+    for (int32_t r0 = 0; r0 < rows; r0 += 64) {
+      const int32_t r = r0 + lane;
+      uint32_t bits = 0u;
+      int32_t ly = 0, k = 0;
+      if (r < rows) {
+        ly = r / nb;
+        k = r % nb;
+        const int32_t rr = (lx << 4) | ly;
+        bits = (B.bits[static_cast<int64_t>(slot0 + k) * kBrickWords + (rr >> 1)] >> ((rr & 1) << 4)) & 0xffffu;
+      }
+      const int32_t c = __popc(bits);
+      int32_t incl = c;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int32_t u = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += u;
+      }
+      int64_t at = out + incl - c;
+      const int64_t key0 = (static_cast<int64_t>(ix) * B.v.NY + ((by << 4) + ly)) * B.v.NZ + (static_cast<int64_t>(bz_of[k < kBrickColumnMax ? k : 0]) << 4);
+      while (bits) {
+        vox[at++] = key0 + __builtin_ctz(bits);
+        bits &= bits - 1u;
+      }
+      out += __shfl(incl, 63, 64);
+    }
   }
 }
 
@@ -1937,11 +2148,139 @@ struct VgdStream {  // plain data: kept in ctx->vgd_blob between pcp_mls_stream_
   const int32_t *remap;
   size_t plane;
   int32_t order_poly;
+  int32_t bricks;         // 1: the voxel set is in bricks (chunks are runs of strips), 0: dense bitmap (runs of words)
+  int32_t NBX, NBY, NBZ;
 };
 
-static int vgd_prepare(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *p, VoxelDesc *out_v,
-                       std::vector<int32_t> *tile_counts, unsigned long long *out_total) {
+// PCP_VGD_DENSE=1: the dense bitmap of rounds 2-3 (one bit per voxel of the bounding box); results identical
+static bool vgd_dense_form() {
+  const char *e = std::getenv("PCP_VGD_DENSE");
+  return e && e[0] == '1';
+}
+
+static BrickDesc brick_desc(pcp_context *ctx, const VoxelDesc &v) {
+  BrickDesc B{};
+  B.v = v;
+  B.NBX = (v.NX + kBrick - 1) / kBrick;
+  B.NBY = (v.NY + kBrick - 1) / kBrick;
+  B.NBZ = (v.NZ + kBrick - 1) / kBrick;
+  B.occ = ctx->v_occ.p;
+  B.rank = ctx->v_rank.p;
+  B.bits = ctx->v_bitmap.p;
+  return B;
+}
+
+// The dilated voxel set in bricks: occupancy marks, ranks, storage sized from the number of occupied bricks, stamps,
+// counts per strip and per plane.  `plane_counts` (NX entries, 64-bit) come to the host; the strips' counts stay on the
+// device (ctx->v_offsets) and the chunk planner fetches a plane's strips only where a chunk boundary falls inside it.
+static int vgd_prepare_bricks(pcp_context *ctx, const CloudView &cv, const VoxelDesc &v0, std::vector<unsigned long long> *plane_counts,
+                              unsigned long long *out_total, bool *fits) {
+  *fits = false;
+  VoxelDesc v = v0;
+  v.words = 0;
+  BrickDesc B = brick_desc(ctx, v);
+  if (B.NBZ > kBrickColumnMax) return PCP_OK;  // (taller than the brick form handles: the caller falls back to the dense form)
+  const int64_t places = static_cast<int64_t>(B.NBX) * B.NBY * B.NBZ;
+  const int64_t occ_words = (places + 31) / 32 + 1;
+  const int64_t strips = static_cast<int64_t>(v.NX) * B.NBY;
+  size_t free_b = 0, total_b = 0;
+  PCP_HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+  const double have = static_cast<double>(free_b) + 4.0 * (static_cast<double>(ctx->v_occ.count) + static_cast<double>(ctx->v_rank.count) +
+                                                            static_cast<double>(ctx->v_offsets.count) + static_cast<double>(ctx->v_bitmap.count));
+  if (8.0 * static_cast<double>(occ_words) + 4.0 * static_cast<double>(strips) > 0.5 * have) return PCP_OK;
+  PCP_HIP_TRY(ctx, ctx->v_occ.ensure(static_cast<size_t>(occ_words) + 8));
+  PCP_HIP_TRY(ctx, ctx->v_rank.ensure(static_cast<size_t>(occ_words) + 8));
+  PCP_HIP_TRY(ctx, ctx->v_offsets.ensure(static_cast<size_t>(strips) + 8));
+  PCP_HIP_TRY(ctx, ctx->v_plane.ensure(static_cast<size_t>(v.NX) + 8));
+  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->v_occ.p, 0, static_cast<size_t>(occ_words) * 4, ctx->stream));
+  B = brick_desc(ctx, v);
   const int64_t n = cv.n;
+  const int64_t tiles = std::max<int64_t>(1, div_up(occ_words, kScanTile));
+  PCP_HIP_TRY(ctx, ctx->s_tiles.ensure(static_cast<size_t>(tiles) + 16));
+  unsigned long long *d_total = reinterpret_cast<unsigned long long *>(ctx->v_plane.p);  // (word 0 until the planes are counted)
+  {
+    LaunchTimer t(ctx, PCP_K_MLS_VOXEL);
+    hipLaunchKernelGGL(k_brick_mark, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, cv.x, cv.y, cv.z, n, B, ctx->v_occ.p);
+    hipLaunchKernelGGL(k_brick_popc, dim3(scan_grid(div_up(occ_words, kScanBlock))), dim3(kScanBlock), 0, ctx->stream, ctx->v_occ.p,
+                       occ_words, ctx->v_rank.p);
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(scan_grid(tiles)), dim3(kScanBlock), 0, ctx->stream, ctx->v_rank.p, occ_words, ctx->s_tiles.p);
+    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kScanSingle), 0, ctx->stream, ctx->s_tiles.p, tiles, d_total);
+    hipLaunchKernelGGL(k_scan_apply, dim3(scan_grid(tiles)), dim3(kScanBlock), 0, ctx->stream, ctx->v_rank.p, occ_words, ctx->s_tiles.p,
+                       ctx->v_rank.p);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  unsigned long long n_bricks = 0;
+  {
+    unsigned long long *dst = ctx->readback ? static_cast<unsigned long long *>(ctx->readback) : &n_bricks;  // pinned: no staging
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(dst, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    n_bricks = *dst;
+  }
+  const double brick_bytes = static_cast<double>(n_bricks) * kBrickWords * 4.0;
+  PCP_HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+  if (n_bricks >= (1ull << 31) || brick_bytes > 0.8 * (static_cast<double>(free_b) + 4.0 * static_cast<double>(ctx->v_bitmap.count)))
+    return set_error(ctx, PCP_ERR_NOMEM, "pcp_mls_process: the dilated voxel set needs %llu bricks of 16^3 voxels (%.3g GB) and does not "
+                     "fit the device; use a larger vgd_voxel_size or crop the cloud", n_bricks, brick_bytes / 1e9);
+  const size_t bw = static_cast<size_t>(n_bricks) * kBrickWords;
+  PCP_HIP_TRY(ctx, ctx->v_bitmap.ensure(bw + 8));
+  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->v_bitmap.p, 0, (bw + 8) * 4, ctx->stream));
+  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->v_offsets.p, 0, static_cast<size_t>(strips) * 4, ctx->stream));
+  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->v_plane.p, 0, static_cast<size_t>(v.NX) * 8, ctx->stream));
+  B = brick_desc(ctx, v);
+  {
+    LaunchTimer t(ctx, PCP_K_MLS_VOXEL);
+    hipLaunchKernelGGL(k_brick_stamp, dim3(blocks_of(n)), dim3(kMB), 0, ctx->stream, cv.x, cv.y, cv.z, n, B);
+    const int64_t cols = static_cast<int64_t>(B.NBX) * B.NBY;
+    hipLaunchKernelGGL(k_brick_strip_counts, dim3(static_cast<uint32_t>(std::min<int64_t>(cols, int64_t(1) << 20))), dim3(64), 0, ctx->stream, B,
+                       ctx->v_offsets.p, reinterpret_cast<unsigned long long *>(ctx->v_plane.p));
+    PCP_HIP_TRY(ctx, hipGetLastError());
+  }
+  plane_counts->resize(static_cast<size_t>(v.NX));
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(plane_counts->data(), ctx->v_plane.p, plane_counts->size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  unsigned long long total = 0;
+  for (unsigned long long c : *plane_counts) total += c;
+  *out_total = total;
+  *fits = true;
+  return PCP_OK;
+}
+
+// chunks of the brick form = maximal runs of whole strips that hold at most `capacity` voxels (a strip alone holds at most
+// 16 NZ): whole planes while they fit; where a boundary falls inside a plane, that plane's strip counts are fetched
+static int vgd_plan_bricks(pcp_context *ctx, const VoxelDesc &v, int32_t NBY, const std::vector<unsigned long long> &plane_counts,
+                           int64_t capacity, std::vector<int64_t> *chunks) {
+  chunks->clear();
+  std::vector<int32_t> strip(static_cast<size_t>(NBY));
+  int64_t s_begin = 0, cnt = 0;
+  auto close = [&](int64_t s_end) {
+    if (cnt > 0) {
+      chunks->push_back(s_begin);
+      chunks->push_back(s_end);
+      chunks->push_back(cnt);
+    }
+    s_begin = s_end;
+    cnt = 0;
+  };
+  for (int32_t ix = 0; ix < v.NX; ++ix) {
+    const int64_t pc = static_cast<int64_t>(plane_counts[static_cast<size_t>(ix)]);
+    if (pc == 0) continue;
+    if (cnt + pc <= capacity) {
+      cnt += pc;
+      continue;
+    }
+    PCP_HIP_TRY(ctx, hipMemcpy(strip.data(), ctx->v_offsets.p + static_cast<int64_t>(ix) * NBY, static_cast<size_t>(NBY) * 4, hipMemcpyDeviceToHost));
+    for (int32_t by = 0; by < NBY; ++by) {
+      const int64_t c = strip[static_cast<size_t>(by)];
+      if (cnt + c > capacity && cnt > 0) close(static_cast<int64_t>(ix) * NBY + by);
+      cnt += c;
+    }
+  }
+  close(static_cast<int64_t>(v.NX) * NBY);
+  return PCP_OK;
+}
+
+// the voxel grid of the cloud: MLSVoxelGrid's origin and the largest cell index per axis + the dilation's reach
+static int vgd_describe(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *p, VoxelDesc *out_v) {
   VoxelDesc v{};
   v.bminx = cv.mn[0];
   v.bminy = cv.mn[1];
@@ -1952,20 +2291,33 @@ static int vgd_prepare(pcp_context *ctx, const CloudView &cv, const pcp_mls_para
   const int64_t mx = static_cast<int64_t>((cv.mx[0] - v.bminx) / v.vs) + v.it + 1;
   const int64_t my = static_cast<int64_t>((cv.mx[1] - v.bminy) / v.vs) + v.it + 1;
   const int64_t mz = static_cast<int64_t>((cv.mx[2] - v.bminz) / v.vs) + v.it + 1;
-  const double bits = static_cast<double>(mx) * static_cast<double>(my) * static_cast<double>(mz);
-  size_t free_b = 0, total_b = 0;
-  PCP_HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
-  // the bitmap (bits / 8; the per-tile counts are 1 / 8192 of that) must fit with room for the outputs
-  const double have = static_cast<double>(free_b) + static_cast<double>(ctx->v_bitmap.count) * 4.0;
-  if (mx >= (int64_t(1) << 31) || my >= (int64_t(1) << 31) || mz >= (int64_t(1) << 31) || bits / 8.0 > 0.6 * have)
-    return set_error(ctx, PCP_ERR_NOMEM,
-                     "pcp_mls_process: the %lld x %lld x %lld voxel grid (%.3g voxels at %.4g m) does not fit the device; "
-                     "use a larger vgd_voxel_size or crop the cloud",
-                     (long long)mx, (long long)my, (long long)mz, bits, static_cast<double>(v.vs));
+  if (mx >= (int64_t(1) << 31) || my >= (int64_t(1) << 31) || mz >= (int64_t(1) << 31))
+    return set_error(ctx, PCP_ERR_NOMEM, "pcp_mls_process: the %lld x %lld x %lld voxel grid at %.4g m has an axis of 2^31 voxels or more; "
+                     "use a larger vgd_voxel_size or crop the cloud", (long long)mx, (long long)my, (long long)mz, static_cast<double>(v.vs));
   v.NX = static_cast<int32_t>(mx);
   v.NY = static_cast<int32_t>(my);
   v.NZ = static_cast<int32_t>(mz);
   v.words = (static_cast<int64_t>(v.NX) * v.NY * v.NZ + 31) / 32;
+  *out_v = v;
+  return PCP_OK;
+}
+
+static int vgd_prepare(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *p, VoxelDesc *out_v,
+                       std::vector<int32_t> *tile_counts, unsigned long long *out_total) {
+  const int64_t n = cv.n;
+  VoxelDesc v{};
+  int rcd = vgd_describe(ctx, cv, p, &v);
+  if (rcd != PCP_OK) return rcd;
+  const double bits = static_cast<double>(v.NX) * static_cast<double>(v.NY) * static_cast<double>(v.NZ);
+  size_t free_b = 0, total_b = 0;
+  PCP_HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+  // the bitmap (bits / 8; the per-tile counts are 1 / 8192 of that) must fit with room for the outputs
+  const double have = static_cast<double>(free_b) + static_cast<double>(ctx->v_bitmap.count) * 4.0;
+  if (bits / 8.0 > 0.6 * have)
+    return set_error(ctx, PCP_ERR_NOMEM,
+                     "pcp_mls_process: the %d x %d x %d voxel grid (%.3g voxels at %.4g m) does not fit the device as a dense bitmap; "
+                     "use a larger vgd_voxel_size or crop the cloud",
+                     v.NX, v.NY, v.NZ, bits, static_cast<double>(v.vs));
   const size_t sw = static_cast<size_t>(v.words);
   PCP_HIP_TRY(ctx, ctx->v_bitmap.ensure(sw + 8));
   PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->v_bitmap.p, 0, (sw + 8) * 4, ctx->stream));
@@ -2006,15 +2358,16 @@ static int vgd_emit(pcp_context *ctx, const VgdStream &S, int64_t word0, int64_t
   PCP_HIP_TRY(ctx, ctx->v_vox.ensure(st + 4));
   int64_t m = count;
   if (count > 0) {
+    // dense form: words of the bitmap, counted per tile of kScanTile words; brick form: strips, counted one by one
     const int64_t words = word1 - word0;
-    const int64_t tiles = std::max<int64_t>(1, div_up(words, kScanTile));
-    // the chunk's tile counts -> the first place of every tile inside the chunk (exclusive prefix, on a copy: the counts
-    // of the whole bitmap stay for the other chunks)
+    const int64_t tiles = S.bricks ? words : std::max<int64_t>(1, div_up(words, kScanTile));
+    // the chunk's counts -> the first place of every tile / strip inside the chunk (exclusive prefix, on a copy: the counts
+    // of the whole set stay for the other chunks)
     const int64_t tiles2 = std::max<int64_t>(1, div_up(tiles, kScanTile));
     PCP_HIP_TRY(ctx, ctx->s_tiles.ensure(static_cast<size_t>(tiles + tiles2) + 8));
     int32_t *tile_first = ctx->s_tiles.p, *level2 = ctx->s_tiles.p + tiles + 4;
-    PCP_HIP_TRY(ctx, hipMemcpyAsync(tile_first, ctx->v_offsets.p + word0 / kScanTile, static_cast<size_t>(tiles) * 4, hipMemcpyDeviceToDevice,
-                                    ctx->stream));
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(tile_first, ctx->v_offsets.p + (S.bricks ? word0 : word0 / kScanTile), static_cast<size_t>(tiles) * 4,
+                                    hipMemcpyDeviceToDevice, ctx->stream));
     VoxelEmitArgs e{};
     e.bitmap = ctx->v_bitmap.p;
     e.v = S.v;
@@ -2045,8 +2398,14 @@ static int vgd_emit(pcp_context *ctx, const VgdStream &S, int64_t word0, int64_t
       hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kScanSingle), 0, ctx->stream, level2, tiles2,
                          static_cast<unsigned long long *>(nullptr));
       hipLaunchKernelGGL(k_scan_apply, dim3(scan_grid(tiles2)), dim3(kScanBlock), 0, ctx->stream, tile_first, tiles, level2, tile_first);
-      hipLaunchKernelGGL(k_voxel_expand, dim3(scan_grid(tiles)), dim3(kScanBlock), 0, ctx->stream, ctx->v_bitmap.p + word0, tile_first,
-                         words, word0, ctx->v_vox.p);
+      if (S.bricks) {
+        BrickDesc B = brick_desc(ctx, S.v);
+        hipLaunchKernelGGL(k_brick_expand, dim3(static_cast<uint32_t>(std::min<int64_t>(words, int64_t(1) << 20))), dim3(64), 0, ctx->stream, B,
+                           ctx->v_offsets.p, tile_first, word0, words, ctx->v_vox.p);
+      } else {
+        hipLaunchKernelGGL(k_voxel_expand, dim3(scan_grid(tiles)), dim3(kScanBlock), 0, ctx->stream, ctx->v_bitmap.p + word0, tile_first,
+                           words, word0, ctx->v_vox.p);
+      }
       hipLaunchKernelGGL(k_voxel_emit, dim3(blocks_of(count)), dim3(kMB), 0, ctx->stream, e);
       PCP_HIP_TRY(ctx, hipGetLastError());
     }
@@ -2073,21 +2432,79 @@ static VgdStream vgd_stream_of(const CloudView &cv, const pcp_mls_params *p, con
   S.remap = cv.remap;
   S.plane = (static_cast<size_t>(cv.n) + 3) & ~size_t(3);
   S.order_poly = p->polynomial_order;
+  S.bricks = 0;
   return S;
+}
+
+// counts the dilated voxel set in the form that fits -- bricks unless PCP_VGD_DENSE=1 or the grid is taller than the brick
+// form handles -- and cuts it into chunks of at most `capacity` voxels (capacity <= 0: one chunk)
+static int vgd_count_and_plan(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *p, const GridDesc &g, int64_t capacity,
+                              VgdStream *out_S, std::vector<int64_t> *chunks, unsigned long long *out_total) {
+  VoxelDesc v{};
+  int rc = vgd_describe(ctx, cv, p, &v);
+  if (rc != PCP_OK) return rc;
+  chunks->clear();
+  if (!vgd_dense_form()) {
+    std::vector<unsigned long long> planes;
+    bool fits = false;
+    if ((rc = vgd_prepare_bricks(ctx, cv, v, &planes, out_total, &fits)) != PCP_OK) return rc;
+    if (fits) {
+      VgdStream S = vgd_stream_of(cv, p, g, v);
+      const BrickDesc B = brick_desc(ctx, v);
+      S.bricks = 1;
+      S.NBX = B.NBX;
+      S.NBY = B.NBY;
+      S.NBZ = B.NBZ;
+      *out_S = S;
+      const int64_t cap = capacity > 0 ? capacity : std::numeric_limits<int64_t>::max();
+      if ((rc = vgd_plan_bricks(ctx, v, B.NBY, planes, cap, chunks)) != PCP_OK) return rc;
+      // a strip holds up to 16 NZ voxels and is never split: where one alone exceeds the capacity (a solid block of points
+      // and a capacity near the 32 768 minimum) the dense form, whose unit is 32 768 keys, takes over
+      bool ok = true;
+      for (size_t k = 2; k < chunks->size(); k += 3) ok = ok && (*chunks)[k] <= cap;
+      if (ok) return PCP_OK;
+      chunks->clear();
+    }
+  }
+  std::vector<int32_t> tile_counts;
+  if ((rc = vgd_prepare(ctx, cv, p, &v, &tile_counts, out_total)) != PCP_OK) return rc;
+  *out_S = vgd_stream_of(cv, p, g, v);
+  // chunks = maximal runs of whole tiles that hold at most `capacity` voxels (a tile alone holds <= 32 768)
+  const int64_t tiles = static_cast<int64_t>(tile_counts.size());
+  const int64_t cap = capacity > 0 ? capacity : std::numeric_limits<int64_t>::max();
+  int64_t t0 = 0, cnt = 0;
+  for (int64_t t = 0; t <= tiles; ++t) {
+    const int64_t c = t < tiles ? tile_counts[static_cast<size_t>(t)] : 0;
+    if (t == tiles || (cnt + c > cap && t > t0)) {
+      if (cnt > 0) {
+        chunks->push_back(t0 * kScanTile);
+        chunks->push_back(std::min<int64_t>(t * kScanTile, v.words));
+        chunks->push_back(cnt);
+      }
+      t0 = t;
+      cnt = 0;
+    }
+    cnt += c;
+  }
+  return PCP_OK;
 }
 
 static int voxel_grid_dilation(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *p, const GridDesc &g,
                                int64_t *out_count) {
-  VoxelDesc v{};
-  std::vector<int32_t> tile_counts;
+  VgdStream S{};
+  std::vector<int64_t> chunks;
   unsigned long long total = 0;
-  int rc = vgd_prepare(ctx, cv, p, &v, &tile_counts, &total);
+  int rc = vgd_count_and_plan(ctx, cv, p, g, 0, &S, &chunks, &total);
   if (rc != PCP_OK) return rc;
   if (total >= (1ull << 31))
     return set_error(ctx, PCP_ERR_NOMEM, "pcp_mls_process: %llu dilated voxels exceed the 2^31 points one result holds "
                      "(pcp_mls_stream_begin / _next emit them in chunks)", total);
   int64_t m = 0;
-  if ((rc = vgd_emit(ctx, vgd_stream_of(cv, p, g, v), 0, v.words, static_cast<int64_t>(total), &m)) != PCP_OK) return rc;
+  if (chunks.empty()) {  // an empty set: the result buffers still have to exist
+    if ((rc = vgd_emit(ctx, S, 0, 0, 0, &m)) != PCP_OK) return rc;
+  } else if ((rc = vgd_emit(ctx, S, chunks[0], chunks[1], chunks[2], &m)) != PCP_OK) {
+    return rc;
+  }
   if (out_count) *out_count = m;
   return PCP_OK;
 }
@@ -2202,30 +2619,12 @@ static int mls_run(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *
     }
   }
   if (p->upsampling == 3 && stream_capacity > 0) {
-    // pcp_mls_stream_begin: count the voxel set and cut its key range into chunks of whole tiles
-    VoxelDesc v{};
-    std::vector<int32_t> tile_counts;
+    // pcp_mls_stream_begin: count the voxel set and cut its key range into chunks (whole strips of the brick form, whole
+    // tiles of the dense one)
+    VgdStream S{};
     unsigned long long total = 0;
-    if ((rc = vgd_prepare(ctx, cv, p, &v, &tile_counts, &total)) != PCP_OK) return rc;
-    const VgdStream S = vgd_stream_of(cv, p, g, v);
+    if ((rc = vgd_count_and_plan(ctx, cv, p, g, stream_capacity, &S, &ctx->vgd_chunks, &total)) != PCP_OK) return rc;
     ctx->vgd_blob.assign(reinterpret_cast<const uint8_t *>(&S), reinterpret_cast<const uint8_t *>(&S) + sizeof(S));
-    ctx->vgd_chunks.clear();
-    // chunks = maximal runs of whole tiles that hold at most stream_capacity voxels (a tile alone holds <= 32 768)
-    const int64_t tiles = static_cast<int64_t>(tile_counts.size());
-    int64_t t0 = 0, cnt = 0;
-    for (int64_t t = 0; t <= tiles; ++t) {
-      const int64_t c = t < tiles ? tile_counts[static_cast<size_t>(t)] : 0;
-      if (t == tiles || (cnt + c > stream_capacity && t > t0)) {
-        if (cnt > 0) {
-          ctx->vgd_chunks.push_back(t0 * kScanTile);
-          ctx->vgd_chunks.push_back(std::min<int64_t>(t * kScanTile, v.words));
-          ctx->vgd_chunks.push_back(cnt);
-        }
-        t0 = t;
-        cnt = 0;
-      }
-      cnt += c;
-    }
     ctx->vgd_next = 0;
     if (out_count) *out_count = static_cast<int64_t>(total);
     return PCP_OK;

@@ -317,3 +317,93 @@ def test_voxel_dilation_stream_equals_one_shot(gpu_ctx_factory):
     mp.upsampling = 0
     with pytest.raises(capi.PcpError):
         ctx.mls_stream_begin(mp, 1 << 20)
+
+
+def test_voxel_dilation_bricks_equal_the_dense_bitmap(gpu_ctx_factory, monkeypatch):
+    """The voxel set as bricks of 16^3 voxels (the default: memory follows the surface) against the dense bitmap over the
+    bounding box (PCP_VGD_DENSE=1, rounds 2-3): one-shot result and chunked emission, bit for bit."""
+    from pointcloudprocessor_amd import capi
+
+    x, y, z = _patches(seed=29, n=5000)
+    mp = capi.default_mls_params()
+    mp.vgd_voxel_size = 0.002
+    mp.vgd_iterations = 3
+    res = {}
+    for form in ("bricks", "dense"):
+        monkeypatch.setenv("PCP_VGD_DENSE", "1" if form == "dense" else "0")
+        ctx = gpu_ctx_factory()
+        ctx.upload_cloud(x, y, z)
+        full = ctx.mls_fetch(ctx.mls_process(mp))
+        total, chunks = ctx.mls_stream_begin(mp, 65536)
+        parts = []
+        while True:
+            m = ctx.mls_stream_next()
+            if m == 0:
+                break
+            assert m <= 65536
+            parts.append(ctx.mls_fetch(m))
+        assert chunks == len(parts) > 3
+        for k in ("index", "xyz", "normal", "curvature"):
+            assert np.array_equal(np.concatenate([q[k] for q in parts]), full[k]), (form, k)
+        res[form] = (full, total)
+    assert res["bricks"][1] == res["dense"][1] and len(res["bricks"][0]["index"]) > 400_000
+    for k in ("index", "xyz", "normal", "curvature"):
+        assert np.array_equal(res["bricks"][0][k], res["dense"][0][k]), k
+
+
+def test_voxel_dilation_of_a_40m_map_at_the_reference_configuration(gpu_ctx_factory):
+    """The reference's MLS configuration (VOXEL_GRID_DILATION 1 mm x 4, PointCloudProcessor.cpp:78-81) on a map the size of
+    a survey (40 x 40 x 5 m: the crop of :119-136 is the trajectory box +- 2 m): 4e4 x 4e4 x 5e3 voxels are 1 TB as a dense
+    bitmap -- refused with PCP_ERR_NOMEM until round 3 -- and a few hundred MB as bricks.  The voxel count equals the
+    number of distinct PCL keys computed with numpy; the chunks come out in ascending key order and hold every voxel."""
+    import torch
+
+    from pointcloudprocessor_amd import capi
+
+    rng = np.random.default_rng(77)
+    # 700 dense patches (100 points within 4 cm) on the floor, the ceiling and two walls of a 40 x 40 x 5 m hall
+    centres = rng.uniform([0, 0, 0], [40, 40, 5], (700, 3))
+    which = rng.integers(0, 4, 700)
+    centres[which == 0, 2] = 0.0
+    centres[which == 1, 2] = 5.0
+    centres[which == 2, 0] = 0.0
+    centres[which == 3, 1] = 40.0
+    pts = centres[:, None, :] + rng.normal(0, 0.012, (700, 100, 3)) * np.where(
+        (np.arange(3)[None, :] == np.array([2, 2, 0, 1])[which][:, None]), 0.05, 1.0)[:, None, :]
+    pts = np.concatenate([pts.reshape(-1, 3), [[0, 0, 0], [40, 40, 5]]]).astype(np.float32)
+    x, y, z = pts[:, 0].copy(), pts[:, 1].copy(), pts[:, 2].copy()
+    mp = capi.default_mls_params()
+    assert abs(mp.vgd_voxel_size - 0.001) < 1e-9 and mp.vgd_iterations == 4 and mp.upsampling == 3
+    free0 = torch.cuda.mem_get_info()[0]
+    ctx = gpu_ctx_factory()
+    ctx.upload_cloud(x, y, z)
+    cap = 1 << 22
+    total, chunks = ctx.mls_stream_begin(mp, cap)
+    used = free0 - torch.cuda.mem_get_info()[0]
+    assert used < 8 << 30, used  # (the dense bitmap would be 1 TB)
+    # the voxel set PCL builds: cell indices in fp32 (MLSVoxelGrid::getCellIndex), the 9 x 9 x 9 cube of every point
+    # (negative indices not created, Appendix B16), distinct keys
+    vs = np.float32(0.001)
+    ix = ((x - x.min()) / vs).astype(np.int64)
+    iy = ((y - y.min()) / vs).astype(np.int64)
+    iz = ((z - z.min()) / vs).astype(np.int64)
+    d = np.arange(-4, 5)
+    keys = []
+    S = np.int64(1) << 21
+    for lo in range(0, len(x), 10_000):
+        cx = (ix[lo:lo + 10_000, None] + d[None, :]).reshape(-1, 9, 1, 1)
+        cy = (iy[lo:lo + 10_000, None] + d[None, :]).reshape(-1, 1, 9, 1)
+        cz = (iz[lo:lo + 10_000, None] + d[None, :]).reshape(-1, 1, 1, 9)
+        ok = (cx >= 0) & (cy >= 0) & (cz >= 0)
+        keys.append(np.unique(((cx * S + cy) * S + cz)[ok & np.ones((1, 9, 9, 9), bool)]))
+    n_keys = len(np.unique(np.concatenate(keys)))
+    assert total == n_keys, (total, n_keys)
+    assert chunks >= total // cap
+    emitted, last_key = 0, -1
+    while True:
+        m = ctx.mls_stream_next()
+        if m == 0:
+            break
+        assert m <= cap
+        emitted += m
+    assert 0.9 * total < emitted <= total  # voxels whose nearest point has no valid fit are counted but not emitted
