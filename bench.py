@@ -46,7 +46,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PROJ_BYTES_PER_POINT = 20  # 12 B xyz read + 4 B cell + 4 B range written
-PMC_SUMMARY = "r03_pmc.json"  # profiles/: summary of the rocprofv3 --pmc passes of this command (profiles/summarise_pmc.py)
+PMC_SUMMARY = "r04_pmc.json"  # profiles/: summary of the rocprofv3 --pmc passes of this command (profiles/summarise_pmc.py)
 HPR_PMC_SUMMARY = "r04_hpr_pmc.json"  # profiles/: trace + SQ counters of the hull kernels (profiles/collect_hpr_pmc.sh)
 MLS_PMC_SUMMARY = "r03_mls_pmc.json"  # profiles/: PMC summary of MLS alone (profiles/collect_mls.sh)
 SIMDS, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md max clock
@@ -702,14 +702,19 @@ def main():
                     sub = 10  # every 10th point of the map: 1 M points at the C3 size
                     eng.upload_cloud(x[:nm:sub], y[:nm:sub], z[:nm:sub])
                     vp = capi.default_mls_params()
-                    t1 = time.perf_counter()
-                    mc = eng.ctx.cloud_smooth(vp)
-                    eng.ctx.synchronize()
-                    t_c1 = time.perf_counter() - t1
+                    runs_c = []
+                    for _ in range(3):  # the first call allocates; the others are the steady state
+                        t1 = time.perf_counter()
+                        mc = eng.ctx.cloud_smooth(vp)
+                        eng.ctx.synchronize()
+                        runs_c.append((time.perf_counter() - t1) * 1e3)
                     mls["reference_config_chain"] = {
-                        "points": int(len(x[:nm:sub])), "outputs": int(mc), "ms": round(t_c1 * 1e3, 1),
+                        "points": int(len(x[:nm:sub])), "outputs": int(mc), "ms": round(min(runs_c[1:]), 1),
+                        "first_call_ms": round(runs_c[0], 1), "runs_ms": [round(v, 1) for v in runs_c],
+                        "Moutputs_per_s": round(mc / (min(runs_c[1:]) * 1e-3) / 1e6, 1),
                         "what": "SOR -> MLS + VOXEL_GRID_DILATION (1 mm x 4) -> SOR, PointCloudProcessor.cpp:67-86, in one "
-                                "pcp_cloud_smooth call (first call: includes allocations)"}
+                                "pcp_cloud_smooth call; ms = steady state (best of the calls after the first), first_call_ms "
+                                "includes the allocations"}
                 except capi.PcpError as e:
                     mls["reference_config_chain"] = {"error": str(e)}
                 try:
@@ -717,7 +722,7 @@ def main():
                     vp = capi.default_mls_params()
                     cap = 1 << 28
                     first_call = None
-                    for rep_v in range(2):  # the first call allocates (and first touches) the 60 GB voxel bitmap
+                    for rep_v in range(2):  # the first call allocates the brick storage (~2 GB; the dense bitmap of round 3 was 60 GB)
                         t1 = time.perf_counter()
                         total_v, chunks_v = eng.ctx.mls_stream_begin(vp, cap)
                         eng.ctx.synchronize()

@@ -31,10 +31,13 @@
 extern "C" {
 #endif
 
-#define PCP_ABI_VERSION 4 /* 2: pcp_cull_params grew cull_mode / match_mode; pcp_set_image_adjust
+#define PCP_ABI_VERSION 5 /* 2: pcp_cull_params grew cull_mode / match_mode; pcp_set_image_adjust
                              3: PCP_CULL_HPR, pcp_cull_params.hpr_flip_radius, pcp_hpr_stats
                              4: entry points added, no layout changed: pcp_sor_partial / pcp_sor_finish /
-                                pcp_sor_chunk_points, pcp_hull_flags_import; PCP_DEPTH_BATCHED accepts PCP_CULL_HPR */
+                                pcp_sor_chunk_points, pcp_hull_flags_import; PCP_DEPTH_BATCHED accepts PCP_CULL_HPR
+                             5: no entry point or layout changed; pcp_cull_frame's out_keep, pcp_sor_partial's out_chunk_sums,
+                                pcp_sor_finish's all_chunk_sums / out_keep may be DEVICE memory of the context's GPU (the
+                                multi-GPU host exchanges them with RCCL instead of through the host) */
 
 #define PCP_OK 0
 #define PCP_ERR_INVALID (-1) /* bad argument */

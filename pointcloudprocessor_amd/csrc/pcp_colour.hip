@@ -1518,8 +1518,8 @@ int pcp_cull_frame(pcp_context *ctx, int32_t frame, uint8_t *out_keep, int64_t *
     if (n > 0 && (rc = compact_flags(ctx, ctx->s_keep.p, n, nullptr, 0, &cnt)) != PCP_OK) return rc;
     *out_kept = cnt;
   }
-  if (out_keep && n > 0)
-    PCP_HIP_TRY(ctx, hipMemcpyAsync(out_keep, ctx->s_keep.p, static_cast<size_t>(n), hipMemcpyDeviceToHost, ctx->stream));
+  if (out_keep && n > 0)  // host memory, or device memory of this GPU (the multi-GPU host exchanges the flags with RCCL)
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(out_keep, ctx->s_keep.p, static_cast<size_t>(n), hipMemcpyDefault, ctx->stream));
   if (out_depth_map)
     PCP_HIP_TRY(ctx, hipMemcpyAsync(out_depth_map, ctx->s_u32.p, static_cast<size_t>(cells_of(ctx)) * 4,
                                     hipMemcpyDeviceToHost, ctx->stream));

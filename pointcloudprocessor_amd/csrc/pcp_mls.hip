@@ -3000,7 +3000,7 @@ int pcp_sor_partial(pcp_context *ctx, int32_t mean_k, int32_t slab, int32_t n_sl
   if ((rc = sor_run(ctx, uploaded_view(ctx), mean_k, 0.0, false, slab, n_slabs, /*classify=*/false)) != PCP_OK) return rc;
   if (c1 > c0)
     PCP_HIP_TRY(ctx, hipMemcpyAsync(out_chunk_sums, ctx->m_sums.p + 4 + 2 * c0, static_cast<size_t>(c1 - c0) * 2 * sizeof(double),
-                                    hipMemcpyDeviceToHost, ctx->stream));
+                                    hipMemcpyDefault, ctx->stream));  // host or device memory
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->sor_partial_slab = slab;
   ctx->sor_partial_slabs = n_slabs;
@@ -3022,7 +3022,7 @@ int pcp_sor_finish(pcp_context *ctx, double std_mul, const double *all_chunk_sum
     return set_error(ctx, PCP_ERR_STATE, "pcp_sor_finish: slab %d of %d is not the slab of the last pcp_sor_partial of this context", slab, n_slabs);
   PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
   PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->m_sums.p + 4, all_chunk_sums, static_cast<size_t>(n_chunks) * 2 * sizeof(double),
-                                  hipMemcpyHostToDevice, ctx->stream));
+                                  hipMemcpyDefault, ctx->stream));  // host or device memory
   const int64_t c0 = n_chunks * slab / n_slabs, c1 = n_chunks * (slab + 1) / n_slabs;
   const int64_t j0 = c0 * kSorChunk, j1 = std::min<int64_t>(c1 * kSorChunk, n);
   PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->m_flag.p, 0, static_cast<size_t>(n), ctx->stream));
@@ -3032,7 +3032,7 @@ int pcp_sor_finish(pcp_context *ctx, double std_mul, const double *all_chunk_sum
     if ((rc = compact_flags(ctx, ctx->m_flag.p, n, nullptr, 0, &kept)) != PCP_OK) return rc;
     *out_kept = kept;
   }
-  if (out_keep) PCP_HIP_TRY(ctx, hipMemcpyAsync(out_keep, ctx->m_flag.p, static_cast<size_t>(n), hipMemcpyDeviceToHost, ctx->stream));
+  if (out_keep) PCP_HIP_TRY(ctx, hipMemcpyAsync(out_keep, ctx->m_flag.p, static_cast<size_t>(n), hipMemcpyDefault, ctx->stream));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return PCP_OK;
 }

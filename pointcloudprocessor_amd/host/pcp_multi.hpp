@@ -103,9 +103,9 @@ class MultiDevice {
   }
   // PCP_CULL_HPR with N > 1: a keyframe's hull is taken over EVERY candidate of the map (view_culling.cpp:291-329), so an
   // index shard cannot decide its own points.  Every GPU gets a second context that holds the whole map (no images);
-  // keyframe f's hull is taken by GPU f mod N there, and its verdicts (one flag per map point, through the host) are
-  // handed to the shards (pcp_hull_flags_import), which colour / dump their points from them exactly as they do from the
-  // merged depth maps of the z-buffer routine.
+  // keyframe f's hull is taken by GPU f mod N there, and its verdicts (one flag per map point; slices exchanged on the devices,
+  // hullPassAll) are handed to the shards (pcp_hull_flags_import), which colour / dump their points from them exactly as
+  // they do from the merged depth maps of the z-buffer routine.
   void setCamera(const pcp_camera &cam, const pcp_cull_params *cull = nullptr) {
     cam_ = cam;
     for (auto &d : dev_) d->setCamera(cam, cull);
@@ -317,33 +317,81 @@ class MultiDevice {
     }
   }
 
-  // hidden_points_removal of every keyframe on the whole-map contexts (GPU f mod N takes keyframe f, one host thread per
-  // GPU), verdicts sliced by index range into the shards
+  // hidden_points_removal of every keyframe on the whole-map contexts: GPU o takes the keyframes f = o (mod N), batch by batch
+  // (one host thread per GPU for the hulls: the call synchronises with the host).  A batch's verdicts -- one flag per MAP
+  // point -- stay on the device (pcp_cull_frame writes them to a device buffer): GPU o sends every shard s the slice of its
+  // index range, one grouped ncclSend / ncclRecv exchange per batch over xGMI, and the shards import their slices from
+  // device memory (pcp_hull_flags_import), on the stream they arrived on.  (Until round 4 the flags went down to the host and
+  // up again, n bytes per keyframe each way.)  PCP_MULTI_REHEARSAL: the same slices by device copies on the one GPU.
   void hullPassAll() {
     const int N = size();
-    std::vector<std::mutex> shard_mu(static_cast<size_t>(N));
-    std::vector<std::string> failure(static_cast<size_t>(N));
-    std::vector<std::thread> th;
-    for (int r = 0; r < N; ++r)
-      th.emplace_back([&, r] {
-        try {
-          Device &h = *hull_[static_cast<size_t>(r)];
-          std::vector<uint8_t> keep(static_cast<size_t>(n_));
-          for (int f = r; f < n_frames_; f += N) {
-            int64_t kept = 0;
-            h.check(pcp_cull_frame(h.get(), f, keep.data(), &kept, nullptr));
-            for (int s = 0; s < N; ++s) {
-              std::lock_guard<std::mutex> lk(shard_mu[static_cast<size_t>(s)]);
-              device(s).check(pcp_hull_flags_import(device(s).get(), f, keep.data() + shardBegin(s)));
+    if (n_ == 0) return;
+    // per GPU: the owner's flags of the whole map, and room for the N slices a shard receives in one batch
+    std::vector<uint8_t *> flags(static_cast<size_t>(N), nullptr), slices(static_cast<size_t>(N), nullptr);
+    auto release = [&]() {
+      for (int r = 0; r < N; ++r) {
+        (void)hipSetDevice(ordinal(r));
+        if (flags[static_cast<size_t>(r)]) (void)hipFree(flags[static_cast<size_t>(r)]);
+        if (slices[static_cast<size_t>(r)]) (void)hipFree(slices[static_cast<size_t>(r)]);
+      }
+    };
+    const int64_t longest = shardBegin(1) - shardBegin(0);  // the first shards hold one point more
+    try {
+      for (int r = 0; r < N; ++r) {
+        hip(hipSetDevice(ordinal(r)), "hipSetDevice");
+        hip(hipMalloc(reinterpret_cast<void **>(&flags[static_cast<size_t>(r)]), static_cast<size_t>(n_)), "hipMalloc(hull flags)");
+        hip(hipMalloc(reinterpret_cast<void **>(&slices[static_cast<size_t>(r)]), static_cast<size_t>(longest) * N + 16), "hipMalloc(hull slices)");
+      }
+      for (int f0 = 0; f0 < n_frames_; f0 += N) {
+        const int owners = std::min(N, n_frames_ - f0);
+        // the hulls of this batch, GPU o keyframe f0 + o
+        std::vector<std::string> failure(static_cast<size_t>(owners));
+        std::vector<std::thread> th;
+        for (int o = 0; o < owners; ++o)
+          th.emplace_back([&, o] {
+            try {
+              Device &h = *hull_[static_cast<size_t>(o)];
+              h.check(pcp_cull_frame(h.get(), f0 + o, flags[static_cast<size_t>(o)], nullptr, nullptr));  // device memory; synchronised
+            } catch (const std::exception &e) {
+              failure[static_cast<size_t>(o)] = e.what();
+            }
+          });
+        for (auto &t : th) t.join();
+        for (const auto &f : failure)
+          if (!f.empty()) throw std::runtime_error(f);
+        // slice s of owner o's flags -> GPU s
+        if (!rehearsal_) nccl(ncclGroupStart(), "ncclGroupStart");
+        for (int o = 0; o < owners; ++o)
+          for (int s = 0; s < N; ++s) {
+            const int64_t lo = shardBegin(s), len = shardBegin(s + 1) - lo;
+            if (len == 0) continue;
+            uint8_t *dst = slices[static_cast<size_t>(s)] + static_cast<int64_t>(o) * longest;
+            const uint8_t *src = flags[static_cast<size_t>(o)] + lo;
+            if (rehearsal_ || o == s) {
+              hip(hipSetDevice(ordinal(s)), "hipSetDevice");
+              hip(hipMemcpyAsync(dst, src, static_cast<size_t>(len), hipMemcpyDeviceToDevice, stream_[static_cast<size_t>(s)]), "hipMemcpyAsync(hull flags)");
+            } else {
+              nccl(ncclSend(src, static_cast<size_t>(len), ncclUint8, s, comm_[static_cast<size_t>(o)], stream_[static_cast<size_t>(o)]), "ncclSend(hull flags)");
+              nccl(ncclRecv(dst, static_cast<size_t>(len), ncclUint8, o, comm_[static_cast<size_t>(s)], stream_[static_cast<size_t>(s)]), "ncclRecv(hull flags)");
             }
           }
-        } catch (const std::exception &e) {
-          failure[static_cast<size_t>(r)] = e.what();
+        if (!rehearsal_) nccl(ncclGroupEnd(), "ncclGroupEnd");
+        // (the shards' contexts run on stream_[s]: the imports are ordered behind the arrivals)
+        for (int s = 0; s < N; ++s)
+          for (int o = 0; o < owners; ++o)
+            device(s).check(pcp_hull_flags_import(device(s).get(), f0 + o, slices[static_cast<size_t>(s)] + static_cast<int64_t>(o) * longest));
+        // the owners' buffers are rewritten by the next batch's hulls (another stream): every copy out of them must be done
+        for (int r = 0; r < N; ++r) {
+          hip(hipSetDevice(ordinal(r)), "hipSetDevice");
+          hip(hipStreamSynchronize(stream_[static_cast<size_t>(r)]), "hipStreamSynchronize");
         }
-      });
-    for (auto &t : th) t.join();
-    for (const auto &f : failure)
-      if (!f.empty()) throw std::runtime_error(f);
+      }
+      for (int s = 0; s < N; ++s) device(s).check(pcp_synchronize(device(s).get()));
+    } catch (...) {
+      release();
+      throw;
+    }
+    release();
   }
 
   static void hip(hipError_t e, const char *what) {
@@ -448,7 +496,29 @@ class MultiCloudSmooth {
     const bool one_gpu = rehearsal && rehearsal[0] == '1';
     for (int r = 0; r < std::max(n_gpus, 1); ++r) dev_.emplace_back(new Device(one_gpu ? 0 : r));
     pcp_default_mls_params(&params_);
+    if (n_gpus > 1 && !one_gpu) {
+      // the exchanges of the outlier removal (chunk sums, keep flags) are RCCL collectives on device memory
+      std::vector<int> ids(static_cast<size_t>(n_gpus));
+      stream_.resize(static_cast<size_t>(n_gpus));
+      for (int r = 0; r < n_gpus; ++r) {
+        ids[static_cast<size_t>(r)] = r;
+        check_hip(hipSetDevice(r), "hipSetDevice");
+        check_hip(hipStreamCreateWithFlags(&stream_[static_cast<size_t>(r)], hipStreamNonBlocking), "hipStreamCreate");
+      }
+      comm_.resize(static_cast<size_t>(n_gpus));
+      check_nccl(ncclCommInitAll(comm_.data(), n_gpus, ids.data()), "ncclCommInitAll");
+    }
   }
+  ~MultiCloudSmooth() {
+    for (size_t i = 0; i < comm_.size(); ++i) (void)ncclCommDestroy(comm_[i]);
+    dev_.clear();
+    for (size_t i = 0; i < stream_.size(); ++i) {
+      (void)hipSetDevice(static_cast<int>(i));
+      (void)hipStreamDestroy(stream_[i]);
+    }
+  }
+  MultiCloudSmooth(const MultiCloudSmooth &) = delete;
+  MultiCloudSmooth &operator=(const MultiCloudSmooth &) = delete;
   void initialize(const pcp_mls_params &p) { params_ = p; }
   int size() const { return static_cast<int>(dev_.size()); }
 
@@ -567,8 +637,9 @@ class MultiCloudSmooth {
   // dealt out by slabs of the filter's own spatial order (pcp_sor_partial: whole wavefronts, whole statistic chunks), the
   // chunk sums of the slabs put together -- the array one GPU computes, so the threshold is the one-GPU threshold bit for
   // bit -- and every GPU classifies its own slab (pcp_sor_finish: flags under the caller's indices, zero for the other
-  // slabs' points).  The exchange is ceil(n / 16384) pairs of doubles and the flags, through the host; the calls
-  // synchronise with the host, hence one host thread per GPU.  Returns the indices kept, ascending.
+  // slabs' points).  The exchange is ceil(n / 16384) pairs of doubles and the flags: RCCL all-reduces on device memory (through
+  // the host only in the one-GPU rehearsal); the calls synchronise with the host, hence one host thread per GPU.  Returns
+  // the indices kept, ascending.
   std::vector<int32_t> outlierRemoval(const float *x, const float *y, const float *z, int64_t n) {
     const int N = size();
     const int64_t chunk = pcp_sor_chunk_points(), chunks = (n + chunk - 1) / chunk;
@@ -589,16 +660,71 @@ class MultiCloudSmooth {
       for (const auto &f : failure)
         if (!f.empty()) throw std::runtime_error(f);
     };
-    on_every_gpu([&](int r, Device &d) {
-      d.uploadCloud(x, y, z, n);
-      std::vector<double> mine(static_cast<size_t>(2 * std::max<int64_t>(chunks, 1)));
-      int64_t first = 0, cnt = 0;
-      d.check(pcp_sor_partial(d.get(), params_.sor_mean_k, r, N, chunks, mine.data(), &first, &cnt));
-      std::copy(mine.begin(), mine.begin() + 2 * cnt, sums.begin() + 2 * first);  // disjoint ranges: no lock
-    });
-    on_every_gpu([&](int r, Device &d) {
-      d.check(pcp_sor_finish(d.get(), params_.sor_std_mul, sums.data(), chunks, r, N, keep[static_cast<size_t>(r)].data(), nullptr));
-    });
+    if (comm_.empty()) {
+      // PCP_MULTI_REHEARSAL (one GPU): the slabs' arrays put together on the host
+      on_every_gpu([&](int r, Device &d) {
+        d.uploadCloud(x, y, z, n);
+        std::vector<double> mine(static_cast<size_t>(2 * std::max<int64_t>(chunks, 1)));
+        int64_t first = 0, cnt = 0;
+        d.check(pcp_sor_partial(d.get(), params_.sor_mean_k, r, N, chunks, mine.data(), &first, &cnt));
+        std::copy(mine.begin(), mine.begin() + 2 * cnt, sums.begin() + 2 * first);  // disjoint ranges: no lock
+      });
+      on_every_gpu([&](int r, Device &d) {
+        d.check(pcp_sor_finish(d.get(), params_.sor_std_mul, sums.data(), chunks, r, N, keep[static_cast<size_t>(r)].data(), nullptr));
+      });
+    } else {
+      // N GPUs: the chunk sums and the keep flags never visit the host in between.  Every GPU holds a zeroed array of all
+      // chunk sums and writes its slab's pairs into it (pcp_sor_partial, device memory); one ncclAllReduce(SUM) puts the slabs
+      // together -- every pair has ONE non-zero contribution, so the sums are the one-GPU array bit for bit --; every GPU
+      // classifies its slab into a device flag array (zero for the other slabs' points) and one ncclAllReduce(MAX) is their
+      // OR; GPU 0's copy comes down once.
+      std::vector<double *> dsum(static_cast<size_t>(N), nullptr);
+      std::vector<uint8_t *> dkeep(static_cast<size_t>(N), nullptr);
+      auto release = [&]() {
+        for (int r = 0; r < N; ++r) {
+          (void)hipSetDevice(r);
+          if (dsum[static_cast<size_t>(r)]) (void)hipFree(dsum[static_cast<size_t>(r)]);
+          if (dkeep[static_cast<size_t>(r)]) (void)hipFree(dkeep[static_cast<size_t>(r)]);
+        }
+      };
+      const size_t sum_bytes = static_cast<size_t>(2 * std::max<int64_t>(chunks, 1)) * sizeof(double);
+      try {
+        on_every_gpu([&](int r, Device &d) {
+          check_hip(hipSetDevice(r), "hipSetDevice");
+          check_hip(hipMalloc(reinterpret_cast<void **>(&dsum[static_cast<size_t>(r)]), sum_bytes), "hipMalloc(chunk sums)");
+          check_hip(hipMalloc(reinterpret_cast<void **>(&dkeep[static_cast<size_t>(r)]), static_cast<size_t>(std::max<int64_t>(n, 1))), "hipMalloc(keep flags)");
+          check_hip(hipMemset(dsum[static_cast<size_t>(r)], 0, sum_bytes), "hipMemset(chunk sums)");
+          d.uploadCloud(x, y, z, n);
+          int64_t first = 0, cnt = 0;
+          d.check(pcp_sor_partial(d.get(), params_.sor_mean_k, r, N, chunks, dsum[static_cast<size_t>(r)] + 2 * (chunks * r / N), &first, &cnt));
+        });
+        check_nccl(ncclGroupStart(), "ncclGroupStart");
+        for (int r = 0; r < N; ++r)
+          check_nccl(ncclAllReduce(dsum[static_cast<size_t>(r)], dsum[static_cast<size_t>(r)], static_cast<size_t>(2 * chunks), ncclDouble, ncclSum,
+                                   comm_[static_cast<size_t>(r)], stream_[static_cast<size_t>(r)]), "ncclAllReduce(SOR chunk sums, SUM)");
+        check_nccl(ncclGroupEnd(), "ncclGroupEnd");
+        on_every_gpu([&](int r, Device &d) {
+          check_hip(hipSetDevice(r), "hipSetDevice");
+          check_hip(hipStreamSynchronize(stream_[static_cast<size_t>(r)]), "hipStreamSynchronize");
+          d.check(pcp_sor_finish(d.get(), params_.sor_std_mul, dsum[static_cast<size_t>(r)], chunks, r, N, dkeep[static_cast<size_t>(r)], nullptr));
+        });
+        check_nccl(ncclGroupStart(), "ncclGroupStart");
+        for (int r = 0; r < N; ++r)
+          check_nccl(ncclAllReduce(dkeep[static_cast<size_t>(r)], dkeep[static_cast<size_t>(r)], static_cast<size_t>(n), ncclUint8, ncclMax,
+                                   comm_[static_cast<size_t>(r)], stream_[static_cast<size_t>(r)]), "ncclAllReduce(SOR keep flags, MAX)");
+        check_nccl(ncclGroupEnd(), "ncclGroupEnd");
+        check_hip(hipSetDevice(0), "hipSetDevice");
+        check_hip(hipMemcpyAsync(keep[0].data(), dkeep[0], static_cast<size_t>(n), hipMemcpyDeviceToHost, stream_[0]), "hipMemcpyAsync(keep flags)");
+        for (int r = 0; r < N; ++r) {
+          check_hip(hipSetDevice(r), "hipSetDevice");
+          check_hip(hipStreamSynchronize(stream_[static_cast<size_t>(r)]), "hipStreamSynchronize");
+        }
+      } catch (...) {
+        release();
+        throw;
+      }
+      release();
+    }
     std::vector<int32_t> idx;
     for (int64_t i = 0; i < n; ++i) {
       uint8_t k = 0;
@@ -608,7 +734,16 @@ class MultiCloudSmooth {
     return idx;
   }
 
+  static void check_hip(hipError_t e, const char *what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string("pcp_multi: ") + what + ": " + hipGetErrorString(e));
+  }
+  static void check_nccl(ncclResult_t r, const char *what) {
+    if (r != ncclSuccess) throw std::runtime_error(std::string("pcp_multi: ") + what + ": " + ncclGetErrorString(r));
+  }
+
   std::vector<std::unique_ptr<Device>> dev_;
+  std::vector<hipStream_t> stream_;  // N > 1 on real GPUs: RCCL's stream per GPU
+  std::vector<ncclComm_t> comm_;
   pcp_mls_params params_;
 };
 
