@@ -70,6 +70,8 @@ def parse():
     ap.add_argument("--no-mls", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-side-legs", action="store_true", help="only the timed step and the roofline leg")
+    ap.add_argument("--sharded-legs-points", type=int, default=10_000_000, help="N > 1: map size of the hpr / smooth legs (every rank holds it whole)")
+    ap.add_argument("--sharded-legs-frames", type=int, default=256, help="N > 1: keyframes of the hpr leg")
     ap.add_argument("--no-ic-leg", action="store_true",
                     help="skip the cache-resident projection launches (roofline.ic_resident): under rocprofv3 --kernel-trace "
                          "--stats the k_project_frame row then holds the HBM launches only")
@@ -300,6 +302,92 @@ def main():
             verify = {"equal_to_one_gpu_run": same, "points": int(N * world), "keyframes": int(F),
                       "coloured": int(full["has"].sum()), "differing_points": int((ref["rgb"] != full["rgb"]).any(axis=1).sum())}
             del fx, fy, fz
+    # ---- N > 1: hidden_points_removal and the smoothing stage over the ranks (every rank takes part: collectives).  Both
+    # need the WHOLE map on every GPU, so they run on a map of their own -- the C3 scene, seeded alike on every rank
+    # (--sharded-legs-points / -frames) --: `hpr` = every rank takes the hulls of its block of keyframes on a whole-map
+    # context, the verdicts are all-gathered and imported into the rank's index shard (pipeline.HullSharding); `smooth` =
+    # StatisticalOutlierRemoval + MovingLeastSquares (NONE) with the queries dealt out by slabs (pipeline.CloudSmooth) ----
+    sharded_legs = None
+    if sharded and not args.no_side_legs:
+        sharded_legs = {}
+        Ns, Fs = args.sharded_legs_points, min(args.sharded_legs_frames, F)
+        sx_, sy_, sz_, _ = synth.make_cloud(Ns, seed=synth.SEED)
+        dev_name = f"cuda:{local_rank}"
+
+        def rank_max(v):
+            t = torch.tensor([float(v)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        def rank_sum(v):
+            t = torch.tensor([float(v)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return float(t.item())
+
+        try:
+            hcull = capi.default_cull_params()
+            hcull.cull_mode = capi.CULL_HPR
+            hull_ctx = capi.Context(local_rank)
+            hull_ctx.set_camera(capi.camera_from_dict(cam), hcull)
+            hull_ctx.upload_cloud(sx_, sy_, sz_)
+            hull_ctx.set_frames(poses[:Fs])
+            lo_s, hi_s = pipeline.shard_bounds(Ns, rank, world)
+            shard_ctx = capi.Context(local_rank)
+            shard_ctx.set_camera(capi.camera_from_dict(cam), hcull)
+            shard_ctx.upload_cloud(sx_[lo_s:hi_s], sy_[lo_s:hi_s], sz_[lo_s:hi_s])
+            shard_ctx.set_frames(poses[:Fs])
+            shard_ctx.set_depth_source(True)
+            shard_ctx.depth_pass()  # the shard's own part of a run (tile masks; no hull on an index shard): as MultiDevice::depthPassAll
+            hs = pipeline.HullSharding(hull_ctx, shard_ctx, Ns, rank, world)
+            hs.run(Fs, device=dev_name)  # warm-up (allocations)
+            dist.barrier()
+            t1 = time.perf_counter()
+            hres = hs.run(Fs, device=dev_name)
+            dist.barrier()
+            t_all = time.perf_counter() - t1
+            # every verdict arrived: the hull vertices the shards hold for keyframe 0 add up to what its owner kept
+            mine0 = int(shard_ctx.cull_frame(0)[2])
+            owner0 = int(hull_ctx.cull_frame(0)[2]) if pipeline.keyframe_block(Fs, rank, world)[0] == 0 and pipeline.keyframe_block(Fs, rank, world)[1] > 0 else 0
+            sharded_legs["hpr"] = {"points": Ns, "keyframes": Fs, "hpr_ms": round(rank_max(t_all) * 1e3, 2),
+                                   "hull_ms_max_rank": round(rank_max(hres["hull_s"]) * 1e3, 2),
+                                   "exchange_ms_max_rank": round(rank_max(hres["exchange_s"]) * 1e3, 2),
+                                   "hull_vertices": int(rank_sum(hres["kept"])),
+                                   "keyframe0_shards_equal_owner": bool(rank_sum(mine0) == rank_sum(owner0)),
+                                   "what": "hidden_points_removal of the whole C3-scene map over the ranks: hulls of each rank's block of "
+                                           "keyframes (whole-map context), all-gather of the verdicts keyframe by keyframe, import into the "
+                                           "rank's index shard"}
+            hull_ctx.close()
+            shard_ctx.close()
+        except (RuntimeError, capi.PcpError) as e:
+            sharded_legs["hpr"] = {"error": str(e)}
+        try:
+            seng = pipeline.HipEngine(local_rank)
+            seng.configure(cam, cull)
+            seng.upload_cloud(sx_, sy_, sz_)
+            mp_s = capi.default_mls_params()
+            mp_s.upsampling = 0
+            cs = pipeline.CloudSmooth(seng, mp_s)
+            cs.outlier_removal_sharded(Ns, rank, world)  # warm-up
+            dist.barrier()
+            t1 = time.perf_counter()
+            keep_s = cs.outlier_removal_sharded(Ns, rank, world)
+            dist.barrier()
+            t_sor = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            fit_s = cs.process_sharded(Ns, rank, world)
+            dist.barrier()
+            t_fit = time.perf_counter() - t1
+            sharded_legs["smooth"] = {"points": Ns, "smooth_ms": round(rank_max(t_sor + t_fit) * 1e3, 2),
+                                      "sor_ms": round(rank_max(t_sor) * 1e3, 2), "mls_ms": round(rank_max(t_fit) * 1e3, 2),
+                                      "kept": int(keep_s.sum()), "fitted": int(len(fit_s["index"])),
+                                      "same_mask_on_every_rank": bool(rank_max(int(keep_s.sum())) == int(keep_s.sum())),
+                                      "what": "StatisticalOutlierRemoval (k = 60, 0.7 sigma) + MovingLeastSquares (r = 0.03, NONE) of the "
+                                              "whole map with the queries dealt out by slabs; results on every rank's host (the "
+                                              "variable-length MLS rows are all-gathered and merged by source index)"}
+            seng.close()
+        except (RuntimeError, capi.PcpError) as e:
+            sharded_legs["smooth"] = {"error": str(e)}
+        del sx_, sy_, sz_
     # ---- per-kernel times of one more step (hipEvents on the launch stream).  Every rank takes the step:
     # with N > 1 it contains the all-reduce, a collective ----
     eng.ctx.timing_enable(True)
@@ -921,6 +1009,8 @@ def main():
             "hpr": hpr,
             "mls": mls,
         }
+        if sharded_legs is not None:
+            result["sharded_legs"] = sharded_legs
         if verify is not None:
             result["verify"] = verify
             parity_fail = parity_fail or not verify.get("equal_to_one_gpu_run", True)

@@ -311,6 +311,17 @@ class Context:
         self._check(self.lib.pcp_cull_frame(self.h, C.c_int32(frame), _ptr(keep), C.byref(kept), _ptr(dmap)))
         return keep, dmap.reshape(mh, mw), kept.value
 
+    def cull_frame_into(self, frame: int, device_ptr: int) -> int:
+        """pcp_cull_frame with the n keep flags written to DEVICE memory of this context's GPU (ABI v5): the multi-GPU hosts
+        exchange them with RCCL.  Returns the number kept."""
+        kept = C.c_int64()
+        self._check(self.lib.pcp_cull_frame(self.h, C.c_int32(frame), C.c_void_p(device_ptr), C.byref(kept), None))
+        return kept.value
+
+    def hull_flags_import_ptr(self, frame: int, device_ptr: int):
+        """pcp_hull_flags_import from device memory (n flags of THIS context's points)."""
+        self._check(self.lib.pcp_hull_flags_import(self.h, C.c_int32(frame), C.c_void_p(device_ptr)))
+
     def hpr_stats(self) -> dict:
         """Counters of the last hidden_points_removal run (pcp_hpr_stats)."""
         out = np.zeros(10, np.int64)

@@ -1168,9 +1168,11 @@ static int frame_keep_flags(pcp_context *ctx, int32_t frame, bool require_pixel)
   if (n == 0) return PCP_OK;
   const size_t plane = plane_of(ctx);
   const bool hull = ctx->cull.cull_mode == PCP_CULL_HPR;
-  if (hull && ctx->depth_from_batch) {
-    // one index shard of a larger map: the hull was taken over the WHOLE map elsewhere and its verdicts were imported
-    if (!ctx->hull_bits.p || static_cast<size_t>(frame) >= ctx->hull_valid.size() || !ctx->hull_valid[static_cast<size_t>(frame)])
+  const bool have_bits = hull && ctx->hull_bits.p && static_cast<size_t>(frame) < ctx->hull_valid.size() && ctx->hull_valid[static_cast<size_t>(frame)];
+  if (hull && (ctx->depth_from_batch || have_bits)) {
+    // the keyframe's verdicts are in the whole-run bits already: imported (one index shard of a larger map: the hull was taken
+    // over the WHOLE map elsewhere), or left there by this context's own hull pass (pcp_depth_pass) -- nothing is recomputed
+    if (!have_bits)
       return set_error(ctx, PCP_ERR_STATE, "PCP_CULL_HPR on an index shard: pcp_hull_flags_import has not covered keyframe %d", frame);
     LaunchTimer t(ctx, PCP_K_VISIBILITY);
     hipLaunchKernelGGL(k_flags_from_hull_bits, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream,
@@ -1668,6 +1670,8 @@ int pcp_depth_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
       const char *le = std::getenv("PCP_HPR_LANES");
       const int32_t lanes = le && le[0] >= '1' && le[0] <= '8' ? le[0] - '0' : 4;
       if ((rc = hpr_run_range(ctx, frame_begin, frame_end, lanes)) != PCP_OK) return rc;
+      // (the single-keyframe calls read these bits instead of taking the keyframe's hull again)
+      for (int32_t f = frame_begin; f < frame_end; ++f) ctx->hull_valid[static_cast<size_t>(f)] = 1;
     }
   }
   for (int32_t f = frame_begin; f < frame_end; ++f) ctx->depth_valid[static_cast<size_t>(f)] = 1;

@@ -179,6 +179,74 @@ class PointCloudColorizer:
         return dict(rgb=rgb, has=has)
 
 
+def keyframe_block(n_frames: int, rank: int, world: int):
+    """[f0, f1): the keyframes whose hulls rank `rank` takes when hidden_points_removal runs over `world` GPUs."""
+    return n_frames * rank // world, n_frames * (rank + 1) // world
+
+
+class HullSharding:
+    """hidden_points_removal (view_culling.cpp:266-334) over point-index shards.  A keyframe's hull is taken over EVERY
+    candidate of the map, so an index shard cannot decide its own points: every rank holds a second context with the whole
+    map (`hull_ctx`, cull_mode PCP_CULL_HPR, no images), takes the hulls of its block of keyframes there in one
+    pcp_depth_pass (several keyframes in flight), and the verdicts -- one flag per map point -- are all-gathered keyframe
+    by keyframe; every rank imports the slice of its own index range into its shard context (`shard_ctx`,
+    PCP_DEPTH_BATCHED), which then colours / dumps from the bits exactly as a one-GPU run does.  With the "nccl" backend
+    the flags stay in device memory from pcp_cull_frame to pcp_hull_flags_import (ABI v5)."""
+
+    def __init__(self, hull_ctx, shard_ctx, n_total: int, rank: int, world: int, group=None):
+        self.hull_ctx, self.shard_ctx = hull_ctx, shard_ctx
+        self.n_total, self.rank, self.world, self.group = int(n_total), rank, world, group
+
+    def run(self, n_frames: int, device: str | None = None):
+        """Returns dict(hull_s, exchange_s, kept) -- kept = hull vertices of this rank's keyframes."""
+        import time
+
+        import torch
+        import torch.distributed as dist
+
+        W, r, n = self.world, self.rank, self.n_total
+        lo, hi = shard_bounds(n, r, W)
+        f0, f1 = keyframe_block(n_frames, r, W)
+        t0 = time.perf_counter()
+        if f1 > f0:
+            self.hull_ctx.depth_pass(f0, f1)
+        self.hull_ctx.synchronize()
+        t_hull = time.perf_counter() - t0
+        on_gpu = W > 1 and dist.get_backend(self.group) == "nccl"
+        dev = (device or "cuda") if on_gpu else "cpu"
+        rounds = max(keyframe_block(n_frames, k, W)[1] - keyframe_block(n_frames, k, W)[0] for k in range(W))
+        send = torch.zeros(n, dtype=torch.uint8, device=dev)
+        recv = torch.zeros((W, n), dtype=torch.uint8, device=dev) if W > 1 else send.view(1, n)
+        kept = 0
+        t0 = time.perf_counter()
+        for i in range(rounds):
+            f = f0 + i
+            if f < f1:
+                if on_gpu:
+                    kept += self.hull_ctx.cull_frame_into(f, send.data_ptr())  # from the whole-run bits: nothing recomputed
+                else:
+                    keep, _, k = self.hull_ctx.cull_frame(f)
+                    send.copy_(torch.from_numpy(np.ascontiguousarray(keep)))
+                    kept += int(k)
+            else:
+                send.zero_()
+            if W > 1:
+                dist.all_gather_into_tensor(recv.view(-1), send, group=self.group)
+            for k in range(W):
+                fk0, fk1 = keyframe_block(n_frames, k, W)
+                if fk0 + i >= fk1:
+                    continue
+                piece = recv[k, lo:hi]
+                if on_gpu:
+                    torch.cuda.current_stream().synchronize()  # the library imports on its own stream
+                    self.shard_ctx.hull_flags_import_ptr(fk0 + i, piece.data_ptr())
+                else:
+                    self.shard_ctx.hull_flags_import(fk0 + i, piece.cpu().numpy())
+        if on_gpu:
+            self.shard_ctx.synchronize()
+        return dict(hull_s=t_hull, exchange_s=time.perf_counter() - t0, kept=kept)
+
+
 class VisualLiDARCalibration:
     """vlcal::VisualLiDARCalibration::calibrate (calibrate.cpp:42-126) over an index-sharded map.
 

@@ -6,10 +6,14 @@
 #
 #  1. bench.py --gpus N --verify under torch.distributed.run: RCCL all-reduce(MIN) of the depth maps, all-gather of the
 #     keyframes over xGMI; the gathered colours must equal a one-GPU run of the same seeded map (verify.equal_to_one_gpu_run).
+#     The same line times the two stages that need the whole map on every GPU (sharded_legs): hidden_points_removal over the
+#     ranks (hulls of each rank's block of keyframes, all-gather of the verdicts on device memory, import into the index
+#     shards: hpr_ms) and the smoothing stage (outlier removal + MLS, queries dealt out by slabs: smooth_ms).
 #  2. the C++ host: PointCloudProcessor --gpus N against --gpus 1 on a generated scene, every output file byte for byte
 #     (ncclCommInitAll, grouped ncclAllReduce(ncclMin), ncclBroadcast of the images, ncclAllReduce(ncclSum) of the NID
 #     histograms with --enableNIDOptimize 1).
-#     Also --cull hpr (the hulls taken on whole-map contexts, keyframe f on GPU f mod N, verdicts handed to the shards) and
+#     Also --cull hpr (the hulls taken on whole-map contexts, keyframe f on GPU f mod N, slices of the verdicts sent to the
+#     shards by grouped ncclSend / ncclRecv on device memory) and
 #     --enableMLS 1 (both outlier-removal brackets, MLS queries and voxel chunks dealt out): --gpus N against --gpus 1.
 #  3. the RCCL plumbing tests of the suite (device-pointer all-reduce on the library's stream).
 set -u -o pipefail
@@ -93,6 +97,11 @@ def line(p):
 bn, b1 = line(os.path.join(out, f"bench_n{n}.json")), line(os.path.join(out, "bench_n1.json"))
 v = {"n_gpus": n, "bench_rc": rc_bench, "bench_value": bn.get("value"), "bench_ms_per_step": bn.get("ms_per_step"),
      "bench_verify": bn.get("verify"), "bench_n1_value": b1.get("value"), "cli_rc": rc_cli,
+     "hpr_ms": ((bn.get("sharded_legs") or {}).get("hpr") or {}).get("hpr_ms"),
+     "hpr_exchange_ms": ((bn.get("sharded_legs") or {}).get("hpr") or {}).get("exchange_ms_max_rank"),
+     "hpr_shards_equal_owner": ((bn.get("sharded_legs") or {}).get("hpr") or {}).get("keyframe0_shards_equal_owner"),
+     "smooth_ms": ((bn.get("sharded_legs") or {}).get("smooth") or {}).get("smooth_ms"),
+     "parity_gate": bn.get("parity_gate"),
      "cli_outputs_identical_to_one_gpu": d0 == 0, "cli_nid_outputs_identical_to_one_gpu": d1 == 0,
      "cli_hpr_outputs_identical_to_one_gpu": dh == 0, "cli_mls_outputs_identical_to_one_gpu": dm == 0, "pytest_rc": rc_test}
 v["ok"] = bool(rc_bench == 0 and (bn.get("verify") or {}).get("equal_to_one_gpu_run") and rc_cli == 0 and d0 == 0 and dh == 0)

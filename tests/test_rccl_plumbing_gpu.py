@@ -66,7 +66,7 @@ def test_bench_two_rank_path_runs_to_completion():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--points", "200000",
            "--frames", "8", "--steps", "1", "--warmup", "1", "--roofline-points", "2000000", "--settle-ms", "0", "--verify",
-           "--cpu-points", "100000", "--cpu-frames", "2"]
+           "--cpu-points", "100000", "--cpu-frames", "2", "--sharded-legs-points", "150000", "--sharded-legs-frames", "5"]
     proc = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=root)
     assert proc.returncode == 0, proc.stderr[-2000:]
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
@@ -79,3 +79,7 @@ def test_bench_two_rank_path_runs_to_completion():
     # --verify: the two shards' colours, all-gathered, equal a one-GPU run of the whole 400 k-point map on rank 0
     assert line["verify"]["equal_to_one_gpu_run"] is True and line["verify"]["coloured"] > 0
     assert line["cpu_baseline"]["value"] > 0  # reported at N > 1 as well (rank 0)
+    # the hidden_points_removal and smoothing legs of N > 1 (what the first multi-GPU lease times): ran on both ranks
+    legs = line["sharded_legs"]
+    assert legs["hpr"]["hpr_ms"] > 0 and legs["hpr"]["hull_vertices"] > 0 and legs["hpr"]["keyframe0_shards_equal_owner"] is True
+    assert legs["smooth"]["smooth_ms"] > 0 and legs["smooth"]["kept"] > 0 and legs["smooth"]["same_mask_on_every_rank"] is True

@@ -334,3 +334,81 @@ def test_two_rank_mls_query_sharding(tmp_path, oracle):
         got = np.load(tmp_path / f"mls{r}.npz")
         for k in ("index", "xyz", "normal", "curvature"):
             assert np.array_equal(got[k], ref[k]), (r, k)
+
+
+# ---- hidden_points_removal over index shards: the exchange of the verdicts (pipeline.HullSharding) ----
+def _hull_flags(f, n):
+    """stand-in verdicts of keyframe f for the n points of the map (the protocol under test moves them, it does not compute them)"""
+    return (((np.arange(n, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(97 * f + 13)) >> np.uint64(9)) & np.uint64(1)).astype(np.uint8)
+
+
+class _FakeHullCtx:
+    def __init__(self, n):
+        self.n, self.done = n, set()
+
+    def depth_pass(self, f0, f1):
+        self.done |= set(range(f0, f1))
+
+    def synchronize(self):
+        pass
+
+    def cull_frame(self, f):
+        assert f in self.done, "a keyframe outside this rank's block was asked for"
+        keep = _hull_flags(f, self.n)
+        return keep, None, int(keep.sum())
+
+
+class _FakeShardCtx:
+    def __init__(self):
+        self.got = {}
+
+    def hull_flags_import(self, f, piece):
+        assert f not in self.got
+        self.got[f] = np.array(piece, np.uint8)
+
+    def synchronize(self):
+        pass
+
+
+def _hull_worker(rank, world, port, out_dir, n, n_frames):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+
+    from pointcloudprocessor_amd import pipeline
+    from test_sharding_gloo import _FakeHullCtx, _FakeShardCtx
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shard = _FakeShardCtx()
+    hs = pipeline.HullSharding(_FakeHullCtx(n), shard, n, rank, world)
+    res = hs.run(n_frames)
+    np.savez(os.path.join(out_dir, f"hull{rank}.npz"), kept=res["kept"], frames=np.array(sorted(shard.got)),
+             **{f"f{f}": v for f, v in shard.got.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_frames", [(2, 7), (3, 4)])
+def test_hull_verdicts_reach_every_index_shard(tmp_path, world, n_frames):
+    """Every rank takes the hulls of its block of keyframes on a whole-map context; after the exchange every rank holds,
+    for EVERY keyframe, the verdicts of exactly its own index range (uneven blocks and uneven shards included)."""
+    import torch.multiprocessing as mp
+
+    from pointcloudprocessor_amd import pipeline
+
+    n = 1001
+    port = _free_port()
+    mp.spawn(_hull_worker, args=(world, port, str(tmp_path), n, n_frames), nprocs=world, join=True)
+    kept = 0
+    for r in range(world):
+        d = np.load(tmp_path / f"hull{r}.npz")
+        lo, hi = pipeline.shard_bounds(n, r, world)
+        assert list(d["frames"]) == list(range(n_frames))
+        for f in range(n_frames):
+            assert np.array_equal(d[f"f{f}"], _hull_flags(f, n)[lo:hi]), (r, f)
+        kept += int(d["kept"])
+    assert kept == sum(int(_hull_flags(f, n).sum()) for f in range(n_frames))
+    blocks = [pipeline.keyframe_block(n_frames, r, world) for r in range(world)]
+    assert blocks[0][0] == 0 and blocks[-1][1] == n_frames and all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
