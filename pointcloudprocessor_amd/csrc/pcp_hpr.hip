@@ -40,6 +40,7 @@
 // pcp_hpr_stats) and classified hidden, as qhull classifies points on a facet ("coplanar points" are not vertices).
 // Exact duplicates: the lowest input index of a group of identical flipped points stands for the group.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 
@@ -677,6 +678,36 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_candidates(const float *__res
       atomicMax(&mine[2], ~bmin);
       atomicMax(&mine[3], bmax);
     }
+  }
+}
+
+// The number of candidates and the folded bounds, written straight into pinned HOST memory behind k_hpr_candidates, the
+// sequence number last: the host polls that word instead of waiting for a device-to-host copy and its event (the copy
+// engine's round trip was the larger part of a keyframe's one host wait, and its latency depends on what else the process
+// has initialised: the same pass took 0.148 s alone and 0.163 s once torch had touched the device).
+struct HprCounts {
+  unsigned long long count, inv_amin, amax, inv_bmin, bmax, seq;
+};
+__global__ __launch_bounds__(64) void k_hpr_publish(const unsigned long long *__restrict__ stats, unsigned long long seq,
+                                                    volatile HprCounts *__restrict__ host) {
+  const int l = lane_id();
+  unsigned long long v[4] = {0ull, 0ull, 0ull, 0ull};
+  for (int c = 1 + l; c <= kStatCopies; c += 64)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = max(v[k], stats[kStatStride * c + 24 + k]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = max(v[k], static_cast<unsigned long long>(__shfl_xor(static_cast<long long>(v[k]), o, 64)));
+  if (l == 0) {
+    host->count = stats[kStatCandidates];
+    host->inv_amin = v[0];
+    host->amax = v[1];
+    host->inv_bmin = v[2];
+    host->bmax = v[3];
+    __threadfence_system();
+    host->seq = seq;
+    __threadfence_system();
   }
 }
 
@@ -1643,7 +1674,7 @@ __device__ void hpr_exact_one(const HprArrays &A, const HprGrid &G, double reach
 
 // (a fixed grid whose wavefronts stride over the list; its length is read where k_hpr_decide counted it -- stats[8] -- so the
 // host neither waits for the count nor adds launches, however long the list)
-constexpr int32_t kHprExactGrid = 1024;
+constexpr int32_t kHprExactGrid = 64;  // (a handful of candidates per keyframe; every wavefront of the launch reserves 2.8 KB of scratch per lane)
 __global__ __launch_bounds__(64) void k_hpr_exact(HprArrays A, HprGrid G, double reach, const int32_t *__restrict__ undecided,
                                                   uint8_t *__restrict__ state, unsigned long long *__restrict__ stats) {
   __shared__ int32_t ids[kHprExactIds];
@@ -1707,10 +1738,13 @@ int hpr_begin(pcp_context *ctx, HprLane &L, hipStream_t stream, bool timed, int3
   L.d_flags = d_flags;
   L.hull_plane = hull_plane;
   L.bit = bit;
-  if (!L.counted) PCP_HIP_TRY(ctx, hipEventCreateWithFlags(&L.counted, hipEventDisableTiming));
-  if (!L.readback && hipHostMalloc(&L.readback, pcp_context::kReadbackBytes, hipHostMallocDefault) != hipSuccess) {
-    L.readback = nullptr;
-    return set_error(ctx, PCP_ERR_NOMEM, "hidden_points_removal: no pinned readback for a lane");
+  if (!L.readback) {
+    if (hipHostMalloc(&L.readback, pcp_context::kReadbackBytes, hipHostMallocDefault) != hipSuccess) {
+      L.readback = nullptr;
+      return set_error(ctx, PCP_ERR_NOMEM, "hidden_points_removal: no pinned readback for a lane");
+    }
+    std::memset(L.readback, 0, pcp_context::kReadbackBytes);
+    L.seq = 0;
   }
   // doubles: px py pz ga gb rho | sx sy sz, `cap` apart; ints: candidate's input index | its place in the sorted order
   PCP_HIP_TRY(ctx, L.f64.ensure(9 * cap + 16));
@@ -1728,9 +1762,11 @@ int hpr_begin(pcp_context *ctx, HprLane &L, hipStream_t stream, bool timed, int3
                        cidx, cplace, px, stats);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
-  // the number of candidates (block 0) and the copies of the bounds (words 24..27 of the other blocks), one download
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(L.readback, stats, kStatWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-  PCP_HIP_TRY(ctx, hipEventRecord(L.counted, stream));
+  // the number of candidates (block 0) and the bounds (folded from the copies in words 24..27 of the other blocks) into the
+  // lane's pinned readback, the keyframe's sequence number behind them
+  L.seq += 1;
+  hipLaunchKernelGGL(k_hpr_publish, dim3(1), dim3(64), 0, stream, stats, L.seq, static_cast<volatile HprCounts *>(L.readback));
+  PCP_HIP_TRY(ctx, hipGetLastError());
   L.busy = true;
   return PCP_OK;
 }
@@ -1754,14 +1790,26 @@ int hpr_finish(pcp_context *ctx, HprLane &L, bool timed) {
   double *sx = rho + cap, *sy = sx + cap, *sz = sy + cap;
   int32_t *cidx = L.index.p, *cplace = cidx + cap;
   unsigned long long *stats = L.stats.p;
-  PCP_HIP_TRY(ctx, hipEventSynchronize(L.counted));
-  const unsigned long long *hall = static_cast<const unsigned long long *>(L.readback);
-  const int64_t m64 = static_cast<int64_t>(hall[kStatCandidates]);
-  unsigned long long hb[4] = {0ull, 0ull, 0ull, 0ull};
-  for (int c = 1; c <= kStatCopies; ++c)
-    for (int k = 0; k < 4; ++k) hb[k] = std::max(hb[k], hall[static_cast<size_t>(kStatStride * c + 24 + k)]);
-  hb[0] = ~hb[0];  // the minima were kept as maxima of the inverted keys
-  hb[2] = ~hb[2];
+  // The one host wait of a keyframe: polling the sequence number k_hpr_publish writes last (an error on the stream ends it)
+  const volatile HprCounts *hc = static_cast<const volatile HprCounts *>(L.readback);
+  {
+    const auto t_wait = std::chrono::steady_clock::now();
+    for (uint64_t spins = 0; hc->seq != L.seq; ++spins) {
+      __builtin_ia32_pause();
+      if ((spins & 0xfffffu) == 0xfffffu) {  // now and then: is the stream still alive?
+        const hipError_t q = hipStreamQuery(stream);
+        if (q != hipSuccess && q != hipErrorNotReady) PCP_HIP_TRY(ctx, q);
+        if (q == hipSuccess && hc->seq != L.seq) {
+          __sync_synchronize();
+          if (hc->seq != L.seq) return set_error(ctx, PCP_ERR_DEVICE, "hidden_points_removal: the candidates' count never arrived");
+        }
+      }
+    }
+    __sync_synchronize();
+    ctx->hpr_host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count();
+  }
+  const int64_t m64 = static_cast<int64_t>(hc->count);
+  unsigned long long hb[4] = {~hc->inv_amin, hc->amax, ~hc->inv_bmin, hc->bmax};  // the minima were kept as maxima of the inverted keys
   std::memset(ctx->hpr_stats, 0, sizeof(ctx->hpr_stats));
   ctx->hpr_stats_pending = false;
   ctx->hpr_stats[9] = m64;
@@ -1962,7 +2010,24 @@ int hpr_run_range(pcp_context *ctx, int32_t f0, int32_t f1, int32_t lanes) {
   int rc = PCP_OK;
   if (!ctx->hpr_fork) PCP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->hpr_fork, hipEventDisableTiming));
   LaunchTimer t(ctx, PCP_K_HPR);  // the whole pass as one bracket on the context's stream
+  ctx->hpr_host_wait_s = 0.0;
+  const auto t_pass = std::chrono::steady_clock::now();
   PCP_HIP_TRY(ctx, hipEventRecord(ctx->hpr_fork, ctx->stream));
+  // every lane holds the scratch of a keyframe whose every point may be a candidate (80 B per map point): where the device
+  // has no room for all of them, fewer keyframes are in flight
+  {
+    const size_t cap = static_cast<size_t>(ctx->n);
+    for (int32_t k = 1; k < lanes; ++k) {
+      HprLane &L = ctx->hpr_lane[k];
+      if (L.f64.ensure(9 * cap + 16) != hipSuccess || L.index.ensure(2 * cap + 16) != hipSuccess) {
+        (void)hipGetLastError();
+        L.f64.release();
+        L.index.release();
+        lanes = k;
+        break;
+      }
+    }
+  }
   for (int32_t k = 0; k < lanes; ++k) {
     HprLane &L = ctx->hpr_lane[k];
     if (!L.own_stream) PCP_HIP_TRY(ctx, hipStreamCreateWithFlags(&L.own_stream, hipStreamNonBlocking));
@@ -1987,6 +2052,9 @@ int hpr_run_range(pcp_context *ctx, int32_t f0, int32_t f1, int32_t lanes) {
     PCP_HIP_TRY(ctx, hipEventRecord(ctx->hpr_join[k], ctx->hpr_lane[k].own_stream));
     PCP_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->hpr_join[k], 0));
   }
+  if (std::getenv("PCP_HPR_HOST_TIMING"))
+    fprintf(stderr, "hpr: pass of %d keyframes on %d lanes: host %.1f ms, of which %.1f ms waiting for counts\n", f1 - f0, lanes,
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pass).count() * 1e3, ctx->hpr_host_wait_s * 1e3);
   return rc;
 }
 

@@ -94,13 +94,14 @@ struct DevBuf {
 };
 
 // hidden_points_removal: the scratch of ONE keyframe's hull (pcp_hpr.hip).  The keyframes of a run are independent, so the
-// whole-run pass keeps several of them in flight, each on a lane of its own: a stream, the buffers, a pinned readback and
-// the event recorded behind the download of the candidates' count and bounds (the one host wait of a keyframe).  Lane 0
+// whole-run pass keeps several of them in flight, each on a lane of its own: a stream, the buffers and a pinned readback
+// into which the device publishes the candidates' count and bounds (the one host wait of a keyframe polls it).  Lane 0
 // also serves the single-keyframe calls, on the context's stream.
 struct HprLane {
   hipStream_t own_stream = nullptr;  // created on first use by the whole-run pass
   hipStream_t stream = nullptr;      // the stream the keyframe in flight was queued on
-  hipEvent_t counted = nullptr;
+  hipEvent_t counted = nullptr;      // (unused since the counts are published to pinned memory by the device)
+  unsigned long long seq = 0;        // sequence number of the keyframe whose counts the readback is waited for
   DevBuf<int32_t> index, i32, tiles;
   DevBuf<double> f64, cells_d;
   DevBuf<uint8_t> state;
@@ -230,6 +231,7 @@ struct pcp_context {
   static constexpr int kHprMaxLanes = 8;
   pcp::HprLane hpr_lane[kHprMaxLanes];
   int32_t hpr_last_lane = 0;  // whose tallies pcp_hpr_stats reads
+  double hpr_host_wait_s = 0.0;  // host time of the last whole-run pass spent waiting for the keyframes' counts (PCP_HPR_DEBUG prints it)
   hipEvent_t hpr_fork = nullptr, hpr_join[kHprMaxLanes] = {};
   pcp::DevBuf<uint32_t> hull_bits;  // whole run: uint32[(F + 31) / 32][n], bit f & 31 of word (f >> 5, j) = point j (Morton
                                     // order) is a hull vertex of keyframe f
