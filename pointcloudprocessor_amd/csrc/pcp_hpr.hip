@@ -468,23 +468,25 @@ struct Window {
 };
 
 __device__ __forceinline__ Window reach_window(const Search &S, const HprGrid &G) {
+  // (only a SUPERSET of the cells is asked for: reciprocals instead of divisions, |a| + |b| for the norm, a cell of margin
+  // for the rounding of the products -- this routine was a quarter of k_hpr_radial's vector instructions)
   Window W = {0, G.cgw - 1, 0, G.cgh - 1};
-  const double ratio = S.hp_lo / (*G.rho_max * S.nn_hi);
+  const double ratio = S.hp_lo * quick_rcp(*G.rho_max * S.nn_hi) * (1.0 - 1.0e-14);
   if (ratio >= 1.0) return {1, 0, 1, 0};
   if (!(S.nh.z > 1.0e-3)) return W;
   const double sep = sqrt(2.0 * (1.0 - ratio)) * (1.0 + 1.0e-9) + 1.0e-12;
   const double inz = quick_rcp(S.nh.z);
   const double ax = S.nh.x * inz, ay = S.nh.y * inz;  // to ~1 ulp; R below carries 1e-9 of slack
-  const double R = sep * (1.0 + sqrt(ax * ax + ay * ay)) * G.a_reach * (1.0 + 1.0e-9);
-  const double H = G.h * kHprCoarse;
-  const double fi0 = floor((ax - R - G.a0) / H), fi1 = floor((ax + R - G.a0) / H);
-  const double fj0 = floor((ay - R - G.b0) / H), fj1 = floor((ay + R - G.b0) / H);
+  const double R = sep * (1.0 + (fabs(ax) + fabs(ay))) * G.a_reach * (1.0 + 1.0e-9);
+  const double iH = G.inv_h * (1.0 / kHprCoarse);
+  const double fi0 = floor((ax - R - G.a0) * iH) - 1.0, fi1 = floor((ax + R - G.a0) * iH) + 1.0;
+  const double fj0 = floor((ay - R - G.b0) * iH) - 1.0, fj1 = floor((ay + R - G.b0) * iH) + 1.0;
   if (!(fi0 == fi0 && fi1 == fi1 && fj0 == fj0 && fj1 == fj1)) return W;  // NaN: no window
+  if (fi1 < 0.0 || fj1 < 0.0 || fi0 > G.cgw - 1 || fj0 > G.cgh - 1) return {1, 0, 1, 0};
   W.i0 = static_cast<int32_t>(fmax(fi0, 0.0));
   W.j0 = static_cast<int32_t>(fmax(fj0, 0.0));
   W.i1 = static_cast<int32_t>(fmin(fi1, static_cast<double>(G.cgw - 1)));
   W.j1 = static_cast<int32_t>(fmin(fj1, static_cast<double>(G.cgh - 1)));
-  if (fi1 < 0.0 || fj1 < 0.0 || fi0 > G.cgw - 1 || fj0 > G.cgh - 1) return {1, 0, 1, 0};
   return W;
 }
 
@@ -874,10 +876,10 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_radial(HprArrays A, HprGrid G
   search_frame(S);
   S.n = S.e0;
   {
-    const double nn = sqrt((S.n.x * S.n.x + S.n.y * S.n.y) + S.n.z * S.n.z);
-    const double inv = quick_rcp(nn);
-    S.nh = {S.n.x * inv, S.n.y * inv, S.n.z * inv};
-    S.nn_hi = nn * (1.0 + 1.0e-14);
+    // e0 = p / |p| to a few ulp (search_frame): |n| = 1 within 1e-15, so n stands for its own unit vector (the cell bound
+    // carries 1e-12 of slack for that) and 1 + 1e-13 bounds its norm -- no second square root and reciprocal per candidate
+    S.nh = S.n;
+    S.nn_hi = 1.0 + 1.0e-13;
     S.hp_lo = ((S.n.x * S.p.x + S.n.y * S.p.y) + S.n.z * S.p.z) * (1.0 - 1.0e-13);
   }
   bool open = have && state[S.self] == kStUndecided;  // the row may still certify its candidate (k_hpr_quick may have settled it)
