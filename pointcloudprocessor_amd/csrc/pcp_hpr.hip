@@ -490,6 +490,15 @@ __device__ __forceinline__ Window reach_window(const Search &S, const HprGrid &G
   return W;
 }
 
+// t / w for 0 <= t < 2^24, 0 < w < 2^24 without the integer division's expansion: the float quotient is within one of the
+// true one, two comparisons settle it
+__device__ __forceinline__ int32_t small_div(int32_t t, int32_t w) {
+  int32_t q = static_cast<int32_t>(static_cast<float>(t) * __builtin_amdgcn_rcpf(static_cast<float>(w)));
+  q -= q * w > t ? 1 : 0;
+  q += (q + 1) * w <= t ? 1 : 0;
+  return q;
+}
+
 // skip_near: leave out the 3 x 3 cells traverse_near covers (run_search only calls this after a near pass that changed
 // nothing: those cells are cleared for the current trial normal already; the exact path enumerates everything)
 template <bool kSkipNear = false, typename RangeFn>
@@ -926,7 +935,9 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_radial(HprArrays A, HprGrid G
   const int32_t ww = has_window ? W.i1 - W.i0 + 1 : 1, wn = has_window ? ww * (W.j1 - W.j0 + 1) : 0;
   for (int32_t cb = 0; __ballot(open && cb < wn); cb += 16) {
     const int32_t t = cb + rl;
-    const int32_t C = (open && t < wn) ? (W.j0 + t / ww) * G.cgw + W.i0 + t % ww : -1;
+    const int32_t tq = small_div(t, ww);
+    const int32_t Ci = W.i0 + (t - tq * ww), Cj = W.j0 + tq;  // (kept apart: the fine cells need them, not the linear index)
+    const int32_t C = (open && t < wn) ? Cj * G.cgw + Ci : -1;
     bool copen = false;
     if (C >= 0) {
       const float4 c4 = A.Cell4[C];
@@ -937,10 +948,10 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_radial(HprArrays A, HprGrid G
       const bool go_c = open && open_c != 0u;
       const int bc = go_c ? __builtin_ctz(open_c) : 0;
       open_c &= open_c - 1u;
-      const int32_t Cc = __shfl(C, row_base + bc, 64);
+      const int32_t Cci = __shfl(Ci, row_base + bc, 64), Ccj = __shfl(Cj, row_base + bc, 64);
       for (int q4 = 0; q4 < 4; ++q4) {  // the 64 fine cells of the coarse cell, 16 at a time
         const int fidx = q4 * 16 + rl;
-        const int32_t fi = (go_c ? Cc % G.cgw : 0) * kHprCoarse + (fidx & 7), fj = (go_c ? Cc / G.cgw : 0) * kHprCoarse + (fidx >> 3);
+        const int32_t fi = (go_c ? Cci : 0) * kHprCoarse + (fidx & 7), fj = (go_c ? Ccj : 0) * kHprCoarse + (fidx >> 3);
         bool fopen = false;
         int32_t f = 0;
         if (go_c && fi < G.gw && fj < G.gh && !(abs(fi - ci) <= 1 && abs(fj - cj) <= 1)) {
@@ -1299,7 +1310,9 @@ __global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_T
       }
       for (int32_t cbk = 0; __ballot(run && cbk < wn); cbk += 16) {
         const int32_t t = cbk + rl;
-        const int32_t C = (run && t < wn) ? (W.j0 + t / ww) * G.cgw + W.i0 + t % ww : -1;
+        const int32_t tq = small_div(t, ww);
+        const int32_t Ci = W.i0 + (t - tq * ww), Cj = W.j0 + tq;
+        const int32_t C = (run && t < wn) ? Cj * G.cgw + Ci : -1;
         bool copen = false;
         if (C >= 0) {
           const float4 c4 = A.Cell4[C];
@@ -1310,11 +1323,11 @@ __global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_T
           const bool go_c = run && open_c != 0u;
           const int bc = go_c ? __builtin_ctz(open_c) : 0;
           open_c &= open_c - 1u;
-          const int32_t Cc = __shfl(C, row_base + bc, 64);
+          const int32_t Cci = __shfl(Ci, row_base + bc, 64), Ccj = __shfl(Cj, row_base + bc, 64);
 #pragma unroll 1
           for (int q4 = 0; q4 < 4; ++q4) {  // the 64 fine cells of the coarse cell, 16 at a time
             const int fidx = q4 * 16 + rl;
-            const int32_t fi = (go_c ? Cc % G.cgw : 0) * kHprCoarse + (fidx & 7), fj = (go_c ? Cc / G.cgw : 0) * kHprCoarse + (fidx >> 3);
+            const int32_t fi = (go_c ? Cci : 0) * kHprCoarse + (fidx & 7), fj = (go_c ? Ccj : 0) * kHprCoarse + (fidx >> 3);
             bool fopen = false;
             int32_t f = 0;
             if (go_c && run && fi < G.gw && fj < G.gh && !(abs(fi - ci) <= 1 && abs(fj - cj) <= 1)) {
