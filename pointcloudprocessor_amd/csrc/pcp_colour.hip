@@ -215,7 +215,8 @@ constexpr int kTileGroup = 16;
 __global__ __launch_bounds__(kBlock) void k_group_mask_flat(const float4 *__restrict__ spheres, int64_t groups, DevCamera cam,
                                                             const DevFrame *__restrict__ frames, int32_t n_frames,
                                                             int32_t w0, int32_t w1, int32_t words,
-                                                            uint32_t *__restrict__ group_mask, int32_t cull_enabled) {
+                                                            uint32_t *__restrict__ group_mask,
+                                                            uint32_t *__restrict__ group_inside, int32_t cull_enabled) {
   const int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const int32_t nw = w1 - w0;
   const int64_t gw = idx >> 5;  // word of this half wavefront, counted over the launch
@@ -223,10 +224,16 @@ __global__ __launch_bounds__(kBlock) void k_group_mask_flat(const float4 *__rest
   const bool live = group < groups;
   const int32_t w = w0 + static_cast<int32_t>(gw - group * nw);
   const int32_t f = (w << 5) + static_cast<int32_t>(idx & 31);
-  bool keep = false;
-  if (live && f < n_frames) keep = !cull_enabled || tile_classify(cam, frames[f], spheres[group]) != 1;
-  const unsigned long long m = __ballot(keep);
-  if (live && (idx & 31) == 0) group_mask[group * words + w] = static_cast<uint32_t>((threadIdx.x & 32) ? (m >> 32) : m);
+  int cls = 1;
+  if (live && f < n_frames) cls = cull_enabled ? tile_classify(cam, frames[f], spheres[group]) : 0;
+  // a group that images wholly inside the acceptance box (and in front of the camera): none of its tiles can be rejected
+  // -- a tile's interval image contains the images of its points, which lie in the box -- so the tile level has nothing to
+  // decide for that pair
+  const unsigned long long m = __ballot(cls != 1), in = __ballot(cls == 2);
+  if (live && (idx & 31) == 0) {
+    group_mask[group * words + w] = static_cast<uint32_t>((threadIdx.x & 32) ? (m >> 32) : m);
+    group_inside[group * words + w] = static_cast<uint32_t>((threadIdx.x & 32) ? (in >> 32) : in);
+  }
 }
 
 // Tile level, dense form: one wavefront per (group of 16 tiles, 32-keyframe word), lane = slot * 16 + tile-in-group.
@@ -239,6 +246,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_mask_dense(const float4 *__rest
                                                             DevCamera cam, const DevFrame *__restrict__ frames,
                                                             int32_t n_frames, int32_t w0, int32_t w1, int32_t words,
                                                             const uint32_t *__restrict__ group_mask,
+                                                            const uint32_t *__restrict__ group_inside,
                                                             uint32_t *__restrict__ tile_mask,
                                                             uint32_t *__restrict__ inside_mask, int32_t cull_enabled) {
   const int lane = threadIdx.x & 63;
@@ -253,7 +261,10 @@ __global__ __launch_bounds__(kBlock) void k_tile_mask_dense(const float4 *__rest
   uint32_t todo = __builtin_amdgcn_readfirstlane(group_mask[group * words + w]);
   const int32_t nb = n_frames - (w << 5);
   if (nb < 32) todo &= nb <= 0 ? 0u : ((1u << nb) - 1u);
-  uint32_t word = 0u, inside = 0u;
+  // keyframes in which the whole group images inside the box: every tile keeps the pair (and skips the pre-test) unexamined
+  const uint32_t whole = __builtin_amdgcn_readfirstlane(group_inside[group * words + w]) & todo;
+  todo &= ~whole;
+  uint32_t word = whole, inside = whole;
   if (todo) {
     const float4 sph = spheres[have ? tile : tiles - 1];
     while (todo) {
@@ -1616,13 +1627,15 @@ int pcp_depth_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
       LaunchTimer t(ctx, PCP_K_TILE_MASK);
       const int64_t groups = div_up(ctx->n_tiles, kTileGroup);
       const float4 *tile_sph = reinterpret_cast<const float4 *>(ctx->tile_sphere.p);
-      PCP_HIP_TRY(ctx, ctx->group_mask.ensure(static_cast<size_t>(groups) * ctx->mask_words + 4));
+      const size_t gwords = static_cast<size_t>(groups) * ctx->mask_words;
+      PCP_HIP_TRY(ctx, ctx->group_mask.ensure(2 * gwords + 8));  // keep bits | "wholly inside" bits
+      uint32_t *group_inside = ctx->group_mask.p + gwords + 4;
       hipLaunchKernelGGL(k_group_mask_flat, dim3(blocks_for(groups * (w1 - w0) * 32)), dim3(kBlock), 0, ctx->stream,
                          tile_sph + ctx->n_tiles, groups, ctx->dcam, ctx->frames.p, ctx->n_frames, w0, w1,
-                         ctx->mask_words, ctx->group_mask.p, cull_tiles ? 1 : 0);
+                         ctx->mask_words, ctx->group_mask.p, group_inside, cull_tiles ? 1 : 0);
       hipLaunchKernelGGL(k_tile_mask_dense, dim3(static_cast<uint32_t>(div_up(groups * (w1 - w0), kBlock / 64))), dim3(kBlock),
                          0, ctx->stream, tile_sph, ctx->n_tiles, ctx->dcam, ctx->frames.p, ctx->n_frames, w0, w1,
-                         ctx->mask_words, ctx->group_mask.p, ctx->tile_mask.p, ctx->tile_inside.p, cull_tiles ? 1 : 0);
+                         ctx->mask_words, ctx->group_mask.p, group_inside, ctx->tile_mask.p, ctx->tile_inside.p, cull_tiles ? 1 : 0);
       hipLaunchKernelGGL(k_tile_work, dim3(blocks_for(ctx->n_tiles)), dim3(kBlock), 0, ctx->stream, ctx->tile_mask.p,
                          ctx->n_tiles, w0, w1, ctx->mask_words, ctx->tile_work.p);
       // longest-work-first order of the tiles for this pass
