@@ -318,3 +318,50 @@ def test_whole_run_bits_in_chunks_of_keyframes(gpu_ctx_factory, oracle):
     ref = oracle.colorize(ocam, ocp, x, y, z, poses, imgs)
     assert np.array_equal(whole["rgb"], ref["rgb"]) and np.array_equal(whole["has"], ref["has"])
     ctx.close()
+
+
+@pytest.mark.parametrize("lanes", ["1", "3", "8"])
+def test_whole_run_bits_do_not_depend_on_the_keyframes_in_flight(gpu_ctx_factory, oracle, monkeypatch, lanes):
+    """The whole-run hull pass keeps several keyframes in flight on lanes of their own (PCP_HPR_LANES, default 4): with one,
+    three (ranges shorter than the lanes, a count that does not divide) and eight lanes the colours are the oracle's, the
+    per-keyframe verdicts read back from the pass's bits equal pcp_cull_frame on a context that never ran the pass, and the
+    16-lane search switched off (PCP_HPR_TILT=0) changes nothing."""
+    from pointcloudprocessor_amd import capi, synth
+
+    cd = synth.camera_dict("tiny")
+    F = 11
+    x, y, z, _ = synth.make_cloud(40000, seed=11)
+    poses, _ = synth.make_trajectory(F)
+    imgs = [synth.make_image(f, cd["image_width"], cd["image_height"]) for f in range(F)]
+    cull = capi.default_cull_params()
+    cull.cull_mode = capi.CULL_HPR
+    monkeypatch.setenv("PCP_HPR_LANES", lanes)
+
+    def ctx_of():
+        c = gpu_ctx_factory()
+        c.set_camera(cam_struct(capi, cd), cull)
+        c.upload_cloud(x, y, z)
+        c.set_frames(poses)
+        for f, im in enumerate(imgs):
+            c.upload_image(f, im)
+        return c
+
+    ctx = ctx_of()
+    got = ctx.colorize()
+    ocam = cam_struct(oracle, cd)
+    ocp = oracle.default_cull_params()
+    ocp.cull_mode = oracle.CULL_HPR
+    ref = oracle.colorize(ocam, ocp, x, y, z, poses, imgs)
+    assert np.array_equal(got["rgb"], ref["rgb"]) and np.array_equal(got["has"], ref["has"])
+    # ranges shorter than the lanes, and the verdicts of the pass read back per keyframe
+    ctx.depth_pass(0, 2)
+    ctx.depth_pass(2, F)
+    fresh = ctx_of()  # never ran the pass: pcp_cull_frame takes each hull itself
+    for f in (0, 1, 5, F - 1):
+        a, b = ctx.cull_frame(f), fresh.cull_frame(f)
+        assert np.array_equal(a[0], b[0]) and a[2] == b[2], f
+    monkeypatch.setenv("PCP_HPR_TILT", "0")
+    again = ctx.colorize()
+    assert np.array_equal(again["rgb"], got["rgb"]) and np.array_equal(again["has"], got["has"])
+    ctx.close()
+    fresh.close()
