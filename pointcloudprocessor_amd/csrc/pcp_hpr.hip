@@ -52,6 +52,7 @@ namespace pcp {
 
 constexpr int kHprBlock = 256;
 constexpr int kHprCoarse = 8;           // fine cells per coarse cell edge: 64 fine cells = one wavefront of tests
+constexpr int kHprMid = 4;              // ... per "mid" cell edge: 16 fine cells = one row of tests of the 16-lane passes
 constexpr double kHprTargetPerCell = 8.0;
 constexpr int64_t kHprMaxCells = int64_t(1) << 22;
 constexpr int kHprMaxRestarts = 96;
@@ -65,7 +66,8 @@ enum : int { kSearchVisible = 1, kSearchEmpty = 2, kSearchFail = 3, kSearchHidde
 struct HprGrid {
   double a0, b0, h, inv_h;
   int32_t gw, gh, cgw, cgh;
-  double r_fine, r_coarse;  // chord bound between a cell's centre direction and any direction inside it
+  int32_t mgw, mgh;         // mid cells (kHprMid x kHprMid fine cells): the upper level of the 16-lane passes
+  double r_fine, r_coarse, r_mid;  // chord bound between a cell's centre direction and any direction inside it
   double a_reach;           // sqrt(1 + max |A|^2) over the grid: bounds 1 / u_z of every candidate direction
   const double *rho_max;    // device: upper bound of |q| over all candidates (k_hpr_cells)
   int32_t m;
@@ -84,6 +86,7 @@ struct HprArrays {
   // round trips of their cell tests: centre direction rounded to fp32 (off by <= 1.1e-7 in chord: kCell4Slack is added to
   // the cell's radius) and the norm bound rounded UP to fp32 (0 = empty)
   const float4 *cell4, *Cell4;
+  const float4 *Mid4;  // mid cells: 4 x 4 fine cells, the same record
 };
 constexpr double kCell4Slack = 2.5e-7;
 
@@ -467,10 +470,13 @@ struct Window {
   int32_t i0, i1, j0, j1;  // coarse cells, inclusive; i0 > i1: empty
 };
 
+// kEdge: fine cells per edge of the upper-level cells the window is in (kHprCoarse: cgw x cgh of them; kHprMid: mgw x mgh)
+template <int kEdge = kHprCoarse>
 __device__ __forceinline__ Window reach_window(const Search &S, const HprGrid &G) {
   // (only a SUPERSET of the cells is asked for: reciprocals instead of divisions, |a| + |b| for the norm, a cell of margin
   // for the rounding of the products -- this routine was a quarter of k_hpr_radial's vector instructions)
-  Window W = {0, G.cgw - 1, 0, G.cgh - 1};
+  const int32_t ugw = kEdge == kHprCoarse ? G.cgw : G.mgw, ugh = kEdge == kHprCoarse ? G.cgh : G.mgh;
+  Window W = {0, ugw - 1, 0, ugh - 1};
   const double ratio = S.hp_lo * quick_rcp(*G.rho_max * S.nn_hi) * (1.0 - 1.0e-14);
   if (ratio >= 1.0) return {1, 0, 1, 0};
   if (!(S.nh.z > 1.0e-3)) return W;
@@ -478,15 +484,15 @@ __device__ __forceinline__ Window reach_window(const Search &S, const HprGrid &G
   const double inz = quick_rcp(S.nh.z);
   const double ax = S.nh.x * inz, ay = S.nh.y * inz;  // to ~1 ulp; R below carries 1e-9 of slack
   const double R = sep * (1.0 + (fabs(ax) + fabs(ay))) * G.a_reach * (1.0 + 1.0e-9);
-  const double iH = G.inv_h * (1.0 / kHprCoarse);
+  const double iH = G.inv_h * (1.0 / kEdge);
   const double fi0 = floor((ax - R - G.a0) * iH) - 1.0, fi1 = floor((ax + R - G.a0) * iH) + 1.0;
   const double fj0 = floor((ay - R - G.b0) * iH) - 1.0, fj1 = floor((ay + R - G.b0) * iH) + 1.0;
   if (!(fi0 == fi0 && fi1 == fi1 && fj0 == fj0 && fj1 == fj1)) return W;  // NaN: no window
-  if (fi1 < 0.0 || fj1 < 0.0 || fi0 > G.cgw - 1 || fj0 > G.cgh - 1) return {1, 0, 1, 0};
+  if (fi1 < 0.0 || fj1 < 0.0 || fi0 > ugw - 1 || fj0 > ugh - 1) return {1, 0, 1, 0};
   W.i0 = static_cast<int32_t>(fmax(fi0, 0.0));
   W.j0 = static_cast<int32_t>(fmax(fj0, 0.0));
-  W.i1 = static_cast<int32_t>(fmin(fi1, static_cast<double>(G.cgw - 1)));
-  W.j1 = static_cast<int32_t>(fmin(fj1, static_cast<double>(G.cgh - 1)));
+  W.i1 = static_cast<int32_t>(fmin(fi1, static_cast<double>(ugw - 1)));
+  W.j1 = static_cast<int32_t>(fmin(fj1, static_cast<double>(ugh - 1)));
   return W;
 }
 
@@ -768,9 +774,24 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_scatter(const double *__restr
 __global__ __launch_bounds__(kHprBlock) void k_hpr_cells(HprGrid G, const unsigned long long *__restrict__ crho_bits,
                                                          double *__restrict__ cdir, double *__restrict__ Crho,
                                                          double *__restrict__ Cdir, unsigned long long *__restrict__ rho_max_bits,
-                                                         float4 *__restrict__ cell4, float4 *__restrict__ Cell4) {
+                                                         float4 *__restrict__ cell4, float4 *__restrict__ Cell4,
+                                                         float4 *__restrict__ Mid4) {
   const int32_t t = static_cast<int32_t>(blockIdx.x) * kHprBlock + static_cast<int32_t>(threadIdx.x);
   const int32_t n_fine = G.gw * G.gh, n_coarse = G.cgw * G.cgh;
+  if (t < G.mgw * G.mgh) {
+    const int32_t Mi = t % G.mgw, Mj = t / G.mgw;
+    unsigned long long best = 0ull;
+    for (int dj = 0; dj < kHprMid; ++dj)
+      for (int di = 0; di < kHprMid; ++di) {
+        const int32_t fi = Mi * kHprMid + di, fj = Mj * kHprMid + dj;
+        if (fi < G.gw && fj < G.gh) best = max(best, crho_bits[fj * G.gw + fi]);
+      }
+    const double a = G.a0 + (static_cast<double>(Mi) + 0.5) * (G.h * kHprMid);
+    const double b = G.b0 + (static_cast<double>(Mj) + 0.5) * (G.h * kHprMid);
+    const double inv = 1.0 / sqrt((a * a + b * b) + 1.0);
+    Mid4[t] = make_float4(static_cast<float>(a * inv), static_cast<float>(b * inv), static_cast<float>(inv),
+                          best ? __double2float_ru(__longlong_as_double(static_cast<long long>(best))) : 0.0f);
+  }
   if (t < n_fine) {
     const double a = G.a0 + (static_cast<double>(t % G.gw) + 0.5) * G.h, b = G.b0 + (static_cast<double>(t / G.gw) + 0.5) * G.h;
     const double inv = 1.0 / sqrt((a * a + b * b) + 1.0);
@@ -928,20 +949,21 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_radial(HprArrays A, HprGrid G
     const int32_t c0 = (in ? rj : cj) * G.gw + max(ci - 1, 0), c1 = (in ? rj : cj) * G.gw + min(ci + 1, G.gw - 1);
     test_points(in, A.cstart[c0], A.cstart[c1 + 1]);
   }
-  // every other cell the bound cannot clear
-  const int32_t n_coarse = G.cgw * G.cgh, n_fine = G.gw * G.gh;
-  const Window W = reach_window(S, G);
+  // every other cell the bound cannot clear: mid cells (4 x 4 fine cells) of the window, 16 at a time, then the 16 fine cells
+  // of a mid cell that stays open -- one row of tests each.  (Through the coarse cells of the 64-lane search an open cell
+  // cost four rows of fine tests, most of them on cells nowhere near the plane: k_hpr_radial is bound by its arithmetic.)
+  const Window W = reach_window<kHprMid>(S, G);
   const bool has_window = open && W.i0 <= W.i1 && W.j0 <= W.j1;
   const int32_t ww = has_window ? W.i1 - W.i0 + 1 : 1, wn = has_window ? ww * (W.j1 - W.j0 + 1) : 0;
   for (int32_t cb = 0; __ballot(open && cb < wn); cb += 16) {
     const int32_t t = cb + rl;
     const int32_t tq = small_div(t, ww);
     const int32_t Ci = W.i0 + (t - tq * ww), Cj = W.j0 + tq;  // (kept apart: the fine cells need them, not the linear index)
-    const int32_t C = (open && t < wn) ? Cj * G.cgw + Ci : -1;
+    const int32_t C = (open && t < wn) ? Cj * G.mgw + Ci : -1;
     bool copen = false;
     if (C >= 0) {
-      const float4 c4 = A.Cell4[C];
-      copen = c4.w > 0.0f && !cell_cleared_f32sep(S.nh.x, S.nh.y, S.nh.z, S.nn_hi, S.hp_lo, c4.x, c4.y, c4.z, c4.w, G.r_coarse + kCell4Slack);
+      const float4 c4 = A.Mid4[C];
+      copen = c4.w > 0.0f && !cell_cleared_f32sep(S.nh.x, S.nh.y, S.nh.z, S.nn_hi, S.hp_lo, c4.x, c4.y, c4.z, c4.w, G.r_mid + kCell4Slack);
     }
     uint32_t open_c = row_mask(copen);
     while (__ballot(open && open_c != 0u)) {
@@ -949,9 +971,8 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_radial(HprArrays A, HprGrid G
       const int bc = go_c ? __builtin_ctz(open_c) : 0;
       open_c &= open_c - 1u;
       const int32_t Cci = __shfl(Ci, row_base + bc, 64), Ccj = __shfl(Cj, row_base + bc, 64);
-      for (int q4 = 0; q4 < 4; ++q4) {  // the 64 fine cells of the coarse cell, 16 at a time
-        const int fidx = q4 * 16 + rl;
-        const int32_t fi = (go_c ? Cci : 0) * kHprCoarse + (fidx & 7), fj = (go_c ? Ccj : 0) * kHprCoarse + (fidx >> 3);
+      {
+        const int32_t fi = (go_c ? Cci : 0) * kHprMid + (rl & 3), fj = (go_c ? Ccj : 0) * kHprMid + (rl >> 2);
         bool fopen = false;
         int32_t f = 0;
         if (go_c && fi < G.gw && fj < G.gh && !(abs(fi - ci) <= 1 && abs(fj - cj) <= 1)) {
@@ -1001,6 +1022,7 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_radial(HprArrays A, HprGrid G
 constexpr double kTiltMargin = 1.0e-9;  // the trial tilt stays this far (rad) inside every half-plane it knows: n . d <= -1e-9 |D| against a rounding bound of ~1e-13
 constexpr int kTiltMaxSteps = 200;      // half-planes added per search (a dense cluster next to the candidate: 41 seen on C3)
 constexpr int kTiltMaxPasses = 8;       // traversals per search
+constexpr int kTiltWideWindow = 128;    // mid cells: a wider window is walked in coarse cells
 
 // the maximum over the 16 lanes of a row, in every lane of the row (four rotations inside the row)
 __device__ __forceinline__ float row_max16(float v) {
@@ -1124,7 +1146,8 @@ struct TiltRow {
 #endif
 template <bool kDebug>
 __global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_TILT_WPE, PCP_TILT_WPE))) void k_hpr_tilt(
-    HprArrays A, HprGrid G, uint8_t *__restrict__ state, const int32_t *__restrict__ todo, unsigned long long *__restrict__ stats) {
+    HprArrays A, HprGrid G, uint8_t *__restrict__ state, const int32_t *__restrict__ todo, unsigned long long *__restrict__ stats,
+    int32_t wide_window) {
   // Really in LDS: a compiler barrier in front of every group of reads keeps the compiler from forwarding the stores to them
   // (and so from carrying the record in registers after all); not `volatile`, which turns the accesses into flat ones with an
   // address pair per field (60 VGPRs).
@@ -1293,15 +1316,31 @@ __global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_T
       // every other cell the bound cannot clear.  A point in there that moves the plane does not end the sweep: the rest of
       // the window is taken with the new plane (its half-planes are collected in this sweep instead of one per pass) and
       // the next pass starts over -- a plane is only a witness after a whole pass in which it did not move.
+      // The window in mid cells (4 x 4 fine cells: an open one costs ONE row of fine tests) -- unless the plane is tilted so far
+      // that the window is wide: then the upper level is the coarse cells (8 x 8: a quarter of the upper rows, four rows of
+      // fine tests per open cell).  Per row: `big` selects the level.
       Window W;
+      bool big = false;
       {
         TILT_FENCE();
         Search S;
         S.nh = {R.nh[0], R.nh[1], R.nh[2]};
         S.nn_hi = R.nn_hi;
         S.hp_lo = R.hp_lo;
-        W = reach_window(S, G);
+        W = reach_window<kHprMid>(S, G);
+        big = run && W.i0 <= W.i1 && (W.i1 - W.i0 + 1) * (W.j1 - W.j0 + 1) > wide_window;
+        if (big) {  // the same window in coarse cells (a superset: the mid window's corners, halved)
+          W.i0 >>= 1;
+          W.j0 >>= 1;
+          W.i1 = min(W.i1 >> 1, G.cgw - 1);
+          W.j1 = min(W.j1 >> 1, G.cgh - 1);
+        }
       }
+      const int32_t ugw = big ? G.cgw : G.mgw;
+      const int eshift = big ? 3 : 2;                          // log2 of the upper cell's edge in fine cells
+      const int fsteps = big ? 4 : 1;                          // rows of 16 fine cells per upper cell
+      const float4 *upper = big ? A.Cell4 : A.Mid4;
+      const double r_upper = (big ? G.r_coarse : G.r_mid) + kCell4Slack;
       const bool has_window = run && W.i0 <= W.i1 && W.j0 <= W.j1;
       const int32_t ww = has_window ? W.i1 - W.i0 + 1 : 1, wn = has_window ? ww * (W.j1 - W.j0 + 1) : 0;
       if (kDebug) {
@@ -1312,11 +1351,11 @@ __global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_T
         const int32_t t = cbk + rl;
         const int32_t tq = small_div(t, ww);
         const int32_t Ci = W.i0 + (t - tq * ww), Cj = W.j0 + tq;
-        const int32_t C = (run && t < wn) ? Cj * G.cgw + Ci : -1;
+        const int32_t C = (run && t < wn) ? Cj * ugw + Ci : -1;
         bool copen = false;
         if (C >= 0) {
-          const float4 c4 = A.Cell4[C];
-          copen = c4.w > 0.0f && !cleared(c4.x, c4.y, c4.z, c4.w, G.r_coarse + kCell4Slack);
+          const float4 c4 = upper[C];
+          copen = c4.w > 0.0f && !cleared(c4.x, c4.y, c4.z, c4.w, r_upper);
         }
         uint32_t open_c = row_mask(copen);
         while (__ballot(run && open_c != 0u)) {
@@ -1324,13 +1363,13 @@ __global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_T
           const int bc = go_c ? __builtin_ctz(open_c) : 0;
           open_c &= open_c - 1u;
           const int32_t Cci = __shfl(Ci, row_base + bc, 64), Ccj = __shfl(Cj, row_base + bc, 64);
-#pragma unroll 1
-          for (int q4 = 0; q4 < 4; ++q4) {  // the 64 fine cells of the coarse cell, 16 at a time
+          for (int q4 = 0; __ballot(go_c && q4 < fsteps); ++q4) {  // the fine cells of the upper cell, 16 at a time
+            const bool go_q = go_c && q4 < fsteps;
             const int fidx = q4 * 16 + rl;
-            const int32_t fi = (go_c ? Cci : 0) * kHprCoarse + (fidx & 7), fj = (go_c ? Ccj : 0) * kHprCoarse + (fidx >> 3);
+            const int32_t fi = ((go_q ? Cci : 0) << eshift) + (fidx & ((1 << eshift) - 1)), fj = ((go_q ? Ccj : 0) << eshift) + (fidx >> eshift);
             bool fopen = false;
             int32_t f = 0;
-            if (go_c && run && fi < G.gw && fj < G.gh && !(abs(fi - ci) <= 1 && abs(fj - cj) <= 1)) {
+            if (go_q && run && fi < G.gw && fj < G.gh && !(abs(fi - ci) <= 1 && abs(fj - cj) <= 1)) {
               f = fj * G.gw + fi;
               const float4 c4 = A.cell4[f];
               fopen = c4.w > 0.0f && !cleared(c4.x, c4.y, c4.z, c4.w, G.r_fine + kCell4Slack);
@@ -1865,10 +1904,13 @@ int hpr_finish(pcp_context *ctx, HprLane &L, bool timed) {
     G.inv_h = 1.0 / h;
     G.cgw = (G.gw + kHprCoarse - 1) / kHprCoarse;
     G.cgh = (G.gh + kHprCoarse - 1) / kHprCoarse;
+    G.mgw = (G.gw + kHprMid - 1) / kHprMid;
+    G.mgh = (G.gh + kHprMid - 1) / kHprMid;
     // the gnomonic plane z = 1 projects onto the unit sphere without stretching any distance, so half a cell diagonal
     // bounds the chord from the centre direction; the slack covers a coordinate that rounding put on a cell's edge
     G.r_fine = 0.5 * h * std::sqrt(2.0) * (1.0 + 1e-9) + 1e-12;
     G.r_coarse = 0.5 * h * kHprCoarse * std::sqrt(2.0) * (1.0 + 1e-9) + 1e-12;
+    G.r_mid = 0.5 * h * kHprMid * std::sqrt(2.0) * (1.0 + 1e-9) + 1e-12;
     const double ax = std::max(std::fabs(amin), std::fabs(amin + G.gw * h)), ay = std::max(std::fabs(bmin), std::fabs(bmin + G.gh * h));
     G.a_reach = std::sqrt(1.0 + ax * ax + ay * ay) * (1.0 + 1e-9);
     G.rho_max = reinterpret_cast<const double *>(L.stats.p + 28);
@@ -1879,21 +1921,22 @@ int hpr_finish(pcp_context *ctx, HprLane &L, bool timed) {
   // and cursor (n_fine) as int32 | centre directions (3 n_fine), coarse rho / directions (4 n_coarse)
   const size_t nf = static_cast<size_t>(n_fine), nc = static_cast<size_t>(n_coarse);
   const size_t int_words = (2 * nf + 16 + 1) / 2;  // the int32 part, in 8-byte words
-  PCP_HIP_TRY(ctx, L.cells_d.ensure(2 * nf + int_words + 3 * nf + 4 * nc + 2 * nf + 2 * nc + 18));
+  const size_t nm = static_cast<size_t>(G.mgw) * static_cast<size_t>(G.mgh);
+  PCP_HIP_TRY(ctx, L.cells_d.ensure(2 * nf + int_words + 3 * nf + 4 * nc + 2 * nf + 2 * nc + 2 * nm + 18));
   double *crho = L.cells_d.p;
   unsigned long long *crep_all = reinterpret_cast<unsigned long long *>(crho + nf);
   int32_t *cstart = reinterpret_cast<int32_t *>(crho + 2 * nf), *cursor = cstart + n_fine + 2;
   double *cdir = crho + 2 * nf + int_words, *Crho = cdir + 3 * nf, *Cdir = Crho + nc;
   size_t off4 = 5 * nf + int_words + 4 * nc;
   off4 += off4 & 1;  // 16-byte aligned
-  float4 *cell4 = reinterpret_cast<float4 *>(crho + off4), *Cell4 = cell4 + nf;
+  float4 *cell4 = reinterpret_cast<float4 *>(crho + off4), *Cell4 = cell4 + nf, *Mid4 = Cell4 + nc;
   PCP_HIP_TRY(ctx, hipMemsetAsync(crho, 0, (2 * nf + int_words) * sizeof(double), stream));
   // PCP_HPR_QUICK=0 / PCP_HPR_RADIAL=0: without the two passes in front of the search (results identical; the place of a
   // representative needs 26 bits)
   const char *qe = std::getenv("PCP_HPR_QUICK");
   const bool quick = !(qe && qe[0] == '0') && m < (1 << 26);
   unsigned long long *crep = quick ? crep_all : nullptr;
-  HprArrays A{sx, sy, sz, sidx, scell, cstart, crho, cdir, Crho, Cdir, crep, cell4, Cell4};
+  HprArrays A{sx, sy, sz, sidx, scell, cstart, crho, cdir, Crho, Cdir, crep, cell4, Cell4, Mid4};
   // PCP_HPR_FORCE_EXACT=1 (tests): every candidate takes the exact path; read per call
   const char *fe = std::getenv("PCP_HPR_FORCE_EXACT");
   const bool force_exact = fe && fe[0] == '1';
@@ -1905,7 +1948,7 @@ int hpr_finish(pcp_context *ctx, HprLane &L, bool timed) {
                        cell, m, cstart, cursor, sx, sy, sz, sidx, splace, scell,
                        reinterpret_cast<unsigned long long *>(crho), crep);
     hipLaunchKernelGGL(k_hpr_cells, dim3(hpr_blocks(std::max(n_fine, n_coarse))), dim3(kHprBlock), 0, stream, G,
-                       reinterpret_cast<const unsigned long long *>(crho), cdir, Crho, Cdir, stats + 28, cell4, Cell4);
+                       reinterpret_cast<const unsigned long long *>(crho), cdir, Crho, Cdir, stats + 28, cell4, Cell4, Mid4);
     // PCP_HPR_RADIAL=0: every candidate through k_hpr_decide (results identical)
     const char *re = std::getenv("PCP_HPR_RADIAL");
     if (quick && !force_exact)
@@ -1935,7 +1978,8 @@ int hpr_finish(pcp_context *ctx, HprLane &L, bool timed) {
                          L.state.p, m, todo, stats + kStatTilt);
       hipLaunchKernelGGL(std::getenv("PCP_HPR_DEBUG") ? k_hpr_tilt<true> : k_hpr_tilt<false>,
                          dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(m, kHprBlock / 16), kHprTiltGrid))),
-                         dim3(kHprBlock), 0, stream, A, G, L.state.p, todo, stats);
+                         dim3(kHprBlock), 0, stream, A, G, L.state.p, todo, stats,
+                         std::getenv("PCP_TILT_WIDE") ? std::atoi(std::getenv("PCP_TILT_WIDE")) : kTiltWideWindow);
     }
     hipLaunchKernelGGL(k_hpr_list, dim3(static_cast<uint32_t>(div_up(m, kHprBlock * kHprListPer))), dim3(kHprBlock), 0, stream,
                        L.state.p, m, todo, stats + kStatSearch);
