@@ -603,6 +603,7 @@ __device__ __forceinline__ int tetra_contains_filtered(const Vec3d &p, const Vec
 // place in the sorted order (the whole-run bits are addressed by it), index[] its input index (the duplicate rule and the
 // flags of pcp_cull_frame).  The order of the candidates is whatever the appends make it; no result depends on it.
 constexpr int kStatCandidates = 20;  // block 0 of the tallies: number of candidates (a cache line away from the bounds)
+constexpr int kStatSearch = 21;      // block 0 of the tallies: length of the list of the 64-lane searches
 __global__ __launch_bounds__(kHprBlock) void k_hpr_candidates(const float *__restrict__ x, const float *__restrict__ y,
                                                               const float *__restrict__ z, int64_t n, DevCamera cam, DevFrame fr,
                                                               const int32_t *__restrict__ perm, double flip_radius,
@@ -647,7 +648,8 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_candidates(const float *__res
       const double norm = sqrt((X * X + Y * Y) + Z * Z);
       const double s = 2.0 * (flip_radius - norm);
       const double fx = X + (s * X) / norm, fy = Y + (s * Y) / norm, fz = Z + (s * Z) / norm;
-      const double a = fx / fz, b = fy / fz;
+      const double ifz = quick_rcp(fz);  // (the gnomonic coordinates only bin the candidates: no IEEE division needed)
+      const double a = fx * ifz, b = fy * ifz;
       f64[k] = fx;
       f64[stride + k] = fy;
       f64[2 * stride + k] = fz;
@@ -1147,7 +1149,7 @@ struct TiltRow {
 template <bool kDebug>
 __global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_TILT_WPE, PCP_TILT_WPE))) void k_hpr_tilt(
     HprArrays A, HprGrid G, uint8_t *__restrict__ state, const int32_t *__restrict__ todo, unsigned long long *__restrict__ stats,
-    int32_t wide_window) {
+    int32_t wide_window, int32_t *__restrict__ left_over) {
   // Really in LDS: a compiler barrier in front of every group of reads keeps the compiler from forwarding the stores to them
   // (and so from carrying the record in registers after all); not `volatile`, which turns the accesses into flat ones with an
   // address pair per field (60 VGPRs).
@@ -1401,6 +1403,9 @@ __global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_T
       if (out != kStUndecided) {
         state[j] = static_cast<uint8_t>(out);
         atomicAdd(&mine[out], 1ull);
+      } else {
+        // what this pass gives up on (a handful per keyframe) goes straight onto the list of the 64-lane search
+        left_over[atomicAdd(&stats[kStatSearch], 1ull)] = j;
       }
       atomicAdd(&mine[3], static_cast<unsigned long long>(steps + 1));
       atomicAdd(&mine[4], (batches + 3ull) / 4ull);
@@ -1436,7 +1441,6 @@ __global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_T
 // work.  Launched over every candidate, nine wavefronts in ten found theirs decided and left after one load -- and the
 // dispatcher could not refill the slots as fast as they emptied: 1.15 resident wavefronts per SIMD of the 3 the registers
 // allow, vector ALU busy 28 % (profiles/r03m_hpr_pmc.json).  One atomic per 1024 candidates.
-constexpr int kStatSearch = 21;  // block 0 of the tallies: length of the list
 constexpr int kHprListPer = 4;   // candidates per lane
 __global__ __launch_bounds__(kHprBlock) void k_hpr_list(const uint8_t *__restrict__ state, int32_t m, int32_t *__restrict__ list,
                                                         unsigned long long *__restrict__ length) {
@@ -1979,14 +1983,21 @@ int hpr_finish(pcp_context *ctx, HprLane &L, bool timed) {
       hipLaunchKernelGGL(std::getenv("PCP_HPR_DEBUG") ? k_hpr_tilt<true> : k_hpr_tilt<false>,
                          dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(m, kHprBlock / 16), kHprTiltGrid))),
                          dim3(kHprBlock), 0, stream, A, G, L.state.p, todo, stats,
-                         std::getenv("PCP_TILT_WIDE") ? std::atoi(std::getenv("PCP_TILT_WIDE")) : kTiltWideWindow);
+                         std::getenv("PCP_TILT_WIDE") ? std::atoi(std::getenv("PCP_TILT_WIDE")) : kTiltWideWindow,
+                         cell);  // (`cell`, the candidates' cells in arrival order, is free after k_hpr_scatter)
     }
-    hipLaunchKernelGGL(k_hpr_list, dim3(static_cast<uint32_t>(div_up(m, kHprBlock * kHprListPer))), dim3(kHprBlock), 0, stream,
-                       L.state.p, m, todo, stats + kStatSearch);
-    // (after k_hpr_tilt a few dozen candidates are left: a grid of 64 K one-wavefront workgroups that find nothing costs 15 us)
+    // the list of the 64-lane search: what k_hpr_tilt gave up on (it appended them itself: no third listing launch), or, without
+    // that pass, every candidate still undecided
     const bool tilted = !force_exact && !(te && te[0] == '0');
+    const int32_t *decide_todo = cell;
+    if (!tilted) {
+      hipLaunchKernelGGL(k_hpr_list, dim3(static_cast<uint32_t>(div_up(m, kHprBlock * kHprListPer))), dim3(kHprBlock), 0, stream,
+                         L.state.p, m, todo, stats + kStatSearch);
+      decide_todo = todo;
+    }
+    // (after k_hpr_tilt a few dozen candidates are left: a grid of 64 K one-wavefront workgroups that find nothing costs 15 us)
     hipLaunchKernelGGL(k_hpr_decide, dim3(static_cast<uint32_t>(std::min<int64_t>(m, tilted ? 2048 : kHprDecideGrid))), dim3(64),
-                       0, stream, A, G, L.state.p, todo, undecided, stats, force_exact ? 1 : 0);
+                       0, stream, A, G, L.state.p, decide_todo, undecided, stats, force_exact ? 1 : 0);
     if (!dbg_before.empty()) {
       std::vector<uint8_t> after(sm);
       (void)hipMemcpyAsync(after.data(), L.state.p, sm, hipMemcpyDeviceToHost, stream);
