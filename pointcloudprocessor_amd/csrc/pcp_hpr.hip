@@ -1757,6 +1757,12 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_writeback(const uint8_t *__re
   if (k < m) keep[sidx[k]] = state[k] == kStVisible ? 1 : 0;
 }
 
+// zeroes `words` 8-byte words (the per-keyframe clears of the hull: a kernel of the stream it belongs to -- hipMemsetAsync goes
+// through the runtime's own fill path)
+__global__ __launch_bounds__(kHprBlock) void k_hpr_zero(unsigned long long *__restrict__ p, int64_t words) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kHprBlock + threadIdx.x; i < words; i += static_cast<int64_t>(gridDim.x) * kHprBlock) p[i] = 0ull;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // host
 // ------------------------------------------------------------------------------------------------------------------
@@ -1811,7 +1817,8 @@ int hpr_begin(pcp_context *ctx, HprLane &L, hipStream_t stream, bool timed, int3
   double *px = L.f64.p;
   int32_t *cidx = L.index.p, *cplace = cidx + cap;
   unsigned long long *stats = L.stats.p;
-  PCP_HIP_TRY(ctx, hipMemsetAsync(L.stats.p, 0, kStatWords * sizeof(unsigned long long), stream));
+  hipLaunchKernelGGL(k_hpr_zero, dim3(static_cast<uint32_t>(div_up(kStatWords, kHprBlock))), dim3(kHprBlock), 0, stream, L.stats.p,
+                     static_cast<int64_t>(kStatWords));
   const DevFrame &fr = ctx->hframes[static_cast<size_t>(frame)];
   {
     LaunchTimer t(timed ? ctx : nullptr, PCP_K_HPR);
@@ -1934,7 +1941,8 @@ int hpr_finish(pcp_context *ctx, HprLane &L, bool timed) {
   size_t off4 = 5 * nf + int_words + 4 * nc;
   off4 += off4 & 1;  // 16-byte aligned
   float4 *cell4 = reinterpret_cast<float4 *>(crho + off4), *Cell4 = cell4 + nf, *Mid4 = Cell4 + nc;
-  PCP_HIP_TRY(ctx, hipMemsetAsync(crho, 0, (2 * nf + int_words) * sizeof(double), stream));
+  hipLaunchKernelGGL(k_hpr_zero, dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(static_cast<int64_t>(2 * nf + int_words), kHprBlock), 1024))),
+                     dim3(kHprBlock), 0, stream, reinterpret_cast<unsigned long long *>(crho), static_cast<int64_t>(2 * nf + int_words));
   // PCP_HPR_QUICK=0 / PCP_HPR_RADIAL=0: without the two passes in front of the search (results identical; the place of a
   // representative needs 26 bits)
   const char *qe = std::getenv("PCP_HPR_QUICK");
