@@ -100,7 +100,6 @@ struct DevBuf {
 struct HprLane {
   hipStream_t own_stream = nullptr;  // created on first use by the whole-run pass
   hipStream_t stream = nullptr;      // the stream the keyframe in flight was queued on
-  hipEvent_t counted = nullptr;      // (unused since the counts are published to pinned memory by the device)
   unsigned long long seq = 0;        // sequence number of the keyframe whose counts the readback is waited for
   DevBuf<int32_t> index, i32, tiles;
   DevBuf<double> f64, cells_d;
@@ -123,8 +122,6 @@ struct HprLane {
     stats.release();
     if (readback) (void)hipHostFree(readback);
     readback = nullptr;
-    if (counted) (void)hipEventDestroy(counted);
-    counted = nullptr;
     if (own_stream) (void)hipStreamDestroy(own_stream);
     own_stream = nullptr;
   }
