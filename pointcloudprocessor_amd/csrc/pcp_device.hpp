@@ -230,13 +230,33 @@ __device__ __forceinline__ bool roundtrip_sample(const DevCamera &c, const DevFr
 
 // A6 scores: computeOrientationScore hpp:205-220 (B4 reproduced),
 // computeDistanceScore hpp:222-236, final cpp:588; (xc, yc, zc) is p_c (PCP_MATCH_IDENTITY) or p_c' (PCP_MATCH_ROUNDTRIP).
+//
+// The orientation score is f32((cosA + 1) / 2) with cosA = RN(dz / RN(sqrt(sq))) in fp64: a correctly rounded square root and
+// a correctly rounded division (~45 instructions) whose result is rounded to fp32 right away.  c = dz * y, y = 1 / sqrt(sq)
+// from the hardware estimate and one third-order correction (7 instructions), is within 5e-16 of the real quotient, and so is
+// the reference's cosA within 2.3e-16; the two values of (cosA + 1) / 2 differ by less than 1e-15.  When t - 4e-15 and
+// t + 4e-15 round to the same fp32 number the reference's value rounds to it too; otherwise (1.3e-7 of the samples) and for
+// magnitudes outside [2^-100, 2^100] the square root and the division are taken as written.
 __device__ __forceinline__ float final_score(float xc, float yc, float zc, double px, double py, double pz) {
   const double dx = static_cast<double>(xc) - px;
   const double dy = static_cast<double>(yc) - py;
   const double dz = static_cast<double>(zc) - pz;
   const double sq = (dx * dx + dy * dy) + dz * dz;
-  const double cosA = sq > 0.0 ? dz / sqrt(sq) : dz;
-  float o = static_cast<float>((cosA + 1.0) / 2.0);
+  float o;
+  bool settled = false;
+  if (sq > 0x1p-100 && sq < 0x1p100) {
+    const double y0 = __builtin_amdgcn_rsq(sq);
+    const double e = __builtin_fma(-(sq * y0), y0, 1.0);
+    const double y = __builtin_fma(y0 * e, __builtin_fma(0.375, e, 0.5), y0);
+    const double t = (dz * y + 1.0) * 0.5;
+    const float lo = static_cast<float>(t - 4e-15), hi = static_cast<float>(t + 4e-15);
+    o = lo;
+    settled = lo == hi;
+  }
+  if (!settled) {
+    const double cosA = sq > 0.0 ? dz / sqrt(sq) : dz;
+    o = static_cast<float>((cosA + 1.0) / 2.0);
+  }
   o = 0.2f + 0.8f * o;
   const float dist = sqrtf((xc * xc + yc * yc) + zc * zc);
   const float diff = fabsf(dist - 2.0f);
