@@ -2077,11 +2077,10 @@ int hpr_run(pcp_context *ctx, int32_t frame, uint8_t *d_flags, uint32_t *hull_pl
   return hpr_finish(ctx, L, true);
 }
 
-// The hulls of keyframes [f0, f1) into the whole-run bits, `lanes` keyframes in flight: lane k takes keyframes f0 + k,
-// f0 + k + lanes, ... on a stream of its own; the host walks the keyframes in order, finishing the lane's previous
-// keyframe (its count and bounds arrived long ago: the other lanes' work was queued in between) before it begins the next
-// one there.  The lanes start behind everything queued on the context's stream so far (the cleared planes) and the
-// context's stream continues behind the last kernel of every lane.
+// The hulls of keyframes [f0, f1) into the whole-run bits, `lanes` keyframes in flight, each lane on a stream of its own; the
+// host walks the keyframes in order and gives the next one to a lane that is free (see below), finishing the keyframe that
+// lane holds before it begins the next one there.  The lanes start behind everything queued on the context's stream so far
+// (the cleared planes) and the context's stream continues behind the last kernel of every lane.
 int hpr_run_range(pcp_context *ctx, int32_t f0, int32_t f1, int32_t lanes) {
   if (f1 <= f0 || ctx->n == 0) return PCP_OK;
   lanes = std::max(1, std::min<int32_t>(std::min<int32_t>(lanes, pcp_context::kHprMaxLanes), f1 - f0));
@@ -2112,18 +2111,44 @@ int hpr_run_range(pcp_context *ctx, int32_t f0, int32_t f1, int32_t lanes) {
     if (!ctx->hpr_join[k]) PCP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->hpr_join[k], hipEventDisableTiming));
     PCP_HIP_TRY(ctx, hipStreamWaitEvent(L.own_stream, ctx->hpr_fork, 0));
   }
+  // A lane is free for the next keyframe when it holds none, or when the count of the one it holds has arrived -- its stream
+  // is in order, so everything queued there before has run.  The next keyframe goes to the first free lane, looked for from the
+  // one after the lane served last: a keyframe whose searches take milliseconds holds up its own lane only (handing the
+  // keyframes out in turn made the host wait for that lane's next count while the other lanes ran dry).
+  auto arrived = [](const HprLane &L) {
+    return !L.busy || static_cast<const volatile HprCounts *>(L.readback)->seq == L.seq;
+  };
+  int32_t turn = 0;
   for (int32_t f = f0; f < f1 && rc == PCP_OK; ++f) {
-    HprLane &L = ctx->hpr_lane[(f - f0) % lanes];
+    int32_t pick = -1;
+    const auto t_wait = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0; pick < 0 && spins < (1u << 22); ++spins) {
+      for (int32_t k = 0; k < lanes && pick < 0; ++k)
+        if (arrived(ctx->hpr_lane[(turn + k) % lanes])) pick = (turn + k) % lanes;
+      if (pick < 0) __builtin_ia32_pause();
+    }
+    ctx->hpr_host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count();
+    if (pick < 0) pick = turn;  // nothing for a long while: hpr_finish waits for this lane and looks after its stream
+    HprLane &L = ctx->hpr_lane[pick];
+    turn = (pick + 1) % lanes;
     if ((rc = hpr_finish(ctx, L, false)) != PCP_OK) break;
     uint32_t *plane = ctx->hull_bits.p + static_cast<size_t>(f >> 5) * static_cast<size_t>(ctx->n);
     rc = hpr_begin(ctx, L, L.own_stream, false, f, nullptr, plane, 1u << (f & 31));
   }
-  // the keyframes still in flight, oldest first; then the join (also after an error: nothing may stay queued on a lane
-  // whose buffers the next call reuses on another stream)
-  const int32_t count = f1 - f0;
-  for (int32_t k = 0; k < lanes; ++k) {
-    HprLane &L = ctx->hpr_lane[(count + k) % lanes];
-    const int rcl = hpr_finish(ctx, L, false);
+  // the keyframes still in flight, whichever count arrives first; then the join (also after an error: nothing may stay queued
+  // on a lane whose buffers the next call reuses on another stream)
+  for (int32_t left = lanes; left > 0; --left) {
+    int32_t pick = -1;
+    for (uint32_t spins = 0; pick < 0 && spins < (1u << 22); ++spins) {
+      for (int32_t k = 0; k < lanes && pick < 0; ++k)
+        if (ctx->hpr_lane[k].busy && arrived(ctx->hpr_lane[k])) pick = k;
+      if (pick < 0) __builtin_ia32_pause();
+    }
+    if (pick < 0)
+      for (int32_t k = 0; k < lanes && pick < 0; ++k)
+        if (ctx->hpr_lane[k].busy) pick = k;
+    if (pick < 0) break;  // no lane holds a keyframe any more
+    const int rcl = hpr_finish(ctx, ctx->hpr_lane[pick], false);
     if (rc == PCP_OK) rc = rcl;
   }
   for (int32_t k = 0; k < lanes; ++k) {
