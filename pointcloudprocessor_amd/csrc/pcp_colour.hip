@@ -440,6 +440,14 @@ __global__ __launch_bounds__(kBlock) void k_depth_pass(const float *__restrict__
   if (!__ballot(live)) return;
   const float px = live ? x[j] : 0.0f, py = live ? y[j] : 0.0f, pz = live ? z[j] : 0.0f;
   const int64_t tile = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(j >> 6));
+  // The map's atomic of a visit waits for a plain read of the cell (depth_min), and that read for the memory: the read is
+  // issued at the end of the visit and the atomic follows behind the NEXT visit's projection, which needs nothing from memory.
+  unsigned long long *held_at = nullptr;  // the held lane's cell in its keyframe's map (null: this lane holds nothing)
+  unsigned long long held_bits = 0ull, held_seen = 0ull;
+  auto settle_held = [&]() {
+    if (held_at && held_bits < held_seen) atomicMin(held_at, held_bits);
+    held_at = nullptr;
+  };
   for (int32_t w = f0 >> 5; w <= (f1 - 1) >> 5; ++w) {
     const uint32_t in_range = range_bits(w, f0, f1);
     uint32_t todo = in_range;
@@ -457,6 +465,7 @@ __global__ __launch_bounds__(kBlock) void k_depth_pass(const float *__restrict__
       const bool in_map = live && p.cell >= 0;
       const bool cand = live && p.pixel >= 0 && (cam.enable_zbuf ? p.cell >= 0 : p.cell != -1);
       if (__ballot(cand)) seen |= 1u << b;
+      settle_held();
       if (cam.enable_zbuf && __ballot(in_map)) {
         // wave-level combine: lanes of a tile hit a handful of cells, one atomic per cell suffices.  (Reading the
         // cell's current value first and skipping the square root, the combine and the atomic for points that cannot
@@ -477,7 +486,11 @@ __global__ __launch_bounds__(kBlock) void k_depth_pass(const float *__restrict__
         if (in_map) {
           const unsigned long long got = tbl[p.cell & 63];
           // winner of its cell, or a cell that lost its slot to a smaller cell id
-          if (got == key || static_cast<uint32_t>(got >> 32) != static_cast<uint32_t>(p.cell)) depth_min(map, p.cell, sbits);
+          if (got == key || static_cast<uint32_t>(got >> 32) != static_cast<uint32_t>(p.cell)) {
+            held_at = map + p.cell;
+            held_bits = sbits;
+            held_seen = *held_at;  // (possibly stale, hence >= the cell's value: the read filters most atomics)
+          }
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -488,6 +501,7 @@ __global__ __launch_bounds__(kBlock) void k_depth_pass(const float *__restrict__
       *dst = (*dst & ~in_range) | seen;
     }
   }
+  settle_held();
 }
 
 // ---------------------------------------------------------------------------
