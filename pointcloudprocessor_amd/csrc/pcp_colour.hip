@@ -471,7 +471,7 @@ __global__ __launch_bounds__(kBlock) void k_depth_pass(const float *__restrict__
         // cell's current value first and skipping the square root, the combine and the atomic for points that cannot
         // lower it -- s >= m * m -- was slower, 0.79 -> 0.82 ms: some lane of the wavefront nearly always stays, so the
         // wavefront pays for the whole path anyway, plus the extra gather.)
-        unsigned long long *map = depth + static_cast<int64_t>(f - depth_first_frame) * cells;
+        unsigned long long *map = depth + static_cast<uint64_t>(static_cast<uint32_t>(f - depth_first_frame)) * static_cast<uint32_t>(cells);
         // the table elects by the upper half of s's bit pattern (monotone in s): lanes of a cell that tie there (ranges
         // within 1e-6 of each other) all go to the map, which settles them in full precision
         unsigned long long key = ~0ull, sbits = 0ull;
@@ -600,7 +600,8 @@ __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict_
       const bool cand = live && p.pixel >= 0 && (cam.enable_zbuf ? p.cell >= 0 : p.cell != -1) &&
                         ((hull_word >> (f & 31)) & 1u);
       if (cand) {
-        const uint32_t dbits = cam.enable_zbuf ? depth[static_cast<int64_t>(f) * cells + p.cell] : 0u;
+        // (cells and image_px are below 2^31 -- a cell / pixel index is an int32 --, f is not negative: a 32 x 32-bit product)
+        const uint32_t dbits = cam.enable_zbuf ? depth[static_cast<uint64_t>(static_cast<uint32_t>(f)) * static_cast<uint32_t>(cells) + static_cast<uint32_t>(p.cell)] : 0u;
         // A4 keep rule (view_culling.cpp:135-171)
         bool keep = true;
         if (cam.enable_zbuf) keep = keep_by_depth(p.xc, p.yc, p.zc, static_cast<double>(__uint_as_float(dbits)) + cam.slack);
@@ -613,7 +614,7 @@ __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict_
         // with the dependent fetch (enough wavefronts hide the latency).
         if (keep) {
           // texel = B | G<<8 | R<<16 | mask<<24; its low 24 bits are 0x00RRGGBB (PointCloudProcessor.cpp:760-762)
-          const uint32_t texel = images[static_cast<int64_t>(f) * image_px + p.pixel];
+          const uint32_t texel = images[static_cast<uint64_t>(static_cast<uint32_t>(f)) * static_cast<uint32_t>(image_px) + static_cast<uint32_t>(p.pixel)];
           t.insert(final_score(sx, sy, sz, fr.px, fr.py, fr.pz), texel & 0xffffffu, f);
         }
       }
@@ -710,7 +711,13 @@ __global__ __launch_bounds__(kBlock) void k_selftest_div32(DevCamera cam, unsign
   for (uint32_t k = 0; k < 256u; ++k) {
     const float x = __uint_as_float((k << 24) | lane);
     const float a = div_by_ds(cam, x), b = x / cam.ds_f;
-    if (!((a != a && b != b) || __float_as_uint(a) == __float_as_uint(b))) ++wrong;
+    const float ax = fabsf(x);
+    if (ax >= 0x1p-40f && ax <= 0x1p60f) {  // the window in which div_by_ds is the quotient itself
+      if (!((a != a && b != b) || __float_as_uint(a) == __float_as_uint(b))) ++wrong;
+    } else {  // elsewhere: what cull_cell makes of it, along either axis
+      if (cell_of_quotient(a, cam.cull_wf) != cell_of_quotient(b, cam.cull_wf)) ++wrong;
+      if (cell_of_quotient(a, cam.cull_hf) != cell_of_quotient(b, cam.cull_hf)) ++wrong;
+    }
   }
   if (wrong) atomicAdd(bad, static_cast<unsigned long long>(wrong));
 }

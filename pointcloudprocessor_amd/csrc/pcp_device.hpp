@@ -81,12 +81,14 @@ __device__ __forceinline__ void project_uv(const DevCamera &c, float xc, float y
 // Correctly rounded x / ds (fp32) by a constant divisor: with r = RN(1 / ds) precomputed,
 // q0 = RN(x r) is within 2 ulp, one residual correction makes it faithful, and a second one
 // (exact residual by FMA, Markstein's theorem: r correctly rounded, q faithful) returns
-// RN(x / ds).  The residuals are exact only away from the underflow / overflow ranges, hence
-// the magnitude window; everything else (zeros, denormals, huge, non-finite) divides plainly.
-// pcp_selftest_arithmetic() checks the window exhaustively against `/` for the configured ds.
+// RN(x / ds).  The residuals are exact only away from the underflow / overflow ranges: for
+// 2^-40 <= |x| <= 2^60 the result IS RN(x / ds) (pcp_selftest_arithmetic checks every such x against `/`
+// for the configured ds).  Outside that window the value may differ from the quotient, but not what cull_cell
+// makes of it (ds in [2^-20, 2^20], see ds_fast): below the window |x / ds| < 2^-20 and the sequence stays as
+// small -- inside (-1, cull size), truncated to 0; above it |x / ds| > 2^40 and the sequence returns a value beyond
+// +-2^39, an infinity or a NaN -- rejected like the quotient.  The self-test checks that decision for every other x.
 __device__ __forceinline__ float div_by_ds(const DevCamera &c, float x) {
-  const float ax = fabsf(x);
-  if (c.ds_fast && ax >= 0x1p-40f && ax <= 0x1p60f) {
+  if (c.ds_fast) {
     float q = x * c.ds_rcp;
     float e = __builtin_fmaf(-c.ds_f, q, x);
     q = __builtin_fmaf(e, c.ds_rcp, q);
@@ -94,6 +96,11 @@ __device__ __forceinline__ float div_by_ds(const DevCamera &c, float x) {
     return __builtin_fmaf(e, c.ds_rcp, q);
   }
   return x / c.ds_f;
+}
+// what cull_cell makes of a quotient along one axis (`size` = the cull size as fp32): -1 rejected, else the cell coordinate
+__device__ __forceinline__ int32_t cell_of_quotient(float q, float size) {
+  // C truncation: 0 <= (int)t < W  <=>  -1 < t < W (W an integer below 2^24); NaN / inf / out-of-int32 fail
+  return (q > -1.0f) & (q < size) ? static_cast<int32_t>(q) : -1;
 }
 
 // A4 cell: (project(p).cast<float>() / 14).cast<int>(), bounds vs the FULL cull
@@ -109,12 +116,10 @@ __device__ __forceinline__ int32_t cull_cell(const DevCamera &c, double u, doubl
   }
   const float cxf = kShortDiv ? div_by_ds(c, static_cast<float>(u)) : static_cast<float>(u) / c.ds_f;
   const float cyf = kShortDiv ? div_by_ds(c, static_cast<float>(v)) : static_cast<float>(v) / c.ds_f;
-  // C truncation: 0 <= (int)t < W  <=>  -1 < t < W (W an integer below 2^24); NaN / inf / out-of-int32 fail
-  if (!(cxf > -1.0f && cxf < c.cull_wf && cyf > -1.0f && cyf < c.cull_hf)) return -1;
-  const int32_t cx = static_cast<int32_t>(cxf);
-  const int32_t cy = static_cast<int32_t>(cyf);
+  const int32_t cx = cell_of_quotient(cxf, c.cull_wf), cy = cell_of_quotient(cyf, c.cull_hf);
+  if ((cx < 0) | (cy < 0)) return -1;
   // -2 (candidate without a map cell) is only reported when the depth buffer is off
-  return (cx < c.mw && cy < c.mh) ? cy * c.mw + cx : (c.enable_zbuf ? -1 : -2);
+  return (cx < c.mw) & (cy < c.mh) ? cy * c.mw + cx : (c.enable_zbuf ? -1 : -2);
 }
 
 // A5 pixel: static_cast<int>(fx*xd+cx) with C truncation, bounds vs the actual
