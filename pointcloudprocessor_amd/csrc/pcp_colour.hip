@@ -440,6 +440,8 @@ __global__ __launch_bounds__(kBlock) void k_depth_pass(const float *__restrict__
   if (!__ballot(live)) return;
   const float px = live ? x[j] : 0.0f, py = live ? y[j] : 0.0f, pz = live ? z[j] : 0.0f;
   const int64_t tile = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(j >> 6));
+  // every camera coordinate of this wavefront is finite (divide_xy_by_z)
+  const bool finite_sure = cam.frames_bounded != 0 && __all(fabsf(px) <= 0x1p40f && fabsf(py) <= 0x1p40f && fabsf(pz) <= 0x1p40f);
   // The map's atomic of a visit waits for a plain read of the cell (depth_min), and that read for the memory: the read is
   // issued at the end of the visit and the atomic follows behind the NEXT visit's projection, which needs nothing from memory.
   unsigned long long *held_at = nullptr;  // the held lane's cell in its keyframe's map (null: this lane holds nothing)
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(kBlock) void k_depth_pass(const float *__restrict__
       const int32_t f = (w << 5) + b;
       todo &= todo - 1u;
       const DevFrame &fr = frames[f];
-      const Projected p = project_point(cam, fr.w2c, px, py, pz, ((inside >> b) & 1u) == 0u);
+      const Projected p = project_point(cam, fr.w2c, px, py, pz, ((inside >> b) & 1u) == 0u, finite_sure);
       const bool in_map = live && p.cell >= 0;
       const bool cand = live && p.pixel >= 0 && (cam.enable_zbuf ? p.cell >= 0 : p.cell != -1);
       if (__ballot(cand)) seen |= 1u << b;
@@ -574,6 +576,8 @@ __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict_
   if (!__ballot(live)) return;
   const float px = live ? x[j] : 0.0f, py = live ? y[j] : 0.0f, pz = live ? z[j] : 0.0f;
   const int64_t tile = __builtin_amdgcn_readfirstlane(static_cast<int32_t>(j >> 6));
+  // every camera coordinate of this wavefront is finite (divide_xy_by_z)
+  const bool finite_sure = cam.frames_bounded != 0 && __all(fabsf(px) <= 0x1p40f && fabsf(py) <= 0x1p40f && fabsf(pz) <= 0x1p40f);
   Top5 t;
   t.init();
   if ((flags & 1) && live) {
@@ -596,7 +600,7 @@ __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict_
       todo &= todo - 1u;
       const DevFrame &fr = frames[f];
       // the refined masks only keep pairs with a candidate lane: the fp32 rejection test cannot skip the wavefront
-      const Projected p = project_point<false>(cam, fr.w2c, px, py, pz);
+      const Projected p = project_point<false>(cam, fr.w2c, px, py, pz, true, finite_sure);
       const bool cand = live && p.pixel >= 0 && (cam.enable_zbuf ? p.cell >= 0 : p.cell != -1) &&
                         ((hull_word >> (f & 31)) & 1u);
       if (cand) {

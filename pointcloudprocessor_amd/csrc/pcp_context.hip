@@ -945,6 +945,14 @@ int pcp_set_frames(pcp_context *ctx, const pcp_pose *poses, int32_t n_frames, co
       d.norm_bound = std::sqrt(rowmax) * (1.0 + 1e-9);
     }
   }
+  {
+    // camera coordinates of a point below 2^40 in every coordinate are finite under such matrices: the batched passes then
+    // skip the per-visit test for non-finite operands in front of the short division (pcp_device.hpp divide_xy_by_z)
+    bool bounded = true;
+    for (int32_t f = 0; f < n_frames; ++f)
+      for (int k = 0; k < 12; ++k) bounded = bounded && std::fabs(ctx->hframes[static_cast<size_t>(f)].w2c[k]) <= 0x1p40f;
+    ctx->dcam.frames_bounded = bounded ? 1 : 0;
+  }
   PCP_HIP_TRY(ctx, ctx->frames.ensure(static_cast<size_t>(n_frames) + 1));
   if (n_frames > 0)
     PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->frames.p, ctx->hframes.data(), sizeof(DevFrame) * n_frames,

@@ -34,9 +34,11 @@ __device__ __forceinline__ void xform(const float *__restrict__ m, float x, floa
 // difference from the two `/` it replaces is the sign of a zero quotient, which no later
 // operation of the projection can observe.  Non-finite operands take the plain divisions.
 // pcp_selftest_arithmetic() compares both forms on the device.
-__device__ __forceinline__ void divide_xy_by_z(float xc, float yc, float zc, double &xn, double &yn) {
+// finite_sure (wave-uniform): the caller knows the operands are finite -- a point below 2^40 in every coordinate under
+// matrices below 2^40 in every entry (DevCamera::frames_bounded) -- and the test per call is left out.
+__device__ __forceinline__ void divide_xy_by_z(float xc, float yc, float zc, double &xn, double &yn, bool finite_sure = false) {
   const double X = xc, Y = yc, Z = zc;
-  if ((xc - xc) + (yc - yc) + (zc - zc) == 0.0f) {  // all three finite
+  if (finite_sure || (xc - xc) + (yc - yc) + (zc - zc) == 0.0f) {  // all three finite
     double r = __builtin_amdgcn_rcp(Z);
     double e = __builtin_fma(-Z, r, 1.0);
     r = __builtin_fma(r, e, r);
@@ -55,10 +57,14 @@ __device__ __forceinline__ void divide_xy_by_z(float xc, float yc, float zc, dou
 // A3: PinholeProjection::operator() + distort, pinhole.hpp:13-51 (duplicate
 // PointCloudProcessor.hpp:100-123), fp64, left-to-right as written.
 template <bool kShortDiv = true>
-__device__ __forceinline__ void project_uv(const DevCamera &c, float xc, float yc, float zc, double &u, double &v) {
+__device__ __forceinline__ void project_uv(const DevCamera &c, float xc, float yc, float zc, double &u, double &v,
+                                           bool finite_sure = false) {
   double xn, yn;
   if (kShortDiv && c.ds_fast) {
-    divide_xy_by_z(xc, yc, zc, xn, yn);
+    if (finite_sure)  // (two copies of the sequence: a scalar branch instead of a test per lane)
+      divide_xy_by_z(xc, yc, zc, xn, yn, true);
+    else
+      divide_xy_by_z(xc, yc, zc, xn, yn);
   } else {
     xn = static_cast<double>(xc) / static_cast<double>(zc);
     yn = static_cast<double>(yc) / static_cast<double>(zc);
@@ -184,7 +190,7 @@ struct Projected {
 // make the extra code paths cost more registers than the divisions save).
 template <bool kPretest = true, bool kShortDiv = true>
 __device__ __forceinline__ Projected project_point(const DevCamera &c, const float *__restrict__ m, float x, float y,
-                                                   float z, bool pretest_here = true) {
+                                                   float z, bool pretest_here = true, bool finite_sure = false) {
   Projected p;
   xform(m, x, y, z, p.xc, p.yc, p.zc);
   p.cell = -1;
@@ -192,7 +198,7 @@ __device__ __forceinline__ Projected project_point(const DevCamera &c, const flo
   // pretest_here is wave-uniform (a tile-level hint); the rejection test never changes a result
   if (p.zc > 0.0f && !(kPretest && pretest_here && c.pretest && surely_rejected(c, p.xc, p.yc, p.zc))) {
     double u, v;
-    project_uv<kShortDiv>(c, p.xc, p.yc, p.zc, u, v);
+    project_uv<kShortDiv>(c, p.xc, p.yc, p.zc, u, v, finite_sure);
     p.cell = cull_cell<kShortDiv>(c, u, v);
     p.pixel = colour_pixel(c, u, v);
   }
@@ -247,17 +253,14 @@ __device__ __forceinline__ float final_score(float xc, float yc, float zc, doubl
   const double dy = static_cast<double>(yc) - py;
   const double dz = static_cast<double>(zc) - pz;
   const double sq = (dx * dx + dy * dy) + dz * dz;
-  float o;
-  bool settled = false;
-  if (sq > 0x1p-100 && sq < 0x1p100) {
-    const double y0 = __builtin_amdgcn_rsq(sq);
-    const double e = __builtin_fma(-(sq * y0), y0, 1.0);
-    const double y = __builtin_fma(y0 * e, __builtin_fma(0.375, e, 0.5), y0);
-    const double t = (dz * y + 1.0) * 0.5;
-    const float lo = static_cast<float>(t - 4e-15), hi = static_cast<float>(t + 4e-15);
-    o = lo;
-    settled = lo == hi;
-  }
+  // (taken on every lane, accepted where it holds: one rare branch instead of two)
+  const double y0 = __builtin_amdgcn_rsq(sq);
+  const double e = __builtin_fma(-(sq * y0), y0, 1.0);
+  const double y = __builtin_fma(y0 * e, __builtin_fma(0.375, e, 0.5), y0);
+  const double t = (dz * y + 1.0) * 0.5;
+  const float lo = static_cast<float>(t - 4e-15), hi = static_cast<float>(t + 4e-15);
+  float o = lo;
+  const bool settled = (sq > 0x1p-100) & (sq < 0x1p100) & (lo == hi);
   if (!settled) {
     const double cosA = sq > 0.0 ? dz / sqrt(sq) : dz;
     o = static_cast<float>((cosA + 1.0) / 2.0);

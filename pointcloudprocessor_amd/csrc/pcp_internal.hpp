@@ -37,6 +37,7 @@ struct DevCamera {
   double cull_wd, cull_hd;  // cull size as fp64: bounds of hidden_points_removal's (int)u, (int)v rule
   float match_r2;      // f32(1e-5 * 1e-5): radiusSearch(epsilon) squared radius, PointCloudProcessor.cpp:482,571
   int32_t pretest;  // 1: run the conservative fp32 rejection test before the fp64 projection
+  int32_t frames_bounded;  // 1: no entry of any keyframe's w2c exceeds 2^40 in magnitude (pcp_set_frames; see divide_xy_by_z)
   // fp32 copies for the rejection test (pcp_device.hpp surely_rejected): the coefficients (their absolute
   // values are source modifiers of the same registers) and the (u, v) box outside of which BOTH the cell rule
   // and the pixel rule reject, widened by 0.5 px
