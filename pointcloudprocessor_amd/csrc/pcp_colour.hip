@@ -216,8 +216,10 @@ __global__ __launch_bounds__(kBlock) void k_group_mask_flat(const float4 *__rest
                                                             const DevFrame *__restrict__ frames, int32_t n_frames,
                                                             int32_t w0, int32_t w1, int32_t words,
                                                             uint32_t *__restrict__ group_mask,
-                                                            uint32_t *__restrict__ group_inside, int32_t cull_enabled) {
+                                                            uint32_t *__restrict__ group_inside, int32_t cull_enabled,
+                                                            int32_t *__restrict__ zeroed, int32_t n_zeroed) {
   const int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (idx < n_zeroed) zeroed[idx] = 0;  // the counters of the stage's last kernels (sort_tiles_by_work)
   const int32_t nw = w1 - w0;
   const int64_t gw = idx >> 5;  // word of this half wavefront, counted over the launch
   const int64_t group = gw / nw;
@@ -293,58 +295,65 @@ __global__ __launch_bounds__(kBlock) void k_tile_mask_dense(const float4 *__rest
   }
 }
 
-// keyframes a tile will walk in this pass: the scheduling weight of its wavefront
-__global__ __launch_bounds__(kBlock) void k_tile_work(const uint32_t *__restrict__ tile_mask, int64_t tiles, int32_t w0,
-                                                      int32_t w1, int32_t words, int32_t *__restrict__ tile_work) {
-  const int64_t tile = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (tile >= tiles) return;
-  int32_t visits = 0;
-  for (int32_t w = w0; w < w1; ++w) visits += __builtin_popcount(tile_mask[tile * words + w]);
-  tile_work[tile] = visits;
-}
-
 // Longest-work-first order of the tiles (counting sort on the number of keyframes a tile walks, descending).  The
 // batched passes run one wavefront-sized workgroup per tile in this order: the number of keyframes per tile ranges
 // from 0 to several times the mean, and in cloud order the last heavy tiles leave most of the chip idle at the end
 // of a pass (list-scheduling the measured C3 weights: 1.14x the ideal makespan in cloud order with 4-tile
 // workgroups, 1.0003x longest-first with 1-tile workgroups).  Ties are placed in arrival order: any permutation is
 // correct, the results do not depend on it.
+// Two launches (they were four and a memset: each small launch costs its 5 us and a gap): k_tile_work_hist counts a tile's
+// keyframes (the scheduling weight of its wavefront) and bins them; k_work_scatter turns the histogram into offsets itself,
+// in every workgroup, and places the tiles.  The histogram and the bins' cursors are zeroed by the first kernel of the stage
+// (k_group_mask_flat).
 constexpr int kWorkBins = 1024;
 constexpr int kWorkPerBlock = 1024;  // tiles per workgroup of the two sorting kernels (4 per lane)
 // workgroup-local histogram in LDS, then one global atomic per occupied bin (many tiles share a weight: per-tile
 // global atomics on the same few addresses serialise)
-__global__ __launch_bounds__(kBlock) void k_work_hist(const int32_t *__restrict__ work, int64_t tiles,
-                                                     int32_t *__restrict__ hist) {
+__global__ __launch_bounds__(kBlock) void k_tile_work_hist(const uint32_t *__restrict__ tile_mask, int64_t tiles, int32_t w0,
+                                                          int32_t w1, int32_t words, int32_t *__restrict__ tile_work,
+                                                          int32_t *__restrict__ hist) {
   __shared__ int32_t cnt[kWorkBins];
   for (int b = threadIdx.x; b < kWorkBins; b += kBlock) cnt[b] = 0;
   __syncthreads();
   const int64_t base = static_cast<int64_t>(blockIdx.x) * kWorkPerBlock;
   for (int q = 0; q < kWorkPerBlock / kBlock; ++q) {
     const int64_t t = base + q * kBlock + threadIdx.x;
-    if (t < tiles) atomicAdd(&cnt[min(work[t], kWorkBins - 1)], 1);
+    if (t < tiles) {
+      int32_t visits = 0;
+      for (int32_t w = w0; w < w1; ++w) visits += __builtin_popcount(tile_mask[t * words + w]);
+      tile_work[t] = visits;
+      atomicAdd(&cnt[min(visits, kWorkBins - 1)], 1);
+    }
   }
   __syncthreads();
   for (int b = threadIdx.x; b < kWorkBins; b += kBlock)
     if (cnt[b]) atomicAdd(&hist[b], cnt[b]);
 }
-// cursor[b] = number of tiles with more work than bin b (single workgroup of kWorkBins threads)
-__global__ __launch_bounds__(kWorkBins) void k_work_offsets(const int32_t *__restrict__ hist, int32_t *__restrict__ cursor) {
-  __shared__ int32_t sh[kWorkBins];
-  const int b = threadIdx.x;
-  sh[b] = hist[kWorkBins - 1 - b];  // reversed: heaviest bin first
-  __syncthreads();
-  for (int o = 1; o < kWorkBins; o <<= 1) {
-    const int32_t v = b >= o ? sh[b - o] : 0;
-    __syncthreads();
-    sh[b] += v;
-    __syncthreads();
-  }
-  cursor[kWorkBins - 1 - b] = sh[b] - hist[kWorkBins - 1 - b];  // exclusive
-}
+__device__ __forceinline__ int32_t block_exclusive_scan(int32_t v, int32_t *total);
+// hist: the finished histogram; cursor[b] (zeroed): tiles of bin b placed so far
 __global__ __launch_bounds__(kBlock) void k_work_scatter(const int32_t *__restrict__ work, int64_t tiles,
-                                                        int32_t *__restrict__ cursor, int32_t *__restrict__ order) {
-  __shared__ int32_t cnt[kWorkBins];  // local count, then the workgroup's first slot of the bin
+                                                        const int32_t *__restrict__ hist, int32_t *__restrict__ cursor,
+                                                        int32_t *__restrict__ order) {
+  __shared__ int32_t cnt[kWorkBins];    // local count, then the workgroup's first slot of the bin
+  __shared__ int32_t first[kWorkBins];  // number of tiles with more work than the bin
   for (int b = threadIdx.x; b < kWorkBins; b += kBlock) cnt[b] = 0;
+  {
+    // heaviest bin first: thread t takes bins kWorkBins - 1 - 4 t ... kWorkBins - 4 - 4 t
+    constexpr int kPer = kWorkBins / kBlock;
+    int32_t h[kPer], mine = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      h[k] = hist[kWorkBins - 1 - (static_cast<int>(threadIdx.x) * kPer + k)];
+      mine += h[k];
+    }
+    int32_t total = 0;
+    int32_t run = block_exclusive_scan(mine, &total);
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      first[kWorkBins - 1 - (static_cast<int>(threadIdx.x) * kPer + k)] = run;
+      run += h[k];
+    }
+  }
   __syncthreads();
   const int64_t base = static_cast<int64_t>(blockIdx.x) * kWorkPerBlock;
   int32_t bin[kWorkPerBlock / kBlock], rank[kWorkPerBlock / kBlock];
@@ -356,7 +365,7 @@ __global__ __launch_bounds__(kBlock) void k_work_scatter(const int32_t *__restri
   }
   __syncthreads();
   for (int b = threadIdx.x; b < kWorkBins; b += kBlock)
-    if (cnt[b]) cnt[b] = atomicAdd(&cursor[b], cnt[b]);
+    if (cnt[b]) cnt[b] = first[b] + atomicAdd(&cursor[b], cnt[b]);
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < kWorkPerBlock / kBlock; ++q)
@@ -1030,15 +1039,14 @@ int wait_images(pcp_context *ctx, int32_t f0, int32_t f1) {
   return PCP_OK;
 }
 
-// counting sort of the tiles by ctx->tile_work, heaviest first, into `order`
-static int sort_tiles_by_work(pcp_context *ctx, int32_t *order) {
-  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->work_hist.p, 0, 2 * kWorkBins * sizeof(int32_t), ctx->stream));
+// tile_work = the keyframes every tile walks in words [w0, w1) of its mask, and the tiles sorted by it, heaviest first, into
+// `order` (ctx->work_hist: histogram | cursors, zeroed by k_group_mask_flat earlier in the stage)
+static int sort_tiles_by_work(pcp_context *ctx, int32_t w0, int32_t w1, int32_t *order) {
   const uint32_t sort_blocks = static_cast<uint32_t>(div_up(ctx->n_tiles, static_cast<int64_t>(kWorkPerBlock)));
-  hipLaunchKernelGGL(k_work_hist, dim3(sort_blocks), dim3(kBlock), 0, ctx->stream, ctx->tile_work.p, ctx->n_tiles,
-                     ctx->work_hist.p);
-  hipLaunchKernelGGL(k_work_offsets, dim3(1), dim3(kWorkBins), 0, ctx->stream, ctx->work_hist.p, ctx->work_hist.p + kWorkBins);
+  hipLaunchKernelGGL(k_tile_work_hist, dim3(sort_blocks), dim3(kBlock), 0, ctx->stream, ctx->tile_mask.p, ctx->n_tiles, w0, w1,
+                     ctx->mask_words, ctx->tile_work.p, ctx->work_hist.p);
   hipLaunchKernelGGL(k_work_scatter, dim3(sort_blocks), dim3(kBlock), 0, ctx->stream, ctx->tile_work.p, ctx->n_tiles,
-                     ctx->work_hist.p + kWorkBins, order);
+                     ctx->work_hist.p, ctx->work_hist.p + kWorkBins, order);
   PCP_HIP_TRY(ctx, hipGetLastError());
   return PCP_OK;
 }
@@ -1660,16 +1668,15 @@ int pcp_depth_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
       const size_t gwords = static_cast<size_t>(groups) * ctx->mask_words;
       PCP_HIP_TRY(ctx, ctx->group_mask.ensure(2 * gwords + 8));  // keep bits | "wholly inside" bits
       uint32_t *group_inside = ctx->group_mask.p + gwords + 4;
-      hipLaunchKernelGGL(k_group_mask_flat, dim3(blocks_for(groups * (w1 - w0) * 32)), dim3(kBlock), 0, ctx->stream,
-                         tile_sph + ctx->n_tiles, groups, ctx->dcam, ctx->frames.p, ctx->n_frames, w0, w1,
-                         ctx->mask_words, ctx->group_mask.p, group_inside, cull_tiles ? 1 : 0);
+      hipLaunchKernelGGL(k_group_mask_flat, dim3(std::max(blocks_for(groups * (w1 - w0) * 32), blocks_for(2 * kWorkBins))),
+                         dim3(kBlock), 0, ctx->stream, tile_sph + ctx->n_tiles, groups, ctx->dcam, ctx->frames.p, ctx->n_frames,
+                         w0, w1, ctx->mask_words, ctx->group_mask.p, group_inside, cull_tiles ? 1 : 0, ctx->work_hist.p,
+                         2 * kWorkBins);
       hipLaunchKernelGGL(k_tile_mask_dense, dim3(static_cast<uint32_t>(div_up(groups * (w1 - w0), kBlock / 64))), dim3(kBlock),
                          0, ctx->stream, tile_sph, ctx->n_tiles, ctx->dcam, ctx->frames.p, ctx->n_frames, w0, w1,
                          ctx->mask_words, ctx->group_mask.p, group_inside, ctx->tile_mask.p, ctx->tile_inside.p, cull_tiles ? 1 : 0);
-      hipLaunchKernelGGL(k_tile_work, dim3(blocks_for(ctx->n_tiles)), dim3(kBlock), 0, ctx->stream, ctx->tile_mask.p,
-                         ctx->n_tiles, w0, w1, ctx->mask_words, ctx->tile_work.p);
       // longest-work-first order of the tiles for this pass
-      if ((rc = sort_tiles_by_work(ctx, ctx->tile_order.p)) != PCP_OK) return rc;
+      if ((rc = sort_tiles_by_work(ctx, w0, w1, ctx->tile_order.p)) != PCP_OK) return rc;
       ctx->tile_order_live = true;
     }
     {

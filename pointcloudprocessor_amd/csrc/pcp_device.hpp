@@ -174,7 +174,10 @@ __device__ __forceinline__ bool surely_rejected(const DevCamera &c, float xc, fl
   constexpr float kErr = 1.52587890625e-05f;  // 2^-16
   const float eu = kErr * __builtin_fmaf(fabsf(c.qfx), sx, fabsf(c.qcx));
   const float ev = kErr * __builtin_fmaf(fabsf(c.qfy), sy, fabsf(c.qcy));
-  return (u + eu < c.u_lo) | (u - eu > c.u_hi) | (v + ev < c.v_lo) | (v - ev > c.v_hi);
+  // any of u + eu < u_lo, u - eu > u_hi, v + ev < v_lo, v - ev > v_hi -- as the sign of the largest excess (v_max3_f32 drops a
+  // NaN operand as the comparison would be false; four NaNs compare false below)
+  const float over = fmaxf(fmaxf(c.u_lo - (u + eu), (u - eu) - c.u_hi), fmaxf(c.v_lo - (v + ev), (v - ev) - c.v_hi));
+  return over > 0.0f;
 }
 
 struct Projected {
