@@ -1679,6 +1679,39 @@ int pcp_depth_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
       if ((rc = sort_tiles_by_work(ctx, w0, w1, ctx->tile_order.p)) != PCP_OK) return rc;
       ctx->tile_order_live = true;
     }
+    if (ctx->cull.cull_mode == PCP_CULL_HPR) {
+      // hidden_points_removal has no depth map to pass on: its verdict per (point, keyframe) is a bit (pcp_hpr.hip), taken
+      // here keyframe by keyframe; the colour pass reads the bits where the z-buffer routine reads the maps.  The hulls come
+      // BEFORE the depth kernel: their candidate kernels skip the tiles the masks cleared, and the depth kernel is about to
+      // refine the masks by a rule of its own (a candidate lane must also have a colour pixel) which the hull does not share.
+      int rch = ensure_hull_bits(ctx);
+      if (rch != PCP_OK) return rch;
+      // an index shard (PCP_DEPTH_BATCHED) cannot take a hull: its bits come through pcp_hull_flags_import
+      if (!ctx->depth_from_batch) {
+        // first every bit this range is about to write is cleared (whole planes by one memset where all 32 keyframes of the
+        // plane are coming, single bits otherwise), then the hulls -- several keyframes in flight on lanes of their own
+        // (pcp_hpr.hip hpr_run_range; PCP_HPR_LANES, default 4: the keyframes are independent and one keyframe's kernels
+        // leave most of the chip idle), each setting its bit at the sorted place of every hull vertex
+        int32_t clear_until = frame_begin;  // keyframes below this one have their plane zeroed already
+        for (int32_t f = frame_begin; f < frame_end; ++f) {
+          uint32_t *hull_plane = ctx->hull_bits.p + static_cast<size_t>(f >> 5) * static_cast<size_t>(ctx->n);
+          if ((f & 31) == 0 && std::min(f + 32, ctx->n_frames) <= frame_end) {  // all keyframes of this plane are coming
+            PCP_HIP_TRY(ctx, hipMemsetAsync(hull_plane, 0, static_cast<size_t>(ctx->n) * 4, ctx->stream));
+            clear_until = std::min(f + 32, ctx->n_frames);
+          }
+          if (f >= clear_until) {
+            LaunchTimer t(ctx, PCP_K_HPR);
+            hipLaunchKernelGGL(k_hull_clear, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, hull_plane, ctx->n, 1u << (f & 31));
+          }
+        }
+        PCP_HIP_TRY(ctx, hipGetLastError());
+        const char *le = std::getenv("PCP_HPR_LANES");
+        const int32_t lanes = le && le[0] >= '1' && le[0] <= '8' ? le[0] - '0' : 4;
+        if ((rc = hpr_run_range(ctx, frame_begin, frame_end, lanes, ctx->tile_mask.p)) != PCP_OK) return rc;
+        // (the single-keyframe calls read these bits instead of taking the keyframe's hull again)
+        for (int32_t f = frame_begin; f < frame_end; ++f) ctx->hull_valid[static_cast<size_t>(f)] = 1;
+      }
+    }
     {
       LaunchTimer t(ctx, PCP_K_DEPTH);
       hipLaunchKernelGGL(is_common_camera(ctx->dcam) ? k_depth_pass<true> : k_depth_pass<false>,
@@ -1691,37 +1724,6 @@ int pcp_depth_pass(pcp_context *ctx, int32_t frame_begin, int32_t frame_end) {
                            dim3(kBlock), 0, ctx->stream, ctx->depth_sq.p, map_cells,
                            ctx->depth.p + static_cast<int64_t>(frame_begin) * cells);
       PCP_HIP_TRY(ctx, hipGetLastError());
-    }
-  }
-  if (ctx->cull.cull_mode == PCP_CULL_HPR && ctx->n > 0) {
-    // hidden_points_removal has no depth map to pass on: its verdict per (point, keyframe) is a bit (pcp_hpr.hip), taken
-    // here keyframe by keyframe; the colour pass reads the bits where the z-buffer routine reads the maps
-    int rch = ensure_hull_bits(ctx);
-    if (rch != PCP_OK) return rch;
-    // an index shard (PCP_DEPTH_BATCHED) cannot take a hull: its bits come through pcp_hull_flags_import
-    if (!ctx->depth_from_batch) {
-      // first every bit this range is about to write is cleared (whole planes by one memset where all 32 keyframes of the
-      // plane are coming, single bits otherwise), then the hulls -- several keyframes in flight on lanes of their own
-      // (pcp_hpr.hip hpr_run_range; PCP_HPR_LANES, default 4: the keyframes are independent and one keyframe's kernels
-      // leave most of the chip idle), each setting its bit at the sorted place of every hull vertex
-      int32_t clear_until = frame_begin;  // keyframes below this one have their plane zeroed already
-      for (int32_t f = frame_begin; f < frame_end; ++f) {
-        uint32_t *hull_plane = ctx->hull_bits.p + static_cast<size_t>(f >> 5) * static_cast<size_t>(ctx->n);
-        if ((f & 31) == 0 && std::min(f + 32, ctx->n_frames) <= frame_end) {  // all keyframes of this plane are coming
-          PCP_HIP_TRY(ctx, hipMemsetAsync(hull_plane, 0, static_cast<size_t>(ctx->n) * 4, ctx->stream));
-          clear_until = std::min(f + 32, ctx->n_frames);
-        }
-        if (f >= clear_until) {
-          LaunchTimer t(ctx, PCP_K_HPR);
-          hipLaunchKernelGGL(k_hull_clear, dim3(blocks_for(ctx->n)), dim3(kBlock), 0, ctx->stream, hull_plane, ctx->n, 1u << (f & 31));
-        }
-      }
-      PCP_HIP_TRY(ctx, hipGetLastError());
-      const char *le = std::getenv("PCP_HPR_LANES");
-      const int32_t lanes = le && le[0] >= '1' && le[0] <= '8' ? le[0] - '0' : 4;
-      if ((rc = hpr_run_range(ctx, frame_begin, frame_end, lanes)) != PCP_OK) return rc;
-      // (the single-keyframe calls read these bits instead of taking the keyframe's hull again)
-      for (int32_t f = frame_begin; f < frame_end; ++f) ctx->hull_valid[static_cast<size_t>(f)] = 1;
     }
   }
   for (int32_t f = frame_begin; f < frame_end; ++f) ctx->depth_valid[static_cast<size_t>(f)] = 1;

@@ -609,11 +609,18 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_candidates(const float *__res
                                                               const int32_t *__restrict__ perm, double flip_radius,
                                                               int64_t stride, int32_t *__restrict__ index,
                                                               int32_t *__restrict__ place, double *__restrict__ f64,
-                                                              unsigned long long *__restrict__ stats) {
+                                                              unsigned long long *__restrict__ stats,
+                                                              const uint32_t *__restrict__ tile_mask, int32_t mask_words,
+                                                              int32_t frame) {
   const int64_t j = static_cast<int64_t>(blockIdx.x) * kHprBlock + threadIdx.x;
   bool cand = false;
   float xc = 0.0f, yc = 0.0f, zc = 0.0f;
-  if (j < n) {
+  // tile_mask (the whole-run pass; null for a single keyframe): the tile x keyframe masks of the batched passes as the tile
+  // level left them (pcp_colour.hip k_tile_mask_dense) -- a cleared bit says that no point of the tile (this wavefront's 64
+  // points of the sorted copy) can pass the filter in this keyframe, so the wavefront neither reads nor projects them
+  bool visit = j < n;
+  if (tile_mask && visit) visit = ((tile_mask[(j >> 6) * mask_words + (frame >> 5)] >> (frame & 31)) & 1u) != 0u;
+  if (visit) {
     const Projected p = project_point(cam, fr.w2c, x[j], y[j], z[j]);
     cand = p.cell != -1;
     xc = p.xc;
@@ -1790,7 +1797,7 @@ static_assert(kStatWords * sizeof(unsigned long long) <= pcp_context::kReadbackB
 // Two outputs of the keyframe, each optional: d_flags (n bytes on the device, input order: 1 = hull vertex), and the
 // keyframe's bit in a CLEARED plane of the whole-run bits (hull_plane[place in the sorted order] |= bit).
 int hpr_begin(pcp_context *ctx, HprLane &L, hipStream_t stream, bool timed, int32_t frame, uint8_t *d_flags,
-              uint32_t *hull_plane, uint32_t bit) {
+              uint32_t *hull_plane, uint32_t bit, const uint32_t *tile_mask = nullptr) {
   const int64_t n = ctx->n;
   L.busy = false;
   if (n == 0) return PCP_OK;
@@ -1824,7 +1831,7 @@ int hpr_begin(pcp_context *ctx, HprLane &L, hipStream_t stream, bool timed, int3
     LaunchTimer t(timed ? ctx : nullptr, PCP_K_HPR);
     hipLaunchKernelGGL(k_hpr_candidates, dim3(hpr_blocks(n)), dim3(kHprBlock), 0, stream, ctx->sxyz.p, ctx->sxyz.p + plane,
                        ctx->sxyz.p + 2 * plane, n, ctx->dcam, fr, ctx->perm.p, ctx->cull.hpr_flip_radius, static_cast<int64_t>(cap),
-                       cidx, cplace, px, stats);
+                       cidx, cplace, px, stats, tile_mask, ctx->mask_words, frame);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   // the number of candidates (block 0) and the bounds (folded from the copies in words 24..27 of the other blocks) into the
@@ -2081,7 +2088,9 @@ int hpr_run(pcp_context *ctx, int32_t frame, uint8_t *d_flags, uint32_t *hull_pl
 // host walks the keyframes in order and gives the next one to a lane that is free (see below), finishing the keyframe that
 // lane holds before it begins the next one there.  The lanes start behind everything queued on the context's stream so far
 // (the cleared planes) and the context's stream continues behind the last kernel of every lane.
-int hpr_run_range(pcp_context *ctx, int32_t f0, int32_t f1, int32_t lanes) {
+// tile_mask: the batched passes' tile x keyframe masks of these keyframes as the tile level left them (not yet refined by the
+// depth pass, whose rule also asks for a colour pixel), or null.
+int hpr_run_range(pcp_context *ctx, int32_t f0, int32_t f1, int32_t lanes, const uint32_t *tile_mask) {
   if (f1 <= f0 || ctx->n == 0) return PCP_OK;
   lanes = std::max(1, std::min<int32_t>(std::min<int32_t>(lanes, pcp_context::kHprMaxLanes), f1 - f0));
   int rc = PCP_OK;
@@ -2133,7 +2142,7 @@ int hpr_run_range(pcp_context *ctx, int32_t f0, int32_t f1, int32_t lanes) {
     turn = (pick + 1) % lanes;
     if ((rc = hpr_finish(ctx, L, false)) != PCP_OK) break;
     uint32_t *plane = ctx->hull_bits.p + static_cast<size_t>(f >> 5) * static_cast<size_t>(ctx->n);
-    rc = hpr_begin(ctx, L, L.own_stream, false, f, nullptr, plane, 1u << (f & 31));
+    rc = hpr_begin(ctx, L, L.own_stream, false, f, nullptr, plane, 1u << (f & 31), tile_mask);
   }
   // the keyframes still in flight, whichever count arrives first; then the join (also after an error: nothing may stay queued
   // on a lane whose buffers the next call reuses on another stream)

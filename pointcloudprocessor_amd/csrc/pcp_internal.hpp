@@ -329,7 +329,7 @@ int cull_frame_indices(pcp_context *ctx, int32_t frame, int32_t *d_index, int64_
 // in: 1 = candidate; out: 1 = hull vertex
 int hpr_run(pcp_context *ctx, int32_t frame, uint8_t *d_flags, uint32_t *hull_plane, uint32_t bit);
 // the hulls of keyframes [f0, f1) into the (cleared) whole-run bits, `lanes` keyframes in flight on streams of their own
-int hpr_run_range(pcp_context *ctx, int32_t f0, int32_t f1, int32_t lanes);
+int hpr_run_range(pcp_context *ctx, int32_t f0, int32_t f1, int32_t lanes, const uint32_t *tile_mask = nullptr);
 
 inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
