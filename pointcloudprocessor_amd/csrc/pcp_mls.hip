@@ -1319,18 +1319,22 @@ __global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(PCP_SE
     return 0;
   };
   // The candidate coordinates come through buffer descriptors (one per coordinate plane: uniform base in SGPRs, 32-bit
-  // byte offset per lane; a 16-byte load needs dword alignment only).  The planes hold n < 2^30 floats.
+  // byte offset per lane; a 16-byte load needs dword alignment only).  The three planes end below 2^32 bytes.
+  // ONE descriptor over the three planes (x first, z last: one allocation, its end below 2^32 bytes), the y and z planes through
+  // the instruction's scalar offset, which the range check includes: three descriptors did not stay in the scalar registers, and
+  // half of each was rebuilt in front of every load.  A load that runs past the end of the x or y plane reads the start of the
+  // next one, past the z plane zeros: such candidates are masked by their x (the ragged end below).
   const uint32_t plane_bytes = static_cast<uint32_t>(n) * 4u;
-  const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sx), 0, plane_bytes, 0x00020000);
-  const auto ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sy), 0, plane_bytes, 0x00020000);
-  const auto rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sz), 0, plane_bytes, 0x00020000);
+  const uint32_t ry = static_cast<uint32_t>(reinterpret_cast<const char *>(sy) - reinterpret_cast<const char *>(sx));
+  const uint32_t rz = static_cast<uint32_t>(reinterpret_cast<const char *>(sz) - reinterpret_cast<const char *>(sx));
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sx), 0, rz + plane_bytes, 0x00020000);
   const sel_v2f qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
   auto d2_of = [&](sel_v2f px, sel_v2f py, sel_v2f pz) {
     const sel_v2f dx = px - qx2, dy = py - qy2, dz = pz - qz2;
     return (dx * dx + dy * dy) + dz * dz;
   };
-  auto load4 = [&](decltype(rx) r, uint32_t q) {
-    const sel_v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, q * 4u, 0, 0);
+  auto load4 = [&](uint32_t plane, uint32_t q) {
+    const sel_v4u v = __builtin_amdgcn_raw_buffer_load_b128(rx, q * 4u, plane, 0);
     return sel_v4f{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
   };
   // squared distances of this lane's candidates, four per call: four(d of candidates 0 1, d of candidates 2 3)
@@ -1342,13 +1346,13 @@ __global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(PCP_SE
         const uint32_t e = static_cast<uint32_t>(cell_start(g, start, zz, yy, x1 + 1));
         if (q + 4 <= e) {
           // the next four candidates are on their way while these four are tested
-          sel_v4f X = load4(rx, q), Y = load4(ry, q), Z = load4(rz, q);
+          sel_v4f X = load4(0u, q), Y = load4(ry, q), Z = load4(rz, q);
           for (;;) {
             q += 4;
             const bool more = q + 4 <= e;
             sel_v4f Xn = X, Yn = Y, Zn = Z;
             if (more) {
-              Xn = load4(rx, q);
+              Xn = load4(0u, q);
               Yn = load4(ry, q);
               Zn = load4(rz, q);
             }
@@ -1362,7 +1366,7 @@ __global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(PCP_SE
         }
         if (q < e) {  // 1..3 candidates left: the others at infinity (loads past the planes' end read zeros)
           const uint32_t rem = e - q;
-          const sel_v4f X = load4(rx, q), Y = load4(ry, q), Z = load4(rz, q);
+          const sel_v4f X = load4(0u, q), Y = load4(ry, q), Z = load4(rz, q);
           four(d2_of(sel_v2f{X[0], rem > 1 ? X[1] : INFINITY}, sel_v2f{Y[0], Y[1]}, sel_v2f{Z[0], Z[1]}),
                d2_of(sel_v2f{rem > 2 ? X[2] : INFINITY, INFINITY}, sel_v2f{Y[2], Y[3]}, sel_v2f{Z[2], Z[3]}));
         }
@@ -2727,9 +2731,10 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
   const size_t heap_lds = static_cast<size_t>(mean_k + 1) * kSorBlock * sizeof(float);
   const char *heap_only = std::getenv("PCP_SOR_HEAP_ONLY");
   // the selection kernel addresses the coordinate planes through buffer descriptors (32-bit byte offsets)
-  const bool use_select = (!(heap_only && heap_only[0] == '1') || !whole) && n < (int64_t(1) << 30);
+  // (the three planes of ctx->g_xyz are one allocation which one buffer descriptor must span: fewer than 2^32 bytes)
+  const bool use_select = (!(heap_only && heap_only[0] == '1') || !whole) && 2 * static_cast<int64_t>(plane) + n < (int64_t(1) << 30);
   if (!whole && !(use_select && mean_k + 1 <= 250))
-    return set_error(ctx, PCP_ERR_INVALID, "pcp_sor_partial: slabs need mean_k <= 249 and fewer than 2^30 points");
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_sor_partial: slabs need mean_k <= 249 and fewer than 3.5e8 points");
   if (use_select && mean_k + 1 <= 250) {
     // selection kernel for every point, heap kernel for the few it flags (sparse spots, borders of a surface)
     PCP_HIP_TRY(ctx, ctx->s_cell.ensure(sn + 8));
