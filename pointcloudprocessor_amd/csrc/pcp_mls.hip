@@ -1268,6 +1268,9 @@ typedef uint32_t sel_v4u __attribute__((ext_vector_type(4)));
 #ifndef PCP_SEL_WPE
 #define PCP_SEL_WPE 6
 #endif
+// kOneDescriptor: the three coordinate planes end below 2^32 bytes (n below ~ 3.5e8) and are read through one buffer descriptor;
+// else (up to 2^30 points: the dilated clouds of VOXEL_GRID_DILATION) through one descriptor per plane.
+template <bool kOneDescriptor>
 __global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(PCP_SEL_WPE, 8))) void k_sor_select(const float *__restrict__ sx, const float *__restrict__ sy,
                                                          const float *__restrict__ sz,
                                                          const int32_t *__restrict__ order,
@@ -1319,22 +1322,31 @@ __global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(PCP_SE
     return 0;
   };
   // The candidate coordinates come through buffer descriptors (one per coordinate plane: uniform base in SGPRs, 32-bit
-  // byte offset per lane; a 16-byte load needs dword alignment only).  The three planes end below 2^32 bytes.
+  // byte offset per lane; a 16-byte load needs dword alignment only).  The planes hold n < 2^30 floats.
   // ONE descriptor over the three planes (x first, z last: one allocation, its end below 2^32 bytes), the y and z planes through
   // the instruction's scalar offset, which the range check includes: three descriptors did not stay in the scalar registers, and
   // half of each was rebuilt in front of every load.  A load that runs past the end of the x or y plane reads the start of the
   // next one, past the z plane zeros: such candidates are masked by their x (the ragged end below).
   const uint32_t plane_bytes = static_cast<uint32_t>(n) * 4u;
-  const uint32_t ry = static_cast<uint32_t>(reinterpret_cast<const char *>(sy) - reinterpret_cast<const char *>(sx));
-  const uint32_t rz = static_cast<uint32_t>(reinterpret_cast<const char *>(sz) - reinterpret_cast<const char *>(sx));
-  const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sx), 0, rz + plane_bytes, 0x00020000);
+  const uint32_t ry = kOneDescriptor ? static_cast<uint32_t>(reinterpret_cast<const char *>(sy) - reinterpret_cast<const char *>(sx)) : 1u;
+  const uint32_t rz = kOneDescriptor ? static_cast<uint32_t>(reinterpret_cast<const char *>(sz) - reinterpret_cast<const char *>(sx)) : 2u;
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sx), 0, kOneDescriptor ? rz + plane_bytes : plane_bytes, 0x00020000);
+  const auto dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sy), 0, plane_bytes, 0x00020000);  // (!kOneDescriptor)
+  const auto dz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sz), 0, plane_bytes, 0x00020000);
   const sel_v2f qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
   auto d2_of = [&](sel_v2f px, sel_v2f py, sel_v2f pz) {
     const sel_v2f dx = px - qx2, dy = py - qy2, dz = pz - qz2;
     return (dx * dx + dy * dy) + dz * dz;
   };
+  // plane: 0u (x), ry, rz
   auto load4 = [&](uint32_t plane, uint32_t q) {
-    const sel_v4u v = __builtin_amdgcn_raw_buffer_load_b128(rx, q * 4u, plane, 0);
+    sel_v4u v;
+    if constexpr (kOneDescriptor)
+      v = __builtin_amdgcn_raw_buffer_load_b128(rx, q * 4u, plane, 0);
+    else
+      v = plane == 0u ? __builtin_amdgcn_raw_buffer_load_b128(rx, q * 4u, 0, 0)
+                      : (plane == 1u ? __builtin_amdgcn_raw_buffer_load_b128(dy, q * 4u, 0, 0)
+                                     : __builtin_amdgcn_raw_buffer_load_b128(dz, q * 4u, 0, 0));
     return sel_v4f{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
   };
   // squared distances of this lane's candidates, four per call: four(d of candidates 0 1, d of candidates 2 3)
@@ -2732,16 +2744,20 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
   const char *heap_only = std::getenv("PCP_SOR_HEAP_ONLY");
   // the selection kernel addresses the coordinate planes through buffer descriptors (32-bit byte offsets)
   // (the three planes of ctx->g_xyz are one allocation which one buffer descriptor must span: fewer than 2^32 bytes)
-  const bool use_select = (!(heap_only && heap_only[0] == '1') || !whole) && 2 * static_cast<int64_t>(plane) + n < (int64_t(1) << 30);
+  const bool use_select = (!(heap_only && heap_only[0] == '1') || !whole) && n < (int64_t(1) << 30);
+  // (PCP_SOR_THREE_DESCRIPTORS=1: the form of the large clouds on any cloud -- the tests compare the two)
+  const char *three = std::getenv("PCP_SOR_THREE_DESCRIPTORS");
+  const bool one_descriptor = 2 * static_cast<int64_t>(plane) + n < (int64_t(1) << 30) && !(three && three[0] == '1');
   if (!whole && !(use_select && mean_k + 1 <= 250))
-    return set_error(ctx, PCP_ERR_INVALID, "pcp_sor_partial: slabs need mean_k <= 249 and fewer than 3.5e8 points");
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_sor_partial: slabs need mean_k <= 249 and fewer than 2^30 points");
   if (use_select && mean_k + 1 <= 250) {
     // selection kernel for every point, heap kernel for the few it flags (sparse spots, borders of a surface)
     PCP_HIP_TRY(ctx, ctx->s_cell.ensure(sn + 8));
     if (!whole) PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->m_flag.p, 0, sn, ctx->stream));  // nothing to redo outside the slab
     if (q_end > q_begin) {
       LaunchTimer t(ctx, PCP_K_SOR);
-      hipLaunchKernelGGL(k_sor_select, dim3(static_cast<uint32_t>(div_up(q_end - q_begin, kSelWave))), dim3(kSelWave), 0, ctx->stream,
+      hipLaunchKernelGGL(one_descriptor ? k_sor_select<true> : k_sor_select<false>,
+                         dim3(static_cast<uint32_t>(div_up(q_end - q_begin, kSelWave))), dim3(kSelWave), 0, ctx->stream,
                          ctx->g_xyz.p, ctx->g_xyz.p + plane, ctx->g_xyz.p + 2 * plane, ctx->g_order.p, remap,
                          ctx->g_start.p, n, g, mean_k, dist, ctx->m_flag.p, q_begin, q_end);
       PCP_HIP_TRY(ctx, hipGetLastError());

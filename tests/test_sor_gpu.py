@@ -165,6 +165,23 @@ def test_sor_dense_and_sparse_grid_forms(gpu_ctx_factory, oracle, monkeypatch, f
     _check(ctx, oracle, pts[:, 0].copy(), pts[:, 1].copy(), pts[:, 2].copy(), 60, 0.7)
 
 
+@pytest.mark.parametrize("three", ["0", "1"])
+def test_sor_selection_reads_the_planes_through_one_descriptor_or_three(gpu_ctx_factory, oracle, monkeypatch, three):
+    """k_sor_select reads the three coordinate planes through ONE buffer descriptor while they end below 2^32 bytes, and
+    through one descriptor per plane above (the dilated clouds of VOXEL_GRID_DILATION: up to 2^30 points);
+    PCP_SOR_THREE_DESCRIPTORS=1 takes the second form on any cloud.  A size that is no multiple of four, so that the last
+    loads run past the planes' ends."""
+    monkeypatch.setenv("PCP_SOR_THREE_DESCRIPTORS", three)
+    rng = np.random.default_rng(21)
+    n = 50003
+    a = rng.uniform(-0.5, 0.5, (n, 2))
+    pts = np.stack([a[:, 0], a[:, 1], 0.05 * np.sin(7 * a[:, 0] * a[:, 1]) + rng.normal(0, 1e-3, n)], 1)
+    pts = np.concatenate([pts, rng.uniform(-0.6, 0.6, (150, 3))]).astype(np.float32)
+    ctx = gpu_ctx_factory()
+    _check(ctx, oracle, pts[:, 0].copy(), pts[:, 1].copy(), pts[:, 2].copy(), 60, 0.7)
+    assert ctx.sor_redo_fraction() < 0.5  # the selection kernel did the work
+
+
 def test_sor_stray_points_far_from_the_cloud(gpu_ctx_factory, oracle):
     """Points hundreds of metres from a 1 m sheet: the bounding box needs 10^12 cells at the wanted edge (sparse form,
     coarser cells), and a stray point's block of cells would have to grow over millions of empty rows -- it reads every
