@@ -292,6 +292,37 @@ def test_non_finite_points_are_rejected_not_fatal(gpu_ctx_factory, oracle, small
     ctx.close()
 
 
+@pytest.mark.parametrize("far", ["pose", "points"])
+def test_huge_finite_operands_keep_the_general_division(gpu_ctx_factory, oracle, small_scene, far):
+    """The batched passes leave out the per-visit test for non-finite camera coordinates when every coordinate of a tile's points
+    and every entry of every keyframe's matrix is below 2^40 (DevCamera::frames_bounded, pcp_device.hpp divide_xy_by_z).  A pose
+    translated by 1e30 switches that off for the whole run; points at 1e12 (just above 2^40) for their tiles.  Same colours as
+    the oracle either way."""
+    from pointcloudprocessor_amd import capi
+
+    x, y, z = (small_scene[k].copy() for k in "xyz")
+    poses = [list(p) for p in small_scene["poses"]]
+    if far == "pose":
+        poses[1][0] = 1.0e30
+        poses[1][2] = -3.0e29
+    else:
+        x[100:164] = 1.2e12
+        z[7000] = -1.15e12
+        y[9000] = 1.0e12  # below 2^40: stays on the short path, far outside every image
+    cd = small_scene["cam"]
+    ctx = gpu_ctx_factory()
+    ctx.set_camera(cam_struct(capi, cd))
+    ctx.upload_cloud(x, y, z)
+    ctx.set_frames(poses)
+    for f, im in enumerate(small_scene["images"]):
+        ctx.upload_image(f, im)
+    got = ctx.colorize()
+    ref = oracle.colorize(cam_struct(oracle, cd), oracle.default_cull_params(), x, y, z, poses, small_scene["images"])
+    assert np.array_equal(got["rgb"], ref["rgb"]) and np.array_equal(got["has"], ref["has"])
+    assert got["has"].sum() > 100
+    ctx.close()
+
+
 @pytest.mark.parametrize("stride", [12, 16, 32, 13])
 def test_upload_aos_equals_soa(gpu_ctx_factory, small_scene, stride):
     """pcl::PointXYZI records (x y z first, any stride) uploaded as they are give the same cloud as SoA arrays;
