@@ -106,7 +106,7 @@ __device__ __forceinline__ float div_by_ds(const DevCamera &c, float x) {
 // what cull_cell makes of a quotient along one axis (`size` = the cull size as fp32): -1 rejected, else the cell coordinate
 __device__ __forceinline__ int32_t cell_of_quotient(float q, float size) {
   // C truncation: 0 <= (int)t < W  <=>  -1 < t < W (W an integer below 2^24); NaN / inf / out-of-int32 fail
-  return (q > -1.0f) & (q < size) ? static_cast<int32_t>(q) : -1;
+  return ((q > -1.0f) & (q < size)) ? static_cast<int32_t>(q) : -1;
 }
 
 // A4 cell: (project(p).cast<float>() / 14).cast<int>(), bounds vs the FULL cull
@@ -125,7 +125,7 @@ __device__ __forceinline__ int32_t cull_cell(const DevCamera &c, double u, doubl
   const int32_t cx = cell_of_quotient(cxf, c.cull_wf), cy = cell_of_quotient(cyf, c.cull_hf);
   if ((cx < 0) | (cy < 0)) return -1;
   // -2 (candidate without a map cell) is only reported when the depth buffer is off
-  return (cx < c.mw) & (cy < c.mh) ? cy * c.mw + cx : (c.enable_zbuf ? -1 : -2);
+  return ((cx < c.mw) & (cy < c.mh)) ? cy * c.mw + cx : (c.enable_zbuf ? -1 : -2);
 }
 
 // A5 pixel: static_cast<int>(fx*xd+cx) with C truncation, bounds vs the actual
