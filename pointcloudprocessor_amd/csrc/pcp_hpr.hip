@@ -1168,7 +1168,7 @@ __global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_T
   const int32_t count = static_cast<int32_t>(stats[kStatTilt]);
   const int32_t rows_total = static_cast<int32_t>(gridDim.x) * (kHprBlock / 16);
   auto row_mask = [&](bool b) -> uint32_t { return static_cast<uint32_t>((__ballot(b) >> row_base) & 0xffffull); };
-  const int32_t n_coarse = G.cgw * G.cgh, n_fine = G.gw * G.gh;
+  const int32_t n_coarse = G.cgw * G.cgh;
   for (int32_t u0 = static_cast<int32_t>(blockIdx.x) * (kHprBlock / 16) + static_cast<int32_t>(threadIdx.x >> 6) * 4; u0 < count;
        u0 += rows_total) {  // (u0: the first row of this wavefront; uniform over the wavefront)
     const int32_t u = u0 + (lane >> 4);
