@@ -227,6 +227,23 @@ __global__ __launch_bounds__(kMB) void k_grid_order(const float *__restrict__ x,
   sxyz[2 * plane + j] = z[i];
 }
 
+// 1 / x and 1 / sqrt(x) in fp64 to an ulp or two: the hardware estimate and Newton steps, without the range scaling, the exact
+// residual correction and the special-case fix-ups of the IEEE sequences (~8 instead of ~28 instructions).  For the fit's own
+// arithmetic (tolerance-gated against the oracle: 3 um, 1e-4), whose operands are covariances, lengths and pivots -- normal
+// numbers; zero, negative and non-finite arguments give infinities / NaNs that the callers' guards (ok, isfinite) catch as before.
+__device__ __forceinline__ double mls_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ double mls_rsqrt(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = __builtin_fma(-(x * y), y, 1.0);
+  return __builtin_fma(y * e, __builtin_fma(0.375, e, 0.5), y);
+}
+
 // ---- pcl::eigen33 smallest eigenpair (common/impl/eigen.hpp) [upstream] --------
 __device__ __forceinline__ void roots2(double b, double c, double &r0, double &r1, double &r2) {
   r0 = 0.0;
@@ -247,8 +264,9 @@ __device__ __forceinline__ void swap2(double &a, double &b) {
 __device__ __forceinline__ void smallest_eigenpair(const double m[6] /* xx xy xz yy yz zz */, double &ev, double n[3]) {
   double scale = fmax(fmax(fmax(fabs(m[0]), fabs(m[1])), fmax(fabs(m[2]), fabs(m[3]))), fmax(fabs(m[4]), fabs(m[5])));
   if (scale <= DBL_MIN) scale = 1.0;
-  const double a00 = m[0] / scale, a01 = m[1] / scale, a02 = m[2] / scale, a11 = m[3] / scale, a12 = m[4] / scale,
-               a22 = m[5] / scale;
+  const double inv_scale = mls_rcp(scale);
+  const double a00 = m[0] * inv_scale, a01 = m[1] * inv_scale, a02 = m[2] * inv_scale, a11 = m[3] * inv_scale,
+               a12 = m[4] * inv_scale, a22 = m[5] * inv_scale;
   const double c0 = a00 * a11 * a22 + 2.0 * a01 * a02 * a12 - a00 * a12 * a12 - a11 * a02 * a02 - a22 * a01 * a01;
   const double c1 = a00 * a11 - a01 * a01 + a00 * a22 - a02 * a02 + a11 * a22 - a12 * a12;
   const double c2 = a00 + a11 + a22;
@@ -293,10 +311,10 @@ __device__ __forceinline__ void smallest_eigenpair(const double m[6] /* xx xy xz
   if (l2 > l) {
     vx = k2x; vy = k2y; vz = k2z; l = l2;
   }
-  const double len = sqrt(l);
-  n[0] = vx / len;
-  n[1] = vy / len;
-  n[2] = vz / len;
+  const double inv_len = mls_rsqrt(l);  // (l == 0: infinity, the components NaN as with the division by zero)
+  n[0] = vx * inv_len;
+  n[1] = vy * inv_len;
+  n[2] = vz * inv_len;
 }
 
 // doubles kept per input point for the upsampling stage (MLSResult)
@@ -514,7 +532,7 @@ __global__ __launch_bounds__(kFitBlock) void k_mls_fit(MlsArgs a) {
     a.flag[i] = 0;
     return;
   }
-  const double invK = 1.0 / static_cast<double>(K);
+  const double invK = mls_rcp(static_cast<double>(K));
   const double mx = s1x * invK, my = s1y * invK, mz = s1z * invK;  // centroid - q
   double C[6];
   C[0] = sxx - s1x * mx;
@@ -547,10 +565,10 @@ __global__ __launch_bounds__(kFitBlock) void k_mls_fit(MlsArgs a) {
   // Darboux frame: v = n.unitOrthogonal(), u = n x v (Eigen OrthoMethods.h)
   double vx, vy, vz;
   if (!(fabs(nrm[0]) <= fabs(nrm[2]) * 1e-12) || !(fabs(nrm[1]) <= fabs(nrm[2]) * 1e-12)) {
-    const double inv = 1.0 / sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1]);
+    const double inv = mls_rsqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1]);
     vx = -nrm[1] * inv; vy = nrm[0] * inv; vz = 0.0;
   } else {
-    const double inv = 1.0 / sqrt(nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+    const double inv = mls_rsqrt(nrm[1] * nrm[1] + nrm[2] * nrm[2]);
     vx = 0.0; vy = -nrm[2] * inv; vz = nrm[1] * inv;
   }
   const double ux = nrm[1] * vz - nrm[2] * vy, uy = nrm[2] * vx - nrm[0] * vz, uz = nrm[0] * vy - nrm[1] * vx;
@@ -598,19 +616,19 @@ __global__ __launch_bounds__(kFitBlock) void k_mls_fit(MlsArgs a) {
     double d;
     // the divisions by the six pivots are multiplications by their reciprocals (27 -> 6 divisions)
     double i0, i1, i2, i3, i4, i5;
-    d = A00; ok = ok && d > 0.0; L00 = sqrt(d); i0 = 1.0 / L00;
+    d = A00; ok = ok && d > 0.0; i0 = mls_rsqrt(d); L00 = d * i0;
     L10 = A01 * i0; L20 = A02 * i0; L30 = A03 * i0; L40 = A04 * i0; L50 = A05 * i0;
-    d = A11 - L10 * L10; ok = ok && d > 0.0; L11 = sqrt(d); i1 = 1.0 / L11;
+    d = A11 - L10 * L10; ok = ok && d > 0.0; i1 = mls_rsqrt(d); L11 = d * i1;
     L21 = (A12 - L20 * L10) * i1; L31 = (A13 - L30 * L10) * i1; L41 = (A14 - L40 * L10) * i1;
     L51 = (A15 - L50 * L10) * i1;
-    d = A22 - L20 * L20 - L21 * L21; ok = ok && d > 0.0; L22 = sqrt(d); i2 = 1.0 / L22;
+    d = A22 - L20 * L20 - L21 * L21; ok = ok && d > 0.0; i2 = mls_rsqrt(d); L22 = d * i2;
     L32 = (A23 - L30 * L20 - L31 * L21) * i2; L42 = (A24 - L40 * L20 - L41 * L21) * i2;
     L52 = (A25 - L50 * L20 - L51 * L21) * i2;
-    d = A33 - L30 * L30 - L31 * L31 - L32 * L32; ok = ok && d > 0.0; L33 = sqrt(d); i3 = 1.0 / L33;
+    d = A33 - L30 * L30 - L31 * L31 - L32 * L32; ok = ok && d > 0.0; i3 = mls_rsqrt(d); L33 = d * i3;
     L43 = (A34 - L40 * L30 - L41 * L31 - L42 * L32) * i3; L53 = (A35 - L50 * L30 - L51 * L31 - L52 * L32) * i3;
-    d = A44 - L40 * L40 - L41 * L41 - L42 * L42 - L43 * L43; ok = ok && d > 0.0; L44 = sqrt(d); i4 = 1.0 / L44;
+    d = A44 - L40 * L40 - L41 * L41 - L42 * L42 - L43 * L43; ok = ok && d > 0.0; i4 = mls_rsqrt(d); L44 = d * i4;
     L54 = (A45 - L50 * L40 - L51 * L41 - L52 * L42 - L53 * L43) * i4;
-    d = A55 - L50 * L50 - L51 * L51 - L52 * L52 - L53 * L53 - L54 * L54; ok = ok && d > 0.0; L55 = sqrt(d); i5 = 1.0 / L55;
+    d = A55 - L50 * L50 - L51 * L51 - L52 * L52 - L53 * L53 - L54 * L54; ok = ok && d > 0.0; i5 = mls_rsqrt(d); L55 = d * i5;
     if (ok) {
       const double y0_ = b0 * i0;
       const double y1_ = (b1 - L10 * y0_) * i1;
@@ -638,9 +656,10 @@ __global__ __launch_bounds__(kFitBlock) void k_mls_fit(MlsArgs a) {
     nx = nrm[0] - c[3] * ux - c[1] * vx;
     ny = nrm[1] - c[3] * uy - c[1] * vy;
     nz = nrm[2] - c[3] * uz - c[1] * vz;
-    const double l = sqrt((nx * nx + ny * ny) + nz * nz);
-    if (l > 0.0) {
-      nx /= l; ny /= l; nz /= l;
+    const double l2 = (nx * nx + ny * ny) + nz * nz;
+    if (l2 > 0.0) {
+      const double il = mls_rsqrt(l2);
+      nx *= il; ny *= il; nz *= il;
     }
   }
   out[0] = static_cast<float>(ox); out[1] = static_cast<float>(oy); out[2] = static_cast<float>(oz);
