@@ -324,6 +324,18 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             return float(t.item())
 
+        def all_ranks_ok(local_error):
+            """A collective verdict on a rank-local set-up phase: every rank learns whether ANY rank failed, so that the ranks
+            leave a leg together instead of one of them recording its error while the others block in the leg's next collective."""
+            t = torch.tensor([0 if local_error is None else 1], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return int(t.item()) == 0
+
+        # Each leg: a rank-local set-up phase (contexts, uploads: where a rank can fail alone, e.g. hipMalloc of the second
+        # whole-map context) whose outcome is agreed on collectively, then the phase with the collectives -- an exception in
+        # THAT phase is not caught: it ends the rank, and torch.distributed.run tears the job down with a non-zero exit.
+        hull_ctx = shard_ctx = None
+        err = None
         try:
             hcull = capi.default_cull_params()
             hcull.cull_mode = capi.CULL_HPR
@@ -338,6 +350,11 @@ def main():
             shard_ctx.set_frames(poses[:Fs])
             shard_ctx.set_depth_source(True)
             shard_ctx.depth_pass()  # the shard's own part of a run (tile masks; no hull on an index shard): as MultiDevice::depthPassAll
+        except (RuntimeError, capi.PcpError) as e:
+            err = str(e)
+        if not all_ranks_ok(err):
+            sharded_legs["hpr"] = {"error": err or "another rank failed its set-up; the leg was skipped on every rank"}
+        else:
             hs = pipeline.HullSharding(hull_ctx, shard_ctx, Ns, rank, world)
             hs.run(Fs, device=dev_name)  # warm-up (allocations)
             dist.barrier()
@@ -351,15 +368,17 @@ def main():
             sharded_legs["hpr"] = {"points": Ns, "keyframes": Fs, "hpr_ms": round(rank_max(t_all) * 1e3, 2),
                                    "hull_ms_max_rank": round(rank_max(hres["hull_s"]) * 1e3, 2),
                                    "exchange_ms_max_rank": round(rank_max(hres["exchange_s"]) * 1e3, 2),
+                                   "exchange_bytes_per_rank": int(hres.get("exchange_bytes", 0)),
                                    "hull_vertices": int(rank_sum(hres["kept"])),
                                    "keyframe0_shards_equal_owner": bool(rank_sum(mine0) == rank_sum(owner0)),
                                    "what": "hidden_points_removal of the whole C3-scene map over the ranks: hulls of each rank's block of "
-                                           "keyframes (whole-map context), all-gather of the verdicts keyframe by keyframe, import into the "
-                                           "rank's index shard"}
-            hull_ctx.close()
-            shard_ctx.close()
-        except (RuntimeError, capi.PcpError) as e:
-            sharded_legs["hpr"] = {"error": str(e)}
+                                           "keyframes (whole-map context), the verdicts bit-packed and exchanged slice by slice "
+                                           "(all_to_all_single: a rank receives only its own index range), imported into the rank's index shard"}
+        for c_ in (hull_ctx, shard_ctx):
+            if c_ is not None:
+                c_.close()
+        seng = cs = None
+        err = None
         try:
             seng = pipeline.HipEngine(local_rank)
             seng.configure(cam, cull)
@@ -367,6 +386,11 @@ def main():
             mp_s = capi.default_mls_params()
             mp_s.upsampling = 0
             cs = pipeline.CloudSmooth(seng, mp_s)
+        except (RuntimeError, capi.PcpError) as e:
+            err = str(e)
+        if not all_ranks_ok(err):
+            sharded_legs["smooth"] = {"error": err or "another rank failed its set-up; the leg was skipped on every rank"}
+        else:
             cs.outlier_removal_sharded(Ns, rank, world)  # warm-up
             dist.barrier()
             t1 = time.perf_counter()
@@ -384,9 +408,8 @@ def main():
                                       "what": "StatisticalOutlierRemoval (k = 60, 0.7 sigma) + MovingLeastSquares (r = 0.03, NONE) of the "
                                               "whole map with the queries dealt out by slabs; results on every rank's host (the "
                                               "variable-length MLS rows are all-gathered and merged by source index)"}
+        if seng is not None:
             seng.close()
-        except (RuntimeError, capi.PcpError) as e:
-            sharded_legs["smooth"] = {"error": str(e)}
         del sx_, sy_, sz_
     # ---- per-kernel times of one more step (hipEvents on the launch stream).  Every rank takes the step:
     # with N > 1 it contains the all-reduce, a collective ----

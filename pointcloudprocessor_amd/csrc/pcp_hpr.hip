@@ -1127,6 +1127,9 @@ __device__ __forceinline__ void tilt_normal(Search &S, const Tilt &T) {
 }
 
 constexpr int kStatTilt = 23;  // block 0 of the tallies: length of k_hpr_tilt's list
+// PCP_HPR_DEBUG only: searches by the binary logarithm of their test batches [0..15], the batches of each class [16..31], and
+// per wavefront the rows' batches summed [32] against four times the longest row's [33] (what lockstep rows cost), wavefronts [34]
+__device__ unsigned long long g_tilt_hist[40];
 // The state of a search lives in LDS, one record per row (every lane of the row writes the same values, so each thread
 // reads what it wrote itself): carried in registers through the eight loop levels below it cost a copy per level -- the
 // first build of this kernel took 263 VGPRs (one wavefront per SIMD) for ~100 registers of state.
@@ -1200,7 +1203,7 @@ __global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_T
     int outcome = 0;        // 0 none, 1 visible, 2 hidden duplicate, 3 empty (a, b, c below), 4 gave up
     int32_t ca = -1, cb = -1, cc = -1;
     int steps = 0, passes = 0, why4 = 0, wide = 0, last_wn = 0;
-    unsigned long long batches = 0;
+    unsigned long long batches = 0, csteps = 0;  // (csteps: rows of cell tests, PCP_HPR_DEBUG only)
     auto stop = [&](int why) {
       outcome = why;
       run = false;
@@ -1360,6 +1363,7 @@ __global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_T
         const int32_t t = cbk + rl;
         const int32_t tq = small_div(t, ww);
         const int32_t Ci = W.i0 + (t - tq * ww), Cj = W.j0 + tq;
+        if (kDebug && run && cbk < wn && rl == 0) ++csteps;
         const int32_t C = (run && t < wn) ? Cj * ugw + Ci : -1;
         bool copen = false;
         if (C >= 0) {
@@ -1374,6 +1378,7 @@ __global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_T
           const int32_t Cci = __shfl(Ci, row_base + bc, 64), Ccj = __shfl(Cj, row_base + bc, 64);
           for (int q4 = 0; __ballot(go_c && q4 < fsteps); ++q4) {  // the fine cells of the upper cell, 16 at a time
             const bool go_q = go_c && q4 < fsteps;
+            if (kDebug && go_q && rl == 0) ++csteps;
             const int fidx = q4 * 16 + rl;
             const int32_t fi = ((go_q ? Cci : 0) << eshift) + (fidx & ((1 << eshift) - 1)), fj = ((go_q ? Ccj : 0) << eshift) + (fidx >> eshift);
             bool fopen = false;
@@ -1433,6 +1438,20 @@ __global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_T
           atomicAdd(&mine[31], batches);
         }
         atomicAdd(&mine[30], static_cast<unsigned long long>(wide));
+        const unsigned long long trips = batches + csteps;
+        const int hb = trips ? min(63 - __clzll(static_cast<long long>(trips)), 15) : 0;
+        atomicAdd(&g_tilt_hist[hb], 1ull);
+        atomicAdd(&g_tilt_hist[16 + hb], trips);
+        atomicAdd(&g_tilt_hist[35], csteps);
+      }
+    }
+    if (kDebug) {
+      const unsigned long long trips = batches + csteps;
+      const unsigned long long b0 = __shfl(trips, 0, 64), b1 = __shfl(trips, 16, 64), b2 = __shfl(trips, 32, 64), b3 = __shfl(trips, 48, 64);
+      if (lane == 0) {
+        atomicAdd(&g_tilt_hist[32], b0 + b1 + b2 + b3);
+        atomicAdd(&g_tilt_hist[33], 4ull * max(max(b0, b1), max(b2, b3)));
+        atomicAdd(&g_tilt_hist[34], 1ull);
       }
     }
   }
@@ -2070,6 +2089,16 @@ int hpr_finish(pcp_context *ctx, HprLane &L, bool timed) {
       fprintf(stderr, "hpr: tilt: %llu searches: visible %llu duplicate %llu empty %llu (certified %llu) gave up %llu (same point %llu, step cap %llu, "
               "no conclusion %llu, pass cap %llu); passes %llu steps %llu batches %llu\n", w[0], w[2], w[3], w[4], w[6], w[5], w[7], w[8], w[9],
               w[10], w[11], w[12], w[13]);
+    }
+    {
+      unsigned long long hist[40] = {0}, zero[40] = {0};
+      (void)hipMemcpyFromSymbol(hist, HIP_SYMBOL(g_tilt_hist), sizeof(hist));
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tilt_hist), zero, sizeof(zero));
+      fprintf(stderr, "hpr: tilt: searches by log2(round trips):");
+      for (int b = 0; b < 16; ++b) fprintf(stderr, " %llu", hist[b]);
+      fprintf(stderr, "\nhpr: tilt: round trips of each class:");
+      for (int b = 0; b < 16; ++b) fprintf(stderr, " %llu", hist[16 + b]);
+      fprintf(stderr, "\nhpr: tilt: %llu wavefronts, rows' round trips (point batches + cell rows) %llu of %llu row slots (4 x the longest row); cell rows %llu\n", hist[34], hist[32], hist[33], hist[35]);
     }
     fprintf(stderr, "hpr: to the exact path: uncertain_left %llu tetra_filter %llu box_cert %llu fail: guard %llu restarts %llu noncontig %llu overflow %llu\n", dbg[10], dbg[11], dbg[12], dbg[14], dbg[15], dbg[16], dbg[17]);
   }

@@ -188,24 +188,35 @@ class HullSharding:
     """hidden_points_removal (view_culling.cpp:266-334) over point-index shards.  A keyframe's hull is taken over EVERY
     candidate of the map, so an index shard cannot decide its own points: every rank holds a second context with the whole
     map (`hull_ctx`, cull_mode PCP_CULL_HPR, no images), takes the hulls of its block of keyframes there in one
-    pcp_depth_pass (several keyframes in flight), and the verdicts -- one flag per map point -- are all-gathered keyframe
-    by keyframe; every rank imports the slice of its own index range into its shard context (`shard_ctx`,
-    PCP_DEPTH_BATCHED), which then colours / dumps from the bits exactly as a one-GPU run does.  With the "nccl" backend
-    the flags stay in device memory from pcp_cull_frame to pcp_hull_flags_import (ABI v5)."""
+    pcp_depth_pass (several keyframes in flight), and the verdicts -- one flag per map point -- go to the ranks that own the
+    points: in round i rank o holds keyframe f0(o) + i and sends every rank k the slice [lo(k), hi(k)) of its verdicts, ONE
+    BIT per point, in one all_to_all_single (a rank receives W slices of its own index range: ~n / 8 bytes per round and
+    rank where an all-gather of byte flags moved W x n to everyone; host/pcp_multi.hpp sends slices the same way).  Every
+    rank imports the slices into its shard context (`shard_ctx`, PCP_DEPTH_BATCHED), which then colours / dumps from the
+    bits exactly as a one-GPU run does.  With the "nccl" backend the flags stay in device memory from pcp_cull_frame to
+    pcp_hull_flags_import (ABI v5)."""
 
     def __init__(self, hull_ctx, shard_ctx, n_total: int, rank: int, world: int, group=None):
         self.hull_ctx, self.shard_ctx = hull_ctx, shard_ctx
         self.n_total, self.rank, self.world, self.group = int(n_total), rank, world, group
 
+    @staticmethod
+    def packed_bytes(count: int) -> int:
+        """bytes of a bit-packed slice of `count` verdicts (bit j of byte b = point 8 b + j of the slice)"""
+        return (int(count) + 7) // 8
+
     def run(self, n_frames: int, device: str | None = None):
-        """Returns dict(hull_s, exchange_s, kept) -- kept = hull vertices of this rank's keyframes."""
+        """Returns dict(hull_s, exchange_s, kept, exchange_bytes, rounds) -- kept = hull vertices of this rank's keyframes,
+        exchange_bytes = what this rank sent (== what it received up to padding) over all rounds."""
         import time
 
         import torch
         import torch.distributed as dist
 
         W, r, n = self.world, self.rank, self.n_total
-        lo, hi = shard_bounds(n, r, W)
+        bounds = [shard_bounds(n, k, W) for k in range(W)]
+        lo, hi = bounds[r]
+        mine_n = hi - lo
         f0, f1 = keyframe_block(n_frames, r, W)
         t0 = time.perf_counter()
         if f1 > f0:
@@ -214,37 +225,55 @@ class HullSharding:
         t_hull = time.perf_counter() - t0
         on_gpu = W > 1 and dist.get_backend(self.group) == "nccl"
         dev = (device or "cuda") if on_gpu else "cpu"
-        rounds = max(keyframe_block(n_frames, k, W)[1] - keyframe_block(n_frames, k, W)[0] for k in range(W))
-        send = torch.zeros(n, dtype=torch.uint8, device=dev)
-        recv = torch.zeros((W, n), dtype=torch.uint8, device=dev) if W > 1 else send.view(1, n)
-        kept = 0
+        blocks = [keyframe_block(n_frames, k, W) for k in range(W)]
+        rounds = max(b1 - b0 for b0, b1 in blocks)
+        send_sizes = [self.packed_bytes(b - a) for a, b in bounds]      # to rank k: its index range, bit-packed
+        recv_sizes = [self.packed_bytes(mine_n)] * W                    # from every rank: my index range
+        flags = torch.zeros(n, dtype=torch.uint8, device=dev)
+        padded = torch.zeros(8 * max(send_sizes), dtype=torch.uint8, device=dev)  # a slice, zero-padded to whole bytes
+        weights = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=dev)
+        shifts = torch.arange(8, dtype=torch.uint8, device=dev)
+        send = torch.zeros(sum(send_sizes), dtype=torch.uint8, device=dev)
+        recv = torch.zeros(sum(recv_sizes), dtype=torch.uint8, device=dev)
+        kept = moved = 0
         t0 = time.perf_counter()
         for i in range(rounds):
             f = f0 + i
             if f < f1:
                 if on_gpu:
-                    kept += self.hull_ctx.cull_frame_into(f, send.data_ptr())  # from the whole-run bits: nothing recomputed
+                    kept += self.hull_ctx.cull_frame_into(f, flags.data_ptr())  # from the whole-run bits: nothing recomputed
                 else:
                     keep, _, k = self.hull_ctx.cull_frame(f)
-                    send.copy_(torch.from_numpy(np.ascontiguousarray(keep)))
+                    flags.copy_(torch.from_numpy(np.ascontiguousarray(keep)))
                     kept += int(k)
+                at = 0
+                for (a, b), sz in zip(bounds, send_sizes):
+                    padded.zero_()
+                    padded[: b - a] = flags[a:b] != 0
+                    send[at:at + sz] = (padded[: 8 * sz].view(sz, 8) * weights).sum(dim=1, dtype=torch.uint8)
+                    at += sz
             else:
-                send.zero_()
+                send.zero_()  # (no keyframe of mine in this round: the others ignore what arrives from me)
             if W > 1:
-                dist.all_gather_into_tensor(recv.view(-1), send, group=self.group)
+                dist.all_to_all_single(recv, send, output_split_sizes=recv_sizes, input_split_sizes=send_sizes, group=self.group)
+                moved += int(send.numel())
+            else:
+                recv.copy_(send)
+            psz = recv_sizes[0]
             for k in range(W):
-                fk0, fk1 = keyframe_block(n_frames, k, W)
+                fk0, fk1 = blocks[k]
                 if fk0 + i >= fk1:
                     continue
-                piece = recv[k, lo:hi]
+                bits = ((recv[k * psz:(k + 1) * psz].unsqueeze(1) >> shifts) & 1).reshape(-1)[:mine_n].contiguous()
                 if on_gpu:
                     torch.cuda.current_stream().synchronize()  # the library imports on its own stream
-                    self.shard_ctx.hull_flags_import_ptr(fk0 + i, piece.data_ptr())
+                    self.shard_ctx.hull_flags_import_ptr(fk0 + i, bits.data_ptr())
+                    self.shard_ctx.synchronize()  # `bits` is released next
                 else:
-                    self.shard_ctx.hull_flags_import(fk0 + i, piece.cpu().numpy())
+                    self.shard_ctx.hull_flags_import(fk0 + i, bits.cpu().numpy())
         if on_gpu:
             self.shard_ctx.synchronize()
-        return dict(hull_s=t_hull, exchange_s=time.perf_counter() - t0, kept=kept)
+        return dict(hull_s=t_hull, exchange_s=time.perf_counter() - t0, kept=kept, exchange_bytes=moved, rounds=rounds)
 
 
 class VisualLiDARCalibration:

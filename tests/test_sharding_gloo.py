@@ -385,7 +385,7 @@ def _hull_worker(rank, world, port, out_dir, n, n_frames):
     hs = pipeline.HullSharding(_FakeHullCtx(n), shard, n, rank, world)
     res = hs.run(n_frames)
     np.savez(os.path.join(out_dir, f"hull{rank}.npz"), kept=res["kept"], frames=np.array(sorted(shard.got)),
-             **{f"f{f}": v for f, v in shard.got.items()})
+             exchange_bytes=res["exchange_bytes"], rounds=res["rounds"], **{f"f{f}": v for f, v in shard.got.items()})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -409,6 +409,10 @@ def test_hull_verdicts_reach_every_index_shard(tmp_path, world, n_frames):
         for f in range(n_frames):
             assert np.array_equal(d[f"f{f}"], _hull_flags(f, n)[lo:hi]), (r, f)
         kept += int(d["kept"])
+        # what a rank moves per round: the map's verdicts ONE BIT per point, each slice padded to whole bytes -- not the
+        # W x n bytes of an all-gather of byte flags
+        assert int(d["rounds"]) == max(b - a for a, b in (pipeline.keyframe_block(n_frames, k, world) for k in range(world)))
+        assert int(d["exchange_bytes"]) <= int(d["rounds"]) * (n // 8 + world)
     assert kept == sum(int(_hull_flags(f, n).sum()) for f in range(n_frames))
     blocks = [pipeline.keyframe_block(n_frames, r, world) for r in range(world)]
     assert blocks[0][0] == 0 and blocks[-1][1] == n_frames and all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
