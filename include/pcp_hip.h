@@ -228,7 +228,10 @@ int pcp_frame_visible(pcp_context *ctx, int32_t frame, int64_t capacity, int32_t
  * out[0] visible, [1] hidden, [2] candidates that went to the exact path (neither floating-point certificate held),
  * [3] trial normals, [4] batches of 64 point tests, [5] reserved (0), [6] UNRESOLVED (no exact
  * certificate either: exactly degenerate input such as four coplanar flipped points; classified hidden), [7] exact
- * predicate evaluations, [8] grid cells, [9] candidates. */
+ * predicate evaluations, [8] grid cells, [9] candidates.
+ * After a single-keyframe call (pcp_cull_frame, pcp_frame_visible, NID) that was SERVED FROM THE WHOLE-RUN BITS -- a
+ * pcp_depth_pass of this context had taken the keyframe's hull already, or pcp_hull_flags_import had brought it -- nothing
+ * was recomputed and there are no tallies of that keyframe: out[0..8] = 0 and out[9] = -1. */
 int pcp_hpr_stats(pcp_context *ctx, int64_t out[10]);
 
 /* ---- whole run (pcdColorizationAndSmooth, PointCloudProcessor.cpp:474-602) -- */

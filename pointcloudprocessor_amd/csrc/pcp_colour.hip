@@ -1224,6 +1224,11 @@ static int frame_keep_flags(pcp_context *ctx, int32_t frame, bool require_pixel)
     // over the WHOLE map elsewhere), or left there by this context's own hull pass (pcp_depth_pass) -- nothing is recomputed
     if (!have_bits)
       return set_error(ctx, PCP_ERR_STATE, "PCP_CULL_HPR on an index shard: pcp_hull_flags_import has not covered keyframe %d", frame);
+    // pcp_hpr_stats describes the keyframe asked for LAST: this one was not recomputed, so there are no tallies of it (the
+    // ones of the whole-run pass's last lane would be another keyframe's): zeros, candidates = -1
+    std::memset(ctx->hpr_stats, 0, sizeof(ctx->hpr_stats));
+    ctx->hpr_stats[9] = -1;
+    ctx->hpr_stats_pending = false;
     LaunchTimer t(ctx, PCP_K_VISIBILITY);
     hipLaunchKernelGGL(k_flags_from_hull_bits, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream,
                        ctx->hull_bits.p + static_cast<size_t>(frame >> 5) * static_cast<size_t>(n), 1u << (frame & 31), ctx->perm.p,

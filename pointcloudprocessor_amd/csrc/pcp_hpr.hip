@@ -43,6 +43,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "pcp_device.hpp"
 #include "pcp_exact.hpp"
@@ -714,6 +715,7 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_candidates(const float *__res
 struct HprCounts {
   unsigned long long count, inv_amin, amax, inv_bmin, bmax, seq;
 };
+// `host` must be COHERENT (fine-grained) pinned memory: hipHostMallocCoherent (hpr_begin allocates it that way).
 __global__ __launch_bounds__(64) void k_hpr_publish(const unsigned long long *__restrict__ stats, unsigned long long seq,
                                                     volatile HprCounts *__restrict__ host) {
   const int l = lane_id();
@@ -897,137 +899,7 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_quick(HprArrays A, HprGrid G,
 // ------------------------------------------------------------------------------------------------------------------
 // `todo` (nullable): the candidates k_hpr_quick left undecided, as a list (k_hpr_list; its length in the tallies): the four rows
 // of a wavefront then all have work on keyframes where most candidates are hidden and certified already.
-constexpr int kStatRadial = 22;  // block 0 of the tallies: length of that list
-__global__ __launch_bounds__(kHprBlock) void k_hpr_radial(HprArrays A, HprGrid G, uint8_t *__restrict__ state,
-                                                          const int32_t *__restrict__ todo, unsigned long long *__restrict__ stats) {
-  const int lane = lane_id();
-  const int rl = lane & 15, row_base = lane & 48;
-  const int32_t u = static_cast<int32_t>(blockIdx.x) * (kHprBlock / 16) + static_cast<int32_t>(threadIdx.x >> 4);
-  const int32_t count = todo ? static_cast<int32_t>(stats[kStatRadial]) : G.m;
-  if (static_cast<int32_t>(blockIdx.x) * (kHprBlock / 16) >= count) return;  // (the grid covers every candidate)
-  const bool have = u < count;
-  const int32_t j = have ? (todo ? todo[u] : u) : 0;
-  auto row_mask = [&](bool b) -> uint32_t { return static_cast<uint32_t>((__ballot(b) >> row_base) & 0xffffull); };
-  Search S;
-  S.self = have ? j : 0;
-  S.p = load_point(A, S.self);
-  S.self_idx = A.sidx[S.self];
-  search_frame(S);
-  S.n = S.e0;
-  {
-    // e0 = p / |p| to a few ulp (search_frame): |n| = 1 within 1e-15, so n stands for its own unit vector (the cell bound
-    // carries 1e-12 of slack for that) and 1 + 1e-13 bounds its norm -- no second square root and reciprocal per candidate
-    S.nh = S.n;
-    S.nn_hi = 1.0 + 1.0e-13;
-    S.hp_lo = ((S.n.x * S.p.x + S.n.y * S.p.y) + S.n.z * S.p.z) * (1.0 - 1.0e-13);
-  }
-  bool open = have && state[S.self] == kStUndecided;  // the row may still certify its candidate (k_hpr_quick may have settled it)
-  const bool mine_to_write = open;
-  bool hidden_dup = false;
-  unsigned long long batches = 0;
-  // points [k0, k1) of the cell order against the plane, 16 at a time; `go`: this row takes part
-  auto test_points = [&](bool go, int32_t k0, int32_t k1) {
-    for (int32_t base = k0; __ballot(go && open && base < k1); base += 16) {
-      const int32_t k = base + rl;
-      const bool active = go && open && k < k1 && k != S.self;
-      bool bad = false, dup_lower = false;
-      if (active) {
-        const double dx = A.sx[k] - S.p.x, dy = A.sy[k] - S.p.y, dz = A.sz[k] - S.p.z;
-        if (dx == 0.0 && dy == 0.0 && dz == 0.0) {
-          dup_lower = A.sidx[k] < S.self_idx;  // identical flipped points: the lowest input index stands for the group
-        } else {
-          const double tx = S.n.x * dx, ty = S.n.y * dy, tz = S.n.z * dz;
-          const double t = (tx + ty) + tz, T = (fabs(tx) + fabs(ty)) + fabs(tz);
-          bad = !(t < -kPointSlack * T);
-        }
-      }
-      if (go && open && base < k1 && rl == 0) batches += 1;
-      if (row_mask(dup_lower)) {
-        hidden_dup = true;
-        open = false;
-      }
-      if (row_mask(bad)) open = false;
-    }
-  };
-  const int32_t cell = A.scell[S.self];
-  const int32_t ci = cell % G.gw, cj = cell / G.gw;
-  // the 3 x 3 cells around the candidate's own
-  for (int dj = -1; dj <= 1; ++dj) {
-    const int32_t rj = cj + dj;
-    const bool in = rj >= 0 && rj < G.gh;
-    const int32_t c0 = (in ? rj : cj) * G.gw + max(ci - 1, 0), c1 = (in ? rj : cj) * G.gw + min(ci + 1, G.gw - 1);
-    test_points(in, A.cstart[c0], A.cstart[c1 + 1]);
-  }
-  // every other cell the bound cannot clear: mid cells (4 x 4 fine cells) of the window, 16 at a time, then the 16 fine cells
-  // of a mid cell that stays open -- one row of tests each.  (Through the coarse cells of the 64-lane search an open cell
-  // cost four rows of fine tests, most of them on cells nowhere near the plane: k_hpr_radial is bound by its arithmetic.)
-  const Window W = reach_window<kHprMid>(S, G);
-  const bool has_window = open && W.i0 <= W.i1 && W.j0 <= W.j1;
-  const int32_t ww = has_window ? W.i1 - W.i0 + 1 : 1, wn = has_window ? ww * (W.j1 - W.j0 + 1) : 0;
-  for (int32_t cb = 0; __ballot(open && cb < wn); cb += 16) {
-    const int32_t t = cb + rl;
-    const int32_t tq = small_div(t, ww);
-    const int32_t Ci = W.i0 + (t - tq * ww), Cj = W.j0 + tq;  // (kept apart: the fine cells need them, not the linear index)
-    const int32_t C = (open && t < wn) ? Cj * G.mgw + Ci : -1;
-    bool copen = false;
-    if (C >= 0) {
-      const float4 c4 = A.Mid4[C];
-      copen = c4.w > 0.0f && !cell_cleared_f32sep(S.nh.x, S.nh.y, S.nh.z, S.nn_hi, S.hp_lo, c4.x, c4.y, c4.z, c4.w, G.r_mid + kCell4Slack);
-    }
-    uint32_t open_c = row_mask(copen);
-    while (__ballot(open && open_c != 0u)) {
-      const bool go_c = open && open_c != 0u;
-      const int bc = go_c ? __builtin_ctz(open_c) : 0;
-      open_c &= open_c - 1u;
-      const int32_t Cci = __shfl(Ci, row_base + bc, 64), Ccj = __shfl(Cj, row_base + bc, 64);
-      {
-        const int32_t fi = (go_c ? Cci : 0) * kHprMid + (rl & 3), fj = (go_c ? Ccj : 0) * kHprMid + (rl >> 2);
-        bool fopen = false;
-        int32_t f = 0;
-        if (go_c && fi < G.gw && fj < G.gh && !(abs(fi - ci) <= 1 && abs(fj - cj) <= 1)) {
-          f = fj * G.gw + fi;
-          const float4 c4 = A.cell4[f];
-          fopen = c4.w > 0.0f && !cell_cleared_f32sep(S.nh.x, S.nh.y, S.nh.z, S.nn_hi, S.hp_lo, c4.x, c4.y, c4.z, c4.w, G.r_fine + kCell4Slack);
-        }
-        uint32_t open_f = row_mask(fopen);
-        while (__ballot(open && open_f != 0u)) {
-          const bool go_f = open && open_f != 0u;
-          const int bf = go_f ? __builtin_ctz(open_f) : 0;
-          open_f &= open_f - 1u;
-          const int32_t ff = __shfl(f, row_base + bf, 64);
-          test_points(go_f, go_f ? A.cstart[ff] : 0, go_f ? A.cstart[ff + 1] : 0);
-        }
-      }
-    }
-  }
-  if (mine_to_write && rl == 0) {
-    const int32_t out = hidden_dup ? kStHidden : (open ? kStVisible : kStUndecided);
-    state[j] = static_cast<uint8_t>(out);
-    unsigned long long *mine = stats + kStatStride * (1 + (blockIdx.x % kStatCopies));
-    if (out != kStUndecided) {
-      atomicAdd(&mine[out], 1ull);
-      atomicAdd(&mine[3], 1ull);
-    }
-    atomicAdd(&mine[4], batches);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// The search itself, 16 lanes per candidate (round 4).  What the radial pass leaves are candidates whose least-tilted
-// supporting plane is not the radial one (or that have none).  Their feasibility problem -- find s with s . D_q < E_q for
-// every q -- is solved here as the LEAST-NORM problem  min |s|^2  s.t.  s . D_q <= E_q - margin |D_q|  by the dual
-// active-set method: the trial tilt s is the least-norm point of at most two "active" half-planes (s = 0: none, the radial
-// plane); a point the trial plane does not clear adds its half-plane, the least-norm point of (active + new) is taken from
-// the three places where the new line can be tight (alone, or meeting one of the active lines), and the half-planes that
-// are tight there become the active set.  |s| grows strictly with every step, so no active set comes back; three
-// half-planes with nothing in common end the search with the same witness the polygon search ends with -- p inside the
-// tetrahedron (origin, q_a, q_b, q_c) -- CHECKED by the same filtered determinants, and a trial plane is a witness of
-// visibility only after one whole traversal in which it did not move: the same rounding-proof point test and cell bound
-// as k_hpr_radial / k_hpr_decide.  So the state of a search is two doubles and two lines -- no polygon, no cross-lane
-// bookkeeping --, four searches share a wavefront, and the arithmetic every lane of a 64-lane search repeated for one
-// candidate (frame, trial normal, window) now serves four.  Whatever ends otherwise (round-off, a parallel pair, a cap)
-// stays kStUndecided for k_hpr_decide, whose polygon remembers every half-plane it has seen.
-// ------------------------------------------------------------------------------------------------------------------
+// ---- the least-norm tilt of a trial plane (shared by k_hpr_radial<true> and k_hpr_tilt; described at k_hpr_tilt) ----
 constexpr double kTiltMargin = 1.0e-9;  // the trial tilt stays this far (rad) inside every half-plane it knows: n . d <= -1e-9 |D| against a rounding bound of ~1e-13
 constexpr int kTiltMaxSteps = 200;      // half-planes added per search (a dense cluster next to the candidate: 41 seen on C3)
 constexpr int kTiltMaxPasses = 8;       // traversals per search
@@ -1126,9 +998,204 @@ __device__ __forceinline__ void tilt_normal(Search &S, const Tilt &T) {
   S.hp_lo = ((S.n.x * S.p.x + S.n.y * S.p.y) + S.n.z * S.p.z) * (1.0 - 1.0e-13);
 }
 
+constexpr int kStatRadial = 22;  // block 0 of the tallies: length of that list
+// kOneStep (round 5): the same pass for the candidates the radial plane FAILED, with the plane tilted once.  What the radial
+// pass leaves undecided are mostly visible candidates whose supporting plane leans with the local surface, and on C3 a visible
+// search of k_hpr_tilt adds 1.1-2.4 half-planes on average: most of them are settled by the FIRST one.  So before the searches
+// (LDS records, a dual active set, 168 VGPRs, 3 wavefronts per SIMD) this pass probes the 3 x 3 near cells with the radial
+// plane, takes the worst violator's half-plane, moves to the least tilted plane that clears it by the searches' margin
+// (tilt_add on an empty active set) and runs the ordinary traversal with THAT plane: a plane that has every other point
+// strictly on its inner side is a witness whatever produced it (same point test, same cell bound).  Whatever it cannot
+// certify stays undecided for k_hpr_tilt.  `stat_len`: the word of block 0 that holds the length of `todo`.
+template <bool kOneStep>
+__global__ __launch_bounds__(kHprBlock) void k_hpr_radial(HprArrays A, HprGrid G, uint8_t *__restrict__ state,
+                                                          const int32_t *__restrict__ todo, unsigned long long *__restrict__ stats,
+                                                          int32_t stat_len) {
+  const int lane = lane_id();
+  const int rl = lane & 15, row_base = lane & 48;
+  const int32_t u = static_cast<int32_t>(blockIdx.x) * (kHprBlock / 16) + static_cast<int32_t>(threadIdx.x >> 4);
+  const int32_t count = todo ? static_cast<int32_t>(stats[stat_len]) : G.m;
+  if (static_cast<int32_t>(blockIdx.x) * (kHprBlock / 16) >= count) return;  // (the grid covers every candidate)
+  const bool have = u < count;
+  const int32_t j = have ? (todo ? todo[u] : u) : 0;
+  auto row_mask = [&](bool b) -> uint32_t { return static_cast<uint32_t>((__ballot(b) >> row_base) & 0xffffull); };
+  Search S;
+  S.self = have ? j : 0;
+  S.p = load_point(A, S.self);
+  S.self_idx = A.sidx[S.self];
+  search_frame(S);
+  S.n = S.e0;
+  {
+    // e0 = p / |p| to a few ulp (search_frame): |n| = 1 within 1e-15, so n stands for its own unit vector (the cell bound
+    // carries 1e-12 of slack for that) and 1 + 1e-13 bounds its norm -- no second square root and reciprocal per candidate
+    S.nh = S.n;
+    S.nn_hi = 1.0 + 1.0e-13;
+    S.hp_lo = ((S.n.x * S.p.x + S.n.y * S.p.y) + S.n.z * S.p.z) * (1.0 - 1.0e-13);
+  }
+  bool open = have && state[S.self] == kStUndecided;  // the row may still certify its candidate (k_hpr_quick may have settled it)
+  const bool mine_to_write = open;
+  bool hidden_dup = false;
+  unsigned long long batches = 0;
+  const int32_t cell = A.scell[S.self];
+  const int32_t ci = cell % G.gw, cj = cell / G.gw;
+  if (kOneStep) {
+    // the worst violator of the radial plane among the 3 x 3 near cells (largest n . d relative to its rounding bound, as the
+    // searches choose), one per lane, then over the row
+    float best = -INFINITY;
+    double bx = 0.0, by = 0.0, bz = 0.0;
+    int32_t bk = -1;
+    for (int dj = -1; dj <= 1; ++dj) {
+      const int32_t rj = cj + dj;
+      const bool in = rj >= 0 && rj < G.gh;
+      const int32_t c0 = (in ? rj : cj) * G.gw + max(ci - 1, 0), c1 = (in ? rj : cj) * G.gw + min(ci + 1, G.gw - 1);
+      const int32_t k0 = A.cstart[c0], k1 = A.cstart[c1 + 1];
+      for (int32_t base = k0; __ballot(in && open && base < k1); base += 16) {
+        const int32_t k = base + rl;
+        if (in && open && k < k1 && k != S.self) {
+          const double dx = A.sx[k] - S.p.x, dy = A.sy[k] - S.p.y, dz = A.sz[k] - S.p.z;
+          const double tx = S.n.x * dx, ty = S.n.y * dy, tz = S.n.z * dz;
+          const double t = (tx + ty) + tz, T = (fabs(tx) + fabs(ty)) + fabs(tz);
+          if (!(dx == 0.0 && dy == 0.0 && dz == 0.0) && !(t < -kPointSlack * T)) {
+            const float score = static_cast<float>(t) * __builtin_amdgcn_rcpf(static_cast<float>(T));
+            if (score > best) {
+              best = score;
+              bx = dx;
+              by = dy;
+              bz = dz;
+              bk = k;
+            }
+          }
+        }
+        if (in && open && base < k1 && rl == 0) batches += 1;
+      }
+    }
+    const float worst = row_max16(best);
+    const uint32_t at = row_mask(open && bk >= 0 && best == worst);
+    if (!at) {
+      open = false;  // nothing near violates the radial plane (a far point did): the searches' business
+    } else {
+      const int src = row_base + __builtin_ctz(at);
+      const double qx = __shfl(bx, src, 64), qy = __shfl(by, src, 64), qz = __shfl(bz, src, 64);
+      const double Dx = (qx * S.e1.x + qy * S.e1.y) + qz * S.e1.z;
+      const double Dy = (qx * S.e2.x + qy * S.e2.y) + qz * S.e2.z;
+      const double E = -((qx * S.e0.x + qy * S.e0.y) + qz * S.e0.z);
+      Tilt T;
+      T.sx = T.sy = 0.0;
+      T.na = 0;
+      T.a = T.b = {0.0, 0.0, 0.0, -1};
+      if (tilt_add(T, Dx, Dy, E, __shfl(bk, src, 64)) == 1)
+        tilt_normal(S, T);
+      else
+        open = false;
+    }
+  }
+  // points [k0, k1) of the cell order against the plane, 16 at a time; `go`: this row takes part
+  auto test_points = [&](bool go, int32_t k0, int32_t k1) {
+    for (int32_t base = k0; __ballot(go && open && base < k1); base += 16) {
+      const int32_t k = base + rl;
+      const bool active = go && open && k < k1 && k != S.self;
+      bool bad = false, dup_lower = false;
+      if (active) {
+        const double dx = A.sx[k] - S.p.x, dy = A.sy[k] - S.p.y, dz = A.sz[k] - S.p.z;
+        if (dx == 0.0 && dy == 0.0 && dz == 0.0) {
+          dup_lower = A.sidx[k] < S.self_idx;  // identical flipped points: the lowest input index stands for the group
+        } else {
+          const double tx = S.n.x * dx, ty = S.n.y * dy, tz = S.n.z * dz;
+          const double t = (tx + ty) + tz, T = (fabs(tx) + fabs(ty)) + fabs(tz);
+          bad = !(t < -kPointSlack * T);
+        }
+      }
+      if (go && open && base < k1 && rl == 0) batches += 1;
+      if (row_mask(dup_lower)) {
+        hidden_dup = true;
+        open = false;
+      }
+      if (row_mask(bad)) open = false;
+    }
+  };
+  // the 3 x 3 cells around the candidate's own
+  for (int dj = -1; dj <= 1; ++dj) {
+    const int32_t rj = cj + dj;
+    const bool in = rj >= 0 && rj < G.gh;
+    const int32_t c0 = (in ? rj : cj) * G.gw + max(ci - 1, 0), c1 = (in ? rj : cj) * G.gw + min(ci + 1, G.gw - 1);
+    test_points(in, A.cstart[c0], A.cstart[c1 + 1]);
+  }
+  // every other cell the bound cannot clear: mid cells (4 x 4 fine cells) of the window, 16 at a time, then the 16 fine cells
+  // of a mid cell that stays open -- one row of tests each.  (Through the coarse cells of the 64-lane search an open cell
+  // cost four rows of fine tests, most of them on cells nowhere near the plane: k_hpr_radial is bound by its arithmetic.)
+  const Window W = reach_window<kHprMid>(S, G);
+  const bool has_window = open && W.i0 <= W.i1 && W.j0 <= W.j1;
+  const int32_t ww = has_window ? W.i1 - W.i0 + 1 : 1, wn = has_window ? ww * (W.j1 - W.j0 + 1) : 0;
+  for (int32_t cb = 0; __ballot(open && cb < wn); cb += 16) {
+    const int32_t t = cb + rl;
+    const int32_t tq = small_div(t, ww);
+    const int32_t Ci = W.i0 + (t - tq * ww), Cj = W.j0 + tq;  // (kept apart: the fine cells need them, not the linear index)
+    const int32_t C = (open && t < wn) ? Cj * G.mgw + Ci : -1;
+    bool copen = false;
+    if (C >= 0) {
+      const float4 c4 = A.Mid4[C];
+      copen = c4.w > 0.0f && !cell_cleared_f32sep(S.nh.x, S.nh.y, S.nh.z, S.nn_hi, S.hp_lo, c4.x, c4.y, c4.z, c4.w, G.r_mid + kCell4Slack);
+    }
+    uint32_t open_c = row_mask(copen);
+    while (__ballot(open && open_c != 0u)) {
+      const bool go_c = open && open_c != 0u;
+      const int bc = go_c ? __builtin_ctz(open_c) : 0;
+      open_c &= open_c - 1u;
+      const int32_t Cci = __shfl(Ci, row_base + bc, 64), Ccj = __shfl(Cj, row_base + bc, 64);
+      {
+        const int32_t fi = (go_c ? Cci : 0) * kHprMid + (rl & 3), fj = (go_c ? Ccj : 0) * kHprMid + (rl >> 2);
+        bool fopen = false;
+        int32_t f = 0;
+        if (go_c && fi < G.gw && fj < G.gh && !(abs(fi - ci) <= 1 && abs(fj - cj) <= 1)) {
+          f = fj * G.gw + fi;
+          const float4 c4 = A.cell4[f];
+          fopen = c4.w > 0.0f && !cell_cleared_f32sep(S.nh.x, S.nh.y, S.nh.z, S.nn_hi, S.hp_lo, c4.x, c4.y, c4.z, c4.w, G.r_fine + kCell4Slack);
+        }
+        uint32_t open_f = row_mask(fopen);
+        while (__ballot(open && open_f != 0u)) {
+          const bool go_f = open && open_f != 0u;
+          const int bf = go_f ? __builtin_ctz(open_f) : 0;
+          open_f &= open_f - 1u;
+          const int32_t ff = __shfl(f, row_base + bf, 64);
+          test_points(go_f, go_f ? A.cstart[ff] : 0, go_f ? A.cstart[ff + 1] : 0);
+        }
+      }
+    }
+  }
+  if (mine_to_write && rl == 0) {
+    const int32_t out = hidden_dup ? kStHidden : (open ? kStVisible : kStUndecided);
+    state[j] = static_cast<uint8_t>(out);
+    unsigned long long *mine = stats + kStatStride * (1 + (blockIdx.x % kStatCopies));
+    if (out != kStUndecided) {
+      atomicAdd(&mine[out], 1ull);
+      atomicAdd(&mine[3], 1ull);
+    }
+    atomicAdd(&mine[4], batches);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The search itself, 16 lanes per candidate (round 4).  What the radial pass leaves are candidates whose least-tilted
+// supporting plane is not the radial one (or that have none).  Their feasibility problem -- find s with s . D_q < E_q for
+// every q -- is solved here as the LEAST-NORM problem  min |s|^2  s.t.  s . D_q <= E_q - margin |D_q|  by the dual
+// active-set method: the trial tilt s is the least-norm point of at most two "active" half-planes (s = 0: none, the radial
+// plane); a point the trial plane does not clear adds its half-plane, the least-norm point of (active + new) is taken from
+// the three places where the new line can be tight (alone, or meeting one of the active lines), and the half-planes that
+// are tight there become the active set.  |s| grows strictly with every step, so no active set comes back; three
+// half-planes with nothing in common end the search with the same witness the polygon search ends with -- p inside the
+// tetrahedron (origin, q_a, q_b, q_c) -- CHECKED by the same filtered determinants, and a trial plane is a witness of
+// visibility only after one whole traversal in which it did not move: the same rounding-proof point test and cell bound
+// as k_hpr_radial / k_hpr_decide.  So the state of a search is two doubles and two lines -- no polygon, no cross-lane
+// bookkeeping --, four searches share a wavefront, and the arithmetic every lane of a 64-lane search repeated for one
+// candidate (frame, trial normal, window) now serves four.  Whatever ends otherwise (round-off, a parallel pair, a cap)
+// stays kStUndecided for k_hpr_decide, whose polygon remembers every half-plane it has seen.
+// ------------------------------------------------------------------------------------------------------------------
 constexpr int kStatTilt = 23;  // block 0 of the tallies: length of k_hpr_tilt's list
-// PCP_HPR_DEBUG only: searches by the binary logarithm of their test batches [0..15], the batches of each class [16..31], and
-// per wavefront the rows' batches summed [32] against four times the longest row's [33] (what lockstep rows cost), wavefronts [34]
+constexpr int kStatOneStep = 30;   // block 0: length of the list of k_hpr_radial<true>
+constexpr int kStatTiltCont = 29;  // block 0: length of the list of searches the 16-lane rows handed on to a wavefront each
+// PCP_HPR_DEBUG only: searches by the binary logarithm of their round trips [0..15], the round trips of each class [16..31], and
+// per wavefront the rows' round trips summed [32] against (rows x the longest row's) [33] (what lockstep rows cost),
+// wavefronts [34], rows of cell tests [35]
 __device__ unsigned long long g_tilt_hist[40];
 // The state of a search lives in LDS, one record per row (every lane of the row writes the same values, so each thread
 // reads what it wrote itself): carried in registers through the eight loop levels below it cost a copy per level -- the
@@ -1139,6 +1206,19 @@ struct TiltRow {
   double sx, sy;                     // trial tilt
   double ax, ay, af, bx, by, bf;     // active lines
   int32_t aid, bid, na, last_id;
+};
+
+// A search handed on (round 5).  The search is a serial chain of round trips -- a batch of loads, a test, a ballot --, a launch
+// lasts as long as its longest chain, and a chain of 16-lane steps can be a thousand long while the bulk takes 4-60 (the
+// launches were tails: 1.06 resident wavefronts per SIMD of 3, profiles/r04_hpr_pmc.json).  So a row stops after `budget` round
+// trips and writes down what the search has found so far -- the trial tilt and the active half-planes, which IS its state: the
+// least-norm point of at most two half-planes of real points, |s| only ever grows -- and a second launch continues every such
+// search on a whole wavefront: the same algorithm on rows of 64 lanes (a quarter of the round trips, coarse cells of 8 x 8
+// fine ones as the upper level), starting its passes over with the plane it was handed.  Every verdict still rests on the
+// same certificates (one whole pass with an unmoved plane / the checked tetrahedron).
+struct TiltCont {
+  double sx, sy, ax, ay, af, bx, by, bf;
+  int32_t j, na, aid, bid;
 };
 
 #define TILT_STORE_NORMAL(R, S) \
@@ -1156,27 +1236,55 @@ struct TiltRow {
 #ifndef PCP_TILT_WPE
 #define PCP_TILT_WPE 3
 #endif
-template <bool kDebug>
-__global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_TILT_WPE, PCP_TILT_WPE))) void k_hpr_tilt(
+// Workgroups of ONE wavefront (round 5).  A workgroup's wave slots are given back when its LAST wavefront ends, so with four
+// wavefronts to a workgroup the lockstep group was sixteen searches, not four: the slots of the three wavefronts that had
+// finished stood empty behind the longest (1.06 resident wavefronts per SIMD of 3, profiles/r04_hpr_pmc.json; k_hpr_decide
+// had shown the same in round 3).
+#ifndef PCP_TILT_BLOCK
+#define PCP_TILT_BLOCK 64
+#endif
+constexpr int kTiltBlock = PCP_TILT_BLOCK;
+// kRow = 16: four searches per wavefront, from the list `todo`, each with a budget of round trips; kRow = 64: one search per
+// wavefront, from the records `cont` the first launch wrote (budget: none).
+template <bool kDebug, int kRow>
+__global__ __launch_bounds__(kTiltBlock) __attribute__((amdgpu_waves_per_eu(PCP_TILT_WPE, PCP_TILT_WPE))) void k_hpr_tilt(
     HprArrays A, HprGrid G, uint8_t *__restrict__ state, const int32_t *__restrict__ todo, unsigned long long *__restrict__ stats,
-    int32_t wide_window, int32_t *__restrict__ left_over) {
+    int32_t wide_window, int32_t *__restrict__ left_over, TiltCont *__restrict__ cont, int32_t budget) {
+  static_assert(kRow == 16 || kRow == 64, "rows of 16 or 64 lanes");
+  constexpr int kRowsPerWave = 64 / kRow, kRowsPerBlock = kTiltBlock / kRow;
   // Really in LDS: a compiler barrier in front of every group of reads keeps the compiler from forwarding the stores to them
   // (and so from carrying the record in registers after all); not `volatile`, which turns the accesses into flat ones with an
   // address pair per field (60 VGPRs).
-  __shared__ TiltRow rows[kHprBlock / 16];
-#define R rows[threadIdx.x >> 4]
+  __shared__ TiltRow rows[kRowsPerBlock];
+#define R rows[threadIdx.x / kRow]
 #define TILT_FENCE() asm volatile("" ::: "memory")
   const int lane = lane_id();
-  const int rl = lane & 15, row_base = lane & 48;
-  const int32_t count = static_cast<int32_t>(stats[kStatTilt]);
-  const int32_t rows_total = static_cast<int32_t>(gridDim.x) * (kHprBlock / 16);
-  auto row_mask = [&](bool b) -> uint32_t { return static_cast<uint32_t>((__ballot(b) >> row_base) & 0xffffull); };
+  const int rl = lane & (kRow - 1), row_base = lane & (64 - kRow);
+  const int32_t count = static_cast<int32_t>(stats[kRow == 16 ? kStatTilt : kStatTiltCont]);
+  const int32_t rows_total = static_cast<int32_t>(gridDim.x) * kRowsPerBlock;
+  using mask_t = typename std::conditional<kRow == 64, unsigned long long, uint32_t>::type;  // a row's lanes as bits
+  auto row_mask = [&](bool b) -> mask_t {
+    const unsigned long long m = __ballot(b);
+    return static_cast<mask_t>(kRow == 64 ? m : ((m >> row_base) & 0xffffull));
+  };
+  auto first_bit = [](mask_t m) -> int { return kRow == 64 ? static_cast<int>(__builtin_ctzll(m)) : __builtin_ctz(static_cast<uint32_t>(m)); };
+  auto row_max = [&](float v) -> float {
+    v = row_max16(v);
+    if (kRow == 64) {
+      const int iv = __float_as_int(v);
+      v = fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(iv, 0)), __int_as_float(__builtin_amdgcn_readlane(iv, 16))),
+                fmaxf(__int_as_float(__builtin_amdgcn_readlane(iv, 32)), __int_as_float(__builtin_amdgcn_readlane(iv, 48))));
+    }
+    return v;
+  };
   const int32_t n_coarse = G.cgw * G.cgh;
-  for (int32_t u0 = static_cast<int32_t>(blockIdx.x) * (kHprBlock / 16) + static_cast<int32_t>(threadIdx.x >> 6) * 4; u0 < count;
+  for (int32_t u0 = static_cast<int32_t>(blockIdx.x) * kRowsPerBlock + static_cast<int32_t>(threadIdx.x >> 6) * kRowsPerWave; u0 < count;
        u0 += rows_total) {  // (u0: the first row of this wavefront; uniform over the wavefront)
-    const int32_t u = u0 + (lane >> 4);
+    const int32_t u = u0 + lane / kRow;
     const bool have = u < count;
-    const int32_t j = have ? todo[u] : 0;
+    TiltCont c0 = {};
+    if (kRow == 64 && have) c0 = cont[u];
+    const int32_t j = have ? (kRow == 16 ? todo[u] : c0.j) : 0;
     const int32_t self = j, self_idx = A.sidx[j];
     const Vec3d p = load_point(A, j);
     {
@@ -1186,24 +1294,34 @@ __global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_T
       Tilt T;
       T.sx = T.sy = 0.0;
       T.na = 0;
+      T.a = T.b = {0.0, 0.0, 0.0, -1};
+      if (kRow == 64 && have) {  // the search so far
+        T.sx = c0.sx;
+        T.sy = c0.sy;
+        T.na = c0.na;
+        T.a = {c0.ax, c0.ay, c0.af, c0.aid};
+        T.b = {c0.bx, c0.by, c0.bf, c0.bid};
+      }
       tilt_normal(S, T);
       TILT_STORE_NORMAL(R, S);
       R.e0[0] = S.e0.x; R.e0[1] = S.e0.y; R.e0[2] = S.e0.z;
       R.e1[0] = S.e1.x; R.e1[1] = S.e1.y; R.e1[2] = S.e1.z;
       R.e2[0] = S.e2.x; R.e2[1] = S.e2.y; R.e2[2] = S.e2.z;
-      R.sx = R.sy = 0.0;
-      R.ax = R.ay = R.af = R.bx = R.by = R.bf = 0.0;
-      R.aid = R.bid = -1;
-      R.na = 0;
+      R.sx = T.sx;
+      R.sy = T.sy;
+      R.ax = T.a.x; R.ay = T.a.y; R.af = T.a.f; R.aid = T.a.id;
+      R.bx = T.b.x; R.by = T.b.y; R.bf = T.b.f; R.bid = T.b.id;
+      R.na = T.na;
       R.last_id = -1;
       TILT_FENCE();
     }
     bool run = have;        // the row is still searching
     bool changed = false;   // the trial plane moved during this pass
-    int outcome = 0;        // 0 none, 1 visible, 2 hidden duplicate, 3 empty (a, b, c below), 4 gave up
+    int outcome = 0;        // 0 none, 1 visible, 2 hidden duplicate, 3 empty (a, b, c below), 4 gave up, 5 handed on (budget)
     int32_t ca = -1, cb = -1, cc = -1;
     int steps = 0, passes = 0, why4 = 0, wide = 0, last_wn = 0;
-    unsigned long long batches = 0, csteps = 0;  // (csteps: rows of cell tests, PCP_HPR_DEBUG only)
+    int32_t trips = 0;      // round trips of this row so far: batches of point tests + rows of cell tests (row-uniform)
+    unsigned long long batches = 0, csteps = 0;  // (tallies, lane 0 of the row; csteps: PCP_HPR_DEBUG only)
     auto stop = [&](int why) {
       outcome = why;
       run = false;
@@ -1247,10 +1365,12 @@ __global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_T
         stop(4);
       }
     };
-    // points [k0, k1) of the cell order against the trial plane, 16 at a time; `go`: this row takes part
+    // points [k0, k1) of the cell order against the trial plane, kRow at a time; `go`: this row takes part
     auto test_points = [&](bool go, int32_t k0, int32_t k1) {
-      for (int32_t base = k0; __ballot(go && run && base < k1); base += 16) {
+      for (int32_t base = k0; __ballot(go && run && base < k1); base += kRow) {
+        if (go && run && base < k1 && trips >= budget) stop(5);  // (row-uniform)
         const bool on = go && run && base < k1;
+        if (on) ++trips;
         const int32_t k = base + rl;
         const bool active = on && k < k1 && k != self;
         double dx = 0.0, dy = 0.0, dz = 0.0;
@@ -1271,13 +1391,13 @@ __global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_T
           const double t = (tx + ty) + tz, Tt = (fabs(tx) + fabs(ty)) + fabs(tz);
           const bool bad = run && mine && !(t < -kPointSlack * Tt);
           if (!__ballot(bad)) break;
-          const uint32_t rm = row_mask(bad);
+          const mask_t rm = row_mask(bad);
           if (rm) {
             // the worst of the row's points (largest n . d relative to its bound; the choice only steers)
             const float score = bad ? static_cast<float>(t) * __builtin_amdgcn_rcpf(static_cast<float>(Tt)) : -INFINITY;
-            const float worst = row_max16(score);
-            const uint32_t at = row_mask(bad && score == worst);
-            const int src = row_base + __builtin_ctz(at ? at : rm);
+            const float worst = row_max(score);
+            const mask_t at = row_mask(bad && score == worst);
+            const int src = row_base + first_bit(at ? at : rm);
             const double qx = __shfl(dx, src, 64), qy = __shfl(dy, src, 64), qz = __shfl(dz, src, 64);
             const int32_t qid = base + (src - row_base);
             // a point that is not cleared right after its own half-plane was added lies within round-off of every plane the
@@ -1315,8 +1435,8 @@ __global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_T
         for (int dj = -1; dj <= 1; ++dj) {
           const int32_t rj = cj + dj;
           const bool in = rj >= 0 && rj < G.gh;
-          const int32_t c0 = (in ? rj : cj) * G.gw + max(ci - 1, 0), c1 = (in ? rj : cj) * G.gw + min(ci + 1, G.gw - 1);
-          test_points(in && again, A.cstart[c0], A.cstart[c1 + 1]);
+          const int32_t c0n = (in ? rj : cj) * G.gw + max(ci - 1, 0), c1n = (in ? rj : cj) * G.gw + min(ci + 1, G.gw - 1);
+          test_points(in && again, A.cstart[c0n], A.cstart[c1n + 1]);
         }
         if (run && again && changed && nit >= 12) {
           why4 = 3;
@@ -1328,29 +1448,33 @@ __global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_T
       // every other cell the bound cannot clear.  A point in there that moves the plane does not end the sweep: the rest of
       // the window is taken with the new plane (its half-planes are collected in this sweep instead of one per pass) and
       // the next pass starts over -- a plane is only a witness after a whole pass in which it did not move.
-      // The window in mid cells (4 x 4 fine cells: an open one costs ONE row of fine tests) -- unless the plane is tilted so far
-      // that the window is wide: then the upper level is the coarse cells (8 x 8: a quarter of the upper rows, four rows of
-      // fine tests per open cell).  Per row: `big` selects the level.
+      // Rows of 16: the window in mid cells (4 x 4 fine cells: an open one costs ONE row of fine tests) -- unless the plane is
+      // tilted so far that the window is wide: then the upper level is the coarse cells (8 x 8: a quarter of the upper rows, four
+      // rows of fine tests per open cell).  Per row: `big` selects the level.  Rows of 64: always coarse cells (one row each).
       Window W;
-      bool big = false;
+      bool big = kRow == 64;
       {
         TILT_FENCE();
         Search S;
         S.nh = {R.nh[0], R.nh[1], R.nh[2]};
         S.nn_hi = R.nn_hi;
         S.hp_lo = R.hp_lo;
-        W = reach_window<kHprMid>(S, G);
-        big = run && W.i0 <= W.i1 && (W.i1 - W.i0 + 1) * (W.j1 - W.j0 + 1) > wide_window;
-        if (big) {  // the same window in coarse cells (a superset: the mid window's corners, halved)
-          W.i0 >>= 1;
-          W.j0 >>= 1;
-          W.i1 = min(W.i1 >> 1, G.cgw - 1);
-          W.j1 = min(W.j1 >> 1, G.cgh - 1);
+        if (kRow == 64) {
+          W = reach_window<kHprCoarse>(S, G);
+        } else {
+          W = reach_window<kHprMid>(S, G);
+          big = run && W.i0 <= W.i1 && (W.i1 - W.i0 + 1) * (W.j1 - W.j0 + 1) > wide_window;
+          if (big) {  // the same window in coarse cells (a superset: the mid window's corners, halved)
+            W.i0 >>= 1;
+            W.j0 >>= 1;
+            W.i1 = min(W.i1 >> 1, G.cgw - 1);
+            W.j1 = min(W.j1 >> 1, G.cgh - 1);
+          }
         }
       }
       const int32_t ugw = big ? G.cgw : G.mgw;
       const int eshift = big ? 3 : 2;                          // log2 of the upper cell's edge in fine cells
-      const int fsteps = big ? 4 : 1;                          // rows of 16 fine cells per upper cell
+      const int fsteps = big ? 64 / kRow : 1;                  // rows of fine cells per upper cell
       const float4 *upper = big ? A.Cell4 : A.Mid4;
       const double r_upper = (big ? G.r_coarse : G.r_mid) + kCell4Slack;
       const bool has_window = run && W.i0 <= W.i1 && W.j0 <= W.j1;
@@ -1359,7 +1483,9 @@ __global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_T
         if (wn > 256) ++wide;
         if (run) last_wn = wn;
       }
-      for (int32_t cbk = 0; __ballot(run && cbk < wn); cbk += 16) {
+      for (int32_t cbk = 0; __ballot(run && cbk < wn); cbk += kRow) {
+        if (run && cbk < wn && trips >= budget) stop(5);
+        if (run && cbk < wn) ++trips;
         const int32_t t = cbk + rl;
         const int32_t tq = small_div(t, ww);
         const int32_t Ci = W.i0 + (t - tq * ww), Cj = W.j0 + tq;
@@ -1370,29 +1496,31 @@ __global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_T
           const float4 c4 = upper[C];
           copen = c4.w > 0.0f && !cleared(c4.x, c4.y, c4.z, c4.w, r_upper);
         }
-        uint32_t open_c = row_mask(copen);
-        while (__ballot(run && open_c != 0u)) {
-          const bool go_c = run && open_c != 0u;
-          const int bc = go_c ? __builtin_ctz(open_c) : 0;
-          open_c &= open_c - 1u;
+        mask_t open_c = row_mask(copen);
+        while (__ballot(run && open_c != 0)) {
+          const bool go_c = run && open_c != 0;
+          const int bc = go_c ? first_bit(open_c) : 0;
+          open_c &= open_c - 1;
           const int32_t Cci = __shfl(Ci, row_base + bc, 64), Ccj = __shfl(Cj, row_base + bc, 64);
-          for (int q4 = 0; __ballot(go_c && q4 < fsteps); ++q4) {  // the fine cells of the upper cell, 16 at a time
-            const bool go_q = go_c && q4 < fsteps;
+          for (int q4 = 0; __ballot(go_c && run && q4 < fsteps); ++q4) {  // the fine cells of the upper cell, kRow at a time
+            if (go_c && run && q4 < fsteps && trips >= budget) stop(5);
+            const bool go_q = go_c && run && q4 < fsteps;
+            if (go_q) ++trips;
             if (kDebug && go_q && rl == 0) ++csteps;
-            const int fidx = q4 * 16 + rl;
+            const int fidx = q4 * kRow + rl;
             const int32_t fi = ((go_q ? Cci : 0) << eshift) + (fidx & ((1 << eshift) - 1)), fj = ((go_q ? Ccj : 0) << eshift) + (fidx >> eshift);
             bool fopen = false;
             int32_t f = 0;
-            if (go_q && run && fi < G.gw && fj < G.gh && !(abs(fi - ci) <= 1 && abs(fj - cj) <= 1)) {
+            if (go_q && fi < G.gw && fj < G.gh && !(abs(fi - ci) <= 1 && abs(fj - cj) <= 1)) {
               f = fj * G.gw + fi;
               const float4 c4 = A.cell4[f];
               fopen = c4.w > 0.0f && !cleared(c4.x, c4.y, c4.z, c4.w, G.r_fine + kCell4Slack);
             }
-            uint32_t open_f = row_mask(fopen);
-            while (__ballot(run && open_f != 0u)) {
-              const bool go_f = run && open_f != 0u;
-              const int bf = go_f ? __builtin_ctz(open_f) : 0;
-              open_f &= open_f - 1u;
+            mask_t open_f = row_mask(fopen);
+            while (__ballot(run && open_f != 0)) {
+              const bool go_f = run && open_f != 0;
+              const int bf = go_f ? first_bit(open_f) : 0;
+              open_f &= open_f - 1;
               const int32_t ff = __shfl(f, row_base + bf, 64);
               test_points(go_f, go_f ? A.cstart[ff] : 0, go_f ? A.cstart[ff + 1] : 0);
             }
@@ -1415,42 +1543,52 @@ __global__ __launch_bounds__(kHprBlock) __attribute__((amdgpu_waves_per_eu(PCP_T
       if (out != kStUndecided) {
         state[j] = static_cast<uint8_t>(out);
         atomicAdd(&mine[out], 1ull);
+      } else if (kRow == 16 && outcome == 5) {
+        // out of round trips: the search continues on a wavefront of its own, from the plane it has reached
+        TILT_FENCE();
+        TiltCont c;
+        c.sx = R.sx; c.sy = R.sy;
+        c.ax = R.ax; c.ay = R.ay; c.af = R.af;
+        c.bx = R.bx; c.by = R.by; c.bf = R.bf;
+        c.j = j; c.na = R.na; c.aid = R.aid; c.bid = R.bid;
+        cont[atomicAdd(&stats[kStatTiltCont], 1ull)] = c;
       } else {
-        // what this pass gives up on (a handful per keyframe) goes straight onto the list of the 64-lane search
+        // what this pass gives up on (a handful per keyframe) goes straight onto the list of the polygon search
         left_over[atomicAdd(&stats[kStatSearch], 1ull)] = j;
       }
       atomicAdd(&mine[3], static_cast<unsigned long long>(steps + 1));
-      atomicAdd(&mine[4], (batches + 3ull) / 4ull);
+      atomicAdd(&mine[4], (batches * kRow + 63ull) / 64ull);
       if (kDebug) {  // PCP_HPR_DEBUG: what became of the searches (words 9.. of the copies; nothing else uses them)
         if (outcome == 4)
-          printf("hpr: tilt gave up on %d: why %d passes %d steps %d batches %llu |s| %.3g na %d window %d coarse cells of %d, p = (%.17g, %.17g, %.17g)\n",
-                 j, why4, passes, steps, batches, sqrt(R.sx * R.sx + R.sy * R.sy), R.na, last_wn, n_coarse, p.x, p.y, p.z);
+          printf("hpr: tilt%d gave up on %d: why %d passes %d steps %d batches %llu |s| %.3g na %d window %d coarse cells of %d, p = (%.17g, %.17g, %.17g)\n",
+                 kRow, j, why4, passes, steps, batches, sqrt(R.sx * R.sx + R.sy * R.sy), R.na, last_wn, n_coarse, p.x, p.y, p.z);
         atomicAdd(&mine[9], 1ull);
-        atomicAdd(&mine[10 + min(outcome, 4)], 1ull);  // 10 none 11 visible 12 duplicate 13 empty 14 gave up
+        atomicAdd(&mine[10 + min(outcome, 4)], 1ull);  // 10 none 11 visible 12 duplicate 13 empty 14 gave up / handed on
         if (outcome == 3 && out == kStHidden) atomicAdd(&mine[15], 1ull);
         if (outcome == 4) atomicAdd(&mine[16 + min(why4, 3)], 1ull);  // 16 same point again 17 step cap 18 no conclusion 19 pass cap
         atomicAdd(&mine[20], static_cast<unsigned long long>(passes));
         atomicAdd(&mine[21], static_cast<unsigned long long>(steps));
         atomicAdd(&mine[22], batches);
         atomicMax(&mine[28], batches);
-        if (batches > 2000ull) {
-          atomicAdd(&mine[29], 1ull);
-          atomicAdd(&mine[31], batches);
-        }
+        if (outcome == 5) atomicAdd(&mine[29], 1ull);
         atomicAdd(&mine[30], static_cast<unsigned long long>(wide));
-        const unsigned long long trips = batches + csteps;
-        const int hb = trips ? min(63 - __clzll(static_cast<long long>(trips)), 15) : 0;
+        const int hb = trips ? min(31 - __clz(trips), 15) : 0;
         atomicAdd(&g_tilt_hist[hb], 1ull);
-        atomicAdd(&g_tilt_hist[16 + hb], trips);
+        atomicAdd(&g_tilt_hist[16 + hb], static_cast<unsigned long long>(trips));
         atomicAdd(&g_tilt_hist[35], csteps);
       }
     }
     if (kDebug) {
-      const unsigned long long trips = batches + csteps;
-      const unsigned long long b0 = __shfl(trips, 0, 64), b1 = __shfl(trips, 16, 64), b2 = __shfl(trips, 32, 64), b3 = __shfl(trips, 48, 64);
+      unsigned long long tsum = 0, tmax = 0;
+#pragma unroll
+      for (int r4 = 0; r4 < kRowsPerWave; ++r4) {
+        const unsigned long long tr = static_cast<unsigned long long>(__shfl(trips, r4 * kRow, 64));
+        tsum += tr;
+        tmax = max(tmax, tr);
+      }
       if (lane == 0) {
-        atomicAdd(&g_tilt_hist[32], b0 + b1 + b2 + b3);
-        atomicAdd(&g_tilt_hist[33], 4ull * max(max(b0, b1), max(b2, b3)));
+        atomicAdd(&g_tilt_hist[32], tsum);
+        atomicAdd(&g_tilt_hist[33], kRowsPerWave * tmax);
         atomicAdd(&g_tilt_hist[34], 1ull);
       }
     }
@@ -1537,6 +1675,9 @@ __device__ __forceinline__ void hpr_decide_one(const HprArrays &A, const HprGrid
 // (1.38 resident wavefronts per SIMD of 2, profiles/r03q_hpr_pmc.json)
 constexpr int32_t kHprDecideGrid = 65536;
 constexpr int32_t kHprTiltGrid = 4096;  // workgroups of k_hpr_tilt (16 rows each) striding over its list
+constexpr int32_t kHprOneStepGrid = 1 << 20;  // (k_hpr_radial does not stride: its grid covers the list's upper bound, extra workgroups leave at once)
+constexpr int32_t kHprTilt64Grid = 768;  // workgroups of its continuation (4 rows of 64 each): every resident slot at 3 wavefronts per SIMD
+constexpr int32_t kTiltBudget = 128;     // round trips of a search on a row of 16 lanes before it is handed on (PCP_TILT_BUDGET; 32: pass +12 %, 48-128 and never: within 1 %)
 #ifndef PCP_DECIDE_WPE
 #define PCP_DECIDE_WPE 2  // 214 VGPRs, nothing spilled; at 3 wavefronts per SIMD (168 VGPRs) 63 registers went to scratch: hull pass 0.312 -> 0.285 s once the searches ran from a list
 #endif
@@ -1829,7 +1970,10 @@ int hpr_begin(pcp_context *ctx, HprLane &L, hipStream_t stream, bool timed, int3
   L.hull_plane = hull_plane;
   L.bit = bit;
   if (!L.readback) {
-    if (hipHostMalloc(&L.readback, pcp_context::kReadbackBytes, hipHostMallocDefault) != hipSuccess) {
+    // fine-grained (coherent) pinned memory, asked for explicitly: the host polls a word k_hpr_publish writes while the stream is
+    // still running; with non-coherent pinned memory (HIP_HOST_COHERENT=0 or a runtime default) the kernel's
+    // __threadfence_system() writes are only guaranteed visible when the kernel ends
+    if (hipHostMalloc(&L.readback, pcp_context::kReadbackBytes, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
       L.readback = nullptr;
       return set_error(ctx, PCP_ERR_NOMEM, "hidden_points_removal: no pinned readback for a lane");
     }
@@ -2000,8 +2144,16 @@ int hpr_finish(pcp_context *ctx, HprLane &L, bool timed) {
                            L.state.p, m, undecided, stats + kStatRadial);  // (`undecided` is free until the searches)
         radial_todo = undecided;
       }
-      hipLaunchKernelGGL(k_hpr_radial, dim3(static_cast<uint32_t>(div_up(m, kHprBlock / 16))), dim3(kHprBlock), 0, stream, A, G,
-                         L.state.p, radial_todo, stats);
+      hipLaunchKernelGGL(k_hpr_radial<false>, dim3(static_cast<uint32_t>(div_up(m, kHprBlock / 16))), dim3(kHprBlock), 0, stream, A, G,
+                         L.state.p, radial_todo, stats, static_cast<int32_t>(kStatRadial));
+      // PCP_HPR_ONESTEP=0: without the once-tilted plane for what the radial plane failed (results identical)
+      const char *oe = std::getenv("PCP_HPR_ONESTEP");
+      if (!(oe && oe[0] == '0')) {
+        hipLaunchKernelGGL(k_hpr_list, dim3(static_cast<uint32_t>(div_up(m, kHprBlock * kHprListPer))), dim3(kHprBlock), 0, stream,
+                           L.state.p, m, todo, stats + kStatOneStep);
+        hipLaunchKernelGGL(k_hpr_radial<true>, dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(m, kHprBlock / 16), kHprOneStepGrid))),
+                           dim3(kHprBlock), 0, stream, A, G, L.state.p, todo, stats, static_cast<int32_t>(kStatOneStep));
+      }
     }
     std::vector<uint8_t> dbg_before;
     if (std::getenv("PCP_HPR_DEBUG")) {  // what the two passes in front left to the searches
@@ -2009,16 +2161,45 @@ int hpr_finish(pcp_context *ctx, HprLane &L, bool timed) {
       (void)hipMemcpyAsync(dbg_before.data(), L.state.p, sm, hipMemcpyDeviceToHost, stream);
       (void)hipStreamSynchronize(stream);
     }
-    // PCP_HPR_TILT=0: without the 16-lane search in front of the 64-lane one (results identical)
+    // PCP_HPR_TILT=0: without the least-norm searches in front of the polygon search (results identical)
     const char *te = std::getenv("PCP_HPR_TILT");
     if (!force_exact && !(te && te[0] == '0')) {
+      const bool dbg = std::getenv("PCP_HPR_DEBUG") != nullptr;
+      // PCP_TILT_BUDGET: round trips a search gets on a row of 16 lanes before it is handed on to a wavefront of its own
+      // (0: never handed on -- the form of round 4)
+      const char *be = std::getenv("PCP_TILT_BUDGET");
+      int32_t budget = be ? std::atoi(be) : kTiltBudget;
+      if (budget <= 0) budget = INT32_MAX;
+      const int32_t wide_window = std::getenv("PCP_TILT_WIDE") ? std::atoi(std::getenv("PCP_TILT_WIDE")) : kTiltWideWindow;
+      PCP_HIP_TRY(ctx, L.cont.ensure((sizeof(TiltCont) / sizeof(double)) * sm + 16));
+      TiltCont *cont = reinterpret_cast<TiltCont *>(L.cont.p);
+      auto debug_hist = [&](const char *what, int rows_per_wave) {
+        if (!dbg) return;
+        (void)hipStreamSynchronize(stream);
+        unsigned long long hist[40] = {0}, zero[40] = {0};
+        (void)hipMemcpyFromSymbol(hist, HIP_SYMBOL(g_tilt_hist), sizeof(hist));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tilt_hist), zero, sizeof(zero));
+        fprintf(stderr, "hpr: tilt (%s): searches by log2(round trips):", what);
+        for (int b = 0; b < 16; ++b) fprintf(stderr, " %llu", hist[b]);
+        fprintf(stderr, "\nhpr: tilt (%s): round trips of each class:", what);
+        for (int b = 0; b < 16; ++b) fprintf(stderr, " %llu", hist[16 + b]);
+        fprintf(stderr, "\nhpr: tilt (%s): %llu wavefronts, rows' round trips (point batches + cell rows) %llu of %llu row slots (%d x the longest row); cell rows %llu\n",
+                what, hist[34], hist[32], hist[33], rows_per_wave, hist[35]);
+      };
       hipLaunchKernelGGL(k_hpr_list, dim3(static_cast<uint32_t>(div_up(m, kHprBlock * kHprListPer))), dim3(kHprBlock), 0, stream,
                          L.state.p, m, todo, stats + kStatTilt);
-      hipLaunchKernelGGL(std::getenv("PCP_HPR_DEBUG") ? k_hpr_tilt<true> : k_hpr_tilt<false>,
-                         dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(m, kHprBlock / 16), kHprTiltGrid))),
-                         dim3(kHprBlock), 0, stream, A, G, L.state.p, todo, stats,
-                         std::getenv("PCP_TILT_WIDE") ? std::atoi(std::getenv("PCP_TILT_WIDE")) : kTiltWideWindow,
-                         cell);  // (`cell`, the candidates' cells in arrival order, is free after k_hpr_scatter)
+      // (`cell`, the candidates' cells in arrival order, is free after k_hpr_scatter: the list of what the searches give up on)
+      hipLaunchKernelGGL((dbg ? k_hpr_tilt<true, 16> : k_hpr_tilt<false, 16>),
+                         dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(m, kTiltBlock / 16), kHprTiltGrid * (kHprBlock / kTiltBlock)))),
+                         dim3(kTiltBlock), 0, stream, A, G, L.state.p, todo, stats, wide_window, cell, cont, budget);
+      debug_hist("rows of 16", 4);
+      if (budget != INT32_MAX) {
+        hipLaunchKernelGGL((dbg ? k_hpr_tilt<true, 64> : k_hpr_tilt<false, 64>),
+                           dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(m, kTiltBlock / 64), kHprTilt64Grid * (kHprBlock / kTiltBlock)))),
+                           dim3(kTiltBlock), 0, stream, A, G, L.state.p, static_cast<const int32_t *>(nullptr), stats, wide_window, cell,
+                           cont, INT32_MAX);
+        debug_hist("rows of 64", 1);
+      }
     }
     // the list of the 64-lane search: what k_hpr_tilt gave up on (it appended them itself: no third listing launch), or, without
     // that pass, every candidate still undecided
@@ -2084,21 +2265,12 @@ int hpr_finish(pcp_context *ctx, HprLane &L, bool timed) {
         wide += all[static_cast<size_t>(c * kStatStride + 30)];
         bigsum += all[static_cast<size_t>(c * kStatStride + 31)];
       }
-      fprintf(stderr, "hpr: tilt: longest search %llu batches; %llu searches of > 2000 batches (%llu batches together); %llu passes with a window of > 256 coarse cells\n",
-              bmax, big, bigsum, wide);
+      (void)bigsum;
+      fprintf(stderr, "hpr: tilt: longest search %llu batches; %llu searches handed on to a wavefront each; %llu passes with a window of > 256 upper cells\n",
+              bmax, big, wide);
       fprintf(stderr, "hpr: tilt: %llu searches: visible %llu duplicate %llu empty %llu (certified %llu) gave up %llu (same point %llu, step cap %llu, "
               "no conclusion %llu, pass cap %llu); passes %llu steps %llu batches %llu\n", w[0], w[2], w[3], w[4], w[6], w[5], w[7], w[8], w[9],
               w[10], w[11], w[12], w[13]);
-    }
-    {
-      unsigned long long hist[40] = {0}, zero[40] = {0};
-      (void)hipMemcpyFromSymbol(hist, HIP_SYMBOL(g_tilt_hist), sizeof(hist));
-      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tilt_hist), zero, sizeof(zero));
-      fprintf(stderr, "hpr: tilt: searches by log2(round trips):");
-      for (int b = 0; b < 16; ++b) fprintf(stderr, " %llu", hist[b]);
-      fprintf(stderr, "\nhpr: tilt: round trips of each class:");
-      for (int b = 0; b < 16; ++b) fprintf(stderr, " %llu", hist[16 + b]);
-      fprintf(stderr, "\nhpr: tilt: %llu wavefronts, rows' round trips (point batches + cell rows) %llu of %llu row slots (4 x the longest row); cell rows %llu\n", hist[34], hist[32], hist[33], hist[35]);
     }
     fprintf(stderr, "hpr: to the exact path: uncertain_left %llu tetra_filter %llu box_cert %llu fail: guard %llu restarts %llu noncontig %llu overflow %llu\n", dbg[10], dbg[11], dbg[12], dbg[14], dbg[15], dbg[16], dbg[17]);
   }
@@ -2127,7 +2299,7 @@ int hpr_run_range(pcp_context *ctx, int32_t f0, int32_t f1, int32_t lanes, const
   LaunchTimer t(ctx, PCP_K_HPR);  // the whole pass as one bracket on the context's stream
   ctx->hpr_host_wait_s = 0.0;
   const auto t_pass = std::chrono::steady_clock::now();
-  PCP_HIP_TRY(ctx, hipEventRecord(ctx->hpr_fork, ctx->stream));
+  PCP_HIP_TRY(ctx, hipEventRecord(ctx->hpr_fork, ctx->stream));  // (nothing is queued on a lane yet: an early return is safe)
   // every lane holds the scratch of a keyframe whose every point may be a candidate (80 B per map point): where the device
   // has no room for all of them, fewer keyframes are in flight
   {
@@ -2143,11 +2315,18 @@ int hpr_run_range(pcp_context *ctx, int32_t f0, int32_t f1, int32_t lanes, const
       }
     }
   }
-  for (int32_t k = 0; k < lanes; ++k) {
+  // From here on an error does not return: it is kept in `rc` and the function falls through to the drain-and-join block --
+  // nothing may stay queued on a lane whose buffers the next call reuses on another stream, no lane may stay `busy`.
+  auto keep = [&](hipError_t e, const char *what) {
+    if (e != hipSuccess && rc == PCP_OK) rc = set_error(ctx, PCP_ERR_DEVICE, "hidden_points_removal: %s: %s", what, hipGetErrorString(e));
+  };
+  int32_t forked = 0;  // lanes whose stream waits behind the fork (the others are left alone)
+  for (int32_t k = 0; k < lanes && rc == PCP_OK; ++k) {
     HprLane &L = ctx->hpr_lane[k];
-    if (!L.own_stream) PCP_HIP_TRY(ctx, hipStreamCreateWithFlags(&L.own_stream, hipStreamNonBlocking));
-    if (!ctx->hpr_join[k]) PCP_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->hpr_join[k], hipEventDisableTiming));
-    PCP_HIP_TRY(ctx, hipStreamWaitEvent(L.own_stream, ctx->hpr_fork, 0));
+    if (!L.own_stream) keep(hipStreamCreateWithFlags(&L.own_stream, hipStreamNonBlocking), "lane stream");
+    if (rc == PCP_OK && !ctx->hpr_join[k]) keep(hipEventCreateWithFlags(&ctx->hpr_join[k], hipEventDisableTiming), "join event");
+    if (rc == PCP_OK) keep(hipStreamWaitEvent(L.own_stream, ctx->hpr_fork, 0), "fork");
+    if (rc == PCP_OK) forked = k + 1;
   }
   // A lane is free for the next keyframe when it holds none, or when the count of the one it holds has arrived -- its stream
   // is in order, so everything queued there before has run.  The next keyframe goes to the first free lane, looked for from the
@@ -2189,10 +2368,16 @@ int hpr_run_range(pcp_context *ctx, int32_t f0, int32_t f1, int32_t lanes, const
     const int rcl = hpr_finish(ctx, ctx->hpr_lane[pick], false);
     if (rc == PCP_OK) rc = rcl;
   }
-  for (int32_t k = 0; k < lanes; ++k) {
-    PCP_HIP_TRY(ctx, hipEventRecord(ctx->hpr_join[k], ctx->hpr_lane[k].own_stream));
-    PCP_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->hpr_join[k], 0));
+  for (int32_t k = 0; k < forked; ++k) {
+    // the context's stream continues behind the lane; where the join cannot even be queued, the lane is waited for here
+    hipError_t e = hipEventRecord(ctx->hpr_join[k], ctx->hpr_lane[k].own_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->hpr_join[k], 0);
+    if (e != hipSuccess) {
+      (void)hipStreamSynchronize(ctx->hpr_lane[k].own_stream);
+      keep(e, "join");
+    }
   }
+  for (int32_t k = 0; k < pcp_context::kHprMaxLanes; ++k) ctx->hpr_lane[k].busy = false;
   if (std::getenv("PCP_HPR_HOST_TIMING"))
     fprintf(stderr, "hpr: pass of %d keyframes on %d lanes: host %.1f ms, of which %.1f ms waiting for counts\n", f1 - f0, lanes,
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pass).count() * 1e3, ctx->hpr_host_wait_s * 1e3);

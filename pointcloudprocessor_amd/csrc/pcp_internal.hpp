@@ -103,7 +103,7 @@ struct HprLane {
   hipStream_t stream = nullptr;      // the stream the keyframe in flight was queued on
   unsigned long long seq = 0;        // sequence number of the keyframe whose counts the readback is waited for
   DevBuf<int32_t> index, i32, tiles;
-  DevBuf<double> f64, cells_d;
+  DevBuf<double> f64, cells_d, cont;  // cont: the searches k_hpr_tilt hands on (TiltCont records)
   DevBuf<uint8_t> state;
   DevBuf<unsigned long long> stats;
   void *readback = nullptr;  // pinned, kReadbackBytes
@@ -119,6 +119,7 @@ struct HprLane {
     tiles.release();
     f64.release();
     cells_d.release();
+    cont.release();
     state.release();
     stats.release();
     if (readback) (void)hipHostFree(readback);

@@ -2098,7 +2098,17 @@ static int build_grid(pcp_context *ctx, const CloudView &cv, float cell, float r
   PCP_HIP_TRY(ctx, ctx->g_cell.ensure(sn + 4));
   PCP_HIP_TRY(ctx, ctx->g_rank.ensure(sn + 4));
   PCP_HIP_TRY(ctx, ctx->g_order.ensure(2 * sn + 8));
-  PCP_HIP_TRY(ctx, ctx->g_xyz.ensure(3 * plane + 4));
+  {
+    // k_sor_select<true> reads the planes in 16-byte pieces through one descriptor: a run's ragged end reads up to three
+    // floats past the run -- the next cell's points, the up-to-3 floats of padding behind a plane, the start of the next plane
+    // -- and masks those candidates by their x alone.  What it reads there must never be a NaN bit pattern (inf + NaN would
+    // slip past the mask as NaN): the buffer only ever holds finite coordinates (non-finite clouds are refused) or, right
+    // after an allocation, whatever hipMalloc left -- so a NEW allocation is zeroed once, and the padding stays non-NaN for
+    // the buffer's life.
+    const size_t before = ctx->g_xyz.count;  // (ensure() only ever grows: a changed count is a new allocation)
+    PCP_HIP_TRY(ctx, ctx->g_xyz.ensure(3 * plane + 4));
+    if (ctx->g_xyz.count != before) PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->g_xyz.p, 0, ctx->g_xyz.count * sizeof(float), ctx->stream));
+  }
   if (geometry_only) {
     PCP_HIP_TRY(ctx, ctx->g_start.ensure(static_cast<size_t>(ncell) + 8));
     *out = g;
