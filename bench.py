@@ -90,6 +90,72 @@ def read_summary(name):
     return {} if stale else d
 
 
+def cli_e2e_leg(synth, n_points=1_000_000, n_frames=32, W=1920, H=1080):
+    """The C++ command line end to end on a configs[1]-size dataset (1 M points, 32 keyframes @1920x1080) written to a tmpfs:
+    binary PCD + odometry + JPEG keyframes in, the reference's ASCII PCD outputs out (PointCloudProcessor.cpp:1007-1032).
+    Wall time of the process and the split the binary reports itself (PCP_CLI_TIMING): decode / upload / GPU / ASCII writes,
+    with the per-keyframe dumps (--skip_filtered_dumps 0, what the reference always writes: :1017) and without."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    from PIL import Image
+
+    from pointcloudprocessor_amd import host_build
+
+    exe = host_build.build()["PointCloudProcessor"]
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    d = tempfile.mkdtemp(prefix="pcp_cli_e2e_", dir=base)
+    res = {"points": n_points, "keyframes": n_frames, "image": f"{W}x{H}", "filesystem": base,
+           "what": "host/bin/PointCloudProcessor on a dataset in a tmpfs: binary PCD, odometry, JPEG keyframes (quality 92) -> "
+                   "scans-crop.pcd, filtered_pcd/*_beforeNID.pcd, cloudInWorldWithRGB.pcd (ASCII, PCL layout); camera = the "
+                   "reference's constants (PointCloudProcessor.cpp:57-62); phases as the binary reports them (seconds)"}
+    try:
+        x, y, z, inten = synth.make_cloud(n_points)
+        pcd = os.path.join(d, "scans.pcd")
+        hdr = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\n"
+               f"TYPE F F F F\nCOUNT 1 1 1 1\nWIDTH {n_points}\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS {n_points}\nDATA binary\n")
+        with open(pcd, "wb") as fh:
+            fh.write(hdr.encode())
+            fh.write(np.stack([x, y, z, inten], 1).astype(np.float32).tobytes())
+        poses, ts = synth.make_trajectory(n_frames)
+        jpeg_bytes = 0
+        with open(os.path.join(d, "odo.txt"), "w") as fh:
+            for k, (t, p_) in enumerate(zip(ts, poses)):
+                fh.write(synth.odometry_line(t, p_))
+                fn = os.path.join(d, "%f.jpg" % t)
+                Image.fromarray(synth.make_image(k, W, H)[:, :, ::-1]).save(fn, quality=92)
+                jpeg_bytes += os.path.getsize(fn)
+        res["input_bytes"] = {"pcd": os.path.getsize(pcd), "jpeg": jpeg_bytes}
+        for skip in (0, 1):
+            out = os.path.join(d, f"out{skip}") + "/"
+            os.makedirs(out)
+            env = dict(os.environ, PCP_CLI_TIMING=os.path.join(out, "timing.json"))
+            t1 = time.perf_counter()
+            p = subprocess.run([exe, "-p", pcd, "-o", os.path.join(d, "odo.txt"), "-i", d + "/", "-t", out,
+                                "--skip_filtered_dumps", str(skip)], capture_output=True, text=True, env=env, cwd=out)
+            wall = time.perf_counter() - t1
+            key = "skip_filtered_dumps_on" if skip else "skip_filtered_dumps_off"
+            if p.returncode != 0:
+                res[key] = {"error": f"exit {p.returncode}: {p.stderr[-300:]}"}
+                continue
+            with open(os.path.join(out, "timing.json")) as fh:
+                phases = json.load(fh)
+            written = 0
+            for root_, _dirs, files in os.walk(out):
+                written += sum(os.path.getsize(os.path.join(root_, f)) for f in files if f.endswith(".pcd"))
+            gpu_s = sum(v for k_, v in phases.items() if k_.endswith("_gpu_s"))
+            ascii_s = sum(v for k_, v in phases.items() if "write_ascii" in k_)
+            res[key] = {"wall_s": round(wall, 3), "phases_s": {k_: round(v, 4) for k_, v in phases.items()},
+                        "gpu_calls_s": round(gpu_s, 4), "ascii_writes_s": round(ascii_s, 4),
+                        "decode_and_upload_wall_s": round(phases.get("images_decode_and_upload_wall_s", 0.0), 4),
+                        "pcd_bytes_written": int(written),
+                        "Mpoints_frames_per_s_end_to_end": round(n_points * n_frames / wall / 1e6, 1)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return res
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1048,6 +1114,13 @@ def main():
         kt_ms = {k: round(v[0], 3) for k, v in kt.items()}
         kt_sum = sum(v for k, v in kt_ms.items() if k != "misc")
         kt_key = "kernels_ms" if kt_sum <= ms_per_step else "kernels_ms_timing_pass"
+        # ---- the command line end to end (decode / upload / GPU / ASCII writes) ----
+        cli_e2e = None
+        if side and not args.no_cpu:
+            try:
+                cli_e2e = cli_e2e_leg(synth)
+            except (OSError, RuntimeError, ImportError, ValueError, KeyError) as e:
+                cli_e2e = {"error": str(e)}
         result = {
             "metric": "Mpoints×frames/sec colorized",
             "value": round(value, 1),
@@ -1101,6 +1174,7 @@ def main():
             "nid": nid,
             "hpr": hpr,
             "mls": mls,
+            "cli_e2e": cli_e2e,
         }
         if sharded_legs is not None:
             result["sharded_legs"] = sharded_legs

@@ -31,13 +31,16 @@
 extern "C" {
 #endif
 
-#define PCP_ABI_VERSION 5 /* 2: pcp_cull_params grew cull_mode / match_mode; pcp_set_image_adjust
+#define PCP_ABI_VERSION 6 /* 2: pcp_cull_params grew cull_mode / match_mode; pcp_set_image_adjust
                              3: PCP_CULL_HPR, pcp_cull_params.hpr_flip_radius, pcp_hpr_stats
                              4: entry points added, no layout changed: pcp_sor_partial / pcp_sor_finish /
                                 pcp_sor_chunk_points, pcp_hull_flags_import; PCP_DEPTH_BATCHED accepts PCP_CULL_HPR
                              5: no entry point or layout changed; pcp_cull_frame's out_keep, pcp_sor_partial's out_chunk_sums,
                                 pcp_sor_finish's all_chunk_sums / out_keep may be DEVICE memory of the context's GPU (the
-                                multi-GPU host exchanges them with RCCL instead of through the host) */
+                                multi-GPU host exchanges them with RCCL instead of through the host)
+                             6: entry points added: pcp_cloud_smooth_stream_begin / _next / _stats (the whole enableMLS chain
+                                with its trailing outlier removal over a chunked voxel dilation); pcp_hpr_stats reports
+                                candidates = -1 after a call served from the whole-run bits */
 
 #define PCP_OK 0
 #define PCP_ERR_INVALID (-1) /* bad argument */
@@ -319,6 +322,31 @@ int pcp_mls_fetch(pcp_context *ctx, int64_t capacity, float *out_xyz, float *out
  * MovingLeastSquares (+ upsampling) -> SOR, cloudSmooth.cpp:109-164.  Results through
  * pcp_mls_fetch; out_index refers to the uploaded cloud. */
 int pcp_cloud_smooth(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_count);
+
+/* CloudSmooth::process WHOLE for clouds whose dilated voxel set exceeds one result (PCP/src/cloudSmooth.cpp:109-164 with the
+ * reference's own MLS configuration, PointCloudProcessor.cpp:67-86: VOXEL_GRID_DILATION 1 mm x 4 makes ~3.8e9 points of a
+ * 10 M-point map): StatisticalOutlierRemoval -> MovingLeastSquares + upsampling -> StatisticalOutlierRemoval ON THE UPSAMPLED
+ * CLOUD (:160-164), the last two stages streamed over chunks of the voxel key order (whole planes of the first axis).
+ *   _begin: first filter, fit, voxel set; then sweep 1 -- every chunk is emitted together with a halo of neighbouring
+ *           planes, the mean k-NN distances of its own rows are computed against chunk + halo and kept on the device (4 B per
+ *           row of the whole upsampled cloud), (sum, sum of squares) are taken over ALL rows in row order, the filter's
+ *           threshold follows.  The halo is CHECKED, not assumed: a row's neighbourhood (bound of the distance to its
+ *           (k + 1)-th nearest) must end inside the part of space whose rows the halo is guaranteed to hold, given the largest
+ *           displacement any row has from its voxel; a chunk that fails is redone with a wider halo.  The distances are
+ *           therefore the ones the one-shot pcp_cloud_smooth computes, bit for bit; the threshold is summed in another
+ *           order (row order instead of the cell order of one big grid) and agrees to rounding (~1e-16 relative).
+ *           out_total_rows = rows of the upsampled cloud before the last filter, out_kept_rows = after it.
+ *   _next:  sweep 2 -- the next chunk's own rows are emitted again, classified by their stored distance and compacted:
+ *           *out_count survivors in key order, fetched with pcp_mls_fetch (out_index refers to the uploaded cloud); 0 after
+ *           the last chunk.  The concatenation over the chunks is what pcp_cloud_smooth returns when the cloud fits one result.
+ * chunk_capacity: most voxels per chunk, own rows (>= 4096; every plane of the voxel grid must fit). */
+int pcp_cloud_smooth_stream_begin(pcp_context *ctx, const pcp_mls_params *p, int64_t chunk_capacity, int64_t *out_total_rows,
+                                  int64_t *out_kept_rows, int32_t *out_chunks);
+int pcp_cloud_smooth_stream_next(pcp_context *ctx, int64_t *out_count);
+/* diagnostic of the last pcp_cloud_smooth_stream_begin: out[0] halo in planes (as finally used, the widest), [1] chunks redone
+ * with a wider halo, [2] threshold of the last filter, [3] largest |x displacement| of a row from its voxel (m),
+ * [4] smallest margin of any chunk (m; > [3] proves the halo), [5] rows computed including halos. */
+int pcp_cloud_smooth_stream_stats(pcp_context *ctx, double out[6]);
 /* pcl::StatisticalOutlierRemoval (k, std_mul) keep mask of the uploaded cloud,
  * cloudSmooth.cpp:109-116,160-164.
  * The smoothing entry points (pcp_sor, pcp_mls_process[_shard], pcp_cloud_smooth, pcp_close_pairs) need finite

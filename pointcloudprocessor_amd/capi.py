@@ -442,6 +442,27 @@ class Context:
         self._check(self.lib.pcp_mls_stream_next(self.h, C.byref(m)))
         return m.value
 
+    def cloud_smooth_stream_begin(self, params: "MLSParams", chunk_capacity: int):
+        """CloudSmooth::process whole, its last two stages streamed (pcp_cloud_smooth_stream_begin): (rows of the upsampled
+        cloud, rows the trailing outlier removal keeps, chunks)."""
+        total, kept = C.c_int64(), C.c_int64()
+        chunks = C.c_int32()
+        self._check(self.lib.pcp_cloud_smooth_stream_begin(self.h, C.byref(params), C.c_int64(chunk_capacity), C.byref(total),
+                                                           C.byref(kept), C.byref(chunks)))
+        return total.value, kept.value, chunks.value
+
+    def cloud_smooth_stream_next(self) -> int:
+        """Survivors of the next chunk (fetch them with mls_fetch); 0 after the last one."""
+        m = C.c_int64()
+        self._check(self.lib.pcp_cloud_smooth_stream_next(self.h, C.byref(m)))
+        return m.value
+
+    def cloud_smooth_stream_stats(self) -> dict:
+        out = (C.c_double * 6)()
+        self._check(self.lib.pcp_cloud_smooth_stream_stats(self.h, out))
+        return {"halo_planes": int(out[0]), "chunks_redone": int(out[1]), "threshold": float(out[2]),
+                "max_displacement_m": float(out[3]), "min_margin_m": float(out[4]), "rows_computed": int(out[5])}
+
     def mls_stream_seek(self, chunk: int):
         self._check(self.lib.pcp_mls_stream_seek(self.h, C.c_int32(chunk)))
 

@@ -675,6 +675,9 @@ void pcp_destroy(pcp_context *ctx) {
   ctx->g_xyz.release();
   ctx->m_tmp.release();
   ctx->s_dist.release();
+  ctx->css_dist.release();
+  ctx->s_kth.release();
+  ctx->css_words.release();
   ctx->m_state.release();
   ctx->m_flag.release();
   ctx->intensity.release();

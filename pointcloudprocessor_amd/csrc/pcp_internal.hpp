@@ -271,6 +271,14 @@ struct pcp_context {
   std::vector<uint8_t> vgd_blob;
   std::vector<int64_t> vgd_chunks;
   int64_t vgd_next = -1;
+  // pcp_cloud_smooth_stream_*: the whole chain with the trailing outlier removal over the chunked emission (pcp_mls.hip
+  // SmoothStream; per chunk: first plane, last plane, voxels, first result row, result rows)
+  std::vector<uint8_t> css_blob;
+  std::vector<int64_t> css_chunks;
+  int64_t css_next = -1;
+  pcp::DevBuf<float> css_dist;      // mean kNN distance of EVERY row of the dilated cloud (4 B x ~3.8e9 at C3)
+  pcp::DevBuf<float> s_kth;         // per row of a chunk: bound of the squared distance to its (k + 1)-th nearest
+  pcp::DevBuf<uint32_t> css_words;  // device scalars of the stream (max displacement, margins, counts)
   double sor_redo_fraction = 0.0;  // diagnostic: share of points the SOR selection kernel handed to the heap kernel
 
   // NID stage (section 8 f1): per-point intensity, per-keyframe culled clouds in camera

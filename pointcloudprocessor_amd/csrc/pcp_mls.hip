@@ -1007,6 +1007,7 @@ struct VoxelEmitArgs {
   float *xyz, *normal, *curv;
   int32_t *index;
   uint8_t *valid;
+  uint32_t *max_dx;  // nullable: max over the emitted points of |x of the point - x of its voxel position| (bits of a float >= 0)
 };
 
 // the occupied voxels of bitmap words [word_base, word_base + words) in key order: a workgroup per tile of kScanTile words,
@@ -1041,9 +1042,8 @@ __global__ __launch_bounds__(kScanBlock) void k_voxel_expand(const uint32_t *__r
 
 // one lane per occupied voxel (consecutive lanes = consecutive keys = neighbouring voxels of one z-row, so the
 // nearest-point searches of a wavefront read the same cells)
-__global__ __launch_bounds__(kMB) void k_voxel_emit(VoxelEmitArgs a) {
-  const int64_t out = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
-  if (out >= a.total) return;
+// (returns |x of the emitted point - x of its voxel position|, 0 for a voxel without output)
+__device__ __forceinline__ float voxel_emit_one(const VoxelEmitArgs &a, int64_t out) {
   const int64_t L = a.vox[out];
   const int32_t iz = static_cast<int32_t>(L % a.v.NZ);
   const int64_t q = L / a.v.NZ;
@@ -1108,6 +1108,21 @@ __global__ __launch_bounds__(kMB) void k_voxel_emit(VoxelEmitArgs a) {
     a.index[out] = best;
   }
   a.valid[out] = ok ? 1 : 0;
+  float d = ok ? fabsf(a.xyz[3 * out] - px) : 0.0f;
+  if (!(d == d)) d = INFINITY;  // a NaN position: no bound
+  return d;
+}
+
+__global__ __launch_bounds__(kMB) void k_voxel_emit(VoxelEmitArgs a) {
+  const int64_t out = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  const float d = out < a.total ? voxel_emit_one(a, out) : 0.0f;
+  if (a.max_dx) {
+    // how far (along x, the axis the streamed chain cuts the key order by) the projection moved a point from its voxel: the
+    // maximum over the launch (every lane takes part in the reduction)
+    uint32_t b = __float_as_uint(d);
+    for (int o = 32; o >= 1; o >>= 1) b = max(b, static_cast<uint32_t>(__shfl_xor(static_cast<int>(b), o, 64)));
+    if ((threadIdx.x & 63) == 0 && b) atomicMax(a.max_dx, b);
+  }
 }
 
 // in-place style compaction of the voxel outputs when some voxels were dropped
@@ -1187,7 +1202,11 @@ __global__ __launch_bounds__(kSorBlock) void k_sor_mean_distance(const float *__
                                                                  const int32_t *__restrict__ start, int64_t n, GridDesc g,
                                                                  int32_t mean_k, float *__restrict__ distances,
                                                                  const int32_t *__restrict__ list, int64_t list_n,
-                                                                 const uint8_t *__restrict__ only_flagged) {
+                                                                 const uint8_t *__restrict__ only_flagged,
+                                                                 float *__restrict__ kth = nullptr) {
+  // kth (nullable, all three distance kernels): an upper bound of the SQUARED distance to the (mean_k + 1)-th nearest point,
+  // under the index `distances` uses -- how far the neighbourhood of the point reaches (the streamed chain checks it against
+  // the halo of its chunks)
   extern __shared__ float sor_heap[];
   // list == nullptr: every point; else only the cell-sorted positions named by the list (k_sor_select's leftovers),
   // and of those only the ones k_sor_wave left flagged (only_flagged[j] == 2) when that array is given
@@ -1250,6 +1269,7 @@ __global__ __launch_bounds__(kSorBlock) void k_sor_mean_distance(const float *__
   }
   if (size > 0) sum -= static_cast<double>(sqrtf(smallest));
   distances[remap ? remap[order[j]] : order[j]] = static_cast<float>(sum / static_cast<double>(mean_k));
+  if (kth) kth[remap ? remap[order[j]] : order[j]] = size == k ? heap[0] : INFINITY;  // the heap's root: the largest of the k + 1
 }
 
 // Selection without a heap (the common case), one wavefront per 64 consecutive cell-sorted points.
@@ -1296,7 +1316,8 @@ __global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(PCP_SE
                                                          const int32_t *__restrict__ remap,
                                                          const int32_t *__restrict__ start, int64_t n, GridDesc g,
                                                          int32_t mean_k, float *__restrict__ distances,
-                                                         uint8_t *__restrict__ redo, int64_t j_begin, int64_t j_end) {
+                                                         uint8_t *__restrict__ redo, int64_t j_begin, int64_t j_end,
+                                                         float *__restrict__ kth) {
   // [j_begin, j_end): the slab of the cell order this launch covers (the whole cloud, or one GPU's share: pcp_sor_partial)
 #pragma clang fp contract(off)
   __shared__ uint32_t sel_lds[kSelLdsWords];
@@ -1589,7 +1610,11 @@ __global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(PCP_SE
       members[at * kSelWave + lane] = FLT_MAX;
     }
     sum -= static_cast<double>(sqrt_rn(smallest));  // hit 0 of nearestKSearch(k + 1) is the query itself
-    if (live && !tiny) distances[remap ? remap[order[j]] : order[j]] = static_cast<float>(sum / static_cast<double>(mean_k));
+    if (live && !tiny) {
+      const int32_t at_i = remap ? remap[order[j]] : order[j];
+      distances[at_i] = static_cast<float>(sum / static_cast<double>(mean_k));
+      if (kth) kth[at_i] = limit2;  // the k + 1 nearest were found inside the ball of one cell
+    }
   }
   // 1: the ball of one cell holds too few points (k_sor_wave starts with two cells); 3: any other reason
   if (live) redo[j] = sparse ? 1 : ((bad || tiny) ? 3 : 0);
@@ -1618,7 +1643,7 @@ __global__ __launch_bounds__(kSelWave) void k_sor_wave(const float *__restrict__
                                                        const int32_t *__restrict__ start, int64_t n, GridDesc g,
                                                        int32_t mean_k, float *__restrict__ distances,
                                                        uint8_t *__restrict__ redo, const int32_t *__restrict__ list,
-                                                       int64_t list_n) {
+                                                       int64_t list_n, float *__restrict__ kth) {
 #pragma clang fp contract(off)
   __shared__ float cache[kWsCap];
   const int lane = threadIdx.x;
@@ -1817,6 +1842,9 @@ __global__ __launch_bounds__(kSelWave) void k_sor_wave(const float *__restrict__
   sum -= static_cast<double>(sqrtf(smallest));  // hit 0 of nearestKSearch(k + 1) is the query itself
   if (lane == 0) {
     distances[remap ? remap[order[j]] : order[j]] = static_cast<float>(sum / static_cast<double>(mean_k));
+    // (every cached value is below T0, and at least k of them were: the k + 1 nearest lie within sqrt(T0); a cloud of fewer
+    // than k points: no bound needed, every point was seen -- T0 is then +inf anyway)
+    if (kth) kth[remap ? remap[order[j]] : order[j]] = T0;
     redo[j] = 0;
   }
 }
@@ -2388,7 +2416,8 @@ static int vgd_prepare(pcp_context *ctx, const CloudView &cv, const pcp_mls_para
 }
 
 // the voxels of bitmap words [word0, word1) (word0 a multiple of kScanTile), `count` of them: results in ctx->mls_*
-static int vgd_emit(pcp_context *ctx, const VgdStream &S, int64_t word0, int64_t word1, int64_t count, int64_t *out_m) {
+static int vgd_emit(pcp_context *ctx, const VgdStream &S, int64_t word0, int64_t word1, int64_t count, int64_t *out_m,
+                    uint32_t *max_dx = nullptr) {
   const size_t st = static_cast<size_t>(count);
   size_t free_b = 0, total_b = 0;
   PCP_HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
@@ -2437,6 +2466,7 @@ static int vgd_emit(pcp_context *ctx, const VgdStream &S, int64_t word0, int64_t
     e.curv = ctx->mls_curv.p;
     e.index = ctx->mls_index.p;
     e.valid = ctx->m_flag.p;
+    e.max_dx = max_dx;
     {
       LaunchTimer t(ctx, PCP_K_MLS_VOXEL);
       hipLaunchKernelGGL(k_scan_tile_sums, dim3(scan_grid(tiles2)), dim3(kScanBlock), 0, ctx->stream, tile_first, tiles, level2);
@@ -2594,6 +2624,17 @@ static int check_mls_params(pcp_context *ctx, const pcp_mls_params *p) {
   return PCP_OK;
 }
 
+// the grid the emission of the dilated voxels searches the nearest input point in (see mls_run); leaves *g alone when the
+// fit's own grid serves (PCP_VGD_GRID=fit, or cells of 2 dmax would not be finer)
+static int emission_grid(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *p, GridDesc *g) {
+  const char *ge = std::getenv("PCP_VGD_GRID");
+  if (ge && ge[0] == 'f') return PCP_OK;
+  const float dmax = static_cast<float>(1.7321 * (p->vgd_iterations + 1) * static_cast<double>(p->vgd_voxel_size) * 1.01 + 1e-6);
+  const float cell_emit = 2.0f * dmax;  // measured at C3: 439 ms of emission (1.5 dmax: 449, 3: 474, 1: 604; the fit's grid: 543)
+  if (cell_emit < static_cast<float>(p->search_radius)) return build_grid(ctx, cv, cell_emit, cell_emit, g);
+  return PCP_OK;
+}
+
 // MovingLeastSquares::process on a cloud view; results in ctx->mls_* (index = view index)
 // keep_rows: leave the fitted rows in ctx->m_tmp (7 floats at the view index mls_index names) instead of gathering them
 // into the result arrays -- pcp_cloud_smooth picks the survivors of its last filter straight from there
@@ -2602,6 +2643,8 @@ static int mls_run(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *
                    int32_t slab = 0, int32_t n_slabs = 1) {
   const int64_t n = cv.n;
   ctx->mls_count = 0;
+  ctx->vgd_next = -1;  // a stream of an earlier call rests on the grid and the fits this call replaces
+  ctx->css_next = -1;
   if (out_count) *out_count = 0;
   if (n == 0) return PCP_OK;
   const size_t sn = static_cast<size_t>(n);
@@ -2654,14 +2697,7 @@ static int mls_run(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *
     // dilation, < 9 mm for the reference's 1 mm x 4): the fit's own grid (3 cm cells) makes that ~85 candidates per voxel,
     // a grid with cells of 2 dmax ~25 -- the fit is done (its results sit under the input indices), so the cell tables are
     // rebuilt for the emission.  PCP_VGD_GRID=fit keeps the fit's grid (results identical).
-    const char *ge = std::getenv("PCP_VGD_GRID");
-    if (!(ge && ge[0] == 'f')) {
-      const float dmax = static_cast<float>(1.7321 * (p->vgd_iterations + 1) * static_cast<double>(p->vgd_voxel_size) * 1.01 + 1e-6);
-      const float cell_emit = 2.0f * dmax;  // measured at C3: 439 ms of emission (1.5 dmax: 449, 3: 474, 1: 604; the fit's grid: 543)
-      if (cell_emit < static_cast<float>(p->search_radius)) {
-        if ((rc = build_grid(ctx, cv, cell_emit, cell_emit, &g)) != PCP_OK) return rc;
-      }
-    }
+    if ((rc = emission_grid(ctx, cv, p, &g)) != PCP_OK) return rc;
   }
   if (p->upsampling == 3 && stream_capacity > 0) {
     // pcp_mls_stream_begin: count the voxel set and cut its key range into chunks (whole strips of the brick form, whole
@@ -2699,10 +2735,11 @@ static int mls_run(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *
 // k_sor_stats); `classify` false stops after the chunk sums (they sit in ctx->m_sums from double 4 on).
 static int sor_classify(pcp_context *ctx, int64_t n, const int32_t *remap, double std_mul, int64_t j_begin, int64_t j_end);
 static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double std_mul, bool view_order = false,
-                   int32_t slab = 0, int32_t n_slabs = 1, bool classify = true) {
+                   int32_t slab = 0, int32_t n_slabs = 1, bool classify = true, float *kth = nullptr) {
   const int32_t *remap = view_order ? nullptr : cv.remap;
   const int64_t n = cv.n;
   if (n == 0) return PCP_OK;
+  ctx->vgd_next = -1;  // (pcp_mls_stream_next searches the grid this call rebuilds; pcp_cloud_smooth_stream_* rebuild theirs per chunk)
   const int64_t n_chunks = div_up(n, kSorChunk);
   const int64_t c0 = n_chunks * slab / n_slabs, c1 = n_chunks * (slab + 1) / n_slabs;
   const int64_t q_begin = c0 * kSorChunk, q_end = std::min<int64_t>(c1 * kSorChunk, n);  // places of the cell order
@@ -2788,7 +2825,7 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
       hipLaunchKernelGGL(one_descriptor ? k_sor_select<true> : k_sor_select<false>,
                          dim3(static_cast<uint32_t>(div_up(q_end - q_begin, kSelWave))), dim3(kSelWave), 0, ctx->stream,
                          ctx->g_xyz.p, ctx->g_xyz.p + plane, ctx->g_xyz.p + 2 * plane, ctx->g_order.p, remap,
-                         ctx->g_start.p, n, g, mean_k, dist, ctx->m_flag.p, q_begin, q_end);
+                         ctx->g_start.p, n, g, mean_k, dist, ctx->m_flag.p, q_begin, q_end, kth);
       PCP_HIP_TRY(ctx, hipGetLastError());
     }
     int64_t redo = 0;
@@ -2803,11 +2840,11 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
       if (wave)
         hipLaunchKernelGGL(k_sor_wave, dim3(static_cast<uint32_t>(redo)), dim3(kSelWave), 0, ctx->stream, ctx->g_xyz.p,
                            ctx->g_xyz.p + plane, ctx->g_xyz.p + 2 * plane, ctx->g_order.p, remap, ctx->g_start.p, n, g, mean_k,
-                           dist, ctx->m_flag.p, ctx->s_cell.p, redo);
+                           dist, ctx->m_flag.p, ctx->s_cell.p, redo, kth);
       hipLaunchKernelGGL(k_sor_mean_distance, dim3(static_cast<uint32_t>(div_up(redo, kSorBlock))), dim3(kSorBlock), heap_lds,
                          ctx->stream, ctx->g_xyz.p, ctx->g_xyz.p + plane, ctx->g_xyz.p + 2 * plane, ctx->g_order.p,
                          remap, ctx->g_start.p, n, g, mean_k, dist, ctx->s_cell.p, redo,
-                         wave ? ctx->m_flag.p : static_cast<const uint8_t *>(nullptr));
+                         wave ? ctx->m_flag.p : static_cast<const uint8_t *>(nullptr), kth);
       PCP_HIP_TRY(ctx, hipGetLastError());
     }
   } else {
@@ -2816,7 +2853,7 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
     hipLaunchKernelGGL(k_sor_mean_distance, dim3(static_cast<uint32_t>(div_up(n, kSorBlock))), dim3(kSorBlock), heap_lds,
                        ctx->stream, ctx->g_xyz.p, ctx->g_xyz.p + plane, ctx->g_xyz.p + 2 * plane, ctx->g_order.p,
                        remap, ctx->g_start.p, n, g, mean_k, dist, static_cast<const int32_t *>(nullptr), int64_t(0),
-                       static_cast<const uint8_t *>(nullptr));
+                       static_cast<const uint8_t *>(nullptr), kth);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   {
@@ -2842,6 +2879,107 @@ static int sor_classify(pcp_context *ctx, int64_t n, const int32_t *remap, doubl
                        remap, j_begin, j_end, threshold, ctx->m_flag.p);
   PCP_HIP_TRY(ctx, hipGetLastError());
   return PCP_OK;
+}
+
+
+// ---- pcp_cloud_smooth_stream_*: the trailing StatisticalOutlierRemoval over the chunked voxel dilation ----
+
+// (sum, sum of fp32 squares) of d[0, n) per chunk of kSorChunk consecutive ROWS, the arithmetic and the tree of k_sor_stats
+__global__ __launch_bounds__(kMB) void k_rows_stats(const float *__restrict__ d, int64_t n, double *__restrict__ partial) {
+  __shared__ double sh[2][kMB / 64];
+  const int64_t chunk = blockIdx.x;
+  const int64_t lo = chunk * kSorChunk, hi = min(lo + kSorChunk, n);
+  double s = 0.0, q = 0.0;
+  for (int64_t j = lo + threadIdx.x; j < hi; j += kMB) {
+    const float v = d[j];
+    s += static_cast<double>(v);
+    q += static_cast<double>(__fmul_rn(v, v));
+  }
+  for (int o = 32; o >= 1; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    q += __shfl_xor(q, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sh[0][threadIdx.x >> 6] = s;
+    sh[1][threadIdx.x >> 6] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ts = 0.0, tq = 0.0;
+    for (int k = 0; k < kMB / 64; ++k) {
+      ts += sh[0][k];
+      tq += sh[1][k];
+    }
+    partial[2 * chunk] = ts;
+    partial[2 * chunk + 1] = tq;
+  }
+}
+
+// keep flags of rows [0, m) by their stored distance (the rule of k_sor_classify); optionally only counts the survivors
+__global__ __launch_bounds__(kMB) void k_rows_classify(const float *__restrict__ d, int64_t m, const double *__restrict__ threshold,
+                                                       uint8_t *__restrict__ keep, unsigned long long *__restrict__ count) {
+  int64_t i = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  unsigned long long mine = 0;
+  for (; i < m; i += static_cast<int64_t>(gridDim.x) * kMB) {
+    const bool k = !(static_cast<double>(d[i]) > *threshold);
+    if (keep) keep[i] = k ? 1 : 0;
+    mine += k ? 1ull : 0ull;
+  }
+  if (count) {
+    for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(count, mine);
+  }
+}
+
+// order-preserving map of a float onto unsigned integers (negative margins included)
+__device__ __forceinline__ uint32_t float_key(float f) {
+  const uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+inline float float_of_key(uint32_t k) {
+  const uint32_t b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  float f;
+  std::memcpy(&f, &b, 4);
+  return f;
+}
+
+// The smallest margin of a chunk's own rows [r0, r1) of the emitted cloud (xyz interleaved): how far the ball of a row --
+// centre x, radius sqrt(kth) -- stays from the first plane the emission did NOT hold on either side (x_lo / x_hi = the voxel
+// positions of those planes; use_lo / use_hi: there is such a plane).  A row of a missing plane lies within `max displacement`
+// of its voxel position, so a margin above that proves every neighbour of every row was present.
+__global__ __launch_bounds__(kMB) void k_rows_margin(const float *__restrict__ xyz, const float *__restrict__ kth, int64_t r0, int64_t r1,
+                                                     double x_lo, double x_hi, int use_lo, int use_hi, uint32_t *__restrict__ min_key) {
+  float m = INFINITY;
+  for (int64_t i = r0 + static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x; i < r1; i += static_cast<int64_t>(gridDim.x) * kMB) {
+    const double x = static_cast<double>(xyz[3 * i]);
+    const double r = sqrt(static_cast<double>(kth[i])) * (1.0 + 1.0e-6);
+    double mm = INFINITY;
+    if (use_lo) mm = fmin(mm, (x - r) - x_lo);
+    if (use_hi) mm = fmin(mm, x_hi - (x + r));
+    if (!(mm == mm)) mm = -INFINITY;  // NaN: no proof
+    m = fminf(m, __double2float_rd(mm));
+  }
+  uint32_t k = float_key(m);
+  for (int o = 32; o >= 1; o >>= 1) k = min(k, static_cast<uint32_t>(__shfl_xor(static_cast<int>(k), o, 64)));
+  if ((threadIdx.x & 63) == 0) atomicMin(min_key, k);
+}
+
+struct SmoothStream {  // plain data, kept in ctx->css_blob between pcp_cloud_smooth_stream_begin and _next
+  pcp_mls_params p;
+  VgdStream S;
+  CloudView cv1;  // the survivors of the first filter (planes in ctx->c_xyz)
+  int64_t total_rows, kept_rows, rows_computed;
+  double threshold, max_dx, min_margin;
+  int32_t halo, redone;
+};
+
+// the grid the emission searches, rebuilt (the outlier removal of a chunk overwrites it): the same call sequence as mls_run's
+static int stream_grid(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *p, GridDesc *g) {
+  const char *ge = std::getenv("PCP_VGD_GRID");
+  const float dmax = static_cast<float>(1.7321 * (p->vgd_iterations + 1) * static_cast<double>(p->vgd_voxel_size) * 1.01 + 1e-6);
+  const float cell_emit = 2.0f * dmax;
+  if (!(ge && ge[0] == 'f') && cell_emit < static_cast<float>(p->search_radius)) return build_grid(ctx, cv, cell_emit, cell_emit, g);
+  return build_grid(ctx, cv, static_cast<float>(p->search_radius) * 1.001f, static_cast<float>(p->search_radius), g);
 }
 
 // bounding box of three device planes -> view
@@ -2878,6 +3016,40 @@ static int view_of(pcp_context *ctx, const float *x, const float *y, const float
     cv->mn[a] = decode(box[a * kBoxStride]);
     cv->mx[a] = decode(box[(3 + a) * kBoxStride]);
   }
+  return PCP_OK;
+}
+
+// The first StatisticalOutlierRemoval of CloudSmooth::process (cloudSmooth.cpp:109-116) and its survivors as a new device
+// cloud (planes in ctx->c_xyz; ctx->c_index[i] = the caller's index of point i of that cloud).  The intermediate clouds stay
+// in the order of the view they come from (the Morton-ordered copy of the upload): their grids are then built from
+// spatially ordered input (cell histogram, scatter and in-cell ordering touch neighbouring memory: -1.2 ms per chain
+// against clouds in the caller's order); the caller's order comes back in the last compaction.
+static int smooth_first_filter(pcp_context *ctx, const pcp_mls_params *p, const CloudView &cv0, CloudView *out_cv1, int64_t *out_n1) {
+  int rc;
+  *out_n1 = 0;
+  if ((rc = sor_run(ctx, cv0, p->sor_mean_k, p->sor_std_mul, /*view_order=*/true)) != PCP_OK) return rc;
+  PCP_HIP_TRY(ctx, ctx->c_index.ensure(2 * (static_cast<size_t>(cv0.n) + 4)));
+  int32_t *c_pos = ctx->c_index.p + static_cast<size_t>(cv0.n) + 4;  // view positions of the survivors
+  int64_t n1 = 0;
+  if ((rc = compact_flags(ctx, ctx->m_flag.p, cv0.n, c_pos, cv0.n, &n1)) != PCP_OK) return rc;
+  if (n1 == 0) return PCP_OK;
+  const size_t plane1 = (static_cast<size_t>(n1) + 3) & ~size_t(3);
+  PCP_HIP_TRY(ctx, ctx->c_xyz.ensure(3 * plane1 + 4));
+  float *x1 = ctx->c_xyz.p, *y1 = ctx->c_xyz.p + plane1, *z1 = ctx->c_xyz.p + 2 * plane1;
+  hipLaunchKernelGGL(k_gather_view, dim3(blocks_of(n1)), dim3(kMB), 0, ctx->stream, cv0.x, cv0.y, cv0.z, cv0.remap, c_pos, n1,
+                     x1, y1, z1, ctx->c_index.p);  // c_index: the caller's indices of cloud 1
+  PCP_HIP_TRY(ctx, hipGetLastError());
+  // cloud 1 is a subset of the upload: without upsampling the upload's box serves (any enclosing box gives the same grid
+  // searches); the voxel dilation counts its voxels from the cloud's own box (getMinMax3D, mls.hpp [upstream])
+  CloudView cv1 = cv0;
+  cv1.x = x1;
+  cv1.y = y1;
+  cv1.z = z1;
+  cv1.n = n1;
+  cv1.remap = nullptr;
+  if (p->upsampling != 0 && (rc = view_of(ctx, x1, y1, z1, n1, &cv1)) != PCP_OK) return rc;
+  *out_cv1 = cv1;
+  *out_n1 = n1;
   return PCP_OK;
 }
 
@@ -3105,31 +3277,11 @@ int pcp_cloud_smooth(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_cou
   if (out_count) *out_count = 0;
   const CloudView cv0 = uploaded_view(ctx);
   if (cv0.n == 0) return PCP_OK;
-  // 1st SOR (cloudSmooth.cpp:109-116) and the surviving points as a new device cloud.  The intermediate clouds stay in
-  // the order of the view they come from (the Morton-ordered copy of the upload): their grids are then built from
-  // spatially ordered input (cell histogram, scatter and in-cell ordering touch neighbouring memory: -1.2 ms per chain
-  // against clouds in the caller's order); the caller's order comes back in the last compaction.
-  if ((rc = sor_run(ctx, cv0, p->sor_mean_k, p->sor_std_mul, /*view_order=*/true)) != PCP_OK) return rc;
-  PCP_HIP_TRY(ctx, ctx->c_index.ensure(2 * (static_cast<size_t>(cv0.n) + 4)));
-  int32_t *c_pos = ctx->c_index.p + static_cast<size_t>(cv0.n) + 4;  // view positions of the survivors
+  CloudView cv1;
   int64_t n1 = 0;
-  if ((rc = compact_flags(ctx, ctx->m_flag.p, cv0.n, c_pos, cv0.n, &n1)) != PCP_OK) return rc;
+  if ((rc = smooth_first_filter(ctx, p, cv0, &cv1, &n1)) != PCP_OK) return rc;
   if (n1 == 0) return PCP_OK;
-  const size_t plane1 = (static_cast<size_t>(n1) + 3) & ~size_t(3);
-  PCP_HIP_TRY(ctx, ctx->c_xyz.ensure(3 * plane1 + 4));
-  float *x1 = ctx->c_xyz.p, *y1 = ctx->c_xyz.p + plane1, *z1 = ctx->c_xyz.p + 2 * plane1;
-  hipLaunchKernelGGL(k_gather_view, dim3(blocks_of(n1)), dim3(kMB), 0, ctx->stream, cv0.x, cv0.y, cv0.z, cv0.remap, c_pos, n1,
-                     x1, y1, z1, ctx->c_index.p);  // c_index: the caller's indices of cloud 1
-  PCP_HIP_TRY(ctx, hipGetLastError());
-  // cloud 1 is a subset of the upload: without upsampling the upload's box serves (any enclosing box gives the same grid
-  // searches); the voxel dilation counts its voxels from the cloud's own box (getMinMax3D, mls.hpp [upstream])
-  CloudView cv1 = cv0;
-  cv1.x = x1;
-  cv1.y = y1;
-  cv1.z = z1;
-  cv1.n = n1;
-  cv1.remap = nullptr;
-  if (p->upsampling != 0 && (rc = view_of(ctx, x1, y1, z1, n1, &cv1)) != PCP_OK) return rc;
+  int32_t *c_pos = ctx->c_index.p + static_cast<size_t>(cv0.n) + 4;  // (free again: reused for the rows' caller indices)
   // MLS (cloudSmooth.cpp:124-154).  Without upsampling the fitted rows stay where the fit wrote them (7 floats per point
   // of cloud 1): the second filter only needs their positions, and the survivors are picked from there at the end.
   const bool plain = p->upsampling == 0;
@@ -3187,6 +3339,266 @@ int pcp_cloud_smooth(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_cou
   }
   ctx->mls_count = kept;
   if (out_count) *out_count = kept;
+  return PCP_OK;
+}
+
+// ---- the streamed chain (include/pcp_hip.h) ----
+
+namespace pcp {
+
+// Sweep 1 of one chunk: the voxels of planes [ia, ib] emitted together with `H` planes on either side, the mean k-NN
+// distances of every emitted row, the chunk's own rows' distances into css_dist at row0.  *out_rows = the chunk's own rows,
+// *out_margin = how far their neighbourhoods stay from the first missing planes (k_rows_margin), *out_ext_rows = rows computed.
+static int css_sweep1_chunk(pcp_context *ctx, SmoothStream &st, const std::vector<unsigned long long> &planes, int64_t ia, int64_t ib,
+                            int64_t H, int64_t row0, int64_t *out_rows, float *out_margin, int64_t *out_ext_rows) {
+  const int64_t NX = st.S.v.NX, NBY = st.S.NBY;
+  const int64_t ea = std::max<int64_t>(0, ia - H), eb = std::min<int64_t>(NX - 1, ib + H);
+  unsigned long long a = 0, core = 0, ext = 0;
+  for (int64_t ix = ea; ix <= eb; ++ix) {
+    const unsigned long long c = planes[static_cast<size_t>(ix)];
+    ext += c;
+    if (ix < ia) a += c;
+    else if (ix <= ib) core += c;
+  }
+  if (ext >= (1ull << 31) - (1ull << 20))
+    return set_error(ctx, PCP_ERR_RANGE, "pcp_cloud_smooth_stream_begin: a chunk and its halo hold %llu voxels (2^31 is the limit of one "
+                     "emission): use a smaller chunk_capacity", ext);
+  int rc;
+  GridDesc g;
+  if ((rc = stream_grid(ctx, st.cv1, &st.p, &g)) != PCP_OK) return rc;
+  st.S.g = g;
+  int64_t m = 0;
+  if ((rc = vgd_emit(ctx, st.S, ea * NBY, (eb + 1) * NBY, static_cast<int64_t>(ext), &m, ctx->css_words.p)) != PCP_OK) return rc;
+  // the chunk's own rows inside the (compacted, order-preserving) emission: voxels without a valid fit give no row
+  int64_t r0 = 0, r1 = 0;
+  if (a > 0 && (rc = compact_flags(ctx, ctx->m_flag.p, static_cast<int64_t>(a), nullptr, 0, &r0)) != PCP_OK) return rc;
+  if ((rc = compact_flags(ctx, ctx->m_flag.p, static_cast<int64_t>(a + core), nullptr, 0, &r1)) != PCP_OK) return rc;
+  *out_rows = r1 - r0;
+  *out_ext_rows = m;
+  *out_margin = INFINITY;
+  if (r1 == r0) return PCP_OK;
+  const size_t plane2 = (static_cast<size_t>(m) + 3) & ~size_t(3);
+  PCP_HIP_TRY(ctx, ctx->c_xyz2.ensure(3 * plane2 + 4));
+  float *x2 = ctx->c_xyz2.p, *y2 = ctx->c_xyz2.p + plane2, *z2 = ctx->c_xyz2.p + 2 * plane2;
+  hipLaunchKernelGGL(k_deinterleave, dim3(blocks_of(m)), dim3(kMB), 0, ctx->stream, ctx->mls_xyz.p, m, x2, y2, z2);
+  PCP_HIP_TRY(ctx, hipGetLastError());
+  CloudView cv2;
+  if ((rc = view_of(ctx, x2, y2, z2, m, &cv2)) != PCP_OK) return rc;
+  PCP_HIP_TRY(ctx, ctx->s_kth.ensure(static_cast<size_t>(m) + 8));
+  if ((rc = sor_run(ctx, cv2, st.p.sor_mean_k, st.p.sor_std_mul, false, 0, 1, /*classify=*/false, ctx->s_kth.p)) != PCP_OK) return rc;
+  // MLSVoxelGrid::getPosition of the first missing plane on either side (fp32, as k_voxel_emit forms it)
+  const float xl = static_cast<float>(ea - 1) * st.S.v.vs + st.S.v.bminx, xh = static_cast<float>(eb + 1) * st.S.v.vs + st.S.v.bminx;
+  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->css_words.p + 1, 0xff, 4, ctx->stream));
+  hipLaunchKernelGGL(k_rows_margin, dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(r1 - r0, kMB), 4096))), dim3(kMB), 0, ctx->stream,
+                     ctx->mls_xyz.p, ctx->s_kth.p, r0, r1, static_cast<double>(xl), static_cast<double>(xh), ea > 0 ? 1 : 0,
+                     eb < NX - 1 ? 1 : 0, ctx->css_words.p + 1);
+  PCP_HIP_TRY(ctx, hipGetLastError());
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->css_dist.p + row0, ctx->s_dist.p + r0, static_cast<size_t>(r1 - r0) * sizeof(float),
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+  uint32_t key = 0;
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(&key, ctx->css_words.p + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  *out_margin = float_of_key(key);
+  return PCP_OK;
+}
+
+}  // namespace pcp
+
+int pcp_cloud_smooth_stream_begin(pcp_context *ctx, const pcp_mls_params *p, int64_t chunk_capacity, int64_t *out_total_rows,
+                                  int64_t *out_kept_rows, int32_t *out_chunks) {
+  if (!ctx) return PCP_ERR_INVALID;
+  int rc = check_mls_params(ctx, p);
+  if (rc != PCP_OK) return rc;
+  if (p->upsampling != 3) return set_error(ctx, PCP_ERR_INVALID, "pcp_cloud_smooth_stream_begin: upsampling must be VOXEL_GRID_DILATION (3)");
+  if (chunk_capacity < 4096 || chunk_capacity >= (int64_t(1) << 31))
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_cloud_smooth_stream_begin: chunk_capacity must be in [4096, 2^31)");
+  if (!ctx->xyz.p) return set_error(ctx, PCP_ERR_STATE, "pcp_cloud_smooth_stream_begin: no cloud uploaded");
+  if (int rcf = require_finite_cloud(ctx, "pcp_cloud_smooth_stream_begin")) return rcf;
+  if (p->sor_mean_k < 1 || p->sor_mean_k > 254)
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_cloud_smooth_stream_begin: sor_mean_k %d out of range (1..254)", p->sor_mean_k);
+  PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ctx->mls_count = 0;
+  ctx->css_next = -1;
+  ctx->css_chunks.clear();
+  ctx->sor_distances_live = false;
+  ctx->sor_partial_slab = ctx->sor_partial_slabs = -1;
+  if (out_total_rows) *out_total_rows = 0;
+  if (out_kept_rows) *out_kept_rows = 0;
+  if (out_chunks) *out_chunks = 0;
+  SmoothStream st{};
+  st.p = *p;
+  const CloudView cv0 = uploaded_view(ctx);
+  auto publish = [&]() {
+    ctx->css_blob.assign(reinterpret_cast<const uint8_t *>(&st), reinterpret_cast<const uint8_t *>(&st) + sizeof(st));
+    ctx->css_next = 0;
+  };
+  if (cv0.n == 0) {
+    publish();
+    return PCP_OK;
+  }
+  int64_t n1 = 0;
+  if ((rc = smooth_first_filter(ctx, p, cv0, &st.cv1, &n1)) != PCP_OK) return rc;
+  if (n1 == 0) {
+    publish();
+    return PCP_OK;
+  }
+  // the fits and the dilated voxel set (counted per plane of the first axis), as pcp_mls_stream_begin leaves them
+  int64_t total_voxels = 0;
+  // (the strip-wise chunk plan of that call is not used -- the chain cuts by whole planes --: its capacity is set so that
+  // the brick form is never left for a strip's sake)
+  if ((rc = mls_run(ctx, st.cv1, p, &total_voxels, 0, -1, false, (int64_t(1) << 31) - 1)) != PCP_OK) return rc;
+  if (ctx->vgd_blob.size() != sizeof(VgdStream)) return set_error(ctx, PCP_ERR_STATE, "pcp_cloud_smooth_stream_begin: no voxel set");
+  std::memcpy(&st.S, ctx->vgd_blob.data(), sizeof(VgdStream));
+  ctx->vgd_next = -1;  // (that stream's own chunk plan is not used)
+  if (!st.S.bricks)
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_cloud_smooth_stream_begin: the voxel set is in its dense form (PCP_VGD_DENSE=1, or a grid taller "
+                     "than the brick form handles); the streamed chain cuts the brick form by planes");
+  const int64_t NX = st.S.v.NX;
+  std::vector<unsigned long long> planes(static_cast<size_t>(NX));
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(planes.data(), ctx->v_plane.p, planes.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  // chunks = maximal runs of whole planes that hold at most chunk_capacity voxels
+  std::vector<int64_t> &ch = ctx->css_chunks;  // per chunk: ia, ib, voxels, row0, rows
+  {
+    int64_t ia = -1;
+    unsigned long long cnt = 0;
+    for (int64_t ix = 0; ix < NX; ++ix) {
+      const unsigned long long c = planes[static_cast<size_t>(ix)];
+      if (c > static_cast<unsigned long long>(chunk_capacity))
+        return set_error(ctx, PCP_ERR_RANGE, "pcp_cloud_smooth_stream_begin: plane %lld of the voxel grid holds %llu voxels, more than "
+                         "chunk_capacity %lld", (long long)ix, c, (long long)chunk_capacity);
+      if (ia >= 0 && cnt + c > static_cast<unsigned long long>(chunk_capacity)) {
+        ch.insert(ch.end(), {ia, ix - 1, static_cast<int64_t>(cnt), 0, 0});
+        ia = -1;
+        cnt = 0;
+      }
+      if (c > 0 && ia < 0) ia = ix;
+      cnt += c;
+    }
+    if (ia >= 0 && cnt > 0) ch.insert(ch.end(), {ia, NX - 1, static_cast<int64_t>(cnt), 0, 0});
+  }
+  const size_t n_chunks = ch.size() / 5;
+  PCP_HIP_TRY(ctx, ctx->css_dist.ensure(static_cast<size_t>(total_voxels) + 8));
+  PCP_HIP_TRY(ctx, ctx->css_words.ensure(32));
+  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->css_words.p, 0, 32 * 4, ctx->stream));
+  // halo in planes: twice the reach of the dilation (a row sits within ~1.75 (it + 1) voxels of its voxel position) and the
+  // k-NN radius of the dense upsampled surface, with room; CHECKED below, widened where the check fails
+  int64_t H = 4 * (static_cast<int64_t>(p->vgd_iterations) + 1) + 20;
+  if (const char *he = std::getenv("PCP_CSS_HALO")) H = std::max(1, std::atoi(he));
+  st.halo = static_cast<int32_t>(H);
+  std::vector<float> margin(n_chunks, INFINITY);
+  int64_t row0 = 0;
+  for (size_t c = 0; c < n_chunks; ++c) {
+    int64_t rows = 0, ext_rows = 0;
+    if ((rc = css_sweep1_chunk(ctx, st, planes, ch[5 * c], ch[5 * c + 1], H, row0, &rows, &margin[c], &ext_rows)) != PCP_OK) return rc;
+    ch[5 * c + 3] = row0;
+    ch[5 * c + 4] = rows;
+    row0 += rows;
+    st.rows_computed += ext_rows;
+  }
+  st.total_rows = row0;
+  // every voxel has been emitted as some chunk's own: the largest displacement of a row from its voxel position is final
+  uint32_t dx_bits = 0;
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(&dx_bits, ctx->css_words.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  float max_dx;
+  std::memcpy(&max_dx, &dx_bits, 4);
+  st.max_dx = static_cast<double>(max_dx);
+  st.min_margin = INFINITY;
+  for (size_t c = 0; c < n_chunks; ++c) {
+    int64_t Hc = H;
+    // a margin at or below the displacement: some neighbourhood may reach rows the halo did not hold -- again, wider
+    while (!(static_cast<double>(margin[c]) > st.max_dx * (1.0 + 1e-6) + 1e-9)) {
+      if (Hc >= NX) return set_error(ctx, PCP_ERR_RANGE, "pcp_cloud_smooth_stream_begin: the neighbourhood of a row of chunk %zu has no bound "
+                                     "(margin %g m against a displacement of %g m with every plane emitted)", c, (double)margin[c], st.max_dx);
+      Hc *= 2;
+      int64_t rows = 0, ext_rows = 0;
+      if ((rc = css_sweep1_chunk(ctx, st, planes, ch[5 * c], ch[5 * c + 1], Hc, ch[5 * c + 3], &rows, &margin[c], &ext_rows)) != PCP_OK) return rc;
+      if (rows != ch[5 * c + 4]) return set_error(ctx, PCP_ERR_STATE, "pcp_cloud_smooth_stream_begin: chunk %zu changed its rows", c);
+      st.redone += 1;
+      st.rows_computed += ext_rows;
+      st.halo = static_cast<int32_t>(std::max<int64_t>(st.halo, std::min<int64_t>(Hc, NX)));
+    }
+    if (ch[5 * c + 4] > 0) st.min_margin = std::min(st.min_margin, static_cast<double>(margin[c]));
+  }
+  if (st.total_rows > 0) {
+    // mean + mul * stddev over ALL rows in row order (chunks of kSorChunk rows, fixed trees: the same on every run)
+    const int64_t blocks = div_up(st.total_rows, kSorChunk);
+    PCP_HIP_TRY(ctx, ctx->m_sums.ensure(4 + 2 * static_cast<size_t>(blocks)));
+    hipLaunchKernelGGL(k_rows_stats, dim3(static_cast<uint32_t>(blocks)), dim3(kMB), 0, ctx->stream, ctx->css_dist.p, st.total_rows,
+                       ctx->m_sums.p + 4);
+    hipLaunchKernelGGL(k_sor_threshold, dim3(1), dim3(64), 0, ctx->stream, ctx->m_sums.p + 4, blocks, st.total_rows, p->sor_std_mul,
+                       ctx->m_sums.p);
+    unsigned long long *d_count = reinterpret_cast<unsigned long long *>(ctx->css_words.p + 4);
+    hipLaunchKernelGGL(k_rows_classify, dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(st.total_rows, kMB), 1 << 16))), dim3(kMB), 0,
+                       ctx->stream, ctx->css_dist.p, st.total_rows, ctx->m_sums.p, static_cast<uint8_t *>(nullptr), d_count);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+    unsigned long long kept = 0;
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(&st.threshold, ctx->m_sums.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(&kept, d_count, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    st.kept_rows = static_cast<int64_t>(kept);
+  }
+  publish();
+  if (out_total_rows) *out_total_rows = st.total_rows;
+  if (out_kept_rows) *out_kept_rows = st.kept_rows;
+  if (out_chunks) *out_chunks = static_cast<int32_t>(n_chunks);
+  return PCP_OK;
+}
+
+int pcp_cloud_smooth_stream_next(pcp_context *ctx, int64_t *out_count) {
+  if (!ctx || !out_count) return PCP_ERR_INVALID;
+  *out_count = 0;
+  if (ctx->css_next < 0 || ctx->css_blob.size() != sizeof(SmoothStream))
+    return set_error(ctx, PCP_ERR_STATE, "pcp_cloud_smooth_stream_next: no stream (call pcp_cloud_smooth_stream_begin; any other "
+                     "smoothing call ends a stream)");
+  PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ctx->mls_count = 0;
+  SmoothStream st;
+  std::memcpy(&st, ctx->css_blob.data(), sizeof(st));
+  const std::vector<int64_t> &ch = ctx->css_chunks;
+  // (chunks whose every voxel lacks a valid fit have no rows: skipped)
+  while (static_cast<size_t>(ctx->css_next) * 5 < ch.size() && ch[static_cast<size_t>(ctx->css_next) * 5 + 4] == 0) ctx->css_next += 1;
+  const size_t c = static_cast<size_t>(ctx->css_next);
+  if (c * 5 >= ch.size()) return PCP_OK;  // past the last chunk
+  const int64_t ia = ch[5 * c], ib = ch[5 * c + 1], voxels = ch[5 * c + 2], row0 = ch[5 * c + 3], rows = ch[5 * c + 4];
+  const int64_t next_before = ctx->css_next;
+  int rc;
+  GridDesc g;
+  if ((rc = stream_grid(ctx, st.cv1, &st.p, &g)) != PCP_OK) return rc;  // (build_grid does not go through mls_run: the stream stays)
+  st.S.g = g;
+  int64_t m = 0;
+  if ((rc = vgd_emit(ctx, st.S, ia * st.S.NBY, (ib + 1) * st.S.NBY, voxels, &m)) != PCP_OK) return rc;
+  if (m != rows) return set_error(ctx, PCP_ERR_STATE, "pcp_cloud_smooth_stream_next: chunk %zu emitted %lld rows, sweep 1 saw %lld", c,
+                                  (long long)m, (long long)rows);
+  // source indices back to the uploaded cloud (ctx->c_index: the caller's indices of cloud 1), keep flags by the stored distance
+  double *d_thr = reinterpret_cast<double *>(ctx->css_words.p + 8);
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(d_thr, &st.threshold, 8, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_remap_index, dim3(blocks_of(m)), dim3(kMB), 0, ctx->stream, ctx->mls_index.p, m, ctx->c_index.p);
+  hipLaunchKernelGGL(k_rows_classify, dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(m, kMB), 1 << 16))), dim3(kMB), 0, ctx->stream,
+                     ctx->css_dist.p + row0, m, d_thr, ctx->m_flag.p, static_cast<unsigned long long *>(nullptr));
+  PCP_HIP_TRY(ctx, hipGetLastError());
+  int64_t kept = 0;
+  PCP_HIP_TRY(ctx, ctx->s_cell.ensure(static_cast<size_t>(m) + 4));
+  if ((rc = compact_flags(ctx, ctx->m_flag.p, m, ctx->s_cell.p, m, &kept)) != PCP_OK) return rc;
+  if (kept != m && (rc = compact_results(ctx, ctx->s_cell.p, m, kept)) != PCP_OK) return rc;
+  ctx->mls_count = kept;
+  ctx->css_next = next_before + 1;
+  *out_count = kept;
+  return PCP_OK;
+}
+
+int pcp_cloud_smooth_stream_stats(pcp_context *ctx, double out[6]) {
+  if (!ctx || !out) return PCP_ERR_INVALID;
+  if (ctx->css_blob.size() != sizeof(SmoothStream)) return set_error(ctx, PCP_ERR_STATE, "pcp_cloud_smooth_stream_stats: no stream");
+  SmoothStream st;
+  std::memcpy(&st, ctx->css_blob.data(), sizeof(st));
+  out[0] = st.halo;
+  out[1] = st.redone;
+  out[2] = st.threshold;
+  out[3] = st.max_dx;
+  out[4] = st.min_margin;
+  out[5] = static_cast<double>(st.rows_computed);
   return PCP_OK;
 }
 

@@ -32,6 +32,7 @@
 //     (same optimum, last-digit differences in the printed cost); --enableMLS deals the MLS queries / the dilated voxel
 //     chunks out over the GPUs (MultiCloudSmooth), the two outlier-removal brackets run on GPU 0.
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -51,6 +52,37 @@
 
 namespace fs = std::filesystem;
 using namespace pcp_amd;
+
+// Wall-clock split of a run (PCP_CLI_TIMING=<file>: one JSON object, seconds): where the time of the command line goes --
+// the reference has no such report; `bench.py`'s cli_e2e leg reads it (at scale the ASCII I/O dominates).
+struct PhaseClock {
+  std::vector<std::pair<std::string, double>> phases;
+  std::mutex mu;
+  using clock = std::chrono::steady_clock;
+  static double since(clock::time_point t0) { return std::chrono::duration<double>(clock::now() - t0).count(); }
+  void add(const std::string &name, double s) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &p : phases)
+      if (p.first == name) {
+        p.second += s;
+        return;
+      }
+    phases.emplace_back(name, s);
+  }
+  void write(const char *path, double total) {
+    std::ofstream f(path);
+    f << "{";
+    for (const auto &p : phases) f << "\"" << p.first << "\": " << p.second << ", ";
+    f << "\"total\": " << total << "}\n";
+  }
+};
+static PhaseClock g_clock;
+struct Phase {  // adds its lifetime to a named phase
+  std::string name;
+  PhaseClock::clock::time_point t0 = PhaseClock::clock::now();
+  explicit Phase(const char *n) : name(n) {}
+  ~Phase() { g_clock.add(name, PhaseClock::since(t0)); }
+};
 
 struct Frame {  // FrameData (PCP/include/FrameData.hpp:89-126)
   std::string imagePath, maskImagePath;
@@ -169,6 +201,7 @@ class Processor {
   std::vector<double> T_camera_lidar_optimized;
 
   void loadImagesAndOdometry() {  // :965-1005
+    Phase ph("odometry_s");
     std::ifstream vo(opt.odometryPath);
     std::string line;
     while (std::getline(vo, line)) {
@@ -205,12 +238,16 @@ class Processor {
       mx[a] += 2.0;
     }
     XYZICloud original;
-    if (loadPCDFile(opt.pointCloudPath, original) == -1) throw std::runtime_error("Couldn't read point cloud file.");
+    {
+      Phase ph("pcd_read_s");
+      if (loadPCDFile(opt.pointCloudPath, original) == -1) throw std::runtime_error("Couldn't read point cloud file.");
+    }
     std::cout << "Start crop pcd..." << std::endl;
     // pcl::CropBox with Vector4f(min), Vector4f(max): keep min <= p <= max (fp32 bounds)
     const float fmn[3] = {static_cast<float>(mn[0]), static_cast<float>(mn[1]), static_cast<float>(mn[2])};
     const float fmx[3] = {static_cast<float>(mx[0]), static_cast<float>(mx[1]), static_cast<float>(mx[2])};
     XYZICloud cropped;
+    const auto t_crop = PhaseClock::clock::now();
     for (size_t i = 0; i < original.size(); ++i) {
       const float p[3] = {original.x[i], original.y[i], original.z[i]};
       if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
@@ -223,6 +260,8 @@ class Processor {
     const std::string cropPath = opt.outputPath + "scans-crop.pcd";  // outputPath must end in '/' (:131)
     writeASCII_XYZI(cropPath, cropped.x.data(), cropped.y.data(), cropped.z.data(), cropped.intensity.data(), cropped.size());
     std::cout << "Cropped point cloud saved to: " << cropPath << std::endl;
+    g_clock.add("crop_and_write_ascii_s", PhaseClock::since(t_crop));
+    Phase ph_mls(opt.enableMLS ? "enable_mls_stage_s" : "cloud_move_s");
     if (opt.enableMLS) {
       // CloudSmooth re-reads the ASCII crop it was handed (cloudSmooth.cpp:92): 8 significant digits
       XYZICloud crop8;
@@ -285,6 +324,7 @@ class Processor {
   }
 
   void setupDevice() {
+    Phase ph("device_setup_and_cloud_upload_s");
     if (!gpu) gpu.reset(new MultiDevice(opt.gpus));
     gpu->uploadCloud(cloud.x.data(), cloud.y.data(), cloud.z.data(), static_cast<int64_t>(cloud.size()));
     // image size from the first keyframe image; cull size stays the reference's {4096,3000} (:206,:525)
@@ -348,8 +388,11 @@ class Processor {
     const size_t n = cloud.size();
     std::vector<float> cam(3 * n);
     for (size_t k = 0; k < keyframes.size(); ++k) {
+      const auto t_gpu = PhaseClock::clock::now();
       const std::vector<int32_t> kept = gpu->cull(static_cast<int>(k));
       gpu->cameraCoordinates(static_cast<int>(k), cam);
+      g_clock.add("filtered_dumps_gpu_s", PhaseClock::since(t_gpu));
+      Phase ph("filtered_dumps_write_ascii_s");
       std::vector<float> x(kept.size()), y(kept.size()), z(kept.size()), in(kept.size());
       for (size_t q = 0; q < kept.size(); ++q) {
         const size_t i = static_cast<size_t>(kept[q]);
@@ -372,6 +415,7 @@ class Processor {
   // frame is 37 MB).  The reference decodes one image per keyframe iteration on its one thread.
   void uploadImages(bool adjusted) {
     if (images_uploaded && images_adjusted == adjusted) return;
+    Phase ph_all("images_decode_and_upload_wall_s");  // decoders on the host threads, uploads on this one, overlapped
     gpu->setImageAdjust(adjusted);  // cvtColor(BGR2HSV) ... cvtColor(HSV2BGR), :722-741, fused into the upload
     const size_t n = keyframes.size();
     mask_missing.assign(n, 0);
@@ -394,9 +438,11 @@ class Processor {
           if (stop || next >= n) return;
           k = next++;
         }
+        const auto t_dec = PhaseClock::clock::now();
         Image8 a = read_image_bgr(keyframes[k].imagePath);  // cv::imread, :716
         Image8 b;
         if (enableMaskSegmentation) b = read_image_gray(keyframes[k].maskImagePath);  // cv::IMREAD_GRAYSCALE, :775
+        g_clock.add("images_decode_thread_seconds", PhaseClock::since(t_dec));  // summed over the decoder threads
         {
           std::lock_guard<std::mutex> lk(mu);
           img[k] = std::move(a);
@@ -425,7 +471,10 @@ class Processor {
         std::cout << "Reading image from: " << keyframes[k].imagePath << std::endl;
         if (img[k].empty() || img[k].width != img_w || img[k].height != img_h)
           throw std::runtime_error("Failed to read image from: " + keyframes[k].imagePath);
-        gpu->uploadImage(static_cast<int>(k), img[k].data.data(), static_cast<int64_t>(img[k].width) * 3);
+        {
+          Phase ph_up("images_upload_calls_s");
+          gpu->uploadImage(static_cast<int>(k), img[k].data.data(), static_cast<int64_t>(img[k].width) * 3);
+        }
         if (enableMaskSegmentation) {
           std::cout << "Reading segment mask image from: " << keyframes[k].maskImagePath << std::endl;
           if (!gray[k].empty() && gray[k].width == img_w && gray[k].height == img_h)
@@ -461,8 +510,11 @@ class Processor {
         VisiblePoints v;
         if (mask_missing[k])  // :779-780: message, empty scanInBodyWithRGBandMask -> PCDWriter throws below (exit -2)
           std::cout << "Failed to read image from: " << keyframes[k].maskImagePath << std::endl;
-        else
+        else {
+          Phase ph("frame_visible_gpu_s");
           v = gpu->frameVisible(static_cast<int>(k));
+        }
+        Phase ph_w("rgb_mask_dumps_write_ascii_s");
         const std::string path =
             opt.outputPath + "filtered_pcd/" + std::to_string(keyframes[k].imageTimestamp) + "_rgb-mask" + ".pcd";
         if (writeASCII_XYZRGBMask(path, v.xyz_cam.data(), v.rgb.data(), v.mask.data(), v.index.size()) == -1)
@@ -474,7 +526,11 @@ class Processor {
       }
     }
     std::vector<uint8_t> rgb, has;
-    gpu->colorize(rgb, has);  // smoothColors + removePointsWithNoColor flag
+    {
+      Phase ph("colourise_gpu_s");
+      gpu->colorize(rgb, has);  // smoothColors + removePointsWithNoColor flag
+    }
+    Phase ph_w("final_pcd_write_ascii_s");
     XYZICloud out;
     std::vector<uint8_t> out_rgb;
     for (size_t i = 0; i < cloud.size(); ++i)
@@ -498,6 +554,13 @@ class Processor {
 };
 
 int main(int argc, char **argv) {
+  const auto t_main = PhaseClock::clock::now();
+  struct TimingAtExit {  // also after an exception: the phases reached so far
+    PhaseClock::clock::time_point t0;
+    ~TimingAtExit() {
+      if (const char *path = std::getenv("PCP_CLI_TIMING")) g_clock.write(path, PhaseClock::since(t0));
+    }
+  } timing_at_exit{t_main};
   try {
     const Options o = parse(argc, argv);
     if (o.help) {

@@ -16,7 +16,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert len(names) >= 30 and "pcp_colorize" in names and "pcp_mls_process" in names
     missing = [s for s in names if not hasattr(lib, s)]
     assert not missing, missing
-    assert lib.pcp_abi_version() == 5
+    assert lib.pcp_abi_version() == 6
     assert path.endswith("libpcp_hip.so")
 
 
