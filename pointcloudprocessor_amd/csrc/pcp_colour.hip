@@ -565,7 +565,8 @@ struct TopState {
 };
 
 // kMatch: 0 = match mode read from the camera block, else the mode itself (PCP_MATCH_IDENTITY 1 ... see match_constant)
-// kOneShot: flags == 4 (no top-5 state loaded or stored, packed result written in input order): the usual whole-run call
+// kOneShot: flags == 4 or 12 (no top-5 state loaded or stored; packed result written in input order, or -- bit 8 -- in the
+// sorted order the pass walks, un-permuted by whatever reads it): the usual whole-run call
 template <bool kCommon, int kMatch, bool kOneShot>
 __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict__ x, const float *__restrict__ y,
                                                         const float *__restrict__ z, int64_t n, DevCamera cam_in,
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict_
   // the common configuration walks the cloud order and has no hull bits (both are null then: the host checks)
   const int32_t *__restrict__ tile_order = kCommon ? nullptr : tile_order_in;
   const uint32_t *__restrict__ hull_bits = kCommon ? nullptr : hull_bits_in;
-  const int32_t flags = kOneShot ? 4 : flags_in;
+  const int32_t flags = kOneShot ? (4 | (flags_in & 8)) : flags_in;
   const int64_t j = tile_order ? static_cast<int64_t>(tile_order[blockIdx.x]) * 64 + threadIdx.x
                                : static_cast<int64_t>(xcd_chunked_block()) * kBlock + threadIdx.x;
   const bool live = j < n;
@@ -649,10 +650,13 @@ __global__ __launch_bounds__(kBlock) void k_colour_pass(const float *__restrict_
     st.frame[3 * n + j] = t.f3; st.frame[4 * n + j] = t.f4;
     st.count[j] = t.count;
   }
-  // Packed result straight into input order: a scattered 4-B store per point, each a 32-B partial write in HBM (8x the
-  // bytes: WRITE_SIZE 316 MB for 40 MB of results), but it retires under this VALU-bound kernel for free.  The
-  // alternative (flags & 8: coalesced stores in Morton order + k_unpermute) writes 45 MB and costs 35 us more per step:
-  // the un-permute is a kernel of its own.  PCP_RESULT_UNPERMUTE=1 selects it (results identical).
+  // The packed result.  Straight into input order (flags & 8 clear: PCP_RESULT_UNPERMUTE=0, the form of rounds 2-4) it is a
+  // scattered 4-B store per point, each a 32-B partial write in HBM: WRITE_SIZE 316 MB for 40 MB of results
+  // (profiles/r04_pmc.json) -- it retires under this VALU-bound kernel for free, but it is 8x the bytes.  flags & 8: coalesced
+  // stores in the sorted order the pass walks (40 MB); the un-permutation is then fused into whatever READS the result
+  // (round 5, PCP_RESULT_UNPERMUTE=2; slower, see unpermute_mode): the download (k_unpermute on the COPY stream, beside the next step's passes, then the copy engine),
+  // the byte-splitting kernel of pcp_colorize's outputs, or -- for a caller that asks for the device array -- a kernel of its own.  PCP_RESULT_UNPERMUTE=1: sorted stores + that kernel right after
+  // the pass (45 MB, +35 us per step: the first form of this alternative).  Results identical in all three.
   if (flags & 4) rgba[(flags & 8) ? j : static_cast<int64_t>(perm[j])] = t.finalise();
 }
 
@@ -745,11 +749,13 @@ __global__ __launch_bounds__(kBlock) void k_selftest_div32(DevCamera cam, unsign
 // small utility kernels
 // ---------------------------------------------------------------------------
 // packed result r | g<<8 | b<<16 | has<<24  ->  rgb[3n] (r, g, b) and has[n]
+// inv_perm (nullable): `packed` is in sorted order -- point i's word is packed[inv_perm[i]] (the un-permutation fused in)
 __global__ __launch_bounds__(kBlock) void k_unpack_result(const uint32_t *__restrict__ packed, int64_t n,
-                                                         uint8_t *__restrict__ rgb, uint8_t *__restrict__ has) {
+                                                         uint8_t *__restrict__ rgb, uint8_t *__restrict__ has,
+                                                         const int32_t *__restrict__ inv_perm) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (i >= n) return;
-  const uint32_t v = packed[i];
+  const uint32_t v = packed[inv_perm ? inv_perm[i] : i];
   rgb[3 * i + 0] = static_cast<uint8_t>(v & 0xffu);
   rgb[3 * i + 1] = static_cast<uint8_t>((v >> 8) & 0xffu);
   rgb[3 * i + 2] = static_cast<uint8_t>((v >> 16) & 0xffu);
@@ -1083,10 +1089,18 @@ static int ensure_depth(pcp_context *ctx) {
   return PCP_OK;
 }
 
-static bool unpermute_results() {  // read per call: tests flip it inside one process
+// PCP_RESULT_UNPERMUTE: 0 (default) = the colour pass scatters its result into input order; 1 = sorted stores + an un-permuting
+// kernel right after the pass; 2 = sorted stores, un-permuted by whatever reads the result.  Read per call: tests flip it
+// inside one process.  Measured at C3 in round 5 (100 steps, driver protocol): 0: 1.345 ms per step; 1: 1.56 ms (the gather
+// of 10 M random words is a 0.17 ms kernel); 2: 1.45 ms (the same kernel on the copy stream, beside the next step's passes,
+// then the copy engine; with the kernel writing the pinned buffer over PCIe itself: 2.06 ms).  The un-permutation is 10 M
+// random 4-byte accesses wherever it is put; as scattered stores of the VALU-bound pass it costs 0.045 ms and 8x the bytes.
+static int unpermute_mode() {
   const char *e = std::getenv("PCP_RESULT_UNPERMUTE");
-  return e && e[0] == '1';
+  if (!e || !e[0]) return 0;
+  return e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2);
 }
+static bool unpermute_results() { return unpermute_mode() == 1; }
 
 static int ensure_state(pcp_context *ctx) {
   const size_t sn = static_cast<size_t>(ctx->n);
@@ -1846,12 +1860,15 @@ static int colour_pass_impl(pcp_context *ctx, int32_t frame_begin, int32_t frame
     // (longest-first order at 4096x3000: 1.96 -> 2.18 ms)
     const bool ordered = false;
     const bool common = is_common_camera(ctx->dcam) && !ordered && ctx->cull.cull_mode != PCP_CULL_HPR;
-    const int32_t launch_flags = flags | ((one_shot && unpermute_results()) ? 8 : 0);
+    // (mode 1 writes the scratch buffer a download of mode 2 may still be filling on the copy stream: tests flip the modes)
+    if (one_shot && unpermute_mode() == 1) PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+    const int32_t launch_flags = flags | ((one_shot && unpermute_mode() != 0) ? 8 : 0);
+    ctx->last_pass_sorted = one_shot && unpermute_mode() == 2;  // the result stays in sorted order: end_result marks the buffer
     auto kernel = k_colour_pass<false, 0, false>;
     if (common && ctx->dcam.match_mode == PCP_MATCH_IDENTITY)
-      kernel = launch_flags == 4 ? k_colour_pass<true, 1, true> : k_colour_pass<true, 1, false>;
+      kernel = (launch_flags & ~8) == 4 ? k_colour_pass<true, 1, true> : k_colour_pass<true, 1, false>;
     if (common && ctx->dcam.match_mode == PCP_MATCH_ROUNDTRIP)
-      kernel = launch_flags == 4 ? k_colour_pass<true, 2, true> : k_colour_pass<true, 2, false>;
+      kernel = (launch_flags & ~8) == 4 ? k_colour_pass<true, 2, true> : k_colour_pass<true, 2, false>;
     hipLaunchKernelGGL(kernel, dim3(ordered ? static_cast<uint32_t>(ctx->n_tiles) : blocks_for(ctx->n)),
                        dim3(ordered ? 64 : kBlock), 0, ctx->stream, ctx->sxyz.p, ctx->sxyz.p + plane,
                        ctx->sxyz.p + 2 * plane, ctx->n, ctx->dcam, ctx->frames.p, frame_begin, frame_end, ctx->depth.p,
@@ -1880,12 +1897,15 @@ static int end_result(pcp_context *ctx, uint8_t *out_rgb, uint8_t *out_has) {
   PCP_HIP_TRY(ctx, hipEventRecord(ctx->result_ready[cur], ctx->stream));
   ctx->rgba_cur = cur;
   ctx->colour_result_live = true;
+  ctx->result_sorted[cur] = ctx->last_pass_sorted;  // the producer left the words in sorted order: readers un-permute
+  ctx->last_pass_sorted = false;
   if ((out_rgb || out_has) && n > 0) {
     // split the packed words on the device: 3 + 1 bytes per point cross PCIe, and no host loop over the points
     const size_t sn = static_cast<size_t>(n);
     PCP_HIP_TRY(ctx, ctx->s_keep.ensure(4 * sn + 16));
     uint8_t *d_rgb = ctx->s_keep.p, *d_has = ctx->s_keep.p + 3 * sn;
-    hipLaunchKernelGGL(k_unpack_result, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, dst, n, d_rgb, d_has);
+    hipLaunchKernelGGL(k_unpack_result, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, dst, n, d_rgb, d_has,
+                       ctx->result_sorted[cur] ? ctx->inv_perm.p : static_cast<const int32_t *>(nullptr));
     PCP_HIP_TRY(ctx, hipGetLastError());
     if (out_rgb) PCP_HIP_TRY(ctx, hipMemcpyAsync(out_rgb, d_rgb, 3 * sn, hipMemcpyDeviceToHost, ctx->stream));
     if (out_has) PCP_HIP_TRY(ctx, hipMemcpyAsync(out_has, d_has, sn, hipMemcpyDeviceToHost, ctx->stream));
@@ -1914,8 +1934,9 @@ int pcp_colour_finalise(pcp_context *ctx, uint8_t *out_rgb, uint8_t *out_has, in
     TopState st{ctx->top_score.p, ctx->top_rgb.p, ctx->top_frame.p, ctx->view_count.p};
     LaunchTimer t(ctx, PCP_K_COLOUR);
     const bool un = unpermute_results();
+    ctx->last_pass_sorted = unpermute_mode() == 2;
     hipLaunchKernelGGL(k_finalise, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, n, st, ctx->perm.p,
-                       un ? ctx->rgba_sorted.p : result, un ? 1 : 0);
+                       un ? ctx->rgba_sorted.p : result, (un || ctx->last_pass_sorted) ? 1 : 0);
     if (un)
       hipLaunchKernelGGL(k_unpermute, dim3(blocks_for(div_up(n, 4))), dim3(kBlock), 0, ctx->stream, ctx->rgba_sorted.p,
                          ctx->inv_perm.p, n, result);
@@ -1968,14 +1989,37 @@ int pcp_colorize_from_depth(pcp_context *ctx, uint8_t *out_rgb, uint8_t *out_has
   return end_result(ctx, out_rgb, out_has);
 }
 
+// The current result as a device array in INPUT order (callers that read rgba2[cur] themselves): where the producer left it in
+// sorted order, one un-permuting kernel into the scratch buffer, which then becomes the result buffer.
+static int result_in_input_order(pcp_context *ctx) {
+  const int32_t cur = ctx->rgba_cur;
+  if (!ctx->result_sorted[cur]) return PCP_OK;
+  if (ctx->copy_pending[cur]) {  // a download of this buffer may still be reading it on the copy stream
+    PCP_HIP_TRY(ctx, hipEventSynchronize(ctx->copy_done[cur]));
+    ctx->copy_pending[cur] = false;
+  }
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));  // (... or still writing the scratch)
+  PCP_HIP_TRY(ctx, ctx->rgba_sorted.ensure(static_cast<size_t>(ctx->n) + 4));
+  hipLaunchKernelGGL(k_unpermute, dim3(blocks_for(div_up(ctx->n, 4))), dim3(kBlock), 0, ctx->stream, ctx->rgba2[cur].p,
+                     ctx->inv_perm.p, ctx->n, ctx->rgba_sorted.p);
+  PCP_HIP_TRY(ctx, hipGetLastError());
+  std::swap(ctx->rgba2[cur], ctx->rgba_sorted);
+  ctx->result_sorted[cur] = false;
+  PCP_HIP_TRY(ctx, hipEventRecord(ctx->result_ready[cur], ctx->stream));
+  return PCP_OK;
+}
+
 int pcp_download_result_packed(pcp_context *ctx, uint32_t *out_rgba) {
   if (!ctx) return PCP_ERR_INVALID;
   if (!ctx->colour_result_live)
     return set_error(ctx, PCP_ERR_STATE, "pcp_download_result_packed: no result (call pcp_colorize / pcp_colour_finalise)");
   if (!out_rgba && ctx->n > 0) return set_error(ctx, PCP_ERR_INVALID, "pcp_download_result_packed: NULL output");
-  if (ctx->n > 0)
+  if (ctx->n > 0) {
+    int rc = result_in_input_order(ctx);
+    if (rc != PCP_OK) return rc;
     PCP_HIP_TRY(ctx, hipMemcpyAsync(out_rgba, ctx->rgba2[ctx->rgba_cur].p, static_cast<size_t>(ctx->n) * 4,
                                     hipMemcpyDeviceToHost, ctx->stream));
+  }
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return PCP_OK;
 }
@@ -1987,9 +2031,21 @@ int pcp_download_result_packed_async(pcp_context *ctx, uint32_t *out_rgba) {
   if (!out_rgba && ctx->n > 0) return set_error(ctx, PCP_ERR_INVALID, "pcp_download_result_packed_async: NULL output");
   const int32_t cur = ctx->rgba_cur;
   PCP_HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->result_ready[cur], 0));
-  if (ctx->n > 0)
+  if (ctx->n > 0 && ctx->result_sorted[cur]) {
+    // the result sits in the sorted order the colour pass walks: the un-permutation rides on the copy stream -- a kernel gathers
+    // sorted[inv_perm[i]] into a device scratch in input order (~35 us at 10 M points, beside the next step's passes), the copy
+    // engine takes it from there.  (Measured and left out: the kernel writing the caller's pinned buffer itself over PCIe, in
+    // place of the blit -- 19.5 GB/s against the copy engine's 55: a step of 2.06 ms instead of 1.30.)
+    PCP_HIP_TRY(ctx, ctx->rgba_sorted.ensure(static_cast<size_t>(ctx->n) + 4));
+    uint32_t *target = ctx->rgba_sorted.p;
+    hipLaunchKernelGGL(k_unpermute, dim3(blocks_for(div_up(ctx->n, 4))), dim3(kBlock), 0, ctx->copy_stream, ctx->rgba2[cur].p,
+                       ctx->inv_perm.p, ctx->n, target);
+    PCP_HIP_TRY(ctx, hipGetLastError());
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(out_rgba, target, static_cast<size_t>(ctx->n) * 4, hipMemcpyDeviceToHost, ctx->copy_stream));
+  } else if (ctx->n > 0) {
     PCP_HIP_TRY(ctx, hipMemcpyAsync(out_rgba, ctx->rgba2[cur].p, static_cast<size_t>(ctx->n) * 4, hipMemcpyDeviceToHost,
                                     ctx->copy_stream));
+  }
   PCP_HIP_TRY(ctx, hipEventRecord(ctx->copy_done[cur], ctx->copy_stream));
   ctx->copy_pending[cur] = true;
   return PCP_OK;
@@ -2033,6 +2089,10 @@ int pcp_colour_result_device(pcp_context *ctx, void **device_ptr, int64_t *n_wor
   if (!ctx) return PCP_ERR_INVALID;
   if (!ctx->colour_result_live)
     return set_error(ctx, PCP_ERR_STATE, "pcp_colour_result_device: no result (call pcp_colorize / pcp_colour_finalise)");
+  if (ctx->n > 0) {
+    const int rc = result_in_input_order(ctx);
+    if (rc != PCP_OK) return rc;
+  }
   if (device_ptr) *device_ptr = ctx->rgba2[ctx->rgba_cur].p;
   if (n_words) *n_words = ctx->n;
   return PCP_OK;

@@ -217,6 +217,8 @@ struct pcp_context {
   bool copy_pending[2] = {false, false};
   bool colour_state_live = false;
   bool colour_result_live = false;
+  bool result_sorted[2] = {false, false};  // rgba2[k] holds its words in the sorted (Morton) order of the passes: readers un-permute
+  bool last_pass_sorted = false;           // ... as the pass that has just run left them (end_result moves it to the buffer)
 
   // scratch for the single-frame calls
   pcp::DevBuf<int32_t> s_cell, s_pixel;
@@ -244,7 +246,7 @@ struct pcp_context {
   pcp::DevBuf<unsigned long long> g_occ;  // sparse grids: one bit per cell
   pcp::DevBuf<int32_t> g_occ_rank;        // ... and the set bits before each 64-bit word
   pcp::DevBuf<float> g_xyz;      // cell-sorted x[n] y[n] z[n]
-  pcp::DevBuf<float> m_tmp;      // 7 floats per input point (xyz, normal, curvature), input order
+  pcp::DevBuf<float> m_tmp;      // 8 floats per input point (xyz, normal, curvature, pad: one 32-byte sector), input order
   pcp::DevBuf<float> s_dist;     // StatisticalOutlierRemoval: mean kNN distance per point
   pcp::DevBuf<double> m_state;   // per-point MLSResult (mean, axes, c_vec ...) for upsampling
   pcp::DevBuf<uint8_t> m_flag;   // n

@@ -319,6 +319,7 @@ __device__ __forceinline__ void smallest_eigenpair(const double m[6] /* xx xy xz
 
 // doubles kept per input point for the upsampling stage (MLSResult)
 constexpr int kMlsState = 22;  // mean3 normal3 u3 v3 c6 curvature K valid(+fitted) pad
+constexpr int kRowStride = 8;  // floats per fitted row in ctx->m_tmp: xyz, normal, curvature, pad -- one 32-byte sector
 
 struct MlsArgs {
   const float *sx, *sy, *sz;     // cell-sorted coordinates
@@ -330,7 +331,7 @@ struct MlsArgs {
   float sq_radius;               // f32(r*r): kdtree_flann radiusSearch [upstream]
   double inv_sq_radius;          // 1 / (r*r), weight exp(-d^2 / r^2) (B13)
   int32_t order_poly;
-  float *tmp;                    // 7 floats per input point
+  float *tmp;                    // kRowStride floats per input point (32-byte aligned rows)
   uint8_t *flag;                 // per input point
   double *state;                 // kMlsState doubles per input point (nullable)
   int32_t q_begin, q_end;        // only queries with q_begin <= input index < q_end are fitted (query sharding by index)
@@ -543,13 +544,15 @@ __global__ __launch_bounds__(kFitBlock) void k_mls_fit(MlsArgs a) {
   C[5] = szz - s1z * mz;
   double ev, nrm[3];
   smallest_eigenpair(C, ev, nrm);
-  float *out = a.tmp + static_cast<int64_t>(i) * 7;
+  // rows of kRowStride = 8 floats (xyz, normal, curvature, pad): ONE aligned 32-byte sector each, written by two 16-byte stores --
+  // the row lands in view-index order (scattered), and seven 4-byte stores into a 28-byte row cost six partial sector writes
+  // (WRITE_SIZE 1.69 GB for 0.28 GB of rows, profiles/r04_pmc.json)
+  float4 *out4 = reinterpret_cast<float4 *>(a.tmp + static_cast<int64_t>(i) * kRowStride);
   double *st = a.state ? a.state + static_cast<int64_t>(i) * kMlsState : nullptr;
   const double Qx = qx, Qy = qy, Qz = qz;
   if (!isfinite(nrm[0]) || !isfinite(nrm[1]) || !isfinite(nrm[2])) {
-    out[0] = qx; out[1] = qy; out[2] = qz;
-    out[3] = 0.0f; out[4] = 0.0f; out[5] = 0.0f;
-    out[6] = 0.0f;
+    out4[0] = make_float4(qx, qy, qz, 0.0f);
+    out4[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     a.flag[i] = 1;
     if (st) {
       for (int k = 0; k < kMlsState; ++k) st[k] = 0.0;
@@ -662,9 +665,8 @@ __global__ __launch_bounds__(kFitBlock) void k_mls_fit(MlsArgs a) {
       nx *= il; ny *= il; nz *= il;
     }
   }
-  out[0] = static_cast<float>(ox); out[1] = static_cast<float>(oy); out[2] = static_cast<float>(oz);
-  out[3] = static_cast<float>(nx); out[4] = static_cast<float>(ny); out[5] = static_cast<float>(nz);
-  out[6] = static_cast<float>(curv);
+  out4[0] = make_float4(static_cast<float>(ox), static_cast<float>(oy), static_cast<float>(oz), static_cast<float>(nx));
+  out4[1] = make_float4(static_cast<float>(ny), static_cast<float>(nz), static_cast<float>(curv), 0.0f);
   a.flag[i] = 1;
   if (st) {
     st[0] = meanx; st[1] = meany; st[2] = meanz;
@@ -707,7 +709,7 @@ __global__ __launch_bounds__(kMB) void k_mls_gather(const float *__restrict__ tm
                                                     float *__restrict__ curv) {
   const int64_t k = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
   if (k >= m) return;
-  const float *t = tmp + static_cast<int64_t>(index[k]) * 7;
+  const float *t = tmp + static_cast<int64_t>(index[k]) * kRowStride;
   xyz[3 * k + 0] = t[0]; xyz[3 * k + 1] = t[1]; xyz[3 * k + 2] = t[2];
   normal[3 * k + 0] = t[3]; normal[3 * k + 1] = t[4]; normal[3 * k + 2] = t[5];
   curv[k] = t[6];
@@ -2021,7 +2023,7 @@ __global__ __launch_bounds__(kMB) void k_rows_xyz(const float *__restrict__ rows
                                                   float *__restrict__ ox, float *__restrict__ oy, float *__restrict__ oz) {
   const int64_t k = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
   if (k >= m) return;
-  const float *t = rows + static_cast<int64_t>(index[k]) * 7;
+  const float *t = rows + static_cast<int64_t>(index[k]) * kRowStride;
   ox[k] = t[0];
   oy[k] = t[1];
   oz[k] = t[2];
@@ -2043,7 +2045,7 @@ __global__ __launch_bounds__(kMB) void k_final_rows(const int32_t *__restrict__ 
   const int64_t t = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
   if (t >= kept) return;
   const int32_t i = list[t];
-  const float *r = rows + static_cast<int64_t>(row_view[where[i]]) * 7;
+  const float *r = rows + static_cast<int64_t>(row_view[where[i]]) * kRowStride;
   xyz[3 * t + 0] = r[0]; xyz[3 * t + 1] = r[1]; xyz[3 * t + 2] = r[2];
   normal[3 * t + 0] = r[3]; normal[3 * t + 1] = r[4]; normal[3 * t + 2] = r[5];
   curv[t] = r[6];
@@ -2654,7 +2656,7 @@ static int mls_run(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *
   // coordinate even with the fp32 slop of the cell assignment, so reach 1 suffices
   int rc = build_grid(ctx, cv, static_cast<float>(p->search_radius) * 1.001f, static_cast<float>(p->search_radius), &g);
   if (rc != PCP_OK) return rc;
-  PCP_HIP_TRY(ctx, ctx->m_tmp.ensure(7 * sn + 8));
+  PCP_HIP_TRY(ctx, ctx->m_tmp.ensure(kRowStride * sn + 8));
   PCP_HIP_TRY(ctx, ctx->m_flag.ensure(sn + 16));
   MlsArgs a{};
   a.sx = ctx->g_xyz.p;
@@ -3481,11 +3483,33 @@ int pcp_cloud_smooth_stream_begin(pcp_context *ctx, const pcp_mls_params *p, int
   PCP_HIP_TRY(ctx, ctx->css_dist.ensure(static_cast<size_t>(total_voxels) + 8));
   PCP_HIP_TRY(ctx, ctx->css_words.ensure(32));
   PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->css_words.p, 0, 32 * 4, ctx->stream));
-  // halo in planes: twice the reach of the dilation (a row sits within ~1.75 (it + 1) voxels of its voxel position) and the
-  // k-NN radius of the dense upsampled surface, with room; CHECKED below, widened where the check fails
-  int64_t H = 4 * (static_cast<int64_t>(p->vgd_iterations) + 1) + 20;
+  // Sweep 0: every chunk emitted once for the largest displacement |x of a row - x of its voxel position| alone (the emission
+  // is ~5 % of the chain's time).  A row of a missing plane lies within that displacement of its plane, a chunk's own row
+  // within it of the chunk, so a halo of H planes leaves a margin of H vs - 2 displacement - (k-NN radius) ...
+  {
+    GridDesc g;
+    if ((rc = stream_grid(ctx, st.cv1, &st.p, &g)) != PCP_OK) return rc;
+    st.S.g = g;
+    for (size_t c = 0; c < n_chunks; ++c) {
+      int64_t m0 = 0;
+      if ((rc = vgd_emit(ctx, st.S, ch[5 * c] * st.S.NBY, (ch[5 * c + 1] + 1) * st.S.NBY, ch[5 * c + 2], &m0, ctx->css_words.p)) != PCP_OK) return rc;
+    }
+  }
+  float max_dx = 0.0f;
+  {
+    uint32_t dx_bits = 0;
+    PCP_HIP_TRY(ctx, hipMemcpyAsync(&dx_bits, ctx->css_words.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(&max_dx, &dx_bits, 4);
+  }
+  if (!(max_dx >= 0.0f) || !std::isfinite(max_dx))
+    return set_error(ctx, PCP_ERR_INVALID, "pcp_cloud_smooth_stream_begin: a row of the upsampled cloud has no finite position");
+  st.max_dx = static_cast<double>(max_dx);
+  // ... halo in planes: twice the displacement and 16 voxels for the k-NN radius of the dense upsampled surface (1-3 voxels);
+  // CHECKED per chunk below, widened where the check fails (PCP_CSS_HALO: another first guess -- the tests force a failure)
+  int64_t H = static_cast<int64_t>(std::ceil(2.0 * st.max_dx / static_cast<double>(st.S.v.vs))) + 16;
   if (const char *he = std::getenv("PCP_CSS_HALO")) H = std::max(1, std::atoi(he));
-  st.halo = static_cast<int32_t>(H);
+  st.halo = static_cast<int32_t>(std::min<int64_t>(H, NX));
   std::vector<float> margin(n_chunks, INFINITY);
   int64_t row0 = 0;
   for (size_t c = 0; c < n_chunks; ++c) {
@@ -3497,13 +3521,6 @@ int pcp_cloud_smooth_stream_begin(pcp_context *ctx, const pcp_mls_params *p, int
     st.rows_computed += ext_rows;
   }
   st.total_rows = row0;
-  // every voxel has been emitted as some chunk's own: the largest displacement of a row from its voxel position is final
-  uint32_t dx_bits = 0;
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(&dx_bits, ctx->css_words.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  float max_dx;
-  std::memcpy(&max_dx, &dx_bits, 4);
-  st.max_dx = static_cast<double>(max_dx);
   st.min_margin = INFINITY;
   for (size_t c = 0; c < n_chunks; ++c) {
     int64_t Hc = H;

@@ -465,6 +465,64 @@ def test_result_unpermute_switch_gives_identical_results(gpu_ctx_factory, small_
     assert base["has"].sum() > 500
 
 
+def test_sorted_result_is_unpermuted_by_every_reader(gpu_ctx_factory, small_scene, monkeypatch):
+    """PCP_RESULT_UNPERMUTE=2 (round 5; measured slower than the scattered store, kept as a switch): the colour pass stores its packed result in the sorted order it walks and
+    whatever reads the result un-permutes it -- the byte outputs of pcp_colorize, the packed downloads (synchronous; on the copy
+    stream into pinned and into pageable memory: an un-permuting kernel into a scratch buffer, then the copy engine), the
+    device array.  All equal to the scattered form of rounds 2-4 (PCP_RESULT_UNPERMUTE=0)."""
+    import torch
+
+    from pointcloudprocessor_amd import capi
+
+    ctx = gpu_ctx_factory()
+    _setup(ctx, capi, small_scene)
+    monkeypatch.setenv("PCP_RESULT_UNPERMUTE", "0")
+    base = ctx.colorize()
+    want = ctx.download_result_packed()
+    assert np.array_equal(want & 0xFF, base["rgb"][:, 0]) and np.array_equal(want >> 24, base["has"])
+    monkeypatch.setenv("PCP_RESULT_UNPERMUTE", "2")
+    n = len(want)
+    got = ctx.colorize()  # the byte-splitting kernel gathers through inv_perm
+    assert np.array_equal(got["rgb"], base["rgb"]) and np.array_equal(got["has"], base["has"])
+    pinned = torch.zeros(n, dtype=torch.int32).pin_memory()
+    for rep in range(3):  # both result buffers in turn
+        ctx.colorize(download=False)
+        ctx.download_result_packed_async(pinned.data_ptr())
+        ctx.download_wait_previous()
+        ctx.synchronize()
+        ctx.colorize(download=False)
+        ctx.download_wait_previous()
+        assert np.array_equal(pinned.numpy().view(np.uint32), want), rep
+        pinned.zero_()
+    pageable = np.zeros(n, np.uint32)
+    ctx.colorize(download=False)
+    ctx.download_result_packed_async(pageable.ctypes.data)
+    ctx.colorize(download=False)
+    ctx.download_wait_previous()
+    ctx.synchronize()
+    assert np.array_equal(pageable, want)
+    ctx.colorize(download=False)
+    assert np.array_equal(ctx.download_result_packed(), want)  # synchronous: un-permuted on the device first
+    ctx.colorize(download=False)
+    ptr, words = ctx.colour_result_device()  # the device array in input order
+    assert words == n
+    dev = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ctx.synchronize()
+    import ctypes
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(ctypes.c_void_p(dev.data_ptr()), ctypes.c_void_p(ptr), ctypes.c_size_t(4 * n), 3) == 0  # device to device
+    assert np.array_equal(dev.cpu().numpy().view(np.uint32), want)
+    # the multi-batch path (k_finalise) too
+    ctx.colour_reset()
+    ctx.depth_pass()
+    ctx.colour_pass(0, 3)
+    ctx.colour_pass(3, 6)
+    fin = ctx.colour_finalise()
+    assert np.array_equal(fin["rgb"], base["rgb"]) and np.array_equal(fin["has"], base["has"])
+    assert np.array_equal(ctx.download_result_packed(), want)
+
+
 def test_async_uploads_from_pinned_memory_are_ordered_against_the_passes(gpu_ctx_factory, oracle, small_scene):
     """pcp_upload_image_async from pinned host memory (read in place by the pack kernel, two upload lanes, an event per
     keyframe): colour batches wait for their own keyframes only, and a re-upload of a keyframe waits for the colour
