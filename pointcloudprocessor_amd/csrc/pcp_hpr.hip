@@ -899,6 +899,25 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_quick(HprArrays A, HprGrid G,
 // ------------------------------------------------------------------------------------------------------------------
 // `todo` (nullable): the candidates k_hpr_quick left undecided, as a list (k_hpr_list; its length in the tallies): the four rows
 // of a wavefront then all have work on keyframes where most candidates are hidden and certified already.
+// ---- the point test of the 16- and 64-lane passes ----
+// A point q is strictly on the inner side of the trial plane when n . (q - p) < 0 EXACTLY.  Computed: d = fl(q - p) per
+// coordinate, t = fma(n_z, d_z, fma(n_y, d_y, fl(n_x d_x))); |t - exact| <= 4.44e-16 T with T = sum |n_i d_i| (the bound the
+// searches have used since round 3, kPointSlack = 1e-15 covers it with or without the fused form).  The test t < -1e-15 T costs
+// three multiplies, two adds with |.|, a multiply and a compare per point beside t itself -- and T <= |n| |q - p| <= nn_hi x
+// 2 rho_max (Cauchy-Schwarz; rho_max bounds every candidate's norm) is a constant of the trial plane: a point with
+// t < -1e-15 nn_hi 2 rho_max (~ -4e-10 m for an untilted plane) is clear whatever its T.  Clearances are millimetres to
+// metres, so the relative test -- and the test for an identical point, whose t is 0 -- only run for the lanes the absolute
+// one leaves (round 5: 7 vector instructions per tested point instead of 17).
+__device__ __forceinline__ double point_side(const Vec3d &n, double dx, double dy, double dz) {
+  return __builtin_fma(n.z, dz, __builtin_fma(n.y, dy, n.x * dx));
+}
+__device__ __forceinline__ double abs_clear_of(double nn_hi, double two_rho) { return -kPointSlack * (nn_hi * two_rho); }
+// the relative test (T returned for the callers that rank violators)
+__device__ __forceinline__ bool point_cleared_rel(const Vec3d &n, double dx, double dy, double dz, double t, double &T) {
+  T = (fabs(n.x * dx) + fabs(n.y * dy)) + fabs(n.z * dz);
+  return t < -kPointSlack * T;
+}
+
 // ---- the least-norm tilt of a trial plane (shared by k_hpr_radial<true> and k_hpr_tilt; described at k_hpr_tilt) ----
 constexpr double kTiltMargin = 1.0e-9;  // the trial tilt stays this far (rad) inside every half-plane it knows: n . d <= -1e-9 |D| against a rounding bound of ~1e-13
 constexpr int kTiltMaxSteps = 200;      // half-planes added per search (a dense cluster next to the candidate: 41 seen on C3)
@@ -1036,6 +1055,8 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_radial(HprArrays A, HprGrid G
   const bool mine_to_write = open;
   bool hidden_dup = false;
   unsigned long long batches = 0;
+  const double two_rho = 2.0 * *G.rho_max;
+  double abs_clear = abs_clear_of(S.nn_hi, two_rho);  // t below this: the point is strictly inside whatever its T (point_side)
   const int32_t cell = A.scell[S.self];
   const int32_t ci = cell % G.gw, cj = cell / G.gw;
   if (kOneStep) {
@@ -1053,9 +1074,9 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_radial(HprArrays A, HprGrid G
         const int32_t k = base + rl;
         if (in && open && k < k1 && k != S.self) {
           const double dx = A.sx[k] - S.p.x, dy = A.sy[k] - S.p.y, dz = A.sz[k] - S.p.z;
-          const double tx = S.n.x * dx, ty = S.n.y * dy, tz = S.n.z * dz;
-          const double t = (tx + ty) + tz, T = (fabs(tx) + fabs(ty)) + fabs(tz);
-          if (!(dx == 0.0 && dy == 0.0 && dz == 0.0) && !(t < -kPointSlack * T)) {
+          const double t = point_side(S.n, dx, dy, dz);
+          double T = 0.0;
+          if (!(t < abs_clear) && !(dx == 0.0 && dy == 0.0 && dz == 0.0) && !point_cleared_rel(S.n, dx, dy, dz, t, T)) {
             const float score = static_cast<float>(t) * __builtin_amdgcn_rcpf(static_cast<float>(T));
             if (score > best) {
               best = score;
@@ -1083,10 +1104,12 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_radial(HprArrays A, HprGrid G
       T.sx = T.sy = 0.0;
       T.na = 0;
       T.a = T.b = {0.0, 0.0, 0.0, -1};
-      if (tilt_add(T, Dx, Dy, E, __shfl(bk, src, 64)) == 1)
+      if (tilt_add(T, Dx, Dy, E, __shfl(bk, src, 64)) == 1) {
         tilt_normal(S, T);
-      else
+        abs_clear = abs_clear_of(S.nn_hi, two_rho);
+      } else {
         open = false;
+      }
     }
   }
   // points [k0, k1) of the cell order against the plane, 16 at a time; `go`: this row takes part
@@ -1097,20 +1120,23 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_radial(HprArrays A, HprGrid G
       bool bad = false, dup_lower = false;
       if (active) {
         const double dx = A.sx[k] - S.p.x, dy = A.sy[k] - S.p.y, dz = A.sz[k] - S.p.z;
-        if (dx == 0.0 && dy == 0.0 && dz == 0.0) {
-          dup_lower = A.sidx[k] < S.self_idx;  // identical flipped points: the lowest input index stands for the group
-        } else {
-          const double tx = S.n.x * dx, ty = S.n.y * dy, tz = S.n.z * dz;
-          const double t = (tx + ty) + tz, T = (fabs(tx) + fabs(ty)) + fabs(tz);
-          bad = !(t < -kPointSlack * T);
+        const double t = point_side(S.n, dx, dy, dz);
+        if (!(t < abs_clear)) {  // rare: not clear by the absolute bound (a duplicate has t = 0)
+          double T;
+          if (dx == 0.0 && dy == 0.0 && dz == 0.0)
+            dup_lower = A.sidx[k] < S.self_idx;  // identical flipped points: the lowest input index stands for the group
+          else
+            bad = !point_cleared_rel(S.n, dx, dy, dz, t, T);
         }
       }
       if (go && open && base < k1 && rl == 0) batches += 1;
-      if (row_mask(dup_lower)) {
-        hidden_dup = true;
-        open = false;
+      if (__ballot(bad || dup_lower)) {  // (rare: one ballot in front of the two row masks)
+        if (row_mask(dup_lower)) {
+          hidden_dup = true;
+          open = false;
+        }
+        if (row_mask(bad)) open = false;
       }
-      if (row_mask(bad)) open = false;
     }
   };
   // the 3 x 3 cells around the candidate's own
@@ -1155,9 +1181,11 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_radial(HprArrays A, HprGrid G
         while (__ballot(open && open_f != 0u)) {
           const bool go_f = open && open_f != 0u;
           const int bf = go_f ? __builtin_ctz(open_f) : 0;
-          open_f &= open_f - 1u;
+          // open cells side by side in one row of the mid cell are one run of the cell order: one range, fuller batches
+          const int len = go_f ? min(kHprMid - (bf & (kHprMid - 1)), __builtin_ctz(~(open_f >> bf))) : 1;
+          open_f &= ~(((1u << len) - 1u) << bf);
           const int32_t ff = __shfl(f, row_base + bf, 64);
-          test_points(go_f, go_f ? A.cstart[ff] : 0, go_f ? A.cstart[ff + 1] : 0);
+          test_points(go_f, go_f ? A.cstart[ff] : 0, go_f ? A.cstart[ff + len] : 0);
         }
       }
     }
@@ -1202,6 +1230,7 @@ __device__ unsigned long long g_tilt_hist[40];
 // first build of this kernel took 263 VGPRs (one wavefront per SIMD) for ~100 registers of state.
 struct TiltRow {
   double n[3], nh[3], nn_hi, hp_lo;  // trial normal (tilt_normal)
+  double abs_clear;                  // ... and the absolute bound of its point test (point_side)
   double e0[3], e1[3], e2[3];        // frame at p
   double sx, sy;                     // trial tilt
   double ax, ay, af, bx, by, bf;     // active lines
@@ -1231,6 +1260,7 @@ struct TiltCont {
     R.nh[2] = S.nh.z;          \
     R.nn_hi = S.nn_hi;         \
     R.hp_lo = S.hp_lo;         \
+    R.abs_clear = abs_clear_of(S.nn_hi, two_rho); \
   } while (0)
 
 #ifndef PCP_TILT_WPE
@@ -1278,6 +1308,7 @@ __global__ __launch_bounds__(kTiltBlock) __attribute__((amdgpu_waves_per_eu(PCP_
     return v;
   };
   const int32_t n_coarse = G.cgw * G.cgh;
+  const double two_rho = 2.0 * *G.rho_max;
   for (int32_t u0 = static_cast<int32_t>(blockIdx.x) * kRowsPerBlock + static_cast<int32_t>(threadIdx.x >> 6) * kRowsPerWave; u0 < count;
        u0 += rows_total) {  // (u0: the first row of this wavefront; uniform over the wavefront)
     const int32_t u = u0 + lane / kRow;
@@ -1372,24 +1403,35 @@ __global__ __launch_bounds__(kTiltBlock) __attribute__((amdgpu_waves_per_eu(PCP_
         const bool on = go && run && base < k1;
         if (on) ++trips;
         const int32_t k = base + rl;
-        const bool active = on && k < k1 && k != self;
+        bool active = on && k < k1 && k != self;
         double dx = 0.0, dy = 0.0, dz = 0.0;
-        bool dup = false, dup_lower = false;
         if (active) {
           dx = A.sx[k] - p.x;
           dy = A.sy[k] - p.y;
           dz = A.sz[k] - p.z;
-          dup = dx == 0.0 && dy == 0.0 && dz == 0.0;
-          if (dup) dup_lower = A.sidx[k] < self_idx;  // identical flipped points: the lowest input index stands for the group
         }
         if (on && rl == 0) batches += 1;
-        if (row_mask(dup_lower) && on) stop(2);
-        const bool mine = active && !dup;
         for (int guard = 0;; ++guard) {
           TILT_FENCE();
-          const double tx = R.n[0] * dx, ty = R.n[1] * dy, tz = R.n[2] * dz;
-          const double t = (tx + ty) + tz, Tt = (fabs(tx) + fabs(ty)) + fabs(tz);
-          const bool bad = run && mine && !(t < -kPointSlack * Tt);
+          const Vec3d nn = {R.n[0], R.n[1], R.n[2]};
+          const double t = point_side(nn, dx, dy, dz);
+          bool bad = run && active && !(t < R.abs_clear);  // (point_side: clear by the absolute bound whatever its T)
+          if (!__ballot(bad)) break;
+          // rare: the relative test, and the test for an identical flipped point (t = 0: it never passes the absolute one) --
+          // the lowest input index stands for a group of identical points
+          double Tt = 1.0;
+          bool dup_lower = false;
+          if (bad) {
+            if (dx == 0.0 && dy == 0.0 && dz == 0.0) {
+              dup_lower = A.sidx[k] < self_idx;
+              active = false;  // not a constraint: out of this batch
+              bad = false;
+            } else {
+              bad = !point_cleared_rel(nn, dx, dy, dz, t, Tt);
+            }
+          }
+          if (row_mask(dup_lower) && on) stop(2);
+          bad = bad && run;
           if (!__ballot(bad)) break;
           const mask_t rm = row_mask(bad);
           if (rm) {
@@ -1520,9 +1562,14 @@ __global__ __launch_bounds__(kTiltBlock) __attribute__((amdgpu_waves_per_eu(PCP_
             while (__ballot(run && open_f != 0)) {
               const bool go_f = run && open_f != 0;
               const int bf = go_f ? first_bit(open_f) : 0;
-              open_f &= open_f - 1;
+              // open cells side by side in one row of the upper cell are one run of the cell order: one range, fuller batches
+              // (a cell holds ~8 candidates: alone it fills half a row of 16 lanes, an eighth of a row of 64)
+              const int wide = 1 << eshift;
+              const mask_t rest = static_cast<mask_t>(~(open_f >> bf));
+              const int len = go_f ? min(wide - (bf & (wide - 1)), rest ? first_bit(rest) : wide) : 1;
+              open_f &= static_cast<mask_t>(~(((static_cast<mask_t>(1) << (len - 1) << 1) - 1) << bf));
               const int32_t ff = __shfl(f, row_base + bf, 64);
-              test_points(go_f, go_f ? A.cstart[ff] : 0, go_f ? A.cstart[ff + 1] : 0);
+              test_points(go_f, go_f ? A.cstart[ff] : 0, go_f ? A.cstart[ff + len] : 0);
             }
           }
         }
