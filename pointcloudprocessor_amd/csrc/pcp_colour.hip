@@ -1290,6 +1290,14 @@ int cull_frame_indices(pcp_context *ctx, int32_t frame, int32_t *d_index, int64_
 
 }  // namespace pcp
 
+namespace pcp {
+// (pcp_create loads every code object of the library up front: see preload_code_objects in pcp_context.hip)
+hipError_t preload_colour() {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_fill_u32));
+}
+}  // namespace pcp
+
 using namespace pcp;
 
 extern "C" {

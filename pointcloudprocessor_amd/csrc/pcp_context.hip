@@ -570,8 +570,19 @@ int pcp_create(int32_t device, pcp_context **out) {
     return PCP_ERR_INVALID;
   }
   e = hipSetDevice(device);
+  if (e == hipSuccess) {
+    // The HIP runtime loads a translation unit's code object at the first launch of one of its kernels (deferred loading), on
+    // the calling thread: tens of milliseconds of host work per unit, wherever that first launch happens to fall.  All five
+    // units are loaded here, where a caller expects set-up time; the first call of every entry point then costs what the
+    // others cost.
+    hipFuncAttributes a;
+    const hipError_t pl[] = {hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_up_bbox)), preload_colour(), preload_mls(),
+                             preload_nid(), preload_hpr()};
+    for (hipError_t x : pl)
+      if (x != hipSuccess && e == hipSuccess) e = x;
+  }
   if (e != hipSuccess) {
-    set_global_error("pcp_create: hipSetDevice(%d) failed: %s", device, hipGetErrorString(e));
+    set_global_error("pcp_create: hipSetDevice(%d) / loading the gfx950 code objects failed: %s", device, hipGetErrorString(e));
     return PCP_ERR_DEVICE;
   }
   pcp_context *ctx = new (std::nothrow) pcp_context();

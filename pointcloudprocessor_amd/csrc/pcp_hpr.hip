@@ -2433,6 +2433,14 @@ int hpr_run_range(pcp_context *ctx, int32_t f0, int32_t f1, int32_t lanes, const
 
 }  // namespace pcp
 
+namespace pcp {
+// (pcp_create loads every code object of the library up front: see preload_code_objects in pcp_context.hip)
+hipError_t preload_hpr() {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_hpr_zero));
+}
+}  // namespace pcp
+
 using namespace pcp;
 
 extern "C" {

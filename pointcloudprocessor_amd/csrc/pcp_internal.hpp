@@ -304,6 +304,11 @@ struct pcp_context {
 namespace pcp {
 
 int set_error(const pcp_context *ctx, int code, const char *fmt, ...);
+// one per translation unit with kernels: forces the runtime to load that unit's code object (pcp_context.hip preload_code_objects)
+hipError_t preload_colour();
+hipError_t preload_mls();
+hipError_t preload_nid();
+hipError_t preload_hpr();
 void set_global_error(const char *fmt, ...);
 
 #define PCP_HIP_TRY(ctx, expr)                                                                       \

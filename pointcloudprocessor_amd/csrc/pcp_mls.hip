@@ -3057,6 +3057,14 @@ static int smooth_first_filter(pcp_context *ctx, const pcp_mls_params *p, const 
 
 }  // namespace pcp
 
+namespace pcp {
+// (pcp_create loads every code object of the library up front: see preload_code_objects in pcp_context.hip)
+hipError_t preload_mls() {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_deinterleave));
+}
+}  // namespace pcp
+
 using namespace pcp;
 
 extern "C" {

@@ -345,6 +345,14 @@ static int nid_eval(pcp_context *ctx, const double T[16], int32_t bins, double *
 
 }  // namespace pcp
 
+namespace pcp {
+// (pcp_create loads every code object of the library up front: see preload_code_objects in pcp_context.hip)
+hipError_t preload_nid() {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_nid_gather));
+}
+}  // namespace pcp
+
 using namespace pcp;
 
 extern "C" {

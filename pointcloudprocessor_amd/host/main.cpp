@@ -39,6 +39,7 @@
 #include <filesystem>
 #include <fstream>
 #include <iostream>
+#include <malloc.h>
 #include <memory>
 #include <sstream>
 #include <thread>
@@ -555,6 +556,13 @@ class Processor {
 
 int main(int argc, char **argv) {
   const auto t_main = PhaseClock::clock::now();
+  // Decoded keyframes are 6-37 MB buffers that live for one upload each.  glibc serves such sizes by mmap / munmap until a
+  // freed block has raised its threshold: sixteen decoder threads then fault fresh pages in and tear mappings down while this
+  // thread's uploads pin and unpin theirs -- all under one address-space lock.  Measured (profiles/r05_cli_e2e_probe_before.log / _after.log, profiles/cli_e2e_probe.py): the
+  // 32 uploads of a 1 M-point / 32-keyframe run took 0.50 s when nothing large had been freed before (--skip_filtered_dumps 1)
+  // and 0.03 s otherwise.  The threshold is set up front: the buffers come from the heaps and are reused.
+  (void)mallopt(M_MMAP_THRESHOLD, 32 << 20);   // (glibc's ceiling)
+  (void)mallopt(M_TRIM_THRESHOLD, 1 << 30);
   struct TimingAtExit {  // also after an exception: the phases reached so far
     PhaseClock::clock::time_point t0;
     ~TimingAtExit() {

@@ -22,4 +22,5 @@ echo "p3 done"
 # (rocprofv3 --list-avail shows the per-block capacity); none is collected here, the SQ counters answer what was asked.
 cd $R
 python3 profiles/summarise_chain.py $OUT/${TAG}_pmc.json $OUT/${TAG}_trace $OUT/${TAG}_p1 $OUT/${TAG}_p2 $OUT/${TAG}_p3
+python3 profiles/build_stamp.py $OUT/${TAG}_pmc.json > /dev/null  # the library these counters belong to (bench.py checks it)
 rm -rf $OUT/${TAG}_p1 $OUT/${TAG}_p2 $OUT/${TAG}_p3 $OUT/${TAG}_p4 $OUT/${TAG}_p5 $OUT/${TAG}_trace

@@ -41,4 +41,5 @@ for k, v in summary.items():
 json.dump(summary, open(out, "w"), indent=1, sort_keys=True)
 print(json.dumps({k: {c: v[c] for c in ("duration_us", "valu_busy", "waves_per_simd", "valu_share_of_instructions", "lane_utilisation") if c in v} for k, v in summary.items()}, indent=1))
 PY
+python3 profiles/build_stamp.py $OUT/${TAG}_pmc.json > /dev/null  # the library these counters belong to (bench.py checks it)
 rm -rf $OUT/${TAG}_p1 $OUT/${TAG}_p2 $OUT/${TAG}_trace

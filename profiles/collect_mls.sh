@@ -13,4 +13,5 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_p2 -- $CMD > /dev/
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_p3 -- $CMD > /dev/null 2> $OUT/${TAG}_p3.err
 cd $R
 python3 profiles/summarise_chain.py $OUT/${TAG}_pmc.json $OUT/${TAG}_trace $OUT/${TAG}_p1 $OUT/${TAG}_p2 $OUT/${TAG}_p3
+python3 profiles/build_stamp.py $OUT/${TAG}_pmc.json > /dev/null  # the library these counters belong to (bench.py checks it)
 rm -rf $OUT/${TAG}_p1 $OUT/${TAG}_p2 $OUT/${TAG}_p3 $OUT/${TAG}_trace
