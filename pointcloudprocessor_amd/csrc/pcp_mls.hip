@@ -1296,12 +1296,18 @@ __global__ __launch_bounds__(kSorBlock) void k_sor_mean_distance(const float *__
 // whose missing candidates sit at infinity (outside every ball).  ~9 VALU instructions per candidate and pass; the
 // first version (one dword load per coordinate, scalar arithmetic, a test and a branch per candidate, sqrt inside the
 // candidate loop) issued 25.
-constexpr int kSelBins = 32;    // + 1 row for candidates outside the ball
-constexpr int kSelList = 16;    // members of the boundary bin a lane can pick from
+// Two shapes of the selection (template arguments kBins, kList of k_sor_select):
+//   32 bins, 16 members -- scanned clouds: a boundary bin holds ~3 of the ball's ~90 candidates, the lists are 6.4 KB of LDS per
+//     wavefront (4.6 wavefronts per SIMD resident);
+//   64 bins, 32 members -- the upsampled clouds of VOXEL_GRID_DILATION (round 5): up to nine voxels of a column project onto
+//     nearly the same surface point, so the distances to a query come in clusters; with 32 bins most wavefronts held a lane
+//     whose boundary bin overflowed 16 members and walked their candidates a third time (refinement).  Measured on the
+//     425 M-row cloud of the reference's chain at 1 M input points (profiles/vgd_sor_probe.py, PCP_SEL_BINS / PCP_SEL_LIST
+//     builds): 32/16 781 ms of outlier removal, 32/32 689, 64/16 753, 64/32 566, 96/40 569, 64/48 650, 128/32 723, 128/64 760;
+//     on the scanned 10 M-point map 64/32 costs 9.0 ms against 7.3.
 constexpr int kSelDrain = 9;    // entries of the per-lane list of the last pass
 constexpr int kSelLevels = 3;
 constexpr int kSelWave = 64;
-constexpr int kSelLdsWords = (kSelDrain + kSelList) * kSelWave;  // the bins (33 x 32 words) share the list's space
 typedef float sel_v2f __attribute__((ext_vector_type(2)));
 typedef float sel_v4f __attribute__((ext_vector_type(4)));
 typedef uint32_t sel_v4u __attribute__((ext_vector_type(4)));
@@ -1311,7 +1317,7 @@ typedef uint32_t sel_v4u __attribute__((ext_vector_type(4)));
 #endif
 // kOneDescriptor: the three coordinate planes end below 2^32 bytes (n below ~ 3.5e8) and are read through one buffer descriptor;
 // else (up to 2^30 points: the dilated clouds of VOXEL_GRID_DILATION) through one descriptor per plane.
-template <bool kOneDescriptor>
+template <bool kOneDescriptor, int kSelBins /* + 1 row for candidates outside the ball */, int kSelList /* members of the boundary bin a lane can pick from */>
 __global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(PCP_SEL_WPE, 8))) void k_sor_select(const float *__restrict__ sx, const float *__restrict__ sy,
                                                          const float *__restrict__ sz,
                                                          const int32_t *__restrict__ order,
@@ -1322,6 +1328,8 @@ __global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(PCP_SE
                                                          float *__restrict__ kth) {
   // [j_begin, j_end): the slab of the cell order this launch covers (the whole cloud, or one GPU's share: pcp_sor_partial)
 #pragma clang fp contract(off)
+  // the bins ((kSelBins + 1) x 32 words) share the lists' space
+  constexpr int kSelLdsWords = (kSelDrain + kSelList) * kSelWave > (kSelBins + 1) * 32 ? (kSelDrain + kSelList) * kSelWave : (kSelBins + 1) * 32;
   __shared__ uint32_t sel_lds[kSelLdsWords];
   float *list = reinterpret_cast<float *>(sel_lds);            // [kSelDrain][64]
   float *members = list + kSelDrain * kSelWave;                // [kSelList][64]
@@ -2736,8 +2744,13 @@ static int mls_run(pcp_context *ctx, const CloudView &cv, const pcp_mls_params *
 // Slabs (pcp_sor_partial / pcp_sor_finish): the places [chunk c0, chunk c1) of the cell order are this GPU's queries (see
 // k_sor_stats); `classify` false stops after the chunk sums (they sit in ctx->m_sums from double 4 on).
 static int sor_classify(pcp_context *ctx, int64_t n, const int32_t *remap, double std_mul, int64_t j_begin, int64_t j_end);
+// clustered: the cloud is an upsampled one (VOXEL_GRID_DILATION): the selection takes its shape for clustered distances
+// area_density > 0: points per unit area of the cloud's surface, known from how the cloud was made (the upsampled clouds: at
+// least 2 it + 1 voxels of a column per vs^2) -- the ball is sized from it instead of from the density probe
 static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double std_mul, bool view_order = false,
-                   int32_t slab = 0, int32_t n_slabs = 1, bool classify = true, float *kth = nullptr) {
+                   int32_t slab = 0, int32_t n_slabs = 1, bool classify = true, float *kth = nullptr, bool clustered = false,
+                   double area_density = 0.0) {
+  if (const char *ce = std::getenv("PCP_SOR_CLUSTERED")) clustered = ce[0] == '1';  // (tests: either shape on any cloud)
   const int32_t *remap = view_order ? nullptr : cv.remap;
   const int64_t n = cv.n;
   if (n == 0) return PCP_OK;
@@ -2756,7 +2769,19 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
   if (!(cell > 1e-4f)) cell = 1e-4f;
   GridDesc g;
   int rc = PCP_OK;
-  {
+  if (area_density > 0.0) {
+    // The density is known.  (The probe below reads the upsampled clouds 3.5x too thin -- their ball then held ~320 points
+    // instead of ~90 and the outlier removal of the reference's 425 M-row cloud took 566 ms; sized from the voxel structure:
+    // profiles/r05_vgd_sor_ball.log.)
+    // (the density handed in is a lower bound -- tilted and noisy sheets carry more voxels per area --: 1.2 (k + 1) points by
+    // the bound leave 0.05 % of the 425 M rows to the wavefront kernel; 1.5: 414 ms, 1.2: 385, 1.0: 354, 0.8: 331)
+    double ball = 1.2;
+    if (const char *e = std::getenv("PCP_SOR_BALL")) ball = atof(e);
+    double final_cell = std::sqrt(ball * (mean_k + 1) / (3.14159265358979 * area_density));
+    if (!(final_cell > 1e-7) || !(final_cell < 1e30)) final_cell = static_cast<double>(cell);
+    rc = build_grid(ctx, cv, static_cast<float>(final_cell), static_cast<float>(final_cell * 0.9999), &g);
+    if (rc != PCP_OK) return rc;
+  } else {
     // density probe on every 8th point, every 32nd of a large cloud (cell edge from the sub-sample's own volume guess):
     // occupied cells -> points per unit area of the surface.  It only sizes the grid; the kNN result does not depend on it.
     // (One returning atomic per probed point: 150-180 us for every 8th of 10 M points, twice per smoothing chain.)
@@ -2824,8 +2849,9 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
     if (!whole) PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->m_flag.p, 0, sn, ctx->stream));  // nothing to redo outside the slab
     if (q_end > q_begin) {
       LaunchTimer t(ctx, PCP_K_SOR);
-      hipLaunchKernelGGL(one_descriptor ? k_sor_select<true> : k_sor_select<false>,
-                         dim3(static_cast<uint32_t>(div_up(q_end - q_begin, kSelWave))), dim3(kSelWave), 0, ctx->stream,
+      auto sel = one_descriptor ? k_sor_select<true, 32, 16> : k_sor_select<false, 32, 16>;
+      if (clustered) sel = one_descriptor ? k_sor_select<true, 64, 32> : k_sor_select<false, 64, 32>;
+      hipLaunchKernelGGL(sel, dim3(static_cast<uint32_t>(div_up(q_end - q_begin, kSelWave))), dim3(kSelWave), 0, ctx->stream,
                          ctx->g_xyz.p, ctx->g_xyz.p + plane, ctx->g_xyz.p + 2 * plane, ctx->g_order.p, remap,
                          ctx->g_start.p, n, g, mean_k, dist, ctx->m_flag.p, q_begin, q_end, kth);
       PCP_HIP_TRY(ctx, hipGetLastError());
@@ -3315,7 +3341,9 @@ int pcp_cloud_smooth(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_cou
   // 2nd SOR on the MLS output (cloudSmooth.cpp:160-164)
   CloudView cv2;
   if ((rc = view_of(ctx, x2, y2, z2, m, &cv2)) != PCP_OK) return rc;
-  if ((rc = sor_run(ctx, cv2, p->sor_mean_k, p->sor_std_mul)) != PCP_OK) return rc;
+  // (the upsampled cloud: every surface patch of vs^2 carries a column of at least 2 it + 1 voxels)
+  const double dens2 = plain ? 0.0 : (2.0 * p->vgd_iterations + 1.0) / (static_cast<double>(p->vgd_voxel_size) * p->vgd_voxel_size);
+  if ((rc = sor_run(ctx, cv2, p->sor_mean_k, p->sor_std_mul, false, 0, 1, true, nullptr, /*clustered=*/!plain, dens2)) != PCP_OK) return rc;
   int64_t kept = 0;
   if (plain) {
     // survivors back in the caller's order (ascending index, as a filter chain on the input cloud leaves them): every
@@ -3395,7 +3423,8 @@ static int css_sweep1_chunk(pcp_context *ctx, SmoothStream &st, const std::vecto
   CloudView cv2;
   if ((rc = view_of(ctx, x2, y2, z2, m, &cv2)) != PCP_OK) return rc;
   PCP_HIP_TRY(ctx, ctx->s_kth.ensure(static_cast<size_t>(m) + 8));
-  if ((rc = sor_run(ctx, cv2, st.p.sor_mean_k, st.p.sor_std_mul, false, 0, 1, /*classify=*/false, ctx->s_kth.p)) != PCP_OK) return rc;
+  const double dens2 = (2.0 * st.p.vgd_iterations + 1.0) / (static_cast<double>(st.p.vgd_voxel_size) * st.p.vgd_voxel_size);
+  if ((rc = sor_run(ctx, cv2, st.p.sor_mean_k, st.p.sor_std_mul, false, 0, 1, /*classify=*/false, ctx->s_kth.p, /*clustered=*/true, dens2)) != PCP_OK) return rc;
   // MLSVoxelGrid::getPosition of the first missing plane on either side (fp32, as k_voxel_emit forms it)
   const float xl = static_cast<float>(ea - 1) * st.S.v.vs + st.S.v.bminx, xh = static_cast<float>(eb + 1) * st.S.v.vs + st.S.v.bminx;
   PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->css_words.p + 1, 0xff, 4, ctx->stream));

@@ -182,6 +182,28 @@ def test_sor_selection_reads_the_planes_through_one_descriptor_or_three(gpu_ctx_
     assert ctx.sor_redo_fraction() < 0.5  # the selection kernel did the work
 
 
+@pytest.mark.parametrize("clustered", ["0", "1"])
+@pytest.mark.parametrize("three", ["0", "1"])
+def test_sor_selection_shapes_give_the_same_distances(gpu_ctx_factory, oracle, monkeypatch, clustered, three):
+    """k_sor_select has two shapes -- 32 bins / 16 members for scanned clouds, 64 / 32 for the upsampled clouds of
+    VOXEL_GRID_DILATION, whose distances come in clusters (PCP_SOR_CLUSTERED forces one on any cloud) --: the same mean
+    distances (bit for bit against the oracle) on a scanned sheet AND on a cloud of stacked near-duplicates, in both
+    descriptor forms."""
+    monkeypatch.setenv("PCP_SOR_CLUSTERED", clustered)
+    monkeypatch.setenv("PCP_SOR_THREE_DESCRIPTORS", three)
+    rng = np.random.default_rng(23)
+    n = 6000
+    a = rng.uniform(-0.25, 0.25, (n, 2))
+    base = np.stack([a[:, 0], a[:, 1], 0.03 * np.sin(9 * a[:, 0]) + rng.normal(0, 5e-4, n)], 1)
+    # every point nine times, the copies within 20 um of each other (a voxel column projected onto the surface)
+    stack = (base[:, None, :] + rng.normal(0, 2e-5, (n, 9, 3))).reshape(-1, 3)
+    pts = np.concatenate([stack, rng.uniform(-0.3, 0.3, (100, 3))]).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    ctx = gpu_ctx_factory()
+    _check(ctx, oracle, pts[:, 0].copy(), pts[:, 1].copy(), pts[:, 2].copy(), 60, 0.7)
+    assert ctx.sor_redo_fraction() < 0.5  # the selection kernel did the work
+
+
 def test_sor_stray_points_far_from_the_cloud(gpu_ctx_factory, oracle):
     """Points hundreds of metres from a 1 m sheet: the bounding box needs 10^12 cells at the wanted edge (sparse form,
     coarser cells), and a stray point's block of cells would have to grow over millions of empty rows -- it reads every
