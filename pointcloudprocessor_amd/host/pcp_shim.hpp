@@ -177,11 +177,52 @@ class CloudSmooth {
   SmoothedCloud processWithOutlierRemoval() const { return run(true); }
   // pcl::MovingLeastSquares::process alone
   SmoothedCloud process() const { return run(false); }
+  // The whole CloudSmooth::process through the streamed form (pcp_cloud_smooth_stream_begin / _next): any size of upsampled
+  // cloud -- the reference's VOXEL_GRID_DILATION 1 mm x 4 (PointCloudProcessor.cpp:78-81) makes ~2.8e9 rows of a 10 M-point
+  // map, more than one result holds.  sink(const SmoothedCloud &chunk) receives the survivors of the trailing outlier
+  // removal chunk by chunk, in the order the one-shot form returns them; total_rows (nullable): rows before that filter.
+  // Returns the rows kept.
+  template <class Sink>
+  int64_t processWithOutlierRemovalStreamed(int64_t chunk_capacity, Sink &&sink, int64_t *total_rows = nullptr) const {
+    int64_t total = 0, kept = 0;
+    int32_t chunks = 0;
+    dev_.check(pcp_cloud_smooth_stream_begin(dev_.get(), &params_, chunk_capacity, &total, &kept, &chunks));
+    if (total_rows) *total_rows = total;
+    SmoothedCloud s;
+    for (;;) {
+      int64_t m = 0;
+      dev_.check(pcp_cloud_smooth_stream_next(dev_.get(), &m));
+      if (m == 0) break;
+      fetch(m, s);
+      sink(static_cast<const SmoothedCloud &>(s));
+    }
+    return kept;
+  }
 
  private:
+  void fetch(int64_t m, SmoothedCloud &s) const {
+    const size_t sm = static_cast<size_t>(m);
+    s.xyz.resize(3 * sm);
+    s.normal.resize(3 * sm);
+    s.curvature.resize(sm);
+    s.index.resize(sm);
+    dev_.check(pcp_mls_fetch(dev_.get(), m, s.xyz.data(), s.normal.data(), s.curvature.data(), s.index.data()));
+  }
   SmoothedCloud run(bool with_sor) const {
     int64_t m = 0;
-    dev_.check(with_sor ? pcp_cloud_smooth(dev_.get(), &params_, &m) : pcp_mls_process(dev_.get(), &params_, &m));
+    int rc = with_sor ? pcp_cloud_smooth(dev_.get(), &params_, &m) : pcp_mls_process(dev_.get(), &params_, &m);
+    if (with_sor && rc == PCP_ERR_NOMEM && params_.upsampling == 3) {
+      // more upsampled points than one result holds: the streamed chain, gathered on the host (the caller asked for one cloud)
+      SmoothedCloud all;
+      processWithOutlierRemovalStreamed(int64_t(1) << 28, [&](const SmoothedCloud &c) {
+        all.xyz.insert(all.xyz.end(), c.xyz.begin(), c.xyz.end());
+        all.normal.insert(all.normal.end(), c.normal.begin(), c.normal.end());
+        all.curvature.insert(all.curvature.end(), c.curvature.begin(), c.curvature.end());
+        all.index.insert(all.index.end(), c.index.begin(), c.index.end());
+      });
+      return all;
+    }
+    dev_.check(rc);
     SmoothedCloud s;
     const size_t sm = static_cast<size_t>(m);
     s.xyz.resize(3 * sm);

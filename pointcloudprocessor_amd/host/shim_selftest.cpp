@@ -57,6 +57,30 @@ int main(int argc, char **argv) {
       checksum += rgb[3 * i] + 3 * rgb[3 * i + 1] + 7 * rgb[3 * i + 2];
     }
     std::printf("kept0 %zu coloured %ld checksum %ld visible1 %zu\n", kept.size(), coloured, checksum, vis.index.size());
+    if (argc > 2) {
+      // CloudSmooth::process, one-shot and streamed (the last two stages in chunks of at most argv[2] voxels): the same rows
+      pcp_mls_params mp;
+      pcp_default_mls_params(&mp);
+      mp.vgd_voxel_size = 0.02f;
+      mp.vgd_iterations = 1;
+      mp.search_radius = 0.25;
+      mp.sqr_gauss_param = 0.0625;
+      mp.sor_mean_k = 12;
+      pcp_amd::CloudSmooth sm(dev, mp);
+      const pcp_amd::SmoothedCloud one = sm.processWithOutlierRemoval();
+      size_t at = 0;
+      bool same = true;
+      int64_t total = 0;
+      int chunks = 0;
+      const int64_t kept_rows = sm.processWithOutlierRemovalStreamed(std::atoll(argv[2]), [&](const pcp_amd::SmoothedCloud &c) {
+        ++chunks;
+        for (size_t i = 0; i < c.index.size(); ++i, ++at)
+          same = same && at < one.index.size() && c.index[i] == one.index[at] && c.xyz[3 * i] == one.xyz[3 * at] &&
+                 c.xyz[3 * i + 1] == one.xyz[3 * at + 1] && c.xyz[3 * i + 2] == one.xyz[3 * at + 2] && c.curvature[i] == one.curvature[at];
+      }, &total);
+      std::printf("smooth rows %zu streamed %lld of %lld in %d chunks same %d\n", one.index.size(), (long long)kept_rows, (long long)total,
+                  chunks, same && at == one.index.size() ? 1 : 0);
+    }
     std::cout << "Processing completed successfully." << std::endl;
   } catch (const std::exception &e) {
     // same convention as PCP/src/main.cpp:64-68

@@ -75,3 +75,15 @@ def test_shim_selftest_matches_oracle(oracle):
     assert checksum == int((rgb[:, 0] + 3 * rgb[:, 1] + 7 * rgb[:, 2]).sum())
     assert visible1 == len(vis["index"])
     assert 0 < kept_ref < n  # the strip occludes part of the wall
+
+
+@pytest.mark.gpu
+def test_shim_streamed_smoothing_equals_one_shot():
+    """pcp_amd::CloudSmooth::processWithOutlierRemovalStreamed (pcp_cloud_smooth_stream_begin / _next: the trailing outlier
+    removal over the chunked voxel dilation) hands its sink the rows processWithOutlierRemoval returns, chunk by chunk."""
+    p = subprocess.run([_exe(), "4000", "4096"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    m = re.search(r"smooth rows (\d+) streamed (\d+) of (\d+) in (\d+) chunks same (\d)", p.stdout)
+    assert m, p.stdout
+    rows, kept, total, chunks, same = map(int, m.groups())
+    assert same == 1 and kept == rows > 1000 and total > kept and chunks >= 3
