@@ -51,3 +51,20 @@ def test_bench_line_carries_the_contract():
     assert line["mls"]["reference_config_chain"]["outputs"] > 0
     rs = line["mls"]["reference_config_stream"]
     assert rs["voxels"] >= rs["outputs"] > 0 and rs["chunks"] >= 1
+    # round 5: the streamed chain on the whole map (kept == what the begin call reported), the command line end to end with its
+    # own phase split, and the counter summaries' build check (a summary of another library is dropped, never divided by this
+    # run's durations)
+    wm = line["mls"]["reference_config_chain_whole_map"]
+    assert wm["rows_before_last_filter"] > wm["outputs"] == wm["kept_reported"] > 0 and wm["chunks"] >= 1
+    assert wm["min_margin_mm"] > wm["max_displacement_mm"] >= 0.0
+    cli = line["cli_e2e"]
+    for form in ("skip_filtered_dumps_off", "skip_filtered_dumps_on"):
+        assert cli[form]["wall_s"] > 0 and "images_decode_and_upload_wall_s" in cli[form]["phases_s"], cli
+    assert "roofline kernel" in line["value_note"] or "k_project_frame" in line["value_note"]
+    prof = line["profiles"]
+    assert len(prof["lib_sha256"]) == 64
+    for name, st_ in prof["summaries"].items():
+        assert "stale" in st_, name
+    if prof["summaries"].get("r05_pmc.json", {}).get("stale", True):
+        assert line["roofline"]["traffic"] is None and line["roofline"]["traffic_stale"] is True
+    assert ("kernels_ms" in line) != ("kernels_ms_timing_pass" in line)
