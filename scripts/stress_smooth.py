@@ -83,6 +83,35 @@ def main():
             rv = oc.mls_voxel_dilation(x[vs], y[vs], z[vs], vo)
             nv = len(rv["index"])
             err = err or compare_mls(gv, rv, 0.03)
+            # the whole chain on the slice, one-shot against streamed (round 5): the same rows, bit for bit -- with a random
+            # first guess of the halo now and then (a guess too small is redone wider)
+            vp.sor_mean_k = int(rng.choice([60, 20]))
+            one = ctx.mls_fetch(ctx.cloud_smooth(vp))
+            halo = rng.choice([None, None, "2", "6"])
+            if halo:
+                os.environ["PCP_CSS_HALO"] = halo
+            cap = 8192
+            while True:
+                try:
+                    total, kept, chunks = ctx.cloud_smooth_stream_begin(vp, cap)
+                    break
+                except capi.PcpError as e:  # a plane of the slice holds more voxels than the chunk may
+                    if e.code != capi.PCP_ERR_RANGE or cap > (1 << 24):
+                        raise
+                    cap *= 4
+            os.environ.pop("PCP_CSS_HALO", None)
+            parts = []
+            while True:
+                mchunk = ctx.cloud_smooth_stream_next()
+                if mchunk == 0:
+                    break
+                parts.append(ctx.mls_fetch(mchunk))
+            for key in ("index", "xyz", "normal", "curvature"):
+                got = np.concatenate([q[key] for q in parts]) if parts else one[key][:0]
+                if not np.array_equal(got, one[key]):
+                    err = err or f"streamed chain differs from the one-shot chain in {key} ({chunks} chunks, halo {halo})"
+            if kept != len(one["index"]):
+                err = err or f"streamed chain kept {kept}, one-shot {len(one['index'])}"
         ctx.close()
         print(f"case {case:3d} n={len(x):7d} r={R:.2f} k={k:3d} mul={mul:.1f} sor_redo={redo:.3f} voxels={nv:7d}  "
               f"{'ok' if not err else 'MISMATCH: ' + err}", flush=True)
