@@ -1325,7 +1325,9 @@ __global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(PCP_SE
                                                          const int32_t *__restrict__ start, int64_t n, GridDesc g,
                                                          int32_t mean_k, float *__restrict__ distances,
                                                          uint8_t *__restrict__ redo, int64_t j_begin, int64_t j_end,
-                                                         float *__restrict__ kth) {
+                                                         float *__restrict__ kth, int32_t row_begin, int32_t row_end) {
+  // [row_begin, row_end) (the shape for upsampled clouds only): the caller's indices whose distances are wanted -- the streamed
+  // chain computes a chunk's own rows against chunk + halo; the halo's rows are candidates, not queries
   // [j_begin, j_end): the slab of the cell order this launch covers (the whole cloud, or one GPU's share: pcp_sor_partial)
 #pragma clang fp contract(off)
   // the bins ((kSelBins + 1) x 32 words) share the lists' space
@@ -1446,7 +1448,7 @@ __global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(PCP_SE
     const uint32_t v = sel_lds[b * 32 + (lane & 31)];
     return static_cast<int>(lane < 32 ? (v & 0xffffu) : (v >> 16));
   };
-  bool bad = false, sparse = false;
+  bool bad = false, sparse = false, skip = false;
   {
     // a counter cannot wrap (and carry into the lane it shares a dword with): the 27 cells hold fewer candidates than
     // it can count, else the heap kernel takes the lane
@@ -1456,6 +1458,11 @@ __global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(PCP_SE
         total += static_cast<uint32_t>(cell_start(g, start, zz, yy, x1 + 1) - cell_start(g, start, zz, yy, x0));
       }
     bad = total > 60000u;
+    if constexpr (kSelBins == 64) {
+      const int32_t at_q = remap ? remap[order[j]] : order[j];
+      skip = at_q < row_begin || at_q >= row_end;
+      bad = bad || skip;
+    }
   }
   int below = 0, level = 0, crowd = 0;
   // level 0 with the plain bin arithmetic (on a uniform cloud no lane needs more)
@@ -1627,7 +1634,7 @@ __global__ __launch_bounds__(kSelWave) __attribute__((amdgpu_waves_per_eu(PCP_SE
     }
   }
   // 1: the ball of one cell holds too few points (k_sor_wave starts with two cells); 3: any other reason
-  if (live) redo[j] = sparse ? 1 : ((bad || tiny) ? 3 : 0);
+  if (live) redo[j] = skip ? 0 : (sparse ? 1 : ((bad || tiny) ? 3 : 0));
 }
 
 // The lanes k_sor_select flags (sparse spots and borders of a surface: fewer than k + 1 points within one cell; dense
@@ -2749,7 +2756,7 @@ static int sor_classify(pcp_context *ctx, int64_t n, const int32_t *remap, doubl
 // least 2 it + 1 voxels of a column per vs^2) -- the ball is sized from it instead of from the density probe
 static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double std_mul, bool view_order = false,
                    int32_t slab = 0, int32_t n_slabs = 1, bool classify = true, float *kth = nullptr, bool clustered = false,
-                   double area_density = 0.0) {
+                   double area_density = 0.0, int64_t row_begin = 0, int64_t row_end = -1) {
   if (const char *ce = std::getenv("PCP_SOR_CLUSTERED")) clustered = ce[0] == '1';  // (tests: either shape on any cloud)
   const int32_t *remap = view_order ? nullptr : cv.remap;
   const int64_t n = cv.n;
@@ -2853,7 +2860,8 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
       if (clustered) sel = one_descriptor ? k_sor_select<true, 64, 32> : k_sor_select<false, 64, 32>;
       hipLaunchKernelGGL(sel, dim3(static_cast<uint32_t>(div_up(q_end - q_begin, kSelWave))), dim3(kSelWave), 0, ctx->stream,
                          ctx->g_xyz.p, ctx->g_xyz.p + plane, ctx->g_xyz.p + 2 * plane, ctx->g_order.p, remap,
-                         ctx->g_start.p, n, g, mean_k, dist, ctx->m_flag.p, q_begin, q_end, kth);
+                         ctx->g_start.p, n, g, mean_k, dist, ctx->m_flag.p, q_begin, q_end, kth, static_cast<int32_t>(row_begin),
+                         static_cast<int32_t>(row_end < 0 ? n : row_end));
       PCP_HIP_TRY(ctx, hipGetLastError());
     }
     int64_t redo = 0;
@@ -3424,7 +3432,7 @@ static int css_sweep1_chunk(pcp_context *ctx, SmoothStream &st, const std::vecto
   if ((rc = view_of(ctx, x2, y2, z2, m, &cv2)) != PCP_OK) return rc;
   PCP_HIP_TRY(ctx, ctx->s_kth.ensure(static_cast<size_t>(m) + 8));
   const double dens2 = (2.0 * st.p.vgd_iterations + 1.0) / (static_cast<double>(st.p.vgd_voxel_size) * st.p.vgd_voxel_size);
-  if ((rc = sor_run(ctx, cv2, st.p.sor_mean_k, st.p.sor_std_mul, false, 0, 1, /*classify=*/false, ctx->s_kth.p, /*clustered=*/true, dens2)) != PCP_OK) return rc;
+  if ((rc = sor_run(ctx, cv2, st.p.sor_mean_k, st.p.sor_std_mul, false, 0, 1, /*classify=*/false, ctx->s_kth.p, /*clustered=*/true, dens2, r0, r1)) != PCP_OK) return rc;
   // MLSVoxelGrid::getPosition of the first missing plane on either side (fp32, as k_voxel_emit forms it)
   const float xl = static_cast<float>(ea - 1) * st.S.v.vs + st.S.v.bminx, xh = static_cast<float>(eb + 1) * st.S.v.vs + st.S.v.bminx;
   PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->css_words.p + 1, 0xff, 4, ctx->stream));
