@@ -83,3 +83,5 @@ def test_bench_two_rank_path_runs_to_completion():
     legs = line["sharded_legs"]
     assert legs["hpr"]["hpr_ms"] > 0 and legs["hpr"]["hull_vertices"] > 0 and legs["hpr"]["keyframe0_shards_equal_owner"] is True
     assert legs["smooth"]["smooth_ms"] > 0 and legs["smooth"]["kept"] > 0 and legs["smooth"]["same_mask_on_every_rank"] is True
+    # the verdicts travel as bit-packed slices: three rounds (5 keyframes over 2 ranks) of at most n / 8 bytes (+ padding) per rank
+    assert 0 < legs["hpr"]["exchange_bytes_per_rank"] <= 3 * (150000 // 8 + 2)
