@@ -85,8 +85,13 @@ def read_summary(name):
         SUMMARY_STATE[name] = {"stale": True, "collected_on": None, "why": "missing"}
         return {}
     have = d.get("_build", {}).get("lib_sha256")
-    stale = have != lib_sha256()
-    SUMMARY_STATE[name] = {"stale": stale, "collected_on": have}
+    have_src = d.get("_build", {}).get("source_sha256")
+    # fresh: collected on the very library that runs, or (no PCP_HIP_LIBRARY override) on one built from the same sources
+    from pointcloudprocessor_amd import _build
+
+    same_sources = have_src is not None and not os.environ.get("PCP_HIP_LIBRARY") and have_src == _build.source_sha256()
+    stale = not (have == lib_sha256() or same_sources)
+    SUMMARY_STATE[name] = {"stale": stale, "collected_on": have, "same_library_bytes": have == lib_sha256(), "same_sources": bool(same_sources)}
     return {} if stale else d
 
 

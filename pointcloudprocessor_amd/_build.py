@@ -39,6 +39,20 @@ def _hipcc() -> str:
     return "hipcc"
 
 
+def source_sha256() -> str:
+    """SHA-256 over everything the library is made from (sources, headers, the C header, the compiler flags): two libraries
+    with the same value hold the same kernels even if they were built in different places."""
+    import hashlib
+
+    h = hashlib.sha256()
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    for f in [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(INCLUDE, "pcp_hip.h")]:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def is_stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
@@ -52,10 +66,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INCLUDE, "-I", CSRC, "-o", LIB_PATH] + [
-        os.path.join(CSRC, s) for s in SOURCES
-    ]
-    proc = subprocess.run(cmd, capture_output=True, text=True)
+    # hipcc runs INSIDE csrc/ with relative file names: the object embeds the names it was given, and a library built from the
+    # same sources must be the same bytes wherever the tree lies (profiles/build_stamp.py keys the counter summaries on its hash)
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", os.path.relpath(INCLUDE, CSRC), "-I", ".", "-o", LIB_PATH] + list(SOURCES)
+    proc = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
     if verbose or proc.returncode != 0:
         print(" ".join(cmd))
         print(proc.stdout)

@@ -26,8 +26,17 @@ def lib_sha256(path=None):
     return h.hexdigest()
 
 
+def source_sha256():
+    sys.path.insert(0, ROOT)
+    from pointcloudprocessor_amd import _build
+
+    return _build.source_sha256()
+
+
 def stamp():
-    return {"lib_sha256": lib_sha256()}
+    # lib_sha256: the bytes that ran; source_sha256: what they were built from (a library rebuilt elsewhere from the same
+    # sources counts as the same build even if a linker detail made its bytes differ)
+    return {"lib_sha256": lib_sha256(), "source_sha256": source_sha256()}
 
 
 def stamp_file(fn):
@@ -45,8 +54,10 @@ def read(fn, running_sha=None):
             d = json.load(fh)
     except (OSError, ValueError):
         return {}, True
-    have = d.get("_build", {}).get("lib_sha256")
-    return d, have is None or have != (running_sha or lib_sha256())
+    b = d.get("_build", {})
+    fresh = (b.get("lib_sha256") is not None and b.get("lib_sha256") == (running_sha or lib_sha256())) or (
+        b.get("source_sha256") is not None and b.get("source_sha256") == source_sha256())
+    return d, not fresh
 
 
 if __name__ == "__main__":
