@@ -27,6 +27,9 @@ HIPCC_FLAGS = [
     "-shared",
     "-ffp-contract=off",
     "-fhip-fp32-correctly-rounded-divide-sqrt",
+    # no compilation-unit id: hipcc derives it from the source's PATH and puts it into symbol names (__hip_cuid_<hash>), which
+    # made the library's bytes depend on where the tree lies; nothing here needs one (no static device variables, no -fgpu-rdc)
+    "-fuse-cuid=none",
     "-Wall",
     "-Wextra",
 ]
