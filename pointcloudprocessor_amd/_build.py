@@ -24,12 +24,8 @@ HIPCC_FLAGS = [
     "-O3",
     "-std=c++17",
     "-fPIC",
-    "-shared",
     "-ffp-contract=off",
     "-fhip-fp32-correctly-rounded-divide-sqrt",
-    # no compilation-unit id: hipcc derives it from the source's PATH and puts it into symbol names (__hip_cuid_<hash>), which
-    # made the library's bytes depend on where the tree lies; nothing here needs one (no static device variables, no -fgpu-rdc)
-    "-fuse-cuid=none",
     "-Wall",
     "-Wextra",
 ]
@@ -69,16 +65,40 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    # hipcc runs INSIDE csrc/ with relative file names: the object embeds the names it was given, and a library built from the
-    # same sources must be the same bytes wherever the tree lies (profiles/build_stamp.py keys the counter summaries on its hash)
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", os.path.relpath(INCLUDE, CSRC), "-I", ".", "-o", LIB_PATH] + list(SOURCES)
-    proc = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
+    # hipcc runs INSIDE csrc/ on relative file names, one translation unit per command with a FIXED compilation-unit id: the
+    # object embeds the names it was given, and hipcc's default unit id is a hash of the source's path that ends up in symbol
+    # names (__hip_cuid_<hash>) -- a library built from the same sources must be the same bytes wherever the tree lies
+    # (profiles/build_stamp.py keys the counter summaries on its hash).  The units compile side by side.
+    from concurrent.futures import ThreadPoolExecutor
+
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    inc = ["-I", os.path.relpath(INCLUDE, CSRC), "-I", "."]
+
+    def compile_one(src):
+        stem = os.path.splitext(src)[0]
+        obj = os.path.join(os.path.relpath(obj_dir, CSRC), stem + ".o")
+        cmd = [_hipcc()] + HIPCC_FLAGS + inc + [f"-cuid={stem}", "-c", src, "-o", obj]
+        return cmd, subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
+        results = list(pool.map(compile_one, SOURCES))
+    log = ""
+    for cmd, proc in results:
+        if verbose or proc.returncode != 0:
+            log += " ".join(cmd) + "\n" + proc.stdout + proc.stderr
+    if any(proc.returncode != 0 for _, proc in results):
+        print(log)
+        raise RuntimeError("hipcc failed building libpcp_hip.so:\n" + log[-4000:])
+    objs = [os.path.join(os.path.relpath(obj_dir, CSRC), os.path.splitext(src)[0] + ".o") for src in SOURCES]
+    link = [_hipcc(), "--offload-arch=gfx950", "--hip-link", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    proc = subprocess.run(link, capture_output=True, text=True, cwd=CSRC)
     if verbose or proc.returncode != 0:
-        print(" ".join(cmd))
+        print(log + " ".join(link))
         print(proc.stdout)
         print(proc.stderr)
     if proc.returncode != 0:
-        raise RuntimeError("hipcc failed building libpcp_hip.so:\n" + proc.stderr[-4000:])
+        raise RuntimeError("hipcc failed linking libpcp_hip.so:\n" + proc.stderr[-4000:])
     return LIB_PATH
 
 
