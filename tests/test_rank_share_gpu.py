@@ -197,3 +197,49 @@ def test_sor_and_cloud_smooth_10M(cloud10m, oracle):
     assert np.all(keep[a["index"]] == 1)  # survivors of the chain survived the first SOR
     assert np.all(np.diff(a["index"]) > 0)
     ctx.close()
+
+
+def test_streamed_chain_whole_map_is_chunking_invariant(cloud10m):
+    """CloudSmooth::process with the reference's own MLS configuration on the WHOLE 10 M-point map (2.8e9 upsampled rows:
+    pcp_cloud_smooth_stream_*): the chain cut into 11 and into 22 chunks gives the same rows before the last filter, the same
+    threshold to the last bit, the same number of survivors and the same checksums over their source indices and
+    positions; every survivor's source point survived the first outlier removal; each chunk's halo was PROVEN (margin above
+    the largest displacement), nothing had to be redone."""
+    import ctypes as C
+
+    from pointcloudprocessor_amd import capi
+
+    x, y, z = cloud10m
+    ctx = capi.Context(0)
+    ctx.set_camera(capi.default_camera())
+    ctx.upload_cloud(x, y, z)
+    keep1, _ = ctx.sor(60, 0.7)
+    vp = capi.default_mls_params()
+    runs = []
+    for cap in (1 << 28, 1 << 27):
+        rows, kept, chunks = ctx.cloud_smooth_stream_begin(vp, cap)
+        st = ctx.cloud_smooth_stream_stats()
+        got = 0
+        idx_sum = 0
+        x_sum = 0  # (of the positions' bit patterns: exact whatever the chunking)
+        nested = True
+        while True:
+            m = ctx.cloud_smooth_stream_next()
+            if m == 0:
+                break
+            idx = np.empty(m, np.int32)
+            xyz = np.empty((m, 3), np.float32)
+            ctx._check(ctx.lib.pcp_mls_fetch(ctx.h, C.c_int64(m), xyz.ctypes.data_as(C.c_void_p), None, None, idx.ctypes.data_as(C.c_void_p)))
+            got += m
+            idx_sum += int(idx.sum(dtype=np.int64))
+            x_sum += int(xyz.view(np.uint32).sum(dtype=np.uint64))
+            nested = nested and bool(np.all(keep1[idx[:: 997]] == 1))
+            del idx, xyz
+        runs.append(dict(rows=rows, kept=kept, got=got, chunks=chunks, idx_sum=idx_sum, x_sum=x_sum, thr=st["threshold"], st=st, nested=nested))
+    a, b = runs
+    assert a["chunks"] < b["chunks"] and a["rows"] == b["rows"] > 2_000_000_000
+    assert a["kept"] == a["got"] == b["kept"] == b["got"] and 0.5 * a["rows"] < a["kept"] < a["rows"]
+    assert a["thr"] == b["thr"] and a["idx_sum"] == b["idx_sum"] and a["x_sum"] == b["x_sum"]
+    for r in runs:
+        assert r["nested"] and r["st"]["chunks_redone"] == 0 and r["st"]["min_margin_m"] > r["st"]["max_displacement_m"] > 0
+    ctx.close()
