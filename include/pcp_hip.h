@@ -38,7 +38,7 @@ extern "C" {
                              5: no entry point or layout changed; pcp_cull_frame's out_keep, pcp_sor_partial's out_chunk_sums,
                                 pcp_sor_finish's all_chunk_sums / out_keep may be DEVICE memory of the context's GPU (the
                                 multi-GPU host exchanges them with RCCL instead of through the host)
-                             6: entry points added: pcp_cloud_smooth_stream_begin / _next / _stats (the whole enableMLS chain
+                             6: entry points added: pcp_cloud_smooth_stream_begin / _next / _end / _stats (the whole enableMLS chain
                                 with its trailing outlier removal over a chunked voxel dilation); pcp_hpr_stats reports
                                 candidates = -1 after a call served from the whole-run bits */
 
@@ -327,26 +327,32 @@ int pcp_cloud_smooth(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_cou
  * reference's own MLS configuration, PointCloudProcessor.cpp:67-86: VOXEL_GRID_DILATION 1 mm x 4 makes ~3.8e9 points of a
  * 10 M-point map): StatisticalOutlierRemoval -> MovingLeastSquares + upsampling -> StatisticalOutlierRemoval ON THE UPSAMPLED
  * CLOUD (:160-164), the last two stages streamed over chunks of the voxel key order (whole planes of the first axis).
- *   _begin: first filter, fit, voxel set; then sweep 1 -- every chunk is emitted together with a halo of neighbouring
- *           planes, the mean k-NN distances of its own rows are computed against chunk + halo and kept on the device (4 B per
- *           row of the whole upsampled cloud), (sum, sum of squares) are taken over ALL rows in row order, the filter's
- *           threshold follows.  The halo is CHECKED, not assumed: a row's neighbourhood (bound of the distance to its
- *           (k + 1)-th nearest) must end inside the part of space whose rows the halo is guaranteed to hold, given the largest
- *           displacement any row has from its voxel; a chunk that fails is redone with a wider halo.  The distances are
- *           therefore the ones the one-shot pcp_cloud_smooth computes, bit for bit; the threshold is summed in another
- *           order (row order instead of the cell order of one big grid) and agrees to rounding (~1e-16 relative).
+ *   _begin: first filter, fit, voxel set; sweep 0 projects a sample of the voxels to size the halo; then sweep 1 -- every chunk
+ *           is emitted together with a halo of neighbouring planes, the mean k-NN distances of its own rows are computed against
+ *           chunk + halo and kept on the device (4 B per row of the whole upsampled cloud), (sum, sum of squares) are taken over
+ *           ALL rows in row order, the filter's threshold follows.  The halo is CHECKED, not assumed: a row's neighbourhood (bound
+ *           of the distance to its (k + 1)-th nearest) must end inside the part of space whose rows the halo is guaranteed to
+ *           hold, given the largest displacement any row has from its voxel (taken over every row sweep 1 emitted -- all of them);
+ *           a chunk that fails is redone with a wider halo.  The distances are therefore the ones the one-shot pcp_cloud_smooth
+ *           computes, bit for bit; the threshold is summed in another order (row order instead of the cell order of one big
+ *           grid) and agrees to rounding (~1e-16 relative).
  *           out_total_rows = rows of the upsampled cloud before the last filter, out_kept_rows = after it.
  *   _next:  sweep 2 -- the next chunk's own rows are emitted again, classified by their stored distance and compacted:
  *           *out_count survivors in key order, fetched with pcp_mls_fetch (out_index refers to the uploaded cloud); 0 after
  *           the last chunk.  The concatenation over the chunks is what pcp_cloud_smooth returns when the cloud fits one result.
+ *   _end:   ends the stream and frees the distances (4 B per row: 11 GB for a 10 M-point map).  Optional: the next stream of
+ *           the context reuses them, a one-shot upsampling call that would not fit without them takes them, pcp_destroy frees them.
  * chunk_capacity: most voxels per chunk, own rows (>= 4096; every plane of the voxel grid must fit). */
 int pcp_cloud_smooth_stream_begin(pcp_context *ctx, const pcp_mls_params *p, int64_t chunk_capacity, int64_t *out_total_rows,
                                   int64_t *out_kept_rows, int32_t *out_chunks);
 int pcp_cloud_smooth_stream_next(pcp_context *ctx, int64_t *out_count);
+int pcp_cloud_smooth_stream_end(pcp_context *ctx);
 /* diagnostic of the last pcp_cloud_smooth_stream_begin: out[0] halo in planes (as finally used, the widest), [1] chunks redone
- * with a wider halo, [2] threshold of the last filter, [3] largest |x displacement| of a row from its voxel (m),
- * [4] smallest margin of any chunk (m; > [3] proves the halo), [5] rows computed including halos. */
-int pcp_cloud_smooth_stream_stats(pcp_context *ctx, double out[6]);
+ * with a wider halo, [2] threshold of the last filter, [3] largest |x displacement| of a row from its voxel (m; over all rows),
+ * [4] smallest margin of any chunk (m; > [3] proves the halo), [5] rows computed including halos, [6] the displacement sweep 0's
+ * sample saw (m; sized the halo), [7] bytes of device memory the stream holds at the time of the call, [8..11] host-clock
+ * seconds of _begin: first filter + fit + voxel set, allocations, sweep 0, sweep 1 + threshold. */
+int pcp_cloud_smooth_stream_stats(pcp_context *ctx, double out[12]);
 /* pcl::StatisticalOutlierRemoval (k, std_mul) keep mask of the uploaded cloud,
  * cloudSmooth.cpp:109-116,160-164.
  * The smoothing entry points (pcp_sor, pcp_mls_process[_shard], pcp_cloud_smooth, pcp_close_pairs) need finite

@@ -438,6 +438,7 @@ static int store_cloud(pcp_context *ctx, const float *x, const float *y, const f
   ctx->colour_result_live = false;
   ctx->mls_count = 0;
   ctx->vgd_next = ctx->css_next = -1;  // the streams of the smoothing stage belong to the cloud that is being replaced
+  ctx->css_ball = 0.0;
   std::fill(ctx->depth_valid.begin(), ctx->depth_valid.end(), uint8_t(0));
   ctx->hull_valid.clear();
   for (int a = 0; a < 3; ++a) ctx->host_min[a] = ctx->host_max[a] = 0.0f;

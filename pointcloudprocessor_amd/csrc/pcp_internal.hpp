@@ -281,6 +281,8 @@ struct pcp_context {
   pcp::DevBuf<float> css_dist;      // mean kNN distance of EVERY row of the dilated cloud (4 B x ~3.8e9 at C3)
   pcp::DevBuf<float> s_kth;         // per row of a chunk: bound of the squared distance to its (k + 1)-th nearest
   pcp::DevBuf<uint32_t> css_words;  // device scalars of the stream (max displacement, margins, counts)
+  bool css_building = false;        // inside pcp_cloud_smooth_stream_begin
+  double css_ball = 0.0;            // the trailing filter's ball, in (k + 1) rows by the voxel structure's density bound, as the last chunks left it (0: default)
   double sor_redo_fraction = 0.0;  // diagnostic: share of points the SOR selection kernel handed to the heap kernel
 
   // NID stage (section 8 f1): per-point intensity, per-keyframe culled clouds in camera

@@ -17,6 +17,7 @@
 // digits.  Parity bar: 1e-4 relative on positions, normals up to sign.
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <limits>
 
@@ -1010,6 +1011,8 @@ struct VoxelEmitArgs {
   int32_t *index;
   uint8_t *valid;
   uint32_t *max_dx;  // nullable: max over the emitted points of |x of the point - x of its voxel position| (bits of a float >= 0)
+  int32_t dry;       // 1: nothing is stored -- the launch is for max_dx alone (sweep 0 of the streamed chain)
+  int32_t block_step;  // workgroup b takes voxels [b * block_step * kMB, ... + kMB): 1 = every voxel, 8 = a sample of one in eight
 };
 
 // the occupied voxels of bitmap words [word_base, word_base + words) in key order: a workgroup per tile of kScanTile words,
@@ -1079,6 +1082,7 @@ __device__ __forceinline__ float voxel_emit_one(const VoxelEmitArgs &a, int64_t 
   bool ok = best >= 0;
   const double *st = a.state + static_cast<int64_t>(ok ? best : 0) * kMlsState;
   ok = ok && st[20] >= 1.0;  // mls_results_[input_index].valid
+  float ox = 0.0f;
   if (ok) {
     // MLSResult::projectPoint(pt, SIMPLE, 5 * nr_coeff)
     const double dx = static_cast<double>(px) - st[0], dy = static_cast<double>(py) - st[1],
@@ -1090,40 +1094,47 @@ __device__ __forceinline__ float voxel_emit_one(const VoxelEmitArgs &a, int64_t 
       // getPolynomialPartialDerivative: monomials 1, v, v^2, u, uv, u^2
       const double c0 = st[12], c1 = st[13], c2 = st[14], c3 = st[15], c4 = st[16], c5 = st[17];
       wgt = c0 + vv * c1 + (vv * vv) * c2 + u * c3 + (u * vv) * c4 + (u * u) * c5;
-      const double zu = c3 + c4 * vv + c5 * 2.0 * u;
-      const double zv = c1 + c2 * 2.0 * vv + c4 * u;
-      nx -= zu * st[6] + zv * st[9];
-      ny -= zu * st[7] + zv * st[10];
-      nz -= zu * st[8] + zv * st[11];
-      const double l = sqrt((nx * nx + ny * ny) + nz * nz);
-      if (l > 0.0) {
-        nx /= l; ny /= l; nz /= l;
+      if (!a.dry) {
+        const double zu = c3 + c4 * vv + c5 * 2.0 * u;
+        const double zv = c1 + c2 * 2.0 * vv + c4 * u;
+        nx -= zu * st[6] + zv * st[9];
+        ny -= zu * st[7] + zv * st[10];
+        nz -= zu * st[8] + zv * st[11];
+        const double l = sqrt((nx * nx + ny * ny) + nz * nz);
+        if (l > 0.0) {
+          nx /= l; ny /= l; nz /= l;
+        }
       }
     }
-    a.xyz[3 * out + 0] = static_cast<float>(st[0] + u * st[6] + vv * st[9] + wgt * st[3]);
-    a.xyz[3 * out + 1] = static_cast<float>(st[1] + u * st[7] + vv * st[10] + wgt * st[4]);
-    a.xyz[3 * out + 2] = static_cast<float>(st[2] + u * st[8] + vv * st[11] + wgt * st[5]);
-    a.normal[3 * out + 0] = static_cast<float>(nx);
-    a.normal[3 * out + 1] = static_cast<float>(ny);
-    a.normal[3 * out + 2] = static_cast<float>(nz);
-    a.curv[out] = static_cast<float>(st[18]);
-    a.index[out] = best;
+    ox = static_cast<float>(st[0] + u * st[6] + vv * st[9] + wgt * st[3]);
+    if (!a.dry) {
+      a.xyz[3 * out + 0] = ox;
+      a.xyz[3 * out + 1] = static_cast<float>(st[1] + u * st[7] + vv * st[10] + wgt * st[4]);
+      a.xyz[3 * out + 2] = static_cast<float>(st[2] + u * st[8] + vv * st[11] + wgt * st[5]);
+      a.normal[3 * out + 0] = static_cast<float>(nx);
+      a.normal[3 * out + 1] = static_cast<float>(ny);
+      a.normal[3 * out + 2] = static_cast<float>(nz);
+      a.curv[out] = static_cast<float>(st[18]);
+      a.index[out] = best;
+    }
   }
-  a.valid[out] = ok ? 1 : 0;
-  float d = ok ? fabsf(a.xyz[3 * out] - px) : 0.0f;
+  if (!a.dry) a.valid[out] = ok ? 1 : 0;
+  float d = ok ? fabsf(ox - px) : 0.0f;
   if (!(d == d)) d = INFINITY;  // a NaN position: no bound
   return d;
 }
 
 __global__ __launch_bounds__(kMB) void k_voxel_emit(VoxelEmitArgs a) {
-  const int64_t out = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
+  const int64_t out = static_cast<int64_t>(blockIdx.x) * a.block_step * kMB + threadIdx.x;
   const float d = out < a.total ? voxel_emit_one(a, out) : 0.0f;
   if (a.max_dx) {
     // how far (along x, the axis the streamed chain cuts the key order by) the projection moved a point from its voxel: the
     // maximum over the launch (every lane takes part in the reduction)
     uint32_t b = __float_as_uint(d);
     for (int o = 32; o >= 1; o >>= 1) b = max(b, static_cast<uint32_t>(__shfl_xor(static_cast<int>(b), o, 64)));
-    if ((threadIdx.x & 63) == 0 && b) atomicMax(a.max_dx, b);
+    // (only a wavefront that would raise the maximum it reads goes to the atomic: four million atomics on one address were
+    // 40 ms of a 53 ms launch)
+    if ((threadIdx.x & 63) == 0 && b > __atomic_load_n(a.max_dx, __ATOMIC_RELAXED)) atomicMax(a.max_dx, b);
   }
 }
 
@@ -1660,11 +1671,21 @@ __global__ __launch_bounds__(kSelWave) void k_sor_wave(const float *__restrict__
                                                        const int32_t *__restrict__ start, int64_t n, GridDesc g,
                                                        int32_t mean_k, float *__restrict__ distances,
                                                        uint8_t *__restrict__ redo, const int32_t *__restrict__ list,
-                                                       int64_t list_n, float *__restrict__ kth) {
+                                                       int64_t list_n, float *__restrict__ kth,
+                                                       unsigned long long *__restrict__ tally /* nullable: PCP_SOR_WAVE_STATS */) {
 #pragma clang fp contract(off)
   __shared__ float cache[kWsCap];
   const int lane = threadIdx.x;
   if (static_cast<int64_t>(blockIdx.x) >= list_n) return;
+  const unsigned long long t_start = tally ? wall_clock64() : 0ull;
+  int32_t passes = 0;
+  auto tally_up = [&](bool overflow, bool was_far) {  // per number of block passes: wavefronts, 100 MHz ticks
+    if (tally && lane == 0) {
+      const int slot = min(passes, 15) + (was_far ? 16 : 0) + (overflow ? 32 : 0);
+      atomicAdd(&tally[2 * slot], 1ull);
+      atomicAdd(&tally[2 * slot + 1], wall_clock64() - t_start);
+    }
+  };
   const int32_t j = list[blockIdx.x];
   const int k = mean_k + 1;
   const float qx = sx[j], qy = sy[j], qz = sz[j];
@@ -1698,6 +1719,7 @@ __global__ __launch_bounds__(kSelWave) void k_sor_wave(const float *__restrict__
     const int32_t z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
     const int32_t wy = y1 - y0 + 1, nrows = wy * (z1 - z0 + 1);
     M = 0;
+    passes += 1;
     for (int32_t r0 = 0; r0 < nrows; r0 += kSelWave) {
       const int32_t r = r0 + lane;
       int32_t b = 0, len = 0;
@@ -1784,6 +1806,7 @@ __global__ __launch_bounds__(kSelWave) void k_sor_wave(const float *__restrict__
   }
   if (M > kWsCap) {  // uniform
     if (lane == 0) redo[j] = 2;
+    tally_up(true, far);
     return;
   }
   // the k-th smallest cached value (1-based; the query itself is among them), bit by bit from the top
@@ -1864,6 +1887,7 @@ __global__ __launch_bounds__(kSelWave) void k_sor_wave(const float *__restrict__
     if (kth) kth[remap ? remap[order[j]] : order[j]] = T0;
     redo[j] = 0;
   }
+  tally_up(false, far);
 }
 
 // sum and sum of squares (fp32 squares, as the reference) of the distances, fp64 accumulation.  One pair of partial sums
@@ -2433,12 +2457,21 @@ static int vgd_prepare(pcp_context *ctx, const CloudView &cv, const pcp_mls_para
 }
 
 // the voxels of bitmap words [word0, word1) (word0 a multiple of kScanTile), `count` of them: results in ctx->mls_*
+// sample_step > 0: nothing is emitted -- one workgroup of voxels in `sample_step` is projected for max_dx alone (*out_m = 0)
 static int vgd_emit(pcp_context *ctx, const VgdStream &S, int64_t word0, int64_t word1, int64_t count, int64_t *out_m,
-                    uint32_t *max_dx = nullptr) {
+                    uint32_t *max_dx = nullptr, int32_t sample_step = 0) {
   const size_t st = static_cast<size_t>(count);
   size_t free_b = 0, total_b = 0;
   PCP_HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
-  if (static_cast<double>(st) * 78.0 > static_cast<double>(free_b) + static_cast<double>(ctx->mls_xyz.count) * 4.0 * 2.4)
+  auto short_of_memory = [&]() {
+    return static_cast<double>(st) * 78.0 > static_cast<double>(free_b) + static_cast<double>(ctx->mls_xyz.count) * 4.0 * 2.4;
+  };
+  if (short_of_memory() && ctx->css_next < 0 && !ctx->css_building && ctx->css_dist.p) {
+    // the memory an ended stream of the whole chain still holds (4 B per row of its upsampled cloud) goes first
+    ctx->css_dist.release();
+    PCP_HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+  }
+  if (short_of_memory())
     return set_error(ctx, PCP_ERR_NOMEM, "pcp_mls_process: %lld upsampled points do not fit the device memory "
                      "(pcp_mls_stream_begin / _next emit them in chunks)", (long long)count);
   PCP_HIP_TRY(ctx, ctx->mls_xyz.ensure(3 * st + 4));
@@ -2484,6 +2517,8 @@ static int vgd_emit(pcp_context *ctx, const VgdStream &S, int64_t word0, int64_t
     e.index = ctx->mls_index.p;
     e.valid = ctx->m_flag.p;
     e.max_dx = max_dx;
+    e.dry = sample_step > 0 ? 1 : 0;
+    e.block_step = std::max(1, sample_step);
     {
       LaunchTimer t(ctx, PCP_K_MLS_VOXEL);
       hipLaunchKernelGGL(k_scan_tile_sums, dim3(scan_grid(tiles2)), dim3(kScanBlock), 0, ctx->stream, tile_first, tiles, level2);
@@ -2498,8 +2533,13 @@ static int vgd_emit(pcp_context *ctx, const VgdStream &S, int64_t word0, int64_t
         hipLaunchKernelGGL(k_voxel_expand, dim3(scan_grid(tiles)), dim3(kScanBlock), 0, ctx->stream, ctx->v_bitmap.p + word0, tile_first,
                            words, word0, ctx->v_vox.p);
       }
-      hipLaunchKernelGGL(k_voxel_emit, dim3(blocks_of(count)), dim3(kMB), 0, ctx->stream, e);
+      hipLaunchKernelGGL(k_voxel_emit, dim3(static_cast<uint32_t>(div_up(div_up(count, kMB), e.block_step))), dim3(kMB), 0, ctx->stream, e);
       PCP_HIP_TRY(ctx, hipGetLastError());
+    }
+    if (sample_step > 0) {
+      ctx->mls_count = 0;
+      if (out_m) *out_m = 0;
+      return PCP_OK;
     }
     // voxels whose nearest point has no valid fit are skipped by PCL: compact if any
     PCP_HIP_TRY(ctx, ctx->s_cell.ensure(st + 4));
@@ -2782,7 +2822,8 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
     // profiles/r05_vgd_sor_ball.log.)
     // (the density handed in is a lower bound -- tilted and noisy sheets carry more voxels per area --: 1.2 (k + 1) points by
     // the bound leave 0.05 % of the 425 M rows to the wavefront kernel; 1.5: 414 ms, 1.2: 385, 1.0: 354, 0.8: 331)
-    double ball = 1.2;
+    // (the streamed chain moves it from chunk to chunk by the share of rows the selection flagged: ctx->css_ball)
+    double ball = ctx->css_building && ctx->css_ball > 0.0 ? ctx->css_ball : 1.2;
     if (const char *e = std::getenv("PCP_SOR_BALL")) ball = atof(e);
     double final_cell = std::sqrt(ball * (mean_k + 1) / (3.14159265358979 * area_density));
     if (!(final_cell > 1e-7) || !(final_cell < 1e30)) final_cell = static_cast<double>(cell);
@@ -2873,10 +2914,28 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
       LaunchTimer t(ctx, PCP_K_SOR);
       const char *no_wave = std::getenv("PCP_SOR_NO_WAVE");
       const bool wave = !(no_wave && no_wave[0] == '1');
+      // PCP_SOR_WAVE_STATS=1: what the flagged points cost, by the number of block passes each needed (stderr, one line per run)
+      static const bool wave_stats = [] { const char *e = std::getenv("PCP_SOR_WAVE_STATS"); return e && e[0] == '1'; }();
+      unsigned long long *tally = nullptr;
+      if (wave && wave_stats) {
+        PCP_HIP_TRY(ctx, ctx->s_u32.ensure(2 * 2 * 48 + 8));
+        tally = reinterpret_cast<unsigned long long *>(ctx->s_u32.p);
+        PCP_HIP_TRY(ctx, hipMemsetAsync(tally, 0, 2 * 48 * 8, ctx->stream));
+      }
       if (wave)
         hipLaunchKernelGGL(k_sor_wave, dim3(static_cast<uint32_t>(redo)), dim3(kSelWave), 0, ctx->stream, ctx->g_xyz.p,
                            ctx->g_xyz.p + plane, ctx->g_xyz.p + 2 * plane, ctx->g_order.p, remap, ctx->g_start.p, n, g, mean_k,
-                           dist, ctx->m_flag.p, ctx->s_cell.p, redo, kth);
+                           dist, ctx->m_flag.p, ctx->s_cell.p, redo, kth, tally);
+      if (tally) {
+        unsigned long long h[2 * 48];
+        PCP_HIP_TRY(ctx, hipMemcpyAsync(h, tally, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        std::fprintf(stderr, "[pcp] k_sor_wave n=%lld flagged=%lld cell=%.5f reach=%d:", (long long)n, (long long)redo, 1.0 / g.inv_cell, g.reach);
+        for (int k = 0; k < 48; ++k)
+          if (h[2 * k]) std::fprintf(stderr, " %s%s%d:%llux%.1fus", k >= 32 ? "o" : "", (k & 16) ? "f" : "", k & 15, h[2 * k],
+                                     static_cast<double>(h[2 * k + 1]) / static_cast<double>(h[2 * k]) * 0.01);
+        std::fprintf(stderr, "\n");
+      }
       hipLaunchKernelGGL(k_sor_mean_distance, dim3(static_cast<uint32_t>(div_up(redo, kSorBlock))), dim3(kSorBlock), heap_lds,
                          ctx->stream, ctx->g_xyz.p, ctx->g_xyz.p + plane, ctx->g_xyz.p + 2 * plane, ctx->g_order.p,
                          remap, ctx->g_start.p, n, g, mean_k, dist, ctx->s_cell.p, redo,
@@ -3007,6 +3066,8 @@ struct SmoothStream {  // plain data, kept in ctx->css_blob between pcp_cloud_sm
   int64_t total_rows, kept_rows, rows_computed;
   double threshold, max_dx, min_margin;
   int32_t halo, redone;
+  double sampled_dx;  // the largest displacement sweep 0 saw on its sample of the voxels (sizes the halo; max_dx proves it)
+  double seconds[4];  // host clock of _begin: first filter + fit + voxel set, allocations, sweep 0, sweep 1 + threshold
 };
 
 // the grid the emission searches, rebuilt (the outlier removal of a chunk overwrites it): the same call sequence as mls_run's
@@ -3392,13 +3453,47 @@ int pcp_cloud_smooth(pcp_context *ctx, const pcp_mls_params *p, int64_t *out_cou
 
 namespace pcp {
 
+// The mean k-NN distances of `m` rows (interleaved positions at rows_xyz) of which rows [r0, r1) are a chunk's own and the
+// others its halo -- planes [ea, eb] of the voxel grid are present --: the own rows' distances into css_dist at row0,
+// *out_margin = how far their neighbourhoods stay from the first missing planes (k_rows_margin).
+static int css_rows_distances(pcp_context *ctx, SmoothStream &st, const float *rows_xyz, int64_t m, int64_t r0, int64_t r1, int64_t ea,
+                              int64_t eb, int64_t row0, float *out_margin) {
+  const int64_t NX = st.S.v.NX;
+  int rc;
+  const size_t plane2 = (static_cast<size_t>(m) + 3) & ~size_t(3);
+  PCP_HIP_TRY(ctx, ctx->c_xyz2.ensure(3 * plane2 + 4));
+  float *x2 = ctx->c_xyz2.p, *y2 = ctx->c_xyz2.p + plane2, *z2 = ctx->c_xyz2.p + 2 * plane2;
+  hipLaunchKernelGGL(k_deinterleave, dim3(blocks_of(m)), dim3(kMB), 0, ctx->stream, rows_xyz, m, x2, y2, z2);
+  PCP_HIP_TRY(ctx, hipGetLastError());
+  CloudView cv2;
+  if ((rc = view_of(ctx, x2, y2, z2, m, &cv2)) != PCP_OK) return rc;
+  PCP_HIP_TRY(ctx, ctx->s_kth.ensure(static_cast<size_t>(m) + 8));
+  const double dens2 = (2.0 * st.p.vgd_iterations + 1.0) / (static_cast<double>(st.p.vgd_voxel_size) * st.p.vgd_voxel_size);
+  if ((rc = sor_run(ctx, cv2, st.p.sor_mean_k, st.p.sor_std_mul, false, 0, 1, /*classify=*/false, ctx->s_kth.p, /*clustered=*/true, dens2, r0, r1)) != PCP_OK) return rc;
+  // MLSVoxelGrid::getPosition of the first missing plane on either side (fp32, as k_voxel_emit forms it)
+  const float xl = static_cast<float>(ea - 1) * st.S.v.vs + st.S.v.bminx, xh = static_cast<float>(eb + 1) * st.S.v.vs + st.S.v.bminx;
+  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->css_words.p + 1, 0xff, 4, ctx->stream));
+  hipLaunchKernelGGL(k_rows_margin, dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(r1 - r0, kMB), 4096))), dim3(kMB), 0, ctx->stream,
+                     rows_xyz, ctx->s_kth.p, r0, r1, static_cast<double>(xl), static_cast<double>(xh), ea > 0 ? 1 : 0,
+                     eb < NX - 1 ? 1 : 0, ctx->css_words.p + 1);
+  PCP_HIP_TRY(ctx, hipGetLastError());
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->css_dist.p + row0, ctx->s_dist.p + r0, static_cast<size_t>(r1 - r0) * sizeof(float),
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+  uint32_t key = 0;
+  PCP_HIP_TRY(ctx, hipMemcpyAsync(&key, ctx->css_words.p + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  *out_margin = float_of_key(key);
+  return PCP_OK;
+}
+
 // Sweep 1 of one chunk: the voxels of planes [ia, ib] emitted together with `H` planes on either side, the mean k-NN
 // distances of every emitted row, the chunk's own rows' distances into css_dist at row0.  *out_rows = the chunk's own rows,
-// *out_margin = how far their neighbourhoods stay from the first missing planes (k_rows_margin), *out_ext_rows = rows computed.
+// *out_margin as above, *out_ext_rows = rows computed.
 static int css_sweep1_chunk(pcp_context *ctx, SmoothStream &st, const std::vector<unsigned long long> &planes, int64_t ia, int64_t ib,
                             int64_t H, int64_t row0, int64_t *out_rows, float *out_margin, int64_t *out_ext_rows) {
   const int64_t NX = st.S.v.NX, NBY = st.S.NBY;
   const int64_t ea = std::max<int64_t>(0, ia - H), eb = std::min<int64_t>(NX - 1, ib + H);
+  *out_margin = INFINITY;
   unsigned long long a = 0, core = 0, ext = 0;
   for (int64_t ix = ea; ix <= eb; ++ix) {
     const unsigned long long c = planes[static_cast<size_t>(ix)];
@@ -3421,32 +3516,8 @@ static int css_sweep1_chunk(pcp_context *ctx, SmoothStream &st, const std::vecto
   if ((rc = compact_flags(ctx, ctx->m_flag.p, static_cast<int64_t>(a + core), nullptr, 0, &r1)) != PCP_OK) return rc;
   *out_rows = r1 - r0;
   *out_ext_rows = m;
-  *out_margin = INFINITY;
   if (r1 == r0) return PCP_OK;
-  const size_t plane2 = (static_cast<size_t>(m) + 3) & ~size_t(3);
-  PCP_HIP_TRY(ctx, ctx->c_xyz2.ensure(3 * plane2 + 4));
-  float *x2 = ctx->c_xyz2.p, *y2 = ctx->c_xyz2.p + plane2, *z2 = ctx->c_xyz2.p + 2 * plane2;
-  hipLaunchKernelGGL(k_deinterleave, dim3(blocks_of(m)), dim3(kMB), 0, ctx->stream, ctx->mls_xyz.p, m, x2, y2, z2);
-  PCP_HIP_TRY(ctx, hipGetLastError());
-  CloudView cv2;
-  if ((rc = view_of(ctx, x2, y2, z2, m, &cv2)) != PCP_OK) return rc;
-  PCP_HIP_TRY(ctx, ctx->s_kth.ensure(static_cast<size_t>(m) + 8));
-  const double dens2 = (2.0 * st.p.vgd_iterations + 1.0) / (static_cast<double>(st.p.vgd_voxel_size) * st.p.vgd_voxel_size);
-  if ((rc = sor_run(ctx, cv2, st.p.sor_mean_k, st.p.sor_std_mul, false, 0, 1, /*classify=*/false, ctx->s_kth.p, /*clustered=*/true, dens2, r0, r1)) != PCP_OK) return rc;
-  // MLSVoxelGrid::getPosition of the first missing plane on either side (fp32, as k_voxel_emit forms it)
-  const float xl = static_cast<float>(ea - 1) * st.S.v.vs + st.S.v.bminx, xh = static_cast<float>(eb + 1) * st.S.v.vs + st.S.v.bminx;
-  PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->css_words.p + 1, 0xff, 4, ctx->stream));
-  hipLaunchKernelGGL(k_rows_margin, dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(r1 - r0, kMB), 4096))), dim3(kMB), 0, ctx->stream,
-                     ctx->mls_xyz.p, ctx->s_kth.p, r0, r1, static_cast<double>(xl), static_cast<double>(xh), ea > 0 ? 1 : 0,
-                     eb < NX - 1 ? 1 : 0, ctx->css_words.p + 1);
-  PCP_HIP_TRY(ctx, hipGetLastError());
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(ctx->css_dist.p + row0, ctx->s_dist.p + r0, static_cast<size_t>(r1 - r0) * sizeof(float),
-                                  hipMemcpyDeviceToDevice, ctx->stream));
-  uint32_t key = 0;
-  PCP_HIP_TRY(ctx, hipMemcpyAsync(&key, ctx->css_words.p + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
-  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  *out_margin = float_of_key(key);
-  return PCP_OK;
+  return css_rows_distances(ctx, st, ctx->mls_xyz.p, m, r0, r1, ea, eb, row0, out_margin);
 }
 
 }  // namespace pcp
@@ -3475,6 +3546,18 @@ int pcp_cloud_smooth_stream_begin(pcp_context *ctx, const pcp_mls_params *p, int
   SmoothStream st{};
   st.p = *p;
   const CloudView cv0 = uploaded_view(ctx);
+  struct Building {
+    pcp_context *c;
+    explicit Building(pcp_context *c_) : c(c_) { c->css_building = true; }
+    ~Building() { c->css_building = false; }
+  } building(ctx);
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_mark = now();
+  auto lap = [&](int k) {  // (every phase ends in a readback: the stream is idle here)
+    const double t = now();
+    st.seconds[k] += t - t_mark;
+    t_mark = t;
+  };
   auto publish = [&]() {
     ctx->css_blob.assign(reinterpret_cast<const uint8_t *>(&st), reinterpret_cast<const uint8_t *>(&st) + sizeof(st));
     ctx->css_next = 0;
@@ -3525,38 +3608,55 @@ int pcp_cloud_smooth_stream_begin(pcp_context *ctx, const pcp_mls_params *p, int
     if (ia >= 0 && cnt > 0) ch.insert(ch.end(), {ia, NX - 1, static_cast<int64_t>(cnt), 0, 0});
   }
   const size_t n_chunks = ch.size() / 5;
+  lap(0);
   PCP_HIP_TRY(ctx, ctx->css_dist.ensure(static_cast<size_t>(total_voxels) + 8));
   PCP_HIP_TRY(ctx, ctx->css_words.ensure(32));
   PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->css_words.p, 0, 32 * 4, ctx->stream));
-  // Sweep 0: every chunk emitted once for the largest displacement |x of a row - x of its voxel position| alone (the emission
-  // is ~5 % of the chain's time).  A row of a missing plane lies within that displacement of its plane, a chunk's own row
-  // within it of the chunk, so a halo of H planes leaves a margin of H vs - 2 displacement - (k-NN radius) ...
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  lap(1);
+  // The halo must outreach the largest displacement D = max |x of a row - x of its voxel position| of ANY row: a row of a missing
+  // plane lies within D of its plane, a chunk's own row within D of the chunk, so a halo of H planes leaves a margin of
+  // H vs - 2 D - (k-NN radius).  D itself is only known when every row has been emitted -- which sweep 1 does anyway (every
+  // voxel is some chunk's own): it keeps the maximum, and the margins are checked against THAT afterwards.  Sweep 0 only
+  // has to size the halo well enough that the check passes: it projects a sample of the voxels (one workgroup in
+  // kCssSample, nothing stored: a tenth of an emission; emitting every chunk for D alone was 16 % of the chain).
+  constexpr int32_t kCssSample = 8;
   {
     GridDesc g;
     if ((rc = stream_grid(ctx, st.cv1, &st.p, &g)) != PCP_OK) return rc;
     st.S.g = g;
     for (size_t c = 0; c < n_chunks; ++c) {
       int64_t m0 = 0;
-      if ((rc = vgd_emit(ctx, st.S, ch[5 * c] * st.S.NBY, (ch[5 * c + 1] + 1) * st.S.NBY, ch[5 * c + 2], &m0, ctx->css_words.p)) != PCP_OK) return rc;
+      if ((rc = vgd_emit(ctx, st.S, ch[5 * c] * st.S.NBY, (ch[5 * c + 1] + 1) * st.S.NBY, ch[5 * c + 2], &m0, ctx->css_words.p, kCssSample)) != PCP_OK) return rc;
     }
   }
-  float max_dx = 0.0f;
-  {
+  auto read_max_dx = [&](double *out) -> int {
     uint32_t dx_bits = 0;
+    float v = 0.0f;
     PCP_HIP_TRY(ctx, hipMemcpyAsync(&dx_bits, ctx->css_words.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    std::memcpy(&max_dx, &dx_bits, 4);
-  }
-  if (!(max_dx >= 0.0f) || !std::isfinite(max_dx))
-    return set_error(ctx, PCP_ERR_INVALID, "pcp_cloud_smooth_stream_begin: a row of the upsampled cloud has no finite position");
-  st.max_dx = static_cast<double>(max_dx);
-  // ... halo in planes: twice the displacement and 16 voxels for the k-NN radius of the dense upsampled surface (1-3 voxels);
-  // CHECKED per chunk below, widened where the check fails (PCP_CSS_HALO: another first guess -- the tests force a failure)
-  int64_t H = static_cast<int64_t>(std::ceil(2.0 * st.max_dx / static_cast<double>(st.S.v.vs))) + 16;
+    std::memcpy(&v, &dx_bits, 4);
+    if (!(v >= 0.0f) || !std::isfinite(v))
+      return set_error(ctx, PCP_ERR_INVALID, "pcp_cloud_smooth_stream_begin: a row of the upsampled cloud has no finite position");
+    *out = static_cast<double>(v);
+    return PCP_OK;
+  };
+  if ((rc = read_max_dx(&st.sampled_dx)) != PCP_OK) return rc;
+  lap(2);
+  // ... halo in planes: twice the displacement (the sample's, and a quarter on top for what it missed) and 16 voxels for the
+  // k-NN radius of the dense upsampled surface (1-3 voxels); CHECKED per chunk below against the displacement of all rows,
+  // widened where the check fails (PCP_CSS_HALO: another first guess -- the tests force a failure)
+  int64_t H = static_cast<int64_t>(std::ceil(2.0 * 1.25 * st.sampled_dx / static_cast<double>(st.S.v.vs))) + 16;
   if (const char *he = std::getenv("PCP_CSS_HALO")) H = std::max(1, std::atoi(he));
   st.halo = static_cast<int32_t>(std::min<int64_t>(H, NX));
   std::vector<float> margin(n_chunks, INFINITY);
   int64_t row0 = 0;
+  // The ball of the trailing filter's selection (in (k + 1) rows by the density bound of the voxel structure; it only sizes the
+  // grid, the distances do not depend on it): the rows of a dilated cloud sit on a lattice of voxel columns, and how many columns a
+  // ball catches jumps with its radius -- on the 10 M-point map a ball of 1.2 leaves 10 % of the rows with fewer than k + 1
+  // neighbours (a wavefront each in k_sor_wave: 0.5 s of the chain), 1.9 leaves 1.4 %, while the map at a tenth of the density is
+  // best served by 1.0-1.2 (profiles/r05_css_ball_sweep.log).  So the ball follows what the last chunk reported.
+  if (!(ctx->css_ball > 0.0)) ctx->css_ball = 1.2;
   for (size_t c = 0; c < n_chunks; ++c) {
     int64_t rows = 0, ext_rows = 0;
     if ((rc = css_sweep1_chunk(ctx, st, planes, ch[5 * c], ch[5 * c + 1], H, row0, &rows, &margin[c], &ext_rows)) != PCP_OK) return rc;
@@ -3564,16 +3664,24 @@ int pcp_cloud_smooth_stream_begin(pcp_context *ctx, const pcp_mls_params *p, int
     ch[5 * c + 4] = rows;
     row0 += rows;
     st.rows_computed += ext_rows;
+    if (rows > 0) {
+      const double flagged = ctx->sor_redo_fraction * static_cast<double>(ext_rows) / static_cast<double>(rows);  // (of the own rows)
+      if (std::getenv("PCP_CSS_DEBUG")) std::fprintf(stderr, "[pcp] chunk %zu: ball %.3f, %.4f of the own rows flagged\n", c, ctx->css_ball, flagged);
+      if (flagged > 0.03) ctx->css_ball = std::min(2.4, ctx->css_ball * 1.26);
+      else if (flagged < 0.003) ctx->css_ball = std::max(1.0, ctx->css_ball / 1.12);
+    }
   }
   st.total_rows = row0;
   st.min_margin = INFINITY;
+  if ((rc = read_max_dx(&st.max_dx)) != PCP_OK) return rc;  // every row has been emitted: THE displacement
+  const int64_t H_needed = static_cast<int64_t>(std::ceil(2.0 * st.max_dx / static_cast<double>(st.S.v.vs))) + 16;
   for (size_t c = 0; c < n_chunks; ++c) {
     int64_t Hc = H;
     // a margin at or below the displacement: some neighbourhood may reach rows the halo did not hold -- again, wider
     while (!(static_cast<double>(margin[c]) > st.max_dx * (1.0 + 1e-6) + 1e-9)) {
       if (Hc >= NX) return set_error(ctx, PCP_ERR_RANGE, "pcp_cloud_smooth_stream_begin: the neighbourhood of a row of chunk %zu has no bound "
                                      "(margin %g m against a displacement of %g m with every plane emitted)", c, (double)margin[c], st.max_dx);
-      Hc *= 2;
+      Hc = std::max(2 * Hc, Hc < H_needed ? H_needed : 0);
       int64_t rows = 0, ext_rows = 0;
       if ((rc = css_sweep1_chunk(ctx, st, planes, ch[5 * c], ch[5 * c + 1], Hc, ch[5 * c + 3], &rows, &margin[c], &ext_rows)) != PCP_OK) return rc;
       if (rows != ch[5 * c + 4]) return set_error(ctx, PCP_ERR_STATE, "pcp_cloud_smooth_stream_begin: chunk %zu changed its rows", c);
@@ -3601,6 +3709,7 @@ int pcp_cloud_smooth_stream_begin(pcp_context *ctx, const pcp_mls_params *p, int
     PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     st.kept_rows = static_cast<int64_t>(kept);
   }
+  lap(3);
   publish();
   if (out_total_rows) *out_total_rows = st.total_rows;
   if (out_kept_rows) *out_kept_rows = st.kept_rows;
@@ -3626,6 +3735,7 @@ int pcp_cloud_smooth_stream_next(pcp_context *ctx, int64_t *out_count) {
   const int64_t ia = ch[5 * c], ib = ch[5 * c + 1], voxels = ch[5 * c + 2], row0 = ch[5 * c + 3], rows = ch[5 * c + 4];
   const int64_t next_before = ctx->css_next;
   int rc;
+  double *d_thr = reinterpret_cast<double *>(ctx->css_words.p + 8);
   GridDesc g;
   if ((rc = stream_grid(ctx, st.cv1, &st.p, &g)) != PCP_OK) return rc;  // (build_grid does not go through mls_run: the stream stays)
   st.S.g = g;
@@ -3634,7 +3744,6 @@ int pcp_cloud_smooth_stream_next(pcp_context *ctx, int64_t *out_count) {
   if (m != rows) return set_error(ctx, PCP_ERR_STATE, "pcp_cloud_smooth_stream_next: chunk %zu emitted %lld rows, sweep 1 saw %lld", c,
                                   (long long)m, (long long)rows);
   // source indices back to the uploaded cloud (ctx->c_index: the caller's indices of cloud 1), keep flags by the stored distance
-  double *d_thr = reinterpret_cast<double *>(ctx->css_words.p + 8);
   PCP_HIP_TRY(ctx, hipMemcpyAsync(d_thr, &st.threshold, 8, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_remap_index, dim3(blocks_of(m)), dim3(kMB), 0, ctx->stream, ctx->mls_index.p, m, ctx->c_index.p);
   hipLaunchKernelGGL(k_rows_classify, dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(m, kMB), 1 << 16))), dim3(kMB), 0, ctx->stream,
@@ -3650,7 +3759,17 @@ int pcp_cloud_smooth_stream_next(pcp_context *ctx, int64_t *out_count) {
   return PCP_OK;
 }
 
-int pcp_cloud_smooth_stream_stats(pcp_context *ctx, double out[6]) {
+int pcp_cloud_smooth_stream_end(pcp_context *ctx) {
+  if (!ctx) return PCP_ERR_INVALID;
+  PCP_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->css_next = -1;
+  ctx->css_chunks.clear();
+  ctx->css_dist.release();
+  return PCP_OK;
+}
+
+int pcp_cloud_smooth_stream_stats(pcp_context *ctx, double out[12]) {
   if (!ctx || !out) return PCP_ERR_INVALID;
   if (ctx->css_blob.size() != sizeof(SmoothStream)) return set_error(ctx, PCP_ERR_STATE, "pcp_cloud_smooth_stream_stats: no stream");
   SmoothStream st;
@@ -3661,6 +3780,9 @@ int pcp_cloud_smooth_stream_stats(pcp_context *ctx, double out[6]) {
   out[3] = st.max_dx;
   out[4] = st.min_margin;
   out[5] = static_cast<double>(st.rows_computed);
+  out[6] = st.sampled_dx;
+  out[7] = 4.0 * static_cast<double>(ctx->css_dist.count);
+  for (int k = 0; k < 4; ++k) out[8 + k] = st.seconds[k];
   return PCP_OK;
 }
 

@@ -182,8 +182,11 @@ class CloudSmooth {
   // map, more than one result holds.  sink(const SmoothedCloud &chunk) receives the survivors of the trailing outlier
   // removal chunk by chunk, in the order the one-shot form returns them; total_rows (nullable): rows before that filter.
   // Returns the rows kept.
+  // hold_device_memory: leave the stream's distances on the device (4 B per row: 11 GB for a 10 M-point map) for the next call
+  // instead of freeing them (pcp_cloud_smooth_stream_end).
   template <class Sink>
-  int64_t processWithOutlierRemovalStreamed(int64_t chunk_capacity, Sink &&sink, int64_t *total_rows = nullptr) const {
+  int64_t processWithOutlierRemovalStreamed(int64_t chunk_capacity, Sink &&sink, int64_t *total_rows = nullptr,
+                                            bool hold_device_memory = false) const {
     int64_t total = 0, kept = 0;
     int32_t chunks = 0;
     dev_.check(pcp_cloud_smooth_stream_begin(dev_.get(), &params_, chunk_capacity, &total, &kept, &chunks));
@@ -196,6 +199,7 @@ class CloudSmooth {
       fetch(m, s);
       sink(static_cast<const SmoothedCloud &>(s));
     }
+    if (!hold_device_memory) dev_.check(pcp_cloud_smooth_stream_end(dev_.get()));
     return kept;
   }
 

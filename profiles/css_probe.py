@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The streamed chain (pcp_cloud_smooth_stream_*) on the whole C3 map: begin / emit seconds and its diagnostics.
-python3 profiles/css_probe.py [capacity_log2]"""
+python3 profiles/css_probe.py [capacity_log2] [calls]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pointcloudprocessor_amd import capi, synth
@@ -11,7 +11,8 @@ ctx.set_camera(capi.default_camera())
 ctx.upload_cloud(x, y, z)
 vp = capi.default_mls_params()
 out = []
-for rep in range(2):
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+for rep in range(reps):
     t = time.perf_counter(); rows, kept, chunks = ctx.cloud_smooth_stream_begin(vp, cap); ctx.synchronize(); tb = time.perf_counter() - t
     t = time.perf_counter(); got = 0
     while True:

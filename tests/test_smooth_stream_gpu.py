@@ -55,6 +55,8 @@ def test_streamed_chain_equals_one_shot(gpu_ctx_factory, monkeypatch, halo):
         monkeypatch.setenv("PCP_CSS_HALO", halo)
     total, kept, chunks, got, st = _stream(ctx, mp, 100_000)
     assert chunks >= 6 and total > kept == len(one["index"])
+    assert st["device_bytes_held"] >= 4 * total  # (the distances stay for the next stream ...)
+    assert 0.0 < st["sampled_displacement_m"] <= st["max_displacement_m"]
     for k in ("index", "xyz", "normal", "curvature"):
         assert np.array_equal(got[k], one[k]), k
     assert st["min_margin_m"] > st["max_displacement_m"] > 0.0
@@ -64,6 +66,14 @@ def test_streamed_chain_equals_one_shot(gpu_ctx_factory, monkeypatch, halo):
         assert st["chunks_redone"] == 0
     assert ctx.cloud_smooth_stream_next() == 0  # the stream is over
     # a fit of another call replaces what the stream rests on: the stream ends
+    ctx.cloud_smooth_stream_begin(mp, 100_000)
+    assert ctx.cloud_smooth_stream_next() > 0
+    ctx.cloud_smooth_stream_end()  # (... until the stream is ended: nothing is held, no chunk follows)
+    assert ctx.cloud_smooth_stream_stats()["device_bytes_held"] == 0
+    with pytest.raises(capi.PcpError):
+        ctx.cloud_smooth_stream_next()
+    total2, kept2, chunks2, got2, st2 = _stream(ctx, mp, 100_000)  # and a new stream starts from nothing: same rows
+    assert (total2, kept2, chunks2) == (total, kept, chunks) and np.array_equal(got2["xyz"], one["xyz"])
     ctx.cloud_smooth_stream_begin(mp, 100_000)
     mp0 = capi.default_mls_params()
     mp0.upsampling = 0
