@@ -228,8 +228,10 @@ int pcp_frame_visible(pcp_context *ctx, int32_t frame, int64_t capacity, int32_t
                       uint16_t *out_mask, float *out_xyz_cam, float *out_xyz_world, int64_t *out_count);
 
 /* diagnostic: the last hidden_points_removal run on ctx (PCP_CULL_HPR; the latest keyframe of a batched call):
- * out[0] visible, [1] hidden, [2] candidates that went to the exact path (neither floating-point certificate held),
- * [3] trial normals, [4] batches of 64 point tests, [5] reserved (0), [6] UNRESOLVED (no exact
+ * out[0] visible, [1] hidden (both counted from the final verdicts), [2] candidates that went to the exact path (neither
+ * floating-point certificate held), [3] trial normals, [4] batches of 64 point tests -- of the polygon and exact searches; the
+ * 16-lane passes in front of them, which settle nearly every candidate, count theirs only under PCP_HPR_DEBUG=1 (the counting
+ * was 9 % of a hull pass) --, [5] reserved (0), [6] UNRESOLVED (no exact
  * certificate either: exactly degenerate input such as four coplanar flipped points; classified hidden), [7] exact
  * predicate evaluations, [8] grid cells, [9] candidates.
  * After a single-keyframe call (pcp_cull_frame, pcp_frame_visible, NID) that was SERVED FROM THE WHOLE-RUN BITS -- a

@@ -58,6 +58,14 @@ constexpr double kHprTargetPerCell = 8.0;
 constexpr int64_t kHprMaxCells = int64_t(1) << 22;
 constexpr int kHprMaxRestarts = 96;
 constexpr int kStatStride = 32, kStatCopies = 64;  // counters: block 0 + kStatCopies copies of 32 words
+// The tallies of the passes every candidate goes through cost what they count: an atomic or three per candidate from every
+// wavefront of k_hpr_quick / k_hpr_radial / k_hpr_tilt were 11.5 of the 182 ms of kernels in a run of C3 and 9 % of the pass
+// (device-scope atomics execute beyond the L2; profiles/r05_hpr_tally_ab.log).  Now: visible / hidden are counted ONCE, from
+// the final states (k_hpr_writeback / k_hpr_set_bits, a ballot per wavefront); the work of the 16-lane passes (trial normals,
+// batches of point tests) goes into word kStatPacked of the copies as ONE atomic per wavefront: normals in bits 0..23,
+// batches above (a copy holds a 64th of one keyframe's tallies: < 2^24 normals).
+constexpr int kStatPacked = 5;
+constexpr int kStatPackedShift = 24;
 constexpr double kHprBox = 1073741824.0;  // half-width of the initial box of trial normals (2^30 rad of tilt)
 constexpr double kPointSlack = 1.0e-15;  // |fl(n . (q - p)) - exact| <= 4.44e-16 sum |n_i (q_i - p_i)| (see test_range)
 
@@ -883,9 +891,7 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_quick(HprArrays A, HprGrid G,
     }
     state[j] = static_cast<uint8_t>(hit ? kStHidden : kStUndecided);
   }
-  const unsigned long long hits = __ballot(hit);
-  if (hits && lane_id() == 0) atomicAdd(&stats[kStatStride * (1 + (blockIdx.x % kStatCopies)) + kStHidden],
-                                        static_cast<unsigned long long>(__popcll(hits)));
+  (void)stats;  // (its verdicts are counted with everyone's, from the final states)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1026,7 +1032,7 @@ constexpr int kStatRadial = 22;  // block 0 of the tallies: length of that list
 // (tilt_add on an empty active set) and runs the ordinary traversal with THAT plane: a plane that has every other point
 // strictly on its inner side is a witness whatever produced it (same point test, same cell bound).  Whatever it cannot
 // certify stays undecided for k_hpr_tilt.  `stat_len`: the word of block 0 that holds the length of `todo`.
-template <bool kOneStep>
+template <bool kOneStep, bool kTally /* PCP_HPR_DEBUG: trial normals and batches counted (the counting is 6-15 % of the pass) */>
 __global__ __launch_bounds__(kHprBlock) void k_hpr_radial(HprArrays A, HprGrid G, uint8_t *__restrict__ state,
                                                           const int32_t *__restrict__ todo, unsigned long long *__restrict__ stats,
                                                           int32_t stat_len) {
@@ -1087,7 +1093,7 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_radial(HprArrays A, HprGrid G
             }
           }
         }
-        if (in && open && base < k1 && rl == 0) batches += 1;
+        if (kTally && in && open && base < k1 && rl == 0) batches += 1;
       }
     }
     const float worst = row_max16(best);
@@ -1129,7 +1135,7 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_radial(HprArrays A, HprGrid G
             bad = !point_cleared_rel(S.n, dx, dy, dz, t, T);
         }
       }
-      if (go && open && base < k1 && rl == 0) batches += 1;
+      if (kTally && go && open && base < k1 && rl == 0) batches += 1;
       if (__ballot(bad || dup_lower)) {  // (rare: one ballot in front of the two row masks)
         if (row_mask(dup_lower)) {
           hidden_dup = true;
@@ -1190,15 +1196,16 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_radial(HprArrays A, HprGrid G
       }
     }
   }
+  unsigned long long work = 0;  // this row's trial normal (if it decided) and batches, packed
   if (mine_to_write && rl == 0) {
     const int32_t out = hidden_dup ? kStHidden : (open ? kStVisible : kStUndecided);
     state[j] = static_cast<uint8_t>(out);
-    unsigned long long *mine = stats + kStatStride * (1 + (blockIdx.x % kStatCopies));
-    if (out != kStUndecided) {
-      atomicAdd(&mine[out], 1ull);
-      atomicAdd(&mine[3], 1ull);
-    }
-    atomicAdd(&mine[4], batches);
+    work = (out != kStUndecided ? 1ull : 0ull) + (batches << kStatPackedShift);
+  }
+  if (kTally) {  // the wavefront's four rows as one atomic
+    work += __shfl_xor(work, 16, 64);
+    work += __shfl_xor(work, 32, 64);
+    if (lane == 0 && work) atomicAdd(&stats[kStatStride * (1 + (blockIdx.x % kStatCopies)) + kStatPacked], work);
   }
 }
 
@@ -1410,7 +1417,7 @@ __global__ __launch_bounds__(kTiltBlock) __attribute__((amdgpu_waves_per_eu(PCP_
           dy = A.sy[k] - p.y;
           dz = A.sz[k] - p.z;
         }
-        if (on && rl == 0) batches += 1;
+        if (kDebug && on && rl == 0) batches += 1;
         for (int guard = 0;; ++guard) {
           TILT_FENCE();
           const Vec3d nn = {R.n[0], R.n[1], R.n[2]};
@@ -1585,11 +1592,13 @@ __global__ __launch_bounds__(kTiltBlock) __attribute__((amdgpu_waves_per_eu(PCP_
           tetra_contains_filtered(p, load_point(A, ca), load_point(A, cb), load_point(A, cc)))
         out = kStHidden;
     }
+    unsigned long long work = 0;
     if (have && rl == 0) {
       unsigned long long *mine = stats + kStatStride * (1 + (blockIdx.x % kStatCopies));
+      (void)mine;
+      work = static_cast<unsigned long long>(steps + 1) + (((batches * kRow + 63ull) / 64ull) << kStatPackedShift);
       if (out != kStUndecided) {
         state[j] = static_cast<uint8_t>(out);
-        atomicAdd(&mine[out], 1ull);
       } else if (kRow == 16 && outcome == 5) {
         // out of round trips: the search continues on a wavefront of its own, from the plane it has reached
         TILT_FENCE();
@@ -1603,8 +1612,6 @@ __global__ __launch_bounds__(kTiltBlock) __attribute__((amdgpu_waves_per_eu(PCP_
         // what this pass gives up on (a handful per keyframe) goes straight onto the list of the polygon search
         left_over[atomicAdd(&stats[kStatSearch], 1ull)] = j;
       }
-      atomicAdd(&mine[3], static_cast<unsigned long long>(steps + 1));
-      atomicAdd(&mine[4], (batches * kRow + 63ull) / 64ull);
       if (kDebug) {  // PCP_HPR_DEBUG: what became of the searches (words 9.. of the copies; nothing else uses them)
         if (outcome == 4)
           printf("hpr: tilt%d gave up on %d: why %d passes %d steps %d batches %llu |s| %.3g na %d window %d coarse cells of %d, p = (%.17g, %.17g, %.17g)\n",
@@ -1624,6 +1631,13 @@ __global__ __launch_bounds__(kTiltBlock) __attribute__((amdgpu_waves_per_eu(PCP_
         atomicAdd(&g_tilt_hist[16 + hb], static_cast<unsigned long long>(trips));
         atomicAdd(&g_tilt_hist[35], csteps);
       }
+    }
+    if (kDebug) {
+      if (kRow == 16) {
+        work += __shfl_xor(work, 16, 64);
+        work += __shfl_xor(work, 32, 64);
+      }
+      if (lane == 0 && work) atomicAdd(&stats[kStatStride * (1 + (blockIdx.x % kStatCopies)) + kStatPacked], work);
     }
     if (kDebug) {
       unsigned long long tsum = 0, tmax = 0;
@@ -1646,7 +1660,8 @@ __global__ __launch_bounds__(kTiltBlock) __attribute__((amdgpu_waves_per_eu(PCP_
 #undef TILT_STORE_NORMAL
 #undef TILT_FENCE
 
-// stats: [0] hidden [1] visible [2] undecided [3] trial normals [4] batches of 64 point tests [5] second-box retries
+// stats: [0] hidden [1] visible (both from the final states) [2] - [3] trial normals [4] batches of 64 point tests (polygon and exact
+// searches; the 16-lane passes': packed in [5] = kStatPacked of the copies)
 // [6] unresolved [7] exact predicate evaluations [8] length of the list for k_hpr_exact
 // The candidates the passes in front left undecided, as a list (any order): the searches then run on wavefronts that all have
 // work.  Launched over every candidate, nine wavefronts in ten found theirs decided and left after one load -- and the
@@ -1710,7 +1725,6 @@ __device__ __forceinline__ void hpr_decide_one(const HprArrays &A, const HprGrid
     // the tallies of all wavefronts on one cache line would queue up behind each other in the L2 (measured: 38 ns per
     // candidate whatever its work): kStatCopies copies, each on lines of its own, summed by the host
     unsigned long long *mine = stats + kStatStride * (1 + (blockIdx.x % kStatCopies));
-    atomicAdd(&mine[out], 1ull);
     atomicAdd(&mine[3], restarts);
     atomicAdd(&mine[4], S.tests);
     if (out == kStUndecided) undecided[atomicAdd(&stats[8], 1ull)] = j;
@@ -1937,7 +1951,6 @@ __device__ void hpr_exact_one(const HprArrays &A, const HprGrid &G, double reach
       out = kStHidden;
     }
     state[j] = static_cast<uint8_t>(out);
-    atomicAdd(&stats[out], 1ull);
     atomicAdd(&stats[3], restarts);
     atomicAdd(&stats[4], S.tests);
     atomicAdd(&stats[7], exact_total);
@@ -1958,17 +1971,34 @@ __global__ __launch_bounds__(64) void k_hpr_exact(HprArrays A, HprGrid G, double
 }
 
 // whole-run bits (pcp_colour.hip, hull_bits): bit of the keyframe at the sorted place of every hull vertex (plane cleared)
-__global__ __launch_bounds__(kHprBlock) void k_hpr_set_bits(const uint8_t *__restrict__ state, const int32_t *__restrict__ splace,
-                                                            int32_t m, uint32_t *__restrict__ word, uint32_t bit) {
-  const int32_t k = static_cast<int32_t>(blockIdx.x) * kHprBlock + static_cast<int32_t>(threadIdx.x);
-  if (k < m && state[k] == kStVisible) atomicOr(word + splace[k], bit);
+// (tally: the counters of the keyframe, or null -- the kernel that reads the final states first counts them: visible / hidden)
+__device__ __forceinline__ void tally_states(bool in, uint8_t st, unsigned long long *__restrict__ tally) {
+  if (!tally) return;
+  const unsigned long long v = __ballot(in && st == kStVisible), h = __ballot(in && st == kStHidden);
+  if (lane_id() == 0) {
+    unsigned long long *mine = tally + kStatStride * (1 + (blockIdx.x % kStatCopies));
+    if (v) atomicAdd(&mine[kStVisible], static_cast<unsigned long long>(__popcll(v)));
+    if (h) atomicAdd(&mine[kStHidden], static_cast<unsigned long long>(__popcll(h)));
+  }
 }
 
-// keep flags (input order): the candidate flags become the visible flags
-__global__ __launch_bounds__(kHprBlock) void k_hpr_writeback(const uint8_t *__restrict__ state, const int32_t *__restrict__ sidx,
-                                                             int32_t m, uint8_t *__restrict__ keep) {
+__global__ __launch_bounds__(kHprBlock) void k_hpr_set_bits(const uint8_t *__restrict__ state, const int32_t *__restrict__ splace,
+                                                            int32_t m, uint32_t *__restrict__ word, uint32_t bit,
+                                                            unsigned long long *__restrict__ tally) {
   const int32_t k = static_cast<int32_t>(blockIdx.x) * kHprBlock + static_cast<int32_t>(threadIdx.x);
-  if (k < m) keep[sidx[k]] = state[k] == kStVisible ? 1 : 0;
+  const uint8_t st = k < m ? state[k] : uint8_t(kStUndecided);
+  if (k < m && st == kStVisible) atomicOr(word + splace[k], bit);
+  tally_states(k < m, st, tally);
+}
+
+// keep flags (input order): the candidate flags become the visible flags (keep == null: the count alone)
+__global__ __launch_bounds__(kHprBlock) void k_hpr_writeback(const uint8_t *__restrict__ state, const int32_t *__restrict__ sidx,
+                                                             int32_t m, uint8_t *__restrict__ keep,
+                                                             unsigned long long *__restrict__ tally) {
+  const int32_t k = static_cast<int32_t>(blockIdx.x) * kHprBlock + static_cast<int32_t>(threadIdx.x);
+  const uint8_t st = k < m ? state[k] : uint8_t(kStUndecided);
+  if (k < m && keep) keep[sidx[k]] = st == kStVisible ? 1 : 0;
+  tally_states(k < m, st, tally);
 }
 
 // zeroes `words` 8-byte words (the per-keyframe clears of the hull: a kernel of the stream it belongs to -- hipMemsetAsync goes
@@ -2191,14 +2221,16 @@ int hpr_finish(pcp_context *ctx, HprLane &L, bool timed) {
                            L.state.p, m, undecided, stats + kStatRadial);  // (`undecided` is free until the searches)
         radial_todo = undecided;
       }
-      hipLaunchKernelGGL(k_hpr_radial<false>, dim3(static_cast<uint32_t>(div_up(m, kHprBlock / 16))), dim3(kHprBlock), 0, stream, A, G,
-                         L.state.p, radial_todo, stats, static_cast<int32_t>(kStatRadial));
+      const bool tally = std::getenv("PCP_HPR_DEBUG") != nullptr;  // (the 16-lane passes count their work only then)
+      hipLaunchKernelGGL((tally ? k_hpr_radial<false, true> : k_hpr_radial<false, false>), dim3(static_cast<uint32_t>(div_up(m, kHprBlock / 16))),
+                         dim3(kHprBlock), 0, stream, A, G, L.state.p, radial_todo, stats, static_cast<int32_t>(kStatRadial));
       // PCP_HPR_ONESTEP=0: without the once-tilted plane for what the radial plane failed (results identical)
       const char *oe = std::getenv("PCP_HPR_ONESTEP");
       if (!(oe && oe[0] == '0')) {
         hipLaunchKernelGGL(k_hpr_list, dim3(static_cast<uint32_t>(div_up(m, kHprBlock * kHprListPer))), dim3(kHprBlock), 0, stream,
                            L.state.p, m, todo, stats + kStatOneStep);
-        hipLaunchKernelGGL(k_hpr_radial<true>, dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(m, kHprBlock / 16), kHprOneStepGrid))),
+        hipLaunchKernelGGL((tally ? k_hpr_radial<true, true> : k_hpr_radial<true, false>),
+                           dim3(static_cast<uint32_t>(std::min<int64_t>(div_up(m, kHprBlock / 16), kHprOneStepGrid))),
                            dim3(kHprBlock), 0, stream, A, G, L.state.p, todo, stats, static_cast<int32_t>(kStatOneStep));
       }
     }
@@ -2287,10 +2319,11 @@ int hpr_finish(pcp_context *ctx, HprLane &L, bool timed) {
   }
   {
     LaunchTimer t(tctx, PCP_K_HPR);
-    if (d_flags)
-      hipLaunchKernelGGL(k_hpr_writeback, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, stream, L.state.p, sidx, m, d_flags);
+    if (d_flags || !hull_plane)
+      hipLaunchKernelGGL(k_hpr_writeback, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, stream, L.state.p, sidx, m, d_flags, stats);
     if (hull_plane)
-      hipLaunchKernelGGL(k_hpr_set_bits, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, stream, L.state.p, splace, m, hull_plane, bit);
+      hipLaunchKernelGGL(k_hpr_set_bits, dim3(hpr_blocks(m)), dim3(kHprBlock), 0, stream, L.state.p, splace, m, hull_plane, bit,
+                         d_flags ? static_cast<unsigned long long *>(nullptr) : stats);
     PCP_HIP_TRY(ctx, hipGetLastError());
   }
   ctx->hpr_stats[8] = n_fine;
@@ -2457,8 +2490,13 @@ int pcp_hpr_stats(pcp_context *ctx, int64_t out[10]) {
     unsigned long long hs[9];
     for (int k = 0; k < 9; ++k) {
       hs[k] = hall[static_cast<size_t>(k)];
-      if (k != 8)
+      if (k != 8 && k != kStatPacked)
         for (int c = 1; c <= kStatCopies; ++c) hs[k] += hall[static_cast<size_t>(c * kStatStride + k)];
+    }
+    for (int c = 1; c <= kStatCopies; ++c) {  // the 16-lane passes' work, packed (kStatPacked)
+      const unsigned long long w = hall[static_cast<size_t>(c * kStatStride + kStatPacked)];
+      hs[3] += w & ((1ull << kStatPackedShift) - 1ull);
+      hs[4] += w >> kStatPackedShift;
     }
     ctx->hpr_stats[0] = static_cast<int64_t>(hs[1]);  // visible, as finally classified (the exact path moved its points out of "undecided")
     ctx->hpr_stats[1] = static_cast<int64_t>(hs[0]);  // hidden
