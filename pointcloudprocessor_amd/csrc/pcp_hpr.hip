@@ -784,9 +784,13 @@ __global__ __launch_bounds__(kHprBlock) void k_hpr_scatter(const double *__restr
   splace[pos] = place[k];
   scell[pos] = c;
   const unsigned long long rb = static_cast<unsigned long long>(__double_as_longlong(rho[k]));
-  atomicMax(&crho_bits[c], rb);  // positive doubles order as integers
+  // (positive doubles order as integers; a candidate that would not raise what it reads stays away from the atomic)
+  if (rb > __atomic_load_n(&crho_bits[c], __ATOMIC_RELAXED)) atomicMax(&crho_bits[c], rb);
   // a representative of the cell for k_hpr_quick: (one of) its outermost candidates, by place in the cell order
-  if (crep) atomicMax(&crep[c], (rb & ~0x3ffffffull) | static_cast<unsigned long long>(pos));
+  if (crep) {
+    const unsigned long long rep = (rb & ~0x3ffffffull) | static_cast<unsigned long long>(pos);
+    if (rep > __atomic_load_n(&crep[c], __ATOMIC_RELAXED)) atomicMax(&crep[c], rep);
+  }
 }
 
 // centre directions of the fine cells; coarse cells: centre direction and the largest rho of their fine cells
