@@ -1021,10 +1021,14 @@ def main():
                         "max_displacement_mm": round(st_c["max_displacement_m"] * 1e3, 3),
                         "min_margin_mm": round(st_c["min_margin_m"] * 1e3, 3), "rows_computed": st_c["rows_computed"],
                         "threshold_mm": round(st_c["threshold"] * 1e3, 6),
+                        "sampled_displacement_mm": round(st_c["sampled_displacement_m"] * 1e3, 3),
+                        "begin_seconds": st_c["begin_seconds"],
                         "what": "SOR -> MLS + VOXEL_GRID_DILATION (1 mm x 4) -> SOR (PointCloudProcessor.cpp:67-86, cloudSmooth.cpp:109-164) on the "
-                                "whole map: begin = first filter, fit, voxel set, sweep 1 (mean 60-NN distances of every row of the upsampled "
-                                "cloud, chunk + proven halo, kept on the device: 4 B per row) and the threshold; emit = sweep 2 (re-emission, "
-                                "classification by the stored distance, compaction) of every chunk"}
+                                "whole map: begin = first filter, fit, voxel set, sweep 0 (a sample of the voxels projected: sizes the halo), "
+                                "sweep 1 (mean 60-NN distances of every row of the upsampled cloud, chunk + halo, kept on the device: 4 B per "
+                                "row; the halo proven against the largest displacement of ALL rows) and the threshold; emit = sweep 2 "
+                                "(re-emission, classification by the stored distance, compaction) of every chunk.  One call, after the "
+                                "reference_config_stream leg has allocated the emission's buffers"}
                     parity_fail = parity_fail or int(out_c) != int(kept_c)
                 except capi.PcpError as e:
                     mls["reference_config_chain_whole_map"] = {"error": str(e)}
