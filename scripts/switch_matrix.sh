@@ -26,3 +26,6 @@ run smooth PCP_SOR_CLUSTERED=0 -- tests/test_smooth_stream_gpu.py tests/test_mls
 run smooth PCP_GRID_SPARSE=1 -- tests/test_smooth_stream_gpu.py tests/test_sor_gpu.py
 run smooth PCP_CSS_HALO=1 -- tests/test_smooth_stream_gpu.py -k oracle
 run smooth PCP_VGD_GRID=fit -- tests/test_smooth_stream_gpu.py
+run hull PCP_HPR_DEBUG=1 -- tests/test_hpr_gpu.py
+run smooth PCP_SOR_BALL=1.2 -- tests/test_smooth_stream_gpu.py
+run smooth PCP_SOR_BALL=2.4 -- tests/test_smooth_stream_gpu.py tests/test_sor_gpu.py
