@@ -132,3 +132,45 @@ def test_full_size_projection_sample_against_oracle(big_scene, oracle):
         got = ctx.project_frame(f, want_cam=False)
         assert np.array_equal(got["cell"], ref["cell"]) and np.array_equal(got["pixel"], ref["pixel"]), f
     ctx.close()
+
+
+def test_full_size_every_hull_equals_the_oracle(big_scene, oracle):
+    """The cull the reference binary runs (hidden_points_removal, view_culling.cpp:46,266-334) at the headline size: the
+    whole-run hull pass over 10 M points x 256 keyframes (up to 431 k candidates per keyframe) against the oracle's exact
+    quickhull -- EVERY verdict of EVERY keyframe (the oracle takes 0.35 s per keyframe and core; 16 keyframes at a time)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from pointcloudprocessor_amd import capi, pipeline
+
+    cd, x, y, z, poses = big_scene
+    cull = capi.default_cull_params()
+    cull.cull_mode = capi.CULL_HPR
+    eng = pipeline.HipEngine(0)
+    eng.configure(cd, cull)
+    eng.upload_cloud(x, y, z)
+    eng.ctx.set_frames(poses)
+    eng.ctx.depth_pass()  # the hull of every keyframe, several in flight
+    eng.ctx.synchronize()
+    ocam = cam_struct(oracle, cd)
+
+    # (the GPU's verdicts first, on the calling thread: one context, one thread)
+    eng_keep = {}
+    for f in range(F):
+        keep, dm, kept = eng.ctx.cull_frame(f)  # served from the whole-run bits
+        eng_keep[f] = (np.packbits(keep), dm, kept)
+    assert eng.ctx.hpr_stats()["candidates"] == -1  # nothing was recomputed
+
+    def one_packed(f):
+        bits, _, kept = eng_keep[f]
+        w2c, _ = oracle.pose_to_matrices(poses[f])
+        okeep, ost = oracle.hpr_frame(ocam, w2c, x, y, z)
+        differing = int(np.unpackbits(np.bitwise_xor(np.packbits(okeep), bits)).sum())
+        return f, differing, int(kept), ost["kept"], ost["candidates"]
+
+    with ThreadPoolExecutor(max_workers=16) as pool:
+        res = list(pool.map(one_packed, range(F)))
+    bad = [(f, d) for f, d, _, _, _ in res if d]
+    assert not bad, f"keyframes whose verdicts differ from the oracle's hull (keyframe, points): {bad[:8]}"
+    assert all(k == ok for _, _, k, ok, _ in res)
+    assert max(c for *_, c in res) > 400_000 and sum(k for _, _, k, _, _ in res) > 0.4 * sum(c for *_, c in res)
+    eng.close()
