@@ -80,6 +80,7 @@ def lib() -> C.CDLL:
         L.orc_frame_visible.restype = C.c_int64
         L.orc_mls.restype = C.c_int64
         L.orc_mls_voxel_dilation.restype = C.c_int64
+        L.orc_mls_voxel_dilation_part.restype = C.c_int64
         L.orc_sor.restype = C.c_int64
         L.orc_select_keyframes.restype = C.c_int32
         L.orc_hardware_threads.restype = C.c_int32
@@ -349,6 +350,24 @@ def mls_voxel_dilation(x, y, z, params: MLSParams):
     idx = np.empty(m, np.int32)
     lib().orc_mls_voxel_dilation(_p(x), _p(y), _p(z), C.c_int64(n), C.byref(params), C.c_int64(m), _p(xyz),
                                  _p(nrm), _p(curv), _p(idx))
+    return dict(xyz=xyz, normal=nrm, curvature=curv, index=idx)
+
+
+def mls_voxel_dilation_part(x, y, z, params: MLSParams, origin, extent: float):
+    """mls_voxel_dilation of a REGION of a larger cloud on that cloud's voxel lattice: origin = the cloud's bounding minimum
+    (3 floats), extent = its largest extent."""
+    x, y, z = _f32(x), _f32(y), _f32(z)
+    n = len(x)
+    org = _f32(np.asarray(origin, np.float32))
+    args = (_p(x), _p(y), _p(z), C.c_int64(n), C.byref(params), _p(org), C.c_double(extent))
+    m = int(lib().orc_mls_voxel_dilation_part(*args, C.c_int64(0), None, None, None, None))
+    if m < 0:
+        raise RuntimeError("orc_mls_voxel_dilation_part failed")
+    xyz = np.empty((m, 3), np.float32)
+    nrm = np.empty((m, 3), np.float32)
+    curv = np.empty(m, np.float32)
+    idx = np.empty(m, np.int32)
+    lib().orc_mls_voxel_dilation_part(*args, C.c_int64(m), _p(xyz), _p(nrm), _p(curv), _p(idx))
     return dict(xyz=xyz, normal=nrm, curvature=curv, index=idx)
 
 

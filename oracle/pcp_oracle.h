@@ -153,6 +153,11 @@ int64_t orc_mls(const float *x, const float *y, const float *z, int64_t n, const
 int64_t orc_mls_voxel_dilation(const float *x, const float *y, const float *z, int64_t n,
                                const orc_mls_params *p, int64_t capacity, float *out_xyz, float *out_normal,
                                float *out_curv, int32_t *out_index);
+/* the same on the voxel lattice of a larger cloud the points are a part of (origin = its bounding_min_, extent = its largest
+ * extent): test infrastructure for restating a REGION of a map */
+int64_t orc_mls_voxel_dilation_part(const float *x, const float *y, const float *z, int64_t n, const orc_mls_params *p,
+                                    const float *origin, double extent, int64_t capacity, float *out_xyz, float *out_normal,
+                                    float *out_curv, int32_t *out_index);
 
 /* f4: the 8-bit BGR -> HSV -> BGR round trip of generateColorMap (PCP/src/PointCloudProcessor.cpp:722-741),
  * OpenCV 4.2 arithmetic [upstream]: n_pixels tightly packed BGR8 pixels in, the adjusted pixels out. */

@@ -535,9 +535,12 @@ static int64_t sort_unique(uint64_t *k, int64_t n) {
   return m;
 }
 
-int64_t orc_mls_voxel_dilation(const float *x, const float *y, const float *z, int64_t n, const orc_mls_params *p,
-                               int64_t capacity, float *out_xyz, float *out_normal, float *out_curv,
-                               int32_t *out_index) {
+/* origin / extent (nullable / <= 0): the voxel lattice of a LARGER cloud these points are a part of -- its bounding_min_ and
+ * its largest extent (MLSVoxelGrid is laid over the bounding box of the cloud it is given) -- so that a region of a map can
+ * be restated on the map's own lattice (tests of the streamed chain at full size); null: the points' own box, as PCL. */
+static int64_t voxel_dilation_impl(const float *x, const float *y, const float *z, int64_t n, const orc_mls_params *p,
+                                   const float *origin, double extent, int64_t capacity, float *out_xyz, float *out_normal,
+                                   float *out_curv, int32_t *out_index) {
   if (n == 0) return 0;
   uint8_t *has = (uint8_t *)malloc((size_t)n);
   mls_result *res = mls_compute_all(x, y, z, n, p, has);
@@ -557,7 +560,13 @@ int64_t orc_mls_voxel_dilation(const float *x, const float *y, const float *z, i
   }
   const float vs = p->vgd_voxel_size;
   const float sx = bmax[0] - bmin[0], sy = bmax[1] - bmin[1], sz = bmax[2] - bmin[2];
-  const double max_size = (double)fmaxf(fmaxf(sx, sy), sz);
+  double max_size = (double)fmaxf(fmaxf(sx, sy), sz);
+  if (origin) {
+    bmin[0] = origin[0];
+    bmin[1] = origin[1];
+    bmin[2] = origin[2];
+    if (extent > 0.0) max_size = extent;
+  }
   const uint64_t S = (uint64_t)(1.5 * max_size / vs);
   int64_t nk = n;
   uint64_t *keys = (uint64_t *)malloc((size_t)nk * sizeof(uint64_t));
@@ -671,6 +680,18 @@ int64_t orc_mls_voxel_dilation(const float *x, const float *y, const float *z, i
   free(res);
   free(has);
   return m;
+}
+
+int64_t orc_mls_voxel_dilation(const float *x, const float *y, const float *z, int64_t n, const orc_mls_params *p,
+                               int64_t capacity, float *out_xyz, float *out_normal, float *out_curv,
+                               int32_t *out_index) {
+  return voxel_dilation_impl(x, y, z, n, p, NULL, 0.0, capacity, out_xyz, out_normal, out_curv, out_index);
+}
+
+int64_t orc_mls_voxel_dilation_part(const float *x, const float *y, const float *z, int64_t n, const orc_mls_params *p,
+                                    const float *origin, double extent, int64_t capacity, float *out_xyz, float *out_normal,
+                                    float *out_curv, int32_t *out_index) {
+  return voxel_dilation_impl(x, y, z, n, p, origin, extent, capacity, out_xyz, out_normal, out_curv, out_index);
 }
 
 /* ------------------------------------------------------------------ */

@@ -139,6 +139,21 @@ def test_g8_voxel_dilation_golden(oracle):
     assert np.abs(r["normal"] * sgn[:, None] - g["normal"]).max() <= 1e-4
     np.testing.assert_allclose(r["curvature"], g["curvature"], rtol=1e-4, atol=1e-9)
     assert len(g["index"]) > 5 * len(g["x"])
+    # the form that restates a region of a larger cloud on that cloud's lattice: with the points' own box it IS the plain form
+    x, y, z = g["x"], g["y"], g["z"]
+    origin = np.array([x.min(), y.min(), z.min()], np.float32)
+    extent = float(max(np.float32(x.max()) - origin[0], np.float32(y.max()) - origin[1], np.float32(z.max()) - origin[2]))
+    rp = oracle.mls_voxel_dilation_part(x, y, z, mp, origin, extent)
+    assert np.array_equal(rp["index"], r["index"]) and np.array_equal(rp["xyz"], r["xyz"])
+    # ... and a sub-cloud on the whole cloud's lattice gives, for the voxels both hold, the whole cloud's rows where the
+    # nearest point and its fit are the same: the rows of points far inside the part
+    part = np.nonzero(x < np.median(x))[0]
+    rq = oracle.mls_voxel_dilation_part(x[part], y[part], z[part], mp, origin, extent)
+    cut = np.median(x) - 0.031  # (a source point this far inside the part has its whole fit neighbourhood -- radius 0.03 -- in it)
+    deep = x[part][rq["index"]] < cut
+    whole_rows = {tuple(v) for v in r["xyz"][x[r["index"]] < cut].view(np.uint32)}
+    got_rows = [tuple(v) for v in rq["xyz"][deep].view(np.uint32)]
+    assert len(got_rows) > 100 and all(v in whole_rows for v in got_rows)
 
 
 def test_g9_nid_cost_golden(oracle):

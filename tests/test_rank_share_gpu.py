@@ -199,13 +199,54 @@ def test_sor_and_cloud_smooth_10M(cloud10m, oracle):
     ctx.close()
 
 
-def test_streamed_chain_whole_map_is_chunking_invariant(cloud10m, monkeypatch):
+def _region_check(oracle, x, y, z, keep1, region, thr):
+    """The survivors of the streamed chain whose source point lies in a region of the map, against the oracle's stages on that
+    region: the first filter's survivors within `outer` of the centre -> the oracle's MLS + VOXEL_GRID_DILATION on the MAP's
+    voxel lattice -> the oracle's mean 60-NN distances of those rows -> kept iff distance <= the chain's threshold (the one
+    number that needs the whole map).  Compared per source point within `inner` of the centre (their fits, voxels and
+    neighbourhoods are complete 0.12 m inside the region): the number of surviving rows and their positions."""
+    c, inner, outer, got_idx, got_xyz = region
+    k1 = keep1.astype(bool)
+    box = k1 & (np.abs(x - c[0]) < outer) & (np.abs(y - c[1]) < outer) & (np.abs(z - c[2]) < outer)
+    sub = np.nonzero(box)[0]
+    assert 2_000 < len(sub) < 60_000, len(sub)
+    op = oracle.default_mls_params()
+    assert op.upsampling == 3 and op.vgd_iterations == 4
+    op.threads = 16
+    origin = np.array([x[k1].min(), y[k1].min(), z[k1].min()], np.float32)
+    extent = float(max(np.float32(x[k1].max()) - origin[0], np.float32(y[k1].max()) - origin[1], np.float32(z[k1].max()) - origin[2]))
+    r = oracle.mls_voxel_dilation_part(x[sub], y[sub], z[sub], op, origin, extent)
+    rx = r["xyz"]
+    _, _, dist, _ = oracle.sor(rx[:, 0].copy(), rx[:, 1].copy(), rx[:, 2].copy(), 60, 0.7, threads=0, details=True)
+    src = sub[r["index"]]
+    core = (np.abs(x[src] - c[0]) < inner) & (np.abs(y[src] - c[1]) < inner) & (np.abs(z[src] - c[2]) < inner)
+    want_keep = core & ~(dist.astype(np.float64) > thr)
+    n_src = len(x)
+    want = np.bincount(src[want_keep], minlength=n_src)
+    gcore = (np.abs(x[got_idx] - c[0]) < inner) & (np.abs(y[got_idx] - c[1]) < inner) & (np.abs(z[got_idx] - c[2]) < inner)
+    got = np.bincount(got_idx[gcore], minlength=n_src)
+    sources = np.nonzero((want > 0) | (got > 0))[0]
+    assert len(sources) > 300 and int(want.sum()) > 100_000
+    # (a row whose distance sits within the fit's tolerance of the threshold may fall on either side: a handful in 10^5)
+    differing = int(np.abs(want - got).sum())
+    assert differing <= 2e-4 * want.sum(), (differing, int(want.sum()), int(got.sum()))
+    # positions: every surviving row of the GPU lies within 3 um (SURVEY A9: 1e-4 r) of an oracle row of the same source
+    same = sources[want[sources] == got[sources]][:200]
+    for s_ in same:
+        a = np.sort(got_xyz[gcore & (got_idx == s_)].astype(np.float64), axis=0)
+        b = np.sort(rx[want_keep & (src == s_)].astype(np.float64), axis=0)
+        assert np.abs(a - b).max() <= 3.0e-6 + 1e-9, s_
+    return int(want.sum()), differing, len(sources)
+
+
+def test_streamed_chain_whole_map_is_chunking_invariant(cloud10m, monkeypatch, oracle):
     """CloudSmooth::process with the reference's own MLS configuration on the WHOLE 10 M-point map (2.8e9 upsampled rows:
     pcp_cloud_smooth_stream_*): the chain cut into 11 and into 22 chunks, and with the ball of the trailing filter's selection
     held fixed instead of adapted, gives the same rows before the last filter, the same threshold to the last bit, the same
     number of survivors and the same checksums over their source indices and positions; every survivor's source point
     survived the first outlier removal; each chunk's halo was PROVEN (margin above the largest displacement), nothing had
-    to be redone."""
+    to be redone.  And against the ORACLE on a region of the map (0.4 m across: its stages restated on the map's own voxel
+    lattice): the surviving rows of every source point in the region's core and their positions."""
     import ctypes as C
 
     from pointcloudprocessor_amd import capi
@@ -217,6 +258,11 @@ def test_streamed_chain_whole_map_is_chunking_invariant(cloud10m, monkeypatch):
     keep1, _ = ctx.sor(60, 0.7)
     vp = capi.default_mls_params()
     runs = []
+    # a region of the map for the comparison with the oracle's stages (below): 0.2 m around a surviving point in mid-map
+    i0 = int(np.nonzero(keep1)[0][len(x) // 3])
+    centre, inner, outer = (float(x[i0]), float(y[i0]), float(z[i0])), 0.08, 0.20
+    in_region = (np.abs(x - centre[0]) < inner) & (np.abs(y - centre[1]) < inner) & (np.abs(z - centre[2]) < inner)
+    reg_idx, reg_xyz = [], []
     for cap, ball in ((1 << 28, None), (1 << 27, None), (1 << 28, "1.2")):
         if ball is not None:
             monkeypatch.setenv("PCP_SOR_BALL", ball)  # (the selection's ball fixed instead of following the flagged share)
@@ -237,6 +283,11 @@ def test_streamed_chain_whole_map_is_chunking_invariant(cloud10m, monkeypatch):
             idx_sum += int(idx.sum(dtype=np.int64))
             x_sum += int(xyz.view(np.uint32).sum(dtype=np.uint64))
             nested = nested and bool(np.all(keep1[idx[:: 997]] == 1))
+            if len(runs) == 0:
+                sel = in_region[idx]
+                if sel.any():
+                    reg_idx.append(idx[sel].copy())
+                    reg_xyz.append(xyz[sel].copy())
             del idx, xyz
         runs.append(dict(rows=rows, kept=kept, got=got, chunks=chunks, idx_sum=idx_sum, x_sum=x_sum, thr=st["threshold"], st=st, nested=nested))
     a, b, c = runs
@@ -247,3 +298,8 @@ def test_streamed_chain_whole_map_is_chunking_invariant(cloud10m, monkeypatch):
     for r in runs:
         assert r["nested"] and r["st"]["chunks_redone"] == 0 and r["st"]["min_margin_m"] > r["st"]["max_displacement_m"] > 0
     ctx.close()
+    # ... and against the oracle on a region of the map (MLS + dilation on the map's own voxel lattice, distances, the chain's
+    # threshold): the surviving rows per source point and their positions
+    rows_cmp, differing, n_sources = _region_check(oracle, x, y, z, keep1, (centre, inner, outer, np.concatenate(reg_idx), np.concatenate(reg_xyz)),
+                                                   a["thr"])
+    print(f"region check: {rows_cmp} surviving rows of {n_sources} source points compared, {differing} differ")
