@@ -43,6 +43,7 @@
 #include <memory>
 #include <sstream>
 #include <thread>
+#include <exception>
 #include <mutex>
 #include <condition_variable>
 
@@ -175,12 +176,28 @@ static void usage(std::ostream &os) {
 class Processor {
  public:
   explicit Processor(const Options &o) : opt(o), enableMaskSegmentation(!o.maskImageFolder.empty()) {}
+  ~Processor() {
+    stopDecoders();
+    if (device_thread.joinable()) device_thread.join();
+  }
 
   void process() {  // PointCloudProcessor::process, PointCloudProcessor.cpp:1007-1032
+    // The GPU context takes a quarter of a second to come up (HIP runtime, code objects, queues): it is created on a thread of
+    // its own while this one reads the odometry and the map and writes the crop, and the keyframes' decoders start as soon as
+    // the keyframes are known -- by the time the device is ready the first images wait decoded (end to end, 1 M points x 32
+    // keyframes from a tmpfs: 0.60 -> 0.42-0.43 s without the per-keyframe dumps, 0.69 -> 0.48 s with them; profiles/r05b_cli_e2e_probe.log).  Same calls in the same order on this thread.
+    device_thread = std::thread([this]() {
+      try {
+        gpu.reset(new MultiDevice(opt.gpus));
+      } catch (...) {
+        device_error = std::current_exception();
+      }
+    });
     loadImagesAndOdometry();
     loadPointCloud();
     generateResultStorageFolder();
     selectKeyframes();
+    if (!opt.enableNIDOptimize) startDecoders();  // (with the NID stage the first consumer wants the images unadjusted and again later: decoded on demand)
     setupDevice();
     if (!opt.skip_filtered_dumps) viewCullingAndSaveFilteredPcds();
     if (opt.enableNIDOptimize)
@@ -196,6 +213,8 @@ class Processor {
   std::vector<Frame> frames, keyframes;
   XYZICloud cloud;
   std::unique_ptr<MultiDevice> gpu;
+  std::thread device_thread;
+  std::exception_ptr device_error;
   int img_w = 0, img_h = 0;
   bool images_uploaded = false, images_adjusted = false;
   std::vector<uint8_t> mask_missing;
@@ -326,10 +345,18 @@ class Processor {
 
   void setupDevice() {
     Phase ph("device_setup_and_cloud_upload_s");
+    if (device_thread.joinable()) device_thread.join();
+    if (device_error) std::rethrow_exception(device_error);
     if (!gpu) gpu.reset(new MultiDevice(opt.gpus));
     gpu->uploadCloud(cloud.x.data(), cloud.y.data(), cloud.z.data(), static_cast<int64_t>(cloud.size()));
     // image size from the first keyframe image; cull size stays the reference's {4096,3000} (:206,:525)
-    if (!keyframes.empty()) {
+    if (!keyframes.empty() && decoders) {  // (the decoders are on it already)
+      std::unique_lock<std::mutex> lk(decoders->mu);
+      decoders->cv.wait(lk, [&] { return decoders->ready[0] != 0; });
+      if (decoders->img[0].empty()) throw std::runtime_error("Failed to read image from: " + keyframes[0].imagePath);
+      img_w = decoders->img[0].width;
+      img_h = decoders->img[0].height;
+    } else if (!keyframes.empty()) {
       const Image8 first = read_image_bgr(keyframes[0].imagePath);
       if (first.empty()) throw std::runtime_error("Failed to read image from: " + keyframes[0].imagePath);
       img_w = first.width;
@@ -413,31 +440,40 @@ class Processor {
 
   // cv::imread of every keyframe (and mask) on all host cores -- the decoders are pure functions of the file -- while
   // this thread uploads them in keyframe order; at most `window` decoded keyframes are held at a time (a 4096x3000
-  // frame is 37 MB).  The reference decodes one image per keyframe iteration on its one thread.
-  void uploadImages(bool adjusted) {
-    if (images_uploaded && images_adjusted == adjusted) return;
-    Phase ph_all("images_decode_and_upload_wall_s");  // decoders on the host threads, uploads on this one, overlapped
-    gpu->setImageAdjust(adjusted);  // cvtColor(BGR2HSV) ... cvtColor(HSV2BGR), :722-741, fused into the upload
-    const size_t n = keyframes.size();
-    mask_missing.assign(n, 0);
-    unsigned threads = std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
-    if (const char *e = std::getenv("PCP_DECODE_THREADS")) threads = static_cast<unsigned>(std::max(1, std::atoi(e)));
-    threads = static_cast<unsigned>(std::min<size_t>(threads, std::max<size_t>(n, 1)));
-    const size_t window = 2 * static_cast<size_t>(threads) + 2;
-    std::vector<Image8> img(n), gray(n);
-    std::vector<uint8_t> ready(n, 0);
+  // frame is 37 MB).  The reference decodes one image per keyframe iteration on its one thread.  The decoders may be started
+  // ahead of their consumer (startDecoders: process() does, while the device comes up): uploadImages then finds them running.
+  struct Decoders {
+    std::vector<Image8> img, gray;
+    std::vector<uint8_t> ready;
     std::mutex mu;
     std::condition_variable cv;
-    size_t next = 0, uploaded = 0;
+    size_t n = 0, next = 0, uploaded = 0, window = 0;
     bool stop = false;
-    auto worker = [&]() {
+    std::vector<std::thread> pool;
+  };
+  std::unique_ptr<Decoders> decoders;
+
+  void startDecoders() {
+    if (decoders) return;
+    decoders.reset(new Decoders);
+    Decoders &D = *decoders;
+    D.n = keyframes.size();
+    unsigned threads = std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
+    if (const char *e = std::getenv("PCP_DECODE_THREADS")) threads = static_cast<unsigned>(std::max(1, std::atoi(e)));
+    threads = static_cast<unsigned>(std::min<size_t>(threads, std::max<size_t>(D.n, 1)));
+    D.window = 2 * static_cast<size_t>(threads) + 2;
+    D.img.resize(D.n);
+    D.gray.resize(D.n);
+    D.ready.assign(D.n, 0);
+    auto worker = [this]() {
+      Decoders &W = *decoders;
       for (;;) {
         size_t k;
         {
-          std::unique_lock<std::mutex> lk(mu);
-          cv.wait(lk, [&] { return stop || next >= n || next < uploaded + window; });
-          if (stop || next >= n) return;
-          k = next++;
+          std::unique_lock<std::mutex> lk(W.mu);
+          W.cv.wait(lk, [&] { return W.stop || W.next >= W.n || W.next < W.uploaded + W.window; });
+          if (W.stop || W.next >= W.n) return;
+          k = W.next++;
         }
         const auto t_dec = PhaseClock::clock::now();
         Image8 a = read_image_bgr(keyframes[k].imagePath);  // cv::imread, :716
@@ -445,57 +481,72 @@ class Processor {
         if (enableMaskSegmentation) b = read_image_gray(keyframes[k].maskImagePath);  // cv::IMREAD_GRAYSCALE, :775
         g_clock.add("images_decode_thread_seconds", PhaseClock::since(t_dec));  // summed over the decoder threads
         {
-          std::lock_guard<std::mutex> lk(mu);
-          img[k] = std::move(a);
-          gray[k] = std::move(b);
-          ready[k] = 1;
+          std::lock_guard<std::mutex> lk(W.mu);
+          W.img[k] = std::move(a);
+          W.gray[k] = std::move(b);
+          W.ready[k] = 1;
         }
-        cv.notify_all();
+        W.cv.notify_all();
       }
     };
-    std::vector<std::thread> pool;
-    for (unsigned t = 0; t < threads; ++t) pool.emplace_back(worker);
-    auto finish = [&]() {
-      {
-        std::lock_guard<std::mutex> lk(mu);
-        stop = true;
-      }
-      cv.notify_all();
-      for (auto &th : pool) th.join();
-    };
+    for (unsigned t = 0; t < threads; ++t) D.pool.emplace_back(worker);
+  }
+
+  void stopDecoders() {
+    if (!decoders) return;
+    {
+      std::lock_guard<std::mutex> lk(decoders->mu);
+      decoders->stop = true;
+    }
+    decoders->cv.notify_all();
+    for (auto &th : decoders->pool) th.join();
+    decoders.reset();
+  }
+
+  void uploadImages(bool adjusted) {
+    if (images_uploaded && images_adjusted == adjusted) {
+      stopDecoders();
+      return;
+    }
+    Phase ph_all("images_decode_and_upload_wall_s");  // decoders on the host threads, uploads on this one, overlapped
+    gpu->setImageAdjust(adjusted);  // cvtColor(BGR2HSV) ... cvtColor(HSV2BGR), :722-741, fused into the upload
+    const size_t n = keyframes.size();
+    mask_missing.assign(n, 0);
+    startDecoders();  // (running already when process() started them ahead)
+    Decoders &D = *decoders;
     try {
       for (size_t k = 0; k < n; ++k) {
         {
-          std::unique_lock<std::mutex> lk(mu);
-          cv.wait(lk, [&] { return ready[k] != 0; });
+          std::unique_lock<std::mutex> lk(D.mu);
+          D.cv.wait(lk, [&] { return D.ready[k] != 0; });
         }
         std::cout << "Reading image from: " << keyframes[k].imagePath << std::endl;
-        if (img[k].empty() || img[k].width != img_w || img[k].height != img_h)
+        if (D.img[k].empty() || D.img[k].width != img_w || D.img[k].height != img_h)
           throw std::runtime_error("Failed to read image from: " + keyframes[k].imagePath);
         {
           Phase ph_up("images_upload_calls_s");
-          gpu->uploadImage(static_cast<int>(k), img[k].data.data(), static_cast<int64_t>(img[k].width) * 3);
+          gpu->uploadImage(static_cast<int>(k), D.img[k].data.data(), static_cast<int64_t>(D.img[k].width) * 3);
         }
         if (enableMaskSegmentation) {
           std::cout << "Reading segment mask image from: " << keyframes[k].maskImagePath << std::endl;
-          if (!gray[k].empty() && gray[k].width == img_w && gray[k].height == img_h)
-            gpu->uploadMask(static_cast<int>(k), gray[k].data.data(), gray[k].width);
+          if (!D.gray[k].empty() && D.gray[k].width == img_w && D.gray[k].height == img_h)
+            gpu->uploadMask(static_cast<int>(k), D.gray[k].data.data(), D.gray[k].width);
           else
             mask_missing[k] = 1;  // generateSegmentMap logs it and returns an empty cloud, :776-781
         }
         {
-          std::lock_guard<std::mutex> lk(mu);
-          img[k] = Image8();
-          gray[k] = Image8();
-          uploaded = k + 1;
+          std::lock_guard<std::mutex> lk(D.mu);
+          D.img[k] = Image8();
+          D.gray[k] = Image8();
+          D.uploaded = k + 1;
         }
-        cv.notify_all();
+        D.cv.notify_all();
       }
     } catch (...) {
-      finish();
+      stopDecoders();
       throw;
     }
-    finish();
+    stopDecoders();
     images_uploaded = true;
     images_adjusted = adjusted;
   }
