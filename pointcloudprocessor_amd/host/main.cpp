@@ -289,6 +289,7 @@ class Processor {
         std::cerr << "Couldn't read file " << cropPath << std::endl;
         return;
       }
+      if (device_thread.joinable()) device_thread.join();  // (one thread at a time creates contexts: pcp_create sets process-wide defaults)
       MultiCloudSmooth smooth(opt.gpus);  // --gpus N: MLS queries / voxel chunks dealt out over the GPUs (pcp_multi.hpp)
       pcp_mls_params mp;
       pcp_default_mls_params(&mp);  // PointCloudProcessor.cpp:67-86
