@@ -353,8 +353,9 @@ int pcp_cloud_smooth_stream_end(pcp_context *ctx);
  * with a wider halo, [2] threshold of the last filter, [3] largest |x displacement| of a row from its voxel (m; over all rows),
  * [4] smallest margin of any chunk (m; > [3] proves the halo), [5] rows computed including halos, [6] the displacement sweep 0's
  * sample saw (m; sized the halo), [7] bytes of device memory the stream holds at the time of the call, [8..11] host-clock
- * seconds of _begin: first filter + fit + voxel set, allocations, sweep 0, sweep 1 + threshold. */
-int pcp_cloud_smooth_stream_stats(pcp_context *ctx, double out[12]);
+ * seconds of _begin: first filter + fit + voxel set, [9] device allocations (hipMalloc / hipFree: they lie inside the other
+ * three; seconds on a first call, none afterwards), sweep 0, sweep 1 + threshold, [12] bytes allocated during _begin. */
+int pcp_cloud_smooth_stream_stats(pcp_context *ctx, double out[13]);
 /* pcl::StatisticalOutlierRemoval (k, std_mul) keep mask of the uploaded cloud,
  * cloudSmooth.cpp:109-116,160-164.
  * The smoothing entry points (pcp_sor, pcp_mls_process[_shard], pcp_cloud_smooth, pcp_close_pairs) need finite

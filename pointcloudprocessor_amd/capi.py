@@ -458,13 +458,14 @@ class Context:
         return m.value
 
     def cloud_smooth_stream_stats(self) -> dict:
-        out = (C.c_double * 12)()
+        out = (C.c_double * 13)()
         self._check(self.lib.pcp_cloud_smooth_stream_stats(self.h, out))
         return {"halo_planes": int(out[0]), "chunks_redone": int(out[1]), "threshold": float(out[2]),
                 "max_displacement_m": float(out[3]), "min_margin_m": float(out[4]), "rows_computed": int(out[5]),
                 "sampled_displacement_m": float(out[6]), "device_bytes_held": int(out[7]),
                 "begin_seconds": {"filter_fit_voxels": round(out[8], 4), "allocations": round(out[9], 4),
-                                  "sweep0": round(out[10], 4), "sweep1_threshold": round(out[11], 4)}}
+                                  "sweep0": round(out[10], 4), "sweep1_threshold": round(out[11], 4)},
+                "allocated_GB": round(out[12] / 1e9, 2)}
 
     def cloud_smooth_stream_end(self):
         """Ends the stream and frees the device memory it holds (pcp_cloud_smooth_stream_end)."""

@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdint>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -73,22 +74,41 @@ struct PendingEvent {
   int32_t kernel;
 };
 
+// seconds and bytes of the device allocations of this process (hipMalloc / hipFree inside DevBuf), for diagnostics
+struct AllocTally {
+  double seconds = 0.0, bytes = 0.0;
+};
+inline AllocTally &alloc_tally() {
+  static AllocTally t;
+  return t;
+}
+struct AllocClock {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  ~AllocClock() { alloc_tally().seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 template <typename T>
 struct DevBuf {
   T *p = nullptr;
   size_t count = 0;
   hipError_t ensure(size_t n) {
     if (n <= count && p) return hipSuccess;
+    AllocClock clk;  // (device allocations cost 20-40 ms per GB on this platform: the diagnostics of the long calls report them)
     if (p) (void)hipFree(p);
     p = nullptr;
     count = 0;
     if (n == 0) return hipSuccess;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T));
-    if (e == hipSuccess) count = n;
+    if (e == hipSuccess) {
+      count = n;
+      alloc_tally().bytes += static_cast<double>(n) * sizeof(T);
+    }
     return e;
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (!p) return;
+    AllocClock clk;
+    (void)hipFree(p);
     p = nullptr;
     count = 0;
   }

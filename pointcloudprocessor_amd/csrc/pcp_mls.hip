@@ -2474,11 +2474,13 @@ static int vgd_emit(pcp_context *ctx, const VgdStream &S, int64_t word0, int64_t
   if (short_of_memory())
     return set_error(ctx, PCP_ERR_NOMEM, "pcp_mls_process: %lld upsampled points do not fit the device memory "
                      "(pcp_mls_stream_begin / _next emit them in chunks)", (long long)count);
-  PCP_HIP_TRY(ctx, ctx->mls_xyz.ensure(3 * st + 4));
-  PCP_HIP_TRY(ctx, ctx->mls_normal.ensure(3 * st + 4));
-  PCP_HIP_TRY(ctx, ctx->mls_curv.ensure(st + 4));
-  PCP_HIP_TRY(ctx, ctx->mls_index.ensure(st + 4));
-  PCP_HIP_TRY(ctx, ctx->m_flag.ensure(st + 16));
+  if (sample_step == 0) {  // (a dry run stores nothing)
+    PCP_HIP_TRY(ctx, ctx->mls_xyz.ensure(3 * st + 4));
+    PCP_HIP_TRY(ctx, ctx->mls_normal.ensure(3 * st + 4));
+    PCP_HIP_TRY(ctx, ctx->mls_curv.ensure(st + 4));
+    PCP_HIP_TRY(ctx, ctx->mls_index.ensure(st + 4));
+    PCP_HIP_TRY(ctx, ctx->m_flag.ensure(st + 16));
+  }
   PCP_HIP_TRY(ctx, ctx->v_vox.ensure(st + 4));
   int64_t m = count;
   if (count > 0) {
@@ -3067,7 +3069,8 @@ struct SmoothStream {  // plain data, kept in ctx->css_blob between pcp_cloud_sm
   double threshold, max_dx, min_margin;
   int32_t halo, redone;
   double sampled_dx;  // the largest displacement sweep 0 saw on its sample of the voxels (sizes the halo; max_dx proves it)
-  double seconds[4];  // host clock of _begin: first filter + fit + voxel set, allocations, sweep 0, sweep 1 + threshold
+  double seconds[4];  // host clock of _begin: first filter + fit + voxel set, device allocations (inside the other three), sweep 0, sweep 1 + threshold
+  double alloc_bytes;  // device memory allocated during _begin
 };
 
 // the grid the emission searches, rebuilt (the outlier removal of a chunk overwrites it): the same call sequence as mls_run's
@@ -3552,6 +3555,7 @@ int pcp_cloud_smooth_stream_begin(pcp_context *ctx, const pcp_mls_params *p, int
     ~Building() { c->css_building = false; }
   } building(ctx);
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const AllocTally alloc_before = alloc_tally();
   double t_mark = now();
   auto lap = [&](int k) {  // (every phase ends in a readback: the stream is idle here)
     const double t = now();
@@ -3608,12 +3612,11 @@ int pcp_cloud_smooth_stream_begin(pcp_context *ctx, const pcp_mls_params *p, int
     if (ia >= 0 && cnt > 0) ch.insert(ch.end(), {ia, NX - 1, static_cast<int64_t>(cnt), 0, 0});
   }
   const size_t n_chunks = ch.size() / 5;
-  lap(0);
   PCP_HIP_TRY(ctx, ctx->css_dist.ensure(static_cast<size_t>(total_voxels) + 8));
   PCP_HIP_TRY(ctx, ctx->css_words.ensure(32));
   PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->css_words.p, 0, 32 * 4, ctx->stream));
   PCP_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  lap(1);
+  lap(0);
   // The halo must outreach the largest displacement D = max |x of a row - x of its voxel position| of ANY row: a row of a missing
   // plane lies within D of its plane, a chunk's own row within D of the chunk, so a halo of H planes leaves a margin of
   // H vs - 2 D - (k-NN radius).  D itself is only known when every row has been emitted -- which sweep 1 does anyway (every
@@ -3649,6 +3652,43 @@ int pcp_cloud_smooth_stream_begin(pcp_context *ctx, const pcp_mls_params *p, int
   int64_t H = static_cast<int64_t>(std::ceil(2.0 * 1.25 * st.sampled_dx / static_cast<double>(st.S.v.vs))) + 16;
   if (const char *he = std::getenv("PCP_CSS_HALO")) H = std::max(1, std::atoi(he));
   st.halo = static_cast<int32_t>(std::min<int64_t>(H, NX));
+  {
+    // Every buffer that holds a row (or a voxel) of a chunk and its halo, sized ONCE for the largest chunk: grown chunk by chunk
+    // they were allocated several times over -- 206 GB of hipMalloc in a first call on the 10 M-point map, 1.8 of its 4.1 s
+    // (a device allocation costs 20-40 ms per GB here; pcp_cloud_smooth_stream_stats [9], [12]).
+    unsigned long long most = 0;
+    for (size_t c = 0; c < n_chunks; ++c) {
+      const int64_t ea = std::max<int64_t>(0, ch[5 * c] - H), eb = std::min<int64_t>(NX - 1, ch[5 * c + 1] + H);
+      unsigned long long e = 0;
+      for (int64_t ix = ea; ix <= eb; ++ix) e += planes[static_cast<size_t>(ix)];
+      most = std::max(most, e);
+    }
+    if (most < (1ull << 31)) {  // (beyond: css_sweep1_chunk reports the chunk that is too large)
+      const size_t n = static_cast<size_t>(most), plane = (n + 3) & ~size_t(3);
+      PCP_HIP_TRY(ctx, ctx->mls_xyz.ensure(3 * n + 4));
+      PCP_HIP_TRY(ctx, ctx->mls_normal.ensure(3 * n + 4));
+      PCP_HIP_TRY(ctx, ctx->mls_curv.ensure(n + 4));
+      PCP_HIP_TRY(ctx, ctx->mls_index.ensure(n + 4));
+      PCP_HIP_TRY(ctx, ctx->m_flag.ensure(n + 16));
+      PCP_HIP_TRY(ctx, ctx->v_vox.ensure(n + 4));
+      PCP_HIP_TRY(ctx, ctx->s_cell.ensure(n + 8));
+      PCP_HIP_TRY(ctx, ctx->mls_alt_xyz.ensure(3 * n + 4));
+      PCP_HIP_TRY(ctx, ctx->mls_alt_normal.ensure(3 * n + 4));
+      PCP_HIP_TRY(ctx, ctx->mls_alt_curv.ensure(n + 4));
+      PCP_HIP_TRY(ctx, ctx->mls_alt_index.ensure(n + 4));
+      PCP_HIP_TRY(ctx, ctx->c_xyz2.ensure(3 * plane + 4));
+      PCP_HIP_TRY(ctx, ctx->s_kth.ensure(n + 8));
+      PCP_HIP_TRY(ctx, ctx->g_cell.ensure(n + 4));
+      PCP_HIP_TRY(ctx, ctx->g_rank.ensure(n + 4));
+      PCP_HIP_TRY(ctx, ctx->g_order.ensure(2 * n + 8));
+      {
+        const size_t before = ctx->g_xyz.count;  // (a new allocation of these planes is zeroed: build_grid says why)
+        PCP_HIP_TRY(ctx, ctx->g_xyz.ensure(3 * plane + 4));
+        if (ctx->g_xyz.count != before) PCP_HIP_TRY(ctx, hipMemsetAsync(ctx->g_xyz.p, 0, ctx->g_xyz.count * sizeof(float), ctx->stream));
+      }
+      PCP_HIP_TRY(ctx, ctx->s_dist.ensure(n + 8));
+    }
+  }
   std::vector<float> margin(n_chunks, INFINITY);
   int64_t row0 = 0;
   // The ball of the trailing filter's selection (in (k + 1) rows by the density bound of the voxel structure; it only sizes the
@@ -3710,6 +3750,8 @@ int pcp_cloud_smooth_stream_begin(pcp_context *ctx, const pcp_mls_params *p, int
     st.kept_rows = static_cast<int64_t>(kept);
   }
   lap(3);
+  st.seconds[1] = alloc_tally().seconds - alloc_before.seconds;
+  st.alloc_bytes = alloc_tally().bytes - alloc_before.bytes;
   publish();
   if (out_total_rows) *out_total_rows = st.total_rows;
   if (out_kept_rows) *out_kept_rows = st.kept_rows;
@@ -3769,7 +3811,7 @@ int pcp_cloud_smooth_stream_end(pcp_context *ctx) {
   return PCP_OK;
 }
 
-int pcp_cloud_smooth_stream_stats(pcp_context *ctx, double out[12]) {
+int pcp_cloud_smooth_stream_stats(pcp_context *ctx, double out[13]) {
   if (!ctx || !out) return PCP_ERR_INVALID;
   if (ctx->css_blob.size() != sizeof(SmoothStream)) return set_error(ctx, PCP_ERR_STATE, "pcp_cloud_smooth_stream_stats: no stream");
   SmoothStream st;
@@ -3783,6 +3825,7 @@ int pcp_cloud_smooth_stream_stats(pcp_context *ctx, double out[12]) {
   out[6] = st.sampled_dx;
   out[7] = 4.0 * static_cast<double>(ctx->css_dist.count);
   for (int k = 0; k < 4; ++k) out[8 + k] = st.seconds[k];
+  out[12] = st.alloc_bytes;
   return PCP_OK;
 }
 
