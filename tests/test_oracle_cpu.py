@@ -342,3 +342,29 @@ def test_nid_oracle_gradient_matches_finite_differences(oracle):
         num[k] = (oracle.nid(cam, imgs, off, x, y, z, inten, T @ exp(d))[0]
                   - oracle.nid(cam, imgs, off, x, y, z, inten, T @ exp(-d))[0]) / 2e-6
     assert np.abs(num - g).max() <= 1e-5 * max(np.abs(g).max(), 1e-3), (num, g)
+
+
+def test_sor_against_scipy_kdtree(oracle):
+    """The outlier removal's neighbour arithmetic against an independent implementation (scipy's cKDTree, fp64): the mean
+    distance to the 60 nearest neighbours of every point, the threshold mean + 0.7 sigma (sample deviation, as
+    pcl::StatisticalOutlierRemoval computes it), the keep mask.  (The oracle searches in fp32 like PCL's FLANN index: the
+    distances agree to fp32 rounding, the masks wherever a distance is not within that rounding of the threshold.)"""
+    from scipy.spatial import cKDTree
+
+    rng = np.random.default_rng(11)
+    n = 20000
+    a = rng.uniform(-1.0, 1.0, (n, 2))
+    pts = np.stack([a[:, 0], a[:, 1], 0.1 * np.sin(3 * a[:, 0]) + rng.normal(0, 2e-3, n)], 1)
+    pts = np.concatenate([pts, rng.uniform(-1, 1, (200, 3)) * [1, 1, 0.3]]).astype(np.float32)
+    x, y, z = pts[:, 0].copy(), pts[:, 1].copy(), pts[:, 2].copy()
+    keep, kept, dist, thr = oracle.sor(x, y, z, 60, 0.7, threads=4, details=True)
+    d, _ = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=61)
+    ref = d[:, 1:].mean(axis=1)
+    assert np.abs(dist - ref).max() <= 2e-6 * ref.max()
+    m = len(ref)
+    s, q = ref.sum(), (ref * ref).sum()
+    ref_thr = s / m + 0.7 * np.sqrt((q - s * s / m) / (m - 1))
+    assert abs(thr - ref_thr) <= 1e-6 * ref_thr
+    clear = np.abs(ref - ref_thr) > 1e-5 * ref_thr
+    assert np.array_equal(keep[clear].astype(bool), ref[clear] <= ref_thr)
+    assert 0.5 * m < kept < m and kept == int(keep.sum())
