@@ -368,3 +368,22 @@ def test_sor_against_scipy_kdtree(oracle):
     clear = np.abs(ref - ref_thr) > 1e-5 * ref_thr
     assert np.array_equal(keep[clear].astype(bool), ref[clear] <= ref_thr)
     assert 0.5 * m < kept < m and kept == int(keep.sum())
+
+
+def test_pose_matrices_against_scipy_rotation(oracle):
+    """A1 (PointCloudProcessor.cpp:495-519: odometry pose -> camera-to-world / world-to-camera, fp64 -> fp32) against an
+    independent implementation of the quaternion-to-matrix map (scipy.spatial.transform.Rotation): c2w = [R | t] and
+    w2c = [R^T | -R^T t], entry by entry to fp32 rounding, for unit quaternions as an odometry file stores them (8 decimals)."""
+    from scipy.spatial.transform import Rotation
+
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        q = np.round(q, 8)  # (w, x, y, z) as written by the odometry producer: unit to ~1e-8
+        t = np.round(rng.uniform(-50, 50, 3), 8)
+        w2c, c2w = oracle.pose_to_matrices([t[0], t[1], t[2], q[0], q[1], q[2], q[3]])
+        w2c, c2w = w2c.reshape(3, 4).astype(np.float64), c2w.reshape(3, 4).astype(np.float64)
+        R = Rotation.from_quat([q[1], q[2], q[3], q[0]]).as_matrix()  # scipy normalises; the reference does not: |q| = 1 +- 1e-8
+        assert np.abs(c2w[:, :3] - R).max() <= 2e-7 and np.abs(c2w[:, 3] - t).max() <= 4e-6
+        assert np.abs(w2c[:, :3] - R.T).max() <= 2e-7 and np.abs(w2c[:, 3] + R.T @ t).max() <= 1e-5
