@@ -1011,7 +1011,8 @@ struct VoxelEmitArgs {
   int32_t *index;
   uint8_t *valid;
   uint32_t *max_dx;  // nullable: max over the emitted points of |x of the point - x of its voxel position| (bits of a float >= 0)
-  int32_t dry;       // 1: nothing is stored -- the launch is for max_dx alone (sweep 0 of the streamed chain)
+  int32_t dry;       // 1: nothing is stored -- the launch is for max_dx alone (sweep 0 of the streamed chain); 2: positions and
+                     // validity only (its sweep 1, which needs no normals, curvatures or source indices)
   int32_t block_step;  // workgroup b takes voxels [b * block_step * kMB, ... + kMB): 1 = every voxel, 8 = a sample of one in eight
 };
 
@@ -1094,7 +1095,7 @@ __device__ __forceinline__ float voxel_emit_one(const VoxelEmitArgs &a, int64_t 
       // getPolynomialPartialDerivative: monomials 1, v, v^2, u, uv, u^2
       const double c0 = st[12], c1 = st[13], c2 = st[14], c3 = st[15], c4 = st[16], c5 = st[17];
       wgt = c0 + vv * c1 + (vv * vv) * c2 + u * c3 + (u * vv) * c4 + (u * u) * c5;
-      if (!a.dry) {
+      if (a.dry == 0) {
         const double zu = c3 + c4 * vv + c5 * 2.0 * u;
         const double zv = c1 + c2 * 2.0 * vv + c4 * u;
         nx -= zu * st[6] + zv * st[9];
@@ -1107,10 +1108,12 @@ __device__ __forceinline__ float voxel_emit_one(const VoxelEmitArgs &a, int64_t 
       }
     }
     ox = static_cast<float>(st[0] + u * st[6] + vv * st[9] + wgt * st[3]);
-    if (!a.dry) {
+    if (a.dry != 1) {
       a.xyz[3 * out + 0] = ox;
       a.xyz[3 * out + 1] = static_cast<float>(st[1] + u * st[7] + vv * st[10] + wgt * st[4]);
       a.xyz[3 * out + 2] = static_cast<float>(st[2] + u * st[8] + vv * st[11] + wgt * st[5]);
+    }
+    if (a.dry == 0) {
       a.normal[3 * out + 0] = static_cast<float>(nx);
       a.normal[3 * out + 1] = static_cast<float>(ny);
       a.normal[3 * out + 2] = static_cast<float>(nz);
@@ -1118,7 +1121,7 @@ __device__ __forceinline__ float voxel_emit_one(const VoxelEmitArgs &a, int64_t 
       a.index[out] = best;
     }
   }
-  if (!a.dry) a.valid[out] = ok ? 1 : 0;
+  if (a.dry != 1) a.valid[out] = ok ? 1 : 0;
   float d = ok ? fabsf(ox - px) : 0.0f;
   if (!(d == d)) d = INFINITY;  // a NaN position: no bound
   return d;
@@ -1147,10 +1150,9 @@ __global__ __launch_bounds__(kMB) void k_voxel_compact(const int32_t *__restrict
   const int64_t k = static_cast<int64_t>(blockIdx.x) * kMB + threadIdx.x;
   if (k >= m) return;
   const int64_t s_ = keep_index[k];
-  for (int c = 0; c < 3; ++c) {
-    oxyz[3 * k + c] = xyz[3 * s_ + c];
-    onormal[3 * k + c] = normal[3 * s_ + c];
-  }
+  for (int c = 0; c < 3; ++c) oxyz[3 * k + c] = xyz[3 * s_ + c];
+  if (!onormal) return;  // (positions only: sweep 1 of the streamed chain)
+  for (int c = 0; c < 3; ++c) onormal[3 * k + c] = normal[3 * s_ + c];
   ocurv[k] = curv[s_];
   oindex[k] = index[s_];
 }
@@ -2231,9 +2233,19 @@ static int build_grid(pcp_context *ctx, const CloudView &cv, float cell, float r
 // keep the `kept` result rows (of m) that keep_index names, in order.  They go into the context's second set of result
 // buffers, sized like the first (m, not kept), and the sets are swapped: either set then serves the next run without a
 // hipMalloc / hipFree pair (fresh buffers per call cost the enableMLS chain 1.5 ms).
-static int compact_results(pcp_context *ctx, const int32_t *keep_index, int64_t m, int64_t kept) {
+static int compact_results(pcp_context *ctx, const int32_t *keep_index, int64_t m, int64_t kept, bool positions_only = false) {
   const size_t sm = static_cast<size_t>(m);
   PCP_HIP_TRY(ctx, ctx->mls_alt_xyz.ensure(std::max(3 * sm + 4, ctx->mls_xyz.count)));
+  if (positions_only) {  // (the other arrays hold nothing: they stay where they are)
+    if (kept > 0) {
+      hipLaunchKernelGGL(k_voxel_compact, dim3(blocks_of(kept)), dim3(kMB), 0, ctx->stream, keep_index, kept, ctx->mls_xyz.p,
+                         static_cast<const float *>(nullptr), static_cast<const float *>(nullptr), static_cast<const int32_t *>(nullptr),
+                         ctx->mls_alt_xyz.p, static_cast<float *>(nullptr), static_cast<float *>(nullptr), static_cast<int32_t *>(nullptr));
+      PCP_HIP_TRY(ctx, hipGetLastError());
+    }
+    std::swap(ctx->mls_xyz, ctx->mls_alt_xyz);
+    return PCP_OK;
+  }
   PCP_HIP_TRY(ctx, ctx->mls_alt_normal.ensure(std::max(3 * sm + 4, ctx->mls_normal.count)));
   PCP_HIP_TRY(ctx, ctx->mls_alt_curv.ensure(std::max(sm + 4, ctx->mls_curv.count)));
   PCP_HIP_TRY(ctx, ctx->mls_alt_index.ensure(std::max(sm + 4, ctx->mls_index.count)));
@@ -2458,8 +2470,9 @@ static int vgd_prepare(pcp_context *ctx, const CloudView &cv, const pcp_mls_para
 
 // the voxels of bitmap words [word0, word1) (word0 a multiple of kScanTile), `count` of them: results in ctx->mls_*
 // sample_step > 0: nothing is emitted -- one workgroup of voxels in `sample_step` is projected for max_dx alone (*out_m = 0)
+// positions_only: the rows' positions alone (ctx->mls_xyz; the other result arrays are left as they are)
 static int vgd_emit(pcp_context *ctx, const VgdStream &S, int64_t word0, int64_t word1, int64_t count, int64_t *out_m,
-                    uint32_t *max_dx = nullptr, int32_t sample_step = 0) {
+                    uint32_t *max_dx = nullptr, int32_t sample_step = 0, bool positions_only = false) {
   const size_t st = static_cast<size_t>(count);
   size_t free_b = 0, total_b = 0;
   PCP_HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
@@ -2476,9 +2489,11 @@ static int vgd_emit(pcp_context *ctx, const VgdStream &S, int64_t word0, int64_t
                      "(pcp_mls_stream_begin / _next emit them in chunks)", (long long)count);
   if (sample_step == 0) {  // (a dry run stores nothing)
     PCP_HIP_TRY(ctx, ctx->mls_xyz.ensure(3 * st + 4));
-    PCP_HIP_TRY(ctx, ctx->mls_normal.ensure(3 * st + 4));
-    PCP_HIP_TRY(ctx, ctx->mls_curv.ensure(st + 4));
-    PCP_HIP_TRY(ctx, ctx->mls_index.ensure(st + 4));
+    if (!positions_only) {
+      PCP_HIP_TRY(ctx, ctx->mls_normal.ensure(3 * st + 4));
+      PCP_HIP_TRY(ctx, ctx->mls_curv.ensure(st + 4));
+      PCP_HIP_TRY(ctx, ctx->mls_index.ensure(st + 4));
+    }
     PCP_HIP_TRY(ctx, ctx->m_flag.ensure(st + 16));
   }
   PCP_HIP_TRY(ctx, ctx->v_vox.ensure(st + 4));
@@ -2519,7 +2534,7 @@ static int vgd_emit(pcp_context *ctx, const VgdStream &S, int64_t word0, int64_t
     e.index = ctx->mls_index.p;
     e.valid = ctx->m_flag.p;
     e.max_dx = max_dx;
-    e.dry = sample_step > 0 ? 1 : 0;
+    e.dry = sample_step > 0 ? 1 : (positions_only ? 2 : 0);
     e.block_step = std::max(1, sample_step);
     {
       LaunchTimer t(ctx, PCP_K_MLS_VOXEL);
@@ -2550,11 +2565,11 @@ static int vgd_emit(pcp_context *ctx, const VgdStream &S, int64_t word0, int64_t
     if (rc != PCP_OK) return rc;
     if (kept != count) {
       LaunchTimer t(ctx, PCP_K_MLS_VOXEL);
-      if ((rc = compact_results(ctx, ctx->s_cell.p, count, kept)) != PCP_OK) return rc;
+      if ((rc = compact_results(ctx, ctx->s_cell.p, count, kept, positions_only)) != PCP_OK) return rc;
       m = kept;
     }
   }
-  ctx->mls_count = m;
+  ctx->mls_count = positions_only ? 0 : m;  // (nothing to fetch from a positions-only emission)
   if (out_m) *out_m = m;
   return PCP_OK;
 }
@@ -3512,7 +3527,7 @@ static int css_sweep1_chunk(pcp_context *ctx, SmoothStream &st, const std::vecto
   if ((rc = stream_grid(ctx, st.cv1, &st.p, &g)) != PCP_OK) return rc;
   st.S.g = g;
   int64_t m = 0;
-  if ((rc = vgd_emit(ctx, st.S, ea * NBY, (eb + 1) * NBY, static_cast<int64_t>(ext), &m, ctx->css_words.p)) != PCP_OK) return rc;
+  if ((rc = vgd_emit(ctx, st.S, ea * NBY, (eb + 1) * NBY, static_cast<int64_t>(ext), &m, ctx->css_words.p, 0, /*positions_only=*/true)) != PCP_OK) return rc;
   // the chunk's own rows inside the (compacted, order-preserving) emission: voxels without a valid fit give no row
   int64_t r0 = 0, r1 = 0;
   if (a > 0 && (rc = compact_flags(ctx, ctx->m_flag.p, static_cast<int64_t>(a), nullptr, 0, &r0)) != PCP_OK) return rc;
@@ -3656,26 +3671,28 @@ int pcp_cloud_smooth_stream_begin(pcp_context *ctx, const pcp_mls_params *p, int
     // Every buffer that holds a row (or a voxel) of a chunk and its halo, sized ONCE for the largest chunk: grown chunk by chunk
     // they were allocated several times over -- 206 GB of hipMalloc in a first call on the 10 M-point map, 1.8 of its 4.1 s
     // (a device allocation costs 20-40 ms per GB here; pcp_cloud_smooth_stream_stats [9], [12]).
-    unsigned long long most = 0;
+    unsigned long long most = 0, most_own = 0;  // voxels of the largest chunk with its halo / on its own
     for (size_t c = 0; c < n_chunks; ++c) {
       const int64_t ea = std::max<int64_t>(0, ch[5 * c] - H), eb = std::min<int64_t>(NX - 1, ch[5 * c + 1] + H);
       unsigned long long e = 0;
       for (int64_t ix = ea; ix <= eb; ++ix) e += planes[static_cast<size_t>(ix)];
       most = std::max(most, e);
+      most_own = std::max(most_own, static_cast<unsigned long long>(ch[5 * c + 2]));
     }
     if (most < (1ull << 31)) {  // (beyond: css_sweep1_chunk reports the chunk that is too large)
-      const size_t n = static_cast<size_t>(most), plane = (n + 3) & ~size_t(3);
+      const size_t n = static_cast<size_t>(most), plane = (n + 3) & ~size_t(3), own = static_cast<size_t>(most_own);
       PCP_HIP_TRY(ctx, ctx->mls_xyz.ensure(3 * n + 4));
-      PCP_HIP_TRY(ctx, ctx->mls_normal.ensure(3 * n + 4));
-      PCP_HIP_TRY(ctx, ctx->mls_curv.ensure(n + 4));
-      PCP_HIP_TRY(ctx, ctx->mls_index.ensure(n + 4));
+      PCP_HIP_TRY(ctx, ctx->mls_alt_xyz.ensure(3 * n + 4));
+      // (sweep 1 emits positions only; normals, curvatures and source indices are sweep 2's: a chunk without its halo)
+      PCP_HIP_TRY(ctx, ctx->mls_normal.ensure(3 * own + 4));
+      PCP_HIP_TRY(ctx, ctx->mls_curv.ensure(own + 4));
+      PCP_HIP_TRY(ctx, ctx->mls_index.ensure(own + 4));
+      PCP_HIP_TRY(ctx, ctx->mls_alt_normal.ensure(3 * own + 4));
+      PCP_HIP_TRY(ctx, ctx->mls_alt_curv.ensure(own + 4));
+      PCP_HIP_TRY(ctx, ctx->mls_alt_index.ensure(own + 4));
       PCP_HIP_TRY(ctx, ctx->m_flag.ensure(n + 16));
       PCP_HIP_TRY(ctx, ctx->v_vox.ensure(n + 4));
       PCP_HIP_TRY(ctx, ctx->s_cell.ensure(n + 8));
-      PCP_HIP_TRY(ctx, ctx->mls_alt_xyz.ensure(3 * n + 4));
-      PCP_HIP_TRY(ctx, ctx->mls_alt_normal.ensure(3 * n + 4));
-      PCP_HIP_TRY(ctx, ctx->mls_alt_curv.ensure(n + 4));
-      PCP_HIP_TRY(ctx, ctx->mls_alt_index.ensure(n + 4));
       PCP_HIP_TRY(ctx, ctx->c_xyz2.ensure(3 * plane + 4));
       PCP_HIP_TRY(ctx, ctx->s_kth.ensure(n + 8));
       PCP_HIP_TRY(ctx, ctx->g_cell.ensure(n + 4));
