@@ -2844,7 +2844,10 @@ static int sor_run(pcp_context *ctx, const CloudView &cv, int32_t mean_k, double
     if (const char *e = std::getenv("PCP_SOR_BALL")) ball = atof(e);
     double final_cell = std::sqrt(ball * (mean_k + 1) / (3.14159265358979 * area_density));
     if (!(final_cell > 1e-7) || !(final_cell < 1e30)) final_cell = static_cast<double>(cell);
-    rc = build_grid(ctx, cv, static_cast<float>(final_cell), static_cast<float>(final_cell * 0.9999), &g);
+    // (cells of 1 / PCP_SOR_REACH of the ball's radius: as below)
+    int sel_reach = 1;
+    if (const char *e = std::getenv("PCP_SOR_REACH")) sel_reach = std::max(1, std::min(4, atoi(e)));
+    rc = build_grid(ctx, cv, static_cast<float>(final_cell / sel_reach), static_cast<float>(final_cell * 0.9999), &g);
     if (rc != PCP_OK) return rc;
   } else {
     // density probe on every 8th point, every 32nd of a large cloud (cell edge from the sub-sample's own volume guess):
