@@ -1248,7 +1248,7 @@ def main():
                      "hpr": None if not hpr or "cpu_baseline" not in hpr else hpr["cpu_baseline"].get("equal_to_gpu"),
                      "mls": None if not mls or "cpu_baseline" not in mls else mls["cpu_baseline"].get("equal_to_gpu")},
             "what": "every timed leg's output compared with the oracle's in the same run (colours of the last timed step; "
-                    "hull keep masks of 8 keyframes; MLS rows of a slab's interior); a failing leg makes bench.py exit 1"}
+                    "hull keep masks of every keyframe; MLS rows of a slab's interior); a failing leg makes bench.py exit 1"}
         if args.backend != "nccl":
             result["rehearsal"] = f"backend {args.backend}: ranks share GPUs, not a measurement"
         # the two boundaries side by side: `value` is the contract's -- inputs resident in HBM when the
