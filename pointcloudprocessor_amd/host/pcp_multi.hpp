@@ -591,12 +591,31 @@ class MultiCloudSmooth {
       }
     } else {
       int32_t chunks = 0;
+      int64_t voxels = 0;
       for (auto &d : dev_) {  // the same plan on every GPU (same cloud, same capacity)
         int64_t total = 0;
         int32_t c = 0;
         d->check(pcp_mls_stream_begin(d->get(), &params_, int64_t(1) << 26, &total, &c));
         if (&d != &dev_[0] && c != chunks) throw std::runtime_error("pcp_multi: the GPUs disagree about the voxel chunks");
         chunks = c;
+        voxels = total;
+      }
+      // The upsampled cloud goes through the host here and back onto every GPU for the last filter: fine up to what one upload
+      // holds.  Beyond that (the reference's 1 mm x 4 on a 10 M-point map makes 2.8e9 rows: 90 GB of host memory, more rows than
+      // a cloud has indices) the whole chain runs in its streamed form on the first GPU -- the same rows, one GPU's 2.7 s
+      // (pcp_cloud_smooth_stream_*; its chunks over several GPUs: DESIGN.md section 8).  PCP_MULTI_STREAM_ABOVE: another limit (tests).
+      int64_t stream_above = int64_t(1) << 30;
+      if (const char *e = std::getenv("PCP_MULTI_STREAM_ABOVE")) stream_above = std::max<long long>(1, std::atoll(e));
+      if (voxels > stream_above) {
+        dev_[0]->uploadCloud(x, y, z, n);
+        SmoothedCloud all;
+        CloudSmooth(*dev_[0], params_).processWithOutlierRemovalStreamed(int64_t(1) << 28, [&](const SmoothedCloud &c) {
+          all.xyz.insert(all.xyz.end(), c.xyz.begin(), c.xyz.end());
+          all.normal.insert(all.normal.end(), c.normal.begin(), c.normal.end());
+          all.curvature.insert(all.curvature.end(), c.curvature.begin(), c.curvature.end());
+          all.index.insert(all.index.end(), c.index.begin(), c.index.end());
+        });
+        return all;
       }
       for (int32_t c = 0; c < chunks; ++c) {
         Device &d = *dev_[static_cast<size_t>(c % size())];

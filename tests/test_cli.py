@@ -595,12 +595,17 @@ def test_cli_cull_hpr_end_to_end(tmp_path, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("upsampling", ["vgd", "none"])
+@pytest.mark.parametrize("upsampling", ["vgd", "none", "vgd_streamed"])
 def test_cli_enable_mls_over_three_gpus_rehearsal(tmp_path, upsampling):
     """--enableMLS 1 --gpus 3 (MultiCloudSmooth: the MLS queries, or the dilated voxel chunks, dealt out over the GPUs;
     here three contexts on the one GPU, PCP_MULTI_REHEARSAL=1) against --gpus 1 (pcp_cloud_smooth): the same rows.
     Not byte-equal by construction: the intermediate clouds are re-uploaded, hence re-sorted, so fp64 sums run in another
-    order and a coordinate may differ in its last fp32 bit; compared at 2e-6."""
+    order and a coordinate may differ in its last fp32 bit; compared at 2e-6.  vgd_streamed: the upsampled cloud counts as
+    too large for the host round trip of the multi-GPU form (PCP_MULTI_STREAM_ABOVE: 2^30 voxels by default -- the reference's
+    configuration on a 10 M-point map makes 2.8e9), and the chain runs in its streamed form on the first GPU."""
+    streamed = upsampling == "vgd_streamed"
+    if streamed:
+        upsampling = "vgd"
     from pointcloudprocessor_amd import synth
     from oracle import np_oracle as npo
 
@@ -629,7 +634,8 @@ def test_cli_enable_mls_over_three_gpus_rehearsal(tmp_path, upsampling):
         p = subprocess.run([_exe(), "-p", str(tmp_path / "scans.pcd"), "-o", str(tmp_path / "odo.txt"), "-i", str(tmp_path) + "/",
                             "-t", str(out) + "/", "--enableMLS", "1", "--mlsVoxelSize", "0.004", "--mlsDilationIterations", "1",
                             "--mlsUpsampling", upsampling, "--gpus", str(gpus), "--skip_filtered_dumps", "1"],
-                           capture_output=True, text=True, cwd=out, env=dict(os.environ, PCP_MULTI_REHEARSAL="1"))
+                           capture_output=True, text=True, cwd=out,
+                           env=dict(os.environ, PCP_MULTI_REHEARSAL="1", **({"PCP_MULTI_STREAM_ABOVE": "1000"} if streamed else {})))
         assert p.returncode == 0, p.stderr[-2000:]
         _, r = _read_pcd_ascii(out / "scans-crop_mls.pcd")
         rows[gpus] = np.array([[float(v) for v in row] for row in r])
