@@ -417,7 +417,37 @@ class CloudSmooth:
         return keep
 
     def process(self, with_outlier_removal: bool = True):
-        """SOR -> MLS (+ upsampling) -> SOR as cloudSmooth.cpp:109-164; MLS alone when asked."""
+        """SOR -> MLS (+ upsampling) -> SOR as cloudSmooth.cpp:109-164; MLS alone when asked.  An upsampled cloud that one
+        result cannot hold (the reference's VOXEL_GRID_DILATION 1 mm x 4 on a real map) goes through the streamed form and is
+        gathered on the host, as the C++ shim does (host/pcp_shim.hpp)."""
         ctx = self.engine.ctx
-        m = ctx.cloud_smooth(self.params) if with_outlier_removal else ctx.mls_process(self.params)
-        return ctx.mls_fetch(m)
+        if not with_outlier_removal:
+            return ctx.mls_fetch(ctx.mls_process(self.params))
+        try:
+            return ctx.mls_fetch(ctx.cloud_smooth(self.params))
+        except capi.PcpError as e:
+            if e.code != capi.PCP_ERR_NOMEM or self.params.upsampling != 3:
+                raise
+        parts = list(self.process_streamed(1 << 28))
+        if not parts:
+            return ctx.mls_fetch(0)
+        import numpy as np
+
+        return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+
+    def process_streamed(self, chunk_capacity: int = 1 << 28, hold_device_memory: bool = False):
+        """The whole CloudSmooth::process through pcp_cloud_smooth_stream_*: yields the survivors of the trailing outlier removal
+        chunk by chunk (dicts as mls_fetch returns them), in the order the one-shot form returns them; `self.streamed` holds
+        (rows before the last filter, rows kept, chunks) and the stream's diagnostics."""
+        ctx = self.engine.ctx
+        total, kept, chunks = ctx.cloud_smooth_stream_begin(self.params, chunk_capacity)
+        self.streamed = {"rows": total, "kept": kept, "chunks": chunks, **ctx.cloud_smooth_stream_stats()}
+        try:
+            while True:
+                m = ctx.cloud_smooth_stream_next()
+                if m == 0:
+                    break
+                yield ctx.mls_fetch(m)
+        finally:
+            if not hold_device_memory:
+                ctx.cloud_smooth_stream_end()

@@ -136,3 +136,42 @@ def test_streamed_chain_argument_checks(gpu_ctx_factory):
     with pytest.raises(capi.PcpError) as e:
         ctx.cloud_smooth_stream_begin(mp, 4096)
     assert e.value.code == capi.PCP_ERR_RANGE
+
+
+def test_python_host_streamed_cloud_smooth():
+    """pipeline.CloudSmooth (the Python mirror of the reference's CloudSmooth): process_streamed yields the rows of process()
+    chunk by chunk, and process() itself takes that road when one result cannot hold the upsampled cloud (here: made to, by a
+    one-shot call that reports PCP_ERR_NOMEM)."""
+    from pointcloudprocessor_amd import capi, pipeline
+
+    x, y, z = _strip()
+    eng = pipeline.HipEngine(0)
+    eng.configure(capi.default_camera())
+    eng.upload_cloud(x, y, z)
+    cs = pipeline.CloudSmooth(eng)
+    one = cs.process()
+    parts = list(cs.process_streamed(100_000))
+    assert cs.streamed["chunks"] >= 6 and cs.streamed["kept"] == len(one["index"]) and len(parts) >= 6
+    for k in ("index", "xyz", "normal", "curvature"):
+        assert np.array_equal(np.concatenate([p[k] for p in parts]), one[k]), k
+    assert eng.ctx.cloud_smooth_stream_stats()["device_bytes_held"] == 0  # (ended: nothing is held)
+
+    class NoRoom:  # the context with a one-shot chain that has no room
+        def __init__(self, ctx):
+            self._ctx = ctx
+
+        def __getattr__(self, name):
+            return getattr(self._ctx, name)
+
+        def cloud_smooth(self, params):
+            raise capi.PcpError(capi.PCP_ERR_NOMEM, "pcp_cloud_smooth: (test) the upsampled points do not fit")
+
+    real = eng.ctx
+    eng.ctx = NoRoom(real)
+    try:
+        again = cs.process()
+    finally:
+        eng.ctx = real
+    for k in ("index", "xyz", "normal", "curvature"):
+        assert np.array_equal(again[k], one[k]), k
+    eng.close()
