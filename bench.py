@@ -134,16 +134,17 @@ def cli_e2e_leg(synth, n_points=1_000_000, n_frames=32, W=1920, H=1080):
         res["input_bytes"] = {"pcd": os.path.getsize(pcd), "jpeg": jpeg_bytes}
         # each form twice, alternating (a process's first HIP calls cost 0.1-0.6 s and vary from start to start): the faster run
         # of a form is reported, every wall time is listed
+        # (a third form: --cull hpr, hidden_points_removal -- the cull the reference binary runs, view_culling.cpp:46 -- without the dumps)
         for rep in range(2):
-            for skip in (0, 1):
-                out = os.path.join(d, f"out{skip}_{rep}") + "/"
+            for skip, cull in ((0, "zbuffer"), (1, "zbuffer"), (1, "hpr")):
+                out = os.path.join(d, f"out{skip}_{cull}_{rep}") + "/"
                 os.makedirs(out)
                 env = dict(os.environ, PCP_CLI_TIMING=os.path.join(out, "timing.json"))
                 t1 = time.perf_counter()
                 p = subprocess.run([exe, "-p", pcd, "-o", os.path.join(d, "odo.txt"), "-i", d + "/", "-t", out,
-                                    "--skip_filtered_dumps", str(skip)], capture_output=True, text=True, env=env, cwd=out)
+                                    "--skip_filtered_dumps", str(skip), "--cull", cull], capture_output=True, text=True, env=env, cwd=out)
                 wall = time.perf_counter() - t1
-                key = "skip_filtered_dumps_on" if skip else "skip_filtered_dumps_off"
+                key = "cull_hpr_skip_filtered_dumps_on" if cull == "hpr" else ("skip_filtered_dumps_on" if skip else "skip_filtered_dumps_off")
                 if p.returncode != 0:
                     res[key] = {"error": f"exit {p.returncode}: {p.stderr[-300:]}"}
                     continue

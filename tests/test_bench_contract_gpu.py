@@ -58,7 +58,7 @@ def test_bench_line_carries_the_contract():
     assert wm["rows_before_last_filter"] > wm["outputs"] == wm["kept_reported"] > 0 and wm["chunks"] >= 1
     assert wm["min_margin_mm"] > wm["max_displacement_mm"] >= 0.0
     cli = line["cli_e2e"]
-    for form in ("skip_filtered_dumps_off", "skip_filtered_dumps_on"):
+    for form in ("skip_filtered_dumps_off", "skip_filtered_dumps_on", "cull_hpr_skip_filtered_dumps_on"):
         assert cli[form]["wall_s"] > 0 and "images_decode_and_upload_wall_s" in cli[form]["phases_s"], cli
     assert "roofline kernel" in line["value_note"] or "k_project_frame" in line["value_note"]
     prof = line["profiles"]
