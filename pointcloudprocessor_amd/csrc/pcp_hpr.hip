@@ -592,13 +592,33 @@ __device__ __forceinline__ int run_search(Search &S, Polygon &P, const HprArrays
 __device__ __forceinline__ Vec3d load_point(const HprArrays &A, int32_t k) { return {A.sx[k], A.sy[k], A.sz[k]}; }
 
 // p inside (or on) the tetrahedron (origin, a, b, c)?  Filtered signs: 1 yes, 0 cannot tell (or no).
+// The eight orientations of the general test -- for each face, the side of the opposite vertex and the side of p -- with one
+// vertex at the origin: orient(o, b, c, a) = orient(o, c, a, b) = orient(o, a, b, c) = -det [a; b; c] = -orient(a, b, c, o), and
+// orient(o, y, z, p) = -det [p; y; z].  So: D = det [a; b; c] certain and non-zero, and det [a - p; b - p; c - p], det [p; b; c],
+// det [p; c; a], det [p; a; b] certain and of D's sign.  The four determinants through the origin are orient3d_det's own formula with
+// d = 0 (differences that are exact: the same forward error bound, 8e-16 x the permanent) and share their 2 x 2 minors: six
+// minors instead of twenty-four -- the quick certificate runs this test up to twelve times per candidate.
 __device__ __forceinline__ int tetra_contains_filtered(const Vec3d &p, const Vec3d &a, const Vec3d &b, const Vec3d &c) {
-  const Vec3d o = {0.0, 0.0, 0.0};
-  const int s0 = orient3d_filtered(a, b, c, o), t0 = orient3d_filtered(a, b, c, p);
-  const int s1 = orient3d_filtered(o, b, c, a), t1 = orient3d_filtered(o, b, c, p);
-  const int s2 = orient3d_filtered(o, c, a, b), t2 = orient3d_filtered(o, c, a, p);
-  const int s3 = orient3d_filtered(o, a, b, c), t3 = orient3d_filtered(o, a, b, p);
-  return (s0 != 0 && s0 == t0 && s1 != 0 && s1 == t1 && s2 != 0 && s2 == t2 && s3 != 0 && s3 == t3) ? 1 : 0;
+  // M(u, v) = u.x v.y - v.x u.y and P(u, v) = |u.x v.y| + |v.x u.y|
+  const double bxcy = b.x * c.y, cxby = c.x * b.y, cxay = c.x * a.y, axcy = a.x * c.y, axby = a.x * b.y, bxay = b.x * a.y;
+  const double Mbc = bxcy - cxby, Mca = cxay - axcy, Mab = axby - bxay;
+  const double Pbc = fabs(bxcy) + fabs(cxby), Pca = fabs(cxay) + fabs(axcy), Pab = fabs(axby) + fabs(bxay);
+  const double D = a.z * Mbc + b.z * Mca + c.z * Mab;
+  const double permD = Pbc * fabs(a.z) + Pca * fabs(b.z) + Pab * fabs(c.z);
+  const int sD = D > 8.0e-16 * permD ? 1 : (-D > 8.0e-16 * permD ? -1 : 0);
+  if (sD == 0) return 0;
+  const double pxay = p.x * a.y, axpy = a.x * p.y, pxby = p.x * b.y, bxpy = b.x * p.y, pxcy = p.x * c.y, cxpy = c.x * p.y;
+  const double Mpa = pxay - axpy, Mpb = pxby - bxpy, Mpc = pxcy - cxpy;  // M(a, p) = -M(p, a): a negation is exact
+  const double Ppa = fabs(pxay) + fabs(axpy), Ppb = fabs(pxby) + fabs(bxpy), Ppc = fabs(pxcy) + fabs(cxpy);
+  auto sign_of = [](double det, double perm) { return det > 8.0e-16 * perm ? 1 : (-det > 8.0e-16 * perm ? -1 : 0); };
+  // det [p; b; c] = p.z M(b, c) + b.z M(c, p) + c.z M(p, b), and cyclically
+  const int s1 = sign_of(p.z * Mbc + b.z * (-Mpc) + c.z * Mpb, Pbc * fabs(p.z) + Ppc * fabs(b.z) + Ppb * fabs(c.z));
+  if (s1 != sD) return 0;
+  const int s2 = sign_of(p.z * Mca + c.z * (-Mpa) + a.z * Mpc, Pca * fabs(p.z) + Ppa * fabs(c.z) + Ppc * fabs(a.z));
+  if (s2 != sD) return 0;
+  const int s3 = sign_of(p.z * Mab + a.z * (-Mpb) + b.z * Mpa, Pab * fabs(p.z) + Ppb * fabs(a.z) + Ppa * fabs(b.z));
+  if (s3 != sD) return 0;
+  return orient3d_filtered(a, b, c, p) == sD ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
